@@ -1,0 +1,11 @@
+"""crnn_amd -- MI355X-native (gfx950) implementation of the neural-ODE hot path of
+DENG-MIT/CRNN: batched stiff CRNN solve (Rosenbrock23) + forward-tangent gradient
++ Flux-style ADAM update, behind the C ABI in include/crnn_hip.h.
+
+Importing this package loads crnn_amd/csrc/libcrnn_hip.so and fails loudly if it
+has not been built (no CPU fallback).
+"""
+from . import cases  # noqa: F401
+from ._lib import (LOSS_MAE, LOSS_MSE, PMAP_CASE1, PMAP_CASE2, PMAP_IDENTITY, PMAP_ROBER, PRESET_CASE1,  # noqa: F401
+                   PRESET_CASE2, PRESET_ROBER, RET_DTMIN, RET_MAXITERS, RET_SUCCESS, RET_UNSTABLE, CrnnError)
+from .api import NeuralODE, ODEProblem, Optimiser, crnn, p2vec, p2vec_jac  # noqa: F401

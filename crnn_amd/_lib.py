@@ -1,0 +1,125 @@
+"""ctypes binding of the C ABI in include/crnn_hip.h (libcrnn_hip.so, gfx950).
+
+The product path has no CPU fallback: if the HIP library is missing this module
+raises at import time, and every compute entry point fails loudly when no
+MI355X is visible (crnn_ctx_create returns an error).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+MAX_N = 12
+MAX_NR = 16
+ABI_VERSION = 1
+UNIQUE_ID_BYTES = 128
+
+PMAP_IDENTITY, PMAP_CASE1, PMAP_CASE2, PMAP_ROBER = 0, 1, 2, 3
+LOSS_MAE, LOSS_MSE = 0, 1
+RET_SUCCESS, RET_MAXITERS, RET_DTMIN, RET_UNSTABLE = 0, 1, 2, 3
+PRESET_CASE1, PRESET_CASE2, PRESET_ROBER = 1, 2, 3
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcrnn_hip.so")
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("ns", C.c_int32), ("nr", C.c_int32), ("has_temp", C.c_int32),
+        ("param_map", C.c_int32), ("n_save", C.c_int32), ("loss_kind", C.c_int32), ("clamp_pred", C.c_int32),
+        ("maxiters", C.c_int32), ("errnorm_sens", C.c_int32), ("device", C.c_int32), ("cols_per_lane", C.c_int32),
+        ("lb", C.c_double), ("ub", C.c_double), ("inv_R", C.c_double), ("t0", C.c_double),
+        ("atol", C.c_double * MAX_N), ("rtol", C.c_double * MAX_N), ("rate_scale", C.c_double * MAX_N),
+        ("gamma", C.c_double), ("qmin", C.c_double), ("qmax", C.c_double), ("beta1", C.c_double),
+        ("beta2", C.c_double), ("qsteady_min", C.c_double), ("qsteady_max", C.c_double),
+        ("qoldinit", C.c_double), ("dtmin", C.c_double),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_traj", C.c_int64), ("n_ok", C.c_int64), ("n_accept", C.c_int64), ("n_reject", C.c_int64),
+                ("kernel_ms", C.c_double)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class OptConfig(C.Structure):
+    _fields_ = [("use_expdecay", C.c_int32), ("decay_step", C.c_int32), ("ed_eta0", C.c_double),
+                ("ed_decay", C.c_double), ("ed_clip", C.c_double), ("eta", C.c_double), ("beta1", C.c_double),
+                ("beta2", C.c_double), ("wd", C.c_double), ("grad_clip_norm", C.c_double)]
+
+
+# every symbol include/crnn_hip.h declares: name -> (restype, argtypes)
+_DP = C.POINTER(C.c_double)
+_IP = C.POINTER(C.c_int32)
+_CTX = C.c_void_p
+SYMBOLS = {
+    "crnn_abi_version": (C.c_int32, []),
+    "crnn_last_error": (C.c_char_p, [_CTX]),
+    "crnn_config_preset": (C.c_int32, [C.POINTER(Config), C.c_int32]),
+    "crnn_opt_preset": (C.c_int32, [C.POINTER(OptConfig), C.c_int32]),
+    "crnn_n_params": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
+    "crnn_n_theta": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
+    "crnn_p2vec": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, _DP, _DP, _DP]),
+    "crnn_ctx_create": (C.c_int32, [C.POINTER(Config), C.POINTER(_CTX)]),
+    "crnn_ctx_destroy": (None, [_CTX]),
+    "crnn_ctx_set_stream": (C.c_int32, [_CTX, C.c_void_p]),
+    "crnn_ctx_set_data": (C.c_int32, [_CTX, _DP, _DP, _DP, _DP, _IP, C.c_int32, C.c_int64]),
+    "crnn_ctx_set_data_device": (C.c_int32, [_CTX, C.c_void_p, C.c_void_p, _DP, _DP, _IP, C.c_int32, C.c_int64]),
+    "crnn_solve": (C.c_int32, [_CTX, _DP, _DP, C.c_int32, C.c_int64, C.c_int64, C.c_int32, _DP, _DP, _DP, _IP, _IP,
+                               C.POINTER(Stats)]),
+    "crnn_loss_grad": (C.c_int32, [_CTX, _DP, C.c_int64, C.c_int64, C.c_int32, _DP, _DP, C.POINTER(Stats)]),
+    "crnn_opt_state_len": (C.c_int32, [C.c_int32]),
+    "crnn_opt_init": (C.c_int32, [C.POINTER(OptConfig), C.c_int32, _DP]),
+    "crnn_opt_update": (C.c_int32, [C.POINTER(OptConfig), C.c_int32, _DP, _DP, _DP]),
+    "crnn_train_init": (C.c_int32, [_CTX, C.POINTER(OptConfig), _DP]),
+    "crnn_train_step": (C.c_int32, [_CTX, C.c_int64, C.c_int64, C.c_int32, _DP]),
+    "crnn_train_step_begin": (C.c_int32, [_CTX, C.c_int64, C.c_int64, C.c_int32]),
+    "crnn_train_step_end": (C.c_int32, [_CTX, _DP]),
+    "crnn_grad_buffer": (C.c_int32, [_CTX, C.POINTER(C.c_void_p), _IP]),
+    "crnn_get_params": (C.c_int32, [_CTX, _DP]),
+    "crnn_set_params": (C.c_int32, [_CTX, _DP]),
+    "crnn_last_stats": (C.c_int32, [_CTX, C.POINTER(Stats)]),
+    "crnn_synchronize": (C.c_int32, [_CTX]),
+    "crnn_comm_get_unique_id": (C.c_int32, [C.c_char_p]),
+    "crnn_comm_init": (C.c_int32, [_CTX, C.c_char_p, C.c_int32, C.c_int32]),
+    "crnn_comm_destroy": (C.c_int32, [_CTX]),
+    "crnn_allreduce_grad": (C.c_int32, [_CTX, _DP, C.c_int32]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C crnn_amd/csrc`). crnn_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.crnn_abi_version() != ABI_VERSION:
+        raise ImportError(f"libcrnn_hip.so ABI {lib.crnn_abi_version()} != binding ABI {ABI_VERSION}")
+    return lib
+
+
+lib = _load()
+
+
+class CrnnError(RuntimeError):
+    pass
+
+
+def check(rc: int, ctx=None):
+    if rc != 0:
+        msg = lib.crnn_last_error(ctx)
+        raise CrnnError(msg.decode() if msg else f"libcrnn_hip error {rc}")
+
+
+def dptr(a):
+    return a.ctypes.data_as(_DP) if a is not None else None
+
+
+def iptr(a):
+    return a.ctypes.data_as(_IP) if a is not None else None

@@ -1,0 +1,697 @@
+// crnn_amd/csrc/crnn_capi.hip -- implementation of include/crnn_hip.h for MI355X (gfx950).
+// Host side: context / buffers / launch geometry / RCCL; device side: ros23_kernel.hpp.
+#include "../../include/crnn_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "p2vec.hpp"
+#include "ros23_kernel.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct Ctx;
+int32_t fail(Ctx *ctx, const std::string &msg);
+
+#define HIP_TRY(ctx, expr)                                                                          \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(ctx, std::string(#expr) + ": " + hipGetErrorString(e_));                    \
+    } while (0)
+#define NCCL_TRY(ctx, expr)                                                                         \
+    do {                                                                                            \
+        ncclResult_t r_ = (expr);                                                                   \
+        if (r_ != ncclSuccess)                                                                      \
+            return fail(ctx, std::string(#expr) + ": " + ncclGetErrorString(r_));                   \
+    } while (0)
+
+using KernelFn = void (*)(const crnn::SolveParams, const double *, const double *);
+
+struct KernelEntry {
+    int ns, nr, has_t, use_scale, C;
+    KernelFn fn;
+};
+
+constexpr int kBlock = 256;
+
+#define KENT(NS, NR, HT, SC, C) \
+    { NS, NR, HT, SC, C, (KernelFn)crnn::ros23_kernel<NS, NR, (HT) != 0, (SC) != 0, C, kBlock> }
+
+// Instantiated shapes: case2 (6 species + T, 3 reactions), robertson (3, 6,
+// dydt_scale), case1 (5, 4).  C = tangent columns per lane.
+const KernelEntry kKernels[] = {
+    KENT(6, 3, 1, 0, 0), KENT(6, 3, 1, 0, 1), KENT(6, 3, 1, 0, 3), KENT(6, 3, 1, 0, 5), KENT(6, 3, 1, 0, 7),
+    KENT(3, 6, 0, 1, 0), KENT(3, 6, 0, 1, 1), KENT(3, 6, 0, 1, 4), KENT(3, 6, 0, 1, 6), KENT(3, 6, 0, 1, 11),
+    KENT(5, 4, 0, 0, 0), KENT(5, 4, 0, 0, 1), KENT(5, 4, 0, 0, 4), KENT(5, 4, 0, 0, 6),
+};
+
+struct Ctx {
+    crnn_config cfg{};
+    int n = 0, n_theta = 0, n_params = 0;
+    bool use_scale = false;
+    std::string err;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int num_cu = 256;
+    // ensemble
+    int64_t B = 0;
+    int n_obs = 0;
+    int drow[CRNN_MAX_N];
+    double inv_yscale[CRNN_MAX_N];
+    double *d_u0 = nullptr, *d_data = nullptr, *d_tsave = nullptr;
+    bool own_u0 = false, own_data = false;
+    std::vector<double> tsave;
+    // per-call device outputs
+    double *d_pred = nullptr, *d_loss = nullptr;
+    int32_t *d_ret = nullptr, *d_nsaved = nullptr;
+    size_t pred_cap = 0;
+    // weights
+    double *d_theta = nullptr, *d_dtheta = nullptr;  // [n_theta], [n_theta * max_dir]
+    int max_dir = 0;
+    // reduction
+    double *d_partials = nullptr;
+    size_t partials_cap = 0;
+    double *d_red = nullptr;  // [npart_max]
+    int npart_max = 0;
+    int last_npart = 0, last_P = 0;
+    // training state
+    double *d_p = nullptr, *d_opt = nullptr;
+    crnn::OptCfg opt{};
+    bool train_ready = false;
+    // comm
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    double *d_comm_buf = nullptr;
+    int comm_buf_len = 0;
+};
+
+int32_t fail(Ctx *ctx, const std::string &msg) {
+    g_last_error = msg;
+    if (ctx) ctx->err = msg;
+    return -1;
+}
+
+const KernelEntry *find_kernel(const Ctx *c, int C) {
+    for (const auto &k : kKernels)
+        if (k.ns == c->cfg.ns && k.nr == c->cfg.nr && k.has_t == c->cfg.has_temp && k.use_scale == (c->use_scale ? 1 : 0) &&
+            k.C == C)
+            return &k;
+    return nullptr;
+}
+
+// choose the tangent-columns-per-lane variant: explicit cfg.cols_per_lane if it
+// exists for this shape, else the largest instantiated C with ceil(P/C) <= 64
+// that minimises idle tangent slots.
+const KernelEntry *pick_kernel(const Ctx *c, int P) {
+    if (P == 0) return find_kernel(c, 0);
+    if (c->cfg.cols_per_lane > 0) {
+        const KernelEntry *k = find_kernel(c, c->cfg.cols_per_lane);
+        if (k && (P + k->C - 1) / k->C <= 64) return k;
+    }
+    const KernelEntry *best = nullptr;
+    double best_cost = 1e300;
+    for (const auto &k : kKernels) {
+        if (k.C == 0 || k.ns != c->cfg.ns || k.nr != c->cfg.nr || k.has_t != c->cfg.has_temp ||
+            k.use_scale != (c->use_scale ? 1 : 0))
+            continue;
+        int L = (P + k.C - 1) / k.C;
+        if (L > 64) continue;
+        int gpw = 64 / L;
+        // cost model: per-lane work (primal ~ 2 column-equivalents + C columns) per trajectory slot
+        double cost = (2.0 + k.C) * 64.0 / gpw;
+        if (cost < best_cost) { best_cost = cost; best = &k; }
+    }
+    return best;
+}
+
+__global__ void p2vec_kernel(int pmap, int ns, int nr, int has_temp, const double *__restrict__ p, double *th, double *dth,
+                             int nth, int P) {
+    for (int i = threadIdx.x; i < nth * P; i += blockDim.x) dth[i] = 0.0;
+    __syncthreads();
+    if (threadIdx.x == 0) crnn::p2vec_eval(pmap, ns, nr, has_temp, p, th, dth);
+}
+
+// red = [grad_sum(P) | pad | loss_sum, n_ok, n_accept, n_reject, n_traj]
+__global__ void opt_kernel(crnn::OptCfg o, int P, int npart, double *p, const double *__restrict__ red, double *state) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double ntraj = red[npart - 1];
+        double gscale = ntraj > 0 ? 1.0 / ntraj : 0.0;
+        crnn::opt_update(o, P, p, red, gscale, state);
+    }
+}
+
+size_t smem_bytes(const Ctx *c, int C, int P) {
+    int N = c->n;
+    int nth = c->cfg.nr * (N + 1 + c->cfg.ns);
+    int nthp = nth | 1;
+    int CC = C > 0 ? C : 1;
+    int L = C > 0 ? (P + C - 1) / C : 1;
+    size_t dth = C > 0 ? (size_t)L * C * nthp : 0;
+    return (dth + (size_t)(CC + crnn::kExtra) * kBlock) * sizeof(double);
+}
+
+template <class T>
+int32_t ensure(Ctx *c, T **ptr, size_t *cap, size_t need) {
+    if (*cap >= need && *ptr) return 0;
+    if (*ptr) HIP_TRY(c, hipFree(*ptr));
+    *ptr = nullptr;
+    HIP_TRY(c, hipMalloc((void **)ptr, need * sizeof(T)));
+    *cap = need;
+    return 0;
+}
+
+// Launch solve (+ fixed-order reduction into c->d_red).  theta/dtheta already on device.
+int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int P, int64_t first, int64_t count,
+                     int n_save_active, bool want_pred, bool want_percase) {
+    if (c->B <= 0) return fail(c, "crnn_solve: no ensemble uploaded (crnn_ctx_set_data)");
+    if (first < 0 || count <= 0 || first + count > c->B) return fail(c, "crnn_solve: [first, first+count) outside the ensemble");
+    if (n_save_active <= 0 || n_save_active > c->cfg.n_save) return fail(c, "crnn_solve: n_save_active out of range");
+    const KernelEntry *k = pick_kernel(c, P);
+    if (!k) return fail(c, "crnn_solve: no gfx950 kernel instantiated for this (ns, nr, has_temp, n_dir) shape");
+    const int C = k->C;
+    const int L = C > 0 ? (P + C - 1) / C : 1;
+    const int gpw = 64 / L;
+    const int waves = kBlock / 64;
+    const int npart = (C > 0 ? L * C : 0) + crnn::kExtra;
+
+    size_t smem = smem_bytes(c, C, P);
+    int occ = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k->fn, kBlock, smem));
+    if (occ < 1) occ = 1;
+    int64_t groups_per_block = (int64_t)waves * gpw;
+    int64_t need_blocks = (count + groups_per_block - 1) / groups_per_block;
+    int64_t resident = (int64_t)c->num_cu * occ;
+    int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(need_blocks, resident));
+
+    size_t need_part = (size_t)nblk * npart;
+    if (ensure(c, &c->d_partials, &c->partials_cap, need_part)) return -1;
+    if (c->npart_max < npart) {
+        if (c->d_red) HIP_TRY(c, hipFree(c->d_red));
+        HIP_TRY(c, hipMalloc((void **)&c->d_red, sizeof(double) * npart));
+        c->npart_max = npart;
+    }
+    if (want_pred) {
+        size_t need = (size_t)c->cfg.n_save * c->n * c->B;
+        if (ensure(c, &c->d_pred, &c->pred_cap, need)) return -1;
+    }
+
+    crnn::SolveParams prm{};
+    prm.u0 = c->d_u0; prm.data = c->d_data; prm.tsave = c->d_tsave;
+    prm.pred = want_pred ? c->d_pred : nullptr;
+    prm.loss = want_percase ? c->d_loss : nullptr;
+    prm.retcode = want_percase ? c->d_ret : nullptr;
+    prm.n_saved = want_percase ? c->d_nsaved : nullptr;
+    prm.partials = c->d_partials;
+    prm.B = c->B; prm.first = first; prm.count = count;
+    prm.n_save = n_save_active; prm.P = P; prm.npart = npart;
+    prm.maxiters = c->cfg.maxiters; prm.clamp_pred = c->cfg.clamp_pred; prm.loss_kind = c->cfg.loss_kind;
+    prm.n_obs = c->n_obs;
+    for (int i = 0; i < CRNN_MAX_N; ++i) {
+        prm.drow[i] = c->drow[i]; prm.inv_yscale[i] = c->inv_yscale[i];
+        prm.atol[i] = c->cfg.atol[i]; prm.rtol[i] = c->cfg.rtol[i]; prm.scale[i] = c->cfg.rate_scale[i];
+    }
+    prm.lb = c->cfg.lb; prm.ub = c->cfg.ub; prm.inv_R = c->cfg.inv_R; prm.t0 = c->cfg.t0;
+    prm.gamma = c->cfg.gamma; prm.qmin = c->cfg.qmin; prm.qmax = c->cfg.qmax;
+    prm.beta1 = c->cfg.beta1; prm.beta2 = c->cfg.beta2;
+    prm.qsteady_min = c->cfg.qsteady_min; prm.qsteady_max = c->cfg.qsteady_max;
+    prm.qoldinit = c->cfg.qoldinit; prm.dtmin = c->cfg.dtmin;
+
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    hipLaunchKernelGGL(k->fn, dim3(nblk), dim3(kBlock), smem, c->stream, prm, d_theta, d_dtheta);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    hipLaunchKernelGGL(crnn::reduce_partials_kernel, dim3(npart), dim3(256), 0, c->stream, c->d_partials, nblk, npart,
+                       c->d_red);
+    HIP_TRY(c, hipGetLastError());
+    c->last_npart = npart;
+    c->last_P = P;
+    return 0;
+}
+
+int32_t fill_stats(Ctx *c, const double *red_host, int npart, crnn_stats *st) {
+    if (!st) return 0;
+    st->n_traj = (int64_t)llround(red_host[npart - 1]);
+    st->n_ok = (int64_t)llround(red_host[npart - 4]);
+    st->n_accept = (int64_t)llround(red_host[npart - 3]);
+    st->n_reject = (int64_t)llround(red_host[npart - 2]);
+    float ms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    st->kernel_ms = ms;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t crnn_abi_version(void) { return CRNN_ABI_VERSION; }
+
+const char *crnn_last_error(const crnn_ctx *ctx) {
+    const Ctx *c = reinterpret_cast<const Ctx *>(ctx);
+    return c ? c->err.c_str() : g_last_error.c_str();
+}
+
+int32_t crnn_config_preset(crnn_config *cfg, int32_t preset) {
+    if (!cfg) return fail(nullptr, "crnn_config_preset: null cfg");
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->abi_version = CRNN_ABI_VERSION;
+    for (int i = 0; i < CRNN_MAX_N; ++i) { cfg->atol[i] = 1e-6; cfg->rtol[i] = 1e-3; cfg->rate_scale[i] = 1.0; }
+    cfg->loss_kind = CRNN_LOSS_MAE;
+    cfg->maxiters = 100000;  // DiffEq default when the script passes none (case2)
+    cfg->ub = INFINITY;
+    // OrdinaryDiffEq PIController defaults for Rosenbrock23 (order 2, implicit)
+    cfg->gamma = 0.9; cfg->qmin = 0.2; cfg->qmax = 10.0;
+    cfg->beta1 = 7.0 / 20.0; cfg->beta2 = 2.0 / 10.0;
+    cfg->qsteady_min = 1.0; cfg->qsteady_max = 1.2; cfg->qoldinit = 1e-4; cfg->dtmin = 0.0;
+    switch (preset) {
+    case CRNN_PRESET_CASE1:  // case1/case1.jl:19-35
+        cfg->ns = 5; cfg->nr = 4; cfg->has_temp = 0; cfg->param_map = CRNN_PMAP_CASE1;
+        cfg->n_save = 100; cfg->clamp_pred = 1; cfg->maxiters = 10000;
+        cfg->lb = 1e-5; cfg->ub = 10.0;
+        for (int i = 0; i < CRNN_MAX_N; ++i) { cfg->atol[i] = 1e-5; cfg->rtol[i] = 1e-2; }
+        break;
+    case CRNN_PRESET_CASE2:  // case2/case2.jl:18-35,113
+        cfg->ns = 6; cfg->nr = 3; cfg->has_temp = 1; cfg->param_map = CRNN_PMAP_CASE2;
+        cfg->n_save = 50; cfg->clamp_pred = 1;
+        cfg->lb = 1e-6; cfg->ub = 10.0;
+        cfg->inv_R = -1.0 / 1.98720425864083e-3;
+        break;
+    case CRNN_PRESET_ROBER:  // robertson/rober_crnn.jl:20-37
+        cfg->ns = 3; cfg->nr = 6; cfg->has_temp = 0; cfg->param_map = CRNN_PMAP_ROBER;
+        cfg->n_save = 40; cfg->clamp_pred = 0; cfg->maxiters = 10000;
+        cfg->lb = 1e-8; cfg->ub = INFINITY;
+        cfg->atol[0] = 1e-6; cfg->atol[1] = 1e-8; cfg->atol[2] = 1e-6;
+        break;
+    default:
+        return fail(nullptr, "crnn_config_preset: unknown preset");
+    }
+    return 0;
+}
+
+int32_t crnn_opt_preset(crnn_opt_config *o, int32_t preset) {
+    if (!o) return fail(nullptr, "crnn_opt_preset: null");
+    std::memset(o, 0, sizeof(*o));
+    o->beta1 = 0.9; o->beta2 = 0.999;
+    switch (preset) {
+    case CRNN_PRESET_CASE1: o->eta = 0.001; o->wd = 1e-8; break;                                  // case1.jl:18
+    case CRNN_PRESET_CASE2:                                                                        // case2.jl:31-32
+        o->eta = 0.005; o->wd = 1e-6; o->use_expdecay = 1; o->ed_eta0 = 5e-3; o->ed_decay = 0.5;
+        o->decay_step = 500 * 20; o->ed_clip = 1e-4; break;
+    case CRNN_PRESET_ROBER: o->eta = 0.005; o->wd = 1e-6; o->grad_clip_norm = 10.0; break;         // rober_crnn.jl:19,29
+    default: return fail(nullptr, "crnn_opt_preset: unknown preset");
+    }
+    return 0;
+}
+
+int32_t crnn_n_params(int32_t pmap, int32_t ns, int32_t nr) {
+    return crnn::n_params_of(pmap, ns, nr, pmap == CRNN_PMAP_CASE2 ? 1 : 0);
+}
+int32_t crnn_n_theta(int32_t ns, int32_t nr, int32_t has_temp) { return crnn::n_theta_of(ns, nr, has_temp); }
+
+int32_t crnn_p2vec(int32_t pmap, int32_t ns, int32_t nr, const double *p, double *theta, double *dtheta) {
+    if (!p || !theta) return fail(nullptr, "crnn_p2vec: null pointer");
+    if (pmap == CRNN_PMAP_IDENTITY) return fail(nullptr, "crnn_p2vec: identity map needs no p2vec");
+    int has_temp = pmap == CRNN_PMAP_CASE2 ? 1 : 0;
+    int nth = crnn::n_theta_of(ns, nr, has_temp), P = crnn::n_params_of(pmap, ns, nr, has_temp);
+    if (P < 0) return fail(nullptr, "crnn_p2vec: unknown param_map");
+    if (dtheta) std::memset(dtheta, 0, sizeof(double) * (size_t)nth * P);
+    if (crnn::p2vec_eval(pmap, ns, nr, has_temp, p, theta, dtheta) != 0) return fail(nullptr, "crnn_p2vec: bad arguments");
+    return 0;
+}
+
+int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
+    if (!cfg || !out) return fail(nullptr, "crnn_ctx_create: null pointer");
+    *out = nullptr;
+    if (cfg->abi_version != CRNN_ABI_VERSION) return fail(nullptr, "crnn_ctx_create: abi_version mismatch");
+    if (cfg->ns < 1 || cfg->nr < 1 || cfg->ns + cfg->has_temp > CRNN_MAX_N || cfg->nr > CRNN_MAX_NR)
+        return fail(nullptr, "crnn_ctx_create: ns/nr out of range");
+    if (cfg->errnorm_sens != 0) return fail(nullptr, "crnn_ctx_create: errnorm_sens=1 is not implemented on device");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return fail(nullptr, std::string("crnn_ctx_create: no HIP device (") + hipGetErrorString(e) + ")");
+    Ctx *c = new Ctx();
+    c->cfg = *cfg;
+    c->n = cfg->ns + cfg->has_temp;
+    c->n_theta = crnn::n_theta_of(cfg->ns, cfg->nr, cfg->has_temp);
+    c->n_params = crnn::n_params_of(cfg->param_map, cfg->ns, cfg->nr, cfg->has_temp);
+    if (c->n_params < 0) { delete c; return fail(nullptr, "crnn_ctx_create: unknown param_map"); }
+    c->use_scale = false;
+    for (int i = 0; i < cfg->ns; ++i) if (cfg->rate_scale[i] != 1.0) c->use_scale = true;
+    // robertson-shaped problems always take the scaled kernel (one instantiation per shape)
+    if (!find_kernel(c, 0)) { c->use_scale = !c->use_scale; if (!find_kernel(c, 0)) c->use_scale = !c->use_scale; }
+    if (!find_kernel(c, 0)) {
+        delete c;
+        return fail(nullptr, "crnn_ctx_create: no gfx950 kernel instantiated for this (ns, nr, has_temp)");
+    }
+    auto bail = [&](const std::string &m) { std::string mm = m; crnn_ctx_destroy((crnn_ctx *)c); return fail(nullptr, mm); };
+    if (hipSetDevice(cfg->device) != hipSuccess) return bail("crnn_ctx_create: hipSetDevice failed");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return bail("crnn_ctx_create: hipGetDeviceProperties failed");
+    c->num_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate failed");
+    c->own_stream = true;
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return bail("hipEventCreate failed");
+    c->max_dir = std::max(c->n_params, c->n_theta);
+    if (hipMalloc((void **)&c->d_theta, sizeof(double) * c->n_theta) != hipSuccess ||
+        hipMalloc((void **)&c->d_dtheta, sizeof(double) * (size_t)c->n_theta * c->max_dir) != hipSuccess ||
+        hipMalloc((void **)&c->d_tsave, sizeof(double) * cfg->n_save) != hipSuccess ||
+        hipMalloc((void **)&c->d_p, sizeof(double) * c->n_params) != hipSuccess ||
+        hipMalloc((void **)&c->d_opt, sizeof(double) * (2 * c->n_params + 4)) != hipSuccess)
+        return bail("crnn_ctx_create: hipMalloc failed");
+    *out = reinterpret_cast<crnn_ctx *>(c);
+    return 0;
+}
+
+void crnn_ctx_destroy(crnn_ctx *ctx) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->own_u0 && c->d_u0) (void)hipFree(c->d_u0);
+    if (c->own_data && c->d_data) (void)hipFree(c->d_data);
+    void *ptrs[] = {c->d_tsave, c->d_pred, c->d_loss, c->d_ret, c->d_nsaved, c->d_theta, c->d_dtheta,
+                    c->d_partials, c->d_red, c->d_p, c->d_opt, c->d_comm_buf};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int32_t crnn_ctx_set_stream(crnn_ctx *ctx, void *hip_stream) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return fail(nullptr, "null ctx");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) HIP_TRY(c, hipStreamDestroy(c->stream));
+    c->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    c->own_stream = false;
+    return 0;
+}
+
+static int32_t set_data_common(Ctx *c, const double *tsteps, const double *yscale, const int32_t *i_obs, int32_t n_obs,
+                               int64_t B) {
+    if (!tsteps) return fail(c, "crnn_ctx_set_data: null tsteps");
+    if (B <= 0) return fail(c, "crnn_ctx_set_data: B must be positive");
+    const int ns = c->cfg.ns;
+    if (!i_obs) n_obs = ns;
+    if (n_obs < 1 || n_obs > ns) return fail(c, "crnn_ctx_set_data: n_obs out of range");
+    for (int i = 0; i < CRNN_MAX_N; ++i) { c->drow[i] = -1; c->inv_yscale[i] = 0.0; }
+    for (int k = 0; k < n_obs; ++k) {
+        int i = i_obs ? i_obs[k] : k;
+        if (i < 0 || i >= ns || c->drow[i] >= 0) return fail(c, "crnn_ctx_set_data: bad i_obs");
+        c->drow[i] = k;
+        double ys = yscale ? yscale[k] : 1.0;
+        if (!(ys > 0)) return fail(c, "crnn_ctx_set_data: yscale must be positive");
+        c->inv_yscale[i] = 1.0 / ys;
+    }
+    c->n_obs = n_obs;
+    for (int j = 1; j < c->cfg.n_save; ++j)
+        if (!(tsteps[j] > tsteps[j - 1])) return fail(c, "crnn_ctx_set_data: tsteps must be strictly increasing");
+    if (tsteps[0] < c->cfg.t0) return fail(c, "crnn_ctx_set_data: tsteps[0] < t0");
+    c->tsave.assign(tsteps, tsteps + c->cfg.n_save);
+    HIP_TRY(c, hipMemcpy(c->d_tsave, tsteps, sizeof(double) * c->cfg.n_save, hipMemcpyHostToDevice));
+    if (B != c->B || !c->d_loss) {
+        if (c->d_loss) HIP_TRY(c, hipFree(c->d_loss));
+        if (c->d_ret) HIP_TRY(c, hipFree(c->d_ret));
+        if (c->d_nsaved) HIP_TRY(c, hipFree(c->d_nsaved));
+        c->d_loss = nullptr; c->d_ret = nullptr; c->d_nsaved = nullptr;
+        HIP_TRY(c, hipMalloc((void **)&c->d_loss, sizeof(double) * B));
+        HIP_TRY(c, hipMalloc((void **)&c->d_ret, sizeof(int32_t) * B));
+        HIP_TRY(c, hipMalloc((void **)&c->d_nsaved, sizeof(int32_t) * B));
+    }
+    c->B = B;
+    return 0;
+}
+
+int32_t crnn_ctx_set_data(crnn_ctx *ctx, const double *u0, const double *data, const double *tsteps, const double *yscale,
+                          const int32_t *i_obs, int32_t n_obs, int64_t B) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return fail(nullptr, "null ctx");
+    if (!u0 || !data) return fail(c, "crnn_ctx_set_data: null u0/data");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->own_u0 && c->d_u0) HIP_TRY(c, hipFree(c->d_u0));
+    if (c->own_data && c->d_data) HIP_TRY(c, hipFree(c->d_data));
+    c->d_u0 = nullptr; c->d_data = nullptr; c->own_u0 = c->own_data = false;
+    if (set_data_common(c, tsteps, yscale, i_obs, n_obs, B)) return -1;
+    size_t nu = (size_t)c->n * B, nd = (size_t)c->cfg.n_save * c->n_obs * B;
+    HIP_TRY(c, hipMalloc((void **)&c->d_u0, sizeof(double) * nu));
+    c->own_u0 = true;
+    HIP_TRY(c, hipMalloc((void **)&c->d_data, sizeof(double) * nd));
+    c->own_data = true;
+    HIP_TRY(c, hipMemcpy(c->d_u0, u0, sizeof(double) * nu, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_data, data, sizeof(double) * nd, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int32_t crnn_ctx_set_data_device(crnn_ctx *ctx, const void *d_u0, const void *d_data, const double *tsteps,
+                                 const double *yscale, const int32_t *i_obs, int32_t n_obs, int64_t B) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return fail(nullptr, "null ctx");
+    if (!d_u0 || !d_data) return fail(c, "crnn_ctx_set_data_device: null u0/data");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->own_u0 && c->d_u0) HIP_TRY(c, hipFree(c->d_u0));
+    if (c->own_data && c->d_data) HIP_TRY(c, hipFree(c->d_data));
+    c->own_u0 = c->own_data = false;
+    c->d_u0 = (double *)d_u0;
+    c->d_data = (double *)d_data;
+    return set_data_common(c, tsteps, yscale, i_obs, n_obs, B);
+}
+
+int32_t crnn_solve(crnn_ctx *ctx, const double *theta, const double *dtheta, int32_t n_dir, int64_t first, int64_t count,
+                   int32_t n_save_active, double *pred, double *loss, double *grad, int32_t *retcode, int32_t *n_saved,
+                   crnn_stats *stats) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return fail(nullptr, "null ctx");
+    if (!theta) return fail(c, "crnn_solve: null theta");
+    if (n_dir < 0 || (n_dir > 0 && !dtheta)) return fail(c, "crnn_solve: n_dir > 0 needs dtheta");
+    if (n_dir > c->max_dir) return fail(c, "crnn_solve: n_dir exceeds max(n_params, n_theta)");
+    if (grad && n_dir == 0) return fail(c, "crnn_solve: grad requested with n_dir = 0");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipMemcpyAsync(c->d_theta, theta, sizeof(double) * c->n_theta, hipMemcpyHostToDevice, c->stream));
+    if (n_dir > 0)
+        HIP_TRY(c, hipMemcpyAsync(c->d_dtheta, dtheta, sizeof(double) * (size_t)c->n_theta * n_dir, hipMemcpyHostToDevice,
+                                  c->stream));
+    if (launch_solve(c, c->d_theta, c->d_dtheta, n_dir, first, count, n_save_active, pred != nullptr, true)) return -1;
+    std::vector<double> red(c->last_npart);
+    HIP_TRY(c, hipMemcpyAsync(red.data(), c->d_red, sizeof(double) * c->last_npart, hipMemcpyDeviceToHost, c->stream));
+    if (loss) HIP_TRY(c, hipMemcpyAsync(loss + first, c->d_loss + first, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+    if (retcode)
+        HIP_TRY(c, hipMemcpyAsync(retcode + first, c->d_ret + first, sizeof(int32_t) * count, hipMemcpyDeviceToHost, c->stream));
+    if (n_saved)
+        HIP_TRY(c, hipMemcpyAsync(n_saved + first, c->d_nsaved + first, sizeof(int32_t) * count, hipMemcpyDeviceToHost, c->stream));
+    if (pred) {
+        // rows (j, i) are B-contiguous; copy the [first, first+count) slice of each row
+        HIP_TRY(c, hipMemcpy2DAsync(pred + first, sizeof(double) * c->B, c->d_pred + first, sizeof(double) * c->B,
+                                    sizeof(double) * count, (size_t)n_save_active * c->n, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (grad) for (int k = 0; k < n_dir; ++k) grad[k] = red[k];
+    return fill_stats(c, red.data(), c->last_npart, stats);
+}
+
+int32_t crnn_loss_grad(crnn_ctx *ctx, const double *p, int64_t first, int64_t count, int32_t n_save_active,
+                       double *loss_mean, double *grad_p, crnn_stats *stats) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return fail(nullptr, "null ctx");
+    if (!p) return fail(c, "crnn_loss_grad: null p");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const int P = grad_p ? c->n_params : 0;
+    HIP_TRY(c, hipMemcpyAsync(c->d_p, p, sizeof(double) * c->n_params, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(p2vec_kernel, dim3(1), dim3(256), 0, c->stream, c->cfg.param_map, c->cfg.ns, c->cfg.nr,
+                       c->cfg.has_temp, c->d_p, c->d_theta, c->d_dtheta, c->n_theta, c->n_params);
+    HIP_TRY(c, hipGetLastError());
+    if (launch_solve(c, c->d_theta, c->d_dtheta, P, first, count, n_save_active, false, false)) return -1;
+    std::vector<double> red(c->last_npart);
+    HIP_TRY(c, hipMemcpyAsync(red.data(), c->d_red, sizeof(double) * c->last_npart, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const int np_ = c->last_npart;
+    double ntraj = red[np_ - 1];
+    if (loss_mean) *loss_mean = ntraj > 0 ? red[np_ - 5] / ntraj : 0.0;
+    if (grad_p) for (int k = 0; k < P; ++k) grad_p[k] = ntraj > 0 ? red[k] / ntraj : 0.0;
+    return fill_stats(c, red.data(), np_, stats);
+}
+
+int32_t crnn_opt_state_len(int32_t n_params) { return 2 * n_params + 4; }
+
+static crnn::OptCfg to_optcfg(const crnn_opt_config *o) {
+    crnn::OptCfg r{};
+    r.use_expdecay = o->use_expdecay; r.decay_step = o->decay_step;
+    r.ed_eta0 = o->ed_eta0; r.ed_decay = o->ed_decay; r.ed_clip = o->ed_clip;
+    r.eta = o->eta; r.beta1 = o->beta1; r.beta2 = o->beta2; r.wd = o->wd; r.grad_clip_norm = o->grad_clip_norm;
+    return r;
+}
+
+int32_t crnn_opt_init(const crnn_opt_config *o, int32_t n_params, double *state) {
+    if (!o || !state || n_params < 1) return fail(nullptr, "crnn_opt_init: bad arguments");
+    if (o->use_expdecay && o->decay_step < 1) return fail(nullptr, "crnn_opt_init: decay_step must be >= 1");
+    crnn::opt_init(to_optcfg(o), n_params, state);
+    return 0;
+}
+
+int32_t crnn_opt_update(const crnn_opt_config *o, int32_t n_params, double *p, const double *grad, double *state) {
+    if (!o || !p || !grad || !state || n_params < 1) return fail(nullptr, "crnn_opt_update: bad arguments");
+    crnn::opt_update(to_optcfg(o), n_params, p, grad, 1.0, state);
+    return 0;
+}
+
+int32_t crnn_train_init(crnn_ctx *ctx, const crnn_opt_config *o, const double *p0) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return fail(nullptr, "null ctx");
+    if (!o || !p0) return fail(c, "crnn_train_init: null pointer");
+    if (o->use_expdecay && o->decay_step < 1) return fail(c, "crnn_train_init: decay_step must be >= 1");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    c->opt = to_optcfg(o);
+    std::vector<double> st(2 * c->n_params + 4);
+    crnn::opt_init(c->opt, c->n_params, st.data());
+    HIP_TRY(c, hipMemcpyAsync(c->d_p, p0, sizeof(double) * c->n_params, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_opt, st.data(), sizeof(double) * st.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->train_ready = true;
+    return 0;
+}
+
+int32_t crnn_train_step_begin(crnn_ctx *ctx, int64_t first, int64_t count, int32_t n_save_active) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return fail(nullptr, "null ctx");
+    if (!c->train_ready) return fail(c, "crnn_train_step: call crnn_train_init first");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipLaunchKernelGGL(p2vec_kernel, dim3(1), dim3(256), 0, c->stream, c->cfg.param_map, c->cfg.ns, c->cfg.nr,
+                       c->cfg.has_temp, c->d_p, c->d_theta, c->d_dtheta, c->n_theta, c->n_params);
+    HIP_TRY(c, hipGetLastError());
+    return launch_solve(c, c->d_theta, c->d_dtheta, c->n_params, first, count, n_save_active, false, false);
+}
+
+int32_t crnn_train_step_end(crnn_ctx *ctx, double *loss_mean) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return fail(nullptr, "null ctx");
+    if (!c->train_ready || c->last_npart == 0) return fail(c, "crnn_train_step_end: no step in flight");
+    hipLaunchKernelGGL(opt_kernel, dim3(1), dim3(64), 0, c->stream, c->opt, c->n_params, c->last_npart, c->d_p, c->d_red,
+                       c->d_opt);
+    HIP_TRY(c, hipGetLastError());
+    if (loss_mean) {
+        double tail[5];
+        HIP_TRY(c, hipMemcpyAsync(tail, c->d_red + c->last_npart - 5, sizeof(tail), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        *loss_mean = tail[4] > 0 ? tail[0] / tail[4] : 0.0;
+    }
+    return 0;
+}
+
+int32_t crnn_train_step(crnn_ctx *ctx, int64_t first, int64_t count, int32_t n_save_active, double *loss_mean) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (crnn_train_step_begin(ctx, first, count, n_save_active)) return -1;
+    if (c->comm)
+        NCCL_TRY(c, ncclAllReduce(c->d_red, c->d_red, c->last_npart, ncclDouble, ncclSum, c->comm, c->stream));
+    return crnn_train_step_end(ctx, loss_mean);
+}
+
+int32_t crnn_grad_buffer(crnn_ctx *ctx, void **d_ptr, int32_t *n_doubles) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return fail(nullptr, "null ctx");
+    if (!c->d_red || c->last_npart == 0) return fail(c, "crnn_grad_buffer: no solve has run yet");
+    if (d_ptr) *d_ptr = c->d_red;
+    if (n_doubles) *n_doubles = c->last_npart;
+    return 0;
+}
+
+int32_t crnn_get_params(crnn_ctx *ctx, double *p) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c || !p) return fail(c, "crnn_get_params: null");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipMemcpyAsync(p, c->d_p, sizeof(double) * c->n_params, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int32_t crnn_set_params(crnn_ctx *ctx, const double *p) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c || !p) return fail(c, "crnn_set_params: null");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipMemcpyAsync(c->d_p, p, sizeof(double) * c->n_params, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int32_t crnn_last_stats(crnn_ctx *ctx, crnn_stats *stats) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c || !stats) return fail(c, "crnn_last_stats: null");
+    if (c->last_npart == 0) return fail(c, "crnn_last_stats: no solve has run yet");
+    std::vector<double> red(c->last_npart);
+    HIP_TRY(c, hipMemcpyAsync(red.data(), c->d_red, sizeof(double) * c->last_npart, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return fill_stats(c, red.data(), c->last_npart, stats);
+}
+
+int32_t crnn_synchronize(crnn_ctx *ctx) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return fail(nullptr, "null ctx");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int32_t crnn_comm_get_unique_id(char id[CRNN_UNIQUE_ID_BYTES]) {
+    static_assert(sizeof(ncclUniqueId) <= CRNN_UNIQUE_ID_BYTES, "unique id size");
+    ncclUniqueId uid;
+    NCCL_TRY(nullptr, ncclGetUniqueId(&uid));
+    std::memset(id, 0, CRNN_UNIQUE_ID_BYTES);
+    std::memcpy(id, &uid, sizeof(uid));
+    return 0;
+}
+
+int32_t crnn_comm_init(crnn_ctx *ctx, const char id[CRNN_UNIQUE_ID_BYTES], int32_t rank, int32_t world) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return fail(nullptr, "null ctx");
+    if (world < 1 || rank < 0 || rank >= world) return fail(c, "crnn_comm_init: bad rank/world");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    NCCL_TRY(c, ncclCommInitRank(&c->comm, world, uid, rank));
+    c->rank = rank;
+    c->world = world;
+    return 0;
+}
+
+int32_t crnn_comm_destroy(crnn_ctx *ctx) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return fail(nullptr, "null ctx");
+    if (c->comm) { NCCL_TRY(c, ncclCommDestroy(c->comm)); c->comm = nullptr; }
+    c->world = 1; c->rank = 0;
+    return 0;
+}
+
+int32_t crnn_allreduce_grad(crnn_ctx *ctx, double *buf, int32_t n) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return fail(nullptr, "null ctx");
+    if (!buf || n < 1) return fail(c, "crnn_allreduce_grad: bad arguments");
+    if (!c->comm) return 0;  // no communicator attached: single process
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (c->comm_buf_len < n) {
+        if (c->d_comm_buf) HIP_TRY(c, hipFree(c->d_comm_buf));
+        HIP_TRY(c, hipMalloc((void **)&c->d_comm_buf, sizeof(double) * n));
+        c->comm_buf_len = n;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_comm_buf, buf, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    NCCL_TRY(c, ncclAllReduce(c->d_comm_buf, c->d_comm_buf, n, ncclDouble, ncclSum, c->comm, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(buf, c->d_comm_buf, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,197 @@
+/*
+ * include/crnn_hip.h -- C ABI of libcrnn_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the neural-ODE hot path of DENG-MIT/CRNN.  The
+ * reference has no FFI of its own (it is a set of Julia scripts); the boundary
+ * is cut at the `solve(prob, alg, u0=u0, p=p)` call inside `predict_neuralode`
+ * (reference case2/case2.jl:126, robertson/rober_crnn.jl:125-127,
+ * case1/case1.jl:94-95) and at `ForwardDiff.gradient(x -> loss_neuralode(x,
+ * i_exp), p)` + `update!(opt, p, grad)` (case2/case2.jl:195-197,
+ * robertson/rober_crnn.jl:219-224).  Every entry point below names the
+ * reference lines it replaces.  A Julia host binds these with `ccall`
+ * (julia/CRNNHip.jl); the Python host in crnn_amd/ binds them
+ * with ctypes.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all floating point is IEEE double;
+ *   - every function returns int32: 0 = ok, <0 = error (crnn_last_error());
+ *     solver failures of individual trajectories are NOT errors: they are
+ *     reported per trajectory in retcode[] / n_saved[] exactly as the reference
+ *     prints "ode solver failed" and carries on with the truncated solution
+ *     (robertson/rober_crnn.jl:130-134);
+ *   - host arrays are caller-owned and only read/written during the call;
+ *     device buffers are library-owned behind the opaque crnn_ctx;
+ *   - a ctx is bound to one HIP device; use one ctx per GPU / per process;
+ *   - batched arrays are "IC-fastest" (species-major), matching Julia's
+ *     column-major u0_list[n_exp, ns+1], ode_data_list[n_exp, ns, datasize]
+ *     (case2/case2.jl:62,69):
+ *        u0  [i*B + b]                 i < n
+ *        data[(j*n_obs + i)*B + b]     j < n_save, i < n_obs
+ *        pred[(j*n     + i)*B + b]     j < n_save, i < n
+ *   - theta = [ w_in (n x nr, column-major) | w_b (nr) | w_out (ns x nr, column-major) ],
+ *     n = ns + has_temp, n_theta = nr*(n + 1 + ns): the "effective weights"
+ *     p2vec returns (case2/case2.jl:91-99).
+ */
+#ifndef CRNN_HIP_H
+#define CRNN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRNN_ABI_VERSION 1
+#define CRNN_MAX_N 12   /* max ODE states  */
+#define CRNN_MAX_NR 16  /* max reactions   */
+
+/* p2vec variants (parameter vector p -> effective weights theta) */
+enum {
+    CRNN_PMAP_IDENTITY = 0, /* p IS theta */
+    CRNN_PMAP_CASE1 = 1,    /* case1/case1.jl:70-78 */
+    CRNN_PMAP_CASE2 = 2,    /* case2/case2.jl:91-99 */
+    CRNN_PMAP_ROBER = 3     /* robertson/rober_crnn.jl:85-96 */
+};
+enum { CRNN_LOSS_MAE = 0, CRNN_LOSS_MSE = 1 };
+/* per-trajectory return codes (DiffEq retcodes Success / MaxIters / DtLessThanMin / Unstable) */
+enum { CRNN_RET_SUCCESS = 0, CRNN_RET_MAXITERS = 1, CRNN_RET_DTMIN = 2, CRNN_RET_UNSTABLE = 3 };
+/* presets for crnn_config_preset */
+enum { CRNN_PRESET_CASE1 = 1, CRNN_PRESET_CASE2 = 2, CRNN_PRESET_ROBER = 3 };
+
+/* Problem descriptor: what `ODEProblem(crnn, u0, tspan; saveat, atol, rtol)` plus
+ * the script-top constants carry in the reference (case2/case2.jl:15-35,113,120-121). */
+typedef struct crnn_config {
+    int32_t abi_version;          /* = CRNN_ABI_VERSION */
+    int32_t ns, nr;               /* species, reactions */
+    int32_t has_temp;             /* 1: trailing temperature state with du_T = 0 (case2) */
+    int32_t param_map;            /* CRNN_PMAP_* used by the p-level entry points */
+    int32_t n_save;               /* D = length(tsteps) */
+    int32_t loss_kind;            /* CRNN_LOSS_* */
+    int32_t clamp_pred;           /* pred = clamp.(Array(sol), -ub, ub) (case1/2) */
+    int32_t maxiters;             /* solver iterations (accepted+rejected) per trajectory */
+    int32_t errnorm_sens;         /* 0: primal-only error norm; 1: reserved (ForwardDiff-style) */
+    int32_t device;               /* HIP device ordinal */
+    int32_t cols_per_lane;        /* kernel tuning: tangent columns per lane, 0 = auto */
+    double lb, ub;                /* log(clamp(u, lb, ub)); ub may be +inf */
+    double inv_R;                 /* -1/R (case2/case2.jl:113); unused when has_temp = 0 */
+    double t0;                    /* tspan[1] */
+    double atol[CRNN_MAX_N];      /* per state (robertson uses a vector, rober_crnn.jl:34) */
+    double rtol[CRNN_MAX_N];
+    double rate_scale[CRNN_MAX_N];/* dydt_scale (rober_crnn.jl:82,115); 1 otherwise */
+    /* PI step-size controller (OrdinaryDiffEq defaults for Rosenbrock23) */
+    double gamma, qmin, qmax, beta1, beta2, qsteady_min, qsteady_max, qoldinit, dtmin;
+} crnn_config;
+
+typedef struct crnn_stats {
+    int64_t n_traj;     /* trajectories integrated by this call */
+    int64_t n_ok;       /* with retcode == CRNN_RET_SUCCESS */
+    int64_t n_accept;   /* accepted Rosenbrock steps, summed */
+    int64_t n_reject;   /* rejected steps, summed */
+    double kernel_ms;   /* HIP-event time of the solve kernel(s) on the ctx stream */
+} crnn_stats;
+
+/* Flux.Optimise chain  Optimiser(ExpDecay?, ADAM, WeightDecay) with optional
+ * gradient-norm clipping in front (case2/case2.jl:31-32; rober_crnn.jl:19,221-223). */
+typedef struct crnn_opt_config {
+    int32_t use_expdecay;   /* 1: ExpDecay(ed_eta0, ed_decay, decay_step, ed_clip) first */
+    int32_t decay_step;
+    double ed_eta0, ed_decay, ed_clip;
+    double eta, beta1, beta2; /* ADAM */
+    double wd;                /* WeightDecay (ADAMW's third argument) */
+    double grad_clip_norm;    /* > 0: grad <- grad/|grad|*clip when |grad| > clip */
+} crnn_opt_config;
+
+typedef struct crnn_ctx crnn_ctx;
+
+int32_t crnn_abi_version(void);
+const char *crnn_last_error(const crnn_ctx *ctx); /* ctx may be NULL: last error of a failed create */
+
+/* Fill cfg with the reference's script-top constants for a preset
+ * (case1/case1.jl:14-35, case2/case2.jl:15-35,113, robertson/rober_crnn.jl:19-37). */
+int32_t crnn_config_preset(crnn_config *cfg, int32_t preset);
+int32_t crnn_opt_preset(crnn_opt_config *o, int32_t preset);
+
+/* ---- host-side parameter maps: p2vec and its Jacobian ------------------- */
+int32_t crnn_n_params(int32_t param_map, int32_t ns, int32_t nr);  /* length of p */
+int32_t crnn_n_theta(int32_t ns, int32_t nr, int32_t has_temp);
+/* theta[n_theta]; dtheta[n_theta x n_params] column-major, may be NULL.
+ * Replaces p2vec (case2/case2.jl:91-99 etc.) and the part of
+ * ForwardDiff.gradient that differentiates through it. */
+int32_t crnn_p2vec(int32_t param_map, int32_t ns, int32_t nr, const double *p,
+                   double *theta, double *dtheta);
+
+/* ---- context ------------------------------------------------------------ */
+int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out);
+void crnn_ctx_destroy(crnn_ctx *ctx);
+/* Run all ctx work on a caller-owned hipStream_t (e.g. torch's current stream). */
+int32_t crnn_ctx_set_stream(crnn_ctx *ctx, void *hip_stream);
+/* Upload the ensemble: u0_list, ode_data_list, tsteps, yscale, i_obs
+ * (case2/case2.jl:62-83,131).  i_obs: 0-based, NULL = all species. */
+int32_t crnn_ctx_set_data(crnn_ctx *ctx, const double *u0, const double *data,
+                          const double *tsteps, const double *yscale,
+                          const int32_t *i_obs, int32_t n_obs, int64_t B);
+/* Same, from buffers already resident on ctx's device (no PCIe copy). */
+int32_t crnn_ctx_set_data_device(crnn_ctx *ctx, const void *d_u0, const void *d_data,
+                                 const double *tsteps, const double *yscale,
+                                 const int32_t *i_obs, int32_t n_obs, int64_t B);
+
+/* ---- the hot path at theta level ---------------------------------------- *
+ * Integrates trajectories [first, first+count) of the uploaded ensemble with
+ * the adaptive Rosenbrock23 stepper up to tsteps[n_save_active-1]
+ * (robertson's random horizon, rober_crnn.jl:125,218), evaluates the loss and,
+ * if n_dir > 0, pushes n_dir forward tangents (columns of dtheta, column-major
+ * n_theta x n_dir) through every step -- what ForwardDiff.gradient does to the
+ * solver (case2/case2.jl:195).
+ *   pred  [n_save x n x B]  or NULL   predict_neuralode (case2/case2.jl:124-128)
+ *   loss  [B]               or NULL   loss_neuralode    (case2/case2.jl:132-137)
+ *   grad  [n_dir]           or NULL   SUM over the count trajectories of d loss_b / d dir
+ *   retcode, n_saved [B]    or NULL   (entries outside [first, first+count) untouched)
+ */
+int32_t crnn_solve(crnn_ctx *ctx, const double *theta, const double *dtheta, int32_t n_dir,
+                   int64_t first, int64_t count, int32_t n_save_active,
+                   double *pred, double *loss, double *grad,
+                   int32_t *retcode, int32_t *n_saved, crnn_stats *stats);
+
+/* ---- the hot path at p level (device-resident p2vec + solve + reduction) - *
+ * loss_mean = mean_b loss_neuralode(p, b), grad_p = d loss_mean / d p.       */
+int32_t crnn_loss_grad(crnn_ctx *ctx, const double *p, int64_t first, int64_t count,
+                       int32_t n_save_active, double *loss_mean, double *grad_p,
+                       crnn_stats *stats);
+
+/* ---- optimiser and fused training step ---------------------------------- */
+int32_t crnn_opt_state_len(int32_t n_params);
+/* Host restatement of update!(opt, p, grad): state = [m | v | beta1^t beta2^t eta_expdecay ncalls] */
+int32_t crnn_opt_init(const crnn_opt_config *o, int32_t n_params, double *state);
+int32_t crnn_opt_update(const crnn_opt_config *o, int32_t n_params, double *p,
+                        const double *grad, double *state);
+
+/* Device-resident training: p and optimiser state live on the GPU; one step =
+ * p2vec kernel -> solve+tangent kernel -> deterministic reduction ->
+ * [RCCL all-reduce of (grad | loss_sum | n_traj) when a communicator is
+ * attached] -> optimiser kernel.  Batch semantics: one update per step with
+ * the gradient of the mean loss over all ranks' trajectories.               */
+int32_t crnn_train_init(crnn_ctx *ctx, const crnn_opt_config *o, const double *p0);
+int32_t crnn_train_step(crnn_ctx *ctx, int64_t first, int64_t count, int32_t n_save_active,
+                        double *loss_mean /* NULL = do not synchronise */);
+/* The two halves of crnn_train_step, for hosts that run their own collective
+ * (e.g. torch.distributed) on crnn_grad_buffer() between them. */
+int32_t crnn_train_step_begin(crnn_ctx *ctx, int64_t first, int64_t count, int32_t n_save_active);
+int32_t crnn_train_step_end(crnn_ctx *ctx, double *loss_mean);
+int32_t crnn_grad_buffer(crnn_ctx *ctx, void **d_ptr, int32_t *n_doubles); /* [grad_p | loss_sum | n_traj] */
+int32_t crnn_get_params(crnn_ctx *ctx, double *p);
+int32_t crnn_set_params(crnn_ctx *ctx, const double *p);
+int32_t crnn_last_stats(crnn_ctx *ctx, crnn_stats *stats); /* of the most recent solve; synchronises */
+int32_t crnn_synchronize(crnn_ctx *ctx);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------- */
+#define CRNN_UNIQUE_ID_BYTES 128
+int32_t crnn_comm_get_unique_id(char id[CRNN_UNIQUE_ID_BYTES]);           /* rank 0, then broadcast */
+int32_t crnn_comm_init(crnn_ctx *ctx, const char id[CRNN_UNIQUE_ID_BYTES], int32_t rank, int32_t world);
+int32_t crnn_comm_destroy(crnn_ctx *ctx);
+/* In-place sum of a host vector over all ranks (gradient | loss | count). */
+int32_t crnn_allreduce_grad(crnn_ctx *ctx, double *buf, int32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRNN_HIP_H */

@@ -1,0 +1,680 @@
+/*
+ * oracle/crnn_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C (double precision, scalar) restatement of the CRNN neural-ODE hot
+ * path of DENG-MIT/CRNN.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this file's shared object; the product path
+ * (crnn_amd/csrc) never links, imports or calls it.
+ *
+ * What it restates (paths relative to /root/reference):
+ *   RHS   crnn / crnn!          case2/case2.jl:113-118, case1/case1.jl:80-83,
+ *                               robertson/rober_crnn.jl:113-116
+ *   p2vec                       case2/case2.jl:91-99, case1/case1.jl:70-78,
+ *                               robertson/rober_crnn.jl:85-96
+ *   solve(prob, Rosenbrock23)   call sites case2/case2.jl:126,
+ *                               robertson/rober_crnn.jl:125-127
+ *   clamp.(Array(sol),-ub,ub)   case2/case2.jl:126, case1/case1.jl:94-95
+ *   loss_neuralode (mae)        case2/case2.jl:132-137,
+ *                               robertson/rober_crnn.jl:139-144
+ *   ForwardDiff.gradient        case2/case2.jl:195, robertson/rober_crnn.jl:219
+ *   update!(opt,p,grad)         case2/case2.jl:31-32,197,
+ *                               robertson/rober_crnn.jl:19,221-224
+ *
+ * PARITY STATUS: *parity unpinned for the solver internals*.  The arithmetic
+ * of `solve`, `ForwardDiff.gradient` and `update!` lives in un-vendored Julia
+ * packages (OrdinaryDiffEq / DiffEqBase / ForwardDiff / Flux; no Manifest for
+ * case1, case2, robertson -- README.md:15-21 says only "Julia 1.6").  Julia is
+ * not installed here, so the reference cannot be executed.  The stepper below
+ * restates the *published* algorithm (Shampine & Reichelt ode23s triple as
+ * implemented by OrdinaryDiffEq's Rosenbrock23: d = 1/(2+sqrt 2),
+ * c32 = 6+sqrt 2, Hermite-type dense output, PI step controller, Hairer
+ * initial step) from memory of those packages.  What IS pinned (tests/):
+ *   - closed-form RHS / p2vec against independent NumPy restatements,
+ *   - trajectories against SciPy Radau (rtol 1e-12) golden vectors,
+ *   - gradients against central finite differences and against SciPy-based
+ *     finite differences of the converged solution,
+ *   - the classical Robertson known answers,
+ *   - the reference's own checkpoint parameter vectors
+ *     (case2/checkpoint/mymodel.bson, robertson/checkpoint/mymodel.bson)
+ *     mapping through p2vec to the physically known mechanisms.
+ *
+ * Gradient method: forward tangents pushed through every arithmetic operation
+ * of the accepted Rosenbrock23 steps with the step sizes held as plain (non
+ * dual) numbers -- i.e. what ForwardDiff.gradient does to the adaptive solver
+ * (discretise-then-differentiate).  The error norm that drives step-size
+ * control uses the primal values only (errnorm_sens = 0) or, optionally, the
+ * ForwardDiff-style norm that includes the partials (errnorm_sens = 1,
+ * [UNVERIFIED-DEP] DiffEqBase ODE_DEFAULT_NORM for Dual arrays).
+ *
+ * Layout conventions (identical to the C ABI in include/crnn_hip.h):
+ *   theta = [ w_in (n x nr, column-major) | w_b (nr) | w_out (ns x nr, col-major) ]
+ *   n = ns + has_temp; state u = [species..., T]
+ *   batched arrays are "IC-fastest": u0[i*B + b], data[(j*n_obs + i)*B + b],
+ *   pred[(j*n + i)*B + b].
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_MAXN 12
+#define ORC_MAXR 16
+#define ORC_MAXTH (ORC_MAXR * (2 * ORC_MAXN + 1))
+
+typedef struct orc_problem {
+    int32_t ns, nr, has_temp;   /* n = ns + has_temp */
+    int32_t n_obs;              /* observed species count */
+    int32_t i_obs[ORC_MAXN];    /* 0-based indices of observed species */
+    int32_t clamp_pred;         /* pred = clamp(sol, -ub, ub)  (case1/case2) */
+    int32_t loss_kind;          /* 0 = MAE, 1 = MSE */
+    int32_t maxiters;
+    int32_t errnorm_sens;       /* 0 primal-only norm, 1 ForwardDiff-style */
+    double lb, ub;              /* log-clamp window; ub may be +inf */
+    double inv_R;               /* -1/R for the Arrhenius row (has_temp) */
+    double rate_scale[ORC_MAXN];/* dydt_scale (robertson), else 1 */
+    double atol[ORC_MAXN], rtol[ORC_MAXN];
+    double yscale[ORC_MAXN];    /* per observed species */
+    double t0;
+    /* step-size controller (OrdinaryDiffEq defaults for Rosenbrock23) */
+    double gamma, qmin, qmax, beta1, beta2, qsteady_min, qsteady_max, qoldinit;
+    double dtmin;
+} orc_problem;
+
+int orc_sizeof_problem(void) { return (int)sizeof(orc_problem); }
+
+void orc_problem_defaults(orc_problem *pb) {
+    memset(pb, 0, sizeof(*pb));
+    for (int i = 0; i < ORC_MAXN; ++i) {
+        pb->rate_scale[i] = 1.0; pb->yscale[i] = 1.0;
+        pb->atol[i] = 1e-6; pb->rtol[i] = 1e-3; pb->i_obs[i] = i;
+    }
+    pb->maxiters = 100000;
+    pb->ub = INFINITY;
+    /* PIController defaults: beta2 = 2/(5*order), beta1 = 7/(10*order), order 2;
+       gamma 9/10, qmin 1/5, qmax 10, qsteady in [1, 6/5] for implicit algs. */
+    pb->gamma = 0.9; pb->qmin = 0.2; pb->qmax = 10.0;
+    pb->beta1 = 7.0 / 20.0; pb->beta2 = 2.0 / 10.0;
+    pb->qsteady_min = 1.0; pb->qsteady_max = 1.2; pb->qoldinit = 1e-4;
+    pb->dtmin = 0.0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* RHS family  du = scale .* (w_out * exp(w_in' * x + w_b)),                */
+/*   x_i = log(clamp(u_i, lb, ub)) (i < ns),  x_ns = inv_R / T (has_temp).  */
+/* Follows case2/case2.jl:114-118; case1/case1.jl:80-83;                    */
+/* robertson/rober_crnn.jl:113-116.                                         */
+/* ------------------------------------------------------------------------ */
+static inline int N_(const orc_problem *pb) { return pb->ns + pb->has_temp; }
+static inline const double *W_IN(const orc_problem *pb, const double *th) { (void)pb; return th; }
+static inline const double *W_B(const orc_problem *pb, const double *th) { return th + N_(pb) * pb->nr; }
+static inline const double *W_OUT(const orc_problem *pb, const double *th) { return th + (N_(pb) + 1) * pb->nr; }
+int orc_n_theta(const orc_problem *pb) { return pb->nr * (N_(pb) + 1 + pb->ns); }
+
+/* x, dx/du (g) and d2x/du2 (h).  ForwardDiff differentiates clamp as 1 inside
+   the closed window and 0 outside. */
+static void feat(const orc_problem *pb, const double *u, double *x, double *g, double *h) {
+    for (int i = 0; i < pb->ns; ++i) {
+        double ui = u[i];
+        int inside = (ui >= pb->lb) && (ui <= pb->ub);
+        double c = ui < pb->lb ? pb->lb : (ui > pb->ub ? pb->ub : ui);
+        x[i] = log(c);
+        if (g) g[i] = inside ? 1.0 / ui : 0.0;
+        if (h) h[i] = inside ? -1.0 / (ui * ui) : 0.0;
+    }
+    if (pb->has_temp) {
+        double T = u[pb->ns];
+        x[pb->ns] = pb->inv_R / T;
+        if (g) g[pb->ns] = -pb->inv_R / (T * T);
+        if (h) h[pb->ns] = 2.0 * pb->inv_R / (T * T * T);
+    }
+}
+
+void orc_rhs(const orc_problem *pb, const double *th, const double *u, double *du) {
+    int n = N_(pb), ns = pb->ns, nr = pb->nr;
+    const double *w_in = W_IN(pb, th), *w_b = W_B(pb, th), *w_out = W_OUT(pb, th);
+    double x[ORC_MAXN], r[ORC_MAXR];
+    feat(pb, u, x, NULL, NULL);
+    for (int j = 0; j < nr; ++j) {
+        double z = w_b[j];
+        for (int i = 0; i < n; ++i) z += w_in[i + n * j] * x[i];
+        r[j] = exp(z);
+    }
+    for (int i = 0; i < ns; ++i) {
+        double a = 0.0;
+        for (int j = 0; j < nr; ++j) a += w_out[i + ns * j] * r[j];
+        du[i] = a * pb->rate_scale[i];
+    }
+    if (pb->has_temp) du[ns] = 0.0;
+}
+
+/* Analytic Jacobian J[i + n*c] = d du_i / d u_c. */
+void orc_jac(const orc_problem *pb, const double *th, const double *u, double *J) {
+    int n = N_(pb), ns = pb->ns, nr = pb->nr;
+    const double *w_in = W_IN(pb, th), *w_b = W_B(pb, th), *w_out = W_OUT(pb, th);
+    double x[ORC_MAXN], g[ORC_MAXN], r[ORC_MAXR];
+    feat(pb, u, x, g, NULL);
+    for (int j = 0; j < nr; ++j) {
+        double z = w_b[j];
+        for (int i = 0; i < n; ++i) z += w_in[i + n * j] * x[i];
+        r[j] = exp(z);
+    }
+    for (int c = 0; c < n; ++c)
+        for (int i = 0; i < n; ++i) {
+            double a = 0.0;
+            if (i < ns)
+                for (int j = 0; j < nr; ++j) a += w_out[i + ns * j] * r[j] * w_in[c + n * j];
+            J[i + n * c] = (i < ns) ? a * g[c] * pb->rate_scale[i] : 0.0;
+        }
+}
+
+/* Directional derivative of f along (su, dth): out = f_u su + f_theta dth. */
+void orc_rhs_jvp(const orc_problem *pb, const double *th, const double *dth,
+                 const double *u, const double *su, double *out) {
+    int n = N_(pb), ns = pb->ns, nr = pb->nr;
+    const double *w_in = W_IN(pb, th), *w_b = W_B(pb, th), *w_out = W_OUT(pb, th);
+    const double *dw_in = W_IN(pb, dth), *dw_b = W_B(pb, dth), *dw_out = W_OUT(pb, dth);
+    double x[ORC_MAXN], g[ORC_MAXN], r[ORC_MAXR], dr[ORC_MAXR];
+    feat(pb, u, x, g, NULL);
+    for (int j = 0; j < nr; ++j) {
+        double z = w_b[j], dz = dw_b[j];
+        for (int i = 0; i < n; ++i) {
+            z += w_in[i + n * j] * x[i];
+            dz += dw_in[i + n * j] * x[i] + w_in[i + n * j] * g[i] * su[i];
+        }
+        r[j] = exp(z);
+        dr[j] = r[j] * dz;
+    }
+    for (int i = 0; i < ns; ++i) {
+        double a = 0.0;
+        for (int j = 0; j < nr; ++j) a += dw_out[i + ns * j] * r[j] + w_out[i + ns * j] * dr[j];
+        out[i] = a * pb->rate_scale[i];
+    }
+    if (pb->has_temp) out[ns] = 0.0;
+}
+
+/* Directional derivative of the Jacobian along (su, dth): dJ (n x n). */
+void orc_jac_dir(const orc_problem *pb, const double *th, const double *dth,
+                 const double *u, const double *su, double *dJ) {
+    int n = N_(pb), ns = pb->ns, nr = pb->nr;
+    const double *w_in = W_IN(pb, th), *w_b = W_B(pb, th), *w_out = W_OUT(pb, th);
+    const double *dw_in = W_IN(pb, dth), *dw_b = W_B(pb, dth), *dw_out = W_OUT(pb, dth);
+    double x[ORC_MAXN], g[ORC_MAXN], h[ORC_MAXN], r[ORC_MAXR], dr[ORC_MAXR];
+    feat(pb, u, x, g, h);
+    for (int j = 0; j < nr; ++j) {
+        double z = w_b[j], dz = dw_b[j];
+        for (int i = 0; i < n; ++i) {
+            z += w_in[i + n * j] * x[i];
+            dz += dw_in[i + n * j] * x[i] + w_in[i + n * j] * g[i] * su[i];
+        }
+        r[j] = exp(z);
+        dr[j] = r[j] * dz;
+    }
+    /* J[i,c] = scale_i * g_c * sum_j w_out[i,j] r_j w_in[c,j] */
+    for (int c = 0; c < n; ++c) {
+        double dg = h[c] * su[c];
+        for (int i = 0; i < n; ++i) {
+            if (i >= ns) { dJ[i + n * c] = 0.0; continue; }
+            double a = 0.0, da = 0.0;
+            for (int j = 0; j < nr; ++j) {
+                double wo = w_out[i + ns * j], wi = w_in[c + n * j];
+                a += wo * r[j] * wi;
+                da += dw_out[i + ns * j] * r[j] * wi + wo * dr[j] * wi + wo * r[j] * dw_in[c + n * j];
+            }
+            dJ[i + n * c] = pb->rate_scale[i] * (da * g[c] + a * dg);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* p2vec variants and their Jacobians d theta / d p (n_theta x P col-major) */
+/* kind: 1 = case1 (case1/case1.jl:70-78), 2 = case2 (case2/case2.jl:91-99),*/
+/*       3 = robertson (robertson/rober_crnn.jl:85-96).                     */
+/* abs'(0) = +1 and clamp' = 1 on the closed window, as ForwardDiff does.   */
+/* ------------------------------------------------------------------------ */
+int orc_n_params(int kind, int ns, int nr) {
+    switch (kind) {
+    case 1: return nr * (ns + 1);
+    case 2: return nr * (ns + 2) + 1;
+    case 3: return nr * (2 * ns + 1) + 1;
+    default: return -1;
+    }
+}
+
+static double clampd(double v, double lo, double hi) { return v > hi ? hi : (v < lo ? lo : v); }
+static double dclamp(double v, double lo, double hi) { return (v > hi || v < lo) ? 0.0 : 1.0; }
+static double dabs_(double v) { return signbit(v) ? -1.0 : 1.0; }
+
+int orc_p2vec(int kind, int ns, int nr, const double *p, double *th, double *dth /* may be NULL */) {
+    int has_temp = (kind == 2);
+    int n = ns + has_temp;
+    int nth = nr * (n + 1 + ns);
+    int P = orc_n_params(kind, ns, nr);
+    if (P < 0) return -1;
+    double *w_in = th, *w_b = th + n * nr, *w_out = th + (n + 1) * nr;
+    if (dth) memset(dth, 0, sizeof(double) * (size_t)nth * (size_t)P);
+#define DTH(row, col) dth[(row) + (size_t)nth * (col)]
+    int o_in = 0, o_b = n * nr, o_out = (n + 1) * nr;
+    if (kind == 1) {
+        const double b0 = -10.0; /* case1/case1.jl:70 */
+        for (int j = 0; j < nr; ++j) {
+            w_b[j] = p[j] + b0;
+            if (dth) DTH(o_b + j, j) = 1.0;
+            for (int i = 0; i < ns; ++i) {
+                int k = nr + i + ns * j;
+                double wo = p[k];
+                w_out[i + ns * j] = wo;
+                w_in[i + n * j] = clampd(-wo, 0.0, 2.5);
+                if (dth) {
+                    DTH(o_out + i + ns * j, k) = 1.0;
+                    DTH(o_in + i + n * j, k) = -dclamp(-wo, 0.0, 2.5);
+                }
+            }
+        }
+    } else if (kind == 2) {
+        double slope = p[P - 1] * 100.0;
+        for (int j = 0; j < nr; ++j) {
+            w_b[j] = p[j] * slope;
+            if (dth) { DTH(o_b + j, j) = slope; DTH(o_b + j, P - 1) = p[j] * 100.0; }
+            for (int i = 0; i < ns; ++i) {
+                int k = nr + i + ns * j;
+                double wo = p[k];
+                w_out[i + ns * j] = wo;
+                w_in[i + n * j] = clampd(-wo, 0.0, 4.0);
+                if (dth) {
+                    DTH(o_out + i + ns * j, k) = 1.0;
+                    DTH(o_in + i + n * j, k) = -dclamp(-wo, 0.0, 4.0);
+                }
+            }
+            int ke = nr * (ns + 1) + j;
+            double v = p[ke] * slope;
+            w_in[ns + n * j] = fabs(v);
+            if (dth) {
+                DTH(o_in + ns + n * j, ke) = dabs_(v) * slope;
+                DTH(o_in + ns + n * j, P - 1) = dabs_(v) * p[ke] * 100.0;
+            }
+        }
+    } else if (kind == 3) {
+        double ps = p[P - 1];
+        double slope = fabs(ps);
+        const double ln10 = 2.302585092994045684;
+        for (int j = 0; j < nr; ++j) {
+            w_b[j] = p[j] * (10.0 * slope);
+            if (dth) { DTH(o_b + j, j) = 10.0 * slope; DTH(o_b + j, P - 1) = p[j] * 10.0 * dabs_(ps); }
+            for (int i = 0; i < ns; ++i) {
+                int ko = nr + i + ns * j;
+                int ki = nr * (ns + 1) + i + ns * j;
+                double wi_raw = p[ki], wo_raw = p[ko];
+                double pw = pow(10.0, wo_raw);
+                w_out[i + ns * j] = -wi_raw * pw;
+                w_in[i + n * j] = clampd(wi_raw, 0.0, 2.5);
+                if (dth) {
+                    DTH(o_out + i + ns * j, ki) = -pw;
+                    DTH(o_out + i + ns * j, ko) = -wi_raw * pw * ln10;
+                    DTH(o_in + i + n * j, ki) = dclamp(wi_raw, 0.0, 2.5);
+                }
+            }
+        }
+    }
+#undef DTH
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Dense LU with partial pivoting (n <= ORC_MAXN).                          */
+/* ------------------------------------------------------------------------ */
+static int lu_factor(int n, double *A, int *piv) {
+    for (int k = 0; k < n; ++k) {
+        int p = k; double best = fabs(A[k + n * k]);
+        for (int i = k + 1; i < n; ++i) { double v = fabs(A[i + n * k]); if (v > best) { best = v; p = i; } }
+        piv[k] = p;
+        if (p != k) for (int c = 0; c < n; ++c) { double t = A[k + n * c]; A[k + n * c] = A[p + n * c]; A[p + n * c] = t; }
+        double d = A[k + n * k];
+        if (d == 0.0) return -1;
+        double inv = 1.0 / d;
+        for (int i = k + 1; i < n; ++i) A[i + n * k] *= inv;
+        for (int c = k + 1; c < n; ++c) {
+            double a = A[k + n * c];
+            for (int i = k + 1; i < n; ++i) A[i + n * c] -= A[i + n * k] * a;
+        }
+    }
+    return 0;
+}
+static void lu_solve(int n, const double *A, const int *piv, double *b) {
+    for (int k = 0; k < n; ++k) { int p = piv[k]; if (p != k) { double t = b[k]; b[k] = b[p]; b[p] = t; } }
+    for (int k = 0; k < n; ++k) { double a = b[k]; for (int i = k + 1; i < n; ++i) b[i] -= A[i + n * k] * a; }
+    for (int k = n - 1; k >= 0; --k) { b[k] /= A[k + n * k]; double a = b[k]; for (int i = 0; i < k; ++i) b[i] -= A[i + n * k] * a; }
+}
+
+static void matvec(int n, const double *A, const double *v, double *out) {
+    for (int i = 0; i < n; ++i) { double a = 0.0; for (int c = 0; c < n; ++c) a += A[i + n * c] * v[c]; out[i] = a; }
+}
+
+static double rms_scaled(const orc_problem *pb, int n, const double *v, const double *ua, const double *ub_) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double m = fmax(fabs(ua[i]), fabs(ub_[i]));
+        double e = v[i] / (pb->atol[i] + pb->rtol[i] * m);
+        s += e * e;
+    }
+    return sqrt(s / n);
+}
+
+/* Hairer initial step as in OrdinaryDiffEq's ode_determine_initdt
+   [UNVERIFIED-DEP] (order = 2 for Rosenbrock23). */
+static double init_dt(const orc_problem *pb, const double *th, const double *u0, const double *f0, double tspan_len) {
+    int n = N_(pb);
+    double sk[ORC_MAXN], d0 = 0, d1 = 0;
+    for (int i = 0; i < n; ++i) {
+        sk[i] = pb->atol[i] + fabs(u0[i]) * pb->rtol[i];
+        d0 += (u0[i] / sk[i]) * (u0[i] / sk[i]);
+        d1 += (f0[i] / sk[i]) * (f0[i] / sk[i]);
+    }
+    d0 = sqrt(d0 / n); d1 = sqrt(d1 / n);
+    double dtmax = tspan_len;
+    double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 / d1);
+    dt0 = fmin(dt0, dtmax);
+    double u1[ORC_MAXN], f1[ORC_MAXN];
+    for (int i = 0; i < n; ++i) u1[i] = u0[i] + dt0 * f0[i];
+    orc_rhs(pb, th, u1, f1);
+    double d2 = 0;
+    for (int i = 0; i < n; ++i) { double e = (f1[i] - f0[i]) / sk[i]; d2 += e * e; }
+    d2 = sqrt(d2 / n) / dt0;
+    double dm = fmax(d1, d2);
+    double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : pow(10.0, -(2.0 + log10(dm)) / 2.0);
+    return fmax(pb->dtmin, fmin(fmin(100.0 * dt0, dt1), dtmax));
+}
+
+/* ------------------------------------------------------------------------ */
+/* One trajectory: adaptive Rosenbrock23 + forward tangents + loss.         */
+/*   u0[n], tsave[nsave] (ascending, tsave[nsave-1] = end of tspan),        */
+/*   data[j*n_obs + i], dth: n_theta x P (col-major) or NULL,               */
+/*   pred (n x nsave, col-major) or NULL, dpred (n x nsave x P) or NULL.    */
+/* retcode: 0 ok, 1 maxiters, 2 dt<dtmin, 3 non-finite.                     */
+/* ------------------------------------------------------------------------ */
+typedef struct orc_stats { int64_t naccept, nreject; } orc_stats;
+
+int orc_solve_one(const orc_problem *pb, const double *th, const double *dth, int P,
+                  const double *u0, const double *tsave, int nsave,
+                  const double *data, double *pred, double *dpred,
+                  double *loss_out, double *grad /* [P] accumulated += */,
+                  int32_t *n_saved_out, orc_stats *st) {
+    const int n = N_(pb), nobs = pb->n_obs;
+    const int nth = orc_n_theta(pb);
+    const double d = 1.0 / (2.0 + sqrt(2.0));
+    const double c32 = 6.0 + sqrt(2.0);
+    const double tend = tsave[nsave - 1];
+    double t = pb->t0;
+    double u[ORC_MAXN], f0[ORC_MAXN];
+    double *S = NULL, *dk1 = NULL, *dk2 = NULL, *dk3 = NULL, *Snew = NULL, *gtr = NULL, *df0 = NULL, *df2 = NULL;
+    if (P > 0) {
+        S = (double *)calloc((size_t)n * P * 7, sizeof(double));
+        Snew = S + (size_t)n * P; dk1 = Snew + (size_t)n * P; dk2 = dk1 + (size_t)n * P;
+        dk3 = dk2 + (size_t)n * P; df0 = dk3 + (size_t)n * P; df2 = df0 + (size_t)n * P;
+        gtr = (double *)calloc((size_t)P, sizeof(double));
+    }
+    memcpy(u, u0, sizeof(double) * n);
+    orc_rhs(pb, th, u, f0);
+    for (int k = 0; k < P; ++k) {
+        double zero[ORC_MAXN] = {0};
+        orc_rhs_jvp(pb, th, dth + (size_t)nth * k, u, zero, df0 + (size_t)n * k);
+    }
+    double dt = init_dt(pb, th, u, f0, tend - pb->t0);
+    double qold = pb->qoldinit;
+    int jsave = 0, retcode = 0, iter = 0;
+    double loss_sum = 0.0;
+
+    /* save_start: OrdinaryDiffEq stores u0 when tspan[1] is in saveat. */
+#define SAVE_POINT(uvec, svec_expr_block)                                              \
+    do {                                                                               \
+        for (int i = 0; i < n; ++i) {                                                  \
+            double v = (uvec)[i];                                                      \
+            if (pb->clamp_pred) v = clampd(v, -pb->ub, pb->ub);                        \
+            if (pred) pred[i + n * jsave] = v;                                         \
+        }                                                                              \
+        for (int io = 0; io < nobs; ++io) {                                            \
+            int i = pb->i_obs[io];                                                     \
+            double v = (uvec)[i];                                                      \
+            double mask = 1.0;                                                         \
+            if (pb->clamp_pred) { mask = dclamp(v, -pb->ub, pb->ub); v = clampd(v, -pb->ub, pb->ub); } \
+            /* mae(data./yscale, pred./yscale) = mean |data - pred| / yscale */        \
+            double r_ = (data[io + nobs * jsave] - v) / pb->yscale[io];                \
+            double w_;                                                                 \
+            if (pb->loss_kind == 0) { loss_sum += fabs(r_); w_ = -dabs_(r_); }         \
+            else { loss_sum += r_ * r_; w_ = -2.0 * r_; }                              \
+            w_ *= mask / pb->yscale[io];                                               \
+            for (int k = 0; k < P; ++k) { double sv; svec_expr_block; gtr[k] += w_ * sv; \
+                if (dpred) dpred[i + n * (jsave + (size_t)nsave * k)] = mask * sv; }   \
+        }                                                                              \
+        ++jsave;                                                                       \
+    } while (0)
+
+    if (nsave > 0 && tsave[0] == pb->t0) SAVE_POINT(u, sv = 0.0);
+
+    double J[ORC_MAXN * ORC_MAXN], W[ORC_MAXN * ORC_MAXN], dJ[ORC_MAXN * ORC_MAXN];
+    int piv[ORC_MAXN];
+    while (jsave < nsave) {
+        if (++iter > pb->maxiters) { retcode = 1; break; }
+        int last = 0;
+        if (t + dt * (1.0 + 1e-13) >= tend) { dt = tend - t; last = 1; }
+        if (!(dt > pb->dtmin) || t + dt == t) { retcode = 2; break; }
+        const double gam = d * dt;
+        orc_jac(pb, th, u, J);
+        for (int c = 0; c < n; ++c) for (int i = 0; i < n; ++i) W[i + n * c] = (i == c ? 1.0 : 0.0) - gam * J[i + n * c];
+        if (lu_factor(n, W, piv) != 0) { retcode = 3; break; }
+        double k1[ORC_MAXN], k2[ORC_MAXN], k3[ORC_MAXN], u1[ORC_MAXN], f1[ORC_MAXN], unew[ORC_MAXN], f2[ORC_MAXN], tmp[ORC_MAXN];
+        memcpy(k1, f0, sizeof(double) * n); lu_solve(n, W, piv, k1);
+        for (int i = 0; i < n; ++i) u1[i] = u[i] + 0.5 * dt * k1[i];
+        orc_rhs(pb, th, u1, f1);
+        for (int i = 0; i < n; ++i) tmp[i] = f1[i] - k1[i];
+        lu_solve(n, W, piv, tmp);
+        for (int i = 0; i < n; ++i) { k2[i] = tmp[i] + k1[i]; unew[i] = u[i] + dt * k2[i]; }
+        orc_rhs(pb, th, unew, f2);
+        for (int i = 0; i < n; ++i) k3[i] = f2[i] - c32 * (k2[i] - f1[i]) - 2.0 * (k1[i] - f0[i]);
+        lu_solve(n, W, piv, k3);
+        double ev[ORC_MAXN];
+        for (int i = 0; i < n; ++i) ev[i] = dt / 6.0 * (k1[i] - 2.0 * k2[i] + k3[i]);
+        int finite = 1;
+        for (int i = 0; i < n; ++i) if (!isfinite(unew[i]) || !isfinite(ev[i])) finite = 0;
+        if (!finite) { retcode = 3; break; }
+        /* Primal-only norm: tangents are evaluated lazily, for accepted steps
+           only.  ForwardDiff-style norm: they are needed before the test. */
+        const int sens_norm = (pb->errnorm_sens && P > 0);
+        double EEst = rms_scaled(pb, n, ev, u, unew);
+        int accept = (EEst <= 1.0);
+        if (P > 0 && (sens_norm || accept)) {
+            for (int k = 0; k < P; ++k) {
+                const double *dthk = dth + (size_t)nth * k;
+                double *s = S + (size_t)n * k, *a1 = dk1 + (size_t)n * k, *a2 = dk2 + (size_t)n * k, *a3 = dk3 + (size_t)n * k;
+                double *sn = Snew + (size_t)n * k, *b0 = df0 + (size_t)n * k, *b2 = df2 + (size_t)n * k;
+                orc_jac_dir(pb, th, dthk, u, s, dJ);
+                /* W k1' = f0' + gam * dJ k1 */
+                matvec(n, dJ, k1, tmp);
+                for (int i = 0; i < n; ++i) a1[i] = b0[i] + gam * tmp[i];
+                lu_solve(n, W, piv, a1);
+                double s1[ORC_MAXN], df1[ORC_MAXN], dd[ORC_MAXN], kd[ORC_MAXN];
+                for (int i = 0; i < n; ++i) s1[i] = s[i] + 0.5 * dt * a1[i];
+                orc_rhs_jvp(pb, th, dthk, u1, s1, df1);
+                /* W (k2-k1)' = f1' - k1' + gam * dJ (k2-k1) */
+                for (int i = 0; i < n; ++i) kd[i] = k2[i] - k1[i];
+                matvec(n, dJ, kd, tmp);
+                for (int i = 0; i < n; ++i) dd[i] = df1[i] - a1[i] + gam * tmp[i];
+                lu_solve(n, W, piv, dd);
+                for (int i = 0; i < n; ++i) { a2[i] = a1[i] + dd[i]; sn[i] = s[i] + dt * a2[i]; }
+                orc_rhs_jvp(pb, th, dthk, unew, sn, b2);
+                if (sens_norm) {
+                    /* W k3' = f2' - c32 (k2' - f1') - 2 (k1' - f0') + gam * dJ k3 */
+                    matvec(n, dJ, k3, tmp);
+                    for (int i = 0; i < n; ++i)
+                        a3[i] = b2[i] - c32 * (a2[i] - df1[i]) - 2.0 * (a1[i] - b0[i]) + gam * tmp[i];
+                    lu_solve(n, W, piv, a3);
+                }
+            }
+            if (sens_norm) {
+                /* [UNVERIFIED-DEP] DiffEqBase norm on Dual arrays: sum of squares of
+                   value and partials, divided by the number of components; the
+                   per-component scale uses the 2-norm of (value, partials). */
+                double ssum = 0.0;
+                for (int i = 0; i < n; ++i) {
+                    double na = u[i] * u[i], nb = unew[i] * unew[i], ee = ev[i] * ev[i];
+                    for (int k = 0; k < P; ++k) {
+                        double s_ = S[i + (size_t)n * k], sn_ = Snew[i + (size_t)n * k];
+                        na += s_ * s_; nb += sn_ * sn_;
+                        double de = dt / 6.0 * (dk1[i + (size_t)n * k] - 2.0 * dk2[i + (size_t)n * k] + dk3[i + (size_t)n * k]);
+                        ee += de * de;
+                    }
+                    double sc = pb->atol[i] + pb->rtol[i] * sqrt(fmax(na, nb));
+                    ssum += ee / (sc * sc);
+                }
+                EEst = sqrt(ssum / n);
+                if (!isfinite(EEst)) { retcode = 3; break; }
+                accept = (EEst <= 1.0);
+            }
+        }
+        /* PI controller (OrdinaryDiffEq PIController) */
+        double q, q11 = 0.0;
+        if (EEst == 0.0) q = 1.0 / pb->qmax;
+        else {
+            q11 = pow(EEst, pb->beta1);
+            q = q11 / pow(qold, pb->beta2);
+            q = fmax(1.0 / pb->qmax, fmin(1.0 / pb->qmin, q / pb->gamma));
+        }
+        if (accept) {
+            if (st) st->naccept++;
+            if (q >= pb->qsteady_min && q <= pb->qsteady_max) q = 1.0;
+            qold = fmax(EEst, pb->qoldinit);
+            double tnew = last ? tend : t + dt;
+            /* saveat via the Rosenbrock23 dense output:
+               u(t+Theta dt) = u + dt (c1 k1 + c2 k2), c1 = Th(1-Th)/(1-2d), c2 = Th(Th-2d)/(1-2d) */
+            while (jsave < nsave && tsave[jsave] <= tnew) {
+                double ts = tsave[jsave];
+                if (ts == tnew) {
+                    SAVE_POINT(unew, sv = Snew[i + (size_t)n * k]);
+                } else {
+                    double Th = (ts - t) / dt;
+                    double c1 = Th * (1.0 - Th) / (1.0 - 2.0 * d), c2 = Th * (Th - 2.0 * d) / (1.0 - 2.0 * d);
+                    double ui[ORC_MAXN];
+                    for (int i = 0; i < n; ++i) ui[i] = u[i] + dt * (c1 * k1[i] + c2 * k2[i]);
+                    SAVE_POINT(ui, sv = S[i + (size_t)n * k] + dt * (c1 * dk1[i + (size_t)n * k] + c2 * dk2[i + (size_t)n * k]));
+                }
+            }
+            memcpy(u, unew, sizeof(double) * n);
+            memcpy(f0, f2, sizeof(double) * n);
+            if (P > 0) {
+                memcpy(S, Snew, sizeof(double) * (size_t)n * P);
+                memcpy(df0, df2, sizeof(double) * (size_t)n * P);
+            }
+            t = tnew;
+            dt = dt / q;
+            double dtmax = tend - pb->t0;
+            if (dt > dtmax) dt = dtmax;
+        } else {
+            if (st) st->nreject++;
+            dt = dt / fmin(1.0 / pb->qmin, q11 / pb->gamma);
+        }
+    }
+#undef SAVE_POINT
+    /* mae / mse over the saved prefix (robertson/rober_crnn.jl:141: data[:, 1:size(pred)[2]]) */
+    double denom = (double)nobs * (double)jsave;
+    double loss = jsave > 0 ? loss_sum / denom : 0.0;
+    if (loss_out) *loss_out = loss;
+    if (n_saved_out) *n_saved_out = jsave;
+    if (grad && jsave > 0) for (int k = 0; k < P; ++k) grad[k] += gtr[k] / denom;
+    if (P > 0) { free(S); free(gtr); }
+    return retcode;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Batch driver over B initial conditions (IC-fastest layout), OpenMP over  */
+/* trajectories: the stand-in for an EnsembleThreads() run.                 */
+/* grad[P] = sum over trajectories of d loss_b / d p (NOT divided by B).    */
+/* ------------------------------------------------------------------------ */
+int orc_solve_batch(const orc_problem *pb, const double *th, const double *dth, int P,
+                    const double *u0 /*[n*B]*/, const double *tsave, int nsave,
+                    const double *data /*[nsave*n_obs*B]*/, int64_t B, int64_t first, int64_t count,
+                    double *pred /*[nsave*n*B] or NULL*/, double *loss /*[B]*/,
+                    double *grad /*[P]*/, int32_t *retcode /*[B]*/, int32_t *n_saved /*[B]*/,
+                    int64_t *stats /* [2]: accepted, rejected */, int nthreads) {
+    const int n = N_(pb), nobs = pb->n_obs;
+    int64_t acc = 0, rej = 0;
+    if (grad) memset(grad, 0, sizeof(double) * (size_t)P);
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel reduction(+ : acc, rej)
+    {
+        double *g_loc = P > 0 ? (double *)calloc((size_t)P, sizeof(double)) : NULL;
+        double *d_loc = (double *)malloc(sizeof(double) * (size_t)nobs * nsave);
+        double *p_loc = pred ? (double *)malloc(sizeof(double) * (size_t)n * nsave) : NULL;
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t b = first; b < first + count; ++b) {
+            double u[ORC_MAXN];
+            for (int i = 0; i < n; ++i) u[i] = u0[(size_t)i * B + b];
+            for (int j = 0; j < nsave; ++j)
+                for (int i = 0; i < nobs; ++i) d_loc[i + nobs * j] = data[((size_t)j * nobs + i) * B + b];
+            orc_stats st = {0, 0};
+            double l = 0; int32_t ns_ = 0;
+            if (p_loc) memset(p_loc, 0, sizeof(double) * (size_t)n * nsave);
+            int rc = orc_solve_one(pb, th, dth, grad ? P : 0, u, tsave, nsave, d_loc, p_loc, NULL, &l, g_loc, &ns_, &st);
+            if (loss) loss[b] = l;
+            if (retcode) retcode[b] = rc;
+            if (n_saved) n_saved[b] = ns_;
+            if (pred) for (int j = 0; j < nsave; ++j) for (int i = 0; i < n; ++i) pred[((size_t)j * n + i) * B + b] = p_loc[i + n * j];
+            acc += st.naccept; rej += st.nreject;
+        }
+#pragma omp critical
+        { if (grad && g_loc) for (int k = 0; k < P; ++k) grad[k] += g_loc[k]; }
+        free(g_loc); free(d_loc); free(p_loc);
+    }
+    if (stats) { stats[0] = acc; stats[1] = rej; }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Flux.Optimise restatement (old "implicit" optimisers; EPS = 1e-8)        */
+/* [UNVERIFIED-DEP]:  Optimiser(ExpDecay(eta0,decay,step,clip), ADAM(eta,   */
+/* beta), WeightDecay(wd)) applied left to right, then p .-= delta.         */
+/* case2/case2.jl:31-32,197; robertson/rober_crnn.jl:19,221-224 (norm clip) */
+/* state = [m(P) | v(P) | beta1^t, beta2^t, expdecay_eta, n_calls]          */
+/* ------------------------------------------------------------------------ */
+typedef struct orc_opt {
+    int32_t use_expdecay; int32_t decay_step;
+    double ed_eta0, ed_decay, ed_clip;
+    double eta, beta1, beta2, wd;
+    double grad_clip_norm; /* <=0: off (robertson: 10) */
+} orc_opt;
+
+int orc_opt_state_len(int P) { return 2 * P + 4; }
+void orc_opt_init(const orc_opt *o, int P, double *state) {
+    memset(state, 0, sizeof(double) * (size_t)(2 * P + 4));
+    state[2 * P + 0] = o->beta1; state[2 * P + 1] = o->beta2;
+    state[2 * P + 2] = o->ed_eta0; state[2 * P + 3] = 0.0;
+}
+void orc_opt_update(const orc_opt *o, int P, double *p, const double *grad_in, double *state) {
+    double *m = state, *v = state + P, *bp = state + 2 * P, *ed_eta = state + 2 * P + 2, *ncalls = state + 2 * P + 3;
+    const double eps = 1e-8;
+    double gn = 0.0, cs = 1.0;
+    if (o->grad_clip_norm > 0) {
+        for (int k = 0; k < P; ++k) gn += grad_in[k] * grad_in[k];
+        gn = sqrt(gn);
+        if (gn > o->grad_clip_norm) cs = o->grad_clip_norm / gn;
+    }
+    double eta_ed = 1.0;
+    if (o->use_expdecay) {
+        *ncalls += 1.0;
+        if (fmod(*ncalls, (double)o->decay_step) == 0.0) *ed_eta = fmax(*ed_eta * o->ed_decay, o->ed_clip);
+        eta_ed = *ed_eta;
+    }
+    for (int k = 0; k < P; ++k) {
+        double g = (o->grad_clip_norm > 0 && cs != 1.0) ? grad_in[k] / gn * o->grad_clip_norm : grad_in[k];
+        g *= eta_ed;
+        m[k] = o->beta1 * m[k] + (1.0 - o->beta1) * g;
+        v[k] = o->beta2 * v[k] + (1.0 - o->beta2) * g * g;
+        double delta = m[k] / (1.0 - bp[0]) / (sqrt(v[k] / (1.0 - bp[1])) + eps) * o->eta;
+        delta += o->wd * p[k];
+        p[k] -= delta;
+    }
+    bp[0] *= o->beta1; bp[1] *= o->beta2;
+}

@@ -1,0 +1,230 @@
+"""ctypes binding of oracle/libcrnn_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this module.  The product package (crnn_amd) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libcrnn_oracle.so")
+MAXN = 12
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "crnn_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "-s"])
+    return _SO
+
+
+class Problem(C.Structure):
+    _fields_ = [
+        ("ns", C.c_int32), ("nr", C.c_int32), ("has_temp", C.c_int32),
+        ("n_obs", C.c_int32), ("i_obs", C.c_int32 * MAXN),
+        ("clamp_pred", C.c_int32), ("loss_kind", C.c_int32),
+        ("maxiters", C.c_int32), ("errnorm_sens", C.c_int32),
+        ("lb", C.c_double), ("ub", C.c_double), ("inv_R", C.c_double),
+        ("rate_scale", C.c_double * MAXN),
+        ("atol", C.c_double * MAXN), ("rtol", C.c_double * MAXN),
+        ("yscale", C.c_double * MAXN),
+        ("t0", C.c_double),
+        ("gamma", C.c_double), ("qmin", C.c_double), ("qmax", C.c_double),
+        ("beta1", C.c_double), ("beta2", C.c_double),
+        ("qsteady_min", C.c_double), ("qsteady_max", C.c_double), ("qoldinit", C.c_double),
+        ("dtmin", C.c_double),
+    ]
+
+
+class Opt(C.Structure):
+    _fields_ = [
+        ("use_expdecay", C.c_int32), ("decay_step", C.c_int32),
+        ("ed_eta0", C.c_double), ("ed_decay", C.c_double), ("ed_clip", C.c_double),
+        ("eta", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("wd", C.c_double),
+        ("grad_clip_norm", C.c_double),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        assert _lib.orc_sizeof_problem() == C.sizeof(Problem), "oracle struct layout mismatch"
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32)) if a is not None else None
+
+
+def make_problem(*, ns, nr, has_temp=0, lb=1e-6, ub=np.inf, inv_R=0.0, rate_scale=None,
+                 atol=1e-6, rtol=1e-3, yscale=None, i_obs=None, clamp_pred=0, loss_kind=0,
+                 maxiters=100000, errnorm_sens=0, t0=0.0) -> Problem:
+    pb = Problem()
+    lib().orc_problem_defaults(C.byref(pb))
+    n = ns + has_temp
+    pb.ns, pb.nr, pb.has_temp = ns, nr, has_temp
+    pb.lb, pb.ub, pb.inv_R = lb, ub, inv_R
+    pb.clamp_pred, pb.loss_kind, pb.maxiters, pb.errnorm_sens = clamp_pred, loss_kind, maxiters, errnorm_sens
+    pb.t0 = t0
+    at = np.broadcast_to(np.asarray(atol, float), (n,))
+    rt = np.broadcast_to(np.asarray(rtol, float), (n,))
+    for i in range(n):
+        pb.atol[i], pb.rtol[i] = at[i], rt[i]
+    if rate_scale is not None:
+        for i in range(ns):
+            pb.rate_scale[i] = float(rate_scale[i])
+    i_obs = list(range(ns)) if i_obs is None else list(i_obs)
+    pb.n_obs = len(i_obs)
+    for k, i in enumerate(i_obs):
+        pb.i_obs[k] = i
+    ys = np.ones(len(i_obs)) if yscale is None else np.asarray(yscale, float)
+    for k in range(len(i_obs)):
+        pb.yscale[k] = ys[k]
+    return pb
+
+
+def n_theta(pb: Problem) -> int:
+    return lib().orc_n_theta(C.byref(pb))
+
+
+def n_params(kind: int, ns: int, nr: int) -> int:
+    return lib().orc_n_params(kind, ns, nr)
+
+
+def rhs(pb, theta, u):
+    n = pb.ns + pb.has_temp
+    du = np.zeros(n)
+    lib().orc_rhs(C.byref(pb), _dp(np.ascontiguousarray(theta, float)), _dp(np.ascontiguousarray(u, float)), _dp(du))
+    return du
+
+
+def jac(pb, theta, u):
+    n = pb.ns + pb.has_temp
+    J = np.zeros((n, n), order="F")
+    lib().orc_jac(C.byref(pb), _dp(np.ascontiguousarray(theta, float)), _dp(np.ascontiguousarray(u, float)), _dp(J))
+    return J
+
+
+def rhs_jvp(pb, theta, dtheta, u, su):
+    n = pb.ns + pb.has_temp
+    out = np.zeros(n)
+    lib().orc_rhs_jvp(C.byref(pb), _dp(np.ascontiguousarray(theta, float)), _dp(np.ascontiguousarray(dtheta, float)),
+                      _dp(np.ascontiguousarray(u, float)), _dp(np.ascontiguousarray(su, float)), _dp(out))
+    return out
+
+
+def jac_dir(pb, theta, dtheta, u, su):
+    n = pb.ns + pb.has_temp
+    dJ = np.zeros((n, n), order="F")
+    lib().orc_jac_dir(C.byref(pb), _dp(np.ascontiguousarray(theta, float)), _dp(np.ascontiguousarray(dtheta, float)),
+                      _dp(np.ascontiguousarray(u, float)), _dp(np.ascontiguousarray(su, float)), _dp(dJ))
+    return dJ
+
+
+def p2vec(kind, ns, nr, p, want_jac=True):
+    """returns theta [n_theta], dtheta [n_theta, P] (Fortran order) or None."""
+    p = np.ascontiguousarray(p, float)
+    P = n_params(kind, ns, nr)
+    assert p.size == P, (p.size, P)
+    n = ns + (1 if kind == 2 else 0)
+    nth = nr * (n + 1 + ns)
+    th = np.zeros(nth)
+    dth = np.zeros((nth, P), order="F") if want_jac else None
+    rc = lib().orc_p2vec(kind, ns, nr, _dp(p), _dp(th), _dp(dth))
+    assert rc == 0
+    return th, dth
+
+
+def solve_one(pb, theta, u0, tsave, data, dtheta=None, want_pred=True, want_dpred=False):
+    """One trajectory.  data: [n_obs, nsave] (Fortran / column-major semantics).
+    Returns dict(pred [n,nsave], loss, grad [P], retcode, n_saved, naccept, nreject, dpred)."""
+    n = pb.ns + pb.has_temp
+    tsave = np.ascontiguousarray(tsave, float)
+    nsave = tsave.size
+    theta = np.ascontiguousarray(theta, float)
+    P = 0
+    dth = None
+    if dtheta is not None:
+        dth = np.asfortranarray(dtheta, float)
+        P = dth.shape[1]
+    dataF = np.asfortranarray(data, float)
+    assert dataF.shape == (pb.n_obs, nsave)
+    pred = np.zeros((n, nsave), order="F") if want_pred else None
+    dpred = np.zeros((n, nsave, P), order="F") if (want_dpred and P) else None
+    loss = C.c_double(0)
+    grad = np.zeros(max(P, 1))
+    nsaved = C.c_int32(0)
+    st = (C.c_int64 * 2)(0, 0)
+    lib().orc_solve_one.restype = C.c_int
+    rc = lib().orc_solve_one(C.byref(pb), _dp(theta), _dp(dth), C.c_int(P), _dp(np.ascontiguousarray(u0, float)),
+                             _dp(tsave), C.c_int(nsave), _dp(dataF), _dp(pred), _dp(dpred), C.byref(loss),
+                             _dp(grad), C.byref(nsaved), C.cast(st, C.c_void_p))
+    return dict(pred=pred, loss=loss.value, grad=grad[:P].copy(), retcode=rc, n_saved=nsaved.value,
+                naccept=st[0], nreject=st[1], dpred=dpred)
+
+
+def solve_batch(pb, theta, u0, tsave, data, dtheta=None, want_pred=False, first=0, count=None, nthreads=0):
+    """Batched (IC-fastest layout): u0 [n, B] C-order (== u0[i*B+b]), data [nsave, n_obs, B] C-order.
+    grad is the SUM over trajectories of d loss_b/dp."""
+    n = pb.ns + pb.has_temp
+    u0 = np.ascontiguousarray(u0, float)
+    B = u0.shape[1]
+    assert u0.shape == (n, B)
+    tsave = np.ascontiguousarray(tsave, float)
+    nsave = tsave.size
+    data = np.ascontiguousarray(data, float)
+    assert data.shape == (nsave, pb.n_obs, B), data.shape
+    count = B - first if count is None else count
+    P = 0
+    dth = None
+    if dtheta is not None:
+        dth = np.asfortranarray(dtheta, float)
+        P = dth.shape[1]
+    pred = np.zeros((nsave, n, B)) if want_pred else None
+    loss = np.zeros(B)
+    grad = np.zeros(P) if P else None
+    retcode = np.zeros(B, np.int32)
+    nsaved = np.zeros(B, np.int32)
+    stats = np.zeros(2, np.int64)
+    lib().orc_solve_batch(C.byref(pb), _dp(np.ascontiguousarray(theta, float)), _dp(dth), C.c_int(P), _dp(u0), _dp(tsave),
+                          C.c_int(nsave), _dp(data), C.c_int64(B), C.c_int64(first), C.c_int64(count),
+                          _dp(pred), _dp(loss), _dp(grad), _ip(retcode), _ip(nsaved),
+                          stats.ctypes.data_as(C.POINTER(C.c_int64)), C.c_int(nthreads))
+    return dict(pred=pred, loss=loss, grad=grad, retcode=retcode, n_saved=nsaved,
+                naccept=int(stats[0]), nreject=int(stats[1]))
+
+
+class Optimiser:
+    """Flux.Optimise chain restatement (ExpDecay? -> ADAM -> WeightDecay [-> norm clip before])."""
+
+    def __init__(self, P, eta=0.005, beta=(0.9, 0.999), wd=1e-6, expdecay=None, grad_clip_norm=0.0):
+        self.o = Opt()
+        self.o.eta, self.o.beta1, self.o.beta2, self.o.wd = eta, beta[0], beta[1], wd
+        self.o.grad_clip_norm = grad_clip_norm
+        if expdecay is not None:
+            eta0, decay, step, clip = expdecay
+            self.o.use_expdecay, self.o.decay_step = 1, int(step)
+            self.o.ed_eta0, self.o.ed_decay, self.o.ed_clip = eta0, decay, clip
+        self.P = P
+        self.state = np.zeros(lib().orc_opt_state_len(P))
+        lib().orc_opt_init(C.byref(self.o), C.c_int(P), _dp(self.state))
+
+    def update(self, p, grad):
+        p = np.ascontiguousarray(p, float)
+        lib().orc_opt_update(C.byref(self.o), C.c_int(self.P), _dp(p), _dp(np.ascontiguousarray(grad, float)), _dp(self.state))
+        return p

@@ -1,0 +1,61 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def fx():
+    with open(os.path.join(ROOT, "tests", "golden", "fixtures.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The CPU oracle (test infrastructure): builds oracle/libcrnn_oracle.so on demand."""
+    from oracle import oracle as o
+    o.build()
+    o.lib()
+    return o
+
+
+INV_R = -1.0 / 1.98720425864083e-3
+
+
+@pytest.fixture(scope="session")
+def case2_setup(fx):
+    c2 = fx["case2"]
+    return dict(u0=np.array(c2["u0"]), tsteps=np.array(c2["tsteps"]), data=np.array(c2["data"]),
+                yscale=np.array(c2["yscale"]), pred_ckpt=np.array(c2["pred_ckpt"]),
+                p_ckpt=np.array(fx["case2_ckpt"]["p"]), p_init=np.array(c2["p_init"]), grads=c2["grads"])
+
+
+@pytest.fixture(scope="session")
+def rober_setup(fx):
+    rb = fx["robertson"]
+    return dict(u0=np.array(rb["u0"]), tsteps=np.array(rb["tsteps"]), data=np.array(rb["data"]),
+                yscale=np.array(rb["yscale"]), dydt_scale=np.array(rb["dydt_scale"]),
+                pred_ckpt=np.array(rb["pred_ckpt"]), p_ckpt=np.array(fx["rober_ckpt"]["p"]), grads=rb["grads"],
+                kat=rb["kat"])
+
+
+def oracle_problem(orc, case, setup, atol=None, rtol=None, maxiters=None, **kw):
+    if case == "case2":
+        return orc.make_problem(ns=6, nr=3, has_temp=1, lb=1e-6, ub=10.0, inv_R=INV_R,
+                                atol=1e-6 if atol is None else atol, rtol=1e-3 if rtol is None else rtol,
+                                yscale=setup["yscale"], clamp_pred=1, maxiters=maxiters or 100000, **kw)
+    if case == "rober":
+        return orc.make_problem(ns=3, nr=6, lb=1e-8, atol=[1e-6, 1e-8, 1e-6] if atol is None else atol,
+                                rtol=1e-3 if rtol is None else rtol, yscale=setup["yscale"],
+                                rate_scale=setup["dydt_scale"], maxiters=maxiters or 10000, **kw)
+    raise ValueError(case)
