@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the CRNN neural-ODE hot path on MI355X.
+
+Metric (BASELINE.json): stiff neural-ODE trajectories+gradients per second,
+case2 (6 species + T, 3 reactions, P = 25), 65 536 random initial conditions
+per GPU, fp64, Rosenbrock23 at the reference tolerances (atol 1e-6, rtol 1e-3).
+
+One "step" = one pass of the hot path over the rank's batch, with the ensemble
+already resident in HBM: p2vec kernel -> fused solve + loss + forward-tangent
+kernel (65 536 trajectories) -> fixed-order gradient reduction -> all-reduce of
+the (P+pad+5)-vector over ranks (RCCL) -> Flux-style ExpDecay/ADAM/WeightDecay
+update of p on the device.  Weak scaling: every rank owns its own 65 536 ICs.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field meanings).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic HBM bytes per trajectory+gradient, case2, no pred output:
+#   8 * [ n (u0) + n_obs*D (data) + 1 (loss) + 1 (retcode + n_saved as 2 x int32) ]
+BYTES_PER_TRAJ = 8 * (7 + 6 * 50 + 1 + 1)
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X FP64 vector peak (spec); 2 flop per FMA
+# FP64 operation model of one Rosenbrock23 attempt of the kernel (DESIGN.md "flop model"):
+FLOP_PRIMAL_STEP = 2 * 1150      # f-evals (12 log, 6 exp, matvecs), J, 6x6 LU, 3 solves, error norm, controller
+FLOP_COL_STEP = 2 * 525          # one tangent column through one accepted step
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=65536, help="initial conditions per GPU")
+    ap.add_argument("--comm", choices=["rccl", "torch"], default="rccl")
+    ap.add_argument("--cols", type=int, default=0, help="tangent columns per lane (0 = library default)")
+    ap.add_argument("--theta0", choices=["ckpt", "init"], default="ckpt",
+                    help="start from the reference's trained checkpoint p or a reference-style random init")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=32768)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import crnn_amd
+    from crnn_amd import NeuralODE, ODEProblem, Optimiser, PRESET_CASE2, cases
+    from crnn_amd._lib import check, dptr, lib
+    from crnn_amd.dist import DataParallel
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); no CPU fallback exists")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    B = args.batch
+    ts = cases.case2_tsteps()
+    rng = np.random.Generator(np.random.PCG64([1234, rank]))
+    u0 = cases.case2_u0(B, rng)
+
+    # ---- synthetic ensemble, mirroring case2/case2.jl:62-83: true mechanism (an exact CRNN)
+    #      integrated at tight tolerance by the same gfx950 stepper, 5 % multiplicative noise ----
+    gen = NeuralODE(ODEProblem(PRESET_CASE2, ts, atol=1e-10, rtol=1e-8, device=local_rank))
+    clean = gen.predict_theta(u0, cases.case2_true_theta())[:, :6, :]      # [B, 6, 50]
+    gen.close()
+    data = cases.add_noise(clean, 0.05, rng)
+    yscale = cases.max_min(data, lb=1e-6)
+    if world > 1:  # yscale is a global statistic of the data set (case2.jl:83)
+        t = torch.tensor(yscale, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        yscale = t.cpu().numpy()
+
+    node = NeuralODE(ODEProblem(PRESET_CASE2, ts, device=local_rank, cols_per_lane=args.cols))
+    node.set_ensemble(u0, data, yscale)          # one PCIe upload; resident in HBM from here on
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fixtures.json")))
+    p0 = np.array(fx["case2_ckpt"]["p"]) if args.theta0 == "ckpt" else cases.case2_init_p(np.random.Generator(np.random.PCG64(7)))
+    node.train_init(Optimiser(25, PRESET_CASE2), p0)
+
+    comm = args.comm
+    dp = DataParallel(node, comm=comm)
+    if not dp.selftest():
+        raise SystemExit(f"rank {rank}: all-reduce self-test failed on comm={comm}")
+
+    def sync_all():
+        check(lib.crnn_synchronize(node.handle), node.handle)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        dp.train_step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dp.train_step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    # ---- per-launch kernel durations over the timed region (HIP events on the ctx stream) ----
+    nk = min(args.steps, 64)
+    kms = np.zeros(nk)
+    check(lib.crnn_kernel_times(node.handle, dptr(kms), nk), node.handle)
+    st = node.stats()          # last step: n_traj, n_ok, n_accept, n_reject
+    p_now = node.params()
+
+    out = None
+    if rank == 0:
+        k_ms = float(kms.mean())
+        value = world * B * args.steps / elapsed
+        ach_gbs = BYTES_PER_TRAJ * B / (k_ms * 1e-3) / 1e9
+        flops = (st["n_accept"] + st["n_reject"]) * FLOP_PRIMAL_STEP + st["n_accept"] * 25 * FLOP_COL_STEP
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md)
+            try:
+                traffic = json.load(open(tpath)).get("case2_B65536_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "stiff neural-ODE trajectories+grads/sec, case2 batch 65k",
+            "value": value, "unit": "trajectories+grads/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "case2: 6 species + T, 3 reactions, P=25, D=50 save points on [0,50], "
+                                   "Rosenbrock23 atol 1e-6 rtol 1e-3, MAE loss, forward-tangent gradient, "
+                                   "ExpDecay+ADAM+WeightDecay update",
+                       "batch_per_gpu": B, "global_batch": B * world, "theta0": args.theta0,
+                       "comm": comm if world > 1 else "none", "parallelism": f"dp{world} (ICs sharded, 1 all-reduce/step)"},
+            "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "ros23_kernel<6,3,T,C>", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_launch": BYTES_PER_TRAJ * B,
+                         "note": "state lives in VGPR/LDS for the whole integration; the path is FP64-VALU/latency bound, "
+                                 "see valu_fp64 (SURVEY F8)"},
+            # flop count and duration of the LAST timed launch (step counts drift slightly as p is updated)
+            "valu_fp64": {"achieved": flops / (kms[-1] * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": flops / (kms[-1] * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                          "steps_per_traj": st["n_accept"] / max(st["n_traj"], 1),
+                          "rejects_per_traj": st["n_reject"] / max(st["n_traj"], 1),
+                          "n_ok": st["n_ok"], "n_traj": st["n_traj"]},
+        }
+        # ---- CPU baseline: the C oracle ("port", OpenMP over trajectories) on a bounded sample ----
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as orc
+            ns_ = min(args.cpu_sample, B)
+            th, dth = orc.p2vec(2, 6, 3, p0)
+            pb = orc.make_problem(ns=6, nr=3, has_temp=1, lb=1e-6, ub=10.0, inv_R=cases.INV_R, atol=1e-6, rtol=1e-3,
+                                  yscale=yscale, clamp_pred=1)
+            u0_s = np.ascontiguousarray(u0[:ns_].T)
+            data_s = np.ascontiguousarray(data[:ns_].transpose(2, 1, 0))
+            cores = os.cpu_count() or 1
+            orc.solve_batch(pb, th, u0_s[:, :256].copy(), ts, data_s[:, :, :256].copy(), dtheta=dth, nthreads=cores)  # warm-up
+            tc = time.perf_counter()
+            orc.solve_batch(pb, th, u0_s, ts, data_s, dtheta=dth, nthreads=cores)
+            tc = time.perf_counter() - tc
+            out["cpu_baseline"] = {"value": ns_ / tc, "unit": "trajectories+grads/s", "cores": cores, "kind": "port",
+                                   "sample": f"first {ns_} ICs of the same ensemble, solve+loss+gradient at the same p, "
+                                             f"C oracle with OpenMP over trajectories ({tc:.2f} s wall); "
+                                             "a C restatement, not DifferentialEquations.jl (Julia absent)"}
+        # RCCL prints a version banner through C stdio (block-buffered on a pipe): flush it first so
+        # that the JSON line is the LAST line of stdout.
+        C.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
+    dp.close()
+    node.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -81,6 +81,7 @@ SYMBOLS = {
     "crnn_get_params": (C.c_int32, [_CTX, _DP]),
     "crnn_set_params": (C.c_int32, [_CTX, _DP]),
     "crnn_last_stats": (C.c_int32, [_CTX, C.POINTER(Stats)]),
+    "crnn_kernel_times": (C.c_int32, [_CTX, _DP, C.c_int32]),
     "crnn_synchronize": (C.c_int32, [_CTX]),
     "crnn_comm_get_unique_id": (C.c_int32, [C.c_char_p]),
     "crnn_comm_init": (C.c_int32, [_CTX, C.c_char_p, C.c_int32, C.c_int32]),

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from . import _lib as L
+
 
 R_KCAL = 1.98720425864083e-3           # case2/case2.jl:56
 INV_R = -1.0 / R_KCAL                  # case2/case2.jl:113

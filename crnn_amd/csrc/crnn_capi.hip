@@ -62,7 +62,10 @@ struct Ctx {
     std::string err;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    static constexpr int kRing = 64;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;           // events of the most recent solve kernel
+    hipEvent_t ring0[kRing] = {}, ring1[kRing] = {};   // ring of (start, stop) pairs, one per launch
+    int64_t n_launch = 0;
     int num_cu = 256;
     // ensemble
     int64_t B = 0;
@@ -227,6 +230,9 @@ int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int 
     prm.qsteady_min = c->cfg.qsteady_min; prm.qsteady_max = c->cfg.qsteady_max;
     prm.qoldinit = c->cfg.qoldinit; prm.dtmin = c->cfg.dtmin;
 
+    c->ev0 = c->ring0[c->n_launch % Ctx::kRing];
+    c->ev1 = c->ring1[c->n_launch % Ctx::kRing];
+    ++c->n_launch;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     hipLaunchKernelGGL(k->fn, dim3(nblk), dim3(kBlock), smem, c->stream, prm, d_theta, d_dtheta);
     HIP_TRY(c, hipGetLastError());
@@ -362,7 +368,9 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
     c->num_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate failed");
     c->own_stream = true;
-    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return bail("hipEventCreate failed");
+    for (int i = 0; i < Ctx::kRing; ++i)
+        if (hipEventCreate(&c->ring0[i]) != hipSuccess || hipEventCreate(&c->ring1[i]) != hipSuccess)
+            return bail("hipEventCreate failed");
     c->max_dir = std::max(c->n_params, c->n_theta);
     if (hipMalloc((void **)&c->d_theta, sizeof(double) * c->n_theta) != hipSuccess ||
         hipMalloc((void **)&c->d_dtheta, sizeof(double) * (size_t)c->n_theta * c->max_dir) != hipSuccess ||
@@ -385,8 +393,10 @@ void crnn_ctx_destroy(crnn_ctx *ctx) {
     void *ptrs[] = {c->d_tsave, c->d_pred, c->d_loss, c->d_ret, c->d_nsaved, c->d_theta, c->d_dtheta,
                     c->d_partials, c->d_red, c->d_p, c->d_opt, c->d_comm_buf};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (int i = 0; i < Ctx::kRing; ++i) {
+        if (c->ring0[i]) (void)hipEventDestroy(c->ring0[i]);
+        if (c->ring1[i]) (void)hipEventDestroy(c->ring1[i]);
+    }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -636,6 +646,20 @@ int32_t crnn_last_stats(crnn_ctx *ctx, crnn_stats *stats) {
     HIP_TRY(c, hipMemcpyAsync(red.data(), c->d_red, sizeof(double) * c->last_npart, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return fill_stats(c, red.data(), c->last_npart, stats);
+}
+
+int32_t crnn_kernel_times(crnn_ctx *ctx, double *ms, int32_t n) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c || !ms || n < 1) return fail(c, "crnn_kernel_times: bad arguments");
+    if (n > Ctx::kRing || n > c->n_launch) return fail(c, "crnn_kernel_times: fewer launches recorded than requested");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; ++i) {  // ms[0] = oldest of the last n launches
+        int64_t idx = (c->n_launch - n + i) % Ctx::kRing;
+        float t = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&t, c->ring0[idx], c->ring1[idx]));
+        ms[i] = t;
+    }
+    return 0;
 }
 
 int32_t crnn_synchronize(crnn_ctx *ctx) {

@@ -95,7 +95,7 @@ CRNN_HD inline int p2vec_eval(int pmap, int ns, int nr, int has_temp, const doub
                 const int ko = nr + i + ns * j;
                 const int ki = nr * (ns + 1) + i + ns * j;
                 const double wi_raw = p[ki], wo_raw = p[ko];
-                const double pw = exp(ln10 * wo_raw);
+                const double pw = pow(10.0, wo_raw);
                 th[o_out + i + ns * j] = -wi_raw * pw;
                 th[o_in + i + n * j] = clampd(wi_raw, 0.0, 2.5);
                 if (dth) {

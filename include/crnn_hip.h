@@ -177,10 +177,14 @@ int32_t crnn_train_step(crnn_ctx *ctx, int64_t first, int64_t count, int32_t n_s
  * (e.g. torch.distributed) on crnn_grad_buffer() between them. */
 int32_t crnn_train_step_begin(crnn_ctx *ctx, int64_t first, int64_t count, int32_t n_save_active);
 int32_t crnn_train_step_end(crnn_ctx *ctx, double *loss_mean);
-int32_t crnn_grad_buffer(crnn_ctx *ctx, void **d_ptr, int32_t *n_doubles); /* [grad_p | loss_sum | n_traj] */
+/* device vector [grad_sum(P) | pad | loss_sum, n_ok, n_accept, n_reject, n_traj] of the step in flight */
+int32_t crnn_grad_buffer(crnn_ctx *ctx, void **d_ptr, int32_t *n_doubles);
 int32_t crnn_get_params(crnn_ctx *ctx, double *p);
 int32_t crnn_set_params(crnn_ctx *ctx, const double *p);
 int32_t crnn_last_stats(crnn_ctx *ctx, crnn_stats *stats); /* of the most recent solve; synchronises */
+/* HIP-event durations (ms) of the solve kernel of the last n launches (n <= 64), oldest first;
+ * synchronises the ctx stream.  The measurement bench.py's roofline figures come from. */
+int32_t crnn_kernel_times(crnn_ctx *ctx, double *ms, int32_t n);
 int32_t crnn_synchronize(crnn_ctx *ctx);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------- */

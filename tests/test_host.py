@@ -1,0 +1,169 @@
+"""CPU-side tests of the product's host logic and of the C-ABI library itself
+(no compute on a GPU): exported symbols, p2vec / optimiser host code against
+the oracle and the golden vectors, presets, argument validation."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    """Every function declared in include/crnn_hip.h is exported by libcrnn_hip.so and bound in _lib.SYMBOLS."""
+    from crnn_amd import _lib as L
+    hdr = open(os.path.join(ROOT, "include", "crnn_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(crnn_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 25
+    raw = C.CDLL(L.LIB_PATH)
+    for n in sorted(names):
+        assert hasattr(raw, n), f"{n} declared in crnn_hip.h but not exported"
+        assert n in L.SYMBOLS, f"{n} not bound in crnn_amd/_lib.py"
+    assert set(L.SYMBOLS) == names
+    assert raw.crnn_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    from crnn_amd import _lib as L
+    # crnn_config: 12 int32 + 4 double + 3*12 double + 9 double
+    assert C.sizeof(L.Config) == 12 * 4 + (4 + 36 + 9) * 8
+    assert C.sizeof(L.Stats) == 4 * 8 + 8
+    assert C.sizeof(L.OptConfig) == 2 * 4 + 8 * 8
+
+
+def test_presets_carry_reference_constants():
+    from crnn_amd import _lib as L
+    cfg = L.Config()
+    L.check(L.lib.crnn_config_preset(C.byref(cfg), L.PRESET_CASE2))
+    assert (cfg.ns, cfg.nr, cfg.has_temp, cfg.n_save, cfg.clamp_pred) == (6, 3, 1, 50, 1)          # case2.jl:18-25
+    assert cfg.lb == 1e-6 and cfg.ub == 10.0 and cfg.atol[0] == 1e-6 and cfg.rtol[0] == 1e-3        # :27-35
+    assert cfg.inv_R == -1.0 / 1.98720425864083e-3                                                   # :113
+    L.check(L.lib.crnn_config_preset(C.byref(cfg), L.PRESET_ROBER))
+    assert (cfg.ns, cfg.nr, cfg.has_temp, cfg.n_save, cfg.maxiters) == (3, 6, 0, 40, 10000)          # rober:20-30
+    assert [cfg.atol[i] for i in range(3)] == [1e-6, 1e-8, 1e-6] and cfg.lb == 1e-8 and np.isinf(cfg.ub)
+    L.check(L.lib.crnn_config_preset(C.byref(cfg), L.PRESET_CASE1))
+    assert (cfg.ns, cfg.nr, cfg.n_save, cfg.maxiters) == (5, 4, 100, 10000) and cfg.rtol[0] == 1e-2
+    assert L.lib.crnn_config_preset(C.byref(cfg), 99) != 0
+    o = L.OptConfig()
+    L.check(L.lib.crnn_opt_preset(C.byref(o), L.PRESET_CASE2))
+    assert (o.use_expdecay, o.decay_step, o.eta, o.wd, o.ed_clip) == (1, 10000, 0.005, 1e-6, 1e-4)   # case2.jl:31-32
+    L.check(L.lib.crnn_opt_preset(C.byref(o), L.PRESET_ROBER))
+    assert o.grad_clip_norm == 10.0 and o.use_expdecay == 0                                         # rober:19,29
+
+
+@pytest.mark.parametrize("kind,ns,nr", [(1, 5, 4), (2, 6, 3), (3, 3, 6)])
+def test_host_p2vec_equals_oracle(orc, kind, ns, nr):
+    from crnn_amd import p2vec_jac
+    rng = np.random.default_rng(10 + kind)
+    P = orc.n_params(kind, ns, nr)
+    for trial in range(5):
+        p = rng.standard_normal(P)
+        if trial == 0:
+            p[3] = 0.0   # kinks: clamp edge / abs at 0
+        th, dth = p2vec_jac(kind, ns, nr, p)
+        th_o, dth_o = orc.p2vec(kind, ns, nr, p)
+        assert np.max(np.abs(th - th_o)) <= 1e-15 * max(1.0, np.max(np.abs(th_o)))
+        assert np.max(np.abs(dth - dth_o)) <= 1e-14 * max(1.0, np.max(np.abs(dth_o)))
+
+
+def test_host_p2vec_checkpoint_golden(fx):
+    from crnn_amd import p2vec, p2vec_jac
+    th, _ = p2vec_jac(2, 6, 3, np.array(fx["case2_ckpt"]["p"]))
+    assert np.max(np.abs(th - np.array(fx["case2_ckpt"]["theta"]))) < 1e-14
+    th, _ = p2vec_jac(3, 3, 6, np.array(fx["rober_ckpt"]["p"]))
+    gold = np.array(fx["rober_ckpt"]["theta"])
+    assert np.max(np.abs(th - gold)) < 1e-14 * np.max(np.abs(gold))
+    w_in, w_b, w_out = p2vec(2, 6, 3, np.array(fx["case2_ckpt"]["p"]))
+    assert w_in.shape == (7, 3) and w_b.shape == (3,) and w_out.shape == (6, 3)
+    assert np.all(w_in[:6] == np.clip(-w_out, 0, 4))
+    with pytest.raises(ValueError):
+        p2vec_jac(2, 6, 3, np.zeros(24))
+
+
+def test_host_optimiser_matches_golden_trace_and_oracle(orc, fx):
+    from crnn_amd import Optimiser, PRESET_CASE1, PRESET_ROBER
+    o = fx["optim"]
+    g = np.array(o["grads"]); p0 = np.array(o["p0"])
+    cases_ = (("case2", Optimiser(25, eta=0.005, wd=1e-6, expdecay=(5e-3, 0.5, 5, 1e-4)),
+               orc.Optimiser(25, eta=0.005, wd=1e-6, expdecay=(5e-3, 0.5, 5, 1e-4))),
+              ("rober", Optimiser(25, PRESET_ROBER), orc.Optimiser(25, eta=0.005, wd=1e-6, grad_clip_norm=10.0)),
+              ("case1", Optimiser(25, PRESET_CASE1), orc.Optimiser(25, eta=0.001, wd=1e-8)))
+    for key, opt, oopt in cases_:
+        p = p0.copy(); po = p0.copy()
+        for i in range(g.shape[0]):
+            opt.update_(p, g[i])
+            po = oopt.update(po, g[i])
+            assert np.max(np.abs(p - np.array(o[key][i]))) < 1e-15
+            assert np.max(np.abs(p - po)) < 1e-15
+
+
+def test_cpu_definition_of_crnn_matches_oracle_rhs(orc, case2_setup):
+    """crnn(du,u,p,t): the CPU definition kept for ODEProblem construction equals the oracle RHS."""
+    from crnn_amd import crnn, p2vec
+    s = case2_setup
+    w = p2vec(2, 6, 3, s["p_ckpt"])
+    u = np.array([0.7, 1.2, 0.3, 0.05, 1e-9, 12.0, 331.0])   # below lb and above ub included
+    du = crnn(np.zeros(7), u, w, lb=1e-6, ub=10.0, inv_R=-1.0 / 1.98720425864083e-3)
+    th, _ = orc.p2vec(2, 6, 3, s["p_ckpt"])
+    pb = orc.make_problem(ns=6, nr=3, has_temp=1, lb=1e-6, ub=10.0, inv_R=-1.0 / 1.98720425864083e-3)
+    assert np.max(np.abs(du - orc.rhs(pb, th, u))) < 1e-13 * np.max(np.abs(du))
+    assert du[6] == 0.0
+
+
+def test_true_mechanisms_are_exact_crnn_instances(orc, fx):
+    """cases.*_true_theta reproduce the literal trueODEfunc right-hand sides (away from the clamp)."""
+    from crnn_amd import cases
+    y = np.array([0.9, 1.4, 0.2, 0.1, 0.05, 0.6, 330.0])
+    k = np.exp(cases.CASE2_LOGA) * np.exp(-cases.CASE2_EA / cases.R_KCAL / y[6])
+    r1, r2, r3 = k[0] * y[0] * y[1], k[1] * y[2] * y[1], k[2] * y[3] * y[1]
+    lit = np.array([-r1, -r1 - r2 - r3, r1 - r2, r2 - r3, r3, r1 + r2 + r3, 0.0])
+    pb = orc.make_problem(ns=6, nr=3, has_temp=1, lb=1e-6, ub=10.0, inv_R=cases.INV_R)
+    assert np.max(np.abs(orc.rhs(pb, cases.case2_true_theta(), y) - lit)) < 1e-12 * np.max(np.abs(lit))
+    y = np.array([0.8, 3e-5, 0.4])
+    kr = cases.ROBER_K
+    lit = np.array([-kr[0] * y[0] + kr[2] * y[1] * y[2], kr[0] * y[0] - kr[1] * y[1] ** 2 - kr[2] * y[1] * y[2], kr[1] * y[1] ** 2])
+    pb = orc.make_problem(ns=3, nr=3, lb=1e-300)
+    assert np.max(np.abs(orc.rhs(pb, cases.rober_true_theta(), y) - lit)) < 1e-12 * np.max(np.abs(lit))
+    y = np.array([0.7, 0.5, 0.2, 0.1, 0.05])
+    kk = cases.CASE1_K
+    lit = np.array([-2 * kk[0] * y[0] ** 2 - kk[1] * y[0], kk[0] * y[0] ** 2 - kk[3] * y[1] * y[3], kk[1] * y[0] - kk[2] * y[2],
+                    kk[2] * y[2] - kk[3] * y[1] * y[3], kk[3] * y[1] * y[3]])
+    pb = orc.make_problem(ns=5, nr=4, lb=1e-5, ub=10.0)
+    assert np.max(np.abs(orc.rhs(pb, cases.case1_true_theta(), y) - lit)) < 1e-12 * np.max(np.abs(lit))
+
+
+def test_product_fails_loudly_without_gpu():
+    """No CPU fallback: creating a context without an MI355X is an error with a message."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from crnn_amd import CrnnError, NeuralODE, ODEProblem, PRESET_CASE2, cases
+    with pytest.raises(CrnnError, match="no HIP device"):
+        NeuralODE(ODEProblem(PRESET_CASE2, cases.case2_tsteps()))
+
+
+def test_product_does_not_touch_the_oracle():
+    """The shipped package never imports, links or names the oracle."""
+    pkg = os.path.join(ROOT, "crnn_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.lower().replace("# oracle-free", ""), f"{f} mentions the oracle"
+    out = os.popen(f"ldd {os.path.join(pkg, 'csrc', 'libcrnn_hip.so')}").read()
+    assert "oracle" not in out
+
+
+def test_shard_ranges_partition_the_ensemble():
+    from crnn_amd.dist import shard_range
+    for n, w in ((65536, 8), (262144, 8), (10, 3), (7, 8), (1, 1)):
+        seen = []
+        for r in range(w):
+            f, c = shard_range(n, r, w)
+            seen.extend(range(f, f + c))
+        assert seen == list(range(n))
+    with pytest.raises(ValueError):
+        shard_range(8, 8, 8)
