@@ -79,6 +79,8 @@ struct Ctx {
     double *d_pred = nullptr, *d_loss = nullptr;
     int32_t *d_ret = nullptr, *d_nsaved = nullptr;
     size_t pred_cap = 0;
+    crnn::KConst *d_kc = nullptr;
+    bool kc_dirty = true;
     // weights
     double *d_theta = nullptr, *d_dtheta = nullptr;  // [n_theta], [n_theta * max_dir]
     int max_dir = 0;
@@ -155,13 +157,25 @@ __global__ void opt_kernel(crnn::OptCfg o, int P, int npart, double *p, const do
 }
 
 size_t smem_bytes(const Ctx *c, int C, int P) {
-    int N = c->n;
-    int nth = c->cfg.nr * (N + 1 + c->cfg.ns);
-    int nthp = nth | 1;
-    int CC = C > 0 ? C : 1;
-    int L = C > 0 ? (P + C - 1) / C : 1;
-    size_t dth = C > 0 ? (size_t)L * C * nthp : 0;
-    return (dth + (size_t)(CC + crnn::kExtra) * kBlock) * sizeof(double);
+    return (size_t)crnn::smem_doubles(c->cfg.ns, c->cfg.nr, c->n, C, P, kBlock) * sizeof(double);
+}
+
+int32_t upload_consts(Ctx *c) {
+    if (!c->kc_dirty) return 0;
+    crnn::KConst k{};
+    k.lb = c->cfg.lb; k.ub = c->cfg.ub; k.inv_R = c->cfg.inv_R; k.t0 = c->cfg.t0;
+    k.gamma = c->cfg.gamma; k.qmin = c->cfg.qmin; k.qmax = c->cfg.qmax;
+    k.beta1 = c->cfg.beta1; k.beta2 = c->cfg.beta2;
+    k.qsteady_min = c->cfg.qsteady_min; k.qsteady_max = c->cfg.qsteady_max;
+    k.qoldinit = c->cfg.qoldinit; k.dtmin = c->cfg.dtmin;
+    for (int i = 0; i < CRNN_MAX_N; ++i) {
+        k.atol[i] = c->cfg.atol[i]; k.rtol[i] = c->cfg.rtol[i]; k.scale[i] = c->cfg.rate_scale[i];
+        k.inv_yscale[i] = c->inv_yscale[i]; k.drow[i] = (double)c->drow[i];
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_kc, &k, sizeof(k), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // k is a stack object
+    c->kc_dirty = false;
+    return 0;
 }
 
 template <class T>
@@ -220,15 +234,10 @@ int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int 
     prm.n_save = n_save_active; prm.P = P; prm.npart = npart;
     prm.maxiters = c->cfg.maxiters; prm.clamp_pred = c->cfg.clamp_pred; prm.loss_kind = c->cfg.loss_kind;
     prm.n_obs = c->n_obs;
-    for (int i = 0; i < CRNN_MAX_N; ++i) {
-        prm.drow[i] = c->drow[i]; prm.inv_yscale[i] = c->inv_yscale[i];
-        prm.atol[i] = c->cfg.atol[i]; prm.rtol[i] = c->cfg.rtol[i]; prm.scale[i] = c->cfg.rate_scale[i];
-    }
-    prm.lb = c->cfg.lb; prm.ub = c->cfg.ub; prm.inv_R = c->cfg.inv_R; prm.t0 = c->cfg.t0;
-    prm.gamma = c->cfg.gamma; prm.qmin = c->cfg.qmin; prm.qmax = c->cfg.qmax;
-    prm.beta1 = c->cfg.beta1; prm.beta2 = c->cfg.beta2;
-    prm.qsteady_min = c->cfg.qsteady_min; prm.qsteady_max = c->cfg.qsteady_max;
-    prm.qoldinit = c->cfg.qoldinit; prm.dtmin = c->cfg.dtmin;
+    prm.kc = c->d_kc;
+    if (upload_consts(c)) return -1;
+    if (smem > 64 * 1024)
+        HIP_TRY(c, hipFuncSetAttribute((const void *)k->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 
     c->ev0 = c->ring0[c->n_launch % Ctx::kRing];
     c->ev1 = c->ring1[c->n_launch % Ctx::kRing];
@@ -375,6 +384,7 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
     if (hipMalloc((void **)&c->d_theta, sizeof(double) * c->n_theta) != hipSuccess ||
         hipMalloc((void **)&c->d_dtheta, sizeof(double) * (size_t)c->n_theta * c->max_dir) != hipSuccess ||
         hipMalloc((void **)&c->d_tsave, sizeof(double) * cfg->n_save) != hipSuccess ||
+        hipMalloc((void **)&c->d_kc, sizeof(crnn::KConst)) != hipSuccess ||
         hipMalloc((void **)&c->d_p, sizeof(double) * c->n_params) != hipSuccess ||
         hipMalloc((void **)&c->d_opt, sizeof(double) * (2 * c->n_params + 4)) != hipSuccess)
         return bail("crnn_ctx_create: hipMalloc failed");
@@ -390,7 +400,7 @@ void crnn_ctx_destroy(crnn_ctx *ctx) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->own_u0 && c->d_u0) (void)hipFree(c->d_u0);
     if (c->own_data && c->d_data) (void)hipFree(c->d_data);
-    void *ptrs[] = {c->d_tsave, c->d_pred, c->d_loss, c->d_ret, c->d_nsaved, c->d_theta, c->d_dtheta,
+    void *ptrs[] = {c->d_kc, c->d_tsave, c->d_pred, c->d_loss, c->d_ret, c->d_nsaved, c->d_theta, c->d_dtheta,
                     c->d_partials, c->d_red, c->d_p, c->d_opt, c->d_comm_buf};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < Ctx::kRing; ++i) {
@@ -429,6 +439,7 @@ static int32_t set_data_common(Ctx *c, const double *tsteps, const double *yscal
         c->inv_yscale[i] = 1.0 / ys;
     }
     c->n_obs = n_obs;
+    c->kc_dirty = true;
     for (int j = 1; j < c->cfg.n_save; ++j)
         if (!(tsteps[j] > tsteps[j - 1])) return fail(c, "crnn_ctx_set_data: tsteps must be strictly increasing");
     if (tsteps[0] < c->cfg.t0) return fail(c, "crnn_ctx_set_data: tsteps[0] < t0");

@@ -11,23 +11,27 @@
 //
 // MI355X mapping:
 //   * a *lane group* of L = ceil(P/C) lanes owns one trajectory; each lane owns
-//     C tangent columns (directions in parameter space) in VGPRs and computes
-//     the small primal step redundantly, so the step needs no cross-lane
-//     traffic at all; 64/L groups share a wavefront;
+//     C tangent columns (directions in parameter space); 64/L groups share a
+//     wavefront.  The small primal step is computed redundantly by the L lanes
+//     (no cross-lane traffic in the stepper);
+//   * the step is split in two register phases.  PRIMAL: W = I - gam*J is built,
+//     LU-factored with partial pivoting and back-substituted in VGPRs, the three
+//     stages, the error estimate, the PI controller and the saveat/loss code run;
+//     everything the tangents need is published once per group in an LDS *step
+//     record* (lane 0 of the group writes, all L lanes read = broadcast).
+//     TANGENT: per column, operands stream from the record / the LDS-staged
+//     d theta/d p matrix, the column itself lives in a per-lane LDS slot; only
+//     the LU factors stay in registers across the phase.  This keeps the kernel
+//     free of scratch (the first version spilled 1 KB/lane and moved 80x the
+//     algorithmic HBM bytes);
 //   * groups are persistent: when a trajectory finishes the group loads the
-//     next one, so the divergence caused by different step counts is confined
-//     to the cheap init/finish code and never idles the stepper;
-//   * the direction matrix d theta/d p is staged once per block in LDS (odd
-//     row pitch -> conflict-free 8-byte reads), theta itself is read through
-//     wave-uniform scalar loads;
-//   * the Jacobian (ns x ns, T is a constant of motion) is built, LU-factored
-//     with partial pivoting and back-substituted entirely in registers;
+//     next one, so step-count divergence never idles the stepper;
+//   * theta is read through wave-uniform scalar loads (SGPR operands);
 //   * all HBM traffic is the compulsory u0 / data / loss stream, IC-fastest so
 //     consecutive groups touch consecutive addresses;
-//   * gradients are reduced deterministically: lane -> LDS -> per-block
-//     partial -> fixed-order second kernel (bitwise reproducible for a given
-//     launch geometry, which keeps replicated optimiser states identical
-//     across ranks).
+//   * gradients are reduced deterministically: lane -> LDS -> per-block partial
+//     -> fixed-order second kernel (bitwise reproducible for a given launch
+//     geometry: replicated optimiser states stay identical across ranks).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -36,6 +40,15 @@ namespace crnn {
 
 constexpr int kMaxN = 12;
 constexpr int kExtra = 5;  // loss_sum, n_ok, n_accept, n_reject, n_traj
+
+// Problem constants: one copy in device memory, staged to LDS by every block.
+struct KConst {
+    double lb, ub, inv_R, t0;
+    double gamma, qmin, qmax, beta1, beta2, qsteady_min, qsteady_max, qoldinit, dtmin;
+    double atol[kMaxN], rtol[kMaxN], scale[kMaxN], inv_yscale[kMaxN];
+    double drow[kMaxN];  // species -> row of data (as double), -1 if unobserved
+};
+constexpr int kNConst = sizeof(KConst) / sizeof(double);
 
 struct SolveParams {
     const double *u0;      // [n][B]
@@ -46,20 +59,27 @@ struct SolveParams {
     int32_t *retcode;      // [B] or null
     int32_t *n_saved;      // [B] or null
     double *partials;      // [gridDim.x][npart]
+    const KConst *kc;
     int64_t B, first, count;
     int32_t n_save;        // active save points
     int32_t P;             // tangent directions
     int32_t npart;         // L*C + kExtra: [grad | loss_sum, n_ok, n_accept, n_reject, n_traj]
     int32_t maxiters, clamp_pred, loss_kind, n_obs;
-    int32_t drow[kMaxN];   // species -> row of data / yscale, or -1 if unobserved
-    double lb, ub, inv_R, t0;
-    double atol[kMaxN], rtol[kMaxN], scale[kMaxN], inv_yscale[kMaxN];
-    double gamma, qmin, qmax, beta1, beta2, qsteady_min, qsteady_max, qoldinit, dtmin;
 };
 
 // ---------------------------------------------------------------------------
-// small dense kernels in registers
+// arithmetic helpers
 // ---------------------------------------------------------------------------
+// 1/a: hardware seed + two Newton steps (<= 1-2 ulp; no denormal / inf special cases needed here)
+__device__ __forceinline__ double frcp(double a) {
+    double x = __builtin_amdgcn_rcp(a);
+    double e = fma(-a, x, 1.0);
+    x = fma(x, e, x);
+    e = fma(-a, x, 1.0);
+    x = fma(x, e, x);
+    return x;
+}
+
 template <int NS>
 __device__ __forceinline__ bool lu_factor(double (&A)[NS][NS], double (&dinv)[NS], int (&piv)[NS]) {
     bool ok = true;
@@ -74,16 +94,21 @@ __device__ __forceinline__ bool lu_factor(double (&A)[NS][NS], double (&dinv)[NS
         }
         piv[k] = p;
         if (p != k) {  // skipped by the whole wave when no lane needs a swap
+            // value-level selects (no control flow, no addressable temporaries): keeps A in VGPRs
 #pragma unroll
-            for (int i = k + 1; i < NS; ++i)
-                if (p == i) {
+            for (int i = k + 1; i < NS; ++i) {
+                const bool sw = (p == i);
 #pragma unroll
-                    for (int c = 0; c < NS; ++c) { double t = A[k][c]; A[k][c] = A[i][c]; A[i][c] = t; }
+                for (int c = 0; c < NS; ++c) {
+                    const double ak = A[k][c], ai = A[i][c];
+                    A[k][c] = sw ? ai : ak;
+                    A[i][c] = sw ? ak : ai;
                 }
+            }
         }
         double d = A[k][k];
         ok = ok && (d != 0.0);
-        double inv = 1.0 / d;
+        double inv = frcp(d);
         dinv[k] = inv;
 #pragma unroll
         for (int i = k + 1; i < NS; ++i) A[i][k] *= inv;
@@ -105,8 +130,12 @@ __device__ __forceinline__ void lu_solve(const double (&A)[NS][NS], const double
         int p = piv[k];
         if (p != k) {
 #pragma unroll
-            for (int i = k + 1; i < NS; ++i)
-                if (p == i) { double t = b[k]; b[k] = b[i]; b[i] = t; }
+            for (int i = k + 1; i < NS; ++i) {
+                const bool sw = (p == i);
+                const double bk = b[k], bi = b[i];
+                b[k] = sw ? bi : bk;
+                b[i] = sw ? bk : bi;
+            }
         }
     }
 #pragma unroll
@@ -124,15 +153,39 @@ __device__ __forceinline__ void lu_solve(const double (&A)[NS][NS], const double
     }
 }
 
-// theta accessors (wave-uniform scalar loads)
 template <int NS, int NR, bool HAS_T>
 struct Lay {
     static constexpr int N = NS + (HAS_T ? 1 : 0);
     static constexpr int NTH = NR * (N + 1 + NS);
     static constexpr int NTHP = NTH | 1;  // odd LDS pitch
-    __device__ __forceinline__ static int wi(int c, int j) { return c + N * j; }
-    __device__ __forceinline__ static int wb(int j) { return N * NR + j; }
-    __device__ __forceinline__ static int wo(int i, int j) { return (N + 1) * NR + i + NS * j; }
+    __device__ __forceinline__ static constexpr int wi(int c, int j) { return c + N * j; }
+    __device__ __forceinline__ static constexpr int wb(int j) { return N * NR + j; }
+    __device__ __forceinline__ static constexpr int wo(int i, int j) { return (N + 1) * NR + i + NS * j; }
+};
+
+// step-record field offsets (in doubles, per group; record laid out [field][group])
+template <int NS, int NR>
+struct Rec {
+    static constexpr int X0 = 0;               // features at u_n   (two ping-pong point areas: PA then PB)
+    static constexpr int G0 = X0 + NS;
+    static constexpr int R0 = G0 + NS;
+    static constexpr int UP = R0 + NR;         // u at the point
+    static constexpr int FP = UP + NS;         // f at the point
+    static constexpr int PT = FP + NS;         // size of one point area
+    static constexpr int PB = PT;              // second point area
+    static constexpr int K1 = 2 * PT;
+    static constexpr int DK = K1 + NS;
+    static constexpr int X1 = DK + NS;
+    static constexpr int G1 = X1 + NS;
+    static constexpr int R1 = G1 + NS;
+    static constexpr int C1J = R1 + NR;
+    static constexpr int CZD = C1J + NR;
+    static constexpr int GR0 = CZD + NR;
+    static constexpr int AA = GR0 + NR;
+    static constexpr int B1 = AA + NS;
+    static constexpr int B2 = B1 + NS;
+    static constexpr int DT = B2 + NS;
+    static constexpr int NREC = DT + 1;
 };
 
 // x = log(clamp(u)), g = dx/du (0 outside the closed window, as ForwardDiff's clamp)
@@ -144,7 +197,7 @@ __device__ __forceinline__ void features(const double (&u)[NS], double lb, doubl
         bool inside = (ui >= lb) && (ui <= ub);
         double c = fmin(fmax(ui, lb), ub);
         x[i] = log(c);
-        g[i] = inside ? 1.0 / ui : 0.0;
+        g[i] = inside ? frcp(ui) : 0.0;
     }
 }
 
@@ -163,16 +216,33 @@ __device__ __forceinline__ void rates(const double *__restrict__ th, const doubl
 }
 
 template <int NS, int NR, bool HAS_T, bool USE_SCALE>
-__device__ __forceinline__ void rhs_from_rates(const double *__restrict__ th, const double (&r)[NR],
-                                               const double (&sc)[NS], double (&f)[NS]) {
+__device__ __forceinline__ void rhs_from_rates(const double *__restrict__ th, const double (&r)[NR], const double *sc_s,
+                                               double (&f)[NS]) {
     using L = Lay<NS, NR, HAS_T>;
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         double a = 0.0;
 #pragma unroll
         for (int j = 0; j < NR; ++j) a = fma(th[L::wo(i, j)], r[j], a);
-        f[i] = USE_SCALE ? a * sc[i] : a;
+        f[i] = USE_SCALE ? a * sc_s[i] : a;
     }
+}
+
+// LDS bytes (in doubles) the kernel needs; shared by host and device.
+__host__ __device__ inline int smem_doubles(int NS, int NR, int N, int C, int P, int block) {
+    const int nth = NR * (N + 1 + NS);
+    const int nthp = nth | 1;
+    const int CC = C > 0 ? C : 1;
+    const int L = C > 0 ? (P + C - 1) / C : 1;
+    const int gpw = 64 / L;
+    const int waves = block / 64;
+    const int PT = NS + NS + NR + NS + NS;
+    const int NREC = 2 * PT + 4 * NS + NR + 3 * NR + 3 * NS + 1;
+    int per_wave = C > 0 ? C * NS * 64 + NREC * gpw : 0;
+    int red = (CC + kExtra) * block;
+    int body = waves * per_wave;
+    if (body < red) body = red;
+    return kNConst + (C > 0 ? L * C * nthp : 0) + body;
 }
 
 // ---------------------------------------------------------------------------
@@ -183,10 +253,13 @@ template <int NS, int NR, bool HAS_T, bool USE_SCALE, int C, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, const double *__restrict__ theta,
                                                       const double *__restrict__ dtheta) {
     using L_ = Lay<NS, NR, HAS_T>;
+    using R_ = Rec<NS, NR>;
     constexpr int N = L_::N;
     constexpr int NTH = L_::NTH;
     constexpr int NTHP = L_::NTHP;
     constexpr int CC = (C > 0) ? C : 1;
+    constexpr int NREC = R_::NREC;
+    static_assert(NREC == 2 * (4 * NS + NR) + 4 * NS + NR + 3 * NR + 3 * NS + 1, "record layout");
     extern __shared__ __attribute__((aligned(16))) double smem[];
 
     const int tid = threadIdx.x;
@@ -195,37 +268,43 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
     constexpr int WAVES = BLOCK / 64;
     const int Lg = (C > 0) ? (prm.P + C - 1) / C : 1;  // lanes per trajectory
     const int gpw = 64 / Lg;                           // groups per wave
-    const int grp_in_wave = lane / Lg;
-    const int chunk = lane - grp_in_wave * Lg;
-    const bool lane_active = grp_in_wave < gpw;
+    const int grp = lane / Lg;
+    const int chunk = lane - grp * Lg;
+    const bool lane_active = grp < gpw;
+    const bool lead = lane_active && chunk == 0;
     const int Ppad = Lg * CC;
 
-    // ---- stage d theta / d p in LDS (zero padded to Ppad columns) ----
-    double *dth_s = smem;                              // [Ppad][NTHP]
-    double *red = smem + (C > 0 ? Ppad * NTHP : 0);    // [CC + kExtra][BLOCK]
+    // ---- LDS carve-up ----
+    double *kc_s = smem;                                        // [kNConst]
+    double *dth_s = smem + kNConst;                             // [Ppad][NTHP]
+    double *body = dth_s + (C > 0 ? Ppad * NTHP : 0);
+    const int per_wave = C > 0 ? C * NS * 64 + NREC * gpw : 0;
+    double *S_s = body + wave * per_wave + lane;                // column qc, species i at S_s[(qc*NS+i)*64]
+    double *rec = body + wave * per_wave + (C > 0 ? C * NS * 64 : 0) + (lane_active ? grp : 0);  // field f at rec[f*gpw]
+    double *red = body;                                         // [CC + kExtra][BLOCK], after the main loop
+
+    for (int idx = tid; idx < kNConst; idx += BLOCK) kc_s[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
     if (C > 0) {
         for (int idx = tid; idx < Ppad * NTHP; idx += BLOCK) {
             int k = idx / NTHP, m = idx - k * NTHP;
             dth_s[idx] = (k < prm.P && m < NTH) ? dtheta[(size_t)k * NTH + m] : 0.0;
         }
-        __syncthreads();
     }
+    __syncthreads();
+    const KConst *kc = reinterpret_cast<const KConst *>(kc_s);
 
     const int64_t ngroups = (int64_t)gridDim.x * WAVES * gpw;
-    int64_t traj = ((int64_t)blockIdx.x * WAVES + wave) * gpw + grp_in_wave;
+    int64_t traj = ((int64_t)blockIdx.x * WAVES + wave) * gpw + grp;
     if (!lane_active) traj = prm.count;
 
     const double *__restrict__ th = theta;
-    const double d_ = 0.29289321881345248;   // 1/(2+sqrt 2)
-    const double c32 = 7.4142135623730950;   // 6+sqrt 2
+    const double d_ = 0.29289321881345248;    // 1/(2+sqrt 2)
+    const double c32 = 7.4142135623730950;    // 6+sqrt 2
     const double inv12d = 2.4142135623730950; // 1/(1-2d)
     const int nsave = prm.n_save;
     const double tend = prm.tsave[nsave - 1];
-    const double dtmax = tend - prm.t0;
-
-    double sc[NS];
-#pragma unroll
-    for (int i = 0; i < NS; ++i) sc[i] = USE_SCALE ? prm.scale[i] : 1.0;
+    const double t0 = kc->t0;
+    const double dtmax = tend - t0;
 
     // lane totals
     double G[CC];
@@ -233,13 +312,12 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
     for (int q = 0; q < CC; ++q) G[q] = 0.0;
     double Lsum = 0.0, n_ok = 0.0, n_acc = 0.0, n_rej = 0.0, n_traj = 0.0;
 
-    // per-trajectory state
-    double u[NS], f0[NS], x0[NS], g0[NS], r0[NR], bT[NR];
-    double S[CC][NS];
+    // per-trajectory state carried in registers between steps
+    double u[NS], f0[NS], g0[NS], r0[NR], bT[NR];
     double gtr[CC];
     double xT = 0.0, Tconst = 0.0;
-    double t = 0.0, dt = 0.0, qold = 0.0, loss_sum = 0.0;
-    int iter = 0, jsave = 0;
+    double t = 0.0, dt = 0.0, lqold = 0.0, loss_sum = 0.0;
+    int iter = 0, jsave = 0, par = 0;
     int64_t b = 0;
     bool need_init = true;
 
@@ -252,92 +330,103 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
             for (int i = 0; i < NS; ++i) u[i] = prm.u0[(size_t)i * prm.B + b];
             if (HAS_T) {
                 Tconst = prm.u0[(size_t)NS * prm.B + b];
-                xT = prm.inv_R / Tconst;
+                xT = kc->inv_R * frcp(Tconst);
             }
 #pragma unroll
             for (int j = 0; j < NR; ++j) bT[j] = HAS_T ? fma(th[L_::wi(NS, j)], xT, th[L_::wb(j)]) : th[L_::wb(j)];
-            features<NS>(u, prm.lb, prm.ub, x0, g0);
+            double x0[NS];
+            features<NS>(u, kc->lb, kc->ub, x0, g0);
             rates<NS, NR, HAS_T>(th, x0, bT, r0);
-            rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r0, sc, f0);
+            rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r0, kc->scale, f0);
+            par = 0;
+            if (C > 0 && lead) {
+#pragma unroll
+                for (int i = 0; i < NS; ++i) { rec[(R_::X0 + i) * gpw] = x0[i]; rec[(R_::G0 + i) * gpw] = g0[i]; }
+#pragma unroll
+                for (int j = 0; j < NR; ++j) rec[(R_::R0 + j) * gpw] = r0[j];
+            }
             // Hairer initial step (OrdinaryDiffEq ode_determine_initdt, order 2)
             {
                 double d0 = 0.0, d1 = 0.0, sk[NS];
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
-                    sk[i] = 1.0 / fma(fabs(u[i]), prm.rtol[i], prm.atol[i]);
+                    sk[i] = frcp(fma(fabs(u[i]), kc->rtol[i], kc->atol[i]));
                     double a = u[i] * sk[i], c = f0[i] * sk[i];
                     d0 = fma(a, a, d0);
                     d1 = fma(c, c, d1);
                 }
-                if (HAS_T) { double a = Tconst / fma(fabs(Tconst), prm.rtol[NS], prm.atol[NS]); d0 = fma(a, a, d0); }
-                d0 = sqrt(d0 / N);
-                d1 = sqrt(d1 / N);
+                if (HAS_T) { double a = Tconst * frcp(fma(fabs(Tconst), kc->rtol[NS], kc->atol[NS])); d0 = fma(a, a, d0); }
+                d0 = sqrt(d0 * (1.0 / N));
+                d1 = sqrt(d1 * (1.0 / N));
                 double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 / d1);
                 dt0 = fmin(dt0, dtmax);
                 double u1[NS], x1[NS], g1[NS], r1[NR], f1[NS];
 #pragma unroll
                 for (int i = 0; i < NS; ++i) u1[i] = fma(dt0, f0[i], u[i]);
-                features<NS>(u1, prm.lb, prm.ub, x1, g1);
+                features<NS>(u1, kc->lb, kc->ub, x1, g1);
                 rates<NS, NR, HAS_T>(th, x1, bT, r1);
-                rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r1, sc, f1);
+                rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r1, kc->scale, f1);
                 double d2 = 0.0;
 #pragma unroll
                 for (int i = 0; i < NS; ++i) { double e = (f1[i] - f0[i]) * sk[i]; d2 = fma(e, e, d2); }
-                d2 = sqrt(d2 / N) / dt0;
+                d2 = sqrt(d2 * (1.0 / N)) / dt0;
                 double dm = fmax(d1, d2);
-                double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : pow(10.0, -(2.0 + log10(dm)) * 0.5);
-                dt = fmax(prm.dtmin, fmin(fmin(100.0 * dt0, dt1), dtmax));
+                // 10^(-(2 + log10 dm)/2) = exp(-(ln 100 + ln dm)/2)
+                double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : exp(-0.5 * (4.605170185988091368 + log(dm)));
+                dt = fmax(kc->dtmin, fmin(fmin(100.0 * dt0, dt1), dtmax));
             }
-            t = prm.t0;
-            qold = prm.qoldinit;
+            t = t0;
+            lqold = log(kc->qoldinit);
             iter = 0;
             jsave = 0;
             loss_sum = 0.0;
 #pragma unroll
-            for (int q = 0; q < CC; ++q) {
-                gtr[q] = 0.0;
+            for (int q = 0; q < CC; ++q) gtr[q] = 0.0;
+            if (C > 0) {
 #pragma unroll
-                for (int i = 0; i < NS; ++i) S[q][i] = 0.0;
+                for (int q = 0; q < C * NS; ++q) S_s[q * 64] = 0.0;
             }
             // save_start: saveat contains tspan[1]  (case2: tsteps[1] = 0)
-            if (prm.tsave[0] == prm.t0) {
+            if (prm.tsave[0] == t0) {
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
                     double v = u[i];
-                    if (prm.clamp_pred) v = fmin(fmax(v, -prm.ub), prm.ub);
+                    if (prm.clamp_pred) v = fmin(fmax(v, -kc->ub), kc->ub);
                     if (prm.pred && chunk == 0) prm.pred[((size_t)0 * N + i) * prm.B + b] = v;
-                    int dr = prm.drow[i];
+                    int dr = (int)kc->drow[i];
                     if (dr >= 0) {
-                        double rr = (prm.data[((size_t)0 * prm.n_obs + dr) * prm.B + b] - v) * prm.inv_yscale[i];
+                        double rr = (prm.data[((size_t)0 * prm.n_obs + dr) * prm.B + b] - v) * kc->inv_yscale[i];
                         loss_sum += (prm.loss_kind == 0) ? fabs(rr) : rr * rr;
                     }
                 }
                 if (HAS_T && prm.pred && chunk == 0) {
                     double v = Tconst;
-                    if (prm.clamp_pred) v = fmin(fmax(v, -prm.ub), prm.ub);
+                    if (prm.clamp_pred) v = fmin(fmax(v, -kc->ub), kc->ub);
                     prm.pred[((size_t)0 * N + NS) * prm.B + b] = v;
                 }
                 jsave = 1;
             }
         }
 
-        // ------------------------------------------------------------------
-        // one Rosenbrock23 attempt
-        // ------------------------------------------------------------------
+        // ==================================================================
+        // PRIMAL phase: one Rosenbrock23 attempt
+        // ==================================================================
         int rc = -1;  // -1: keep going; >= 0: trajectory finished with this retcode
         ++iter;
         bool last = false;
         if (iter > prm.maxiters) rc = 1;
         if (t + dt * (1.0 + 1e-13) >= tend) { dt = tend - t; last = true; }
-        if (rc < 0 && (!(dt > prm.dtmin) || t + dt == t)) rc = 2;
+        if (rc < 0 && (!(dt > kc->dtmin) || t + dt == t)) rc = 2;
 
         bool accept = false;
-        double q = 1.0, q11 = 0.0, EEst = 0.0;
-        double k1[NS], dk[NS], unew[NS], f2[NS], x1[NS], g1[NS], r1[NR], x2[NS], g2[NS], r2[NR];
+        double q = 1.0, lq11 = 0.0, lEE = 0.0;
+        bool ee_zero = false;
         double LU[NS][NS], dinv[NS];
         int piv[NS];
         const double gam = d_ * dt;
+        const int pcur = par ? R_::PB : 0, pnxt = par ? 0 : R_::PB;
         if (rc < 0) {
+            double k1[NS], dk[NS], unew[NS], f2[NS];
             // W = I - gam*J,  J[i][c] = sc_i g_c sum_j w_out[i,j] r_j w_in[c,j]
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
@@ -345,7 +434,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
 #pragma unroll
                 for (int j = 0; j < NR; ++j) {
                     a[j] = th[L_::wo(i, j)] * r0[j];
-                    if (USE_SCALE) a[j] *= sc[i];
+                    if (USE_SCALE) a[j] *= kc->scale[i];
                 }
 #pragma unroll
                 for (int c = 0; c < NS; ++c) {
@@ -360,21 +449,45 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
 #pragma unroll
             for (int i = 0; i < NS; ++i) k1[i] = f0[i];
             lu_solve<NS>(LU, dinv, piv, k1);
-            double u1[NS], f1[NS];
+            double f1[NS];
+            {
+                double u1[NS], x1[NS], g1[NS], r1[NR];
 #pragma unroll
-            for (int i = 0; i < NS; ++i) u1[i] = fma(0.5 * dt, k1[i], u[i]);
-            features<NS>(u1, prm.lb, prm.ub, x1, g1);
-            rates<NS, NR, HAS_T>(th, x1, bT, r1);
-            rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r1, sc, f1);
+                for (int i = 0; i < NS; ++i) u1[i] = fma(0.5 * dt, k1[i], u[i]);
+                features<NS>(u1, kc->lb, kc->ub, x1, g1);
+                rates<NS, NR, HAS_T>(th, x1, bT, r1);
+                rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r1, kc->scale, f1);
+                if (C > 0 && lead) {
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) { rec[(R_::X1 + i) * gpw] = x1[i]; rec[(R_::G1 + i) * gpw] = g1[i]; }
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) rec[(R_::R1 + j) * gpw] = r1[j];
+                }
+            }
             // stage 2
 #pragma unroll
             for (int i = 0; i < NS; ++i) dk[i] = f1[i] - k1[i];
             lu_solve<NS>(LU, dinv, piv, dk);
 #pragma unroll
             for (int i = 0; i < NS; ++i) unew[i] = fma(dt, k1[i] + dk[i], u[i]);
-            features<NS>(unew, prm.lb, prm.ub, x2, g2);
-            rates<NS, NR, HAS_T>(th, x2, bT, r2);
-            rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r2, sc, f2);
+            double g2[NS], r2[NR];
+            {
+                double x2[NS];
+                features<NS>(unew, kc->lb, kc->ub, x2, g2);
+                rates<NS, NR, HAS_T>(th, x2, bT, r2);
+                rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r2, kc->scale, f2);
+                if (C > 0 && lead) {  // next point area (becomes point 0 when the step is accepted)
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        rec[(pnxt + R_::X0 + i) * gpw] = x2[i];
+                        rec[(pnxt + R_::G0 + i) * gpw] = g2[i];
+                        rec[(pnxt + R_::UP + i) * gpw] = unew[i];
+                        rec[(pnxt + R_::FP + i) * gpw] = f2[i];
+                    }
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) rec[(pnxt + R_::R0 + j) * gpw] = r2[j];
+                }
+            }
             // stage 3 + error estimate
             double k3[NS];
 #pragma unroll
@@ -390,193 +503,237 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                 double k2i = k1[i] + dk[i];
                 double ev = dt * (1.0 / 6.0) * (k1[i] - 2.0 * k2i + k3[i]);
                 double m = fmax(fabs(u[i]), fabs(unew[i]));
-                double e = ev / fma(prm.rtol[i], m, prm.atol[i]);
+                double e = ev * frcp(fma(kc->rtol[i], m, kc->atol[i]));
                 es = fma(e, e, es);
                 finite = finite && isfinite(unew[i]) && isfinite(ev);
             }
-            EEst = sqrt(es / N);  // the constant T state contributes a zero residual
+            es = es * (1.0 / N);  // EEst^2; the constant T state contributes a zero residual
             if (!finite) rc = 3;
             else {
-                // PI controller (OrdinaryDiffEq PIController defaults)
-                if (EEst == 0.0) q = 1.0 / prm.qmax;
-                else {
-                    q11 = pow(EEst, prm.beta1);
-                    q = q11 / pow(qold, prm.beta2);
-                    q = fmax(1.0 / prm.qmax, fmin(1.0 / prm.qmin, q / prm.gamma));
+                // PI controller (OrdinaryDiffEq PIController), in log space:
+                //   q = EEst^beta1 / qold^beta2 / gamma, clipped to [1/qmax, 1/qmin]
+                ee_zero = (es == 0.0);
+                lEE = 0.5 * log(ee_zero ? 1.0 : es);
+                lq11 = kc->beta1 * lEE;
+                q = ee_zero ? 1.0 / kc->qmax
+                            : fmax(1.0 / kc->qmax, fmin(1.0 / kc->qmin, exp(lq11 - kc->beta2 * lqold) / kc->gamma));
+                accept = (es <= 1.0);
+            }
+
+            if (rc < 0 && accept) {
+                const double tnew = last ? tend : t + dt;
+                // ---- saveat points inside (t, tnew]: dense output
+                //      u(t + Th dt) = u + dt (c1 k1 + c2 k2),
+                //      c1 = Th (1-Th)/(1-2d),  c2 = Th (Th-2d)/(1-2d)
+                // loss-gradient seeds folded into three vectors:
+                //      g_k += A.s_k + B1.k1'_k + B2.k2'_k
+                double A_[NS], B1[NS], B2[NS];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) { A_[i] = 0.0; B1[i] = 0.0; B2[i] = 0.0; }
+                while (jsave < nsave) {
+                    const double ts = prm.tsave[jsave];
+                    if (!(ts <= tnew)) break;
+                    const bool at_end = (ts == tnew);
+                    const double Th = at_end ? 1.0 : (ts - t) / dt;
+                    const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
+                    const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d_) * inv12d;
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        double k2i = k1[i] + dk[i];
+                        double v = at_end ? unew[i] : fma(dt, fma(c1, k1[i], c2 * k2i), u[i]);
+                        double mask = 1.0;
+                        if (prm.clamp_pred) {
+                            mask = (v > kc->ub || v < -kc->ub) ? 0.0 : 1.0;
+                            v = fmin(fmax(v, -kc->ub), kc->ub);
+                        }
+                        if (prm.pred && chunk == 0) prm.pred[((size_t)jsave * N + i) * prm.B + b] = v;
+                        int dr = (int)kc->drow[i];
+                        if (dr >= 0) {
+                            double iy = kc->inv_yscale[i];
+                            double rr = (prm.data[((size_t)jsave * prm.n_obs + dr) * prm.B + b] - v) * iy;
+                            double w;
+                            if (prm.loss_kind == 0) { loss_sum += fabs(rr); w = signbit(rr) ? 1.0 : -1.0; }
+                            else { loss_sum = fma(rr, rr, loss_sum); w = -2.0 * rr; }
+                            w *= mask * iy;
+                            A_[i] += w;
+                            B1[i] = fma(w, dt * c1, B1[i]);
+                            B2[i] = fma(w, dt * c2, B2[i]);
+                        }
+                    }
+                    if (HAS_T && prm.pred && chunk == 0) {
+                        double v = Tconst;
+                        if (prm.clamp_pred) v = fmin(fmax(v, -kc->ub), kc->ub);
+                        prm.pred[((size_t)jsave * N + NS) * prm.B + b] = v;
+                    }
+                    ++jsave;
                 }
-                accept = (EEst <= 1.0);
+                if (C > 0) {
+                    // publish the step record for the tangent phase
+                    double c1j[NR], czd[NR];
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        double z1 = 0.0, zd = 0.0;
+#pragma unroll
+                        for (int c = 0; c < NS; ++c) {
+                            double wg = th[L_::wi(c, j)] * g0[c];
+                            z1 = fma(wg, k1[c], z1);
+                            zd = fma(wg, dk[c], zd);
+                        }
+                        c1j[j] = fma(gam, z1, 1.0);  // 1 + gam * z_j(k1)
+                        czd[j] = gam * zd;           // gam * z_j(k2-k1)
+                    }
+                    if (lead) {
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) {
+                            rec[(R_::K1 + i) * gpw] = k1[i];
+                            rec[(R_::DK + i) * gpw] = dk[i];
+                            rec[(R_::AA + i) * gpw] = A_[i];
+                            rec[(R_::B1 + i) * gpw] = B1[i];
+                            rec[(R_::B2 + i) * gpw] = B2[i];
+                        }
+#pragma unroll
+                        for (int j = 0; j < NR; ++j) {
+                            rec[(R_::C1J + j) * gpw] = c1j[j];
+                            rec[(R_::CZD + j) * gpw] = czd[j];
+                            rec[(R_::GR0 + j) * gpw] = gam * r0[j];
+                        }
+                        rec[R_::DT * gpw] = dt;
+                    }
+                }
+                if (C == 0) {  // primal-only variant: the FSAL point stays in registers
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) { u[i] = unew[i]; f0[i] = f2[i]; g0[i] = g2[i]; }
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) r0[j] = r2[j];
+                }
+                t = tnew;
             }
         }
+        __builtin_amdgcn_wave_barrier();
 
         if (rc < 0 && accept) {
             n_acc += 1.0;
-            if (q >= prm.qsteady_min && q <= prm.qsteady_max) q = 1.0;
-            qold = fmax(EEst, prm.qoldinit);
-            const double tnew = last ? tend : t + dt;
-            // ---- saveat points inside (t, tnew]: dense output
-            //      u(t + Th dt) = u + dt (c1 k1 + c2 k2),
-            //      c1 = Th (1-Th)/(1-2d),  c2 = Th (Th-2d)/(1-2d)
-            // The loss-gradient seeds are folded into three vectors so that the
-            // tangent phase needs one dot product per column:
-            //      g_k += A.s_k + B1.k1'_k + B2.k2'_k
-            double A_[NS], B1[NS], B2[NS];
-#pragma unroll
-            for (int i = 0; i < NS; ++i) { A_[i] = 0.0; B1[i] = 0.0; B2[i] = 0.0; }
-            while (jsave < nsave) {
-                const double ts = prm.tsave[jsave];
-                if (!(ts <= tnew)) break;
-                const bool at_end = (ts == tnew);
-                const double Th = at_end ? 1.0 : (ts - t) / dt;
-                const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
-                const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d_) * inv12d;
-#pragma unroll
-                for (int i = 0; i < NS; ++i) {
-                    double k2i = k1[i] + dk[i];
-                    double v = at_end ? unew[i] : fma(dt, fma(c1, k1[i], c2 * k2i), u[i]);
-                    double mask = 1.0;
-                    if (prm.clamp_pred) {
-                        mask = (v > prm.ub || v < -prm.ub) ? 0.0 : 1.0;
-                        v = fmin(fmax(v, -prm.ub), prm.ub);
-                    }
-                    if (prm.pred && chunk == 0) prm.pred[((size_t)jsave * N + i) * prm.B + b] = v;
-                    int dr = prm.drow[i];
-                    if (dr >= 0) {
-                        double iy = prm.inv_yscale[i];
-                        double rr = (prm.data[((size_t)jsave * prm.n_obs + dr) * prm.B + b] - v) * iy;
-                        double w;
-                        if (prm.loss_kind == 0) { loss_sum += fabs(rr); w = signbit(rr) ? 1.0 : -1.0; }
-                        else { loss_sum = fma(rr, rr, loss_sum); w = -2.0 * rr; }
-                        w *= mask * iy;
-                        A_[i] += w;
-                        B1[i] = fma(w, dt * c1, B1[i]);
-                        B2[i] = fma(w, dt * c2, B2[i]);
-                    }
-                }
-                if (HAS_T && prm.pred && chunk == 0) {
-                    double v = Tconst;
-                    if (prm.clamp_pred) v = fmin(fmax(v, -prm.ub), prm.ub);
-                    prm.pred[((size_t)jsave * N + NS) * prm.B + b] = v;
-                }
-                ++jsave;
-            }
-
-            // ---- forward tangents of the accepted step, C columns per lane ----
+            // ==============================================================
+            // TANGENT phase: forward tangents of the accepted step, C columns per lane.
+            // Operands stream from the group's step record; only LU/dinv/piv stay in registers.
+            // ==============================================================
             if (C > 0) {
-                // wave-uniform-per-group helpers
-                double gv1[NS], gvd[NS], c1j[NR], czd[NR], gr0[NR];
-#pragma unroll
-                for (int c = 0; c < NS; ++c) { gv1[c] = g0[c] * k1[c]; gvd[c] = g0[c] * dk[c]; }
-#pragma unroll
-                for (int j = 0; j < NR; ++j) {
-                    double z1 = 0.0, zd = 0.0;
-#pragma unroll
-                    for (int c = 0; c < NS; ++c) {
-                        z1 = fma(th[L_::wi(c, j)], gv1[c], z1);
-                        zd = fma(th[L_::wi(c, j)], gvd[c], zd);
-                    }
-                    c1j[j] = fma(gam, z1, 1.0);  // 1 + gam * z_j(k1)
-                    czd[j] = gam * zd;           // gam * z_j(k2-k1)
-                    gr0[j] = gam * r0[j];
-                }
-#pragma unroll
+                const double hdt = 0.5 * dt;
+                const double dtl = dt;
+#pragma unroll 1
                 for (int qc = 0; qc < C; ++qc) {
                     const double *dcol = dth_s + (chunk * C + qc) * NTHP;
-                    double(&s)[NS] = S[qc];
-                    // e_j = dw_in[:,j].x + dw_b[j] + w_in[:,j].(g.s)   at u_n
-                    double gs[NS];
+                    double s[NS], gs[NS], hs[NS];
 #pragma unroll
-                    for (int c = 0; c < NS; ++c) gs[c] = g0[c] * s[c];
-                    double rhs1[NS], w2[NS];
-#pragma unroll
-                    for (int i = 0; i < NS; ++i) { rhs1[i] = 0.0; w2[i] = 0.0; }
+                    for (int c = 0; c < NS; ++c) {
+                        s[c] = S_s[(qc * NS + c) * 64];
+                        double g = rec[(pcur + R_::G0 + c) * gpw];
+                        gs[c] = g * s[c];
+                        hs[c] = -g * gs[c];  // g' = -g^2 s inside the window (g = 1/u), 0 outside
+                    }
+                    // pass 1 over w_in entries: e0_j, z'_j(k1), z'_j(dk), theta-direct part of e1_j
+                    double e0[NR], e1d[NR], zp1[NR], zpd[NR];
 #pragma unroll
                     for (int j = 0; j < NR; ++j) {
                         double e = dcol[L_::wb(j)];
                         if (HAS_T) e = fma(dcol[L_::wi(NS, j)], xT, e);
-                        double zp1 = 0.0, zpd = 0.0;  // z'_j(k1), z'_j(dk)
+                        double a0 = e, a1 = e, z1 = 0.0, zd = 0.0;
 #pragma unroll
                         for (int c = 0; c < NS; ++c) {
                             double dwi = dcol[L_::wi(c, j)];
                             double wi = th[L_::wi(c, j)];
-                            e = fma(dwi, x0[c], e);
-                            e = fma(wi, gs[c], e);
-                            // g' = -g^2 s  inside the window (g = 1/u), 0 outside
-                            double hs = -g0[c] * gs[c];
-                            zp1 = fma(dwi, gv1[c], zp1);
-                            zp1 = fma(wi, hs * k1[c], zp1);
-                            zpd = fma(dwi, gvd[c], zpd);
-                            zpd = fma(wi, hs * dk[c], zpd);
+                            a0 = fma(dwi, rec[(pcur + R_::X0 + c) * gpw], a0);
+                            a0 = fma(wi, gs[c], a0);
+                            a1 = fma(dwi, rec[(R_::X1 + c) * gpw], a1);
+                            double m = fma(dwi, rec[(pcur + R_::G0 + c) * gpw], wi * hs[c]);
+                            z1 = fma(m, rec[(R_::K1 + c) * gpw], z1);
+                            zd = fma(m, rec[(R_::DK + c) * gpw], zd);
                         }
-                        double y1 = gr0[j] * zp1, yd = gr0[j] * zpd;
+                        e0[j] = a0; e1d[j] = a1; zp1[j] = z1; zpd[j] = zd;
+                    }
+                    // pass 2 over w_out entries
+                    double rhs1[NS], w2[NS], f1d[NS];
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) { rhs1[i] = 0.0; w2[i] = 0.0; f1d[i] = 0.0; }
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        const double r0j = rec[(pcur + R_::R0 + j) * gpw], r1j = rec[(R_::R1 + j) * gpw];
+                        const double gr = rec[(R_::GR0 + j) * gpw];
+                        const double c1 = rec[(R_::C1J + j) * gpw], cz = rec[(R_::CZD + j) * gpw];
+                        const double y1 = gr * zp1[j], yd = gr * zpd[j];
 #pragma unroll
                         for (int i = 0; i < NS; ++i) {
                             double wo = th[L_::wo(i, j)];
-                            double H = fma(wo, e, dcol[L_::wo(i, j)]) * r0[j];
-                            rhs1[i] = fma(H, c1j[j], rhs1[i]);
+                            double dwo = dcol[L_::wo(i, j)];
+                            double H = fma(wo, e0[j], dwo) * r0j;
+                            rhs1[i] = fma(H, c1, rhs1[i]);
                             rhs1[i] = fma(wo, y1, rhs1[i]);
-                            w2[i] = fma(H, czd[j], w2[i]);
+                            w2[i] = fma(H, cz, w2[i]);
                             w2[i] = fma(wo, yd, w2[i]);
+                            f1d[i] = fma(dwo, r1j, f1d[i]);
                         }
                     }
                     if (USE_SCALE) {
 #pragma unroll
-                        for (int i = 0; i < NS; ++i) { rhs1[i] *= sc[i]; w2[i] *= sc[i]; }
+                        for (int i = 0; i < NS; ++i) { double sc = kc->scale[i]; rhs1[i] *= sc; w2[i] *= sc; }
                     }
                     // W k1' = f0' + gam (J' k1)
                     lu_solve<NS>(LU, dinv, piv, rhs1);  // rhs1 now holds k1'
                     // f1' at u1 with s1 = s + dt/2 k1'
                     double gs1[NS];
 #pragma unroll
-                    for (int c = 0; c < NS; ++c) gs1[c] = g1[c] * fma(0.5 * dt, rhs1[c], s[c]);
-                    double f1p[NS];
-#pragma unroll
-                    for (int i = 0; i < NS; ++i) f1p[i] = 0.0;
-#pragma unroll
-                    for (int j = 0; j < NR; ++j) {
-                        double e = dcol[L_::wb(j)];
-                        if (HAS_T) e = fma(dcol[L_::wi(NS, j)], xT, e);
-#pragma unroll
-                        for (int c = 0; c < NS; ++c) {
-                            e = fma(dcol[L_::wi(c, j)], x1[c], e);
-                            e = fma(th[L_::wi(c, j)], gs1[c], e);
-                        }
-                        double er = e * r1[j];
-#pragma unroll
-                        for (int i = 0; i < NS; ++i) {
-                            f1p[i] = fma(dcol[L_::wo(i, j)], r1[j], f1p[i]);
-                            f1p[i] = fma(th[L_::wo(i, j)], er, f1p[i]);
-                        }
-                    }
-                    // W (k2-k1)' = f1' - k1' + gam J'(k2-k1)
+                    for (int c = 0; c < NS; ++c) gs1[c] = rec[(R_::G1 + c) * gpw] * fma(hdt, rhs1[c], s[c]);
                     double rhs2[NS];
 #pragma unroll
-                    for (int i = 0; i < NS; ++i) rhs2[i] = (USE_SCALE ? f1p[i] * sc[i] : f1p[i]) - rhs1[i] + w2[i];
+                    for (int i = 0; i < NS; ++i) rhs2[i] = f1d[i];
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        double e = e1d[j];
+#pragma unroll
+                        for (int c = 0; c < NS; ++c) e = fma(th[L_::wi(c, j)], gs1[c], e);
+                        double er = e * rec[(R_::R1 + j) * gpw];
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) rhs2[i] = fma(th[L_::wo(i, j)], er, rhs2[i]);
+                    }
+                    // W (k2-k1)' = f1' - k1' + gam J'(k2-k1)
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) rhs2[i] = (USE_SCALE ? rhs2[i] * kc->scale[i] : rhs2[i]) - rhs1[i] + w2[i];
                     lu_solve<NS>(LU, dinv, piv, rhs2);
                     double acc = 0.0;
 #pragma unroll
                     for (int i = 0; i < NS; ++i) {
                         double k2p = rhs1[i] + rhs2[i];
-                        acc = fma(A_[i], s[i], acc);
-                        acc = fma(B1[i], rhs1[i], acc);
-                        acc = fma(B2[i], k2p, acc);
-                        s[i] = fma(dt, k2p, s[i]);
+                        acc = fma(rec[(R_::AA + i) * gpw], s[i], acc);
+                        acc = fma(rec[(R_::B1 + i) * gpw], rhs1[i], acc);
+                        acc = fma(rec[(R_::B2 + i) * gpw], k2p, acc);
+                        S_s[(qc * NS + i) * 64] = fma(dtl, k2p, s[i]);
                     }
                     gtr[qc] += acc;
                 }
             }
-
-            // ---- advance (FSAL: f2 and its features become f0) ----
+            // ---- advance: reload the FSAL point from the record (it was parked there) ----
+            par ^= 1;
+            if (C > 0) {
+                const int pn = par ? R_::PB : 0;
 #pragma unroll
-            for (int i = 0; i < NS; ++i) { u[i] = unew[i]; f0[i] = f2[i]; x0[i] = x2[i]; g0[i] = g2[i]; }
+                for (int i = 0; i < NS; ++i) {
+                    u[i] = rec[(pn + R_::UP + i) * gpw];
+                    f0[i] = rec[(pn + R_::FP + i) * gpw];
+                    g0[i] = rec[(pn + R_::G0 + i) * gpw];
+                }
 #pragma unroll
-            for (int j = 0; j < NR; ++j) r0[j] = r2[j];
-            t = tnew;
+                for (int j = 0; j < NR; ++j) r0[j] = rec[(pn + R_::R0 + j) * gpw];
+            }
+            // step_accept_controller
+            if (q >= kc->qsteady_min && q <= kc->qsteady_max) q = 1.0;
+            lqold = ee_zero ? log(kc->qoldinit) : fmax(lEE, log(kc->qoldinit));
             dt = fmin(dt / q, dtmax);
             if (jsave >= nsave) rc = 0;
         } else if (rc < 0) {
             n_rej += 1.0;
-            dt = dt / fmin(1.0 / prm.qmin, q11 / prm.gamma);
+            dt = dt / fmin(1.0 / kc->qmin, exp(lq11) / kc->gamma);
         }
+        __builtin_amdgcn_wave_barrier();
 
         if (rc >= 0) {
             // mae/mse over the saved prefix (rober_crnn.jl:141 data[:, 1:size(pred)[2]])
@@ -602,7 +759,6 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
     __syncthreads();
 #pragma unroll
     for (int q_ = 0; q_ < CC; ++q_) red[q_ * BLOCK + tid] = lane_active ? G[q_] : 0.0;
-    const bool lead = lane_active && chunk == 0;
     red[(CC + 0) * BLOCK + tid] = lead ? Lsum : 0.0;
     red[(CC + 1) * BLOCK + tid] = lead ? n_ok : 0.0;
     red[(CC + 2) * BLOCK + tid] = lead ? n_acc : 0.0;
