@@ -80,9 +80,34 @@ __device__ __forceinline__ double frcp(double a) {
     return x;
 }
 
+// log(x) for finite x > 0: fdlibm e_log.c scheme (< 1 ulp), ~35 instructions instead of
+// ocml's ~100-instruction double-double evaluation.  x is always a clamped concentration
+// (lb <= x <= ub) or a positive error norm here, so no zero / negative / inf / nan handling.
+__device__ __forceinline__ double flog(double x) {
+    double m = __builtin_amdgcn_frexp_mant(x);      // [0.5, 1)
+    int k = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;                             // [sqrt(1/2), sqrt 2)
+    k = lo ? k - 1 : k;
+    const double f = m - 1.0;
+    const double r = frcp(2.0 + f);
+    double s = f * r;
+    s = fma(fma(-(2.0 + f), s, f), r, s);           // one correction: s = f/(2+f) to < 1 ulp
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                     2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    return fma(dk, 6.93147180369123816490e-01, -((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f));
+}
+
 template <int NS>
-__device__ __forceinline__ bool lu_factor(double (&A)[NS][NS], double (&dinv)[NS], int (&piv)[NS]) {
+__device__ __forceinline__ bool lu_factor(double (&A)[NS][NS], double (&dinv)[NS], int (&piv)[NS], bool &anyp) {
     bool ok = true;
+    anyp = false;
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         int p = k;
@@ -93,6 +118,7 @@ __device__ __forceinline__ bool lu_factor(double (&A)[NS][NS], double (&dinv)[NS
             if (v > best) { best = v; p = i; }
         }
         piv[k] = p;
+        anyp = anyp || (p != k);
         if (p != k) {  // skipped by the whole wave when no lane needs a swap
             // value-level selects (no control flow, no addressable temporaries): keeps A in VGPRs
 #pragma unroll
@@ -124,11 +150,13 @@ __device__ __forceinline__ bool lu_factor(double (&A)[NS][NS], double (&dinv)[NS
 
 template <int NS>
 __device__ __forceinline__ void lu_solve(const double (&A)[NS][NS], const double (&dinv)[NS], const int (&piv)[NS],
-                                         double (&b)[NS]) {
+                                         const bool wave_pivots, double (&b)[NS]) {
+    // Row interchanges are rare for W = I - gam*J; the whole block is skipped by a scalar branch
+    // unless some lane of the wavefront pivoted in this step (wave_pivots is wave-uniform).
+    if (wave_pivots) {
 #pragma unroll
-    for (int k = 0; k < NS; ++k) {
-        int p = piv[k];
-        if (p != k) {
+        for (int k = 0; k < NS; ++k) {
+            const int p = piv[k];
 #pragma unroll
             for (int i = k + 1; i < NS; ++i) {
                 const bool sw = (p == i);
@@ -196,7 +224,7 @@ __device__ __forceinline__ void features(const double (&u)[NS], double lb, doubl
         double ui = u[i];
         bool inside = (ui >= lb) && (ui <= ub);
         double c = fmin(fmax(ui, lb), ub);
-        x[i] = log(c);
+        x[i] = flog(c);
         g[i] = inside ? frcp(ui) : 0.0;
     }
 }
@@ -305,6 +333,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
     const double tend = prm.tsave[nsave - 1];
     const double t0 = kc->t0;
     const double dtmax = tend - t0;
+    const double lqinit = flog(kc->qoldinit);
 
     // lane totals
     double G[CC];
@@ -372,11 +401,11 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                 d2 = sqrt(d2 * (1.0 / N)) / dt0;
                 double dm = fmax(d1, d2);
                 // 10^(-(2 + log10 dm)/2) = exp(-(ln 100 + ln dm)/2)
-                double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : exp(-0.5 * (4.605170185988091368 + log(dm)));
+                double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : exp(-0.5 * (4.605170185988091368 + flog(dm)));
                 dt = fmax(kc->dtmin, fmin(fmin(100.0 * dt0, dt1), dtmax));
             }
             t = t0;
-            lqold = log(kc->qoldinit);
+            lqold = lqinit;
             iter = 0;
             jsave = 0;
             loss_sum = 0.0;
@@ -423,6 +452,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
         bool ee_zero = false;
         double LU[NS][NS], dinv[NS];
         int piv[NS];
+        bool wave_pivots = false;
         const double gam = d_ * dt;
         const int pcur = par ? R_::PB : 0, pnxt = par ? 0 : R_::PB;
         if (rc < 0) {
@@ -444,11 +474,13 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                     LU[i][c] = ((i == c) ? 1.0 : 0.0) - gam * (s_ * g0[c]);
                 }
             }
-            bool okf = lu_factor<NS>(LU, dinv, piv);
+            bool anyp;
+            bool okf = lu_factor<NS>(LU, dinv, piv, anyp);
+            wave_pivots = __builtin_amdgcn_ballot_w64(anyp) != 0;
             // stage 1
 #pragma unroll
             for (int i = 0; i < NS; ++i) k1[i] = f0[i];
-            lu_solve<NS>(LU, dinv, piv, k1);
+            lu_solve<NS>(LU, dinv, piv, wave_pivots, k1);
             double f1[NS];
             {
                 double u1[NS], x1[NS], g1[NS], r1[NR];
@@ -467,7 +499,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
             // stage 2
 #pragma unroll
             for (int i = 0; i < NS; ++i) dk[i] = f1[i] - k1[i];
-            lu_solve<NS>(LU, dinv, piv, dk);
+            lu_solve<NS>(LU, dinv, piv, wave_pivots, dk);
 #pragma unroll
             for (int i = 0; i < NS; ++i) unew[i] = fma(dt, k1[i] + dk[i], u[i]);
             double g2[NS], r2[NR];
@@ -495,7 +527,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                 double k2i = k1[i] + dk[i];
                 k3[i] = f2[i] - c32 * (k2i - f1[i]) - 2.0 * (k1[i] - f0[i]);
             }
-            lu_solve<NS>(LU, dinv, piv, k3);
+            lu_solve<NS>(LU, dinv, piv, wave_pivots, k3);
             double es = 0.0;
             bool finite = okf;
 #pragma unroll
@@ -513,7 +545,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                 // PI controller (OrdinaryDiffEq PIController), in log space:
                 //   q = EEst^beta1 / qold^beta2 / gamma, clipped to [1/qmax, 1/qmin]
                 ee_zero = (es == 0.0);
-                lEE = 0.5 * log(ee_zero ? 1.0 : es);
+                lEE = 0.5 * flog(ee_zero ? 1.0 : es);
                 lq11 = kc->beta1 * lEE;
                 q = ee_zero ? 1.0 / kc->qmax
                             : fmax(1.0 / kc->qmax, fmin(1.0 / kc->qmin, exp(lq11 - kc->beta2 * lqold) / kc->gamma));
@@ -678,7 +710,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                         for (int i = 0; i < NS; ++i) { double sc = kc->scale[i]; rhs1[i] *= sc; w2[i] *= sc; }
                     }
                     // W k1' = f0' + gam (J' k1)
-                    lu_solve<NS>(LU, dinv, piv, rhs1);  // rhs1 now holds k1'
+                    lu_solve<NS>(LU, dinv, piv, wave_pivots, rhs1);  // rhs1 now holds k1'
                     // f1' at u1 with s1 = s + dt/2 k1'
                     double gs1[NS];
 #pragma unroll
@@ -698,7 +730,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                     // W (k2-k1)' = f1' - k1' + gam J'(k2-k1)
 #pragma unroll
                     for (int i = 0; i < NS; ++i) rhs2[i] = (USE_SCALE ? rhs2[i] * kc->scale[i] : rhs2[i]) - rhs1[i] + w2[i];
-                    lu_solve<NS>(LU, dinv, piv, rhs2);
+                    lu_solve<NS>(LU, dinv, piv, wave_pivots, rhs2);
                     double acc = 0.0;
 #pragma unroll
                     for (int i = 0; i < NS; ++i) {
@@ -726,7 +758,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
             }
             // step_accept_controller
             if (q >= kc->qsteady_min && q <= kc->qsteady_max) q = 1.0;
-            lqold = ee_zero ? log(kc->qoldinit) : fmax(lEE, log(kc->qoldinit));
+            lqold = ee_zero ? lqinit : fmax(lEE, lqinit);
             dt = fmin(dt / q, dtmax);
             if (jsave >= nsave) rc = 0;
         } else if (rc < 0) {
