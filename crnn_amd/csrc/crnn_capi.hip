@@ -38,21 +38,23 @@ int32_t fail(Ctx *ctx, const std::string &msg);
 using KernelFn = void (*)(const crnn::SolveParams, const double *, const double *);
 
 struct KernelEntry {
-    int ns, nr, has_t, use_scale, C;
+    int ns, nr, has_t, use_scale, C, L;
     KernelFn fn;
 };
 
 constexpr int kBlock = 256;
 
-#define KENT(NS, NR, HT, SC, C) \
-    { NS, NR, HT, SC, C, (KernelFn)crnn::ros23_kernel<NS, NR, (HT) != 0, (SC) != 0, C, kBlock> }
+#define KENT(NS, NR, HT, SC, C, L) \
+    { NS, NR, HT, SC, C, L, (KernelFn)crnn::ros23_kernel<NS, NR, (HT) != 0, (SC) != 0, C, L, kBlock> }
 
 // Instantiated shapes: case2 (6 species + T, 3 reactions), robertson (3, 6,
-// dydt_scale), case1 (5, 4).  C = tangent columns per lane.
+// dydt_scale), case1 (5, 4).  C = tangent columns per lane, L = lanes per
+// trajectory (L*C >= number of directions; 64/L trajectories per wavefront).
 const KernelEntry kKernels[] = {
-    KENT(6, 3, 1, 0, 0), KENT(6, 3, 1, 0, 1), KENT(6, 3, 1, 0, 3), KENT(6, 3, 1, 0, 5), KENT(6, 3, 1, 0, 7),
-    KENT(3, 6, 0, 1, 0), KENT(3, 6, 0, 1, 1), KENT(3, 6, 0, 1, 4), KENT(3, 6, 0, 1, 6), KENT(3, 6, 0, 1, 11),
-    KENT(5, 4, 0, 0, 0), KENT(5, 4, 0, 0, 1), KENT(5, 4, 0, 0, 4), KENT(5, 4, 0, 0, 6),
+    KENT(6, 3, 1, 0, 0, 1), KENT(6, 3, 1, 0, 1, 25), KENT(6, 3, 1, 0, 3, 9), KENT(6, 3, 1, 0, 4, 7),
+    KENT(6, 3, 1, 0, 5, 5), KENT(6, 3, 1, 0, 7, 4), KENT(6, 3, 1, 0, 7, 6),
+    KENT(3, 6, 0, 1, 0, 1), KENT(3, 6, 0, 1, 1, 43), KENT(3, 6, 0, 1, 4, 11), KENT(3, 6, 0, 1, 6, 8), KENT(3, 6, 0, 1, 11, 4),
+    KENT(5, 4, 0, 0, 0, 1), KENT(5, 4, 0, 0, 1, 24), KENT(5, 4, 0, 0, 4, 6), KENT(5, 4, 0, 0, 6, 4), KENT(5, 4, 0, 0, 8, 6),
 };
 
 struct Ctx {
@@ -77,8 +79,10 @@ struct Ctx {
     std::vector<double> tsave;
     // per-call device outputs
     double *d_pred = nullptr, *d_loss = nullptr;
-    int32_t *d_ret = nullptr, *d_nsaved = nullptr;
+    int32_t *d_ret = nullptr, *d_nsaved = nullptr, *d_nacc = nullptr, *d_nrej = nullptr;
     size_t pred_cap = 0;
+    double *d_gtraj = nullptr;
+    size_t gtraj_cap = 0;
     crnn::KConst *d_kc = nullptr;
     bool kc_dirty = true;
     // weights
@@ -107,34 +111,27 @@ int32_t fail(Ctx *ctx, const std::string &msg) {
     return -1;
 }
 
-const KernelEntry *find_kernel(const Ctx *c, int C) {
+bool shape_match(const Ctx *c, const KernelEntry &k) {
+    return k.ns == c->cfg.ns && k.nr == c->cfg.nr && k.has_t == c->cfg.has_temp && k.use_scale == (c->use_scale ? 1 : 0);
+}
+
+const KernelEntry *find_primal(const Ctx *c) {
     for (const auto &k : kKernels)
-        if (k.ns == c->cfg.ns && k.nr == c->cfg.nr && k.has_t == c->cfg.has_temp && k.use_scale == (c->use_scale ? 1 : 0) &&
-            k.C == C)
-            return &k;
+        if (shape_match(c, k) && k.C == 0) return &k;
     return nullptr;
 }
 
-// choose the tangent-columns-per-lane variant: explicit cfg.cols_per_lane if it
-// exists for this shape, else the largest instantiated C with ceil(P/C) <= 64
-// that minimises idle tangent slots.
+// Choose the (C, L) variant for P tangent directions: cfg.cols_per_lane if an
+// instance with that C covers P, else the instance that minimises the modelled
+// lane-work per trajectory (primal ~ 3 column-equivalents, 64/L trajectories per wave).
 const KernelEntry *pick_kernel(const Ctx *c, int P) {
-    if (P == 0) return find_kernel(c, 0);
-    if (c->cfg.cols_per_lane > 0) {
-        const KernelEntry *k = find_kernel(c, c->cfg.cols_per_lane);
-        if (k && (P + k->C - 1) / k->C <= 64) return k;
-    }
+    if (P == 0) return find_primal(c);
     const KernelEntry *best = nullptr;
     double best_cost = 1e300;
     for (const auto &k : kKernels) {
-        if (k.C == 0 || k.ns != c->cfg.ns || k.nr != c->cfg.nr || k.has_t != c->cfg.has_temp ||
-            k.use_scale != (c->use_scale ? 1 : 0))
-            continue;
-        int L = (P + k.C - 1) / k.C;
-        if (L > 64) continue;
-        int gpw = 64 / L;
-        // cost model: per-lane work (primal ~ 2 column-equivalents + C columns) per trajectory slot
-        double cost = (2.0 + k.C) * 64.0 / gpw;
+        if (!shape_match(c, k) || k.C == 0 || k.C * k.L < P) continue;
+        double cost = (3.0 + k.C) / (double)(64 / k.L);
+        if (c->cfg.cols_per_lane > 0 && k.C == c->cfg.cols_per_lane) cost *= 1e-3;
         if (cost < best_cost) { best_cost = cost; best = &k; }
     }
     return best;
@@ -154,10 +151,6 @@ __global__ void opt_kernel(crnn::OptCfg o, int P, int npart, double *p, const do
         double gscale = ntraj > 0 ? 1.0 / ntraj : 0.0;
         crnn::opt_update(o, P, p, red, gscale, state);
     }
-}
-
-size_t smem_bytes(const Ctx *c, int C, int P) {
-    return (size_t)crnn::smem_doubles(c->cfg.ns, c->cfg.nr, c->n, C, P, kBlock) * sizeof(double);
 }
 
 int32_t upload_consts(Ctx *c) {
@@ -196,23 +189,25 @@ int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int 
     if (n_save_active <= 0 || n_save_active > c->cfg.n_save) return fail(c, "crnn_solve: n_save_active out of range");
     const KernelEntry *k = pick_kernel(c, P);
     if (!k) return fail(c, "crnn_solve: no gfx950 kernel instantiated for this (ns, nr, has_temp, n_dir) shape");
-    const int C = k->C;
-    const int L = C > 0 ? (P + C - 1) / C : 1;
+    const int C = k->C, L = k->L;
     const int gpw = 64 / L;
     const int waves = kBlock / 64;
-    const int npart = (C > 0 ? L * C : 0) + crnn::kExtra;
+    const int ppad = C > 0 ? L * C : 0;
+    const int npart = ppad + crnn::kExtra;
 
-    size_t smem = smem_bytes(c, C, P);
     int occ = 0;
-    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k->fn, kBlock, smem));
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k->fn, kBlock, 0));
     if (occ < 1) occ = 1;
     int64_t groups_per_block = (int64_t)waves * gpw;
     int64_t need_blocks = (count + groups_per_block - 1) / groups_per_block;
     int64_t resident = (int64_t)c->num_cu * occ;
     int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(need_blocks, resident));
 
-    size_t need_part = (size_t)nblk * npart;
-    if (ensure(c, &c->d_partials, &c->partials_cap, need_part)) return -1;
+    // fixed-order ensemble reduction geometry: depends on count only
+    const int rows_per_block = 256;
+    const int rblk = (int)((count + rows_per_block - 1) / rows_per_block);
+    if (ensure(c, &c->d_partials, &c->partials_cap, (size_t)rblk * npart)) return -1;
+    if (C > 0 && ensure(c, &c->d_gtraj, &c->gtraj_cap, (size_t)count * ppad)) return -1;
     if (c->npart_max < npart) {
         if (c->d_red) HIP_TRY(c, hipFree(c->d_red));
         HIP_TRY(c, hipMalloc((void **)&c->d_red, sizeof(double) * npart));
@@ -222,31 +217,32 @@ int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int 
         size_t need = (size_t)c->cfg.n_save * c->n * c->B;
         if (ensure(c, &c->d_pred, &c->pred_cap, need)) return -1;
     }
+    (void)want_percase;
 
     crnn::SolveParams prm{};
     prm.u0 = c->d_u0; prm.data = c->d_data; prm.tsave = c->d_tsave;
     prm.pred = want_pred ? c->d_pred : nullptr;
-    prm.loss = want_percase ? c->d_loss : nullptr;
-    prm.retcode = want_percase ? c->d_ret : nullptr;
-    prm.n_saved = want_percase ? c->d_nsaved : nullptr;
-    prm.partials = c->d_partials;
+    prm.loss = c->d_loss; prm.retcode = c->d_ret; prm.n_saved = c->d_nsaved;
+    prm.n_accept = c->d_nacc; prm.n_reject = c->d_nrej;
+    prm.gtraj = c->d_gtraj;
     prm.B = c->B; prm.first = first; prm.count = count;
-    prm.n_save = n_save_active; prm.P = P; prm.npart = npart;
+    prm.n_save = n_save_active; prm.P = P;
     prm.maxiters = c->cfg.maxiters; prm.clamp_pred = c->cfg.clamp_pred; prm.loss_kind = c->cfg.loss_kind;
     prm.n_obs = c->n_obs;
     prm.kc = c->d_kc;
     if (upload_consts(c)) return -1;
-    if (smem > 64 * 1024)
-        HIP_TRY(c, hipFuncSetAttribute((const void *)k->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 
     c->ev0 = c->ring0[c->n_launch % Ctx::kRing];
     c->ev1 = c->ring1[c->n_launch % Ctx::kRing];
     ++c->n_launch;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    hipLaunchKernelGGL(k->fn, dim3(nblk), dim3(kBlock), smem, c->stream, prm, d_theta, d_dtheta);
+    hipLaunchKernelGGL(k->fn, dim3(nblk), dim3(kBlock), 0, c->stream, prm, d_theta, d_dtheta);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    hipLaunchKernelGGL(crnn::reduce_partials_kernel, dim3(npart), dim3(256), 0, c->stream, c->d_partials, nblk, npart,
+    hipLaunchKernelGGL(crnn::reduce_traj_kernel, dim3(rblk), dim3(256), 0, c->stream, c->d_gtraj, ppad, c->d_loss, c->d_ret,
+                       c->d_nacc, c->d_nrej, first, count, rows_per_block, c->d_partials);
+    HIP_TRY(c, hipGetLastError());
+    hipLaunchKernelGGL(crnn::reduce_partials_kernel, dim3(npart), dim3(256), 0, c->stream, c->d_partials, rblk, npart,
                        c->d_red);
     HIP_TRY(c, hipGetLastError());
     c->last_npart = npart;
@@ -365,8 +361,8 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
     c->use_scale = false;
     for (int i = 0; i < cfg->ns; ++i) if (cfg->rate_scale[i] != 1.0) c->use_scale = true;
     // robertson-shaped problems always take the scaled kernel (one instantiation per shape)
-    if (!find_kernel(c, 0)) { c->use_scale = !c->use_scale; if (!find_kernel(c, 0)) c->use_scale = !c->use_scale; }
-    if (!find_kernel(c, 0)) {
+    if (!find_primal(c)) { c->use_scale = !c->use_scale; if (!find_primal(c)) c->use_scale = !c->use_scale; }
+    if (!find_primal(c)) {
         delete c;
         return fail(nullptr, "crnn_ctx_create: no gfx950 kernel instantiated for this (ns, nr, has_temp)");
     }
@@ -400,7 +396,7 @@ void crnn_ctx_destroy(crnn_ctx *ctx) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->own_u0 && c->d_u0) (void)hipFree(c->d_u0);
     if (c->own_data && c->d_data) (void)hipFree(c->d_data);
-    void *ptrs[] = {c->d_kc, c->d_tsave, c->d_pred, c->d_loss, c->d_ret, c->d_nsaved, c->d_theta, c->d_dtheta,
+    void *ptrs[] = {c->d_nacc, c->d_nrej, c->d_gtraj, c->d_kc, c->d_tsave, c->d_pred, c->d_loss, c->d_ret, c->d_nsaved, c->d_theta, c->d_dtheta,
                     c->d_partials, c->d_red, c->d_p, c->d_opt, c->d_comm_buf};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < Ctx::kRing; ++i) {
@@ -449,10 +445,14 @@ static int32_t set_data_common(Ctx *c, const double *tsteps, const double *yscal
         if (c->d_loss) HIP_TRY(c, hipFree(c->d_loss));
         if (c->d_ret) HIP_TRY(c, hipFree(c->d_ret));
         if (c->d_nsaved) HIP_TRY(c, hipFree(c->d_nsaved));
-        c->d_loss = nullptr; c->d_ret = nullptr; c->d_nsaved = nullptr;
+        if (c->d_nacc) HIP_TRY(c, hipFree(c->d_nacc));
+        if (c->d_nrej) HIP_TRY(c, hipFree(c->d_nrej));
+        c->d_loss = nullptr; c->d_ret = nullptr; c->d_nsaved = nullptr; c->d_nacc = nullptr; c->d_nrej = nullptr;
         HIP_TRY(c, hipMalloc((void **)&c->d_loss, sizeof(double) * B));
         HIP_TRY(c, hipMalloc((void **)&c->d_ret, sizeof(int32_t) * B));
         HIP_TRY(c, hipMalloc((void **)&c->d_nsaved, sizeof(int32_t) * B));
+        HIP_TRY(c, hipMalloc((void **)&c->d_nacc, sizeof(int32_t) * B));
+        HIP_TRY(c, hipMalloc((void **)&c->d_nrej, sizeof(int32_t) * B));
     }
     c->B = B;
     return 0;

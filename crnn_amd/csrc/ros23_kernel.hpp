@@ -55,15 +55,16 @@ struct SolveParams {
     const double *data;    // [n_save_total][n_obs][B]
     const double *tsave;   // [n_save_total]
     double *pred;          // [n_save_total][n][B] or null
-    double *loss;          // [B] or null
-    int32_t *retcode;      // [B] or null
-    int32_t *n_saved;      // [B] or null
-    double *partials;      // [gridDim.x][npart]
+    double *loss;          // [B]
+    int32_t *retcode;      // [B]
+    int32_t *n_saved;      // [B]
+    int32_t *n_accept;     // [B]
+    int32_t *n_reject;     // [B]
+    double *gtraj;         // [count][L*C] per-trajectory gradient rows (row = trajectory - first)
     const KConst *kc;
     int64_t B, first, count;
     int32_t n_save;        // active save points
     int32_t P;             // tangent directions
-    int32_t npart;         // L*C + kExtra: [grad | loss_sum, n_ok, n_accept, n_reject, n_traj]
     int32_t maxiters, clamp_pred, loss_kind, n_obs;
 };
 
@@ -256,28 +257,14 @@ __device__ __forceinline__ void rhs_from_rates(const double *__restrict__ th, co
     }
 }
 
-// LDS bytes (in doubles) the kernel needs; shared by host and device.
-__host__ __device__ inline int smem_doubles(int NS, int NR, int N, int C, int P, int block) {
-    const int nth = NR * (N + 1 + NS);
-    const int nthp = nth | 1;
-    const int CC = C > 0 ? C : 1;
-    const int L = C > 0 ? (P + C - 1) / C : 1;
-    const int gpw = 64 / L;
-    const int waves = block / 64;
-    const int PT = NS + NS + NR + NS + NS;
-    const int NREC = 2 * PT + 4 * NS + NR + 3 * NR + 3 * NS + 1;
-    int per_wave = C > 0 ? C * NS * 64 + NREC * gpw : 0;
-    int red = (CC + kExtra) * block;
-    int body = waves * per_wave;
-    if (body < red) body = red;
-    return kNConst + (C > 0 ? L * C * nthp : 0) + body;
-}
-
 // ---------------------------------------------------------------------------
 // the fused solve + loss + tangent kernel
-//   C  = tangent columns per lane (0: primal only, one lane per trajectory)
+//   C = tangent columns per lane, L = lanes per trajectory (C = 0, L = 1: primal only)
+// Per-trajectory outputs (loss, retcode, n_saved, step counts, gradient row); the
+// ensemble sums are formed by reduce_traj_kernel in a fixed order, so results do not
+// depend on the launch geometry of this kernel.
 // ---------------------------------------------------------------------------
-template <int NS, int NR, bool HAS_T, bool USE_SCALE, int C, int BLOCK>
+template <int NS, int NR, bool HAS_T, bool USE_SCALE, int C, int L, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, const double *__restrict__ theta,
                                                       const double *__restrict__ dtheta) {
     using L_ = Lay<NS, NR, HAS_T>;
@@ -287,42 +274,41 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
     constexpr int NTHP = L_::NTHP;
     constexpr int CC = (C > 0) ? C : 1;
     constexpr int NREC = R_::NREC;
+    constexpr int WAVES = BLOCK / 64;
+    constexpr int GPW = 64 / L;          // groups (trajectories) per wavefront
+    constexpr int PPAD = L * CC;         // padded number of tangent columns
+    static_assert(C > 0 || L == 1, "primal-only variant uses one lane per trajectory");
     static_assert(NREC == 2 * (4 * NS + NR) + 4 * NS + NR + 3 * NR + 3 * NS + 1, "record layout");
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+
+    // distinct LDS objects (no aliasing between them)
+    __shared__ double kc_lds[kNConst];
+    __shared__ double dth_lds[C > 0 ? PPAD * NTHP : 1];          // d theta / d p, zero padded, odd pitch
+    __shared__ double S_lds[C > 0 ? WAVES * C * NS * 64 : 1];    // tangent columns, one slot per lane
+    __shared__ double rec_lds[C > 0 ? WAVES * NREC * GPW : 1];   // step records, one per group
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    constexpr int WAVES = BLOCK / 64;
-    const int Lg = (C > 0) ? (prm.P + C - 1) / C : 1;  // lanes per trajectory
-    const int gpw = 64 / Lg;                           // groups per wave
-    const int grp = lane / Lg;
-    const int chunk = lane - grp * Lg;
-    const bool lane_active = grp < gpw;
+    const int grp = lane / L;
+    const int chunk = lane - grp * L;
+    const bool lane_active = grp < GPW;
     const bool lead = lane_active && chunk == 0;
-    const int Ppad = Lg * CC;
 
-    // ---- LDS carve-up ----
-    double *kc_s = smem;                                        // [kNConst]
-    double *dth_s = smem + kNConst;                             // [Ppad][NTHP]
-    double *body = dth_s + (C > 0 ? Ppad * NTHP : 0);
-    const int per_wave = C > 0 ? C * NS * 64 + NREC * gpw : 0;
-    double *S_s = body + wave * per_wave + lane;                // column qc, species i at S_s[(qc*NS+i)*64]
-    double *rec = body + wave * per_wave + (C > 0 ? C * NS * 64 : 0) + (lane_active ? grp : 0);  // field f at rec[f*gpw]
-    double *red = body;                                         // [CC + kExtra][BLOCK], after the main loop
+    double *S_s = S_lds + (C > 0 ? wave * C * NS * 64 + lane : 0);            // (qc, i) at S_s[(qc*NS+i)*64]
+    double *rec = rec_lds + (C > 0 ? wave * NREC * GPW + (lane_active ? grp : 0) : 0);  // field f at rec[f*GPW]
 
-    for (int idx = tid; idx < kNConst; idx += BLOCK) kc_s[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
+    for (int idx = tid; idx < kNConst; idx += BLOCK) kc_lds[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
     if (C > 0) {
-        for (int idx = tid; idx < Ppad * NTHP; idx += BLOCK) {
+        for (int idx = tid; idx < PPAD * NTHP; idx += BLOCK) {
             int k = idx / NTHP, m = idx - k * NTHP;
-            dth_s[idx] = (k < prm.P && m < NTH) ? dtheta[(size_t)k * NTH + m] : 0.0;
+            dth_lds[idx] = (k < prm.P && m < NTH) ? dtheta[(size_t)k * NTH + m] : 0.0;
         }
     }
     __syncthreads();
-    const KConst *kc = reinterpret_cast<const KConst *>(kc_s);
+    const KConst *kc = reinterpret_cast<const KConst *>(kc_lds);
 
-    const int64_t ngroups = (int64_t)gridDim.x * WAVES * gpw;
-    int64_t traj = ((int64_t)blockIdx.x * WAVES + wave) * gpw + grp;
+    const int64_t ngroups = (int64_t)gridDim.x * WAVES * GPW;
+    int64_t traj = ((int64_t)blockIdx.x * WAVES + wave) * GPW + grp;
     if (!lane_active) traj = prm.count;
 
     const double *__restrict__ th = theta;
@@ -335,18 +321,12 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
     const double dtmax = tend - t0;
     const double lqinit = flog(kc->qoldinit);
 
-    // lane totals
-    double G[CC];
-#pragma unroll
-    for (int q = 0; q < CC; ++q) G[q] = 0.0;
-    double Lsum = 0.0, n_ok = 0.0, n_acc = 0.0, n_rej = 0.0, n_traj = 0.0;
-
     // per-trajectory state carried in registers between steps
     double u[NS], f0[NS], g0[NS], r0[NR], bT[NR];
     double gtr[CC];
-    double xT = 0.0, Tconst = 0.0;
+    double xT = 0.0;
     double t = 0.0, dt = 0.0, lqold = 0.0, loss_sum = 0.0;
-    int iter = 0, jsave = 0, par = 0;
+    int iter = 0, jsave = 0, par = 0, nacc = 0, nrej = 0;
     int64_t b = 0;
     bool need_init = true;
 
@@ -357,6 +337,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
             b = prm.first + traj;
 #pragma unroll
             for (int i = 0; i < NS; ++i) u[i] = prm.u0[(size_t)i * prm.B + b];
+            double Tconst = 0.0;
             if (HAS_T) {
                 Tconst = prm.u0[(size_t)NS * prm.B + b];
                 xT = kc->inv_R * frcp(Tconst);
@@ -370,9 +351,9 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
             par = 0;
             if (C > 0 && lead) {
 #pragma unroll
-                for (int i = 0; i < NS; ++i) { rec[(R_::X0 + i) * gpw] = x0[i]; rec[(R_::G0 + i) * gpw] = g0[i]; }
+                for (int i = 0; i < NS; ++i) { rec[(R_::X0 + i) * GPW] = x0[i]; rec[(R_::G0 + i) * GPW] = g0[i]; }
 #pragma unroll
-                for (int j = 0; j < NR; ++j) rec[(R_::R0 + j) * gpw] = r0[j];
+                for (int j = 0; j < NR; ++j) rec[(R_::R0 + j) * GPW] = r0[j];
             }
             // Hairer initial step (OrdinaryDiffEq ode_determine_initdt, order 2)
             {
@@ -408,6 +389,8 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
             lqold = lqinit;
             iter = 0;
             jsave = 0;
+            nacc = 0;
+            nrej = 0;
             loss_sum = 0.0;
 #pragma unroll
             for (int q = 0; q < CC; ++q) gtr[q] = 0.0;
@@ -491,9 +474,9 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                 rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r1, kc->scale, f1);
                 if (C > 0 && lead) {
 #pragma unroll
-                    for (int i = 0; i < NS; ++i) { rec[(R_::X1 + i) * gpw] = x1[i]; rec[(R_::G1 + i) * gpw] = g1[i]; }
+                    for (int i = 0; i < NS; ++i) { rec[(R_::X1 + i) * GPW] = x1[i]; rec[(R_::G1 + i) * GPW] = g1[i]; }
 #pragma unroll
-                    for (int j = 0; j < NR; ++j) rec[(R_::R1 + j) * gpw] = r1[j];
+                    for (int j = 0; j < NR; ++j) rec[(R_::R1 + j) * GPW] = r1[j];
                 }
             }
             // stage 2
@@ -511,13 +494,13 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                 if (C > 0 && lead) {  // next point area (becomes point 0 when the step is accepted)
 #pragma unroll
                     for (int i = 0; i < NS; ++i) {
-                        rec[(pnxt + R_::X0 + i) * gpw] = x2[i];
-                        rec[(pnxt + R_::G0 + i) * gpw] = g2[i];
-                        rec[(pnxt + R_::UP + i) * gpw] = unew[i];
-                        rec[(pnxt + R_::FP + i) * gpw] = f2[i];
+                        rec[(pnxt + R_::X0 + i) * GPW] = x2[i];
+                        rec[(pnxt + R_::G0 + i) * GPW] = g2[i];
+                        rec[(pnxt + R_::UP + i) * GPW] = unew[i];
+                        rec[(pnxt + R_::FP + i) * GPW] = f2[i];
                     }
 #pragma unroll
-                    for (int j = 0; j < NR; ++j) rec[(pnxt + R_::R0 + j) * gpw] = r2[j];
+                    for (int j = 0; j < NR; ++j) rec[(pnxt + R_::R0 + j) * GPW] = r2[j];
                 }
             }
             // stage 3 + error estimate
@@ -593,7 +576,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                         }
                     }
                     if (HAS_T && prm.pred && chunk == 0) {
-                        double v = Tconst;
+                        double v = prm.u0[(size_t)NS * prm.B + b];
                         if (prm.clamp_pred) v = fmin(fmax(v, -kc->ub), kc->ub);
                         prm.pred[((size_t)jsave * N + NS) * prm.B + b] = v;
                     }
@@ -617,19 +600,18 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                     if (lead) {
 #pragma unroll
                         for (int i = 0; i < NS; ++i) {
-                            rec[(R_::K1 + i) * gpw] = k1[i];
-                            rec[(R_::DK + i) * gpw] = dk[i];
-                            rec[(R_::AA + i) * gpw] = A_[i];
-                            rec[(R_::B1 + i) * gpw] = B1[i];
-                            rec[(R_::B2 + i) * gpw] = B2[i];
+                            rec[(R_::K1 + i) * GPW] = k1[i];
+                            rec[(R_::DK + i) * GPW] = dk[i];
+                            rec[(R_::AA + i) * GPW] = A_[i];
+                            rec[(R_::B1 + i) * GPW] = B1[i];
+                            rec[(R_::B2 + i) * GPW] = B2[i];
                         }
 #pragma unroll
                         for (int j = 0; j < NR; ++j) {
-                            rec[(R_::C1J + j) * gpw] = c1j[j];
-                            rec[(R_::CZD + j) * gpw] = czd[j];
-                            rec[(R_::GR0 + j) * gpw] = gam * r0[j];
+                            rec[(R_::C1J + j) * GPW] = c1j[j];
+                            rec[(R_::CZD + j) * GPW] = czd[j];
+                            rec[(R_::GR0 + j) * GPW] = gam * r0[j];
                         }
-                        rec[R_::DT * gpw] = dt;
                     }
                 }
                 if (C == 0) {  // primal-only variant: the FSAL point stays in registers
@@ -644,60 +626,62 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
         __builtin_amdgcn_wave_barrier();
 
         if (rc < 0 && accept) {
-            n_acc += 1.0;
+            ++nacc;
             // ==============================================================
             // TANGENT phase: forward tangents of the accepted step, C columns per lane.
             // Operands stream from the group's step record; only LU/dinv/piv stay in registers.
             // ==============================================================
             if (C > 0) {
                 const double hdt = 0.5 * dt;
-                const double dtl = dt;
 #pragma unroll 1
                 for (int qc = 0; qc < C; ++qc) {
-                    const double *dcol = dth_s + (chunk * C + qc) * NTHP;
-                    double s[NS], gs[NS], hs[NS];
-#pragma unroll
-                    for (int c = 0; c < NS; ++c) {
-                        s[c] = S_s[(qc * NS + c) * 64];
-                        double g = rec[(pcur + R_::G0 + c) * gpw];
-                        gs[c] = g * s[c];
-                        hs[c] = -g * gs[c];  // g' = -g^2 s inside the window (g = 1/u), 0 outside
-                    }
-                    // pass 1 over w_in entries: e0_j, z'_j(k1), z'_j(dk), theta-direct part of e1_j
+                    const double *dcol = dth_lds + (chunk * C + qc) * NTHP;
+                    double *Sq = S_s + qc * NS * 64;
+                    // ---- pass 1 (species-major): e0_j, theta-direct part of e1_j, z'_j(k1), z'_j(dk) ----
                     double e0[NR], e1d[NR], zp1[NR], zpd[NR];
 #pragma unroll
                     for (int j = 0; j < NR; ++j) {
                         double e = dcol[L_::wb(j)];
                         if (HAS_T) e = fma(dcol[L_::wi(NS, j)], xT, e);
-                        double a0 = e, a1 = e, z1 = 0.0, zd = 0.0;
-#pragma unroll
-                        for (int c = 0; c < NS; ++c) {
-                            double dwi = dcol[L_::wi(c, j)];
-                            double wi = th[L_::wi(c, j)];
-                            a0 = fma(dwi, rec[(pcur + R_::X0 + c) * gpw], a0);
-                            a0 = fma(wi, gs[c], a0);
-                            a1 = fma(dwi, rec[(R_::X1 + c) * gpw], a1);
-                            double m = fma(dwi, rec[(pcur + R_::G0 + c) * gpw], wi * hs[c]);
-                            z1 = fma(m, rec[(R_::K1 + c) * gpw], z1);
-                            zd = fma(m, rec[(R_::DK + c) * gpw], zd);
-                        }
-                        e0[j] = a0; e1d[j] = a1; zp1[j] = z1; zpd[j] = zd;
+                        e0[j] = e; e1d[j] = e; zp1[j] = 0.0; zpd[j] = 0.0;
                     }
-                    // pass 2 over w_out entries
+#pragma unroll
+                    for (int c = 0; c < NS; ++c) {
+                        const double sc_ = Sq[c * 64];
+                        const double g = rec[(pcur + R_::G0 + c) * GPW];
+                        const double x0c = rec[(pcur + R_::X0 + c) * GPW];
+                        const double x1c = rec[(R_::X1 + c) * GPW];
+                        const double k1c = rec[(R_::K1 + c) * GPW];
+                        const double dkc = rec[(R_::DK + c) * GPW];
+                        const double gsv = g * sc_;
+                        const double hsv = -g * gsv;   // g' = -g^2 s inside the window (g = 1/u), 0 outside
+#pragma unroll
+                        for (int j = 0; j < NR; ++j) {
+                            const double dwi = dcol[L_::wi(c, j)];
+                            const double wi = th[L_::wi(c, j)];
+                            e0[j] = fma(dwi, x0c, e0[j]);
+                            e0[j] = fma(wi, gsv, e0[j]);
+                            e1d[j] = fma(dwi, x1c, e1d[j]);
+                            const double m = fma(dwi, g, wi * hsv);
+                            zp1[j] = fma(m, k1c, zp1[j]);
+                            zpd[j] = fma(m, dkc, zpd[j]);
+                        }
+                    }
+                    // ---- pass 2 (reaction-major): rhs1 = f0' + gam J' k1, w2 = gam J' dk, f1d = dw_out r1 ----
                     double rhs1[NS], w2[NS], f1d[NS];
 #pragma unroll
                     for (int i = 0; i < NS; ++i) { rhs1[i] = 0.0; w2[i] = 0.0; f1d[i] = 0.0; }
 #pragma unroll
                     for (int j = 0; j < NR; ++j) {
-                        const double r0j = rec[(pcur + R_::R0 + j) * gpw], r1j = rec[(R_::R1 + j) * gpw];
-                        const double gr = rec[(R_::GR0 + j) * gpw];
-                        const double c1 = rec[(R_::C1J + j) * gpw], cz = rec[(R_::CZD + j) * gpw];
+                        const double r0j = rec[(pcur + R_::R0 + j) * GPW], r1j = rec[(R_::R1 + j) * GPW];
+                        const double gr = rec[(R_::GR0 + j) * GPW];
+                        const double c1 = rec[(R_::C1J + j) * GPW], cz = rec[(R_::CZD + j) * GPW];
                         const double y1 = gr * zp1[j], yd = gr * zpd[j];
 #pragma unroll
                         for (int i = 0; i < NS; ++i) {
-                            double wo = th[L_::wo(i, j)];
-                            double dwo = dcol[L_::wo(i, j)];
-                            double H = fma(wo, e0[j], dwo) * r0j;
+                            const double wo = th[L_::wo(i, j)];
+                            const double dwo = dcol[L_::wo(i, j)];
+                            const double H = fma(wo, e0[j], dwo) * r0j;
                             rhs1[i] = fma(H, c1, rhs1[i]);
                             rhs1[i] = fma(wo, y1, rhs1[i]);
                             w2[i] = fma(H, cz, w2[i]);
@@ -714,7 +698,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                     // f1' at u1 with s1 = s + dt/2 k1'
                     double gs1[NS];
 #pragma unroll
-                    for (int c = 0; c < NS; ++c) gs1[c] = rec[(R_::G1 + c) * gpw] * fma(hdt, rhs1[c], s[c]);
+                    for (int c = 0; c < NS; ++c) gs1[c] = rec[(R_::G1 + c) * GPW] * fma(hdt, rhs1[c], Sq[c * 64]);
                     double rhs2[NS];
 #pragma unroll
                     for (int i = 0; i < NS; ++i) rhs2[i] = f1d[i];
@@ -723,7 +707,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                         double e = e1d[j];
 #pragma unroll
                         for (int c = 0; c < NS; ++c) e = fma(th[L_::wi(c, j)], gs1[c], e);
-                        double er = e * rec[(R_::R1 + j) * gpw];
+                        const double er = e * rec[(R_::R1 + j) * GPW];
 #pragma unroll
                         for (int i = 0; i < NS; ++i) rhs2[i] = fma(th[L_::wo(i, j)], er, rhs2[i]);
                     }
@@ -734,11 +718,12 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                     double acc = 0.0;
 #pragma unroll
                     for (int i = 0; i < NS; ++i) {
-                        double k2p = rhs1[i] + rhs2[i];
-                        acc = fma(rec[(R_::AA + i) * gpw], s[i], acc);
-                        acc = fma(rec[(R_::B1 + i) * gpw], rhs1[i], acc);
-                        acc = fma(rec[(R_::B2 + i) * gpw], k2p, acc);
-                        S_s[(qc * NS + i) * 64] = fma(dtl, k2p, s[i]);
+                        const double si = Sq[i * 64];
+                        const double k2p = rhs1[i] + rhs2[i];
+                        acc = fma(rec[(R_::AA + i) * GPW], si, acc);
+                        acc = fma(rec[(R_::B1 + i) * GPW], rhs1[i], acc);
+                        acc = fma(rec[(R_::B2 + i) * GPW], k2p, acc);
+                        Sq[i * 64] = fma(dt, k2p, si);
                     }
                     gtr[qc] += acc;
                 }
@@ -749,12 +734,12 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                 const int pn = par ? R_::PB : 0;
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
-                    u[i] = rec[(pn + R_::UP + i) * gpw];
-                    f0[i] = rec[(pn + R_::FP + i) * gpw];
-                    g0[i] = rec[(pn + R_::G0 + i) * gpw];
+                    u[i] = rec[(pn + R_::UP + i) * GPW];
+                    f0[i] = rec[(pn + R_::FP + i) * GPW];
+                    g0[i] = rec[(pn + R_::G0 + i) * GPW];
                 }
 #pragma unroll
-                for (int j = 0; j < NR; ++j) r0[j] = rec[(pn + R_::R0 + j) * gpw];
+                for (int j = 0; j < NR; ++j) r0[j] = rec[(pn + R_::R0 + j) * GPW];
             }
             // step_accept_controller
             if (q >= kc->qsteady_min && q <= kc->qsteady_max) q = 1.0;
@@ -762,7 +747,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
             dt = fmin(dt / q, dtmax);
             if (jsave >= nsave) rc = 0;
         } else if (rc < 0) {
-            n_rej += 1.0;
+            ++nrej;
             dt = dt / fmin(1.0 / kc->qmin, exp(lq11) / kc->gamma);
         }
         __builtin_amdgcn_wave_barrier();
@@ -771,46 +756,76 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
             // mae/mse over the saved prefix (rober_crnn.jl:141 data[:, 1:size(pred)[2]])
             const double denom = (double)prm.n_obs * (double)jsave;
             const double inv_den = jsave > 0 ? 1.0 / denom : 0.0;
-            const double lval = loss_sum * inv_den;
             if (chunk == 0) {
-                if (prm.loss) prm.loss[b] = lval;
-                if (prm.retcode) prm.retcode[b] = rc;
-                if (prm.n_saved) prm.n_saved[b] = jsave;
-                Lsum += lval;
-                n_ok += (rc == 0) ? 1.0 : 0.0;
-                n_traj += 1.0;
+                prm.loss[b] = loss_sum * inv_den;
+                prm.retcode[b] = rc;
+                prm.n_saved[b] = jsave;
+                prm.n_accept[b] = nacc;
+                prm.n_reject[b] = nrej;
             }
+            if (C > 0) {
+                double *grow = prm.gtraj + (size_t)traj * PPAD + chunk * C;
 #pragma unroll
-            for (int q_ = 0; q_ < CC; ++q_) G[q_] = fma(gtr[q_], inv_den, G[q_]);
+                for (int q_ = 0; q_ < C; ++q_) grow[q_] = gtr[q_] * inv_den;
+            }
             traj += ngroups;
             need_init = true;
         }
     }
+}
 
-    // ---- deterministic block reduction: lane -> LDS -> fixed-order sums ----
-    __syncthreads();
-#pragma unroll
-    for (int q_ = 0; q_ < CC; ++q_) red[q_ * BLOCK + tid] = lane_active ? G[q_] : 0.0;
-    red[(CC + 0) * BLOCK + tid] = lead ? Lsum : 0.0;
-    red[(CC + 1) * BLOCK + tid] = lead ? n_ok : 0.0;
-    red[(CC + 2) * BLOCK + tid] = lead ? n_acc : 0.0;
-    red[(CC + 3) * BLOCK + tid] = lead ? n_rej : 0.0;
-    red[(CC + 4) * BLOCK + tid] = lead ? n_traj : 0.0;
-    __syncthreads();
-    double *out = prm.partials + (size_t)blockIdx.x * prm.npart;
-    if (C > 0) {
-        for (int k = tid; k < Ppad; k += BLOCK) {
-            int ch = k / C, q_ = k - ch * C;
-            double a = 0.0;
-            for (int w = 0; w < WAVES; ++w)
-                for (int g = 0; g < gpw; ++g) a += red[q_ * BLOCK + w * 64 + g * Lg + ch];
-            out[k] = a;
-        }
-    }
-    for (int e = tid; e < kExtra; e += BLOCK) {
+// ---------------------------------------------------------------------------
+// Deterministic ensemble reduction of the per-trajectory outputs.
+//   partials[blk][0 .. ppad)          sum over the block's trajectory range of gtraj rows
+//   partials[blk][ppad .. ppad+5)     loss_sum, n_ok, n_accept, n_reject, n_traj
+// Each block owns a contiguous range of trajectories; all sums run in a fixed order.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reduce_traj_kernel(const double *__restrict__ gtraj, int ppad,
+                                                          const double *__restrict__ loss,
+                                                          const int32_t *__restrict__ retcode,
+                                                          const int32_t *__restrict__ n_accept,
+                                                          const int32_t *__restrict__ n_reject, int64_t first,
+                                                          int64_t count, int rows_per_block,
+                                                          double *__restrict__ partials) {
+    __shared__ double sh[256];
+    const int npart = ppad + kExtra;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = (r0 + rows_per_block < count) ? r0 + rows_per_block : count;
+    double *out = partials + (size_t)blockIdx.x * npart;
+    const int tid = threadIdx.x;
+    if (ppad > 0) {
+        const int rl = 256 / ppad;            // row lanes per block
+        const int col = tid % ppad, rlane = tid / ppad;
         double a = 0.0;
-        for (int l = 0; l < BLOCK; ++l) a += red[(CC + e) * BLOCK + l];
-        out[(C > 0 ? Ppad : 0) + e] = a;
+        if (rlane < rl)
+            for (int64_t r = r0 + rlane; r < r1; r += rl) a += gtraj[(size_t)r * ppad + col];
+        sh[tid] = a;
+        __syncthreads();
+        if (tid < ppad) {
+            double s = 0.0;
+            for (int k = 0; k < rl; ++k) s += sh[k * ppad + tid];
+            out[tid] = s;
+        }
+        __syncthreads();
+    }
+    double e[kExtra] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int64_t r = r0 + tid; r < r1; r += 256) {
+        const int64_t b = first + r;
+        e[0] += loss[b];
+        e[1] += (retcode[b] == 0) ? 1.0 : 0.0;
+        e[2] += (double)n_accept[b];
+        e[3] += (double)n_reject[b];
+        e[4] += 1.0;
+    }
+    for (int k = 0; k < kExtra; ++k) {
+        sh[tid] = e[k];
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) sh[tid] += sh[tid + s];
+            __syncthreads();
+        }
+        if (tid == 0) out[ppad + k] = sh[0];
+        __syncthreads();
     }
 }
 
