@@ -36,9 +36,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef CRNN_COL_UNROLL
+#define CRNN_COL_UNROLL 1
+#endif
+
 namespace crnn {
 
 constexpr int kMaxN = 12;
+constexpr int kMaxSave = 256;  // max saveat points (LDS-staged)
 constexpr int kExtra = 5;  // loss_sum, n_ok, n_accept, n_reject, n_traj
 
 // Problem constants: one copy in device memory, staged to LDS by every block.
@@ -282,6 +287,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
 
     // distinct LDS objects (no aliasing between them)
     __shared__ double kc_lds[kNConst];
+    __shared__ double ts_lds[kMaxSave];                           // saveat times
     __shared__ double dth_lds[C > 0 ? PPAD * NTHP : 1];          // d theta / d p, zero padded, odd pitch
     __shared__ double S_lds[C > 0 ? WAVES * C * NS * 64 : 1];    // tangent columns, one slot per lane
     __shared__ double rec_lds[C > 0 ? WAVES * NREC * GPW : 1];   // step records, one per group
@@ -298,6 +304,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
     double *rec = rec_lds + (C > 0 ? wave * NREC * GPW + (lane_active ? grp : 0) : 0);  // field f at rec[f*GPW]
 
     for (int idx = tid; idx < kNConst; idx += BLOCK) kc_lds[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
+    for (int idx = tid; idx < prm.n_save; idx += BLOCK) ts_lds[idx] = prm.tsave[idx];
     if (C > 0) {
         for (int idx = tid; idx < PPAD * NTHP; idx += BLOCK) {
             int k = idx / NTHP, m = idx - k * NTHP;
@@ -317,6 +324,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
     const double inv12d = 2.4142135623730950; // 1/(1-2d)
     const int nsave = prm.n_save;
     const double tend = prm.tsave[nsave - 1];
+    const double ts0 = prm.tsave[0];
     const double t0 = kc->t0;
     const double dtmax = tend - t0;
     const double lqinit = flog(kc->qoldinit);
@@ -324,11 +332,22 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
     // per-trajectory state carried in registers between steps
     double u[NS], f0[NS], g0[NS], r0[NR], bT[NR];
     double gtr[CC];
+    double dA[NS], dB[NS];   // observed data of save points jsave / jsave+1, prefetched (HBM latency hidden)
     double xT = 0.0;
     double t = 0.0, dt = 0.0, lqold = 0.0, loss_sum = 0.0;
     int iter = 0, jsave = 0, par = 0, nacc = 0, nrej = 0;
     int64_t b = 0;
     bool need_init = true;
+
+    // data row of save point j for this trajectory (unobserved species read row 0 and are ignored)
+    auto load_row = [&](int j, double (&d)[NS]) {
+        const int jj = j < nsave ? j : nsave - 1;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int dr = (int)kc->drow[i];
+            d[i] = prm.data[((size_t)jj * prm.n_obs + (dr >= 0 ? dr : 0)) * prm.B + b];
+        }
+    };
 
     while (true) {
         if (need_init) {
@@ -337,6 +356,8 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
             b = prm.first + traj;
 #pragma unroll
             for (int i = 0; i < NS; ++i) u[i] = prm.u0[(size_t)i * prm.B + b];
+            load_row(0, dA);
+            load_row(1, dB);
             double Tconst = 0.0;
             if (HAS_T) {
                 Tconst = prm.u0[(size_t)NS * prm.B + b];
@@ -399,7 +420,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                 for (int q = 0; q < C * NS; ++q) S_s[q * 64] = 0.0;
             }
             // save_start: saveat contains tspan[1]  (case2: tsteps[1] = 0)
-            if (prm.tsave[0] == t0) {
+            if (ts0 == t0) {
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
                     double v = u[i];
@@ -407,10 +428,13 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                     if (prm.pred && chunk == 0) prm.pred[((size_t)0 * N + i) * prm.B + b] = v;
                     int dr = (int)kc->drow[i];
                     if (dr >= 0) {
-                        double rr = (prm.data[((size_t)0 * prm.n_obs + dr) * prm.B + b] - v) * kc->inv_yscale[i];
+                        double rr = (dA[i] - v) * kc->inv_yscale[i];
                         loss_sum += (prm.loss_kind == 0) ? fabs(rr) : rr * rr;
                     }
                 }
+#pragma unroll
+                for (int i = 0; i < NS; ++i) dA[i] = dB[i];
+                load_row(2, dB);
                 if (HAS_T && prm.pred && chunk == 0) {
                     double v = Tconst;
                     if (prm.clamp_pred) v = fmin(fmax(v, -kc->ub), kc->ub);
@@ -546,7 +570,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
 #pragma unroll
                 for (int i = 0; i < NS; ++i) { A_[i] = 0.0; B1[i] = 0.0; B2[i] = 0.0; }
                 while (jsave < nsave) {
-                    const double ts = prm.tsave[jsave];
+                    const double ts = ts_lds[jsave];
                     if (!(ts <= tnew)) break;
                     const bool at_end = (ts == tnew);
                     const double Th = at_end ? 1.0 : (ts - t) / dt;
@@ -565,7 +589,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                         int dr = (int)kc->drow[i];
                         if (dr >= 0) {
                             double iy = kc->inv_yscale[i];
-                            double rr = (prm.data[((size_t)jsave * prm.n_obs + dr) * prm.B + b] - v) * iy;
+                            double rr = (dA[i] - v) * iy;
                             double w;
                             if (prm.loss_kind == 0) { loss_sum += fabs(rr); w = signbit(rr) ? 1.0 : -1.0; }
                             else { loss_sum = fma(rr, rr, loss_sum); w = -2.0 * rr; }
@@ -581,6 +605,9 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                         prm.pred[((size_t)jsave * N + NS) * prm.B + b] = v;
                     }
                     ++jsave;
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) dA[i] = dB[i];
+                    load_row(jsave + 1, dB);
                 }
                 if (C > 0) {
                     // publish the step record for the tangent phase
@@ -631,9 +658,13 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
             // TANGENT phase: forward tangents of the accepted step, C columns per lane.
             // Operands stream from the group's step record; only LU/dinv/piv stay in registers.
             // ==============================================================
+#ifdef CRNN_DBG_SKIP_TANGENT
+            if (false) {
+#else
             if (C > 0) {
+#endif
                 const double hdt = 0.5 * dt;
-#pragma unroll 1
+#pragma unroll CRNN_COL_UNROLL
                 for (int qc = 0; qc < C; ++qc) {
                     const double *dcol = dth_lds + (chunk * C + qc) * NTHP;
                     double *Sq = S_s + qc * NS * 64;
