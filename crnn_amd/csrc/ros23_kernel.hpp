@@ -36,10 +36,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#ifndef CRNN_COL_UNROLL
-#define CRNN_COL_UNROLL 1
-#endif
-
 namespace crnn {
 
 constexpr int kMaxN = 12;
@@ -664,7 +660,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
             if (C > 0) {
 #endif
                 const double hdt = 0.5 * dt;
-#pragma unroll CRNN_COL_UNROLL
+#pragma unroll 1
                 for (int qc = 0; qc < C; ++qc) {
                     const double *dcol = dth_lds + (chunk * C + qc) * NTHP;
                     double *Sq = S_s + qc * NS * 64;
