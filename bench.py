@@ -29,14 +29,15 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic HBM bytes per trajectory+gradient, case2, no pred output:
-#   8 * [ n (u0) + n_obs*D (data) + 1 (loss) + 1 (retcode + n_saved as 2 x int32) ]
-BYTES_PER_TRAJ = 8 * (7 + 6 * 50 + 1 + 1)
+# Algorithmic HBM bytes per trajectory+gradient of the dominant kernel (case2, no pred output):
+#   8 * [ n (u0) + n_obs*D (data) + 1 (loss) ] + 4 * 4 (retcode, n_saved, n_accept, n_reject as int32)
+#   + 8 * 28 (the trajectory's gradient row, 25 columns padded to L*C = 28; summed by a fixed-order second kernel)
+BYTES_PER_TRAJ = 8 * (7 + 6 * 50 + 1) + 16 + 8 * 28
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X FP64 vector peak (spec); 2 flop per FMA
-# FP64 operation model of one Rosenbrock23 attempt of the kernel (DESIGN.md "flop model"):
-FLOP_PRIMAL_STEP = 2 * 1150      # f-evals (12 log, 6 exp, matvecs), J, 6x6 LU, 3 solves, error norm, controller
-FLOP_COL_STEP = 2 * 525          # one tangent column through one accepted step
+# FP64 operation model of the kernel (DESIGN.md "flop model"), 2 flop per operation (upper bound: mul/add count as FMA):
+FLOP_PRIMAL_STEP = 2 * 1480      # one Rosenbrock23 attempt: 12 log, 6 exp, 12 rcp, J, 6x6 LU, 3 solves, error norm, controller
+FLOP_COL_STEP = 2 * 441          # one tangent column through one accepted step
 
 
 def parse():

@@ -221,6 +221,7 @@ int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int 
 
     crnn::SolveParams prm{};
     prm.u0 = c->d_u0; prm.data = c->d_data; prm.tsave = c->d_tsave;
+    prm.row_stride = (int64_t)c->cfg.n_save * c->n_obs;
     prm.pred = want_pred ? c->d_pred : nullptr;
     prm.loss = c->d_loss; prm.retcode = c->d_ret; prm.n_saved = c->d_nsaved;
     prm.n_accept = c->d_nacc; prm.n_reject = c->d_nrej;
@@ -419,6 +420,16 @@ int32_t crnn_ctx_set_stream(crnn_ctx *ctx, void *hip_stream) {
     return 0;
 }
 
+// data (IC-fastest, on device) -> c->d_data (trajectory-major, owned)
+static int32_t transpose_into(Ctx *c, const double *d_src, int64_t B) {
+    const int rows = c->cfg.n_save * c->n_obs;
+    dim3 grid((unsigned)((B + 31) / 32), (unsigned)((rows + 31) / 32));
+    hipLaunchKernelGGL(crnn::transpose_data_kernel, grid, dim3(256), 0, c->stream, d_src, c->d_data, B, rows);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 static int32_t set_data_common(Ctx *c, const double *tsteps, const double *yscale, const int32_t *i_obs, int32_t n_obs,
                                int64_t B) {
     if (!tsteps) return fail(c, "crnn_ctx_set_data: null tsteps");
@@ -475,9 +486,13 @@ int32_t crnn_ctx_set_data(crnn_ctx *ctx, const double *u0, const double *data, c
     c->own_u0 = true;
     HIP_TRY(c, hipMalloc((void **)&c->d_data, sizeof(double) * nd));
     c->own_data = true;
+    double *tmp = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&tmp, sizeof(double) * nd));
     HIP_TRY(c, hipMemcpy(c->d_u0, u0, sizeof(double) * nu, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_data, data, sizeof(double) * nd, hipMemcpyHostToDevice));
-    return 0;
+    HIP_TRY(c, hipMemcpy(tmp, data, sizeof(double) * nd, hipMemcpyHostToDevice));
+    int32_t rc = transpose_into(c, tmp, B);
+    (void)hipFree(tmp);
+    return rc;
 }
 
 int32_t crnn_ctx_set_data_device(crnn_ctx *ctx, const void *d_u0, const void *d_data, const double *tsteps,
@@ -490,9 +505,13 @@ int32_t crnn_ctx_set_data_device(crnn_ctx *ctx, const void *d_u0, const void *d_
     if (c->own_u0 && c->d_u0) HIP_TRY(c, hipFree(c->d_u0));
     if (c->own_data && c->d_data) HIP_TRY(c, hipFree(c->d_data));
     c->own_u0 = c->own_data = false;
-    c->d_u0 = (double *)d_u0;
-    c->d_data = (double *)d_data;
-    return set_data_common(c, tsteps, yscale, i_obs, n_obs, B);
+    c->d_u0 = (double *)d_u0;   // u0 is used in place
+    c->d_data = nullptr;
+    if (set_data_common(c, tsteps, yscale, i_obs, n_obs, B)) return -1;
+    size_t nd = (size_t)c->cfg.n_save * c->n_obs * B;
+    HIP_TRY(c, hipMalloc((void **)&c->d_data, sizeof(double) * nd));   // trajectory-major working copy
+    c->own_data = true;
+    return transpose_into(c, (const double *)d_data, B);
 }
 
 int32_t crnn_solve(crnn_ctx *ctx, const double *theta, const double *dtheta, int32_t n_dir, int64_t first, int64_t count,

@@ -53,7 +53,8 @@ constexpr int kNConst = sizeof(KConst) / sizeof(double);
 
 struct SolveParams {
     const double *u0;      // [n][B]
-    const double *data;    // [n_save_total][n_obs][B]
+    const double *data;    // trajectory-major copy [B][n_save_total][n_obs] (transposed once at upload)
+    int64_t row_stride;    // n_save_total * n_obs
     const double *tsave;   // [n_save_total]
     double *pred;          // [n_save_total][n][B] or null
     double *loss;          // [B]
@@ -338,10 +339,11 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
     // data row of save point j for this trajectory (unobserved species read row 0 and are ignored)
     auto load_row = [&](int j, double (&d)[NS]) {
         const int jj = j < nsave ? j : nsave - 1;
+        const double *row = prm.data + (size_t)b * prm.row_stride + (size_t)jj * prm.n_obs;
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             const int dr = (int)kc->drow[i];
-            d[i] = prm.data[((size_t)jj * prm.n_obs + (dr >= 0 ? dr : 0)) * prm.B + b];
+            d[i] = row[dr >= 0 ? dr : 0];
         }
     };
 
@@ -853,6 +855,28 @@ __global__ __launch_bounds__(256) void reduce_traj_kernel(const double *__restri
         }
         if (tid == 0) out[ppad + k] = sh[0];
         __syncthreads();
+    }
+}
+
+// One-time layout change at upload: IC-fastest data[(j*n_obs+i)*B + b] -> trajectory-major dst[b*rows + r].
+// Every 128-byte line of the transposed copy belongs to one trajectory, so the solver fetches each line once
+// no matter how far the persistent lane groups drift apart in time.
+__global__ __launch_bounds__(256) void transpose_data_kernel(const double *__restrict__ src, double *__restrict__ dst,
+                                                             int64_t B, int rows) {
+    __shared__ double tile[32][33];
+    const int64_t b0 = (int64_t)blockIdx.x * 32;
+    const int r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        int r = r0 + k;
+        int64_t b = b0 + tx;
+        if (r < rows && b < B) tile[k][tx] = src[(size_t)r * B + b];
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        int64_t b = b0 + k;
+        int r = r0 + tx;
+        if (r < rows && b < B) dst[(size_t)b * rows + r] = tile[tx][k];
     }
 }
 
