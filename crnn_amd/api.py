@@ -134,6 +134,8 @@ class ODEProblem:
     maxiters: int | None = None
     lb: float | None = None       # log-clamp window overrides
     ub: float | None = None
+    loss_kind: int | None = None  # LOSS_MAE (reference) / LOSS_MSE
+    dtmin: float | None = None
     t0: float = 0.0
     device: int = 0
     cols_per_lane: int = 0
@@ -163,6 +165,10 @@ class ODEProblem:
             cfg.lb = float(self.lb)
         if self.ub is not None:
             cfg.ub = float(self.ub)
+        if self.loss_kind is not None:
+            cfg.loss_kind = int(self.loss_kind)
+        if self.dtmin is not None:
+            cfg.dtmin = float(self.dtmin)
         return cfg
 
 

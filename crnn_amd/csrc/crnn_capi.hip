@@ -350,10 +350,6 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
         return fail(nullptr, "crnn_ctx_create: ns/nr out of range");
     if (cfg->errnorm_sens != 0) return fail(nullptr, "crnn_ctx_create: errnorm_sens=1 is not implemented on device");
     if (cfg->n_save < 1 || cfg->n_save > crnn::kMaxSave) return fail(nullptr, "crnn_ctx_create: n_save must be in [1, 256]");
-    int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev < 1)
-        return fail(nullptr, std::string("crnn_ctx_create: no HIP device (") + hipGetErrorString(e) + ")");
     Ctx *c = new Ctx();
     c->cfg = *cfg;
     c->n = cfg->ns + cfg->has_temp;
@@ -367,6 +363,16 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
     if (!find_primal(c)) {
         delete c;
         return fail(nullptr, "crnn_ctx_create: no gfx950 kernel instantiated for this (ns, nr, has_temp)");
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1) {
+        delete c;
+        return fail(nullptr, std::string("crnn_ctx_create: no HIP device (") + hipGetErrorString(e) + ")");
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) {
+        delete c;
+        return fail(nullptr, "crnn_ctx_create: device ordinal out of range");
     }
     auto bail = [&](const std::string &m) { std::string mm = m; crnn_ctx_destroy((crnn_ctx *)c); return fail(nullptr, mm); };
     if (hipSetDevice(cfg->device) != hipSuccess) return bail("crnn_ctx_create: hipSetDevice failed");

@@ -73,6 +73,10 @@ struct SolveParams {
 // ---------------------------------------------------------------------------
 // arithmetic helpers
 // ---------------------------------------------------------------------------
+// Julia's clamp(x, lo, hi) = ifelse(x > hi, hi, ifelse(x < lo, lo, x)): a NaN passes through (the trajectory then
+// fails with retcode Unstable, as in the reference) -- fmin/fmax would silently replace it by a bound.
+__device__ __forceinline__ double clampv(double v, double lo, double hi) { return v > hi ? hi : (v < lo ? lo : v); }
+
 // 1/a: hardware seed + two Newton steps (<= 1-2 ulp; no denormal / inf special cases needed here)
 __device__ __forceinline__ double frcp(double a) {
     double x = __builtin_amdgcn_rcp(a);
@@ -226,7 +230,7 @@ __device__ __forceinline__ void features(const double (&u)[NS], double lb, doubl
     for (int i = 0; i < NS; ++i) {
         double ui = u[i];
         bool inside = (ui >= lb) && (ui <= ub);
-        double c = fmin(fmax(ui, lb), ub);
+        double c = clampv(ui, lb, ub);
         x[i] = flog(c);
         g[i] = inside ? frcp(ui) : 0.0;
     }
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
                     double v = u[i];
-                    if (prm.clamp_pred) v = fmin(fmax(v, -kc->ub), kc->ub);
+                    if (prm.clamp_pred) v = clampv(v, -kc->ub, kc->ub);
                     if (prm.pred && chunk == 0) prm.pred[((size_t)0 * N + i) * prm.B + b] = v;
                     int dr = (int)kc->drow[i];
                     if (dr >= 0) {
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                 load_row(2, dB);
                 if (HAS_T && prm.pred && chunk == 0) {
                     double v = Tconst;
-                    if (prm.clamp_pred) v = fmin(fmax(v, -kc->ub), kc->ub);
+                    if (prm.clamp_pred) v = clampv(v, -kc->ub, kc->ub);
                     prm.pred[((size_t)0 * N + NS) * prm.B + b] = v;
                 }
                 jsave = 1;
@@ -448,7 +452,8 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
         int rc = -1;  // -1: keep going; >= 0: trajectory finished with this retcode
         ++iter;
         bool last = false;
-        if (iter > prm.maxiters) rc = 1;
+        if (jsave >= nsave) rc = 0;            // horizon = tspan[1]: nothing to integrate
+        else if (iter > prm.maxiters) rc = 1;
         if (t + dt * (1.0 + 1e-13) >= tend) { dt = tend - t; last = true; }
         if (rc < 0 && (!(dt > kc->dtmin) || t + dt == t)) rc = 2;
 
@@ -581,7 +586,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                         double mask = 1.0;
                         if (prm.clamp_pred) {
                             mask = (v > kc->ub || v < -kc->ub) ? 0.0 : 1.0;
-                            v = fmin(fmax(v, -kc->ub), kc->ub);
+                            v = clampv(v, -kc->ub, kc->ub);
                         }
                         if (prm.pred && chunk == 0) prm.pred[((size_t)jsave * N + i) * prm.B + b] = v;
                         int dr = (int)kc->drow[i];
@@ -599,7 +604,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                     }
                     if (HAS_T && prm.pred && chunk == 0) {
                         double v = prm.u0[(size_t)NS * prm.B + b];
-                        if (prm.clamp_pred) v = fmin(fmax(v, -kc->ub), kc->ub);
+                        if (prm.clamp_pred) v = clampv(v, -kc->ub, kc->ub);
                         prm.pred[((size_t)jsave * N + NS) * prm.B + b] = v;
                     }
                     ++jsave;

@@ -1,0 +1,170 @@
+# julia/CRNNHip.jl -- thin `ccall` shim over libcrnn_hip.so (include/crnn_hip.h).
+#
+# STATUS: WRITTEN, NOT EXECUTED.  Julia is not installed in the build image nor on the GPU
+# boxes used for this project (`julia: command not found`), so this file has never been
+# run; the identical C ABI is exercised through Python/ctypes (crnn_amd/_lib.py) by the
+# test-suite.  It keeps the reference's script-level surface for the hot path
+# (case2/case2.jl:91-137,195-197 of DENG-MIT/CRNN):
+#
+#     p2vec(p) ; crnn!(du,u,p,t) ; prob = ODEProblem(...) ; predict_neuralode(u0, p) ;
+#     loss_neuralode(p, i_exp) ; ForwardDiff.gradient(x -> loss_neuralode(x, i_exp), p) ;
+#     update!(opt, p, grad)
+#
+# and adds the batched entry points the reference lacks (SURVEY F3):
+#     loss_and_grad(p, idxs) ; train_step!()
+module CRNNHip
+
+const LIB = get(ENV, "CRNN_HIP_LIB", joinpath(@__DIR__, "..", "crnn_amd", "csrc", "libcrnn_hip.so"))
+const MAX_N = 12
+
+# mirror of `struct crnn_config` (include/crnn_hip.h) -- field order and types must match
+mutable struct Config
+    abi_version::Int32; ns::Int32; nr::Int32; has_temp::Int32; param_map::Int32; n_save::Int32
+    loss_kind::Int32; clamp_pred::Int32; maxiters::Int32; errnorm_sens::Int32; device::Int32; cols_per_lane::Int32
+    lb::Float64; ub::Float64; inv_R::Float64; t0::Float64
+    atol::NTuple{MAX_N,Float64}; rtol::NTuple{MAX_N,Float64}; rate_scale::NTuple{MAX_N,Float64}
+    gamma::Float64; qmin::Float64; qmax::Float64; beta1::Float64; beta2::Float64
+    qsteady_min::Float64; qsteady_max::Float64; qoldinit::Float64; dtmin::Float64
+    Config() = new()
+end
+
+mutable struct Stats
+    n_traj::Int64; n_ok::Int64; n_accept::Int64; n_reject::Int64; kernel_ms::Float64
+    Stats() = new(0, 0, 0, 0, 0.0)
+end
+
+mutable struct OptConfig
+    use_expdecay::Int32; decay_step::Int32; ed_eta0::Float64; ed_decay::Float64; ed_clip::Float64
+    eta::Float64; beta1::Float64; beta2::Float64; wd::Float64; grad_clip_norm::Float64
+    OptConfig() = new()
+end
+
+const PRESET_CASE1, PRESET_CASE2, PRESET_ROBER = Int32(1), Int32(2), Int32(3)
+
+check(rc, ctx=C_NULL) = rc == 0 ? nothing :
+    error(unsafe_string(ccall((:crnn_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx)))
+
+"""`prob = ODEProblem(crnn, u0, tspan, saveat=tsteps, atol=atol, rtol=rtol)` (case2/case2.jl:120-121)."""
+mutable struct Problem
+    cfg::Config
+    ctx::Ptr{Cvoid}
+    tsteps::Vector{Float64}
+    B::Int
+end
+
+function ODEProblem(preset::Integer, tsteps::AbstractVector; atol=nothing, rtol=nothing, rate_scale=nothing, device=0)
+    cfg = Config()
+    check(ccall((:crnn_config_preset, LIB), Int32, (Ref{Config}, Int32), cfg, preset))
+    cfg.n_save = length(tsteps); cfg.device = device
+    n = cfg.ns + cfg.has_temp
+    atol === nothing || (cfg.atol = ntuple(i -> i <= n ? Float64(atol isa Number ? atol : atol[i]) : 0.0, MAX_N))
+    rtol === nothing || (cfg.rtol = ntuple(i -> i <= n ? Float64(rtol isa Number ? rtol : rtol[i]) : 0.0, MAX_N))
+    rate_scale === nothing || (cfg.rate_scale = ntuple(i -> i <= cfg.ns ? Float64(rate_scale[i]) : 1.0, MAX_N))
+    ctx = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:crnn_ctx_create, LIB), Int32, (Ref{Config}, Ref{Ptr{Cvoid}}), cfg, ctx))
+    prob = Problem(cfg, ctx[], collect(Float64, tsteps), 0)
+    finalizer(p -> ccall((:crnn_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), p.ctx), prob)
+    return prob
+end
+
+"""Upload `u0_list[n_exp, n]`, `ode_data_list[n_exp, n_obs, datasize]`, `yscale` (case2/case2.jl:62-83).
+Julia's column-major layout IS the ABI's IC-fastest layout: no copy, no transpose."""
+function set_ensemble!(prob::Problem, u0_list::Matrix{Float64}, ode_data_list::Array{Float64,3}, yscale::Vector{Float64};
+                       i_obs::Union{Nothing,Vector{Int32}}=nothing)
+    B = size(u0_list, 1)
+    n_obs = i_obs === nothing ? prob.cfg.ns : length(i_obs)
+    GC.@preserve u0_list ode_data_list yscale i_obs begin
+        check(ccall((:crnn_ctx_set_data, LIB), Int32,
+                    (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Int32, Int64),
+                    prob.ctx, u0_list, ode_data_list, prob.tsteps, yscale,
+                    i_obs === nothing ? C_NULL : pointer(i_obs), n_obs, B), prob.ctx)
+    end
+    prob.B = B
+end
+
+"""`w_in, w_b, w_out = p2vec(p)` (case2/case2.jl:91-99) plus the Jacobian d theta / d p."""
+function p2vec_jac(prob::Problem, p::Vector{Float64})
+    c = prob.cfg
+    nth = ccall((:crnn_n_theta, LIB), Int32, (Int32, Int32, Int32), c.ns, c.nr, c.has_temp)
+    th = zeros(nth); dth = zeros(nth, length(p))
+    check(ccall((:crnn_p2vec, LIB), Int32, (Int32, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                c.param_map, c.ns, c.nr, p, th, dth))
+    return th, dth
+end
+function p2vec(prob::Problem, p)
+    c = prob.cfg; n = c.ns + c.has_temp
+    th, _ = p2vec_jac(prob, p)
+    return reshape(th[1:n*c.nr], n, c.nr), th[n*c.nr+1:(n+1)*c.nr], reshape(th[(n+1)*c.nr+1:end], c.ns, c.nr)
+end
+
+function _solve(prob::Problem, th, dth, first, count, sample; want_pred=false)
+    n = prob.cfg.ns + prob.cfg.has_temp; D = length(prob.tsteps); B = prob.B
+    ndir = dth === nothing ? 0 : size(dth, 2)
+    pred = want_pred ? zeros(B, n, D) : Float64[]
+    loss = zeros(B); grad = zeros(max(ndir, 1)); ret = zeros(Int32, B); nsv = zeros(Int32, B); st = Stats()
+    GC.@preserve th dth pred loss grad ret nsv begin
+        check(ccall((:crnn_solve, LIB), Int32,
+                    (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int32, Int64, Int64, Int32, Ptr{Float64}, Ptr{Float64},
+                     Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Ref{Stats}),
+                    prob.ctx, th, dth === nothing ? C_NULL : pointer(dth), ndir, first, count, sample,
+                    want_pred ? pointer(pred) : C_NULL, loss, ndir > 0 ? pointer(grad) : C_NULL, ret, nsv, st), prob.ctx)
+    end
+    any(ret[first+1:first+count] .!= 0) && println("ode solver failed")   # robertson/rober_crnn.jl:130-134
+    return pred, loss, grad[1:ndir], ret, nsv, st
+end
+
+"""`loss_neuralode(p, i_exp)` (case2/case2.jl:132-137); `i_exp` is 1-based like the reference."""
+function loss_neuralode(prob::Problem, p, i_exp; sample=length(prob.tsteps))
+    th, _ = p2vec_jac(prob, p)
+    _, loss, = _solve(prob, th, nothing, i_exp - 1, 1, sample)
+    return loss[i_exp]
+end
+
+"""`ForwardDiff.gradient(x -> loss_neuralode(x, i_exp), p)` (case2/case2.jl:195)."""
+function gradient(prob::Problem, p, i_exp; sample=length(prob.tsteps))
+    th, dth = p2vec_jac(prob, p)
+    _, _, grad, = _solve(prob, th, dth, i_exp - 1, 1, sample)
+    return grad
+end
+
+"""Mean loss over experiments `idxs` (a contiguous range) and its gradient, one launch, device-side p2vec."""
+function loss_and_grad(prob::Problem, p::Vector{Float64}, idxs::UnitRange=1:prob.B; sample=length(prob.tsteps))
+    loss = Ref{Float64}(0.0); grad = zeros(length(p)); st = Stats()
+    check(ccall((:crnn_loss_grad, LIB), Int32,
+                (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int32, Ref{Float64}, Ptr{Float64}, Ref{Stats}),
+                prob.ctx, p, first(idxs) - 1, length(idxs), sample, loss, grad, st), prob.ctx)
+    return loss[], grad
+end
+
+"""`opt = Flux.Optimiser(ExpDecay(...), ADAMW(...))` + `update!(opt, p, grad)` (case2/case2.jl:31-32,197)."""
+mutable struct Optimiser
+    cfg::OptConfig
+    state::Vector{Float64}
+end
+function Optimiser(preset::Integer, np::Integer)
+    o = OptConfig()
+    check(ccall((:crnn_opt_preset, LIB), Int32, (Ref{OptConfig}, Int32), o, preset))
+    st = zeros(ccall((:crnn_opt_state_len, LIB), Int32, (Int32,), np))
+    check(ccall((:crnn_opt_init, LIB), Int32, (Ref{OptConfig}, Int32, Ptr{Float64}), o, np, st))
+    return Optimiser(o, st)
+end
+update!(opt::Optimiser, p::Vector{Float64}, grad::Vector{Float64}) =
+    check(ccall((:crnn_opt_update, LIB), Int32, (Ref{OptConfig}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                opt.cfg, length(p), p, grad, opt.state))
+
+"""Device-resident training (p and optimiser state stay in HBM; one all-reduce per step when a communicator is attached)."""
+train_init!(prob::Problem, opt::Optimiser, p0::Vector{Float64}) =
+    check(ccall((:crnn_train_init, LIB), Int32, (Ptr{Cvoid}, Ref{OptConfig}, Ptr{Float64}), prob.ctx, opt.cfg, p0), prob.ctx)
+function train_step!(prob::Problem; idxs::UnitRange=1:prob.B, sample=length(prob.tsteps))
+    loss = Ref{Float64}(0.0)
+    check(ccall((:crnn_train_step, LIB), Int32, (Ptr{Cvoid}, Int64, Int64, Int32, Ref{Float64}),
+                prob.ctx, first(idxs) - 1, length(idxs), sample, loss), prob.ctx)
+    return loss[]
+end
+
+# The reference's CPU baseline the north star mentions, for a Julia-equipped box (SURVEY 8(d)); also unexecuted:
+#   using OrdinaryDiffEq
+#   ens = EnsembleProblem(prob_ref; prob_func = (pr, i, _) -> remake(pr, u0 = u0_list[i, :]))
+#   @time solve(ens, Rosenbrock23(autodiff=false), EnsembleThreads(); trajectories = size(u0_list, 1), saveat = tsteps)
+
+end # module

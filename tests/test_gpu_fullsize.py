@@ -1,0 +1,263 @@
+"""GPU tests at BASELINE.json's full sizes (65 536 initial conditions) through
+size-independent properties, plus edge cases of the boundary.  The oracle cannot
+integrate 65 536 trajectories in seconds, so at full size it checks a random sample
+and the rest is covered by determinism / additivity / permutation / variant
+invariance."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import INV_R, oracle_problem
+
+pytestmark = pytest.mark.gpu
+B_FULL = 65536
+
+
+def _case2_ensemble(B, seed=1234):
+    from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE2, cases
+    rng = np.random.Generator(np.random.PCG64(seed))
+    ts = cases.case2_tsteps()
+    u0 = cases.case2_u0(B, rng)
+    gen = NeuralODE(ODEProblem(PRESET_CASE2, ts, atol=1e-10, rtol=1e-8))
+    clean = gen.predict_theta(u0, cases.case2_true_theta())[:, :6, :]
+    assert np.all(gen.last_retcode == 0)
+    gen.close()
+    data = cases.add_noise(clean, 0.05, rng)
+    return ts, u0, data, cases.max_min(data, lb=1e-6)
+
+
+@pytest.fixture(scope="module")
+def full_case2(fx):
+    ts, u0, data, ys = _case2_ensemble(B_FULL)
+    return dict(tsteps=ts, u0=u0, data=data, yscale=ys, p=np.array(fx["case2_ckpt"]["p"]), p_init=np.array(fx["case2"]["p_init"]))
+
+
+def _node(s, cols=0, **kw):
+    from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE2
+    node = NeuralODE(ODEProblem(PRESET_CASE2, s["tsteps"], cols_per_lane=cols, **kw))
+    node.set_ensemble(s["u0"], s["data"], s["yscale"])
+    return node
+
+
+def test_case2_full_batch_properties(orc, full_case2):
+    s = full_case2
+    p = s["p"]
+    node = _node(s)
+    loss, grad = node.loss_and_grad(p)
+    st = node.last_stats
+    assert st["n_traj"] == B_FULL and st["n_ok"] == B_FULL
+    assert 20 < st["n_accept"] / B_FULL < 45 and st["n_reject"] < 0.05 * st["n_accept"]
+    # the learned checkpoint explains data made from the true mechanism + 5 % noise: MAE of the order of the noise
+    assert 0.005 < loss < 0.05
+    # determinism: bitwise identical on repetition
+    loss2, grad2 = node.loss_and_grad(p)
+    assert loss2 == loss and np.array_equal(grad, grad2)
+    # additivity over sub-ranges (sums of the same per-trajectory terms, different association)
+    acc_l, acc_g = 0.0, np.zeros(25)
+    q = B_FULL // 4
+    for k in range(4):
+        l_k, g_k = node.loss_and_grad(p, first=k * q, count=q)
+        acc_l += l_k * q
+        acc_g += g_k * q
+    assert abs(acc_l / B_FULL - loss) < 1e-13 * loss
+    assert np.max(np.abs(acc_g / B_FULL - grad)) < 1e-12 * np.max(np.abs(grad))
+    # per-IC losses: mean equals the batched loss
+    losses = node.losses(p)
+    assert abs(losses.mean() - loss) < 1e-13 * loss
+    # random sample against the oracle (reference tolerances, same inputs)
+    rng = np.random.default_rng(5)
+    idx = rng.choice(B_FULL, 96, replace=False)
+    th, dth = orc.p2vec(2, 6, 3, p)
+    pb = oracle_problem(orc, "case2", s)
+    for i in idx[:96]:
+        r = orc.solve_one(pb, th, s["u0"][i], s["tsteps"], s["data"][i], dtheta=None, want_pred=False)
+        assert abs(losses[i] - r["loss"]) < 1e-9 * r["loss"]
+    for i in idx[:8]:
+        r = orc.solve_one(pb, th, s["u0"][i], s["tsteps"], s["data"][i], dtheta=dth, want_pred=False)
+        g = node.gradient(p, int(i))
+        assert np.max(np.abs(g - r["grad"])) < 1e-7 * np.max(np.abs(r["grad"]))
+    node.close()
+    # permutation of the ensemble permutes the per-IC results exactly and leaves the sums unchanged to rounding
+    perm = np.random.default_rng(9).permutation(B_FULL)
+    s2 = dict(s, u0=s["u0"][perm], data=s["data"][perm])
+    node2 = _node(s2)
+    losses2 = node2.losses(p)
+    assert np.array_equal(losses2, losses[perm])
+    lossp, gradp = node2.loss_and_grad(p)
+    assert abs(lossp - loss) < 1e-13 * loss and np.max(np.abs(gradp - grad)) < 1e-11 * np.max(np.abs(grad))
+    node2.close()
+    # a different lanes-per-trajectory variant performs the same primal arithmetic (bitwise) and the same tangents
+    node3 = _node(s, cols=5)
+    assert np.array_equal(node3.losses(p), losses)
+    loss3, grad3 = node3.loss_and_grad(p)
+    assert np.max(np.abs(grad3 - grad)) < 1e-11 * np.max(np.abs(grad))
+    node3.close()
+
+
+def test_case2_full_batch_training_decreases_loss(full_case2):
+    from crnn_amd import Optimiser, PRESET_CASE2
+    s = full_case2
+    node = _node(s)
+    node.train_init(Optimiser(25, PRESET_CASE2), s["p_init"])
+    l0 = node.train_step()
+    for _ in range(30):
+        l = node.train_step()
+    assert np.isfinite(l) and l < 0.9 * l0
+    assert node.stats()["n_ok"] == B_FULL
+    node.close()
+
+
+def test_robertson_full_batch(orc, fx):
+    """BASELINE config 3: robertson, 65 536 ICs, stiff: every trajectory succeeds, sample matches the oracle."""
+    from crnn_amd import NeuralODE, ODEProblem, PRESET_ROBER, cases
+    rng = np.random.Generator(np.random.PCG64(77))
+    B = B_FULL
+    ts = cases.rober_tsteps()
+    u0 = cases.rober_u0(B, rng)
+    th3 = cases.rober_true_theta()
+    w_in = np.zeros((3, 6)); w_b = np.full(6, -700.0); w_out = np.zeros((3, 6))
+    w_in[:, :3] = th3[:9].reshape((3, 3), order="F"); w_b[:3] = th3[9:12]; w_out[:, :3] = th3[12:].reshape((3, 3), order="F")
+    gen = NeuralODE(ODEProblem(PRESET_ROBER, ts, atol=1e-12, rtol=1e-7, maxiters=10**6, lb=1e-300))
+    clean = gen.predict_theta(u0, cases.pack_theta(w_in, w_b, w_out))
+    assert np.all(gen.last_retcode == 0)
+    gen.close()
+    # mass conservation of the true mechanism: y1 + y2 + y3 is invariant (size-independent property)
+    tot0 = u0.sum(axis=1)
+    assert np.max(np.abs(clean.sum(axis=1) - tot0[:, None])) < 1e-6
+    data = cases.add_noise(clean, 1e-4, rng)
+    ys = cases.max_min(data)
+    dydt = ys / ts[-1]
+    p = np.array(fx["rober_ckpt"]["p"])
+    node = NeuralODE(ODEProblem(PRESET_ROBER, ts, rate_scale=dydt))
+    node.set_ensemble(u0, data, ys)
+    loss, grad = node.loss_and_grad(p)
+    st = node.last_stats
+    assert st["n_ok"] == B and np.isfinite(loss) and np.all(np.isfinite(grad))
+    losses = node.losses(p)
+    th, dth = orc.p2vec(3, 3, 6, p)
+    pb = orc.make_problem(ns=3, nr=6, lb=1e-8, atol=[1e-6, 1e-8, 1e-6], rtol=1e-3, yscale=ys, rate_scale=dydt, maxiters=10000)
+    idx = np.random.default_rng(3).choice(B, 48, replace=False)
+    for i in idx:
+        r = orc.solve_one(pb, th, u0[i], ts, data[i], want_pred=False)
+        assert r["retcode"] == 0
+        # stiff steps amplify last-bit differences (exp/log implementations, fused multiply-adds)
+        assert abs(losses[i] - r["loss"]) < 1e-7 * r["loss"]
+    for i in idx[:4]:
+        r = orc.solve_one(pb, th, u0[i], ts, data[i], dtheta=dth, want_pred=False)
+        g = node.gradient(p, int(i))
+        assert np.max(np.abs(g - r["grad"])) < 1e-6 * np.max(np.abs(r["grad"]))
+    node.close()
+
+
+# ------------------------------------------------------------------ edge cases
+def test_tiny_and_ragged_batches(orc, case2_setup):
+    s = case2_setup
+    p = s["p_ckpt"]
+    th, dth = orc.p2vec(2, 6, 3, p)
+    pb = oracle_problem(orc, "case2", s)
+    ref = [orc.solve_one(pb, th, s["u0"][i], s["tsteps"], s["data"][i], dtheta=dth) for i in range(8)]
+    for B in (1, 3, 5):
+        sub = dict(s, u0=s["u0"][:B], data=s["data"][:B])
+        node = _node(sub)
+        loss, grad = node.loss_and_grad(p)
+        assert abs(loss - np.mean([r["loss"] for r in ref[:B]])) < 1e-9 * loss
+        g = np.mean([r["grad"] for r in ref[:B]], axis=0)
+        assert np.max(np.abs(grad - g)) < 1e-7 * np.max(np.abs(g))
+        # last element alone
+        l1, g1 = node.loss_and_grad(p, first=B - 1, count=1)
+        assert abs(l1 - ref[B - 1]["loss"]) < 1e-9 * l1
+        node.close()
+
+
+def test_observation_mask_and_mse(orc, case2_setup):
+    """i_obs = [1,2,4,5,6] as in case2_missing.jl:165 (0-based here) and the MSE loss kind."""
+    from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE2
+    s = case2_setup
+    p = s["p_ckpt"]
+    i_obs = [0, 1, 3, 4, 5]
+    data = s["data"][:, i_obs, :]
+    ys = s["yscale"][i_obs]
+    node = NeuralODE(ODEProblem(PRESET_CASE2, s["tsteps"]))
+    node.set_ensemble(s["u0"], data, ys, i_obs=i_obs)
+    loss, grad = node.loss_and_grad(p)
+    th, dth = orc.p2vec(2, 6, 3, p)
+    pb = orc.make_problem(ns=6, nr=3, has_temp=1, lb=1e-6, ub=10.0, inv_R=INV_R, atol=1e-6, rtol=1e-3, yscale=ys,
+                          i_obs=i_obs, clamp_pred=1)
+    rs = [orc.solve_one(pb, th, s["u0"][i], s["tsteps"], data[i], dtheta=dth) for i in range(8)]
+    assert abs(loss - np.mean([r["loss"] for r in rs])) < 1e-9 * loss
+    g = np.mean([r["grad"] for r in rs], axis=0)
+    assert np.max(np.abs(grad - g)) < 1e-7 * np.max(np.abs(g))
+    node.close()
+    # MSE
+    from crnn_amd import LOSS_MSE
+    node = NeuralODE(ODEProblem(PRESET_CASE2, s["tsteps"], loss_kind=LOSS_MSE))
+    node.set_ensemble(s["u0"], s["data"], s["yscale"])
+    loss, grad = node.loss_and_grad(p)
+    pb = orc.make_problem(ns=6, nr=3, has_temp=1, lb=1e-6, ub=10.0, inv_R=INV_R, atol=1e-6, rtol=1e-3,
+                          yscale=s["yscale"], clamp_pred=1, loss_kind=1)
+    rs = [orc.solve_one(pb, th, s["u0"][i], s["tsteps"], s["data"][i], dtheta=dth) for i in range(8)]
+    assert abs(loss - np.mean([r["loss"] for r in rs])) < 1e-9 * loss
+    g = np.mean([r["grad"] for r in rs], axis=0)
+    assert np.max(np.abs(grad - g)) < 1e-7 * np.max(np.abs(g))
+    node.close()
+
+
+def test_non_finite_and_dtmin_failures_are_per_trajectory(case2_setup):
+    from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE2, RET_DTMIN, RET_UNSTABLE
+    s = case2_setup
+    p = s["p_ckpt"]
+    u0 = s["u0"].copy()
+    u0[2, 0] = np.nan
+    node = NeuralODE(ODEProblem(PRESET_CASE2, s["tsteps"]))
+    node.set_ensemble(u0, s["data"], s["yscale"])
+    losses = node.losses(p)
+    assert node.last_retcode[2] == RET_UNSTABLE and np.all(np.delete(node.last_retcode, 2) == 0)
+    assert node.last_n_saved[2] == 1          # only the save_start column exists
+    loss, grad = node.loss_and_grad(p)
+    assert node.last_stats["n_ok"] == 7
+    assert np.isnan(losses[2]) and np.isnan(loss) and np.all(np.isfinite(np.delete(losses, 2)))
+    # the failed trajectory's gradient row is zero (its tangents never advanced); the others are unaffected
+    assert np.all(node.gradient(p, 2) == 0.0)
+    g_ok = sum(node.gradient(p, i) for i in range(8) if i != 2)
+    assert np.max(np.abs(g_ok / 8 - grad)) < 1e-12 * np.max(np.abs(grad))
+    node.close()
+    # dtmin larger than any step the controller wants: DtLessThanMin
+    node = NeuralODE(ODEProblem(PRESET_CASE2, s["tsteps"], dtmin=1e3))
+    node.set_ensemble(s["u0"], s["data"], s["yscale"])
+    node.losses(p)
+    assert np.all(node.last_retcode == RET_DTMIN)
+    node.close()
+
+
+def test_zero_length_horizon_and_argument_errors(case2_setup):
+    from crnn_amd import CrnnError, NeuralODE, ODEProblem, PRESET_CASE2
+    s = case2_setup
+    p = s["p_ckpt"]
+    node = _node(s)
+    # sample = 1: the horizon is tspan[1] itself -> only the save_start column, success
+    pred = node.predict_neuralode(s["u0"][0], p, sample=1)
+    assert pred.shape == (7, 1) and np.all(node.last_retcode == 0)
+    assert np.allclose(pred[:6, 0], np.clip(s["u0"][0][:6], -10, 10))
+    with pytest.raises(CrnnError, match="n_save_active"):
+        node.loss_and_grad(p, sample=51)
+    with pytest.raises(CrnnError, match="outside the ensemble"):
+        node.loss_and_grad(p, first=4, count=5)
+    with pytest.raises(CrnnError, match="strictly increasing"):
+        bad = NeuralODE(ODEProblem(PRESET_CASE2, s["tsteps"][::-1].copy()))
+        bad.set_ensemble(s["u0"], s["data"], s["yscale"])
+    node.close()
+
+
+def test_theta_level_directions(orc, case2_setup):
+    """crnn_solve with an arbitrary direction matrix: identity in theta space (42 directions, the (7,6) variant)."""
+    from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE2
+    s = case2_setup
+    th, dth = orc.p2vec(2, 6, 3, s["p_ckpt"])
+    node = _node(s)
+    eye = np.eye(42, order="F")
+    _, _, g_theta, _, _ = node._solve(node._ctx, 8, th, eye, 0, 8, None, False)
+    _, _, g_p, _, _ = node._solve(node._ctx, 8, th, dth, 0, 8, None, False)
+    # chain rule on the host: grad_p = (d theta / d p)^T grad_theta
+    assert np.max(np.abs(dth.T @ g_theta - g_p)) < 1e-10 * np.max(np.abs(g_p))
+    node.close()
