@@ -40,6 +40,18 @@ FLOP_PRIMAL_STEP = 2 * 1480      # one Rosenbrock23 attempt: 12 log, 6 exp, 12 r
 FLOP_COL_STEP = 2 * 441          # one tangent column through one accepted step
 
 
+def usable_cores():
+    """host cores this process may actually use: min(affinity mask, cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,7 +192,7 @@ def main():
                                   yscale=yscale, clamp_pred=1)
             u0_s = np.ascontiguousarray(u0[:ns_].T)
             data_s = np.ascontiguousarray(data[:ns_].transpose(2, 1, 0))
-            cores = os.cpu_count() or 1
+            cores = usable_cores()
             orc.solve_batch(pb, th, u0_s[:, :256].copy(), ts, data_s[:, :, :256].copy(), dtheta=dth, nthreads=cores)  # warm-up
             tc = time.perf_counter()
             orc.solve_batch(pb, th, u0_s, ts, data_s, dtheta=dth, nthreads=cores)

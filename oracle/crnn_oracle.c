@@ -396,11 +396,12 @@ static double init_dt(const orc_problem *pb, const double *th, const double *u0,
 /* ------------------------------------------------------------------------ */
 typedef struct orc_stats { int64_t naccept, nreject; } orc_stats;
 
-int orc_solve_one(const orc_problem *pb, const double *th, const double *dth, int P,
-                  const double *u0, const double *tsave, int nsave,
-                  const double *data, double *pred, double *dpred,
-                  double *loss_out, double *grad /* [P] accumulated += */,
-                  int32_t *n_saved_out, orc_stats *st) {
+/* workspace: n*P*7 + P doubles (zeroed here) */
+static int solve_one_ws(const orc_problem *pb, const double *th, const double *dth, int P,
+                        const double *u0, const double *tsave, int nsave,
+                        const double *data, double *pred, double *dpred,
+                        double *loss_out, double *grad /* [P] accumulated += */,
+                        int32_t *n_saved_out, orc_stats *st, double *ws) {
     const int n = N_(pb), nobs = pb->n_obs;
     const int nth = orc_n_theta(pb);
     const double d = 1.0 / (2.0 + sqrt(2.0));
@@ -410,10 +411,11 @@ int orc_solve_one(const orc_problem *pb, const double *th, const double *dth, in
     double u[ORC_MAXN], f0[ORC_MAXN];
     double *S = NULL, *dk1 = NULL, *dk2 = NULL, *dk3 = NULL, *Snew = NULL, *gtr = NULL, *df0 = NULL, *df2 = NULL;
     if (P > 0) {
-        S = (double *)calloc((size_t)n * P * 7, sizeof(double));
+        memset(ws, 0, sizeof(double) * ((size_t)n * P * 7 + P));
+        S = ws;
         Snew = S + (size_t)n * P; dk1 = Snew + (size_t)n * P; dk2 = dk1 + (size_t)n * P;
         dk3 = dk2 + (size_t)n * P; df0 = dk3 + (size_t)n * P; df2 = df0 + (size_t)n * P;
-        gtr = (double *)calloc((size_t)P, sizeof(double));
+        gtr = ws + (size_t)n * P * 7;
     }
     memcpy(u, u0, sizeof(double) * n);
     orc_rhs(pb, th, u, f0);
@@ -582,8 +584,19 @@ int orc_solve_one(const orc_problem *pb, const double *th, const double *dth, in
     if (loss_out) *loss_out = loss;
     if (n_saved_out) *n_saved_out = jsave;
     if (grad && jsave > 0) for (int k = 0; k < P; ++k) grad[k] += gtr[k] / denom;
-    if (P > 0) { free(S); free(gtr); }
     return retcode;
+}
+
+int orc_solve_one(const orc_problem *pb, const double *th, const double *dth, int P,
+                  const double *u0, const double *tsave, int nsave,
+                  const double *data, double *pred, double *dpred,
+                  double *loss_out, double *grad /* [P] accumulated += */,
+                  int32_t *n_saved_out, orc_stats *st) {
+    const int n = N_(pb);
+    double *ws = P > 0 ? (double *)malloc(sizeof(double) * ((size_t)n * P * 7 + P)) : NULL;
+    int rc = solve_one_ws(pb, th, dth, P, u0, tsave, nsave, data, pred, dpred, loss_out, grad, n_saved_out, st, ws);
+    free(ws);
+    return rc;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -608,7 +621,8 @@ int orc_solve_batch(const orc_problem *pb, const double *th, const double *dth, 
         double *g_loc = P > 0 ? (double *)calloc((size_t)P, sizeof(double)) : NULL;
         double *d_loc = (double *)malloc(sizeof(double) * (size_t)nobs * nsave);
         double *p_loc = pred ? (double *)malloc(sizeof(double) * (size_t)n * nsave) : NULL;
-#pragma omp for schedule(dynamic, 16)
+        double *ws = (grad && P > 0) ? (double *)malloc(sizeof(double) * ((size_t)n * P * 7 + P)) : NULL;
+#pragma omp for schedule(dynamic, 8)
         for (int64_t b = first; b < first + count; ++b) {
             double u[ORC_MAXN];
             for (int i = 0; i < n; ++i) u[i] = u0[(size_t)i * B + b];
@@ -617,7 +631,7 @@ int orc_solve_batch(const orc_problem *pb, const double *th, const double *dth, 
             orc_stats st = {0, 0};
             double l = 0; int32_t ns_ = 0;
             if (p_loc) memset(p_loc, 0, sizeof(double) * (size_t)n * nsave);
-            int rc = orc_solve_one(pb, th, dth, grad ? P : 0, u, tsave, nsave, d_loc, p_loc, NULL, &l, g_loc, &ns_, &st);
+            int rc = solve_one_ws(pb, th, dth, grad ? P : 0, u, tsave, nsave, d_loc, p_loc, NULL, &l, g_loc, &ns_, &st, ws);
             if (loss) loss[b] = l;
             if (retcode) retcode[b] = rc;
             if (n_saved) n_saved[b] = ns_;
@@ -626,7 +640,7 @@ int orc_solve_batch(const orc_problem *pb, const double *th, const double *dth, 
         }
 #pragma omp critical
         { if (grad && g_loc) for (int k = 0; k < P; ++k) grad[k] += g_loc[k]; }
-        free(g_loc); free(d_loc); free(p_loc);
+        free(g_loc); free(d_loc); free(p_loc); free(ws);
     }
     if (stats) { stats[0] = acc; stats[1] = rej; }
     return 0;
