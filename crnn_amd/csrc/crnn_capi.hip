@@ -84,6 +84,7 @@ struct Ctx {
     double *d_gtraj = nullptr;
     size_t gtraj_cap = 0;
     crnn::KConst *d_kc = nullptr;
+    unsigned long long *d_queue = nullptr;
     bool kc_dirty = true;
     // weights
     double *d_theta = nullptr, *d_dtheta = nullptr;  // [n_theta], [n_theta * max_dir]
@@ -231,7 +232,9 @@ int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int 
     prm.maxiters = c->cfg.maxiters; prm.clamp_pred = c->cfg.clamp_pred; prm.loss_kind = c->cfg.loss_kind;
     prm.n_obs = c->n_obs;
     prm.kc = c->d_kc;
+    prm.queue = c->d_queue;
     if (upload_consts(c)) return -1;
+    HIP_TRY(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), c->stream));
 
     c->ev0 = c->ring0[c->n_launch % Ctx::kRing];
     c->ev1 = c->ring1[c->n_launch % Ctx::kRing];
@@ -389,6 +392,7 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
         hipMalloc((void **)&c->d_dtheta, sizeof(double) * (size_t)c->n_theta * c->max_dir) != hipSuccess ||
         hipMalloc((void **)&c->d_tsave, sizeof(double) * cfg->n_save) != hipSuccess ||
         hipMalloc((void **)&c->d_kc, sizeof(crnn::KConst)) != hipSuccess ||
+        hipMalloc((void **)&c->d_queue, sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void **)&c->d_p, sizeof(double) * c->n_params) != hipSuccess ||
         hipMalloc((void **)&c->d_opt, sizeof(double) * (2 * c->n_params + 4)) != hipSuccess)
         return bail("crnn_ctx_create: hipMalloc failed");
@@ -404,7 +408,7 @@ void crnn_ctx_destroy(crnn_ctx *ctx) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->own_u0 && c->d_u0) (void)hipFree(c->d_u0);
     if (c->own_data && c->d_data) (void)hipFree(c->d_data);
-    void *ptrs[] = {c->d_nacc, c->d_nrej, c->d_gtraj, c->d_kc, c->d_tsave, c->d_pred, c->d_loss, c->d_ret, c->d_nsaved, c->d_theta, c->d_dtheta,
+    void *ptrs[] = {c->d_queue, c->d_nacc, c->d_nrej, c->d_gtraj, c->d_kc, c->d_tsave, c->d_pred, c->d_loss, c->d_ret, c->d_nsaved, c->d_theta, c->d_dtheta,
                     c->d_partials, c->d_red, c->d_p, c->d_opt, c->d_comm_buf};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < Ctx::kRing; ++i) {

@@ -64,6 +64,7 @@ struct SolveParams {
     int32_t *n_reject;     // [B]
     double *gtraj;         // [count][L*C] per-trajectory gradient rows (row = trajectory - first)
     const KConst *kc;
+    unsigned long long *queue;  // work queue head (zeroed before the launch): next unassigned trajectory - #groups
     int64_t B, first, count;
     int32_t n_save;        // active save points
     int32_t P;             // tangent directions
@@ -315,9 +316,21 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
     __syncthreads();
     const KConst *kc = reinterpret_cast<const KConst *>(kc_lds);
 
+    // Work distribution: the first #groups trajectories are assigned statically; afterwards a group takes the next
+    // unassigned trajectory from a global queue (one atomic per trajectory, issued a whole trajectory ahead of use so
+    // its latency is hidden).  Per-trajectory results do not depend on who computes them, so this stays deterministic.
     const int64_t ngroups = (int64_t)gridDim.x * WAVES * GPW;
     int64_t traj = ((int64_t)blockIdx.x * WAVES + wave) * GPW + grp;
     if (!lane_active) traj = prm.count;
+    auto fetch_next = [&]() -> int64_t {
+        unsigned long long v = 0;
+        if (lead) v = atomicAdd(prm.queue, 1ULL);
+        const int src = grp * L;
+        const unsigned lo = (unsigned)__shfl((int)(unsigned)v, src);
+        const unsigned hi = (unsigned)__shfl((int)(unsigned)(v >> 32), src);
+        return (int64_t)(((unsigned long long)hi << 32) | lo) + ngroups;
+    };
+    int64_t traj_next = lane_active ? fetch_next() : prm.count;
 
     const double *__restrict__ th = theta;
     const double d_ = 0.29289321881345248;    // 1/(2+sqrt 2)
@@ -802,7 +815,8 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
 #pragma unroll
                 for (int q_ = 0; q_ < C; ++q_) grow[q_] = gtr[q_] * inv_den;
             }
-            traj += ngroups;
+            traj = traj_next;
+            traj_next = fetch_next();
             need_init = true;
         }
     }
