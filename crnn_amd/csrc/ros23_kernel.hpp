@@ -265,6 +265,110 @@ __device__ __forceinline__ void rhs_from_rates(const double *__restrict__ th, co
 }
 
 // ---------------------------------------------------------------------------
+// W = I - gam*J solvers.  J = A B^T with A[i][j] = sc_i w_out[i,j] r_j (ns x nr), B^T[j][c] = w_in[c,j] g_c (nr x ns).
+//   DenseLU   : builds W (ns x ns), LU with partial pivoting, triangular solves        (ns <= nr: robertson)
+//   Woodbury  : W^-1 = I + gam A (I_nr - gam B^T A)^-1 B^T; only the nr x nr matrix M is factored (pivoted LU);
+//               a solve costs the same ~57 operations but the factorisation is 4x cheaper and the state that
+//               must survive the tangent phase shrinks from 48 to 15 doubles per lane       (nr < ns: case1, case2)
+// Both are algebraically the reference's `W \ b`; they differ from it (and from each other) only by rounding.
+// ---------------------------------------------------------------------------
+template <int NS, int NR, bool HAS_T, bool USE_SCALE>
+struct DenseLU {
+    using L_ = Lay<NS, NR, HAS_T>;
+    double A[NS][NS], dinv[NS];
+    int piv[NS];
+    bool wave_pivots;
+    __device__ __forceinline__ bool factor(const double *__restrict__ th, const double (&g)[NS], const double (&r)[NR],
+                                           const double gam, const double *sc_s) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            double a[NR];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                a[j] = th[L_::wo(i, j)] * r[j];
+                if (USE_SCALE) a[j] *= sc_s[i];
+            }
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+                double s_ = 0.0;
+#pragma unroll
+                for (int j = 0; j < NR; ++j) s_ = fma(a[j], th[L_::wi(c, j)], s_);
+                A[i][c] = ((i == c) ? 1.0 : 0.0) - gam * (s_ * g[c]);
+            }
+        }
+        bool anyp;
+        const bool ok = lu_factor<NS>(A, dinv, piv, anyp);
+        wave_pivots = __builtin_amdgcn_ballot_w64(anyp) != 0;
+        return ok;
+    }
+    // g, gr (= gam * r) are unused here; the signature is shared with Woodbury
+    __device__ __forceinline__ void solve(const double *__restrict__, const double (&)[NS], const double (&)[NR],
+                                          const double *, double (&b)[NS]) const {
+        lu_solve<NS>(A, dinv, piv, wave_pivots, b);
+    }
+};
+
+template <int NS, int NR, bool HAS_T, bool USE_SCALE>
+struct Woodbury {
+    using L_ = Lay<NS, NR, HAS_T>;
+    double M[NR][NR], dinv[NR];
+    int piv[NR];
+    bool wave_pivots;
+    __device__ __forceinline__ bool factor(const double *__restrict__ th, const double (&g)[NS], const double (&r)[NR],
+                                           const double gam, const double *sc_s) {
+        // M[j][l] = delta_jl - gam r_l sum_c w_in[c,j] g_c sc_c w_out[c,l]
+        double gsc[NS];
+#pragma unroll
+        for (int c = 0; c < NS; ++c) gsc[c] = USE_SCALE ? g[c] * sc_s[c] : g[c];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            double t[NS];
+#pragma unroll
+            for (int c = 0; c < NS; ++c) t[c] = th[L_::wi(c, j)] * gsc[c];
+#pragma unroll
+            for (int l = 0; l < NR; ++l) {
+                double s_ = 0.0;
+#pragma unroll
+                for (int c = 0; c < NS; ++c) s_ = fma(t[c], th[L_::wo(c, l)], s_);
+                M[j][l] = ((j == l) ? 1.0 : 0.0) - (gam * r[l]) * s_;
+            }
+        }
+        bool anyp;
+        const bool ok = lu_factor<NR>(M, dinv, piv, anyp);
+        wave_pivots = __builtin_amdgcn_ballot_w64(anyp) != 0;
+        return ok;
+    }
+    // b <- W^-1 b = b + sc .* ( w_out (gr .* M^-1 (w_in^T (g .* b))) ),  gr = gam * r
+    __device__ __forceinline__ void solve(const double *__restrict__ th, const double (&g)[NS], const double (&gr)[NR],
+                                          const double *sc_s, double (&b)[NS]) const {
+        double y[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) y[j] = 0.0;
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {
+            const double t = g[c] * b[c];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) y[j] = fma(th[L_::wi(c, j)], t, y[j]);
+        }
+        lu_solve<NR>(M, dinv, piv, wave_pivots, y);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) y[j] *= gr[j];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            double a = 0.0;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) a = fma(th[L_::wo(i, j)], y[j], a);
+            b[i] = USE_SCALE ? fma(a, sc_s[i], b[i]) : b[i] + a;
+        }
+    }
+};
+
+template <bool WB, int NS, int NR, bool HAS_T, bool USE_SCALE>
+struct SolverSel { using type = DenseLU<NS, NR, HAS_T, USE_SCALE>; };
+template <int NS, int NR, bool HAS_T, bool USE_SCALE>
+struct SolverSel<true, NS, NR, HAS_T, USE_SCALE> { using type = Woodbury<NS, NR, HAS_T, USE_SCALE>; };
+
+// ---------------------------------------------------------------------------
 // the fused solve + loss + tangent kernel
 //   C = tangent columns per lane, L = lanes per trajectory (C = 0, L = 1: primal only)
 // Per-trajectory outputs (loss, retcode, n_saved, step counts, gradient row); the
@@ -473,37 +577,20 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
         bool accept = false;
         double q = 1.0, lq11 = 0.0, lEE = 0.0;
         bool ee_zero = false;
-        double LU[NS][NS], dinv[NS];
-        int piv[NS];
-        bool wave_pivots = false;
+        typename SolverSel<(NR < NS), NS, NR, HAS_T, USE_SCALE>::type W;
+        W.wave_pivots = false;
         const double gam = d_ * dt;
         const int pcur = par ? R_::PB : 0, pnxt = par ? 0 : R_::PB;
+        double gr0[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) gr0[j] = gam * r0[j];
         if (rc < 0) {
             double k1[NS], dk[NS], unew[NS], f2[NS];
-            // W = I - gam*J,  J[i][c] = sc_i g_c sum_j w_out[i,j] r_j w_in[c,j]
-#pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                double a[NR];
-#pragma unroll
-                for (int j = 0; j < NR; ++j) {
-                    a[j] = th[L_::wo(i, j)] * r0[j];
-                    if (USE_SCALE) a[j] *= kc->scale[i];
-                }
-#pragma unroll
-                for (int c = 0; c < NS; ++c) {
-                    double s_ = 0.0;
-#pragma unroll
-                    for (int j = 0; j < NR; ++j) s_ = fma(a[j], th[L_::wi(c, j)], s_);
-                    LU[i][c] = ((i == c) ? 1.0 : 0.0) - gam * (s_ * g0[c]);
-                }
-            }
-            bool anyp;
-            bool okf = lu_factor<NS>(LU, dinv, piv, anyp);
-            wave_pivots = __builtin_amdgcn_ballot_w64(anyp) != 0;
+            const bool okf = W.factor(th, g0, r0, gam, kc->scale);
             // stage 1
 #pragma unroll
             for (int i = 0; i < NS; ++i) k1[i] = f0[i];
-            lu_solve<NS>(LU, dinv, piv, wave_pivots, k1);
+            W.solve(th, g0, gr0, kc->scale, k1);
             double f1[NS];
             {
                 double u1[NS], x1[NS], g1[NS], r1[NR];
@@ -522,7 +609,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
             // stage 2
 #pragma unroll
             for (int i = 0; i < NS; ++i) dk[i] = f1[i] - k1[i];
-            lu_solve<NS>(LU, dinv, piv, wave_pivots, dk);
+            W.solve(th, g0, gr0, kc->scale, dk);
 #pragma unroll
             for (int i = 0; i < NS; ++i) unew[i] = fma(dt, k1[i] + dk[i], u[i]);
             double g2[NS], r2[NR];
@@ -550,7 +637,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                 double k2i = k1[i] + dk[i];
                 k3[i] = f2[i] - c32 * (k2i - f1[i]) - 2.0 * (k1[i] - f0[i]);
             }
-            lu_solve<NS>(LU, dinv, piv, wave_pivots, k3);
+            W.solve(th, g0, gr0, kc->scale, k3);
             double es = 0.0;
             bool finite = okf;
 #pragma unroll
@@ -653,7 +740,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                         for (int j = 0; j < NR; ++j) {
                             rec[(R_::C1J + j) * GPW] = c1j[j];
                             rec[(R_::CZD + j) * GPW] = czd[j];
-                            rec[(R_::GR0 + j) * GPW] = gam * r0[j];
+                            rec[(R_::GR0 + j) * GPW] = gr0[j];
                         }
                     }
                 }
@@ -672,7 +759,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
             ++nacc;
             // ==============================================================
             // TANGENT phase: forward tangents of the accepted step, C columns per lane.
-            // Operands stream from the group's step record; only LU/dinv/piv stay in registers.
+            // Operands stream from the group's step record; only the factored W stays in registers.
             // ==============================================================
 #ifdef CRNN_DBG_SKIP_TANGENT
             if (false) {
@@ -686,6 +773,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                     double *Sq = S_s + qc * NS * 64;
                     // ---- pass 1 (species-major): e0_j, theta-direct part of e1_j, z'_j(k1), z'_j(dk) ----
                     double e0[NR], e1d[NR], zp1[NR], zpd[NR];
+                    double gq[NS], grq[NR];   // g at u_n and gam*r at u_n: operands of the W solves
 #pragma unroll
                     for (int j = 0; j < NR; ++j) {
                         double e = dcol[L_::wb(j)];
@@ -696,6 +784,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                     for (int c = 0; c < NS; ++c) {
                         const double sc_ = Sq[c * 64];
                         const double g = rec[(pcur + R_::G0 + c) * GPW];
+                        gq[c] = g;
                         const double x0c = rec[(pcur + R_::X0 + c) * GPW];
                         const double x1c = rec[(R_::X1 + c) * GPW];
                         const double k1c = rec[(R_::K1 + c) * GPW];
@@ -722,6 +811,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                     for (int j = 0; j < NR; ++j) {
                         const double r0j = rec[(pcur + R_::R0 + j) * GPW], r1j = rec[(R_::R1 + j) * GPW];
                         const double gr = rec[(R_::GR0 + j) * GPW];
+                        grq[j] = gr;
                         const double c1 = rec[(R_::C1J + j) * GPW], cz = rec[(R_::CZD + j) * GPW];
                         const double y1 = gr * zp1[j], yd = gr * zpd[j];
 #pragma unroll
@@ -741,7 +831,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                         for (int i = 0; i < NS; ++i) { double sc = kc->scale[i]; rhs1[i] *= sc; w2[i] *= sc; }
                     }
                     // W k1' = f0' + gam (J' k1)
-                    lu_solve<NS>(LU, dinv, piv, wave_pivots, rhs1);  // rhs1 now holds k1'
+                    W.solve(th, gq, grq, kc->scale, rhs1);  // rhs1 now holds k1'
                     // f1' at u1 with s1 = s + dt/2 k1'
                     double gs1[NS];
 #pragma unroll
@@ -761,7 +851,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                     // W (k2-k1)' = f1' - k1' + gam J'(k2-k1)
 #pragma unroll
                     for (int i = 0; i < NS; ++i) rhs2[i] = (USE_SCALE ? rhs2[i] * kc->scale[i] : rhs2[i]) - rhs1[i] + w2[i];
-                    lu_solve<NS>(LU, dinv, piv, wave_pivots, rhs2);
+                    W.solve(th, gq, grq, kc->scale, rhs2);
                     double acc = 0.0;
 #pragma unroll
                     for (int i = 0; i < NS; ++i) {
