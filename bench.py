@@ -113,10 +113,28 @@ def main():
     p0 = np.array(fx["case2_ckpt"]["p"]) if args.theta0 == "ckpt" else cases.case2_init_p(np.random.Generator(np.random.PCG64(7)))
     node.train_init(Optimiser(25, PRESET_CASE2), p0)
 
+    # The in-library ncclAllReduce (crnn_comm_init) is the default; if its self-test does not pass on this node the
+    # run switches -- loudly -- to torch.distributed's all_reduce (the same RCCL) on the library's device buffer.
     comm = args.comm
-    dp = DataParallel(node, comm=comm)
-    if not dp.selftest():
-        raise SystemExit(f"rank {rank}: all-reduce self-test failed on comm={comm}")
+    dp = None
+    try:
+        dp = DataParallel(node, comm=comm)
+        ok = dp.selftest()
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench] rank {rank}: comm={comm} failed to initialise: {e}", file=sys.stderr, flush=True)
+        ok = False
+    if world > 1:
+        flag = torch.tensor([1.0 if ok else 0.0], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item() > 0.5)
+    if not ok:
+        if comm == "torch":
+            raise SystemExit(f"rank {rank}: all-reduce self-test failed on comm=torch")
+        print(f"[bench] rank {rank}: comm=rccl self-test failed, falling back to comm=torch", file=sys.stderr, flush=True)
+        comm = "torch"
+        dp = DataParallel(node, comm=comm)
+        if not dp.selftest():
+            raise SystemExit(f"rank {rank}: all-reduce self-test failed on comm=torch")
 
     def sync_all():
         check(lib.crnn_synchronize(node.handle), node.handle)
