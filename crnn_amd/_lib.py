@@ -18,6 +18,7 @@ PMAP_IDENTITY, PMAP_CASE1, PMAP_CASE2, PMAP_ROBER = 0, 1, 2, 3
 LOSS_MAE, LOSS_MSE = 0, 1
 RET_SUCCESS, RET_MAXITERS, RET_DTMIN, RET_UNSTABLE = 0, 1, 2, 3
 PRESET_CASE1, PRESET_CASE2, PRESET_ROBER = 1, 2, 3
+SOLVER_ROSENBROCK23, SOLVER_TSIT5 = 0, 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcrnn_hip.so")
@@ -28,6 +29,7 @@ class Config(C.Structure):
         ("abi_version", C.c_int32), ("ns", C.c_int32), ("nr", C.c_int32), ("has_temp", C.c_int32),
         ("param_map", C.c_int32), ("n_save", C.c_int32), ("loss_kind", C.c_int32), ("clamp_pred", C.c_int32),
         ("maxiters", C.c_int32), ("errnorm_sens", C.c_int32), ("device", C.c_int32), ("cols_per_lane", C.c_int32),
+        ("solver", C.c_int32), ("reserved0", C.c_int32),
         ("lb", C.c_double), ("ub", C.c_double), ("inv_R", C.c_double), ("t0", C.c_double),
         ("atol", C.c_double * MAX_N), ("rtol", C.c_double * MAX_N), ("rate_scale", C.c_double * MAX_N),
         ("gamma", C.c_double), ("qmin", C.c_double), ("qmax", C.c_double), ("beta1", C.c_double),
@@ -56,9 +58,11 @@ _IP = C.POINTER(C.c_int32)
 _CTX = C.c_void_p
 SYMBOLS = {
     "crnn_abi_version": (C.c_int32, []),
+    "crnn_sizeof": (C.c_int32, [C.c_int32]),
     "crnn_last_error": (C.c_char_p, [_CTX]),
     "crnn_config_preset": (C.c_int32, [C.POINTER(Config), C.c_int32]),
     "crnn_opt_preset": (C.c_int32, [C.POINTER(OptConfig), C.c_int32]),
+    "crnn_config_set_solver": (C.c_int32, [C.POINTER(Config), C.c_int32]),
     "crnn_n_params": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "crnn_n_theta": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "crnn_p2vec": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, _DP, _DP, _DP]),
@@ -102,6 +106,9 @@ def _load():
         fn.argtypes = args
     if lib.crnn_abi_version() != ABI_VERSION:
         raise ImportError(f"libcrnn_hip.so ABI {lib.crnn_abi_version()} != binding ABI {ABI_VERSION}")
+    for which, cls in enumerate((Config, Stats, OptConfig)):
+        if lib.crnn_sizeof(which) != C.sizeof(cls):
+            raise ImportError(f"struct layout mismatch for {cls.__name__}: C {lib.crnn_sizeof(which)} != ctypes {C.sizeof(cls)}")
     return lib
 
 

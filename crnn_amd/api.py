@@ -135,6 +135,7 @@ class ODEProblem:
     lb: float | None = None       # log-clamp window overrides
     ub: float | None = None
     loss_kind: int | None = None  # LOSS_MAE (reference) / LOSS_MSE
+    solver: int | None = None     # SOLVER_ROSENBROCK23 / SOLVER_TSIT5 (preset default: the reference's alg)
     dtmin: float | None = None
     t0: float = 0.0
     device: int = 0
@@ -143,6 +144,8 @@ class ODEProblem:
     def config(self) -> Config:
         cfg = Config()
         check(lib.crnn_config_preset(C.byref(cfg), self.preset))
+        if self.solver is not None:
+            check(lib.crnn_config_set_solver(C.byref(cfg), int(self.solver)))
         cfg.n_save = len(self.tsteps)
         cfg.t0 = float(self.t0)
         cfg.device = int(self.device)

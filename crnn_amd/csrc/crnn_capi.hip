@@ -14,6 +14,7 @@
 
 #include "p2vec.hpp"
 #include "ros23_kernel.hpp"
+#include "tsit5_kernel.hpp"
 
 namespace {
 
@@ -38,14 +39,16 @@ int32_t fail(Ctx *ctx, const std::string &msg);
 using KernelFn = void (*)(const crnn::SolveParams, const double *, const double *);
 
 struct KernelEntry {
-    int ns, nr, has_t, use_scale, C, L;
+    int solver, ns, nr, has_t, use_scale, C, L;
     KernelFn fn;
 };
 
 constexpr int kBlock = 256;
 
 #define KENT(NS, NR, HT, SC, C, L) \
-    { NS, NR, HT, SC, C, L, (KernelFn)crnn::ros23_kernel<NS, NR, (HT) != 0, (SC) != 0, C, L, kBlock> }
+    { CRNN_SOLVER_ROSENBROCK23, NS, NR, HT, SC, C, L, (KernelFn)crnn::ros23_kernel<NS, NR, (HT) != 0, (SC) != 0, C, L, kBlock> }
+#define KENT5(NS, NR, HT, SC, C, L) \
+    { CRNN_SOLVER_TSIT5, NS, NR, HT, SC, C, L, (KernelFn)crnn::tsit5_kernel<NS, NR, (HT) != 0, (SC) != 0, C, L, kBlock> }
 
 // Instantiated shapes: case2 (6 species + T, 3 reactions), robertson (3, 6,
 // dydt_scale), case1 (5, 4).  C = tangent columns per lane, L = lanes per
@@ -55,6 +58,9 @@ const KernelEntry kKernels[] = {
     KENT(6, 3, 1, 0, 5, 5), KENT(6, 3, 1, 0, 7, 4), KENT(6, 3, 1, 0, 7, 6),
     KENT(3, 6, 0, 1, 0, 1), KENT(3, 6, 0, 1, 1, 43), KENT(3, 6, 0, 1, 4, 11), KENT(3, 6, 0, 1, 6, 8), KENT(3, 6, 0, 1, 11, 4),
     KENT(5, 4, 0, 0, 0, 1), KENT(5, 4, 0, 0, 1, 24), KENT(5, 4, 0, 0, 4, 6), KENT(5, 4, 0, 0, 6, 4), KENT(5, 4, 0, 0, 8, 6),
+    // explicit Tsit5 (case1's reference algorithm; the non-stiff branch of case2's AutoTsit5)
+    KENT5(5, 4, 0, 0, 0, 1), KENT5(5, 4, 0, 0, 4, 6), KENT5(5, 4, 0, 0, 6, 4), KENT5(5, 4, 0, 0, 8, 6),
+    KENT5(6, 3, 1, 0, 0, 1), KENT5(6, 3, 1, 0, 5, 5), KENT5(6, 3, 1, 0, 7, 6),
 };
 
 struct Ctx {
@@ -113,7 +119,8 @@ int32_t fail(Ctx *ctx, const std::string &msg) {
 }
 
 bool shape_match(const Ctx *c, const KernelEntry &k) {
-    return k.ns == c->cfg.ns && k.nr == c->cfg.nr && k.has_t == c->cfg.has_temp && k.use_scale == (c->use_scale ? 1 : 0);
+    return k.solver == c->cfg.solver && k.ns == c->cfg.ns && k.nr == c->cfg.nr && k.has_t == c->cfg.has_temp &&
+           k.use_scale == (c->use_scale ? 1 : 0);
 }
 
 const KernelEntry *find_primal(const Ctx *c) {
@@ -272,6 +279,15 @@ extern "C" {
 
 int32_t crnn_abi_version(void) { return CRNN_ABI_VERSION; }
 
+int32_t crnn_sizeof(int32_t which) {
+    switch (which) {
+    case 0: return (int32_t)sizeof(crnn_config);
+    case 1: return (int32_t)sizeof(crnn_stats);
+    case 2: return (int32_t)sizeof(crnn_opt_config);
+    default: return -1;
+    }
+}
+
 const char *crnn_last_error(const crnn_ctx *ctx) {
     const Ctx *c = reinterpret_cast<const Ctx *>(ctx);
     return c ? c->err.c_str() : g_last_error.c_str();
@@ -295,6 +311,7 @@ int32_t crnn_config_preset(crnn_config *cfg, int32_t preset) {
         cfg->n_save = 100; cfg->clamp_pred = 1; cfg->maxiters = 10000;
         cfg->lb = 1e-5; cfg->ub = 10.0;
         for (int i = 0; i < CRNN_MAX_N; ++i) { cfg->atol[i] = 1e-5; cfg->rtol[i] = 1e-2; }
+        crnn_config_set_solver(cfg, CRNN_SOLVER_TSIT5);  // alg = Tsit5(), case1/case1.jl:28
         break;
     case CRNN_PRESET_CASE2:  // case2/case2.jl:18-35,113
         cfg->ns = 6; cfg->nr = 3; cfg->has_temp = 1; cfg->param_map = CRNN_PMAP_CASE2;
@@ -311,6 +328,15 @@ int32_t crnn_config_preset(crnn_config *cfg, int32_t preset) {
     default:
         return fail(nullptr, "crnn_config_preset: unknown preset");
     }
+    return 0;
+}
+
+int32_t crnn_config_set_solver(crnn_config *cfg, int32_t solver) {
+    if (!cfg) return fail(nullptr, "crnn_config_set_solver: null cfg");
+    if (solver == CRNN_SOLVER_ROSENBROCK23) { cfg->beta1 = 7.0 / 20.0; cfg->beta2 = 2.0 / 10.0; cfg->qsteady_max = 1.2; }
+    else if (solver == CRNN_SOLVER_TSIT5) { cfg->beta1 = 7.0 / 50.0; cfg->beta2 = 2.0 / 25.0; cfg->qsteady_max = 1.0; }
+    else return fail(nullptr, "crnn_config_set_solver: unknown solver");
+    cfg->solver = solver;
     return 0;
 }
 
@@ -352,6 +378,8 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
     if (cfg->ns < 1 || cfg->nr < 1 || cfg->ns + cfg->has_temp > CRNN_MAX_N || cfg->nr > CRNN_MAX_NR)
         return fail(nullptr, "crnn_ctx_create: ns/nr out of range");
     if (cfg->errnorm_sens != 0) return fail(nullptr, "crnn_ctx_create: errnorm_sens=1 is not implemented on device");
+    if (cfg->solver != CRNN_SOLVER_ROSENBROCK23 && cfg->solver != CRNN_SOLVER_TSIT5)
+        return fail(nullptr, "crnn_ctx_create: unknown solver");
     if (cfg->n_save < 1 || cfg->n_save > crnn::kMaxSave) return fail(nullptr, "crnn_ctx_create: n_save must be in [1, 256]");
     Ctx *c = new Ctx();
     c->cfg = *cfg;
@@ -365,7 +393,7 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
     if (!find_primal(c)) { c->use_scale = !c->use_scale; if (!find_primal(c)) c->use_scale = !c->use_scale; }
     if (!find_primal(c)) {
         delete c;
-        return fail(nullptr, "crnn_ctx_create: no gfx950 kernel instantiated for this (ns, nr, has_temp)");
+        return fail(nullptr, "crnn_ctx_create: no gfx950 kernel instantiated for this (solver, ns, nr, has_temp)");
     }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);

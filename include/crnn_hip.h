@@ -55,6 +55,8 @@ enum {
 enum { CRNN_LOSS_MAE = 0, CRNN_LOSS_MSE = 1 };
 /* per-trajectory return codes (DiffEq retcodes Success / MaxIters / DtLessThanMin / Unstable) */
 enum { CRNN_RET_SUCCESS = 0, CRNN_RET_MAXITERS = 1, CRNN_RET_DTMIN = 2, CRNN_RET_UNSTABLE = 3 };
+/* time steppers (reference: alg = Rosenbrock23(...) rober_crnn.jl:33, AutoTsit5(Rosenbrock23()) case2.jl:26, Tsit5() case1.jl:28) */
+enum { CRNN_SOLVER_ROSENBROCK23 = 0, CRNN_SOLVER_TSIT5 = 1 };
 /* presets for crnn_config_preset */
 enum { CRNN_PRESET_CASE1 = 1, CRNN_PRESET_CASE2 = 2, CRNN_PRESET_ROBER = 3 };
 
@@ -72,6 +74,8 @@ typedef struct crnn_config {
     int32_t errnorm_sens;         /* 0: primal-only error norm; 1: reserved (ForwardDiff-style) */
     int32_t device;               /* HIP device ordinal */
     int32_t cols_per_lane;        /* kernel tuning: tangent columns per lane, 0 = auto */
+    int32_t solver;               /* CRNN_SOLVER_*; set it with crnn_config_set_solver (also sets the controller) */
+    int32_t reserved0;
     double lb, ub;                /* log(clamp(u, lb, ub)); ub may be +inf */
     double inv_R;                 /* -1/R (case2/case2.jl:113); unused when has_temp = 0 */
     double t0;                    /* tspan[1] */
@@ -104,12 +108,18 @@ typedef struct crnn_opt_config {
 typedef struct crnn_ctx crnn_ctx;
 
 int32_t crnn_abi_version(void);
+/* sizeof(crnn_config) / sizeof(crnn_stats) / sizeof(crnn_opt_config) for which = 0 / 1 / 2: lets a binding
+ * (Julia struct, ctypes.Structure) verify its mirror of the C structs at load time. */
+int32_t crnn_sizeof(int32_t which);
 const char *crnn_last_error(const crnn_ctx *ctx); /* ctx may be NULL: last error of a failed create */
 
 /* Fill cfg with the reference's script-top constants for a preset
  * (case1/case1.jl:14-35, case2/case2.jl:15-35,113, robertson/rober_crnn.jl:19-37). */
 int32_t crnn_config_preset(crnn_config *cfg, int32_t preset);
 int32_t crnn_opt_preset(crnn_opt_config *o, int32_t preset);
+/* Select the time stepper and the PI-controller defaults OrdinaryDiffEq attaches to it
+ * (beta1 = 7/(10 q), beta2 = 2/(5 q), q = 2 | 5; steady band [1, 6/5] only for the implicit family). */
+int32_t crnn_config_set_solver(crnn_config *cfg, int32_t solver);
 
 /* ---- host-side parameter maps: p2vec and its Jacobian ------------------- */
 int32_t crnn_n_params(int32_t param_map, int32_t ns, int32_t nr);  /* length of p */

@@ -72,6 +72,8 @@ typedef struct orc_problem {
     int32_t loss_kind;          /* 0 = MAE, 1 = MSE */
     int32_t maxiters;
     int32_t errnorm_sens;       /* 0 primal-only norm, 1 ForwardDiff-style */
+    int32_t solver;             /* 0 Rosenbrock23, 1 Tsit5 (case1/case1.jl:28) */
+    int32_t pad_;
     double lb, ub;              /* log-clamp window; ub may be +inf */
     double inv_R;               /* -1/R for the Arrhenius row (has_temp) */
     double rate_scale[ORC_MAXN];/* dydt_scale (robertson), else 1 */
@@ -84,6 +86,14 @@ typedef struct orc_problem {
 } orc_problem;
 
 int orc_sizeof_problem(void) { return (int)sizeof(orc_problem); }
+
+/* PIController defaults per algorithm: beta2 = 2/(5 order), beta1 = 7/(10 order); the steady band [1, 6/5]
+   exists only for the implicit family (qsteady_max = 1 for explicit methods). [UNVERIFIED-DEP] */
+void orc_set_solver(orc_problem *pb, int solver) {
+    pb->solver = solver;
+    if (solver == 1) { pb->beta1 = 7.0 / 50.0; pb->beta2 = 2.0 / 25.0; pb->qsteady_max = 1.0; }
+    else { pb->beta1 = 7.0 / 20.0; pb->beta2 = 2.0 / 10.0; pb->qsteady_max = 1.2; }
+}
 
 void orc_problem_defaults(orc_problem *pb) {
     memset(pb, 0, sizeof(*pb));
@@ -364,7 +374,7 @@ static double rms_scaled(const orc_problem *pb, int n, const double *v, const do
 
 /* Hairer initial step as in OrdinaryDiffEq's ode_determine_initdt
    [UNVERIFIED-DEP] (order = 2 for Rosenbrock23). */
-static double init_dt(const orc_problem *pb, const double *th, const double *u0, const double *f0, double tspan_len) {
+static double init_dt(const orc_problem *pb, const double *th, const double *u0, const double *f0, double tspan_len, int order) {
     int n = N_(pb);
     double sk[ORC_MAXN], d0 = 0, d1 = 0;
     for (int i = 0; i < n; ++i) {
@@ -383,7 +393,7 @@ static double init_dt(const orc_problem *pb, const double *th, const double *u0,
     for (int i = 0; i < n; ++i) { double e = (f1[i] - f0[i]) / sk[i]; d2 += e * e; }
     d2 = sqrt(d2 / n) / dt0;
     double dm = fmax(d1, d2);
-    double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : pow(10.0, -(2.0 + log10(dm)) / 2.0);
+    double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : pow(10.0, -(2.0 + log10(dm)) / (double)order);
     return fmax(pb->dtmin, fmin(fmin(100.0 * dt0, dt1), dtmax));
 }
 
@@ -423,7 +433,7 @@ static int solve_one_ws(const orc_problem *pb, const double *th, const double *d
         double zero[ORC_MAXN] = {0};
         orc_rhs_jvp(pb, th, dth + (size_t)nth * k, u, zero, df0 + (size_t)n * k);
     }
-    double dt = init_dt(pb, th, u, f0, tend - pb->t0);
+    double dt = init_dt(pb, th, u, f0, tend - pb->t0, 2);
     double qold = pb->qoldinit;
     int jsave = 0, retcode = 0, iter = 0;
     double loss_sum = 0.0;
@@ -587,14 +597,195 @@ static int solve_one_ws(const orc_problem *pb, const double *th, const double *d
     return retcode;
 }
 
+
+/* ------------------------------------------------------------------------ */
+/* Tsit5 (Tsitouras 2011) as OrdinaryDiffEq implements it: 7 stages, FSAL,  */
+/* embedded 4th-order error estimate, "free" 4th-order dense output.        */
+/* The tableau below was written from memory of Tsit5ConstantCache and is   */
+/* verified by tests/test_oracle_golden.py against all 17 order conditions  */
+/* up to order 5, the embedded-pair conditions and the continuous order     */
+/* conditions of the interpolant.  Reference call site: case1/case1.jl:28,  */
+/* 94-95 (alg = Tsit5(), maxiters = 10000).                                 */
+/* ------------------------------------------------------------------------ */
+static const double TS_C[7] = {0.0, 0.161, 0.327, 0.9, 0.9800255409045097, 1.0, 1.0};
+static const double TS_A[7][6] = {
+    {0, 0, 0, 0, 0, 0},
+    {0.161, 0, 0, 0, 0, 0},
+    {-0.008480655492356989, 0.335480655492357, 0, 0, 0, 0},
+    {2.8971530571054935, -6.359448489975075, 4.3622954328695815, 0, 0, 0},
+    {5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525, 0, 0},
+    {5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383, 0},
+    {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774}};
+static const double TS_BT[7] = {-0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995,
+                                -0.1447110071732629, 0.5823571654525552, -0.45808210592918697, 0.015151515151515152};
+void orc_tsit5_tableau(double *c, double *a /*7x6 row-major*/, double *bt) {
+    memcpy(c, TS_C, sizeof(TS_C)); memcpy(a, TS_A, sizeof(TS_A)); memcpy(bt, TS_BT, sizeof(TS_BT));
+}
+void orc_tsit5_dense(double T, double *b) {
+    b[0] = -1.0530884977290216 * T * (T - 1.3299890189751412) * (T * T - 1.4364028541716351 * T + 0.7139816917074209);
+    b[1] = 0.1017 * T * T * (T * T - 2.1966568338249754 * T + 1.2949852507374631);
+    b[2] = 2.490627285651252793 * T * T * (T * T - 2.38535645472061657 * T + 1.57803468208092486);
+    b[3] = -16.54810288924490272 * (T - 1.21712927295533244) * (T - 0.61620406037800089) * T * T;
+    b[4] = 47.37952196281928122 * (T - 1.203071208372362603) * (T - 0.658047292653547382) * T * T;
+    b[5] = -34.87065786149660974 * (T - 1.2) * (T - 0.666666666666666667) * T * T;
+    b[6] = 2.5 * (T - 1.0) * (T - 0.6) * T * T;
+}
+
+/* workspace: n*P*9 + P doubles */
+static int solve_one_tsit5(const orc_problem *pb, const double *th, const double *dth, int P,
+                           const double *u0, const double *tsave, int nsave,
+                           const double *data, double *pred, double *dpred,
+                           double *loss_out, double *grad, int32_t *n_saved_out, orc_stats *st, double *ws) {
+    const int n = N_(pb), nobs = pb->n_obs;
+    const int nth = orc_n_theta(pb);
+    const double tend = tsave[nsave - 1];
+    double t = pb->t0;
+    double u[ORC_MAXN], k[7][ORC_MAXN];
+    double *S = NULL, *Snew = NULL, *dk = NULL, *gtr = NULL;   /* dk: 7 blocks of n*P */
+    if (P > 0) {
+        memset(ws, 0, sizeof(double) * ((size_t)n * P * 9 + P));
+        S = ws; Snew = S + (size_t)n * P; dk = Snew + (size_t)n * P; gtr = ws + (size_t)n * P * 9;
+    }
+#define DK(i) (dk + (size_t)(i) * n * P)
+    memcpy(u, u0, sizeof(double) * n);
+    orc_rhs(pb, th, u, k[0]);
+    for (int c = 0; c < P; ++c) {
+        double zero[ORC_MAXN] = {0};
+        orc_rhs_jvp(pb, th, dth + (size_t)nth * c, u, zero, DK(0) + (size_t)n * c);
+    }
+    double dt = init_dt(pb, th, u, k[0], tend - pb->t0, 5);
+    double qold = pb->qoldinit;
+    int jsave = 0, retcode = 0, iter = 0;
+    double loss_sum = 0.0;
+#define SAVE_POINT(uvec, svec_expr_block)                                              \
+    do {                                                                               \
+        for (int i = 0; i < n; ++i) {                                                  \
+            double v = (uvec)[i];                                                      \
+            if (pb->clamp_pred) v = clampd(v, -pb->ub, pb->ub);                        \
+            if (pred) pred[i + n * jsave] = v;                                         \
+        }                                                                              \
+        for (int io = 0; io < nobs; ++io) {                                            \
+            int i = pb->i_obs[io];                                                     \
+            double v = (uvec)[i];                                                      \
+            double mask = 1.0;                                                         \
+            if (pb->clamp_pred) { mask = dclamp(v, -pb->ub, pb->ub); v = clampd(v, -pb->ub, pb->ub); } \
+            double r_ = (data[io + nobs * jsave] - v) / pb->yscale[io];                \
+            double w_;                                                                 \
+            if (pb->loss_kind == 0) { loss_sum += fabs(r_); w_ = -dabs_(r_); }         \
+            else { loss_sum += r_ * r_; w_ = -2.0 * r_; }                              \
+            w_ *= mask / pb->yscale[io];                                               \
+            for (int c = 0; c < P; ++c) { double sv; svec_expr_block; gtr[c] += w_ * sv; \
+                if (dpred) dpred[i + n * (jsave + (size_t)nsave * c)] = mask * sv; }   \
+        }                                                                              \
+        ++jsave;                                                                       \
+    } while (0)
+    if (nsave > 0 && tsave[0] == pb->t0) SAVE_POINT(u, sv = 0.0);
+
+    while (jsave < nsave) {
+        if (++iter > pb->maxiters) { retcode = 1; break; }
+        int last = 0;
+        if (t + dt * (1.0 + 1e-13) >= tend) { dt = tend - t; last = 1; }
+        if (!(dt > pb->dtmin) || t + dt == t) { retcode = 2; break; }
+        double g[ORC_MAXN], unew[ORC_MAXN];
+        for (int s_ = 1; s_ < 7; ++s_) {          /* stages 2..7 (stage 7 is evaluated at u_{n+1}: FSAL) */
+            for (int i = 0; i < n; ++i) {
+                double a = 0.0;
+                for (int j = 0; j < s_; ++j) a += TS_A[s_][j] * k[j][i];
+                g[i] = u[i] + dt * a;
+            }
+            if (s_ == 6) memcpy(unew, g, sizeof(double) * n);
+            orc_rhs(pb, th, g, k[s_]);
+        }
+        double ev[ORC_MAXN];
+        int finite = 1;
+        for (int i = 0; i < n; ++i) {
+            double a = 0.0;
+            for (int j = 0; j < 7; ++j) a += TS_BT[j] * k[j][i];
+            ev[i] = dt * a;
+            if (!isfinite(unew[i]) || !isfinite(ev[i])) finite = 0;
+        }
+        if (!finite) { retcode = 3; break; }
+        double EEst = rms_scaled(pb, n, ev, u, unew);
+        int accept = (EEst <= 1.0);
+        if (accept && P > 0) {
+            for (int c = 0; c < P; ++c) {
+                const double *dthc = dth + (size_t)nth * c;
+                const double *s = S + (size_t)n * c;
+                double gs[ORC_MAXN], gu[ORC_MAXN];
+                for (int s_ = 1; s_ < 7; ++s_) {
+                    for (int i = 0; i < n; ++i) {
+                        double a = 0.0, b = 0.0;
+                        for (int j = 0; j < s_; ++j) { a += TS_A[s_][j] * k[j][i]; b += TS_A[s_][j] * DK(j)[i + (size_t)n * c]; }
+                        gu[i] = u[i] + dt * a; gs[i] = s[i] + dt * b;
+                    }
+                    if (s_ == 6) memcpy(Snew + (size_t)n * c, gs, sizeof(double) * n);
+                    orc_rhs_jvp(pb, th, dthc, gu, gs, DK(s_) + (size_t)n * c);
+                }
+            }
+        }
+        double q, q11 = 0.0;
+        if (EEst == 0.0) q = 1.0 / pb->qmax;
+        else {
+            q11 = pow(EEst, pb->beta1);
+            q = q11 / pow(qold, pb->beta2);
+            q = fmax(1.0 / pb->qmax, fmin(1.0 / pb->qmin, q / pb->gamma));
+        }
+        if (accept) {
+            if (st) st->naccept++;
+            if (q >= pb->qsteady_min && q <= pb->qsteady_max) q = 1.0;
+            qold = fmax(EEst, pb->qoldinit);
+            double tnew = last ? tend : t + dt;
+            while (jsave < nsave && tsave[jsave] <= tnew) {
+                double ts = tsave[jsave];
+                if (ts == tnew) {
+                    SAVE_POINT(unew, sv = Snew[i + (size_t)n * c]);
+                } else {
+                    double Th = (ts - t) / dt, bth[7], ui[ORC_MAXN];
+                    orc_tsit5_dense(Th, bth);
+                    for (int i = 0; i < n; ++i) {
+                        double a = 0.0;
+                        for (int j = 0; j < 7; ++j) a += bth[j] * k[j][i];
+                        ui[i] = u[i] + dt * a;
+                    }
+                    SAVE_POINT(ui, { double a_ = 0.0; for (int j = 0; j < 7; ++j) a_ += bth[j] * DK(j)[i + (size_t)n * c];
+                                     sv = S[i + (size_t)n * c] + dt * a_; });
+                }
+            }
+            memcpy(u, unew, sizeof(double) * n);
+            memcpy(k[0], k[6], sizeof(double) * n);
+            if (P > 0) {
+                memcpy(S, Snew, sizeof(double) * (size_t)n * P);
+                memcpy(DK(0), DK(6), sizeof(double) * (size_t)n * P);
+            }
+            t = tnew;
+            dt = dt / q;
+            double dtmax = tend - pb->t0;
+            if (dt > dtmax) dt = dtmax;
+        } else {
+            if (st) st->nreject++;
+            dt = dt / fmin(1.0 / pb->qmin, q11 / pb->gamma);
+        }
+    }
+#undef SAVE_POINT
+#undef DK
+    double denom = (double)nobs * (double)jsave;
+    double loss = jsave > 0 ? loss_sum / denom : 0.0;
+    if (loss_out) *loss_out = loss;
+    if (n_saved_out) *n_saved_out = jsave;
+    if (grad && jsave > 0) for (int c = 0; c < P; ++c) grad[c] += gtr[c] / denom;
+    return retcode;
+}
+
 int orc_solve_one(const orc_problem *pb, const double *th, const double *dth, int P,
                   const double *u0, const double *tsave, int nsave,
                   const double *data, double *pred, double *dpred,
                   double *loss_out, double *grad /* [P] accumulated += */,
                   int32_t *n_saved_out, orc_stats *st) {
     const int n = N_(pb);
-    double *ws = P > 0 ? (double *)malloc(sizeof(double) * ((size_t)n * P * 7 + P)) : NULL;
-    int rc = solve_one_ws(pb, th, dth, P, u0, tsave, nsave, data, pred, dpred, loss_out, grad, n_saved_out, st, ws);
+    double *ws = P > 0 ? (double *)malloc(sizeof(double) * ((size_t)n * P * 9 + P)) : NULL;
+    int rc = pb->solver == 1
+                 ? solve_one_tsit5(pb, th, dth, P, u0, tsave, nsave, data, pred, dpred, loss_out, grad, n_saved_out, st, ws)
+                 : solve_one_ws(pb, th, dth, P, u0, tsave, nsave, data, pred, dpred, loss_out, grad, n_saved_out, st, ws);
     free(ws);
     return rc;
 }
@@ -621,7 +812,7 @@ int orc_solve_batch(const orc_problem *pb, const double *th, const double *dth, 
         double *g_loc = P > 0 ? (double *)calloc((size_t)P, sizeof(double)) : NULL;
         double *d_loc = (double *)malloc(sizeof(double) * (size_t)nobs * nsave);
         double *p_loc = pred ? (double *)malloc(sizeof(double) * (size_t)n * nsave) : NULL;
-        double *ws = (grad && P > 0) ? (double *)malloc(sizeof(double) * ((size_t)n * P * 7 + P)) : NULL;
+        double *ws = (grad && P > 0) ? (double *)malloc(sizeof(double) * ((size_t)n * P * 9 + P)) : NULL;
 #pragma omp for schedule(dynamic, 8)
         for (int64_t b = first; b < first + count; ++b) {
             double u[ORC_MAXN];
@@ -631,7 +822,9 @@ int orc_solve_batch(const orc_problem *pb, const double *th, const double *dth, 
             orc_stats st = {0, 0};
             double l = 0; int32_t ns_ = 0;
             if (p_loc) memset(p_loc, 0, sizeof(double) * (size_t)n * nsave);
-            int rc = solve_one_ws(pb, th, dth, grad ? P : 0, u, tsave, nsave, d_loc, p_loc, NULL, &l, g_loc, &ns_, &st, ws);
+            int rc = pb->solver == 1
+                         ? solve_one_tsit5(pb, th, dth, grad ? P : 0, u, tsave, nsave, d_loc, p_loc, NULL, &l, g_loc, &ns_, &st, ws)
+                         : solve_one_ws(pb, th, dth, grad ? P : 0, u, tsave, nsave, d_loc, p_loc, NULL, &l, g_loc, &ns_, &st, ws);
             if (loss) loss[b] = l;
             if (retcode) retcode[b] = rc;
             if (n_saved) n_saved[b] = ns_;

@@ -28,7 +28,7 @@ class Problem(C.Structure):
         ("ns", C.c_int32), ("nr", C.c_int32), ("has_temp", C.c_int32),
         ("n_obs", C.c_int32), ("i_obs", C.c_int32 * MAXN),
         ("clamp_pred", C.c_int32), ("loss_kind", C.c_int32),
-        ("maxiters", C.c_int32), ("errnorm_sens", C.c_int32),
+        ("maxiters", C.c_int32), ("errnorm_sens", C.c_int32), ("solver", C.c_int32), ("pad_", C.c_int32),
         ("lb", C.c_double), ("ub", C.c_double), ("inv_R", C.c_double),
         ("rate_scale", C.c_double * MAXN),
         ("atol", C.c_double * MAXN), ("rtol", C.c_double * MAXN),
@@ -73,7 +73,7 @@ def _ip(a):
 
 def make_problem(*, ns, nr, has_temp=0, lb=1e-6, ub=np.inf, inv_R=0.0, rate_scale=None,
                  atol=1e-6, rtol=1e-3, yscale=None, i_obs=None, clamp_pred=0, loss_kind=0,
-                 maxiters=100000, errnorm_sens=0, t0=0.0) -> Problem:
+                 maxiters=100000, errnorm_sens=0, t0=0.0, solver=0) -> Problem:
     pb = Problem()
     lib().orc_problem_defaults(C.byref(pb))
     n = ns + has_temp
@@ -81,6 +81,7 @@ def make_problem(*, ns, nr, has_temp=0, lb=1e-6, ub=np.inf, inv_R=0.0, rate_scal
     pb.lb, pb.ub, pb.inv_R = lb, ub, inv_R
     pb.clamp_pred, pb.loss_kind, pb.maxiters, pb.errnorm_sens = clamp_pred, loss_kind, maxiters, errnorm_sens
     pb.t0 = t0
+    lib().orc_set_solver(C.byref(pb), int(solver))
     at = np.broadcast_to(np.asarray(atol, float), (n,))
     rt = np.broadcast_to(np.asarray(rtol, float), (n,))
     for i in range(n):
@@ -228,3 +229,15 @@ class Optimiser:
         p = np.ascontiguousarray(p, float)
         lib().orc_opt_update(C.byref(self.o), C.c_int(self.P), _dp(p), _dp(np.ascontiguousarray(grad, float)), _dp(self.state))
         return p
+
+
+def tsit5_tableau():
+    c = np.zeros(7); a = np.zeros((7, 6)); bt = np.zeros(7)
+    lib().orc_tsit5_tableau(_dp(c), _dp(a), _dp(bt))
+    return c, a, bt
+
+
+def tsit5_dense(theta):
+    b = np.zeros(7)
+    lib().orc_tsit5_dense(C.c_double(theta), _dp(b))
+    return b

@@ -200,3 +200,80 @@ def test_rccl_single_rank_allreduce(case2_setup):
     node.train_init(Optimiser(25, PRESET_CASE2), case2_setup["p_ckpt"])
     assert abs(node.train_step() - loss0) < 1e-12
     L.check(L.lib.crnn_comm_destroy(node.handle), node.handle)
+
+
+# ------------------------------------------------------------------ Tsit5 (case1's algorithm; case2's non-stiff branch)
+def _tsit5_node(preset, setup, **kw):
+    from crnn_amd import NeuralODE, ODEProblem, SOLVER_TSIT5
+    node = NeuralODE(ODEProblem(preset, setup["tsteps"], solver=SOLVER_TSIT5, **kw))
+    node.set_ensemble(setup["u0"], setup["data"], setup["yscale"])
+    return node
+
+
+@pytest.mark.parametrize("pkey", ["p_ckpt", "p_init"])
+def test_tsit5_case2_matches_oracle(orc, case2_setup, pkey):
+    from crnn_amd import PRESET_CASE2
+    s = case2_setup
+    p = s[pkey]
+    node = _tsit5_node(PRESET_CASE2, s)
+    th, dth = orc.p2vec(2, 6, 3, p)
+    pb = oracle_problem(orc, "case2", s, solver=1)
+    ref = orc.solve_batch(pb, th, np.ascontiguousarray(s["u0"].T), s["tsteps"],
+                          np.ascontiguousarray(s["data"].transpose(2, 1, 0)), dtheta=dth, want_pred=True)
+    pred = node.predict_neuralode(s["u0"], p)
+    ref_pred = ref["pred"].transpose(2, 1, 0)
+    scale = np.abs(ref_pred).max(axis=(0, 2), keepdims=True) + 1e-300
+    assert np.max(np.abs(pred - ref_pred) / scale) < 1e-9
+    assert np.array_equal(node.last_retcode, ref["retcode"])
+    loss, grad = node.loss_and_grad(p)
+    st = node.last_stats
+    assert st["n_accept"] == ref["naccept"] and st["n_reject"] == ref["nreject"]
+    B = len(ref["loss"])
+    assert abs(loss - ref["loss"].mean()) < 1e-9 * loss
+    assert np.max(np.abs(grad - ref["grad"] / B)) < 1e-7 * np.max(np.abs(ref["grad"] / B))
+    # 5th order: far fewer steps than Rosenbrock23 at the same tolerance, tighter answer
+    gold = s["pred_ckpt"]
+    if pkey == "p_ckpt":
+        assert np.max(np.abs(pred[:, :6] - gold[:, :6])) / np.abs(gold[:, :6]).max() < 1e-4
+    node.close()
+    node = _tsit5_node(PRESET_CASE2, s, atol=1e-11, rtol=1e-9)
+    if pkey == "p_ckpt":
+        pred = node.predict_neuralode(s["u0"], p)
+        assert np.max(np.abs(pred[:, :6] - gold[:, :6])) / np.abs(gold[:, :6]).max() < 1e-8
+    for g in s["grads"]:
+        if (g["p"] == "ckpt") == (pkey == "p_ckpt"):
+            gg = np.array(g["grad"])
+            assert np.max(np.abs(node.gradient(p, g["ic"]) - gg)) < 2e-6 * np.max(np.abs(gg))
+    node.close()
+
+
+def test_tsit5_case1_reference_configuration(orc, fx):
+    """BASELINE config 0: case1 (5 species / 4 reactions), Tsit5, atol 1e-5, rtol 1e-2, maxiters 10000 (case1.jl:19-35)."""
+    from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE1, cases
+    rng = np.random.Generator(np.random.PCG64(11))
+    ts = cases.case1_tsteps()
+    u0 = np.array(fx["case1"]["u0"])
+    p = np.array(fx["case1"]["p"])
+    gen = NeuralODE(ODEProblem(PRESET_CASE1, ts, atol=1e-12, rtol=1e-10))
+    clean = gen.predict_theta(u0, cases.case1_true_theta())
+    gen.close()
+    data = cases.add_noise(clean, 0.05, rng)
+    ys = cases.max_min(data, lb=1e-5)
+    node = NeuralODE(ODEProblem(PRESET_CASE1, ts))          # preset = the reference's Tsit5 configuration
+    node.set_ensemble(u0, data, ys)
+    th, dth = orc.p2vec(1, 5, 4, p)
+    pb = orc.make_problem(ns=5, nr=4, lb=1e-5, ub=10.0, atol=1e-5, rtol=1e-2, yscale=ys, clamp_pred=1, maxiters=10000, solver=1)
+    B = u0.shape[0]
+    ref = orc.solve_batch(pb, th, np.ascontiguousarray(u0.T), ts, np.ascontiguousarray(data.transpose(2, 1, 0)), dtheta=dth,
+                          want_pred=True)
+    pred = node.predict_neuralode(u0, p)
+    assert np.max(np.abs(pred - ref["pred"].transpose(2, 1, 0))) < 1e-9
+    loss, grad = node.loss_and_grad(p)
+    assert abs(loss - ref["loss"].mean()) < 1e-9 * loss
+    assert np.max(np.abs(grad - ref["grad"] / B)) < 1e-7 * np.max(np.abs(ref["grad"] / B))
+    assert node.last_stats["n_accept"] == ref["naccept"]
+    # single initial condition, as the reference's per-IC loop does (case1.jl:191-201)
+    g0 = node.gradient(p, 0)
+    r0 = orc.solve_one(pb, th, u0[0], ts, data[0], dtheta=dth)
+    assert np.max(np.abs(g0 - r0["grad"])) < 1e-7 * np.max(np.abs(r0["grad"]))
+    node.close()

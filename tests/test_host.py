@@ -27,11 +27,12 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
+    """ctypes mirrors == the C structs the library was compiled with (also enforced at import)."""
     from crnn_amd import _lib as L
-    # crnn_config: 12 int32 + 4 double + 3*12 double + 9 double
-    assert C.sizeof(L.Config) == 12 * 4 + (4 + 36 + 9) * 8
-    assert C.sizeof(L.Stats) == 4 * 8 + 8
-    assert C.sizeof(L.OptConfig) == 2 * 4 + 8 * 8
+    assert L.lib.crnn_sizeof(0) == C.sizeof(L.Config) == 14 * 4 + (4 + 36 + 9) * 8
+    assert L.lib.crnn_sizeof(1) == C.sizeof(L.Stats) == 4 * 8 + 8
+    assert L.lib.crnn_sizeof(2) == C.sizeof(L.OptConfig) == 2 * 4 + 8 * 8
+    assert L.lib.crnn_sizeof(3) == -1
 
 
 def test_presets_carry_reference_constants():
@@ -46,6 +47,8 @@ def test_presets_carry_reference_constants():
     assert [cfg.atol[i] for i in range(3)] == [1e-6, 1e-8, 1e-6] and cfg.lb == 1e-8 and np.isinf(cfg.ub)
     L.check(L.lib.crnn_config_preset(C.byref(cfg), L.PRESET_CASE1))
     assert (cfg.ns, cfg.nr, cfg.n_save, cfg.maxiters) == (5, 4, 100, 10000) and cfg.rtol[0] == 1e-2
+    # case1's algorithm is Tsit5 (case1.jl:28) with the explicit-method controller defaults
+    assert cfg.solver == L.SOLVER_TSIT5 and abs(cfg.beta1 - 0.14) < 1e-15 and abs(cfg.beta2 - 0.08) < 1e-15 and cfg.qsteady_max == 1.0
     assert L.lib.crnn_config_preset(C.byref(cfg), 99) != 0
     o = L.OptConfig()
     L.check(L.lib.crnn_opt_preset(C.byref(o), L.PRESET_CASE2))
