@@ -36,6 +36,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Scheduling fence between the phases of a tangent column: stops the pre-RA scheduler from hoisting the LDS loads of
+// later phases to the top of the column (which inflates the live register set and forces VGPR<->AGPR traffic).
+#ifndef CRNN_SCHED_FENCE
+#define CRNN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 namespace crnn {
 
 constexpr int kMaxN = 12;
@@ -803,6 +809,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                             zpd[j] = fma(m, dkc, zpd[j]);
                         }
                     }
+                    CRNN_SCHED_FENCE();
                     // ---- pass 2 (reaction-major): rhs1 = f0' + gam J' k1, w2 = gam J' dk, f1d = dw_out r1 ----
                     double rhs1[NS], w2[NS], f1d[NS];
 #pragma unroll
@@ -830,8 +837,10 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
 #pragma unroll
                         for (int i = 0; i < NS; ++i) { double sc = kc->scale[i]; rhs1[i] *= sc; w2[i] *= sc; }
                     }
+                    CRNN_SCHED_FENCE();
                     // W k1' = f0' + gam (J' k1)
                     W.solve(th, gq, grq, kc->scale, rhs1);  // rhs1 now holds k1'
+                    CRNN_SCHED_FENCE();
                     // f1' at u1 with s1 = s + dt/2 k1'
                     double gs1[NS];
 #pragma unroll
@@ -848,6 +857,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
 #pragma unroll
                         for (int i = 0; i < NS; ++i) rhs2[i] = fma(th[L_::wo(i, j)], er, rhs2[i]);
                     }
+                    CRNN_SCHED_FENCE();
                     // W (k2-k1)' = f1' - k1' + gam J'(k2-k1)
 #pragma unroll
                     for (int i = 0; i < NS; ++i) rhs2[i] = (USE_SCALE ? rhs2[i] * kc->scale[i] : rhs2[i]) - rhs1[i] + w2[i];
