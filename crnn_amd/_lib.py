@@ -46,6 +46,13 @@ class Stats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class CathodeConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("maxiters", C.c_int32), ("reserved0", C.c_int32),
+                ("lb_clamp", C.c_double), ("T0", C.c_double), ("atol", C.c_double), ("rtol", C.c_double),
+                ("gamma", C.c_double), ("qmin", C.c_double), ("qmax", C.c_double), ("beta1", C.c_double),
+                ("beta2", C.c_double), ("qsteady_min", C.c_double), ("qsteady_max", C.c_double), ("qoldinit", C.c_double)]
+
+
 class OptConfig(C.Structure):
     _fields_ = [("use_expdecay", C.c_int32), ("decay_step", C.c_int32), ("ed_eta0", C.c_double),
                 ("ed_decay", C.c_double), ("ed_clip", C.c_double), ("eta", C.c_double), ("beta1", C.c_double),
@@ -91,6 +98,12 @@ SYMBOLS = {
     "crnn_comm_init": (C.c_int32, [_CTX, C.c_char_p, C.c_int32, C.c_int32]),
     "crnn_comm_destroy": (C.c_int32, [_CTX]),
     "crnn_allreduce_grad": (C.c_int32, [_CTX, _DP, C.c_int32]),
+    "crnn_cathode_config_default": (C.c_int32, [C.POINTER(CathodeConfig)]),
+    "crnn_cathode_create": (C.c_int32, [C.POINTER(CathodeConfig), C.POINTER(_CTX)]),
+    "crnn_cathode_destroy": (None, [_CTX]),
+    "crnn_cathode_last_error": (C.c_char_p, [_CTX]),
+    "crnn_cathode_set_obs": (C.c_int32, [_CTX, C.c_int32, C.c_int32, _IP, _DP, _DP, _DP, _DP]),
+    "crnn_cathode_solve": (C.c_int32, [_CTX, _DP, C.c_int64, _DP, _DP, _DP, _IP, _IP, C.POINTER(Stats)]),
 }
 
 

@@ -1,0 +1,162 @@
+"""Host mirror of the Bayesian cathode CRNN scripts (Cathode_NCM333_UQ/src_333), on the C ABI's
+crnn_cathode_* entry points.
+
+    p2vec(p)                         network.jl:90-107    (pure slicing; the scaling by p_scales happens in crnn!)
+    crnn!(du, u, p_for_crnn, t)      network.jl:152-165   (CPU definition kept here)
+    HRR_getter(times, u, p)          network.jl:167-175
+    pred_n_ode(p, i_exp, exp_data)   network.jl:196-218
+    loss_neuralode(p, i_exp)         network.jl:262-275
+    dlnprob(p, i_exp)                network.jl:222-260   (loss, -grad ./ Normalizer.^2 per particle)
+    svgd_kernel(svgd, p, h)          network.jl:67-87     (host, NumPy: the "next" row N3)
+
+`p` are the reference's normalised particles (one row of 17 per particle), `p_scales` the deterministic optimum
+they are scaled by; the device sees theta = p .* p_scales.  Experiments (heating rates) are 0-based here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import CathodeConfig, Stats, check, dptr, iptr, lib
+
+R_GAS = -1.0 / 8.314       # network.jl:151
+T0 = 100 + 273.15          # network.jl:189
+# dataset.jl:27-32
+NORMALIZER = np.array([[.00538199] * 3, [0.01230299] * 3, [0.02823027] * 3, [0.04655562] * 3, [0.05480013] * 3])
+# gradient entry k is divided by Normalizer[i_exp, col]^2 with this column map (network.jl:234-250)
+NORM_COL = np.array([0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 2, 1, 2])
+
+
+def p2vec(p):
+    p = np.asarray(p, float)
+    return p[3:6], p[6:9], np.array([1.0, p[15], p[16]]), p[9:12], p[12:15], p[0:3]
+
+
+def getsampletemp(t, beta):
+    return T0 + beta / 60.0 * np.asarray(t, float)
+
+
+def crnn(du, u, p_for_crnn, t, *, p_scales, beta, lb_clamp=1e-16):
+    """CPU definition of crnn! (never used by the integration)."""
+    Ea, b, w_out, _dH, order, A = p_for_crnn
+    logX = np.log(np.clip(u, lb_clamp, 10.0))
+    T = getsampletemp(t, beta)
+    r = np.exp(np.log(T) * (b * p_scales[6:9]) + (R_GAS / T) * (Ea * p_scales[3:6] * 1e5) + order * p_scales[12:15] * logX
+               + A * p_scales[0:3])
+    du[:] = -r
+    du[1] += w_out[1] * p_scales[15] * r[0]
+    du[2] += w_out[2] * p_scales[16] * r[1]
+    return du
+
+
+def HRR_getter(times, u_outputs, p_hrr, *, p_scales, beta, lb_clamp=1e-16):
+    """u_outputs [3, n]; returns hrr [n]."""
+    logX = np.log(np.clip(u_outputs, lb_clamp, 10.0))
+    T = getsampletemp(times, beta)
+    th = np.asarray(p_hrr, float) * p_scales[:17]
+    z = np.log(T)[:, None] * th[6:9] + (R_GAS / T)[:, None] * (th[3:6] * 1e5) + th[12:15] * logX.T + th[0:3]
+    return np.exp(z) @ th[9:12]
+
+
+def svgd_kernel(p, h=-1.0):
+    """RBF kernel with the median trick and its repulsion term (network.jl:67-87)."""
+    p = np.asarray(p, float)
+    d = np.sqrt(np.maximum(((p[:, None, :] - p[None, :, :]) ** 2).sum(-1), 0.0))
+    sq_dist = d[np.tril_indices(p.shape[0], -1)]
+    pairwise = d ** 2
+    if h < 0:
+        h = np.median(sq_dist) ** 2
+        h = np.sqrt(0.5 * h / np.log(p.shape[0] + 1))
+    Kxy = np.exp(-pairwise / h ** 2 / 2)
+    dxkxy = -Kxy @ p + p * Kxy.sum(axis=1, keepdims=True)
+    return Kxy, dxkxy / h ** 2
+
+
+class CathodeUQ:
+    """exp_data: list of arrays [D_s, 1 + n_replicas] (col 0 = time in s, dataset.jl:19-23), heating_rates in K/min."""
+
+    def __init__(self, exp_data, heating_rates, p_scales, *, atol=None, rtol=None, maxiters=None, lb_clamp=None, device=0,
+                 normalizer=None):
+        self.cfg = CathodeConfig()
+        check(lib.crnn_cathode_config_default(C.byref(self.cfg)))
+        self.cfg.device = device
+        for k, v in (("atol", atol), ("rtol", rtol), ("maxiters", maxiters), ("lb_clamp", lb_clamp)):
+            if v is not None:
+                setattr(self.cfg, k, v)
+        self.h = C.c_void_p()
+        check(lib.crnn_cathode_create(C.byref(self.cfg), C.byref(self.h)))
+        self.p_scales = np.asarray(p_scales, float)[:17].copy()
+        self.beta = np.ascontiguousarray(heating_rates, np.float64)
+        self.exp_data = [np.asarray(e, float) for e in exp_data]
+        self.n_sets = len(self.exp_data)
+        self.D = np.array([e.shape[0] for e in self.exp_data], np.int32)
+        self.Dmax = int(self.D.max())
+        ts = np.zeros((self.n_sets, self.Dmax)); dbar = np.zeros_like(ts); d2bar = np.zeros_like(ts)
+        for s, e in enumerate(self.exp_data):
+            ts[s, :e.shape[0]] = e[:, 0]
+            ts[s, e.shape[0]:] = e[-1, 0] + np.arange(1, self.Dmax - e.shape[0] + 1)
+            dbar[s, :e.shape[0]] = e[:, 1:].mean(axis=1)
+            d2bar[s, :e.shape[0]] = (e[:, 1:] ** 2).mean(axis=1)
+        self.ts = ts
+        self._check(lib.crnn_cathode_set_obs(self.h, self.n_sets, self.Dmax, iptr(self.D), dptr(ts), dptr(dbar), dptr(d2bar),
+                                             dptr(self.beta)))
+        self.normalizer = NORMALIZER[: self.n_sets] if normalizer is None else np.asarray(normalizer, float)
+        self.last_stats = None
+        self.last_retcode = None
+        self.last_n_saved = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise L.CrnnError(lib.crnn_cathode_last_error(self.h).decode())
+
+    def solve(self, p, want_grad=True, want_hrr=False):
+        """All particles x all heating rates in one launch.  p [N, 17] normalised particles.
+        Returns loss [N, n_sets], grad_p [N, n_sets, 17] (d loss / d p, chain rule through p_scales), hrr [N, n_sets, Dmax]."""
+        p = np.atleast_2d(np.asarray(p, float))
+        N = p.shape[0]
+        theta = np.ascontiguousarray(p[:, :17] * self.p_scales)
+        nt = N * self.n_sets
+        loss = np.zeros(nt)
+        grad = np.zeros((nt, 17)) if want_grad else None
+        hrr = np.zeros((nt, self.Dmax)) if want_hrr else None
+        ret = np.zeros(nt, np.int32); nsv = np.zeros(nt, np.int32)
+        st = Stats()
+        self._check(lib.crnn_cathode_solve(self.h, dptr(theta), N, dptr(loss), dptr(grad), dptr(hrr), iptr(ret), iptr(nsv),
+                                           C.byref(st)))
+        self.last_stats = st.asdict()
+        self.last_retcode = ret.reshape(N, self.n_sets)
+        self.last_n_saved = nsv.reshape(N, self.n_sets)
+        if np.any(ret != 0):
+            print("ode solver failed")
+        g = None if grad is None else grad.reshape(N, self.n_sets, 17) * self.p_scales
+        return loss.reshape(N, self.n_sets), g, None if hrr is None else hrr.reshape(N, self.n_sets, self.Dmax)
+
+    # ---- reference surface (per heating rate i_exp) ----
+    def pred_n_ode(self, p_temp, i_exp):
+        """heat_rel, trunc_time for one particle and one heating rate (the solution object is not returned)."""
+        _, _, hrr = self.solve(p_temp, want_grad=False, want_hrr=True)
+        n = int(self.last_n_saved[0, i_exp])
+        return hrr[0, i_exp, :n], self.ts[i_exp, :n]
+
+    def loss_neuralode(self, p_temp, i_exp):
+        loss, _, _ = self.solve(p_temp, want_grad=False)
+        return float(loss[0, i_exp])
+
+    def dlnprob(self, p, i_exp):
+        """(mean loss over particles, -grad ./ Normalizer.^2) for heating rate i_exp (network.jl:222-260)."""
+        loss, grad, _ = self.solve(p, want_grad=True)
+        g = grad[:, i_exp, :] / (self.normalizer[i_exp, NORM_COL] ** 2)
+        return float(loss[:, i_exp].mean()), -g
+
+    def close(self):
+        if self.h:
+            lib.crnn_cathode_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

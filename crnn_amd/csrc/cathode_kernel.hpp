@@ -1,0 +1,380 @@
+// crnn_amd/csrc/cathode_kernel.hpp -- Bayesian cathode CRNN (BASELINE config 5) on gfx950.
+//
+// Reference (paths under Cathode_NCM333_UQ/src_333/):
+//   crnn!           network.jl:152-165   r_j = exp(b_j log T - Ea_j 1e5/(8.314 T) + n_j log(clamp(u_j, lb, 10)) + lnA_j),
+//                                        du = -r;  du_2 += nu_2 r_1;  du_3 += nu_3 r_2;   T = T0 + beta/60 t (:143-149)
+//   HRR_getter      network.jl:167-175   hrr(t_i) = sum_j r_j(t_i, u(t_i)) dH_j
+//   pred_n_ode      network.jl:196-218   u0 = (1,0,0), tspan = [ts[1], ts[end]], saveat = ts
+//   loss_neuralode  network.jl:262-266   sum_{i,k} (hrr_i - data_ik)^2 / n_replicas / D
+//   dlnprob         network.jl:222-260   per particle: loss and ForwardDiff.gradient of it
+// theta (17 per particle, already multiplied by p_scales): [lnA(3) | Ea(3) | b(3) | dH(3) | n(3) | nu2, nu3].
+//
+// Mapping: the system is 3 x 3 with a lower-bidiagonal Jacobian, every particle has its own theta, and one
+// particle is integrated for many heating rates -> one LANE per (particle, heating-rate) trajectory, no primal
+// redundancy at all: W = I - gam*J is lower triangular (forward substitution, no pivoting), the 14 tangent
+// columns that move the ODE (dH only enters the observable) are one-hot directions whose structure is resolved at
+// compile time, S (14 x 3) lives in registers.  Lanes are persistent (global work queue), the replica statistics
+// mean_k data_ik and mean_k data_ik^2 are all the loss needs and are staged per observation set in LDS.
+// Stepper: non-autonomous Rosenbrock23 (the reference uses AutoTsit5(TRBDF2): same tolerances, different
+// algorithm -- results agree to solver tolerance).
+#pragma once
+#include "ros23_kernel.hpp"
+
+namespace crnn {
+
+constexpr int kCathNP = 17;       // parameters per particle
+constexpr int kCathNC = 14;       // tangent columns that act on the ODE
+constexpr int kCathMaxD = 128;    // max rows of an observation set
+constexpr int kCathMaxSets = 8;   // observation sets staged in LDS
+
+struct CathodeParams {
+    const double *theta;     // [n_part][17]
+    const double *ts;        // [n_sets][Dmax]
+    const double *dbar;      // [n_sets][Dmax]
+    const double *d2bar;     // [n_sets][Dmax]
+    const double *beta;      // [n_sets]  K/min
+    const int32_t *D;        // [n_sets]
+    double *loss;            // [n_traj]
+    double *grad;            // [n_traj][17] or null
+    double *hrr;             // [n_traj][Dmax] or null
+    int32_t *retcode, *n_saved, *n_accept, *n_reject;   // [n_traj]
+    unsigned long long *queue;
+    int64_t n_traj;          // n_part * n_sets, trajectory tr = particle * n_sets + set
+    int32_t n_sets, Dmax, maxiters, want_grad;
+    double lb, T0, atol, rtol;
+    double gamma, qmin, qmax, beta1, beta2, qsteady_min, qsteady_max, qoldinit;
+};
+
+// ODE-column k -> theta index (dH columns 9..11 are not ODE columns)
+__device__ __forceinline__ constexpr int cath_col_theta(int k) { return k < 9 ? k : k + 3; }
+
+struct CathPoint {   // everything the RHS / tangents need at one (u, t)
+    double l[3], g[3], r[3];   // log clamp(u), d log/du, rates
+    double lt, rt, it;         // log T, R/T, 1/T
+};
+
+__device__ __forceinline__ void cath_point(const double (&u)[3], double T, const double (&th)[kCathNP], double lb, CathPoint &p) {
+    constexpr double Rg = -1.0 / 8.314;
+    p.it = frcp(T);
+    p.lt = flog(T);
+    p.rt = Rg * p.it;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double uj = u[j];
+        const bool inside = (uj >= lb) && (uj <= 10.0);
+        p.l[j] = flog(clampv(uj, lb, 10.0));
+        p.g[j] = inside ? frcp(uj) : 0.0;
+        p.r[j] = exp(fma(th[6 + j], p.lt, fma(th[3 + j] * 1e5, p.rt, fma(th[12 + j], p.l[j], th[j]))));
+    }
+}
+
+__device__ __forceinline__ void cath_f(const CathPoint &p, const double (&th)[kCathNP], double (&f)[3]) {
+    f[0] = -p.r[0];
+    f[1] = fma(th[15], p.r[0], -p.r[1]);
+    f[2] = fma(th[16], p.r[1], -p.r[2]);
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void cathode_kernel(const CathodeParams prm) {
+    __shared__ double ts_s[kCathMaxSets * kCathMaxD];
+    __shared__ double db_s[kCathMaxSets * kCathMaxD];
+    __shared__ double d2_s[kCathMaxSets * kCathMaxD];
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < prm.n_sets * prm.Dmax; idx += BLOCK) {
+        const int s = idx / prm.Dmax, i = idx - s * prm.Dmax;
+        ts_s[s * kCathMaxD + i] = prm.ts[idx];
+        db_s[s * kCathMaxD + i] = prm.dbar[idx];
+        d2_s[s * kCathMaxD + i] = prm.d2bar[idx];
+    }
+    __syncthreads();
+
+    constexpr double d_ = 0.29289321881345248, c32 = 7.4142135623730950, inv12d = 2.4142135623730950;
+    constexpr double Rg = -1.0 / 8.314;
+    const double lqinit = flog(prm.qoldinit);
+    const int64_t nthreads = (int64_t)gridDim.x * BLOCK;
+    int64_t traj = (int64_t)blockIdx.x * BLOCK + tid;
+    int64_t traj_next = (int64_t)atomicAdd(prm.queue, 1ULL) + nthreads;
+
+    double th[kCathNP];
+    double u[3], f0[3];
+    CathPoint P0;
+    double S[kCathNC][3], gS[kCathNC], gD[kCathNP];
+    double t = 0.0, dt = 0.0, lqold = 0.0, loss_sum = 0.0, Tdot = 0.0, tend = 0.0, t0 = 0.0;
+    const double *tsv = ts_s, *dbv = db_s, *d2v = d2_s;
+    int iter = 0, jsave = 0, nacc = 0, nrej = 0, D = 1;
+    bool need_init = true;
+
+    // HRR observable at a save point: loss term and gradient seeds
+    //   w_j = 2 e dH_j r_j n_j g_j (acts on the state tangent), direct theta terms go to gD
+    auto observe = [&](const double (&uu)[3], double tt, double (&w)[3]) {
+        CathPoint q;
+        cath_point(uu, fma(Tdot, tt - 0.0, prm.T0), th, prm.lb, q);
+        const double hv = fma(q.r[0], th[9], fma(q.r[1], th[10], q.r[2] * th[11]));
+        const double db = dbv[jsave];
+        const double e = hv - db;
+        loss_sum += fma(e, e, d2v[jsave] - db * db);
+        if (prm.hrr) prm.hrr[(size_t)traj * prm.Dmax + jsave] = hv;
+        const double e2 = 2.0 * e;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double c = e2 * th[9 + j] * q.r[j];      // 2 e dH_j r_j
+            gD[j] += c;                                    // d/d lnA_j
+            gD[3 + j] = fma(c * 1e5, q.rt, gD[3 + j]);     // d/d Ea_j
+            gD[6 + j] = fma(c, q.lt, gD[6 + j]);           // d/d b_j
+            gD[9 + j] = fma(e2, q.r[j], gD[9 + j]);        // d/d dH_j
+            gD[12 + j] = fma(c, q.l[j], gD[12 + j]);       // d/d n_j
+            w[j] = c * th[12 + j] * q.g[j];
+        }
+    };
+
+    while (true) {
+        if (need_init) {
+            if (traj >= prm.n_traj) break;
+            need_init = false;
+            const int64_t part = traj / prm.n_sets;
+            const int set = (int)(traj - part * prm.n_sets);
+#pragma unroll
+            for (int k = 0; k < kCathNP; ++k) th[k] = prm.theta[(size_t)part * kCathNP + k];
+            D = prm.D[set];
+            tsv = ts_s + set * kCathMaxD; dbv = db_s + set * kCathMaxD; d2v = d2_s + set * kCathMaxD;
+            Tdot = prm.beta[set] * (1.0 / 60.0);
+            t0 = tsv[0];
+            tend = tsv[D - 1];
+            t = t0;
+            u[0] = 1.0; u[1] = 0.0; u[2] = 0.0;          // network.jl:186-187
+#pragma unroll
+            for (int k = 0; k < kCathNC; ++k) { S[k][0] = 0.0; S[k][1] = 0.0; S[k][2] = 0.0; gS[k] = 0.0; }
+#pragma unroll
+            for (int k = 0; k < kCathNP; ++k) gD[k] = 0.0;
+            loss_sum = 0.0; iter = 0; jsave = 0; nacc = 0; nrej = 0;
+            lqold = lqinit;
+            cath_point(u, fma(Tdot, t, prm.T0), th, prm.lb, P0);
+            cath_f(P0, th, f0);
+            {   // Hairer initial step, order 2
+                double sk[3], d0 = 0.0, d1 = 0.0, d2 = 0.0, u1[3], f1[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    sk[i] = frcp(fma(fabs(u[i]), prm.rtol, prm.atol));
+                    d0 = fma(u[i] * sk[i], u[i] * sk[i], d0);
+                    d1 = fma(f0[i] * sk[i], f0[i] * sk[i], d1);
+                }
+                d0 = sqrt(d0 * (1.0 / 3.0)); d1 = sqrt(d1 * (1.0 / 3.0));
+                const double dtmax = tend - t0;
+                double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 / d1);
+                dt0 = fmin(dt0, dtmax);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) u1[i] = fma(dt0, f0[i], u[i]);
+                CathPoint q;
+                cath_point(u1, fma(Tdot, t + dt0, prm.T0), th, prm.lb, q);
+                cath_f(q, th, f1);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { const double e = (f1[i] - f0[i]) * sk[i]; d2 = fma(e, e, d2); }
+                d2 = sqrt(d2 * (1.0 / 3.0)) / dt0;
+                const double dm = fmax(d1, d2);
+                const double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : exp(-0.5 * (4.605170185988091368 + flog(dm)));
+                dt = fmin(fmin(100.0 * dt0, dt1), dtmax);
+            }
+            {   // saveat contains tspan[1]
+                double w[3];
+                observe(u, t0, w);    // tangents are zero at t0: the state seed w is unused, direct terms are kept
+                jsave = 1;
+            }
+        }
+
+        int rc = -1;
+        ++iter;
+        bool last = false;
+        if (jsave >= D) rc = 0;
+        else if (iter > prm.maxiters) rc = 1;
+        if (t + dt * (1.0 + 1e-13) >= tend) { dt = tend - t; last = true; }
+        if (rc < 0 && (!(dt > 0.0) || t + dt == t)) rc = 2;
+
+        if (rc < 0) {
+            const double gam = d_ * dt;
+            // point-0 quantities: a_j = dr_j/du_j, rho_j = dr_j/dt
+            double a[3], sig[3], rho[3], iw[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                a[j] = P0.r[j] * th[12 + j] * P0.g[j];
+                sig[j] = (th[6 + j] * P0.it - th[3 + j] * 1e5 * Rg * P0.it * P0.it) * Tdot;
+                rho[j] = P0.r[j] * sig[j];
+                iw[j] = frcp(fma(gam, a[j], 1.0));
+            }
+            const double l21 = gam * th[15] * a[0], l32 = gam * th[16] * a[1];   // -W[2][1], -W[3][2]
+            auto wsolve = [&](double (&b)[3]) {
+                b[0] *= iw[0];
+                b[1] = fma(l21, b[0], b[1]) * iw[1];
+                b[2] = fma(l32, b[1], b[2]) * iw[2];
+            };
+            double ft[3] = {-rho[0], fma(th[15], rho[0], -rho[1]), fma(th[16], rho[1], -rho[2])};
+            double k1[3], dk[3], k3[3], u1[3], f1[3], unew[3], f2[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) k1[i] = fma(gam, ft[i], f0[i]);
+            wsolve(k1);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) u1[i] = fma(0.5 * dt, k1[i], u[i]);
+            CathPoint P1, P2;
+            cath_point(u1, fma(Tdot, t + 0.5 * dt, prm.T0), th, prm.lb, P1);
+            cath_f(P1, th, f1);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) dk[i] = f1[i] - k1[i];
+            wsolve(dk);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) unew[i] = fma(dt, k1[i] + dk[i], u[i]);
+            const double tnew = last ? tend : t + dt;
+            cath_point(unew, fma(Tdot, tnew, prm.T0), th, prm.lb, P2);
+            cath_f(P2, th, f2);
+            double es = 0.0;
+            bool finite = true;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double k2i = k1[i] + dk[i];
+                k3[i] = f2[i] - c32 * (k2i - f1[i]) - 2.0 * (k1[i] - f0[i]) + dt * ft[i];
+            }
+            wsolve(k3);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double k2i = k1[i] + dk[i];
+                const double ev = dt * (1.0 / 6.0) * (k1[i] - 2.0 * k2i + k3[i]);
+                const double m = fmax(fabs(u[i]), fabs(unew[i]));
+                const double e = ev * frcp(fma(prm.rtol, m, prm.atol));
+                es = fma(e, e, es);
+                finite = finite && isfinite(unew[i]) && isfinite(ev);
+            }
+            es *= (1.0 / 3.0);
+            if (!finite) rc = 3;
+            else {
+                const bool ee_zero = (es == 0.0);
+                const double lEE = 0.5 * flog(ee_zero ? 1.0 : es);
+                const double lq11 = prm.beta1 * lEE;
+                double q = ee_zero ? 1.0 / prm.qmax
+                                   : fmax(1.0 / prm.qmax, fmin(1.0 / prm.qmin, exp(lq11 - prm.beta2 * lqold) / prm.gamma));
+                if (es <= 1.0) {
+                    ++nacc;
+                    // ---- save points: HRR observable, loss, seeds A, B1, B2 for the state tangents ----
+                    double A_[3] = {0.0, 0.0, 0.0}, B1[3] = {0.0, 0.0, 0.0}, B2[3] = {0.0, 0.0, 0.0};
+                    while (jsave < D) {
+                        const double tsj = tsv[jsave];
+                        if (!(tsj <= tnew)) break;
+                        const bool at_end = (tsj == tnew);
+                        const double Th = at_end ? 1.0 : (tsj - t) / dt;
+                        const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
+                        const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d_) * inv12d;
+                        double ui[3], w[3];
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) ui[i] = at_end ? unew[i] : fma(dt, fma(c1, k1[i], c2 * (k1[i] + dk[i])), u[i]);
+                        observe(ui, tsj, w);
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            A_[i] += w[i];
+                            B1[i] = fma(w[i], dt * c1, B1[i]);
+                            B2[i] = fma(w[i], dt * c2, B2[i]);
+                        }
+                        ++jsave;
+                    }
+                    // ---- forward tangents: 14 one-hot directions, structure folded at compile time ----
+                    if (prm.want_grad) {
+#pragma unroll
+                        for (int k = 0; k < kCathNC; ++k) {
+                            const int m = cath_col_theta(k);           // theta index of this column (compile-time)
+                            const int grp = m / 3, j0 = m % 3;         // 0 lnA, 1 Ea, 2 b, 4 n ; 5 -> nu (m = 15, 16)
+                            const bool is_nu2 = (m == 15), is_nu3 = (m == 16);
+                            double(&s)[3] = S[k];
+                            // dz_j (direct part) at a point with (lt, rt, l)
+                            auto dzdir = [&](const CathPoint &p, int j) -> double {
+                                if (m >= 15 || j != j0) return 0.0;
+                                return grp == 0 ? 1.0 : grp == 1 ? 1e5 * p.rt : grp == 2 ? p.lt : p.l[j];
+                            };
+                            auto fprime = [&](const CathPoint &p, const double (&ss)[3], double (&rp)[3], double (&fp)[3]) {
+#pragma unroll
+                                for (int j = 0; j < 3; ++j) rp[j] = p.r[j] * fma(th[12 + j] * p.g[j], ss[j], dzdir(p, j));
+                                fp[0] = -rp[0];
+                                fp[1] = fma(th[15], rp[0], -rp[1]) + (is_nu2 ? p.r[0] : 0.0);
+                                fp[2] = fma(th[16], rp[1], -rp[2]) + (is_nu3 ? p.r[1] : 0.0);
+                            };
+                            double rp0[3], f0p[3];
+                            fprime(P0, s, rp0, f0p);
+                            // a'_j, rho'_j at point 0
+                            double ap[3], rhop[3];
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) {
+                                const double dn = (grp == 4 && j == j0 && m < 15) ? 1.0 : 0.0;
+                                ap[j] = fma(rp0[j], th[12 + j] * P0.g[j], P0.r[j] * P0.g[j] * (dn - th[12 + j] * P0.g[j] * s[j]));
+                                const double dsig = (m < 15 && j == j0) ? (grp == 2 ? P0.it * Tdot : grp == 1 ? -1e5 * Rg * P0.it * P0.it * Tdot : 0.0) : 0.0;
+                                rhop[j] = fma(rp0[j], sig[j], P0.r[j] * dsig);
+                            }
+                            const double ftp[3] = {-rhop[0], fma(th[15], rhop[0], -rhop[1]) + (is_nu2 ? rho[0] : 0.0),
+                                                   fma(th[16], rhop[1], -rhop[2]) + (is_nu3 ? rho[1] : 0.0)};
+                            auto jprime = [&](const double (&v)[3], double (&o)[3]) {
+                                o[0] = -ap[0] * v[0];
+                                o[1] = fma(th[15], ap[0] * v[0], -ap[1] * v[1]) + (is_nu2 ? a[0] * v[0] : 0.0);
+                                o[2] = fma(th[16], ap[1] * v[1], -ap[2] * v[2]) + (is_nu3 ? a[1] * v[1] : 0.0);
+                            };
+                            double jk[3], k1p[3], dkp[3], s1[3], rp1[3], f1p[3];
+                            jprime(k1, jk);
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) k1p[i] = fma(gam, ftp[i] + jk[i], f0p[i]);
+                            wsolve(k1p);
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) s1[i] = fma(0.5 * dt, k1p[i], s[i]);
+                            fprime(P1, s1, rp1, f1p);
+                            jprime(dk, jk);
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) dkp[i] = fma(gam, jk[i], f1p[i] - k1p[i]);
+                            wsolve(dkp);
+                            double acc = 0.0;
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) {
+                                const double k2p = k1p[i] + dkp[i];
+                                acc = fma(A_[i], s[i], acc);
+                                acc = fma(B1[i], k1p[i], acc);
+                                acc = fma(B2[i], k2p, acc);
+                                s[i] = fma(dt, k2p, s[i]);
+                            }
+                            gS[k] += acc;
+                        }
+                    }
+                    // ---- advance (FSAL) ----
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { u[i] = unew[i]; f0[i] = f2[i]; }
+                    P0 = P2;
+                    t = tnew;
+                    if (q >= prm.qsteady_min && q <= prm.qsteady_max) q = 1.0;
+                    lqold = ee_zero ? lqinit : fmax(lEE, lqinit);
+                    dt = fmin(dt / q, tend - t0);
+                    if (jsave >= D) rc = 0;
+                } else {
+                    ++nrej;
+                    dt = dt / fmin(1.0 / prm.qmin, exp(lq11) / prm.gamma);
+                }
+            }
+        }
+
+        if (rc >= 0) {
+            // loss = sum(...)/n_replicas/size(exp_data)[1]: the FULL row count, also for a truncated solution (network.jl:266)
+            const double invD = 1.0 / (double)D;
+            prm.loss[traj] = loss_sum * invD;
+            prm.retcode[traj] = rc;
+            prm.n_saved[traj] = jsave;
+            prm.n_accept[traj] = nacc;
+            prm.n_reject[traj] = nrej;
+            if (prm.grad) {
+                double *go = prm.grad + (size_t)traj * kCathNP;
+#pragma unroll
+                for (int m = 0; m < kCathNP; ++m) go[m] = gD[m] * invD;
+                if (prm.want_grad) {
+#pragma unroll
+                    for (int k = 0; k < kCathNC; ++k) {
+                        const int m = cath_col_theta(k);
+                        go[m] = (gD[m] + gS[k]) * invD;
+                    }
+                }
+            }
+            traj = traj_next;
+            traj_next = (int64_t)atomicAdd(prm.queue, 1ULL) + nthreads;
+            need_init = true;
+        }
+    }
+}
+
+}  // namespace crnn

@@ -15,6 +15,7 @@
 #include "p2vec.hpp"
 #include "ros23_kernel.hpp"
 #include "tsit5_kernel.hpp"
+#include "cathode_kernel.hpp"
 
 namespace {
 
@@ -273,6 +274,42 @@ int32_t fill_stats(Ctx *c, const double *red_host, int npart, crnn_stats *st) {
     return 0;
 }
 
+}  // namespace
+
+// ---- cathode-UQ context (entry points at the end of the file) ----
+namespace {
+struct CathCtx {
+    crnn_cathode_config cfg{};
+    std::string err;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int num_cu = 256;
+    int n_sets = 0, Dmax = 0;
+    double *d_ts = nullptr, *d_dbar = nullptr, *d_d2bar = nullptr, *d_beta = nullptr;
+    int32_t *d_D = nullptr;
+    unsigned long long *d_queue = nullptr;
+    // per-call buffers
+    double *d_theta = nullptr, *d_loss = nullptr, *d_grad = nullptr, *d_hrr = nullptr;
+    int32_t *d_ret = nullptr, *d_nsv = nullptr, *d_nacc = nullptr, *d_nrej = nullptr;
+    size_t cap_part = 0, cap_traj = 0, cap_hrr = 0;
+};
+int32_t cfail(CathCtx *c, const std::string &msg) {
+    g_last_error = msg;
+    if (c) c->err = msg;
+    return -1;
+}
+#define CHIP(c, expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return cfail(c, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+template <class T>
+int32_t cgrow(CathCtx *c, T **p, size_t n) {
+    if (*p) CHIP(c, hipFree(*p));
+    *p = nullptr;
+    CHIP(c, hipMalloc((void **)p, n * sizeof(T)));
+    return 0;
+}
 }  // namespace
 
 extern "C" {
@@ -784,6 +821,157 @@ int32_t crnn_allreduce_grad(crnn_ctx *ctx, double *buf, int32_t n) {
     NCCL_TRY(c, ncclAllReduce(c->d_comm_buf, c->d_comm_buf, n, ncclDouble, ncclSum, c->comm, c->stream));
     HIP_TRY(c, hipMemcpyAsync(buf, c->d_comm_buf, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+
+// ============================================================================ cathode-UQ entry points
+
+int32_t crnn_cathode_config_default(crnn_cathode_config *cfg) {
+    if (!cfg) return cfail(nullptr, "crnn_cathode_config_default: null cfg");
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->abi_version = CRNN_ABI_VERSION;
+    cfg->maxiters = 2500000;   // config.yaml:10 asks for 2.5e9: more than int32; never reached in practice
+    cfg->lb_clamp = 1e-16; cfg->T0 = 373.15; cfg->atol = 1e-12; cfg->rtol = 1e-3;
+    cfg->gamma = 0.9; cfg->qmin = 0.2; cfg->qmax = 10.0; cfg->beta1 = 7.0 / 20.0; cfg->beta2 = 2.0 / 10.0;
+    cfg->qsteady_min = 1.0; cfg->qsteady_max = 1.2; cfg->qoldinit = 1e-4;
+    return 0;
+}
+
+int32_t crnn_cathode_create(const crnn_cathode_config *cfg, crnn_cathode_ctx **out) {
+    if (!cfg || !out) return cfail(nullptr, "crnn_cathode_create: null pointer");
+    *out = nullptr;
+    if (cfg->abi_version != CRNN_ABI_VERSION) return cfail(nullptr, "crnn_cathode_create: abi_version mismatch");
+    if (!(cfg->atol > 0) || !(cfg->rtol > 0) || cfg->maxiters < 1) return cfail(nullptr, "crnn_cathode_create: bad tolerances/maxiters");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1) return cfail(nullptr, std::string("crnn_cathode_create: no HIP device (") + hipGetErrorString(e) + ")");
+    if (cfg->device < 0 || cfg->device >= ndev) return cfail(nullptr, "crnn_cathode_create: device ordinal out of range");
+    CathCtx *c = new CathCtx();
+    c->cfg = *cfg;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(cfg->device) != hipSuccess || hipGetDeviceProperties(&prop, cfg->device) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
+        hipEventCreate(&c->ev1) != hipSuccess || hipMalloc((void **)&c->d_queue, sizeof(unsigned long long)) != hipSuccess) {
+        crnn_cathode_destroy((crnn_cathode_ctx *)c);
+        return cfail(nullptr, "crnn_cathode_create: HIP initialisation failed");
+    }
+    c->num_cu = prop.multiProcessorCount;
+    *out = reinterpret_cast<crnn_cathode_ctx *>(c);
+    return 0;
+}
+
+void crnn_cathode_destroy(crnn_cathode_ctx *ctx) {
+    CathCtx *c = reinterpret_cast<CathCtx *>(ctx);
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void *ptrs[] = {c->d_ts, c->d_dbar, c->d_d2bar, c->d_beta, c->d_D, c->d_queue, c->d_theta, c->d_loss, c->d_grad,
+                    c->d_hrr, c->d_ret, c->d_nsv, c->d_nacc, c->d_nrej};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *crnn_cathode_last_error(const crnn_cathode_ctx *ctx) {
+    const CathCtx *c = reinterpret_cast<const CathCtx *>(ctx);
+    return c ? c->err.c_str() : g_last_error.c_str();
+}
+
+int32_t crnn_cathode_set_obs(crnn_cathode_ctx *ctx, int32_t n_sets, int32_t Dmax, const int32_t *D, const double *ts,
+                             const double *dbar, const double *d2bar, const double *beta) {
+    CathCtx *c = reinterpret_cast<CathCtx *>(ctx);
+    if (!c) return cfail(nullptr, "null ctx");
+    if (!D || !ts || !dbar || !d2bar || !beta) return cfail(c, "crnn_cathode_set_obs: null pointer");
+    if (n_sets < 1 || n_sets > CRNN_CATHODE_MAX_SETS) return cfail(c, "crnn_cathode_set_obs: n_sets must be in [1, 8]");
+    if (Dmax < 2 || Dmax > CRNN_CATHODE_MAX_D) return cfail(c, "crnn_cathode_set_obs: Dmax must be in [2, 128]");
+    for (int s = 0; s < n_sets; ++s) {
+        if (D[s] < 2 || D[s] > Dmax) return cfail(c, "crnn_cathode_set_obs: D[s] out of range");
+        if (!(beta[s] > 0)) return cfail(c, "crnn_cathode_set_obs: heating rates must be positive");
+        for (int i = 1; i < D[s]; ++i)
+            if (!(ts[(size_t)s * Dmax + i] > ts[(size_t)s * Dmax + i - 1])) return cfail(c, "crnn_cathode_set_obs: ts must be strictly increasing");
+    }
+    CHIP(c, hipSetDevice(c->cfg.device));
+    CHIP(c, hipStreamSynchronize(c->stream));
+    size_t n = (size_t)n_sets * Dmax;
+    if (cgrow(c, &c->d_ts, n) || cgrow(c, &c->d_dbar, n) || cgrow(c, &c->d_d2bar, n) || cgrow(c, &c->d_beta, (size_t)n_sets) ||
+        cgrow(c, &c->d_D, (size_t)n_sets))
+        return -1;
+    CHIP(c, hipMemcpy(c->d_ts, ts, n * sizeof(double), hipMemcpyHostToDevice));
+    CHIP(c, hipMemcpy(c->d_dbar, dbar, n * sizeof(double), hipMemcpyHostToDevice));
+    CHIP(c, hipMemcpy(c->d_d2bar, d2bar, n * sizeof(double), hipMemcpyHostToDevice));
+    CHIP(c, hipMemcpy(c->d_beta, beta, n_sets * sizeof(double), hipMemcpyHostToDevice));
+    CHIP(c, hipMemcpy(c->d_D, D, n_sets * sizeof(int32_t), hipMemcpyHostToDevice));
+    c->n_sets = n_sets;
+    c->Dmax = Dmax;
+    c->cap_hrr = 0;
+    return 0;
+}
+
+int32_t crnn_cathode_solve(crnn_cathode_ctx *ctx, const double *theta, int64_t n_part, double *loss, double *grad,
+                           double *hrr, int32_t *retcode, int32_t *n_saved, crnn_stats *stats) {
+    CathCtx *c = reinterpret_cast<CathCtx *>(ctx);
+    if (!c) return cfail(nullptr, "null ctx");
+    if (!theta || n_part < 1) return cfail(c, "crnn_cathode_solve: bad theta / n_part");
+    if (c->n_sets < 1) return cfail(c, "crnn_cathode_solve: no observation sets (crnn_cathode_set_obs)");
+    CHIP(c, hipSetDevice(c->cfg.device));
+    const int64_t ntraj = n_part * c->n_sets;
+    if ((size_t)n_part > c->cap_part) {
+        if (cgrow(c, &c->d_theta, (size_t)n_part * CRNN_CATHODE_NP)) return -1;
+        c->cap_part = (size_t)n_part;
+    }
+    if ((size_t)ntraj > c->cap_traj) {
+        if (cgrow(c, &c->d_loss, (size_t)ntraj) || cgrow(c, &c->d_grad, (size_t)ntraj * CRNN_CATHODE_NP) ||
+            cgrow(c, &c->d_ret, (size_t)ntraj) || cgrow(c, &c->d_nsv, (size_t)ntraj) || cgrow(c, &c->d_nacc, (size_t)ntraj) ||
+            cgrow(c, &c->d_nrej, (size_t)ntraj))
+            return -1;
+        c->cap_traj = (size_t)ntraj;
+    }
+    if (hrr && (size_t)ntraj * c->Dmax > c->cap_hrr) {
+        if (cgrow(c, &c->d_hrr, (size_t)ntraj * c->Dmax)) return -1;
+        c->cap_hrr = (size_t)ntraj * c->Dmax;
+    }
+    CHIP(c, hipMemcpyAsync(c->d_theta, theta, sizeof(double) * (size_t)n_part * CRNN_CATHODE_NP, hipMemcpyHostToDevice, c->stream));
+    CHIP(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), c->stream));
+    if (hrr) CHIP(c, hipMemsetAsync(c->d_hrr, 0, sizeof(double) * (size_t)ntraj * c->Dmax, c->stream));
+    crnn::CathodeParams prm{};
+    prm.theta = c->d_theta; prm.ts = c->d_ts; prm.dbar = c->d_dbar; prm.d2bar = c->d_d2bar; prm.beta = c->d_beta; prm.D = c->d_D;
+    prm.loss = c->d_loss; prm.grad = c->d_grad; prm.hrr = hrr ? c->d_hrr : nullptr;
+    prm.retcode = c->d_ret; prm.n_saved = c->d_nsv; prm.n_accept = c->d_nacc; prm.n_reject = c->d_nrej;
+    prm.queue = c->d_queue;
+    prm.n_traj = ntraj; prm.n_sets = c->n_sets; prm.Dmax = c->Dmax; prm.maxiters = c->cfg.maxiters;
+    prm.want_grad = grad ? 1 : 0;
+    prm.lb = c->cfg.lb_clamp; prm.T0 = c->cfg.T0; prm.atol = c->cfg.atol; prm.rtol = c->cfg.rtol;
+    prm.gamma = c->cfg.gamma; prm.qmin = c->cfg.qmin; prm.qmax = c->cfg.qmax; prm.beta1 = c->cfg.beta1; prm.beta2 = c->cfg.beta2;
+    prm.qsteady_min = c->cfg.qsteady_min; prm.qsteady_max = c->cfg.qsteady_max; prm.qoldinit = c->cfg.qoldinit;
+    constexpr int kB = 256;
+    int occ = 0;
+    CHIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)crnn::cathode_kernel<kB>, kB, 0));
+    if (occ < 1) occ = 1;
+    int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((ntraj + kB - 1) / kB, (int64_t)c->num_cu * occ));
+    CHIP(c, hipEventRecord(c->ev0, c->stream));
+    hipLaunchKernelGGL(crnn::cathode_kernel<kB>, dim3(nblk), dim3(kB), 0, c->stream, prm);
+    CHIP(c, hipGetLastError());
+    CHIP(c, hipEventRecord(c->ev1, c->stream));
+    std::vector<int32_t> h_ret((size_t)ntraj), h_nacc((size_t)ntraj), h_nrej((size_t)ntraj);
+    if (loss) CHIP(c, hipMemcpyAsync(loss, c->d_loss, sizeof(double) * ntraj, hipMemcpyDeviceToHost, c->stream));
+    if (grad) CHIP(c, hipMemcpyAsync(grad, c->d_grad, sizeof(double) * ntraj * CRNN_CATHODE_NP, hipMemcpyDeviceToHost, c->stream));
+    if (hrr) CHIP(c, hipMemcpyAsync(hrr, c->d_hrr, sizeof(double) * ntraj * c->Dmax, hipMemcpyDeviceToHost, c->stream));
+    if (n_saved) CHIP(c, hipMemcpyAsync(n_saved, c->d_nsv, sizeof(int32_t) * ntraj, hipMemcpyDeviceToHost, c->stream));
+    CHIP(c, hipMemcpyAsync(h_ret.data(), c->d_ret, sizeof(int32_t) * ntraj, hipMemcpyDeviceToHost, c->stream));
+    CHIP(c, hipMemcpyAsync(h_nacc.data(), c->d_nacc, sizeof(int32_t) * ntraj, hipMemcpyDeviceToHost, c->stream));
+    CHIP(c, hipMemcpyAsync(h_nrej.data(), c->d_nrej, sizeof(int32_t) * ntraj, hipMemcpyDeviceToHost, c->stream));
+    CHIP(c, hipStreamSynchronize(c->stream));
+    if (retcode) std::memcpy(retcode, h_ret.data(), sizeof(int32_t) * ntraj);
+    if (stats) {
+        stats->n_traj = ntraj; stats->n_ok = 0; stats->n_accept = 0; stats->n_reject = 0;
+        for (int64_t i = 0; i < ntraj; ++i) { stats->n_ok += h_ret[i] == 0; stats->n_accept += h_nacc[i]; stats->n_reject += h_nrej[i]; }
+        float ms = 0.f;
+        CHIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        stats->kernel_ms = ms;
+    }
     return 0;
 }
 

@@ -205,6 +205,43 @@ int32_t crnn_comm_destroy(crnn_ctx *ctx);
 /* In-place sum of a host vector over all ranks (gradient | loss | count). */
 int32_t crnn_allreduce_grad(crnn_ctx *ctx, double *buf, int32_t n);
 
+/* ======================================================================== *
+ * Bayesian cathode CRNN (BASELINE config 5): per-particle parameters, heat-release-rate observable.
+ * Replaces, per (particle, heating rate):
+ *   pred_n_ode      Cathode_NCM333_UQ/src_333/network.jl:196-218   (solve + HRR_getter :167-175)
+ *   loss_neuralode  network.jl:262-266    sum((hrr - data).^2) / n_replicas / D
+ *   the loop body of dlnprob  network.jl:227-252   (loss and ForwardDiff.gradient per particle; the division by
+ *   Normalizer.^2 and the SVGD update stay on the host)
+ * theta: [n_part x 17] row-major, each row = p .* p_scales as the reference forms it inside crnn!:
+ *   [lnA(3) | Ea(3) (exponent uses Ea*1e5) | b(3) | dH(3) | reaction order n(3) | nu2, nu3].
+ * An observation set = one heating rate: its time grid ts (from the temperatures, dataset.jl:19-23), the replica
+ * statistics dbar_i = mean_k data_ik and d2bar_i = mean_k data_ik^2 (all the MSE needs), beta in K/min.
+ * Trajectory index = particle * n_sets + set.  Stepper: non-autonomous Rosenbrock23 (the reference runs
+ * AutoTsit5(TRBDF2)): agreement to solver tolerance only.
+ * ======================================================================== */
+#define CRNN_CATHODE_NP 17
+#define CRNN_CATHODE_MAX_D 128
+#define CRNN_CATHODE_MAX_SETS 8
+typedef struct crnn_cathode_config {
+    int32_t abi_version, device, maxiters, reserved0;
+    double lb_clamp;   /* config.yaml:6   1e-16 */
+    double T0;         /* network.jl:189  373.15 K */
+    double atol, rtol; /* config.yaml:7 lb_abstol 1e-12; reltol = DiffEq default 1e-3 */
+    double gamma, qmin, qmax, beta1, beta2, qsteady_min, qsteady_max, qoldinit;
+} crnn_cathode_config;
+typedef struct crnn_cathode_ctx crnn_cathode_ctx;
+int32_t crnn_cathode_config_default(crnn_cathode_config *cfg);
+int32_t crnn_cathode_create(const crnn_cathode_config *cfg, crnn_cathode_ctx **out);
+void crnn_cathode_destroy(crnn_cathode_ctx *ctx);
+const char *crnn_cathode_last_error(const crnn_cathode_ctx *ctx);
+/* ts, dbar, d2bar: [n_sets x Dmax] row-major (rows padded beyond D[s]); beta, D: [n_sets] */
+int32_t crnn_cathode_set_obs(crnn_cathode_ctx *ctx, int32_t n_sets, int32_t Dmax, const int32_t *D, const double *ts,
+                             const double *dbar, const double *d2bar, const double *beta);
+/* loss [n_part*n_sets]; grad [n_part*n_sets x 17] or NULL; hrr [n_part*n_sets x Dmax] or NULL;
+ * retcode, n_saved [n_part*n_sets] or NULL */
+int32_t crnn_cathode_solve(crnn_cathode_ctx *ctx, const double *theta, int64_t n_part, double *loss, double *grad,
+                           double *hrr, int32_t *retcode, int32_t *n_saved, crnn_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

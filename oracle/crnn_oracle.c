@@ -885,3 +885,231 @@ void orc_opt_update(const orc_opt *o, int P, double *p, const double *grad_in, d
     }
     bp[0] *= o->beta1; bp[1] *= o->beta2;
 }
+
+/* ======================================================================== */
+/* Cathode-UQ path (BASELINE config 5).  TEST INFRASTRUCTURE like the rest.  */
+/*   crnn!        Cathode_NCM333_UQ/src_333/network.jl:152-165                */
+/*   T(t)         getsampletemp, network.jl:143-149 (T0 = 373.15, :189)       */
+/*   HRR_getter   network.jl:167-175                                          */
+/*   pred_n_ode   network.jl:196-218 (tspan = [ts[1], ts[end]], saveat = ts)  */
+/*   loss         network.jl:262-266: sum((pred - data).^2)/n_replicas/D      */
+/*   gradient     ForwardDiff.gradient, network.jl:232                        */
+/* theta (17, already multiplied by p_scales as the reference does inside the */
+/* RHS): [lnA(3) | Ea(3) (the exponent is R/T * Ea * 1e5) | b(3) | dH(3) |    */
+/* order n(3) | nu2, nu3].  The reference's solver here is                    */
+/* AutoTsit5(TRBDF2(autodiff=true)); this restatement integrates with the     */
+/* non-autonomous Rosenbrock23 of this file (same tolerances): results agree  */
+/* with the reference only to within the solver tolerance -- parity unpinned. */
+/* Tangents are taken by complex-step differentiation of the closed forms, so */
+/* the oracle shares no derivative code with the HIP kernel.                  */
+/* ======================================================================== */
+#include <complex.h>
+typedef double complex cplx;
+
+typedef struct orc_cathode {
+    double lb_clamp, T0, beta;      /* beta in K/min: T = T0 + beta/60 t */
+    double atol, rtol;
+    int32_t maxiters, pad_;
+    double gamma, qmin, qmax, beta1, beta2, qsteady_min, qsteady_max, qoldinit;
+} orc_cathode;
+
+void orc_cathode_defaults(orc_cathode *c) {
+    memset(c, 0, sizeof(*c));
+    c->lb_clamp = 1e-16; c->T0 = 373.15; c->beta = 10.0; c->atol = 1e-12; c->rtol = 1e-3; c->maxiters = 2500000;
+    c->gamma = 0.9; c->qmin = 0.2; c->qmax = 10.0; c->beta1 = 7.0 / 20.0; c->beta2 = 2.0 / 10.0;
+    c->qsteady_min = 1.0; c->qsteady_max = 1.2; c->qoldinit = 1e-4;
+}
+int orc_sizeof_cathode(void) { return (int)sizeof(orc_cathode); }
+
+static const double CATH_R = -1.0 / 8.314;   /* network.jl:151 */
+
+static cplx cclampc(cplx v, double lo, double hi) {
+    double re = creal(v);
+    return re > hi ? (cplx)hi : (re < lo ? (cplx)lo : v);
+}
+/* rates r_j(t, u; theta) in complex arithmetic */
+static void cath_rates(const orc_cathode *c, const cplx *th, const cplx *u, double t, cplx *r) {
+    double T = c->T0 + c->beta / 60.0 * t;
+    for (int j = 0; j < 3; ++j) {
+        cplx lx = clog(cclampc(u[j], c->lb_clamp, 10.0));
+        r[j] = cexp(th[6 + j] * log(T) + (CATH_R / T) * (th[3 + j] * 1e5) + th[12 + j] * lx + th[j]);
+    }
+}
+static void cath_rhs(const orc_cathode *c, const cplx *th, const cplx *u, double t, cplx *du) {
+    cplx r[3];
+    cath_rates(c, th, u, t, r);
+    du[0] = -r[0];
+    du[1] = -r[1] + th[15] * r[0];
+    du[2] = -r[2] + th[16] * r[1];
+}
+static void cath_rhs_real(const orc_cathode *c, const double *th, const double *u, double t, double *du) {
+    cplx thc[17], uc[3], d[3];
+    for (int k = 0; k < 17; ++k) thc[k] = th[k];
+    for (int i = 0; i < 3; ++i) uc[i] = u[i];
+    cath_rhs(c, thc, uc, t, d);
+    for (int i = 0; i < 3; ++i) du[i] = creal(d[i]);
+}
+/* analytic Jacobian and time derivative in complex arithmetic (so that their directional derivatives come for free) */
+static void cath_jac_ft(const orc_cathode *c, const cplx *th, const cplx *u, double t, cplx *J /*3x3 col-major*/, cplx *ft) {
+    double T = c->T0 + c->beta / 60.0 * t, Td = c->beta / 60.0;
+    cplx r[3], a[3], rho[3];
+    cath_rates(c, th, u, t, r);
+    for (int j = 0; j < 3; ++j) {
+        double re = creal(u[j]);
+        cplx g = (re >= c->lb_clamp && re <= 10.0) ? 1.0 / u[j] : 0.0;
+        a[j] = r[j] * th[12 + j] * g;
+        rho[j] = r[j] * (th[6 + j] * (Td / T) - (th[3 + j] * 1e5) * CATH_R * Td / (T * T));
+    }
+    for (int k = 0; k < 9; ++k) J[k] = 0.0;
+    J[0 + 3 * 0] = -a[0];
+    J[1 + 3 * 0] = th[15] * a[0]; J[1 + 3 * 1] = -a[1];
+    J[2 + 3 * 1] = th[16] * a[1]; J[2 + 3 * 2] = -a[2];
+    ft[0] = -rho[0];
+    ft[1] = -rho[1] + th[15] * rho[0];
+    ft[2] = -rho[2] + th[16] * rho[1];
+}
+void orc_cathode_rhs(const orc_cathode *c, const double *th, const double *u, double t, double *du) { cath_rhs_real(c, th, u, t, du); }
+
+static void csolve3(const double *W, const int *piv, cplx *b) {   /* real LU applied to a complex rhs */
+    for (int k = 0; k < 3; ++k) { int p = piv[k]; if (p != k) { cplx tt = b[k]; b[k] = b[p]; b[p] = tt; } }
+    for (int k = 0; k < 3; ++k) { cplx a = b[k]; for (int i = k + 1; i < 3; ++i) b[i] -= W[i + 3 * k] * a; }
+    for (int k = 2; k >= 0; --k) { b[k] /= W[k + 3 * k]; cplx a = b[k]; for (int i = 0; i < k; ++i) b[i] -= W[i + 3 * k] * a; }
+}
+
+/* One (particle, heating-rate) trajectory: HRR prediction, MSE loss against the replica statistics
+   dbar[i] = mean_k data[i,k], d2bar[i] = mean_k data[i,k]^2, gradient wrt theta (17).
+   Complex-step: for direction e_k the whole step is evaluated at theta + i*h*e_k, u + i*h*s_k with the REAL
+   factorisation of W (dt and the pivots are real), which is exactly the first-order tangent. */
+int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *ts, int D,
+                          const double *dbar, const double *d2bar, double *hrr /*[D] or NULL*/,
+                          double *loss_out, double *grad /*[17] or NULL*/, int32_t *n_saved_out, orc_stats *st) {
+    const double d = 1.0 / (2.0 + sqrt(2.0)), c32 = 6.0 + sqrt(2.0), h = 1e-30;
+    const int P = grad ? 17 : 0;
+    const double t0 = ts[0], tend = ts[D - 1];
+    double t = t0;
+    cplx u[18][3];   /* u[P] = primal (imag 0); u[k] = primal + i h s_k */
+    cplx thk[18][17];
+    for (int k = 0; k <= 17; ++k) {
+        for (int m = 0; m < 17; ++m) thk[k][m] = th[m] + ((k < 17 && m == k) ? I * h : 0.0);
+        u[k][0] = 1.0; u[k][1] = 0.0; u[k][2] = 0.0;      /* u0 = (1,0,0), network.jl:186-187 */
+    }
+    const int PR = 17;  /* index of the primal copy */
+    cplx f0[18][3];
+    for (int k = 0; k <= 17; ++k) if (k == PR || k < P) cath_rhs(c, thk[k], u[k], t, f0[k]);
+    /* initial step (Hairer, order 2) on the primal */
+    double dt;
+    {
+        double sk[3], d0 = 0, d1 = 0, d2 = 0, ur[3], fr[3], u1[3], f1[3];
+        for (int i = 0; i < 3; ++i) { ur[i] = creal(u[PR][i]); fr[i] = creal(f0[PR][i]); sk[i] = c->atol + fabs(ur[i]) * c->rtol;
+            d0 += (ur[i] / sk[i]) * (ur[i] / sk[i]); d1 += (fr[i] / sk[i]) * (fr[i] / sk[i]); }
+        d0 = sqrt(d0 / 3); d1 = sqrt(d1 / 3);
+        double dtmax = tend - t0;
+        double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        dt0 = fmin(dt0, dtmax);
+        for (int i = 0; i < 3; ++i) u1[i] = ur[i] + dt0 * fr[i];
+        cath_rhs_real(c, th, u1, t + dt0, f1);
+        for (int i = 0; i < 3; ++i) { double e = (f1[i] - fr[i]) / sk[i]; d2 += e * e; }
+        d2 = sqrt(d2 / 3) / dt0;
+        double dm = fmax(d1, d2);
+        double dt1 = dm <= 1e-15 ? fmax(1e-6, dt0 * 1e-3) : pow(10.0, -(2.0 + log10(dm)) / 2.0);
+        dt = fmin(fmin(100 * dt0, dt1), dtmax);
+    }
+    double qold = c->qoldinit, loss_sum = 0.0, g[17];
+    for (int k = 0; k < 17; ++k) g[k] = 0.0;
+    int jsave = 0, retcode = 0, iter = 0;
+#define CATH_SAVE(UARR_EXPR, tsv)                                                                                \
+    do {                                                                                                        \
+        cplx hv[18];                                                                                            \
+        for (int k = 0; k <= 17; ++k) if (k == PR || k < P) {                                                   \
+            cplx uu[3], r[3];                                                                                   \
+            for (int i = 0; i < 3; ++i) uu[i] = (UARR_EXPR);                                                    \
+            cath_rates(c, thk[k], uu, (tsv), r);                                                                \
+            hv[k] = r[0] * thk[k][9] + r[1] * thk[k][10] + r[2] * thk[k][11];                                   \
+        }                                                                                                       \
+        double hp = creal(hv[PR]), e = hp - dbar[jsave];                                                        \
+        if (hrr) hrr[jsave] = hp;                                                                               \
+        loss_sum += e * e + (d2bar[jsave] - dbar[jsave] * dbar[jsave]);                                         \
+        for (int k = 0; k < P; ++k) g[k] += 2.0 * e * cimag(hv[k]) / h;                                         \
+        ++jsave;                                                                                                \
+    } while (0)
+    CATH_SAVE(u[k][i], t0);   /* saveat contains tspan[1] */
+    while (jsave < D) {
+        if (++iter > c->maxiters) { retcode = 1; break; }
+        int last = 0;
+        if (t + dt * (1.0 + 1e-13) >= tend) { dt = tend - t; last = 1; }
+        if (!(dt > 0.0) || t + dt == t) { retcode = 2; break; }
+        const double gam = d * dt;
+        cplx Jc[9], ftc[3];
+        double W[9]; int piv[3];
+        cath_jac_ft(c, thk[PR], u[PR], t, Jc, ftc);
+        for (int cc = 0; cc < 3; ++cc) for (int i = 0; i < 3; ++i) W[i + 3 * cc] = (i == cc ? 1.0 : 0.0) - gam * creal(Jc[i + 3 * cc]);
+        if (lu_factor(3, W, piv) != 0) { retcode = 3; break; }
+        cplx k1[18][3], k2[18][3], k3[18][3], un[18][3], f2[18][3];
+        int finite = 1;
+        double ev[3], EEst = 0.0;
+        for (int pass = 0; pass < 2; ++pass) {       /* pass 0: primal (and accept test), pass 1: tangents if accepted */
+            for (int k = 0; k <= 17; ++k) {
+                if (pass == 0 ? (k != PR) : !(k < P)) continue;
+                cplx Jk[9], ftk[3], b[3], u1[3], f1[3], tmp[3];
+                cath_jac_ft(c, thk[k], u[k], t, Jk, ftk);
+                /* W_k k1 = f0 + gam ft, with W_k = W + i h W': solve with the real W and move i h W' k1 to the rhs:
+                   to first order in h this is one fixed-point sweep: k1 = W^-1 (rhs + gam (J_k - J) k1_real) */
+                for (int i = 0; i < 3; ++i) b[i] = f0[k][i] + gam * ftk[i];
+                if (k != PR) for (int i = 0; i < 3; ++i) for (int cc = 0; cc < 3; ++cc) b[i] += gam * (Jk[i + 3 * cc] - creal(Jk[i + 3 * cc])) * creal(k1[PR][cc]);
+                csolve3(W, piv, b);
+                for (int i = 0; i < 3; ++i) { k1[k][i] = b[i]; u1[i] = u[k][i] + 0.5 * dt * b[i]; }
+                cath_rhs(c, thk[k], u1, t + 0.5 * dt, f1);
+                for (int i = 0; i < 3; ++i) tmp[i] = f1[i] - k1[k][i];
+                if (k != PR) for (int i = 0; i < 3; ++i) for (int cc = 0; cc < 3; ++cc) tmp[i] += gam * (Jk[i + 3 * cc] - creal(Jk[i + 3 * cc])) * creal(k2[PR][cc] - k1[PR][cc]);
+                csolve3(W, piv, tmp);
+                for (int i = 0; i < 3; ++i) { k2[k][i] = tmp[i] + k1[k][i]; un[k][i] = u[k][i] + dt * k2[k][i]; }
+                cath_rhs(c, thk[k], un[k], t + dt, f2[k]);
+                if (k == PR) {
+                    for (int i = 0; i < 3; ++i) b[i] = f2[k][i] - c32 * (k2[k][i] - f1[i]) - 2.0 * (k1[k][i] - f0[k][i]) + dt * ftk[i];
+                    csolve3(W, piv, b);
+                    for (int i = 0; i < 3; ++i) { k3[k][i] = b[i]; ev[i] = dt / 6.0 * creal(k1[k][i] - 2.0 * k2[k][i] + k3[k][i]);
+                        if (!isfinite(creal(un[k][i])) || !isfinite(ev[i])) finite = 0; }
+                }
+            }
+            if (pass == 0) {
+                if (!finite) break;
+                double s_ = 0.0;
+                for (int i = 0; i < 3; ++i) { double m = fmax(fabs(creal(u[PR][i])), fabs(creal(un[PR][i]))); double e = ev[i] / (c->atol + c->rtol * m); s_ += e * e; }
+                EEst = sqrt(s_ / 3.0);
+                if (!(EEst <= 1.0) || P == 0) break;
+            }
+        }
+        if (!finite) { retcode = 3; break; }
+        int accept = (EEst <= 1.0);
+        double q, q11 = 0.0;
+        if (EEst == 0.0) q = 1.0 / c->qmax;
+        else { q11 = pow(EEst, c->beta1); q = q11 / pow(qold, c->beta2); q = fmax(1.0 / c->qmax, fmin(1.0 / c->qmin, q / c->gamma)); }
+        if (accept) {
+            if (st) st->naccept++;
+            if (q >= c->qsteady_min && q <= c->qsteady_max) q = 1.0;
+            qold = fmax(EEst, c->qoldinit);
+            double tnew = last ? tend : t + dt;
+            while (jsave < D && ts[jsave] <= tnew) {
+                double tsv = ts[jsave];
+                if (tsv == tnew) { CATH_SAVE(un[k][i], tsv); }
+                else {
+                    double Th = (tsv - t) / dt;
+                    double c1 = Th * (1.0 - Th) / (1.0 - 2.0 * d), c2 = Th * (Th - 2.0 * d) / (1.0 - 2.0 * d);
+                    CATH_SAVE(u[k][i] + dt * (c1 * k1[k][i] + c2 * k2[k][i]), tsv);
+                }
+            }
+            for (int k = 0; k <= 17; ++k) if (k == PR || k < P) for (int i = 0; i < 3; ++i) { u[k][i] = un[k][i]; f0[k][i] = f2[k][i]; }
+            t = tnew;
+            dt = fmin(dt / q, tend - t0);
+        } else {
+            if (st) st->nreject++;
+            dt = dt / fmin(1.0 / c->qmin, q11 / c->gamma);
+        }
+    }
+#undef CATH_SAVE
+    /* loss = sum(...)/n_replicas/size(exp_data)[1]: divided by the FULL number of rows (network.jl:266) */
+    if (loss_out) *loss_out = loss_sum / (double)D;
+    if (grad) for (int k = 0; k < 17; ++k) grad[k] = g[k] / (double)D;
+    if (n_saved_out) *n_saved_out = jsave;
+    return retcode;
+}

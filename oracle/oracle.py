@@ -241,3 +241,41 @@ def tsit5_dense(theta):
     b = np.zeros(7)
     lib().orc_tsit5_dense(C.c_double(theta), _dp(b))
     return b
+
+
+# ---------------------------------------------------------------------------- Cathode-UQ restatement
+class Cathode(C.Structure):
+    _fields_ = [("lb_clamp", C.c_double), ("T0", C.c_double), ("beta", C.c_double), ("atol", C.c_double),
+                ("rtol", C.c_double), ("maxiters", C.c_int32), ("pad_", C.c_int32),
+                ("gamma", C.c_double), ("qmin", C.c_double), ("qmax", C.c_double), ("beta1", C.c_double),
+                ("beta2", C.c_double), ("qsteady_min", C.c_double), ("qsteady_max", C.c_double), ("qoldinit", C.c_double)]
+
+
+def make_cathode(beta, atol=1e-12, rtol=1e-3, maxiters=2500000, lb_clamp=1e-16):
+    c = Cathode()
+    lib().orc_cathode_defaults(C.byref(c))
+    assert lib().orc_sizeof_cathode() == C.sizeof(Cathode)
+    c.beta, c.atol, c.rtol, c.maxiters, c.lb_clamp = float(beta), atol, rtol, int(maxiters), lb_clamp
+    return c
+
+
+def cathode_rhs(c, theta, u, t):
+    du = np.zeros(3)
+    lib().orc_cathode_rhs(C.byref(c), _dp(np.ascontiguousarray(theta, float)), _dp(np.ascontiguousarray(u, float)),
+                          C.c_double(t), _dp(du))
+    return du
+
+
+def cathode_solve_one(c, theta, ts, dbar, d2bar, want_grad=True):
+    ts = np.ascontiguousarray(ts, float)
+    D = ts.size
+    hrr = np.zeros(D)
+    grad = np.zeros(17) if want_grad else None
+    loss = C.c_double(0)
+    ns = C.c_int32(0)
+    st = (C.c_int64 * 2)(0, 0)
+    lib().orc_cathode_solve_one.restype = C.c_int
+    rc = lib().orc_cathode_solve_one(C.byref(c), _dp(np.ascontiguousarray(theta, float)), _dp(ts), C.c_int(D),
+                                     _dp(np.ascontiguousarray(dbar, float)), _dp(np.ascontiguousarray(d2bar, float)),
+                                     _dp(hrr), C.byref(loss), _dp(grad), C.byref(ns), C.cast(st, C.c_void_p))
+    return dict(hrr=hrr, loss=loss.value, grad=grad, retcode=rc, n_saved=ns.value, naccept=st[0], nreject=st[1])

@@ -346,5 +346,76 @@ def main():
     print("wrote", os.path.join(OUT, "fixtures.json"), os.path.getsize(os.path.join(OUT, "fixtures.json")))
 
 
+
+
+# ============================================================================
+# Cathode-UQ fixtures (python tests/golden/make_fixtures.py cathode): written to fixtures_cathode.json
+#   * observation sets = the reference's own data files Cathode_NCM333_UQ/exp_data/UNCERT_cath_1_{2,5,10,15,20}.csv
+#     (col 1 temperature [C], cols 2..101 = 100 noisy HRR replicas), reduced to what the loss needs:
+#     times (dataset.jl:19-23), replica mean and mean square per row, de-duplicated as load_exp does (dataset.jl:7-10)
+#   * theta = the deterministic initialiser of Cathode/src/network.jl:9-24 without its random part, mapped by
+#     Cathode/src/network.jl:27-50 (the trained p_opt the UQ scripts load is not in the reference tree)
+#   * golden HRR curves by SciPy Radau (rtol 1e-12) on a NumPy transliteration of crnn! / HRR_getter
+#     (Cathode_NCM333_UQ/src_333/network.jl:152-175) and golden loss gradients from the continuous sensitivity ODE
+# ============================================================================
+def cathode_rhs(u, th, t, beta, lb=1e-16, T0=373.15):
+    R = -1.0 / 8.314
+    T = T0 + beta / 60.0 * t
+    logX = np.log(cclamp(u, lb, 10.0))
+    r = np.exp(np.log(T) * th[6:9] + (R / T) * (th[3:6] * 1e5) + th[12:15] * logX + th[0:3])
+    du = -r
+    du = du + np.array([0 * r[0], th[15] * r[0], th[16] * r[1]])
+    return du, r
+
+
+def cathode_main():
+    out = {}
+    p = np.array([1, 1, 1, 1.0, 1.1, 1.2, 0, 0, 0, 1, 0.2, 0.3, 1, 1, 1, 1, 1, 0.1])
+    slope = p[17] * 10
+    th = np.concatenate([np.clip(p[0:3] * slope * 20, 0, 50), np.clip(np.abs(p[3:6]), 0, 3), p[6:9],
+                         np.clip(np.abs(p[9:12]) * 100, 10, 300), np.clip(p[12:15], 0.01, 10), np.clip(p[15:17], 0.01, 5)])
+    out["theta"] = th.tolist()
+    sets = []
+    for beta in (2, 5, 10, 15, 20):
+        raw = np.loadtxt(f"{REF}/Cathode_NCM333_UQ/exp_data/UNCERT_cath_1_{beta}.csv", delimiter=",")
+        _, idx = np.unique(raw[:, 0], return_index=True)
+        raw = raw[np.sort(idx)]
+        ts = (raw[:, 0] - 100.0) * 60.0 / beta
+        d = raw[:, 1:]
+        sets.append(dict(beta=float(beta), ts=ts.tolist(), dbar=d.mean(axis=1).tolist(), d2bar=(d * d).mean(axis=1).tolist(),
+                         n_replicas=int(d.shape[1])))
+    for s in sets:
+        ts = np.array(s["ts"]); beta = s["beta"]
+        dbar = np.array(s["dbar"]); d2bar = np.array(s["d2bar"])
+        u0 = np.array([1.0, 0.0, 0.0])
+
+        def rhs_p(u, thc):
+            return cathode_rhs(u, thc, rhs_p.t, beta)[0]
+
+        # non-autonomous: integrate with t as an extra state so that sens_solve (autonomous interface) can be reused
+        def rhs_aug(ua, thc):
+            du, _ = cathode_rhs(ua[:3], thc, np.real(ua[3]), beta)
+            return np.concatenate([du, [1.0 + 0 * ua[3]]])
+
+        U, S = sens_solve(rhs_aug, th, np.concatenate([u0, [ts[0]]]), ts, t0=ts[0], method="Radau", rtol=1e-11, atol=1e-14)
+        hrr = np.zeros(ts.size); dh = np.zeros((17, ts.size))
+        for i, t in enumerate(ts):
+            _, r = cathode_rhs(U[:3, i], th, t, beta)
+            hrr[i] = r @ th[9:12]
+            for k in range(17):
+                thk = th.astype(complex); thk[k] += 1e-30j
+                _, rk = cathode_rhs(U[:3, i] + 1e-30j * S[k, :3, i], thk, t, beta)
+                dh[k, i] = np.imag(rk @ thk[9:12]) / 1e-30
+        e = hrr - dbar
+        loss = np.sum(e * e + d2bar - dbar * dbar) / ts.size
+        grad = (2 * e[None, :] * dh).sum(axis=1) / ts.size
+        s.update(hrr=hrr.tolist(), loss=float(loss), grad=grad.tolist(), u_end=U[:3, -1].tolist())
+        print("cathode beta", beta, "D", ts.size, "loss", loss, "|grad|", np.linalg.norm(grad), flush=True)
+    out["sets"] = sets
+    with open(os.path.join(OUT, "fixtures_cathode.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote fixtures_cathode.json", os.path.getsize(os.path.join(OUT, "fixtures_cathode.json")))
+
+
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(cathode_main() if (len(sys.argv) > 1 and sys.argv[1] == "cathode") else main())

@@ -1,0 +1,203 @@
+"""Cathode-UQ row (BASELINE config 5): the C oracle pinned against the golden vectors (Radau + forward
+sensitivities of the reference's crnn!/HRR_getter restated in NumPy, reference data CSVs reduced to their
+replica statistics), the host mirror's CPU definitions, and -- on the GPU -- the HIP kernel against both."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def cfx():
+    with open(os.path.join(HERE, "golden", "fixtures_cathode.json")) as f:
+        return json.load(f)
+
+
+def _two_replicas(s):
+    """exp_data [D, 1+2] with the same replica mean and mean-square as the reference's 100 replicas."""
+    dbar, d2bar = np.array(s["dbar"]), np.array(s["d2bar"])
+    sd = np.sqrt(np.maximum(d2bar - dbar ** 2, 0.0))
+    return np.stack([np.array(s["ts"]), dbar + sd, dbar - sd], axis=1)
+
+
+# ------------------------------------------------------------------ CPU: oracle vs golden
+def test_oracle_cathode_matches_golden_at_tight_tolerance(orc, cfx):
+    th = np.array(cfx["theta"])
+    for s in cfx["sets"]:
+        c = orc.make_cathode(s["beta"], atol=1e-14, rtol=1e-9)
+        r = orc.cathode_solve_one(c, th, s["ts"], s["dbar"], s["d2bar"])
+        assert r["retcode"] == 0 and r["n_saved"] == len(s["ts"])
+        hg, gg = np.array(s["hrr"]), np.array(s["grad"])
+        assert np.max(np.abs(r["hrr"] - hg)) < 2e-8 * max(1.0, np.max(np.abs(hg)))     # measured 5e-10
+        assert abs(r["loss"] - s["loss"]) < 1e-8 * abs(s["loss"])
+        assert np.max(np.abs(r["grad"] - gg)) < 2e-8 * np.max(np.abs(gg))               # measured 3e-10
+
+
+def test_oracle_cathode_reference_tolerances_track_golden(orc, cfx):
+    """At the reference's own tolerances (abstol 1e-12, reltol 1e-3) Rosenbrock23 stays within 1e-2 of converged."""
+    th = np.array(cfx["theta"])
+    s = cfx["sets"][2]
+    c = orc.make_cathode(s["beta"])
+    r = orc.cathode_solve_one(c, th, s["ts"], s["dbar"], s["d2bar"])
+    assert r["retcode"] == 0
+    assert np.max(np.abs(r["hrr"] - np.array(s["hrr"]))) < 1e-2 * np.max(np.abs(s["hrr"]))
+    assert abs(r["loss"] - s["loss"]) < 5e-2 * abs(s["loss"])
+
+
+def test_oracle_cathode_grad_by_central_differences(orc, cfx):
+    th = np.array(cfx["theta"])
+    s = cfx["sets"][1]
+    c = orc.make_cathode(s["beta"], atol=1e-14, rtol=1e-10)
+    g = orc.cathode_solve_one(c, th, s["ts"], s["dbar"], s["d2bar"])["grad"]
+    for k in (0, 4, 7, 10, 13, 15):
+        h = 1e-5 * max(1.0, abs(th[k]))
+        tp, tm = th.copy(), th.copy()
+        tp[k] += h; tm[k] -= h
+        fd = (orc.cathode_solve_one(c, tp, s["ts"], s["dbar"], s["d2bar"], want_grad=False)["loss"]
+              - orc.cathode_solve_one(c, tm, s["ts"], s["dbar"], s["d2bar"], want_grad=False)["loss"]) / (2 * h)
+        assert abs(fd - g[k]) < 1e-5 * np.max(np.abs(g)) + 1e-4 * abs(g[k]), (k, fd, g[k])
+
+
+def test_host_crnn_and_hrr_match_oracle_rhs(orc, cfx):
+    """cathode.crnn / HRR_getter (the CPU definitions of network.jl:152-175) vs the oracle's RHS."""
+    # crnn_amd loads the HIP library at import time; that is fine on CPU (only compute calls need a GPU)
+    from crnn_amd import cathode as ch
+    rng = np.random.default_rng(5)
+    p_scales = np.array(cfx["theta"])
+    for beta in (2.0, 20.0):
+        c = orc.make_cathode(beta)
+        for _ in range(5):
+            p = 1 + 0.1 * rng.standard_normal(17)
+            u = np.abs(rng.standard_normal(3)) * np.array([1, .5, .2])
+            u[rng.integers(0, 3)] = 0.0          # exercises the lower clamp
+            t = float(rng.uniform(0, 3000))
+            du = ch.crnn(np.zeros(3), u, ch.p2vec(p), t, p_scales=p_scales, beta=beta)
+            ref = orc.cathode_rhs(c, p * p_scales, u, t)
+            assert np.max(np.abs(du - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
+
+
+def test_svgd_kernel_properties():
+    from crnn_amd.cathode import svgd_kernel
+    rng = np.random.default_rng(0)
+    p = rng.standard_normal((7, 17))
+    K, dK = svgd_kernel(p)
+    assert np.allclose(K, K.T) and np.allclose(np.diag(K), 1.0)
+    assert np.allclose(dK.sum(axis=0), 0.0, atol=1e-12)          # repulsion is antisymmetric in total
+    d = np.sqrt(((p[:, None] - p[None]) ** 2).sum(-1))
+    h = np.sqrt(0.5 * np.median(d[np.tril_indices(7, -1)]) ** 2 / np.log(8))
+    assert np.allclose(K, np.exp(-d ** 2 / h ** 2 / 2))
+
+
+def test_cathode_config_abi():
+    import ctypes as C
+    from crnn_amd import _lib as L
+    cfg = L.CathodeConfig()
+    assert L.lib.crnn_cathode_config_default(C.byref(cfg)) == 0
+    assert (cfg.atol, cfg.rtol, cfg.lb_clamp, cfg.T0) == (1e-12, 1e-3, 1e-16, 373.15)
+    assert cfg.abi_version == L.lib.crnn_abi_version()
+    import torch
+    if not torch.cuda.is_available():
+        h = C.c_void_p()
+        assert L.lib.crnn_cathode_create(C.byref(cfg), C.byref(h)) != 0        # fails loudly without a GPU
+        assert b"no HIP device" in L.lib.crnn_cathode_last_error(None)
+
+
+# ------------------------------------------------------------------ GPU: kernel vs oracle / golden
+def _uq(cfx, **kw):
+    from crnn_amd.cathode import CathodeUQ
+    return CathodeUQ([_two_replicas(s) for s in cfx["sets"]], [s["beta"] for s in cfx["sets"]], cfx["theta"], **kw)
+
+
+@pytest.mark.gpu
+def test_gpu_cathode_matches_golden_tight(cfx):
+    uq = _uq(cfx, atol=1e-14, rtol=1e-9)
+    loss, grad, hrr = uq.solve(np.ones((1, 17)), want_hrr=True)
+    assert np.all(uq.last_retcode == 0)
+    ps = np.array(cfx["theta"])
+    for i, s in enumerate(cfx["sets"]):
+        D = len(s["ts"])
+        assert uq.last_n_saved[0, i] == D
+        hg, gg = np.array(s["hrr"]), np.array(s["grad"]) * ps     # d/dp = d/dtheta * p_scales
+        assert np.max(np.abs(hrr[0, i, :D] - hg)) < 2e-8 * max(1.0, np.max(np.abs(hg)))
+        assert abs(loss[0, i] - s["loss"]) < 1e-8 * abs(s["loss"])
+        assert np.max(np.abs(grad[0, i] - gg)) < 2e-8 * np.max(np.abs(gg))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tol", [(1e-12, 1e-3), (1e-10, 1e-6)])
+def test_gpu_cathode_matches_oracle_step_for_step(orc, cfx, tol):
+    """Same stepper, same tolerances, perturbed particles: the kernel follows the oracle's step sequence, so results
+    agree far below the solver tolerance (fp64 reassociation only)."""
+    atol, rtol = tol
+    rng = np.random.default_rng(11)
+    N = 6
+    p = 1 + 0.05 * rng.standard_normal((N, 17))
+    p[:, 6:9] = 0.0                                           # p_scales[b] = 0 in the reference's optimum
+    uq = _uq(cfx, atol=atol, rtol=rtol)
+    loss, grad, hrr = uq.solve(p, want_hrr=True)
+    ps = np.array(cfx["theta"])
+    nacc = 0
+    for n in range(N):
+        for i, s in enumerate(cfx["sets"]):
+            c = orc.make_cathode(s["beta"], atol=atol, rtol=rtol)
+            r = orc.cathode_solve_one(c, p[n] * ps, s["ts"], s["dbar"], s["d2bar"])
+            D = len(s["ts"])
+            assert r["retcode"] == uq.last_retcode[n, i] == 0
+            assert np.max(np.abs(hrr[n, i, :D] - r["hrr"])) < 1e-9 * max(1.0, np.max(np.abs(r["hrr"])))
+            assert abs(loss[n, i] - r["loss"]) < 1e-9 * abs(r["loss"])
+            assert np.max(np.abs(grad[n, i] - r["grad"] * ps)) < 1e-7 * np.max(np.abs(r["grad"] * ps))
+            nacc += r["naccept"]
+    assert uq.last_stats["n_accept"] == nacc
+
+
+@pytest.mark.gpu
+def test_gpu_cathode_dlnprob_and_reference_surface(orc, cfx):
+    from crnn_amd.cathode import NORMALIZER, NORM_COL
+    uq = _uq(cfx)
+    rng = np.random.default_rng(3)
+    p = 1 + 0.02 * rng.standard_normal((4, 17))
+    i_exp = 3
+    l, g = uq.dlnprob(p, i_exp)
+    loss, grad, _ = uq.solve(p)
+    assert l == pytest.approx(loss[:, i_exp].mean())
+    assert np.allclose(g, -grad[:, i_exp] / NORMALIZER[i_exp, NORM_COL] ** 2)
+    heat, tt = uq.pred_n_ode(p[0], i_exp)
+    s = cfx["sets"][i_exp]
+    assert np.array_equal(tt, np.array(s["ts"]))
+    c = orc.make_cathode(s["beta"])
+    r = orc.cathode_solve_one(c, p[0] * np.array(cfx["theta"]), s["ts"], s["dbar"], s["d2bar"])
+    assert np.max(np.abs(heat - r["hrr"])) < 1e-9 * np.max(np.abs(r["hrr"]))
+    assert uq.loss_neuralode(p[0], i_exp) == pytest.approx(r["loss"], rel=1e-9)
+
+
+@pytest.mark.gpu
+def test_gpu_cathode_many_particles_consistent(cfx):
+    """4096 particles x 5 heating rates in one launch: repeated particles give bit-identical rows wherever they sit in
+    the work queue, and the batch equals the small launch."""
+    uq = _uq(cfx)
+    rng = np.random.default_rng(8)
+    base = 1 + 0.05 * rng.standard_normal((16, 17))
+    p = np.tile(base, (256, 1))
+    loss, grad, _ = uq.solve(p)
+    assert np.all(uq.last_retcode == 0)
+    l0, g0, _ = uq.solve(base)
+    assert np.array_equal(loss.reshape(256, 16, 5), np.broadcast_to(l0, (256, 16, 5)))
+    assert np.array_equal(grad.reshape(256, 16, 5, 17), np.broadcast_to(g0, (256, 16, 5, 17)))
+
+
+@pytest.mark.gpu
+def test_gpu_cathode_maxiters_and_bad_inputs(cfx):
+    from crnn_amd._lib import CrnnError
+    from crnn_amd.cathode import CathodeUQ
+    uq = _uq(cfx, maxiters=5)
+    loss, grad, _ = uq.solve(np.ones((2, 17)))
+    assert np.all(uq.last_retcode == 1)                       # MaxIters
+    assert np.all(uq.last_n_saved < np.array([len(s["ts"]) for s in cfx["sets"]]))
+    bad = _two_replicas(cfx["sets"][0]); bad[3, 0] = bad[2, 0]
+    with pytest.raises(CrnnError):
+        CathodeUQ([bad], [2.0], cfx["theta"])
+    with pytest.raises(CrnnError):
+        CathodeUQ([_two_replicas(cfx["sets"][0])], [-1.0], cfx["theta"])
