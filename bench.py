@@ -64,6 +64,8 @@ def parse():
                     help="start from the reference's trained checkpoint p or a reference-style random init")
     ap.add_argument("--solver", choices=["rosenbrock23", "tsit5"], default="rosenbrock23",
                     help="time stepper; the headline metric is quoted on the Rosenbrock23-equivalent stepper")
+    ap.add_argument("--grad", choices=["auto", "forward", "adjoint"], default="auto",
+                    help="gradient algorithm: discrete adjoint of the accepted steps (auto) or forward tangents")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=32768)
     return ap.parse_args()
@@ -110,7 +112,9 @@ def main():
         yscale = t.cpu().numpy()
 
     solver = SOLVER_TSIT5 if args.solver == "tsit5" else SOLVER_ROSENBROCK23
-    node = NeuralODE(ODEProblem(PRESET_CASE2, ts, device=local_rank, cols_per_lane=args.cols, solver=solver))
+    gmode = {"auto": 0, "forward": 1, "adjoint": 2}[args.grad]
+    adjoint = gmode != 1 and solver == SOLVER_ROSENBROCK23
+    node = NeuralODE(ODEProblem(PRESET_CASE2, ts, device=local_rank, cols_per_lane=args.cols, solver=solver, grad_mode=gmode))
     node.set_ensemble(u0, data, yscale)          # one PCIe upload; resident in HBM from here on
     fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fixtures.json")))
     p0 = np.array(fx["case2_ckpt"]["p"]) if args.theta0 == "ckpt" else cases.case2_init_p(np.random.Generator(np.random.PCG64(7)))

@@ -11,7 +11,7 @@ import os
 
 MAX_N = 12
 MAX_NR = 16
-ABI_VERSION = 1
+ABI_VERSION = 2
 UNIQUE_ID_BYTES = 128
 
 PMAP_IDENTITY, PMAP_CASE1, PMAP_CASE2, PMAP_ROBER = 0, 1, 2, 3
@@ -19,6 +19,7 @@ LOSS_MAE, LOSS_MSE = 0, 1
 RET_SUCCESS, RET_MAXITERS, RET_DTMIN, RET_UNSTABLE = 0, 1, 2, 3
 PRESET_CASE1, PRESET_CASE2, PRESET_ROBER = 1, 2, 3
 SOLVER_ROSENBROCK23, SOLVER_TSIT5 = 0, 1
+GRAD_AUTO, GRAD_FORWARD, GRAD_ADJOINT = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcrnn_hip.so")
@@ -29,7 +30,7 @@ class Config(C.Structure):
         ("abi_version", C.c_int32), ("ns", C.c_int32), ("nr", C.c_int32), ("has_temp", C.c_int32),
         ("param_map", C.c_int32), ("n_save", C.c_int32), ("loss_kind", C.c_int32), ("clamp_pred", C.c_int32),
         ("maxiters", C.c_int32), ("errnorm_sens", C.c_int32), ("device", C.c_int32), ("cols_per_lane", C.c_int32),
-        ("solver", C.c_int32), ("reserved0", C.c_int32),
+        ("solver", C.c_int32), ("grad_mode", C.c_int32), ("tape_steps", C.c_int32), ("reserved0", C.c_int32),
         ("lb", C.c_double), ("ub", C.c_double), ("inv_R", C.c_double), ("t0", C.c_double),
         ("atol", C.c_double * MAX_N), ("rtol", C.c_double * MAX_N), ("rate_scale", C.c_double * MAX_N),
         ("gamma", C.c_double), ("qmin", C.c_double), ("qmax", C.c_double), ("beta1", C.c_double),
@@ -119,7 +120,7 @@ def _load():
         fn.argtypes = args
     if lib.crnn_abi_version() != ABI_VERSION:
         raise ImportError(f"libcrnn_hip.so ABI {lib.crnn_abi_version()} != binding ABI {ABI_VERSION}")
-    for which, cls in enumerate((Config, Stats, OptConfig)):
+    for which, cls in enumerate((Config, Stats, OptConfig, CathodeConfig)):
         if lib.crnn_sizeof(which) != C.sizeof(cls):
             raise ImportError(f"struct layout mismatch for {cls.__name__}: C {lib.crnn_sizeof(which)} != ctypes {C.sizeof(cls)}")
     return lib

@@ -140,6 +140,8 @@ class ODEProblem:
     t0: float = 0.0
     device: int = 0
     cols_per_lane: int = 0
+    grad_mode: int = 0            # GRAD_AUTO (adjoint where available) / GRAD_FORWARD (tangents) / GRAD_ADJOINT
+    tape_steps: int = 0           # adjoint tape capacity per trajectory, 0 = auto
 
     def config(self) -> Config:
         cfg = Config()
@@ -150,6 +152,8 @@ class ODEProblem:
         cfg.t0 = float(self.t0)
         cfg.device = int(self.device)
         cfg.cols_per_lane = int(self.cols_per_lane)
+        cfg.grad_mode = int(self.grad_mode)
+        cfg.tape_steps = int(self.tape_steps)
         n = cfg.ns + cfg.has_temp
         if self.atol is not None:
             a = np.broadcast_to(np.asarray(self.atol, float), (n,))

@@ -14,6 +14,7 @@
 
 #include "p2vec.hpp"
 #include "ros23_kernel.hpp"
+#include "ros23_adj_kernel.hpp"
 #include "tsit5_kernel.hpp"
 #include "cathode_kernel.hpp"
 
@@ -64,6 +65,15 @@ const KernelEntry kKernels[] = {
     KENT5(6, 3, 1, 0, 0, 1), KENT5(6, 3, 1, 0, 5, 5), KENT5(6, 3, 1, 0, 7, 6),
 };
 
+using AdjKernelFn = void (*)(const crnn::SolveParams, const double *, const crnn::AdjParams);
+struct AdjEntry {
+    int ns, nr, has_t, use_scale;
+    AdjKernelFn fn;
+};
+#define KADJ(NS, NR, HT, SC) { NS, NR, HT, SC, (AdjKernelFn)crnn::ros23_adj_kernel<NS, NR, (HT) != 0, (SC) != 0, kBlock> }
+// discrete-adjoint gradient kernels (Rosenbrock23): one lane per trajectory
+const AdjEntry kAdjKernels[] = {KADJ(6, 3, 1, 0), KADJ(3, 6, 0, 1), KADJ(5, 4, 0, 0)};
+
 struct Ctx {
     crnn_config cfg{};
     int n = 0, n_theta = 0, n_params = 0;
@@ -96,6 +106,12 @@ struct Ctx {
     // weights
     double *d_theta = nullptr, *d_dtheta = nullptr;  // [n_theta], [n_theta * max_dir]
     int max_dir = 0;
+    // adjoint tape
+    double *d_tape = nullptr;
+    size_t tape_doubles = 0;
+    unsigned int *d_overflow = nullptr;
+    double *d_red_theta = nullptr;  // [n_theta + kExtra]
+    int64_t n_fallback = 0;         // calls repeated with forward tangents after a tape overflow
     // reduction
     double *d_partials = nullptr;
     size_t partials_cap = 0;
@@ -190,12 +206,117 @@ int32_t ensure(Ctx *c, T **ptr, size_t *cap, size_t need) {
     return 0;
 }
 
+const AdjEntry *find_adjoint(const Ctx *c) {
+    if (c->cfg.solver != CRNN_SOLVER_ROSENBROCK23) return nullptr;
+    for (const auto &k : kAdjKernels)
+        if (k.ns == c->cfg.ns && k.nr == c->cfg.nr && k.has_t == c->cfg.has_temp && k.use_scale == (c->use_scale ? 1 : 0))
+            return &k;
+    return nullptr;
+}
+
+void fill_params(Ctx *c, crnn::SolveParams &prm, int P, int64_t first, int64_t count, int n_save_active, bool want_pred) {
+    prm.u0 = c->d_u0; prm.data = c->d_data; prm.tsave = c->d_tsave;
+    prm.row_stride = (int64_t)c->cfg.n_save * c->n_obs;
+    prm.pred = want_pred ? c->d_pred : nullptr;
+    prm.loss = c->d_loss; prm.retcode = c->d_ret; prm.n_saved = c->d_nsaved;
+    prm.n_accept = c->d_nacc; prm.n_reject = c->d_nrej;
+    prm.gtraj = c->d_gtraj;
+    prm.B = c->B; prm.first = first; prm.count = count;
+    prm.n_save = n_save_active; prm.P = P;
+    prm.maxiters = c->cfg.maxiters; prm.clamp_pred = c->cfg.clamp_pred; prm.loss_kind = c->cfg.loss_kind;
+    prm.n_obs = c->n_obs;
+    prm.kc = c->d_kc;
+    prm.queue = c->d_queue;
+}
+
+// Gradient by the discrete adjoint (ros23_adj_kernel.hpp): theta-space gradient per trajectory, fixed-order batch
+// reduction, then the chain rule through the P given directions.  Returns 1 (not an error) when some trajectory ran
+// out of tape: the caller repeats the call with forward tangents.
+int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const double *d_dtheta, int P, int64_t first,
+                       int64_t count, int n_save_active, bool want_pred) {
+    const int nth = c->n_theta;
+    const int npart_th = nth + crnn::kExtra, npart = P + crnn::kExtra;
+    int occ = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k->fn, kBlock, 0));
+    if (occ < 1) occ = 1;
+    const int64_t need_blocks = (count + kBlock - 1) / kBlock;
+    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(need_blocks, (int64_t)c->num_cu * occ));
+    const size_t lanes = (size_t)nblk * kBlock;
+    const size_t recw = (size_t)c->cfg.ns + 2;
+    int64_t cap = c->cfg.tape_steps;
+    if (cap <= 0) {  // auto: what fits in min(free/4, 16 GiB), at most maxiters (no trajectory accepts more steps)
+        size_t fr = 0, tot = 0;
+        HIP_TRY(c, hipMemGetInfo(&fr, &tot));
+        fr += c->tape_doubles * sizeof(double);
+        const size_t budget = std::min<size_t>(fr / 4, (size_t)16 << 30);
+        cap = (int64_t)(budget / (lanes * recw * sizeof(double)));
+        cap = std::max<int64_t>(cap, 64);
+    }
+    cap = std::min<int64_t>(cap, c->cfg.maxiters);
+    if (c->tape_doubles < lanes * (size_t)cap * recw) {
+        // keep an existing larger-capacity tape when the geometry shrinks; grow otherwise
+        if (ensure(c, &c->d_tape, &c->tape_doubles, lanes * (size_t)cap * recw)) return -1;
+    }
+    const int rows_per_block = 256;
+    const int rblk = (int)((count + rows_per_block - 1) / rows_per_block);
+    if (ensure(c, &c->d_partials, &c->partials_cap, (size_t)rblk * std::max(npart_th, npart))) return -1;
+    if (ensure(c, &c->d_gtraj, &c->gtraj_cap, (size_t)count * nth)) return -1;
+    if (c->npart_max < npart) {
+        if (c->d_red) HIP_TRY(c, hipFree(c->d_red));
+        c->d_red = nullptr;
+        HIP_TRY(c, hipMalloc((void **)&c->d_red, sizeof(double) * npart));
+        c->npart_max = npart;
+    }
+    if (want_pred) {
+        size_t need = (size_t)c->cfg.n_save * c->n * c->B;
+        if (ensure(c, &c->d_pred, &c->pred_cap, need)) return -1;
+    }
+    crnn::SolveParams prm{};
+    fill_params(c, prm, P, first, count, n_save_active, want_pred);
+    crnn::AdjParams adj{};
+    adj.tape = c->d_tape; adj.tape_cap = (int32_t)cap; adj.overflow = c->d_overflow;
+    if (upload_consts(c)) return -1;
+    HIP_TRY(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_overflow, 0, sizeof(unsigned int), c->stream));
+    c->ev0 = c->ring0[c->n_launch % Ctx::kRing];
+    c->ev1 = c->ring1[c->n_launch % Ctx::kRing];
+    ++c->n_launch;
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    hipLaunchKernelGGL(k->fn, dim3(nblk), dim3(kBlock), 0, c->stream, prm, d_theta, adj);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    hipLaunchKernelGGL(crnn::reduce_traj_kernel, dim3(rblk), dim3(256), 0, c->stream, c->d_gtraj, nth, c->d_loss, c->d_ret,
+                       c->d_nacc, c->d_nrej, first, count, rows_per_block, c->d_partials);
+    HIP_TRY(c, hipGetLastError());
+    hipLaunchKernelGGL(crnn::reduce_partials_kernel, dim3(npart_th), dim3(256), 0, c->stream, c->d_partials, rblk, npart_th,
+                       c->d_red_theta);
+    HIP_TRY(c, hipGetLastError());
+    hipLaunchKernelGGL(crnn::project_kernel, dim3(1), dim3(256), 0, c->stream, c->d_red_theta, d_dtheta, nth, P, c->d_red);
+    HIP_TRY(c, hipGetLastError());
+    unsigned int ovf = 0;
+    HIP_TRY(c, hipMemcpyAsync(&ovf, c->d_overflow, sizeof(ovf), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->last_npart = npart;
+    c->last_P = P;
+    return ovf ? 1 : 0;
+}
+
 // Launch solve (+ fixed-order reduction into c->d_red).  theta/dtheta already on device.
 int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int P, int64_t first, int64_t count,
                      int n_save_active, bool want_pred, bool want_percase) {
     if (c->B <= 0) return fail(c, "crnn_solve: no ensemble uploaded (crnn_ctx_set_data)");
     if (first < 0 || count <= 0 || first + count > c->B) return fail(c, "crnn_solve: [first, first+count) outside the ensemble");
     if (n_save_active <= 0 || n_save_active > c->cfg.n_save) return fail(c, "crnn_solve: n_save_active out of range");
+    if (P > 0 && c->cfg.grad_mode != CRNN_GRAD_FORWARD) {
+        const AdjEntry *ka = find_adjoint(c);
+        if (ka) {
+            const int32_t r = launch_adjoint(c, ka, d_theta, d_dtheta, P, first, count, n_save_active, want_pred);
+            if (r <= 0) return r;
+            ++c->n_fallback;  // tape overflow: same call, forward tangents (results are overwritten)
+        } else if (c->cfg.grad_mode == CRNN_GRAD_ADJOINT) {
+            return fail(c, "crnn_solve: grad_mode = ADJOINT but no adjoint kernel exists for this (solver, ns, nr, has_temp)");
+        }
+    }
     const KernelEntry *k = pick_kernel(c, P);
     if (!k) return fail(c, "crnn_solve: no gfx950 kernel instantiated for this (ns, nr, has_temp, n_dir) shape");
     const int C = k->C, L = k->L;
@@ -229,18 +350,7 @@ int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int 
     (void)want_percase;
 
     crnn::SolveParams prm{};
-    prm.u0 = c->d_u0; prm.data = c->d_data; prm.tsave = c->d_tsave;
-    prm.row_stride = (int64_t)c->cfg.n_save * c->n_obs;
-    prm.pred = want_pred ? c->d_pred : nullptr;
-    prm.loss = c->d_loss; prm.retcode = c->d_ret; prm.n_saved = c->d_nsaved;
-    prm.n_accept = c->d_nacc; prm.n_reject = c->d_nrej;
-    prm.gtraj = c->d_gtraj;
-    prm.B = c->B; prm.first = first; prm.count = count;
-    prm.n_save = n_save_active; prm.P = P;
-    prm.maxiters = c->cfg.maxiters; prm.clamp_pred = c->cfg.clamp_pred; prm.loss_kind = c->cfg.loss_kind;
-    prm.n_obs = c->n_obs;
-    prm.kc = c->d_kc;
-    prm.queue = c->d_queue;
+    fill_params(c, prm, P, first, count, n_save_active, want_pred);
     if (upload_consts(c)) return -1;
     HIP_TRY(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), c->stream));
 
@@ -321,6 +431,7 @@ int32_t crnn_sizeof(int32_t which) {
     case 0: return (int32_t)sizeof(crnn_config);
     case 1: return (int32_t)sizeof(crnn_stats);
     case 2: return (int32_t)sizeof(crnn_opt_config);
+    case 3: return (int32_t)sizeof(crnn_cathode_config);
     default: return -1;
     }
 }
@@ -417,6 +528,8 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
     if (cfg->errnorm_sens != 0) return fail(nullptr, "crnn_ctx_create: errnorm_sens=1 is not implemented on device");
     if (cfg->solver != CRNN_SOLVER_ROSENBROCK23 && cfg->solver != CRNN_SOLVER_TSIT5)
         return fail(nullptr, "crnn_ctx_create: unknown solver");
+    if (cfg->grad_mode < CRNN_GRAD_AUTO || cfg->grad_mode > CRNN_GRAD_ADJOINT || cfg->tape_steps < 0)
+        return fail(nullptr, "crnn_ctx_create: bad grad_mode / tape_steps");
     if (cfg->n_save < 1 || cfg->n_save > crnn::kMaxSave) return fail(nullptr, "crnn_ctx_create: n_save must be in [1, 256]");
     Ctx *c = new Ctx();
     c->cfg = *cfg;
@@ -458,6 +571,8 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
         hipMalloc((void **)&c->d_tsave, sizeof(double) * cfg->n_save) != hipSuccess ||
         hipMalloc((void **)&c->d_kc, sizeof(crnn::KConst)) != hipSuccess ||
         hipMalloc((void **)&c->d_queue, sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void **)&c->d_overflow, sizeof(unsigned int)) != hipSuccess ||
+        hipMalloc((void **)&c->d_red_theta, sizeof(double) * (c->n_theta + crnn::kExtra)) != hipSuccess ||
         hipMalloc((void **)&c->d_p, sizeof(double) * c->n_params) != hipSuccess ||
         hipMalloc((void **)&c->d_opt, sizeof(double) * (2 * c->n_params + 4)) != hipSuccess)
         return bail("crnn_ctx_create: hipMalloc failed");
@@ -473,7 +588,7 @@ void crnn_ctx_destroy(crnn_ctx *ctx) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->own_u0 && c->d_u0) (void)hipFree(c->d_u0);
     if (c->own_data && c->d_data) (void)hipFree(c->d_data);
-    void *ptrs[] = {c->d_queue, c->d_nacc, c->d_nrej, c->d_gtraj, c->d_kc, c->d_tsave, c->d_pred, c->d_loss, c->d_ret, c->d_nsaved, c->d_theta, c->d_dtheta,
+    void *ptrs[] = {c->d_tape, c->d_overflow, c->d_red_theta, c->d_queue, c->d_nacc, c->d_nrej, c->d_gtraj, c->d_kc, c->d_tsave, c->d_pred, c->d_loss, c->d_ret, c->d_nsaved, c->d_theta, c->d_dtheta,
                     c->d_partials, c->d_red, c->d_p, c->d_opt, c->d_comm_buf};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < Ctx::kRing; ++i) {

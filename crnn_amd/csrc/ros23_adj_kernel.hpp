@@ -1,0 +1,578 @@
+// crnn_amd/csrc/ros23_adj_kernel.hpp -- gfx950 (MI355X): loss gradient by the DISCRETE ADJOINT of the accepted
+// Rosenbrock23 steps.
+//
+// ForwardDiff.gradient(x -> loss_neuralode(x, i_exp), p) (case2/case2.jl:195, rober_crnn.jl:219) differentiates the
+// solver's arithmetic with the step sizes held fixed (dt, the accept/reject decisions and the saveat interpolation
+// weights are plain Float64 in OrdinaryDiffEq).  ros23_kernel.hpp reproduces that by pushing P forward tangents through
+// every accepted step -- (1 + P) x the primal work.  The same derivative is obtained here by running the accepted
+// steps BACKWARDS once (reverse accumulation over the identical computational graph):
+//
+//   forward   u_{n+1} = u_n + dt k2,   k1 = W^-1 f(u_n),   k2 = W^-1 (f(u_n + dt/2 k1) - k1) + k1,   W = I - d dt J(u_n)
+//             saveat:  u(t_n + Th dt) = u_n + dt (c1 k1 + c2 k2)
+//   reverse   kb2 = dt lam + B2,  kb1 = B1,  ub = lam + A          (A, B1, B2: loss seeds of the save points in the step)
+//             v = W^-T kb2;  kb1 += kb2 - v
+//             at u_mid:   ub_mid = J^T v,         thb += d(v.f)/dtheta
+//             ub += ub_mid;  kb1 += dt/2 ub_mid;  w = W^-T kb1
+//             at u_n:     ub += J^T w + d/du [gam (v.J dk + w.J k1)],   thb += d/dtheta [w.f + gam (v.J dk + w.J k1)]
+//             lam = ub
+//
+// so a trajectory + gradient costs about two primal solves, independent of the number of parameters, and the result
+// equals the forward-tangent gradient up to rounding (tests/test_gpu_parity.py).  The gradient
+// is produced in theta space (w_in | w_b | w_out); the chain rule through p2vec is a [P x n_theta] product applied to
+// the batch sum (project_kernel).
+//
+// MI355X mapping: ONE LANE PER TRAJECTORY (no lane groups, no redundant primal, no LDS step record).  A wavefront takes
+// 64 trajectories from the global queue, runs the forward sweep for all of them, then the reverse sweep.  The forward
+// sweep appends (t_n, dt_n, u_n) of every accepted step to a per-lane tape in HBM (lane-contiguous, so the partial
+// lines merge in L2; at 18 steps x 72 B the tape of a whole launch stays cache resident); the reverse sweep re-forms
+// J, W and the stages from the tape record instead of storing them.  The observed data are read once, by the reverse
+// sweep, where loss and seeds are formed together.  theta sits in SGPRs, the 42 (case2) gradient accumulators in VGPRs.
+#pragma once
+#include "ros23_kernel.hpp"
+
+namespace crnn {
+
+struct AdjParams {
+    double *tape;                // [lanes][tape_cap][NS + 2]
+    int32_t tape_cap;            // accepted steps a lane can record
+    unsigned int *overflow;      // incremented by every trajectory that ran out of tape (host then falls back)
+};
+
+// Solve A^T x = b with the factors of lu_factor (P A = L U): x = P^T L^-T U^-T b
+template <int NS>
+__device__ __forceinline__ void lu_solve_T(const double (&A)[NS][NS], const double (&dinv)[NS], const int (&piv)[NS],
+                                           const bool wave_pivots, double (&b)[NS]) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        b[k] *= dinv[k];
+        const double a = b[k];
+#pragma unroll
+        for (int i = k + 1; i < NS; ++i) b[i] = fma(-A[k][i], a, b[i]);
+    }
+#pragma unroll
+    for (int k = NS - 1; k >= 0; --k) {
+        const double a = b[k];
+#pragma unroll
+        for (int i = 0; i < k; ++i) b[i] = fma(-A[k][i], a, b[i]);
+    }
+    if (wave_pivots) {
+#pragma unroll
+        for (int k = NS - 1; k >= 0; --k) {
+            const int p = piv[k];
+#pragma unroll
+            for (int i = k + 1; i < NS; ++i) {
+                const bool sw = (p == i);
+                const double bk = b[k], bi = b[i];
+                b[k] = sw ? bi : bk;
+                b[i] = sw ? bk : bi;
+            }
+        }
+    }
+}
+
+// b <- W^-T b for the two W representations of ros23_kernel.hpp
+template <int NS, int NR, bool HAS_T, bool USE_SCALE>
+__device__ __forceinline__ void solve_T(const DenseLU<NS, NR, HAS_T, USE_SCALE> &W, const double *__restrict__,
+                                        const double (&)[NS], const double (&)[NR], const double *, double (&b)[NS]) {
+    lu_solve_T<NS>(W.A, W.dinv, W.piv, W.wave_pivots, b);
+}
+// W^-1 = I + D_sc Wo D_gr M^-1 Wi^T D_g   =>   W^-T = I + D_g Wi M^-T D_gr Wo^T D_sc
+template <int NS, int NR, bool HAS_T, bool USE_SCALE>
+__device__ __forceinline__ void solve_T(const Woodbury<NS, NR, HAS_T, USE_SCALE> &W, const double *__restrict__ th,
+                                        const double (&g)[NS], const double (&gr)[NR], const double *sc_s, double (&b)[NS]) {
+    using L_ = Lay<NS, NR, HAS_T>;
+    double y[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) y[j] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const double t = USE_SCALE ? b[i] * sc_s[i] : b[i];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) y[j] = fma(th[L_::wo(i, j)], t, y[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) y[j] *= gr[j];
+    lu_solve_T<NR>(W.M, W.dinv, W.piv, W.wave_pivots, y);
+#pragma unroll
+    for (int c = 0; c < NS; ++c) {
+        double a = 0.0;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) a = fma(th[L_::wi(c, j)], y[j], a);
+        b[c] = fma(a, g[c], b[c]);
+    }
+}
+
+template <int NS, int NR, bool HAS_T, bool USE_SCALE, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm, const double *__restrict__ theta,
+                                                          const AdjParams adj) {
+    using L_ = Lay<NS, NR, HAS_T>;
+    constexpr int N = L_::N;
+    constexpr int NTH = L_::NTH;
+    constexpr int RECW = NS + 2;
+    using Solver = typename SolverSel<(NR < NS), NS, NR, HAS_T, USE_SCALE>::type;
+
+    __shared__ double kc_lds[kNConst];
+    __shared__ double ts_lds[kMaxSave];
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < kNConst; idx += BLOCK) kc_lds[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
+    for (int idx = tid; idx < prm.n_save; idx += BLOCK) ts_lds[idx] = prm.tsave[idx];
+    __syncthreads();
+    const KConst *kc = reinterpret_cast<const KConst *>(kc_lds);
+    const double *__restrict__ th = theta;
+
+    const double d_ = 0.29289321881345248;    // 1/(2+sqrt 2)
+    const double c32 = 7.4142135623730950;    // 6+sqrt 2
+    const double inv12d = 2.4142135623730950; // 1/(1-2d)
+    const int nsave = prm.n_save;
+    const double tend = ts_lds[nsave - 1];
+    const double ts0 = ts_lds[0];
+    const double t0 = kc->t0;
+    const double dtmax = tend - t0;
+    const double lqinit = flog(kc->qoldinit);
+    const bool start_saved = (ts0 == t0);
+
+    const int lane = tid & 63;
+    double *const tape = adj.tape + (size_t)((size_t)blockIdx.x * BLOCK + tid) * adj.tape_cap * RECW;
+
+    while (true) {
+        // ---- next 64 trajectories for this wavefront
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(prm.queue, 64ULL);
+        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base);
+        const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+        const int64_t wave_base = (int64_t)(((unsigned long long)bhi << 32) | blo);
+        if (wave_base >= prm.count) break;
+        const int64_t traj = wave_base + lane;
+        const bool valid = traj < prm.count;
+        const int64_t b = prm.first + (valid ? traj : 0);
+
+        // ================================================================== forward sweep
+        double u[NS], f0[NS], g0[NS], r0[NR], bT[NR];
+        double xT = 0.0, Tconst = 0.0;
+        double t = t0, dt = 0.0, lqold = lqinit;
+        int iter = 0, jsave = 0, nacc = 0, nrej = 0;
+        int rc = valid ? -1 : 0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) u[i] = prm.u0[(size_t)i * prm.B + b];
+        if (HAS_T) {
+            Tconst = prm.u0[(size_t)NS * prm.B + b];
+            xT = kc->inv_R * frcp(Tconst);
+        }
+#pragma unroll
+        for (int j = 0; j < NR; ++j) bT[j] = HAS_T ? fma(th[L_::wi(NS, j)], xT, th[L_::wb(j)]) : th[L_::wb(j)];
+        {
+            double x0[NS];
+            features<NS>(u, kc->lb, kc->ub, x0, g0);
+            rates<NS, NR, HAS_T>(th, x0, bT, r0);
+            rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r0, kc->scale, f0);
+            // Hairer initial step (OrdinaryDiffEq ode_determine_initdt, order 2)
+            double d0 = 0.0, d1 = 0.0, sk[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                sk[i] = frcp(fma(fabs(u[i]), kc->rtol[i], kc->atol[i]));
+                double a = u[i] * sk[i], c = f0[i] * sk[i];
+                d0 = fma(a, a, d0);
+                d1 = fma(c, c, d1);
+            }
+            if (HAS_T) { double a = Tconst * frcp(fma(fabs(Tconst), kc->rtol[NS], kc->atol[NS])); d0 = fma(a, a, d0); }
+            d0 = sqrt(d0 * (1.0 / N));
+            d1 = sqrt(d1 * (1.0 / N));
+            double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 / d1);
+            dt0 = fmin(dt0, dtmax);
+            double u1[NS], x1[NS], g1[NS], r1[NR], f1[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) u1[i] = fma(dt0, f0[i], u[i]);
+            features<NS>(u1, kc->lb, kc->ub, x1, g1);
+            rates<NS, NR, HAS_T>(th, x1, bT, r1);
+            rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r1, kc->scale, f1);
+            double d2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) { double e = (f1[i] - f0[i]) * sk[i]; d2 = fma(e, e, d2); }
+            d2 = sqrt(d2 * (1.0 / N)) / dt0;
+            double dm = fmax(d1, d2);
+            double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : exp(-0.5 * (4.605170185988091368 + flog(dm)));
+            dt = fmax(kc->dtmin, fmin(fmin(100.0 * dt0, dt1), dtmax));
+        }
+        if (start_saved) {  // save_start: saveat contains tspan[1]
+            if (valid && prm.pred) {
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    double v = u[i];
+                    if (prm.clamp_pred) v = clampv(v, -kc->ub, kc->ub);
+                    prm.pred[((size_t)0 * N + i) * prm.B + b] = v;
+                }
+                if (HAS_T) {
+                    double v = Tconst;
+                    if (prm.clamp_pred) v = clampv(v, -kc->ub, kc->ub);
+                    prm.pred[((size_t)0 * N + NS) * prm.B + b] = v;
+                }
+            }
+            jsave = 1;
+        }
+
+        while (__builtin_amdgcn_ballot_w64(rc < 0) != 0) {
+            if (rc < 0) {
+                ++iter;
+                bool last = false;
+                if (jsave >= nsave) rc = 0;            // horizon = tspan[1]: nothing to integrate
+                else if (iter > prm.maxiters) rc = 1;
+                if (t + dt * (1.0 + 1e-13) >= tend) { dt = tend - t; last = true; }
+                if (rc < 0 && (!(dt > kc->dtmin) || t + dt == t)) rc = 2;
+                if (rc < 0) {
+                    Solver W;
+                    const double gam = d_ * dt;
+                    double gr0[NR];
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) gr0[j] = gam * r0[j];
+                    double k1[NS], dk[NS], unew[NS], f1[NS], f2[NS], g2[NS], r2[NR];
+                    const bool okf = W.factor(th, g0, r0, gam, kc->scale);
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) k1[i] = f0[i];
+                    W.solve(th, g0, gr0, kc->scale, k1);
+                    {
+                        double u1[NS], x1[NS], g1[NS], r1[NR];
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) u1[i] = fma(0.5 * dt, k1[i], u[i]);
+                        features<NS>(u1, kc->lb, kc->ub, x1, g1);
+                        rates<NS, NR, HAS_T>(th, x1, bT, r1);
+                        rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r1, kc->scale, f1);
+                    }
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) dk[i] = f1[i] - k1[i];
+                    W.solve(th, g0, gr0, kc->scale, dk);
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) unew[i] = fma(dt, k1[i] + dk[i], u[i]);
+                    {
+                        double x2[NS];
+                        features<NS>(unew, kc->lb, kc->ub, x2, g2);
+                        rates<NS, NR, HAS_T>(th, x2, bT, r2);
+                        rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r2, kc->scale, f2);
+                    }
+                    double k3[NS];
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        double k2i = k1[i] + dk[i];
+                        k3[i] = f2[i] - c32 * (k2i - f1[i]) - 2.0 * (k1[i] - f0[i]);
+                    }
+                    W.solve(th, g0, gr0, kc->scale, k3);
+                    double es = 0.0;
+                    bool finite = okf;
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        double k2i = k1[i] + dk[i];
+                        double ev = dt * (1.0 / 6.0) * (k1[i] - 2.0 * k2i + k3[i]);
+                        double m = fmax(fabs(u[i]), fabs(unew[i]));
+                        double e = ev * frcp(fma(kc->rtol[i], m, kc->atol[i]));
+                        es = fma(e, e, es);
+                        finite = finite && isfinite(unew[i]) && isfinite(ev);
+                    }
+                    es = es * (1.0 / N);
+                    if (!finite) rc = 3;
+                    else {
+                        // PI controller (OrdinaryDiffEq PIController), in log space
+                        const bool ee_zero = (es == 0.0);
+                        const double lEE = 0.5 * flog(ee_zero ? 1.0 : es);
+                        const double lq11 = kc->beta1 * lEE;
+                        double q = ee_zero ? 1.0 / kc->qmax
+                                           : fmax(1.0 / kc->qmax, fmin(1.0 / kc->qmin, exp(lq11 - kc->beta2 * lqold) / kc->gamma));
+                        if (es <= 1.0) {
+                            if (nacc >= adj.tape_cap) {
+                                rc = 5;  // out of tape: the host re-runs the call with forward tangents
+                                atomicAdd(adj.overflow, 1u);
+                            } else {
+                                double *rec = tape + (size_t)nacc * RECW;
+                                rec[0] = t;
+                                rec[1] = dt;
+#pragma unroll
+                                for (int i = 0; i < NS; ++i) rec[2 + i] = u[i];
+                                ++nacc;
+                                const double tnew = last ? tend : t + dt;
+                                while (jsave < nsave) {
+                                    const double ts = ts_lds[jsave];
+                                    if (!(ts <= tnew)) break;
+                                    if (prm.pred) {
+                                        const bool at_end = (ts == tnew);
+                                        const double Th = at_end ? 1.0 : (ts - t) / dt;
+                                        const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
+                                        const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d_) * inv12d;
+#pragma unroll
+                                        for (int i = 0; i < NS; ++i) {
+                                            double k2i = k1[i] + dk[i];
+                                            double v = at_end ? unew[i] : fma(dt, fma(c1, k1[i], c2 * k2i), u[i]);
+                                            if (prm.clamp_pred) v = clampv(v, -kc->ub, kc->ub);
+                                            prm.pred[((size_t)jsave * N + i) * prm.B + b] = v;
+                                        }
+                                        if (HAS_T) {
+                                            double v = Tconst;
+                                            if (prm.clamp_pred) v = clampv(v, -kc->ub, kc->ub);
+                                            prm.pred[((size_t)jsave * N + NS) * prm.B + b] = v;
+                                        }
+                                    }
+                                    ++jsave;
+                                }
+#pragma unroll
+                                for (int i = 0; i < NS; ++i) { u[i] = unew[i]; f0[i] = f2[i]; g0[i] = g2[i]; }
+#pragma unroll
+                                for (int j = 0; j < NR; ++j) r0[j] = r2[j];
+                                t = tnew;
+                                // step_accept_controller
+                                if (q >= kc->qsteady_min && q <= kc->qsteady_max) q = 1.0;
+                                lqold = ee_zero ? lqinit : fmax(lEE, lqinit);
+                                dt = fmin(dt / q, dtmax);
+                                if (jsave >= nsave) rc = 0;
+                            }
+                        } else {
+                            ++nrej;
+                            dt = dt / fmin(1.0 / kc->qmin, exp(lq11) / kc->gamma);
+                        }
+                    }
+                }
+            }
+        }
+
+        // ================================================================== reverse sweep
+        const int n_saved = jsave;
+        const int jlo = start_saved ? 1 : 0;
+        double thb[NTH];
+#pragma unroll
+        for (int m = 0; m < NTH; ++m) thb[m] = 0.0;
+        double lam[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) lam[i] = 0.0;
+        double loss_sum = 0.0;
+        double tnew = t;             // end time of the step being reversed
+        int s = valid ? nacc - 1 : -1;
+
+        auto load_row = [&](int j, double (&d)[NS]) {
+            const int jj = j > 0 ? j : 0;
+            const double *row = prm.data + (size_t)b * prm.row_stride + (size_t)jj * prm.n_obs;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int dr = (int)kc->drow[i];
+                d[i] = row[dr >= 0 ? dr : 0];
+            }
+        };
+        double dA[NS], dB[NS];       // data rows jsave-1 and jsave-2, prefetched
+        load_row(jsave - 1, dA);
+        load_row(jsave - 2, dB);
+        double rt = 0.0, rdt = 0.0, ru[NS];   // tape record s, prefetched
+        {
+            const double *rec = tape + (size_t)(s > 0 ? s : 0) * RECW;
+            rt = rec[0]; rdt = rec[1];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) ru[i] = rec[2 + i];
+        }
+
+        while (__builtin_amdgcn_ballot_w64(s >= 0) != 0) {
+            if (s >= 0) {
+                const double tn = rt, h = rdt;
+                double un[NS];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) un[i] = ru[i];
+                {   // prefetch the next record (s-1)
+                    const double *rec = tape + (size_t)(s > 0 ? s - 1 : 0) * RECW;
+                    rt = rec[0]; rdt = rec[1];
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) ru[i] = rec[2 + i];
+                }
+                // ---- re-form the step
+                double x0[NS], gg0[NS], rr0[NR], ff0[NS];
+                features<NS>(un, kc->lb, kc->ub, x0, gg0);
+                rates<NS, NR, HAS_T>(th, x0, bT, rr0);
+                rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, rr0, kc->scale, ff0);
+                Solver W;
+                const double gam = d_ * h;
+                double gr0[NR];
+#pragma unroll
+                for (int j = 0; j < NR; ++j) gr0[j] = gam * rr0[j];
+                (void)W.factor(th, gg0, rr0, gam, kc->scale);
+                double k1[NS], dk[NS], x1[NS], g1[NS], r1[NR];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) k1[i] = ff0[i];
+                W.solve(th, gg0, gr0, kc->scale, k1);
+                {
+                    double u1[NS], f1[NS];
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) u1[i] = fma(0.5 * h, k1[i], un[i]);
+                    features<NS>(u1, kc->lb, kc->ub, x1, g1);
+                    rates<NS, NR, HAS_T>(th, x1, bT, r1);
+                    rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r1, kc->scale, f1);
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) dk[i] = f1[i] - k1[i];
+                }
+                W.solve(th, gg0, gr0, kc->scale, dk);
+
+                // ---- loss and its seeds at the save points inside (tn, tnew]
+                double A_[NS], B1[NS], B2[NS];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) { A_[i] = 0.0; B1[i] = 0.0; B2[i] = 0.0; }
+                while (jsave > jlo) {
+                    const double ts = ts_lds[jsave - 1];
+                    if (!(ts > tn)) break;
+                    const bool at_end = (ts == tnew);
+                    const double Th = at_end ? 1.0 : (ts - tn) / h;
+                    const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
+                    const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d_) * inv12d;
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        const int dr = (int)kc->drow[i];
+                        if (dr >= 0) {
+                            const double k2i = k1[i] + dk[i];
+                            double v = at_end ? fma(h, k2i, un[i]) : fma(h, fma(c1, k1[i], c2 * k2i), un[i]);
+                            double mask = 1.0;
+                            if (prm.clamp_pred) {
+                                mask = (v > kc->ub || v < -kc->ub) ? 0.0 : 1.0;
+                                v = clampv(v, -kc->ub, kc->ub);
+                            }
+                            const double iy = kc->inv_yscale[i];
+                            const double rr = (dA[i] - v) * iy;
+                            double w;
+                            if (prm.loss_kind == 0) { loss_sum += fabs(rr); w = signbit(rr) ? 1.0 : -1.0; }
+                            else { loss_sum = fma(rr, rr, loss_sum); w = -2.0 * rr; }
+                            w *= mask * iy;
+                            A_[i] += w;
+                            B1[i] = fma(w, h * c1, B1[i]);
+                            B2[i] = fma(w, h * c2, B2[i]);
+                        }
+                    }
+                    --jsave;
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) dA[i] = dB[i];
+                    load_row(jsave - 2, dB);
+                }
+
+                // ---- adjoint of the step
+                double kb1[NS], v[NS], ub[NS];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) { v[i] = fma(h, lam[i], B2[i]); ub[i] = lam[i] + A_[i]; }
+#pragma unroll
+                for (int i = 0; i < NS; ++i) kb1[i] = B1[i] + v[i];
+                solve_T<NS, NR, HAS_T, USE_SCALE>(W, th, gg0, gr0, kc->scale, v);        // v = W^-T kb2
+#pragma unroll
+                for (int i = 0; i < NS; ++i) kb1[i] -= v[i];
+                double vs[NS];   // sc .* v
+#pragma unroll
+                for (int i = 0; i < NS; ++i) vs[i] = USE_SCALE ? v[i] * kc->scale[i] : v[i];
+                double av[NR];
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) a = fma(vs[i], th[L_::wo(i, j)], a);
+                    av[j] = a;
+                }
+                // point u_mid: d(v.f)/d(u, theta)
+                {
+                    double um[NS];
+#pragma unroll
+                    for (int c = 0; c < NS; ++c) um[c] = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        const double rho = av[j] * r1[j];
+                        thb[L_::wb(j)] += rho;
+                        if (HAS_T) thb[L_::wi(NS, j)] = fma(rho, xT, thb[L_::wi(NS, j)]);
+#pragma unroll
+                        for (int c = 0; c < NS; ++c) {
+                            thb[L_::wi(c, j)] = fma(rho, x1[c], thb[L_::wi(c, j)]);
+                            um[c] = fma(rho, th[L_::wi(c, j)], um[c]);
+                        }
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) thb[L_::wo(i, j)] = fma(vs[i], r1[j], thb[L_::wo(i, j)]);
+                    }
+#pragma unroll
+                    for (int c = 0; c < NS; ++c) {
+                        const double m = um[c] * g1[c];
+                        ub[c] += m;
+                        kb1[c] = fma(0.5 * h, m, kb1[c]);
+                    }
+                }
+                solve_T<NS, NR, HAS_T, USE_SCALE>(W, th, gg0, gr0, kc->scale, kb1);      // kb1 = w = W^-T kb1
+                // point u_n: d/d(u, theta) [ w.f + gam (v.J dk + w.J k1) ]
+                {
+                    double ws[NS];
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) ws[i] = USE_SCALE ? kb1[i] * kc->scale[i] : kb1[i];
+                    double s1[NS], s2[NS];   // sum_j beta_j w_in[c,j];  sum_j w_in[c,j] (pv_j dk_c + gam pw_j k1_c)
+#pragma unroll
+                    for (int c = 0; c < NS; ++c) { s1[c] = 0.0; s2[c] = 0.0; }
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        double aw = 0.0, q1 = 0.0, qd = 0.0;
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) aw = fma(ws[i], th[L_::wo(i, j)], aw);
+#pragma unroll
+                        for (int c = 0; c < NS; ++c) {
+                            const double wg = th[L_::wi(c, j)] * gg0[c];
+                            q1 = fma(wg, k1[c], q1);
+                            qd = fma(wg, dk[c], qd);
+                        }
+                        const double c1j = fma(gam, q1, 1.0), czd = gam * qd;
+                        const double pv = av[j] * gr0[j];        // gam a^v_j r_j
+                        const double pw = aw * rr0[j];           // a^w_j r_j
+                        const double gpw = gam * pw;
+                        const double beta = fma(pw, c1j, pv * qd);
+                        thb[L_::wb(j)] += beta;
+                        if (HAS_T) thb[L_::wi(NS, j)] = fma(beta, xT, thb[L_::wi(NS, j)]);
+#pragma unroll
+                        for (int c = 0; c < NS; ++c) {
+                            const double m = fma(pv, dk[c], gpw * k1[c]);
+                            thb[L_::wi(c, j)] = fma(beta, x0[c], fma(gg0[c], m, thb[L_::wi(c, j)]));
+                            const double wi = th[L_::wi(c, j)];
+                            s1[c] = fma(beta, wi, s1[c]);
+                            s2[c] = fma(wi, m, s2[c]);
+                        }
+#pragma unroll
+                        for (int i = 0; i < NS; ++i)
+                            thb[L_::wo(i, j)] = fma(rr0[j], fma(ws[i], c1j, vs[i] * czd), thb[L_::wo(i, j)]);
+                    }
+#pragma unroll
+                    for (int c = 0; c < NS; ++c) {
+                        const double g = gg0[c];
+                        lam[c] = ub[c] + g * (s1[c] - g * s2[c]);   // g' = -g^2 inside the window, 0 outside
+                    }
+                }
+                tnew = tn;
+                --s;
+            }
+        }
+
+        // ---- outputs
+        if (valid) {
+            if (start_saved && n_saved >= 1) {  // the saved initial point: a loss term without gradient
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    const int dr = (int)kc->drow[i];
+                    if (dr >= 0) {
+                        double v = prm.u0[(size_t)i * prm.B + b];
+                        if (prm.clamp_pred) v = clampv(v, -kc->ub, kc->ub);
+                        const double rr = (dA[i] - v) * kc->inv_yscale[i];
+                        loss_sum += (prm.loss_kind == 0) ? fabs(rr) : rr * rr;
+                    }
+                }
+            }
+            const double denom = (double)prm.n_obs * (double)n_saved;
+            const double inv_den = n_saved > 0 ? 1.0 / denom : 0.0;
+            prm.loss[b] = loss_sum * inv_den;
+            prm.retcode[b] = rc;
+            prm.n_saved[b] = n_saved;
+            prm.n_accept[b] = nacc;
+            prm.n_reject[b] = nrej;
+            double *grow = prm.gtraj + (size_t)traj * NTH;
+#pragma unroll
+            for (int m = 0; m < NTH; ++m) grow[m] = thb[m] * inv_den;
+        }
+    }
+}
+
+// Chain rule through p2vec on the batch sums: out = [ dtheta[k,:] . red_theta[0:nth], k < P | extras ]
+__global__ __launch_bounds__(256) void project_kernel(const double *__restrict__ red_theta, const double *__restrict__ dtheta,
+                                                      int nth, int P, double *__restrict__ out) {
+    for (int k = threadIdx.x; k < P; k += 256) {
+        double a = 0.0;
+        for (int m = 0; m < nth; ++m) a = fma(dtheta[(size_t)k * nth + m], red_theta[m], a);
+        out[k] = a;
+    }
+    if ((int)threadIdx.x < kExtra) out[P + threadIdx.x] = red_theta[nth + threadIdx.x];
+}
+
+}  // namespace crnn

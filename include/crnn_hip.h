@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CRNN_ABI_VERSION 1
+#define CRNN_ABI_VERSION 2
 #define CRNN_MAX_N 12   /* max ODE states  */
 #define CRNN_MAX_NR 16  /* max reactions   */
 
@@ -57,6 +57,15 @@ enum { CRNN_LOSS_MAE = 0, CRNN_LOSS_MSE = 1 };
 enum { CRNN_RET_SUCCESS = 0, CRNN_RET_MAXITERS = 1, CRNN_RET_DTMIN = 2, CRNN_RET_UNSTABLE = 3 };
 /* time steppers (reference: alg = Rosenbrock23(...) rober_crnn.jl:33, AutoTsit5(Rosenbrock23()) case2.jl:26, Tsit5() case1.jl:28) */
 enum { CRNN_SOLVER_ROSENBROCK23 = 0, CRNN_SOLVER_TSIT5 = 1 };
+/* How the loss gradient (ForwardDiff.gradient, case2/case2.jl:195) is formed.  Both differentiate the accepted steps
+ * with dt held fixed and agree to rounding:
+ *   FORWARD  P tangent columns pushed through every step (cost ~ (1+P) primal solves; any stepper);
+ *   ADJOINT  the accepted steps are recorded on a tape and reversed once (cost ~ 2 primal solves; Rosenbrock23);
+ *   AUTO     ADJOINT where available, else FORWARD. */
+enum { CRNN_GRAD_AUTO = 0, CRNN_GRAD_FORWARD = 1, CRNN_GRAD_ADJOINT = 2 };
+/* internal to the adjoint path: a trajectory ran out of tape; the library then repeats the call with FORWARD and this
+ * code never reaches the caller */
+enum { CRNN_RET_TAPE_OVERFLOW = 5 };
 /* presets for crnn_config_preset */
 enum { CRNN_PRESET_CASE1 = 1, CRNN_PRESET_CASE2 = 2, CRNN_PRESET_ROBER = 3 };
 
@@ -75,6 +84,8 @@ typedef struct crnn_config {
     int32_t device;               /* HIP device ordinal */
     int32_t cols_per_lane;        /* kernel tuning: tangent columns per lane, 0 = auto */
     int32_t solver;               /* CRNN_SOLVER_*; set it with crnn_config_set_solver (also sets the controller) */
+    int32_t grad_mode;            /* CRNN_GRAD_* */
+    int32_t tape_steps;           /* adjoint: accepted steps recordable per trajectory; 0 = auto (min(maxiters, memory budget)) */
     int32_t reserved0;
     double lb, ub;                /* log(clamp(u, lb, ub)); ub may be +inf */
     double inv_R;                 /* -1/R (case2/case2.jl:113); unused when has_temp = 0 */
@@ -108,7 +119,7 @@ typedef struct crnn_opt_config {
 typedef struct crnn_ctx crnn_ctx;
 
 int32_t crnn_abi_version(void);
-/* sizeof(crnn_config) / sizeof(crnn_stats) / sizeof(crnn_opt_config) for which = 0 / 1 / 2: lets a binding
+/* sizeof(crnn_config) / crnn_stats / crnn_opt_config / crnn_cathode_config for which = 0 / 1 / 2 / 3: lets a binding
  * (Julia struct, ctypes.Structure) verify its mirror of the C structs at load time. */
 int32_t crnn_sizeof(int32_t which);
 const char *crnn_last_error(const crnn_ctx *ctx); /* ctx may be NULL: last error of a failed create */

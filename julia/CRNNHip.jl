@@ -21,7 +21,7 @@ const MAX_N = 12
 mutable struct Config
     abi_version::Int32; ns::Int32; nr::Int32; has_temp::Int32; param_map::Int32; n_save::Int32
     loss_kind::Int32; clamp_pred::Int32; maxiters::Int32; errnorm_sens::Int32; device::Int32; cols_per_lane::Int32
-    solver::Int32; reserved0::Int32
+    solver::Int32; grad_mode::Int32; tape_steps::Int32; reserved0::Int32
     lb::Float64; ub::Float64; inv_R::Float64; t0::Float64
     atol::NTuple{MAX_N,Float64}; rtol::NTuple{MAX_N,Float64}; rate_scale::NTuple{MAX_N,Float64}
     gamma::Float64; qmin::Float64; qmax::Float64; beta1::Float64; beta2::Float64

@@ -9,13 +9,13 @@ from conftest import oracle_problem
 pytestmark = pytest.mark.gpu
 
 
-def _node(case, setup, atol=None, rtol=None, maxiters=None, cols=0):
+def _node(case, setup, atol=None, rtol=None, maxiters=None, cols=0, grad_mode=0, tape_steps=0):
     from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE2, PRESET_ROBER
+    kw = dict(atol=atol, rtol=rtol, maxiters=maxiters, cols_per_lane=cols, grad_mode=grad_mode, tape_steps=tape_steps)
     if case == "case2":
-        prob = ODEProblem(PRESET_CASE2, setup["tsteps"], atol=atol, rtol=rtol, maxiters=maxiters, cols_per_lane=cols)
+        prob = ODEProblem(PRESET_CASE2, setup["tsteps"], **kw)
     else:
-        prob = ODEProblem(PRESET_ROBER, setup["tsteps"], atol=atol, rtol=rtol, maxiters=maxiters,
-                          rate_scale=setup["dydt_scale"], cols_per_lane=cols)
+        prob = ODEProblem(PRESET_ROBER, setup["tsteps"], rate_scale=setup["dydt_scale"], **kw)
     node = NeuralODE(prob)
     node.set_ensemble(setup["u0"], setup["data"], setup["yscale"])
     return node
@@ -54,12 +54,14 @@ def test_pred_loss_match_oracle_reference_tolerances(orc, case2_setup, rober_set
 
 
 @pytest.mark.parametrize("case,pkey", [("case2", "p_ckpt"), ("case2", "p_init"), ("rober", "p_ckpt")])
-@pytest.mark.parametrize("cols", [0, 1])
-def test_gradient_matches_oracle(orc, case2_setup, rober_setup, case, pkey, cols):
-    """d loss/d p per experiment and batched, reference tolerances; 1e-7 relative to max |grad|."""
+@pytest.mark.parametrize("mode,cols", [(2, 0), (1, 0), (1, 1)])
+def test_gradient_matches_oracle(orc, case2_setup, rober_setup, case, pkey, mode, cols):
+    """d loss/d p per experiment and batched, reference tolerances; 1e-7 relative to max |grad|.
+    mode 2: discrete adjoint of the accepted steps; mode 1: forward tangents (auto and one-column-per-lane variants).
+    The oracle carries forward tangents (ForwardDiff's arithmetic)."""
     setup = case2_setup if case == "case2" else rober_setup
     p = setup[pkey]
-    node = _node(case, setup, cols=cols)
+    node = _node(case, setup, cols=cols, grad_mode=mode)
     ref = _oracle_batch(orc, case, setup, p)
     B = setup["u0"].shape[0]
     loss, grad = node.loss_and_grad(p)
@@ -75,6 +77,57 @@ def test_gradient_matches_oracle(orc, case2_setup, rober_setup, case, pkey, cols
         r1 = orc.solve_one(pb, th, setup["u0"][i], setup["tsteps"], setup["data"][i], dtheta=dth)
         assert np.max(np.abs(g - r1["grad"])) < 1e-7 * np.max(np.abs(r1["grad"]))
         assert abs(node.loss_neuralode(p, i) - r1["loss"]) < 1e-9 * r1["loss"]
+
+
+def _solve_all(node, p, sample=None, want_pred=False):
+    from crnn_amd import p2vec_jac
+    th, dth = p2vec_jac(node.pmap, node.ns, node.nr, p)
+    return node._solve(node._ctx, node.B, th, dth, 0, node.B, sample, want_pred)
+
+
+@pytest.mark.parametrize("case,pkey,tol", [("case2", "p_ckpt", None), ("case2", "p_init", None), ("rober", "p_ckpt", None),
+                                           ("case2", "p_ckpt", (1e-10, 1e-8)), ("rober", "p_ckpt", (1e-9, 1e-6))])
+def test_adjoint_equals_forward_tangents(case2_setup, rober_setup, case, pkey, tol):
+    """Two differentiations of the same accepted steps: identical losses/step counts, gradients equal to rounding."""
+    setup = case2_setup if case == "case2" else rober_setup
+    p = setup[pkey]
+    kw = {} if tol is None else dict(atol=tol[0], rtol=tol[1], maxiters=10**6)
+    fwd, adj = _node(case, setup, grad_mode=1, **kw), _node(case, setup, grad_mode=2, **kw)
+    lf, gf = fwd.loss_and_grad(p)
+    la, ga = adj.loss_and_grad(p)
+    assert fwd.last_stats["n_accept"] == adj.last_stats["n_accept"] and fwd.last_stats["n_reject"] == adj.last_stats["n_reject"]
+    assert abs(lf - la) < 1e-13 * abs(lf)
+    assert np.max(np.abs(gf - ga)) < 1e-9 * np.max(np.abs(gf))
+    B = setup["u0"].shape[0]
+    for i in (1, B // 2):
+        assert np.max(np.abs(fwd.gradient(p, i) - adj.gradient(p, i))) < 1e-9 * np.max(np.abs(fwd.gradient(p, i)))
+    # predictions requested together with the gradient come out of the adjoint kernel's forward sweep
+    pf, lsf, gsf, _, _ = _solve_all(fwd, p, want_pred=True)
+    pa, lsa, gsa, _, _ = _solve_all(adj, p, want_pred=True)
+    assert np.array_equal(pf, pa)
+    assert np.max(np.abs(lsf - lsa) / lsf) < 1e-13
+    assert np.max(np.abs(gsf - gsa)) < 1e-9 * np.max(np.abs(gsf))
+
+
+def test_adjoint_truncated_and_failed_trajectories(rober_setup):
+    """sample horizon, maxiters failures (gradient over the saved prefix) and the tape-overflow fallback."""
+    s = rober_setup
+    p = s["p_ckpt"]
+    for kw, sample in ((dict(), 33), (dict(maxiters=20), None), (dict(maxiters=45), 36)):
+        fwd, adj = _node("rober", s, grad_mode=1, **kw), _node("rober", s, grad_mode=2, **kw)
+        _, lf, gf, rf, nf = _solve_all(fwd, p, sample=sample)
+        _, la, ga, ra, na = _solve_all(adj, p, sample=sample)
+        assert np.array_equal(rf, ra) and np.array_equal(nf, na)
+        assert np.max(np.abs(lf - la)) <= 1e-13 * np.max(np.abs(lf))
+        assert np.max(np.abs(gf - ga)) <= 1e-9 * np.max(np.abs(gf))
+        if kw.get("maxiters") == 20:
+            assert np.all(rf == 1) and np.all(nf < len(s["tsteps"]))
+    # 8 tape slots for ~35-step trajectories: every trajectory overflows, the call is repeated with forward tangents
+    fwd, tiny = _node("rober", s, grad_mode=1), _node("rober", s, grad_mode=2, tape_steps=8)
+    _, lf, gf, rf, _ = _solve_all(fwd, p)
+    _, lt, gt, rt, _ = _solve_all(tiny, p)
+    assert np.array_equal(lf, lt) and np.array_equal(gf, gt)
+    assert np.all(rt == 0) and np.array_equal(rf, rt)
 
 
 def test_case2_converged_golden(case2_setup):

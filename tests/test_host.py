@@ -23,16 +23,17 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, n), f"{n} declared in crnn_hip.h but not exported"
         assert n in L.SYMBOLS, f"{n} not bound in crnn_amd/_lib.py"
     assert set(L.SYMBOLS) == names
-    assert raw.crnn_abi_version() == 1
+    assert raw.crnn_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
     """ctypes mirrors == the C structs the library was compiled with (also enforced at import)."""
     from crnn_amd import _lib as L
-    assert L.lib.crnn_sizeof(0) == C.sizeof(L.Config) == 14 * 4 + (4 + 36 + 9) * 8
+    assert L.lib.crnn_sizeof(0) == C.sizeof(L.Config) == 16 * 4 + (4 + 36 + 9) * 8
     assert L.lib.crnn_sizeof(1) == C.sizeof(L.Stats) == 4 * 8 + 8
     assert L.lib.crnn_sizeof(2) == C.sizeof(L.OptConfig) == 2 * 4 + 8 * 8
-    assert L.lib.crnn_sizeof(3) == -1
+    assert L.lib.crnn_sizeof(3) == C.sizeof(L.CathodeConfig) == 4 * 4 + 12 * 8
+    assert L.lib.crnn_sizeof(4) == -1
 
 
 def test_presets_carry_reference_constants():
