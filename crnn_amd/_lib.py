@@ -22,7 +22,8 @@ SOLVER_ROSENBROCK23, SOLVER_TSIT5 = 0, 1
 GRAD_AUTO, GRAD_FORWARD, GRAD_ADJOINT = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcrnn_hip.so")
+# CRNN_HIP_LIB: load another build of the same ABI (kernel experiments, tools/); the default is the in-tree library
+LIB_PATH = os.environ.get("CRNN_HIP_LIB") or os.path.join(_HERE, "csrc", "libcrnn_hip.so")
 
 
 class Config(C.Structure):

@@ -112,6 +112,8 @@ struct Ctx {
     unsigned int *d_overflow = nullptr;
     double *d_red_theta = nullptr;  // [n_theta + kExtra]
     int64_t n_fallback = 0;         // calls repeated with forward tangents after a tape overflow
+    int adj_occ = 0;                // cached occupancy of the adjoint kernel
+    size_t tape_budget = 0;         // bytes the tape may take (auto mode), fixed at the first gradient call
     // reduction
     double *d_partials = nullptr;
     size_t partials_cap = 0;
@@ -120,6 +122,9 @@ struct Ctx {
     int last_npart = 0, last_P = 0;
     // training state
     double *d_p = nullptr, *d_opt = nullptr;
+    double *d_p_eval = nullptr;     // scratch copy of a caller's p (crnn_loss_grad) -- never the training parameters
+    bool theta_current = false;     // d_theta/d_dtheta already hold p2vec(d_p) (written by the fused optimiser kernel)
+    bool flags_zeroed = false;      // queue head / overflow counter already zeroed on the stream by the optimiser kernel
     crnn::OptCfg opt{};
     bool train_ready = false;
     // comm
@@ -170,11 +175,62 @@ __global__ void p2vec_kernel(int pmap, int ns, int nr, int has_temp, const doubl
 }
 
 // red = [grad_sum(P) | pad | loss_sum, n_ok, n_accept, n_reject, n_traj]
-__global__ void opt_kernel(crnn::OptCfg o, int P, int npart, double *p, const double *__restrict__ red, double *state) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double ntraj = red[npart - 1];
-        double gscale = ntraj > 0 ? 1.0 / ntraj : 0.0;
-        crnn::opt_update(o, P, p, red, gscale, state);
+// Flux chain (p2vec.hpp opt_update) with one thread per parameter; the norm clip is a fixed-order LDS tree.
+// Tail: theta, dtheta = p2vec(updated p) for the next step and zeroing of the next launch's queue head / overflow
+// counter, so that a training step is [this kernel] -> solve -> reductions.
+__global__ __launch_bounds__(256) void opt_kernel(crnn::OptCfg o, int P, int npart, double *p, const double *__restrict__ red,
+                                                  double *state, int pmap, int ns, int nr, int has_temp, double *th, double *dth,
+                                                  int nth, unsigned long long *queue, unsigned int *overflow) {
+    __shared__ double sh[256];
+    const int tid = threadIdx.x;
+    const double ntraj = red[npart - 1];
+    const double gscale = ntraj > 0 ? 1.0 / ntraj : 0.0;
+    double *m = state, *v = state + P, *bp = state + 2 * P;
+    double *ed_eta = state + 2 * P + 2, *ncalls = state + 2 * P + 3;
+    double gn = 0.0;
+    bool clip = false;
+    if (o.grad_clip_norm > 0) {
+        double a = 0.0;
+        for (int k = tid; k < P; k += 256) { const double g = red[k] * gscale; a = fma(g, g, a); }
+        sh[tid] = a;
+        __syncthreads();
+        for (int s_ = 128; s_ > 0; s_ >>= 1) {
+            if (tid < s_) sh[tid] += sh[tid + s_];
+            __syncthreads();
+        }
+        gn = sqrt(sh[0]);
+        clip = gn > o.grad_clip_norm;
+    }
+    double eta_ed = 1.0;
+    if (o.use_expdecay) {
+        const double nc = *ncalls + 1.0;
+        double e = *ed_eta;
+        if (fmod(nc, (double)o.decay_step) == 0.0) { e = e * o.ed_decay; e = e > o.ed_clip ? e : o.ed_clip; }
+        eta_ed = e;
+        __syncthreads();   // every thread has read the old values
+        if (tid == 0) { *ncalls = nc; *ed_eta = e; }
+    }
+    const double b1t = bp[0], b2t = bp[1];
+    for (int k = tid; k < P; k += 256) {
+        double g = red[k] * gscale;
+        if (clip) g = g / gn * o.grad_clip_norm;
+        g *= eta_ed;
+        const double mk = o.beta1 * m[k] + (1.0 - o.beta1) * g;
+        const double vk = o.beta2 * v[k] + (1.0 - o.beta2) * g * g;
+        m[k] = mk;
+        v[k] = vk;
+        double delta = mk / (1.0 - b1t) / (sqrt(vk / (1.0 - b2t)) + 1e-8) * o.eta;
+        delta += o.wd * p[k];
+        p[k] -= delta;
+    }
+    for (int i = tid; i < nth * P; i += 256) dth[i] = 0.0;
+    __syncthreads();
+    if (tid == 0) {
+        bp[0] = b1t * o.beta1;
+        bp[1] = b2t * o.beta2;
+        crnn::p2vec_eval(pmap, ns, nr, has_temp, p, th, dth);
+        *queue = 0ULL;
+        *overflow = 0u;
     }
 }
 
@@ -236,25 +292,27 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
                        int64_t count, int n_save_active, bool want_pred) {
     const int nth = c->n_theta;
     const int npart_th = nth + crnn::kExtra, npart = P + crnn::kExtra;
-    int occ = 0;
-    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k->fn, kBlock, 0));
-    if (occ < 1) occ = 1;
+    if (c->adj_occ < 1) {
+        HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->adj_occ, (const void *)k->fn, kBlock, 0));
+        if (c->adj_occ < 1) c->adj_occ = 1;
+    }
+    const int occ = c->adj_occ;
     const int64_t need_blocks = (count + kBlock - 1) / kBlock;
     const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(need_blocks, (int64_t)c->num_cu * occ));
     const size_t lanes = (size_t)nblk * kBlock;
     const size_t recw = (size_t)c->cfg.ns + 2;
     int64_t cap = c->cfg.tape_steps;
     if (cap <= 0) {  // auto: what fits in min(free/4, 16 GiB), at most maxiters (no trajectory accepts more steps)
-        size_t fr = 0, tot = 0;
-        HIP_TRY(c, hipMemGetInfo(&fr, &tot));
-        fr += c->tape_doubles * sizeof(double);
-        const size_t budget = std::min<size_t>(fr / 4, (size_t)16 << 30);
-        cap = (int64_t)(budget / (lanes * recw * sizeof(double)));
+        if (c->tape_budget == 0) {
+            size_t fr = 0, tot = 0;
+            HIP_TRY(c, hipMemGetInfo(&fr, &tot));
+            c->tape_budget = std::min<size_t>(fr / 4, (size_t)16 << 30);
+        }
+        cap = (int64_t)(c->tape_budget / (lanes * recw * sizeof(double)));
         cap = std::max<int64_t>(cap, 64);
     }
     cap = std::min<int64_t>(cap, c->cfg.maxiters);
     if (c->tape_doubles < lanes * (size_t)cap * recw) {
-        // keep an existing larger-capacity tape when the geometry shrinks; grow otherwise
         if (ensure(c, &c->d_tape, &c->tape_doubles, lanes * (size_t)cap * recw)) return -1;
     }
     const int rows_per_block = 256;
@@ -276,8 +334,11 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
     crnn::AdjParams adj{};
     adj.tape = c->d_tape; adj.tape_cap = (int32_t)cap; adj.overflow = c->d_overflow;
     if (upload_consts(c)) return -1;
-    HIP_TRY(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_overflow, 0, sizeof(unsigned int), c->stream));
+    if (!c->flags_zeroed) {
+        HIP_TRY(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_overflow, 0, sizeof(unsigned int), c->stream));
+    }
+    c->flags_zeroed = false;
     c->ev0 = c->ring0[c->n_launch % Ctx::kRing];
     c->ev1 = c->ring1[c->n_launch % Ctx::kRing];
     ++c->n_launch;
@@ -288,10 +349,8 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
     hipLaunchKernelGGL(crnn::reduce_traj_kernel, dim3(rblk), dim3(256), 0, c->stream, c->d_gtraj, nth, c->d_loss, c->d_ret,
                        c->d_nacc, c->d_nrej, first, count, rows_per_block, c->d_partials);
     HIP_TRY(c, hipGetLastError());
-    hipLaunchKernelGGL(crnn::reduce_partials_kernel, dim3(npart_th), dim3(256), 0, c->stream, c->d_partials, rblk, npart_th,
-                       c->d_red_theta);
-    HIP_TRY(c, hipGetLastError());
-    hipLaunchKernelGGL(crnn::project_kernel, dim3(1), dim3(256), 0, c->stream, c->d_red_theta, d_dtheta, nth, P, c->d_red);
+    hipLaunchKernelGGL(crnn::reduce_project_kernel, dim3(1), dim3(256), 0, c->stream, c->d_partials, rblk, d_dtheta, nth, P,
+                       c->d_red_theta, c->d_red);
     HIP_TRY(c, hipGetLastError());
     unsigned int ovf = 0;
     HIP_TRY(c, hipMemcpyAsync(&ovf, c->d_overflow, sizeof(ovf), hipMemcpyDeviceToHost, c->stream));
@@ -353,6 +412,7 @@ int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int 
     fill_params(c, prm, P, first, count, n_save_active, want_pred);
     if (upload_consts(c)) return -1;
     HIP_TRY(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), c->stream));
+    c->flags_zeroed = false;
 
     c->ev0 = c->ring0[c->n_launch % Ctx::kRing];
     c->ev1 = c->ring1[c->n_launch % Ctx::kRing];
@@ -574,6 +634,7 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
         hipMalloc((void **)&c->d_overflow, sizeof(unsigned int)) != hipSuccess ||
         hipMalloc((void **)&c->d_red_theta, sizeof(double) * (c->n_theta + crnn::kExtra)) != hipSuccess ||
         hipMalloc((void **)&c->d_p, sizeof(double) * c->n_params) != hipSuccess ||
+        hipMalloc((void **)&c->d_p_eval, sizeof(double) * c->n_params) != hipSuccess ||
         hipMalloc((void **)&c->d_opt, sizeof(double) * (2 * c->n_params + 4)) != hipSuccess)
         return bail("crnn_ctx_create: hipMalloc failed");
     *out = reinterpret_cast<crnn_ctx *>(c);
@@ -589,7 +650,7 @@ void crnn_ctx_destroy(crnn_ctx *ctx) {
     if (c->own_u0 && c->d_u0) (void)hipFree(c->d_u0);
     if (c->own_data && c->d_data) (void)hipFree(c->d_data);
     void *ptrs[] = {c->d_tape, c->d_overflow, c->d_red_theta, c->d_queue, c->d_nacc, c->d_nrej, c->d_gtraj, c->d_kc, c->d_tsave, c->d_pred, c->d_loss, c->d_ret, c->d_nsaved, c->d_theta, c->d_dtheta,
-                    c->d_partials, c->d_red, c->d_p, c->d_opt, c->d_comm_buf};
+                    c->d_partials, c->d_red, c->d_p, c->d_p_eval, c->d_opt, c->d_comm_buf};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < Ctx::kRing; ++i) {
         if (c->ring0[i]) (void)hipEventDestroy(c->ring0[i]);
@@ -714,6 +775,7 @@ int32_t crnn_solve(crnn_ctx *ctx, const double *theta, const double *dtheta, int
     if (n_dir > c->max_dir) return fail(c, "crnn_solve: n_dir exceeds max(n_params, n_theta)");
     if (grad && n_dir == 0) return fail(c, "crnn_solve: grad requested with n_dir = 0");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    c->theta_current = false;
     HIP_TRY(c, hipMemcpyAsync(c->d_theta, theta, sizeof(double) * c->n_theta, hipMemcpyHostToDevice, c->stream));
     if (n_dir > 0)
         HIP_TRY(c, hipMemcpyAsync(c->d_dtheta, dtheta, sizeof(double) * (size_t)c->n_theta * n_dir, hipMemcpyHostToDevice,
@@ -743,9 +805,10 @@ int32_t crnn_loss_grad(crnn_ctx *ctx, const double *p, int64_t first, int64_t co
     if (!p) return fail(c, "crnn_loss_grad: null p");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     const int P = grad_p ? c->n_params : 0;
-    HIP_TRY(c, hipMemcpyAsync(c->d_p, p, sizeof(double) * c->n_params, hipMemcpyHostToDevice, c->stream));
+    c->theta_current = false;
+    HIP_TRY(c, hipMemcpyAsync(c->d_p_eval, p, sizeof(double) * c->n_params, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(p2vec_kernel, dim3(1), dim3(256), 0, c->stream, c->cfg.param_map, c->cfg.ns, c->cfg.nr,
-                       c->cfg.has_temp, c->d_p, c->d_theta, c->d_dtheta, c->n_theta, c->n_params);
+                       c->cfg.has_temp, c->d_p_eval, c->d_theta, c->d_dtheta, c->n_theta, c->n_params);
     HIP_TRY(c, hipGetLastError());
     if (launch_solve(c, c->d_theta, c->d_dtheta, P, first, count, n_save_active, false, false)) return -1;
     std::vector<double> red(c->last_npart);
@@ -790,6 +853,7 @@ int32_t crnn_train_init(crnn_ctx *ctx, const crnn_opt_config *o, const double *p
     c->opt = to_optcfg(o);
     std::vector<double> st(2 * c->n_params + 4);
     crnn::opt_init(c->opt, c->n_params, st.data());
+    c->theta_current = false;
     HIP_TRY(c, hipMemcpyAsync(c->d_p, p0, sizeof(double) * c->n_params, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_opt, st.data(), sizeof(double) * st.size(), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -802,9 +866,12 @@ int32_t crnn_train_step_begin(crnn_ctx *ctx, int64_t first, int64_t count, int32
     if (!c) return fail(nullptr, "null ctx");
     if (!c->train_ready) return fail(c, "crnn_train_step: call crnn_train_init first");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    hipLaunchKernelGGL(p2vec_kernel, dim3(1), dim3(256), 0, c->stream, c->cfg.param_map, c->cfg.ns, c->cfg.nr,
-                       c->cfg.has_temp, c->d_p, c->d_theta, c->d_dtheta, c->n_theta, c->n_params);
-    HIP_TRY(c, hipGetLastError());
+    if (!c->theta_current) {
+        hipLaunchKernelGGL(p2vec_kernel, dim3(1), dim3(256), 0, c->stream, c->cfg.param_map, c->cfg.ns, c->cfg.nr,
+                           c->cfg.has_temp, c->d_p, c->d_theta, c->d_dtheta, c->n_theta, c->n_params);
+        HIP_TRY(c, hipGetLastError());
+    }
+    c->theta_current = false;   // consumed: anything else that touches d_theta / d_p must not find a stale flag
     return launch_solve(c, c->d_theta, c->d_dtheta, c->n_params, first, count, n_save_active, false, false);
 }
 
@@ -812,9 +879,12 @@ int32_t crnn_train_step_end(crnn_ctx *ctx, double *loss_mean) {
     Ctx *c = reinterpret_cast<Ctx *>(ctx);
     if (!c) return fail(nullptr, "null ctx");
     if (!c->train_ready || c->last_npart == 0) return fail(c, "crnn_train_step_end: no step in flight");
-    hipLaunchKernelGGL(opt_kernel, dim3(1), dim3(64), 0, c->stream, c->opt, c->n_params, c->last_npart, c->d_p, c->d_red,
-                       c->d_opt);
+    hipLaunchKernelGGL(opt_kernel, dim3(1), dim3(256), 0, c->stream, c->opt, c->n_params, c->last_npart, c->d_p, c->d_red,
+                       c->d_opt, c->cfg.param_map, c->cfg.ns, c->cfg.nr, c->cfg.has_temp, c->d_theta, c->d_dtheta, c->n_theta,
+                       c->d_queue, c->d_overflow);
     HIP_TRY(c, hipGetLastError());
+    c->theta_current = true;
+    c->flags_zeroed = true;
     if (loss_mean) {
         double tail[5];
         HIP_TRY(c, hipMemcpyAsync(tail, c->d_red + c->last_npart - 5, sizeof(tail), hipMemcpyDeviceToHost, c->stream));
@@ -854,6 +924,7 @@ int32_t crnn_set_params(crnn_ctx *ctx, const double *p) {
     Ctx *c = reinterpret_cast<Ctx *>(ctx);
     if (!c || !p) return fail(c, "crnn_set_params: null");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    c->theta_current = false;
     HIP_TRY(c, hipMemcpyAsync(c->d_p, p, sizeof(double) * c->n_params, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return 0;

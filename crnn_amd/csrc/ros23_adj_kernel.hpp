@@ -343,18 +343,17 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
         double tnew = t;             // end time of the step being reversed
         int s = valid ? nacc - 1 : -1;
 
-        auto load_row = [&](int j, double (&d)[NS]) {
-            const int jj = j > 0 ? j : 0;
-            const double *row = prm.data + (size_t)b * prm.row_stride + (size_t)jj * prm.n_obs;
+        // Observed rows are fetched at the top of a reverse step, a whole step re-formation (~2 us of arithmetic) ahead
+        // of their use: rows jsave-1, jsave-2, jsave-3 cover the save points one step usually spans.
+        const double *const drows = prm.data + (size_t)b * prm.row_stride;
+        int doff[NS];
 #pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                const int dr = (int)kc->drow[i];
-                d[i] = row[dr >= 0 ? dr : 0];
-            }
+        for (int i = 0; i < NS; ++i) { const int dr = (int)kc->drow[i]; doff[i] = dr >= 0 ? dr : 0; }
+        auto load_row = [&](int j, double (&d)[NS]) {
+            const double *row = drows + (size_t)(j > 0 ? j : 0) * prm.n_obs;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) d[i] = row[doff[i]];
         };
-        double dA[NS], dB[NS];       // data rows jsave-1 and jsave-2, prefetched
-        load_row(jsave - 1, dA);
-        load_row(jsave - 2, dB);
         double rt = 0.0, rdt = 0.0, ru[NS];   // tape record s, prefetched
         {
             const double *rec = tape + (size_t)(s > 0 ? s : 0) * RECW;
@@ -369,6 +368,10 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                 double un[NS];
 #pragma unroll
                 for (int i = 0; i < NS; ++i) un[i] = ru[i];
+                double dA[NS], dB[NS], dC[NS];
+                load_row(jsave - 1, dA);
+                load_row(jsave - 2, dB);
+                load_row(jsave - 3, dC);
                 {   // prefetch the next record (s-1)
                     const double *rec = tape + (size_t)(s > 0 ? s - 1 : 0) * RECW;
                     rt = rec[0]; rdt = rec[1];
@@ -401,14 +404,15 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                     for (int i = 0; i < NS; ++i) dk[i] = f1[i] - k1[i];
                 }
                 W.solve(th, gg0, gr0, kc->scale, dk);
+                CRNN_SCHED_FENCE();
 
                 // ---- loss and its seeds at the save points inside (tn, tnew]
                 double A_[NS], B1[NS], B2[NS];
 #pragma unroll
                 for (int i = 0; i < NS; ++i) { A_[i] = 0.0; B1[i] = 0.0; B2[i] = 0.0; }
-                while (jsave > jlo) {
+                auto in_step = [&]() -> bool { return jsave > jlo && ts_lds[jsave - 1] > tn; };
+                auto seed_point = [&](const double (&dobs)[NS]) {
                     const double ts = ts_lds[jsave - 1];
-                    if (!(ts > tn)) break;
                     const bool at_end = (ts == tnew);
                     const double Th = at_end ? 1.0 : (ts - tn) / h;
                     const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                                 v = clampv(v, -kc->ub, kc->ub);
                             }
                             const double iy = kc->inv_yscale[i];
-                            const double rr = (dA[i] - v) * iy;
+                            const double rr = (dobs[i] - v) * iy;
                             double w;
                             if (prm.loss_kind == 0) { loss_sum += fabs(rr); w = signbit(rr) ? 1.0 : -1.0; }
                             else { loss_sum = fma(rr, rr, loss_sum); w = -2.0 * rr; }
@@ -436,11 +440,23 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                         }
                     }
                     --jsave;
-#pragma unroll
-                    for (int i = 0; i < NS; ++i) dA[i] = dB[i];
-                    load_row(jsave - 2, dB);
+                };
+                if (in_step()) {
+                    seed_point(dA);
+                    if (in_step()) {
+                        seed_point(dB);
+                        if (in_step()) {
+                            seed_point(dC);
+                            while (in_step()) {  // more than three save points inside one step: fetch on demand
+                                double dD[NS];
+                                load_row(jsave - 1, dD);
+                                seed_point(dD);
+                            }
+                        }
+                    }
                 }
 
+                CRNN_SCHED_FENCE();
                 // ---- adjoint of the step
                 double kb1[NS], v[NS], ub[NS];
 #pragma unroll
@@ -461,6 +477,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                     for (int i = 0; i < NS; ++i) a = fma(vs[i], th[L_::wo(i, j)], a);
                     av[j] = a;
                 }
+                CRNN_SCHED_FENCE();
                 // point u_mid: d(v.f)/d(u, theta)
                 {
                     double um[NS];
@@ -486,7 +503,9 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                         kb1[c] = fma(0.5 * h, m, kb1[c]);
                     }
                 }
+                CRNN_SCHED_FENCE();
                 solve_T<NS, NR, HAS_T, USE_SCALE>(W, th, gg0, gr0, kc->scale, kb1);      // kb1 = w = W^-T kb1
+                CRNN_SCHED_FENCE();
                 // point u_n: d/d(u, theta) [ w.f + gam (v.J dk + w.J k1) ]
                 {
                     double ws[NS];
@@ -545,7 +564,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                     if (dr >= 0) {
                         double v = prm.u0[(size_t)i * prm.B + b];
                         if (prm.clamp_pred) v = clampv(v, -kc->ub, kc->ub);
-                        const double rr = (dA[i] - v) * kc->inv_yscale[i];
+                        const double rr = (drows[doff[i]] - v) * kc->inv_yscale[i];
                         loss_sum += (prm.loss_kind == 0) ? fabs(rr) : rr * rr;
                     }
                 }
@@ -564,15 +583,46 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
     }
 }
 
-// Chain rule through p2vec on the batch sums: out = [ dtheta[k,:] . red_theta[0:nth], k < P | extras ]
-__global__ __launch_bounds__(256) void project_kernel(const double *__restrict__ red_theta, const double *__restrict__ dtheta,
-                                                      int nth, int P, double *__restrict__ out) {
-    for (int k = threadIdx.x; k < P; k += 256) {
+// Fixed-order reduction of the per-block partials (theta space) followed by the chain rule through p2vec:
+//   red_theta[m] = sum_blk partials[blk][m]   (m < nth + kExtra; the order over blk is fixed)
+//   out = [ dtheta[k,:] . red_theta[0:nth], k < P | extras ]
+// One block; nth + kExtra <= 256.
+__global__ __launch_bounds__(256) void reduce_project_kernel(const double *__restrict__ partials, int nblk,
+                                                             const double *__restrict__ dtheta, int nth, int P,
+                                                             double *__restrict__ red_theta, double *__restrict__ out) {
+    __shared__ double sh[256];
+    __shared__ double part[4][256];
+    const int npart = nth + kExtra;
+    const int tid = threadIdx.x;
+    // columns in chunks of 64, four row lanes per column; the combination order is fixed
+    const int col = tid & 63, rl = tid >> 6;
+    for (int c0 = 0; c0 < npart; c0 += 64) {
+        const int k = c0 + col;
+        double a0 = 0.0, a1 = 0.0;
+        if (k < npart) {
+            int bI = rl;
+            for (; bI + 4 < nblk; bI += 8) {
+                a0 += partials[(size_t)bI * npart + k];
+                a1 += partials[(size_t)(bI + 4) * npart + k];
+            }
+            if (bI < nblk) a0 += partials[(size_t)bI * npart + k];
+        }
+        part[rl][col] = a0 + a1;
+        __syncthreads();
+        if (rl == 0 && k < npart) {
+            const double a = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
+            sh[k] = a;
+            red_theta[k] = a;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int k = tid; k < P; k += 256) {
         double a = 0.0;
-        for (int m = 0; m < nth; ++m) a = fma(dtheta[(size_t)k * nth + m], red_theta[m], a);
+        for (int m = 0; m < nth; ++m) a = fma(dtheta[(size_t)k * nth + m], sh[m], a);
         out[k] = a;
     }
-    if ((int)threadIdx.x < kExtra) out[P + threadIdx.x] = red_theta[nth + threadIdx.x];
+    if (tid < kExtra) out[P + tid] = sh[nth + tid];
 }
 
 }  // namespace crnn
