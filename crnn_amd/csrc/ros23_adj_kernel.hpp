@@ -30,6 +30,16 @@
 #pragma once
 #include "ros23_kernel.hpp"
 
+// kernel-timing ablations (tools/adj_ablate.sh): 1 = no reverse sweep, 2 = no observed-data loads, 4 = no tape stores
+#ifndef CRNN_ADJ_DBG
+#define CRNN_ADJ_DBG 0
+#endif
+// 1: the n_theta gradient accumulators of a lane live in LDS ([m][lane], conflict-free) and are updated with
+//    ds_add_f64; 0: they live in registers (84 VGPRs for case2, which the allocator parks in AGPRs)
+#ifndef CRNN_ADJ_THB_LDS
+#define CRNN_ADJ_THB_LDS 1
+#endif
+
 namespace crnn {
 
 struct AdjParams {
@@ -113,12 +123,14 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
 
     __shared__ double kc_lds[kNConst];
     __shared__ double ts_lds[kMaxSave];
+    __shared__ double thb_lds[CRNN_ADJ_THB_LDS ? NTH * BLOCK : 1];
     const int tid = threadIdx.x;
     for (int idx = tid; idx < kNConst; idx += BLOCK) kc_lds[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
     for (int idx = tid; idx < prm.n_save; idx += BLOCK) ts_lds[idx] = prm.tsave[idx];
     __syncthreads();
     const KConst *kc = reinterpret_cast<const KConst *>(kc_lds);
     const double *__restrict__ th = theta;
+    double *const thb_s = thb_lds + (CRNN_ADJ_THB_LDS ? tid : 0);   // accumulator m of this lane: thb_s[m * BLOCK]
 
     const double d_ = 0.29289321881345248;    // 1/(2+sqrt 2)
     const double c32 = 7.4142135623730950;    // 6+sqrt 2
@@ -280,7 +292,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                                 rc = 5;  // out of tape: the host re-runs the call with forward tangents
                                 atomicAdd(adj.overflow, 1u);
                             } else {
-                                double *rec = tape + (size_t)nacc * RECW;
+                                double *rec = tape + (size_t)((CRNN_ADJ_DBG & 4) ? 0 : nacc) * RECW;
                                 rec[0] = t;
                                 rec[1] = dt;
 #pragma unroll
@@ -333,15 +345,24 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
         // ================================================================== reverse sweep
         const int n_saved = jsave;
         const int jlo = start_saved ? 1 : 0;
+#if CRNN_ADJ_THB_LDS
+#pragma unroll
+        for (int m = 0; m < NTH; ++m) thb_s[m * BLOCK] = 0.0;
+#define THB_ADD(m, val) unsafeAtomicAdd(&thb_s[(m) * BLOCK], (val))
+#define THB_REG(m) 0.0
+#else
         double thb[NTH];
 #pragma unroll
         for (int m = 0; m < NTH; ++m) thb[m] = 0.0;
+#define THB_ADD(m, val) thb[m] += (val)
+#define THB_REG(m) thb[m]
+#endif
         double lam[NS];
 #pragma unroll
         for (int i = 0; i < NS; ++i) lam[i] = 0.0;
         double loss_sum = 0.0;
         double tnew = t;             // end time of the step being reversed
-        int s = valid ? nacc - 1 : -1;
+        int s = (valid && !(CRNN_ADJ_DBG & 1)) ? nacc - 1 : -1;
 
         // Observed rows are fetched at the top of a reverse step, a whole step re-formation (~2 us of arithmetic) ahead
         // of their use: rows jsave-1, jsave-2, jsave-3 cover the save points one step usually spans.
@@ -352,7 +373,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
         auto load_row = [&](int j, double (&d)[NS]) {
             const double *row = drows + (size_t)(j > 0 ? j : 0) * prm.n_obs;
 #pragma unroll
-            for (int i = 0; i < NS; ++i) d[i] = row[doff[i]];
+            for (int i = 0; i < NS; ++i) d[i] = (CRNN_ADJ_DBG & 2) ? 0.5 : row[doff[i]];
         };
         double rt = 0.0, rdt = 0.0, ru[NS];   // tape record s, prefetched
         {
@@ -486,15 +507,15 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
 #pragma unroll
                     for (int j = 0; j < NR; ++j) {
                         const double rho = av[j] * r1[j];
-                        thb[L_::wb(j)] += rho;
-                        if (HAS_T) thb[L_::wi(NS, j)] = fma(rho, xT, thb[L_::wi(NS, j)]);
+                        THB_ADD(L_::wb(j), rho);
+                        if (HAS_T) THB_ADD(L_::wi(NS, j), rho * xT);
 #pragma unroll
                         for (int c = 0; c < NS; ++c) {
-                            thb[L_::wi(c, j)] = fma(rho, x1[c], thb[L_::wi(c, j)]);
+                            THB_ADD(L_::wi(c, j), rho * x1[c]);
                             um[c] = fma(rho, th[L_::wi(c, j)], um[c]);
                         }
 #pragma unroll
-                        for (int i = 0; i < NS; ++i) thb[L_::wo(i, j)] = fma(vs[i], r1[j], thb[L_::wo(i, j)]);
+                        for (int i = 0; i < NS; ++i) THB_ADD(L_::wo(i, j), vs[i] * r1[j]);
                     }
 #pragma unroll
                     for (int c = 0; c < NS; ++c) {
@@ -530,19 +551,18 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                         const double pw = aw * rr0[j];           // a^w_j r_j
                         const double gpw = gam * pw;
                         const double beta = fma(pw, c1j, pv * qd);
-                        thb[L_::wb(j)] += beta;
-                        if (HAS_T) thb[L_::wi(NS, j)] = fma(beta, xT, thb[L_::wi(NS, j)]);
+                        THB_ADD(L_::wb(j), beta);
+                        if (HAS_T) THB_ADD(L_::wi(NS, j), beta * xT);
 #pragma unroll
                         for (int c = 0; c < NS; ++c) {
                             const double m = fma(pv, dk[c], gpw * k1[c]);
-                            thb[L_::wi(c, j)] = fma(beta, x0[c], fma(gg0[c], m, thb[L_::wi(c, j)]));
+                            THB_ADD(L_::wi(c, j), fma(beta, x0[c], gg0[c] * m));
                             const double wi = th[L_::wi(c, j)];
                             s1[c] = fma(beta, wi, s1[c]);
                             s2[c] = fma(wi, m, s2[c]);
                         }
 #pragma unroll
-                        for (int i = 0; i < NS; ++i)
-                            thb[L_::wo(i, j)] = fma(rr0[j], fma(ws[i], c1j, vs[i] * czd), thb[L_::wo(i, j)]);
+                        for (int i = 0; i < NS; ++i) THB_ADD(L_::wo(i, j), rr0[j] * fma(ws[i], c1j, vs[i] * czd));
                     }
 #pragma unroll
                     for (int c = 0; c < NS; ++c) {
@@ -578,8 +598,10 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
             prm.n_reject[b] = nrej;
             double *grow = prm.gtraj + (size_t)traj * NTH;
 #pragma unroll
-            for (int m = 0; m < NTH; ++m) grow[m] = thb[m] * inv_den;
+            for (int m = 0; m < NTH; ++m) grow[m] = (CRNN_ADJ_THB_LDS ? thb_s[m * BLOCK] : THB_REG(m)) * inv_den;
         }
+#undef THB_ADD
+#undef THB_REG
     }
 }
 

@@ -230,16 +230,91 @@ struct Rec {
     static constexpr int NREC = DT + 1;
 };
 
-// x = log(clamp(u)), g = dx/du (0 outside the closed window, as ForwardDiff's clamp)
+// x = log(clamp(u)), g = dx/du (0 outside the closed window, as ForwardDiff's clamp).
+// Written species-innermost: every polynomial coefficient of the logarithm (a 64-bit literal = two s_mov) is
+// materialised once and serves all NS species; at one wavefront per SIMD every instruction, scalar ones included,
+// costs an issue slot.  c = min(max(u, lb), ub): a NaN state does not reach here unnoticed -- the stepper rejects
+// non-finite stage results (retcode Unstable) before they are used.
 template <int NS>
 __device__ __forceinline__ void features(const double (&u)[NS], double lb, double ub, double (&x)[NS], double (&g)[NS]) {
+    double m[NS], f[NS], r[NS], s[NS], z[NS], w[NS], t1[NS], t2[NS], dk[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-        double ui = u[i];
-        bool inside = (ui >= lb) && (ui <= ub);
-        double c = clampv(ui, lb, ub);
-        x[i] = flog(c);
-        g[i] = inside ? frcp(ui) : 0.0;
+        const double c = fmin(fmax(u[i], lb), ub);
+        g[i] = (c == u[i]) ? frcp(c) : 0.0;
+        double mm = __builtin_amdgcn_frexp_mant(c);      // [0.5, 1)
+        int k = __builtin_amdgcn_frexp_exp(c);
+        const bool lo = mm < 0.70710678118654752440;
+        mm = lo ? mm + mm : mm;                          // [sqrt(1/2), sqrt 2)
+        k = lo ? k - 1 : k;
+        m[i] = mm;
+        dk[i] = (double)k;
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { f[i] = m[i] - 1.0; r[i] = frcp(2.0 + f[i]); }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { s[i] = f[i] * r[i]; s[i] = fma(fma(-(2.0 + f[i]), s[i], f[i]), r[i], s[i]); }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { z[i] = s[i] * s[i]; w[i] = z[i] * z[i]; }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) t1[i] = fma(w[i], 1.531383769920937332e-01, 2.222219843214978396e-01);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) t1[i] = fma(w[i], t1[i], 3.999999999940941908e-01);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) t2[i] = fma(w[i], 1.479819860511658591e-01, 1.818357216161805012e-01);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) t2[i] = fma(w[i], t2[i], 2.857142874366239149e-01);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) t2[i] = fma(w[i], t2[i], 6.666666666666735130e-01);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const double R = fma(z[i], t2[i], w[i] * t1[i]);
+        const double hfsq = 0.5 * f[i] * f[i];
+        x[i] = fma(dk[i], 6.93147180369123816490e-01, -((hfsq - fma(s[i], hfsq + R, dk[i] * 1.90821492927058770002e-10)) - f[i]));
+    }
+}
+
+// e^z for NR arguments at once, reaction-innermost so that each constant is materialised once (see features()).
+// z = k ln2 + r, |r| <= ln2/2;  e^r by its Taylor polynomial of degree 13 (truncation 4e-18 relative);  2^k by ldexp,
+// which saturates to inf / 0 exactly where exp overflows / underflows; NaN propagates.  < 1 ulp typical, 2 ulp worst.
+template <int NR>
+__device__ __forceinline__ void fexp_vec(const double (&z)[NR], double (&e)[NR]) {
+    double kd[NR], r[NR], p[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) kd[j] = __builtin_rint(z[j] * 1.44269504088896338700e+00);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) r[j] = fma(kd[j], -6.93147180369123816490e-01, z[j]);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) r[j] = fma(kd[j], -1.90821492927058770002e-10, r[j]);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) p[j] = fma(r[j], 1.6059043836821613e-10, 2.08767569878681e-09);   // 1/13!, 1/12!
+#pragma unroll
+    for (int j = 0; j < NR; ++j) p[j] = fma(r[j], p[j], 2.505210838544172e-08);                    // 1/11!
+#pragma unroll
+    for (int j = 0; j < NR; ++j) p[j] = fma(r[j], p[j], 2.755731922398589e-07);                    // 1/10!
+#pragma unroll
+    for (int j = 0; j < NR; ++j) p[j] = fma(r[j], p[j], 2.7557319223985893e-06);                   // 1/9!
+#pragma unroll
+    for (int j = 0; j < NR; ++j) p[j] = fma(r[j], p[j], 2.48015873015873e-05);                     // 1/8!
+#pragma unroll
+    for (int j = 0; j < NR; ++j) p[j] = fma(r[j], p[j], 1.984126984126984e-04);                    // 1/7!
+#pragma unroll
+    for (int j = 0; j < NR; ++j) p[j] = fma(r[j], p[j], 1.388888888888889e-03);                    // 1/6!
+#pragma unroll
+    for (int j = 0; j < NR; ++j) p[j] = fma(r[j], p[j], 8.333333333333333e-03);                    // 1/5!
+#pragma unroll
+    for (int j = 0; j < NR; ++j) p[j] = fma(r[j], p[j], 4.1666666666666664e-02);                   // 1/4!
+#pragma unroll
+    for (int j = 0; j < NR; ++j) p[j] = fma(r[j], p[j], 1.6666666666666666e-01);                   // 1/3!
+#pragma unroll
+    for (int j = 0; j < NR; ++j) p[j] = fma(r[j], p[j], 0.5);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) { const double r2 = r[j] * r[j]; p[j] = fma(r2, p[j], r[j]) + 1.0; }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        // |z| beyond +-1100 would overflow the int conversion's meaning, not its saturation: clamp k, ldexp saturates
+        const int k = (int)fmin(fmax(kd[j], -2200.0), 2200.0);
+        e[j] = __builtin_amdgcn_ldexp(p[j], k);
     }
 }
 
@@ -248,13 +323,15 @@ template <int NS, int NR, bool HAS_T>
 __device__ __forceinline__ void rates(const double *__restrict__ th, const double (&x)[NS], const double (&bT)[NR],
                                       double (&r)[NR]) {
     using L = Lay<NS, NR, HAS_T>;
+    double z[NR];
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
-        double z = bT[j];
+        double zz = bT[j];
 #pragma unroll
-        for (int i = 0; i < NS; ++i) z = fma(th[L::wi(i, j)], x[i], z);
-        r[j] = exp(z);
+        for (int i = 0; i < NS; ++i) zz = fma(th[L::wi(i, j)], x[i], zz);
+        z[j] = zz;
     }
+    fexp_vec<NR>(z, r);
 }
 
 template <int NS, int NR, bool HAS_T, bool USE_SCALE>

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Kernel timing at FIXED parameters (no optimiser update): case2 checkpoint p, B initial conditions, loss+gradient
+launches; prints the median HIP-event kernel time.  CRNN_HIP_LIB selects the library build (tools/kvariants.sh).
+usage: python tools/kbench.py [--batch 65536] [--reps 12] [--grad auto|forward|adjoint] [--case case2|rober]"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=65536)
+ap.add_argument("--reps", type=int, default=12)
+ap.add_argument("--grad", default="auto")
+ap.add_argument("--case", default="case2")
+args = ap.parse_args()
+
+from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE2, PRESET_ROBER, cases  # noqa: E402
+
+fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fixtures.json")))
+rng = np.random.Generator(np.random.PCG64([1234, 0]))
+gm = {"auto": 0, "forward": 1, "adjoint": 2}[args.grad]
+B = args.batch
+if args.case == "case2":
+    ts = cases.case2_tsteps()
+    u0 = cases.case2_u0(B, rng)
+    gen = NeuralODE(ODEProblem(PRESET_CASE2, ts, atol=1e-10, rtol=1e-8))
+    clean = gen.predict_theta(u0, cases.case2_true_theta())[:, :6, :]
+    gen.close()
+    data = cases.add_noise(clean, 0.05, rng)
+    node = NeuralODE(ODEProblem(PRESET_CASE2, ts, grad_mode=gm))
+    node.set_ensemble(u0, data, cases.max_min(data, lb=1e-6))
+    p = np.array(fx["case2_ckpt"]["p"])
+else:
+    ts = cases.rober_tsteps()
+    u0 = cases.rober_u0(B, rng)
+    ys = np.array(fx["rober"]["yscale"]) if "yscale" in fx.get("rober", {}) else np.array([1.0, 4e-5, 1.0])
+    sc = ys / ts[-1]
+    data = np.abs(rng.standard_normal((B, 3, len(ts)))) * ys[None, :, None]
+    node = NeuralODE(ODEProblem(PRESET_ROBER, ts, rate_scale=sc, grad_mode=gm))
+    node.set_ensemble(u0, data, ys)
+    p = np.array(fx["rober_ckpt"]["p"])
+ms = []
+for _ in range(args.reps):
+    loss, grad = node.loss_and_grad(p)
+    ms.append(node.last_stats["kernel_ms"])
+st = node.last_stats
+print(f"lib={os.path.basename(os.environ.get('CRNN_HIP_LIB', 'libcrnn_hip.so'))} case={args.case} grad={args.grad} B={B} "
+      f"kernel_ms median {np.median(ms[2:]):.4f} min {min(ms[2:]):.4f}  steps/traj {st['n_accept'] / st['n_traj']:.2f} "
+      f"rej/traj {st['n_reject'] / st['n_traj']:.2f} loss {loss:.6e} |g| {np.linalg.norm(grad):.6e}")
