@@ -6,10 +6,12 @@ case2 (6 species + T, 3 reactions, P = 25), 65 536 random initial conditions
 per GPU, fp64, Rosenbrock23 at the reference tolerances (atol 1e-6, rtol 1e-3).
 
 One "step" = one pass of the hot path over the rank's batch, with the ensemble
-already resident in HBM: p2vec kernel -> fused solve + loss + forward-tangent
-kernel (65 536 trajectories) -> fixed-order gradient reduction -> all-reduce of
-the (P+pad+5)-vector over ranks (RCCL) -> Flux-style ExpDecay/ADAM/WeightDecay
-update of p on the device.  Weak scaling: every rank owns its own 65 536 ICs.
+already resident in HBM: solve + loss + gradient kernel (65 536 trajectories;
+--grad adjoint: forward sweep + reversed accepted steps, one lane per trajectory;
+--grad forward: P tangent columns on lane groups) -> fixed-order gradient
+reduction + chain rule through p2vec -> all-reduce of the (P+5)-vector over ranks
+(RCCL) -> Flux-style ExpDecay/ADAM/WeightDecay update of p on the device (the same
+kernel forms p2vec of the new p).  Weak scaling: every rank owns its own 65 536 ICs.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -29,15 +31,20 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# Algorithmic HBM bytes per trajectory+gradient of the dominant kernel (case2, no pred output):
-#   8 * [ n (u0) + n_obs*D (data) + 1 (loss) ] + 4 * 4 (retcode, n_saved, n_accept, n_reject as int32)
-#   + 8 * 28 (the trajectory's gradient row, 25 columns padded to L*C = 28; summed by a fixed-order second kernel)
-BYTES_PER_TRAJ = 8 * (7 + 6 * 50 + 1) + 16 + 8 * 28
+# Algorithmic HBM bytes per trajectory+gradient (case2, no pred output) -- SURVEY 8(d)'s per-unit figure:
+#   8 * [ n (u0) + n_obs*D (data) + 1 (loss) + 1 (retcode, n_saved as 2 x int32) ] = 2472 B.
+# Implementation traffic on top of it (per-trajectory gradient rows, step counters, the adjoint's step tape) is NOT
+# counted here; it shows up in roofline.traffic.
+BYTES_PER_TRAJ = 8 * (7 + 6 * 50 + 1 + 1)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X FP64 vector peak (spec); 2 flop per FMA
 # FP64 operation model of the kernel (DESIGN.md "flop model"), 2 flop per operation (upper bound: mul/add count as FMA):
 FLOP_PRIMAL_STEP = 2 * 1480      # one Rosenbrock23 attempt: 12 log, 6 exp, 12 rcp, J, 6x6 LU, 3 solves, error norm, controller
 FLOP_COL_STEP = 2 * 441          # one tangent column through one accepted step
+# adjoint kernel: v_fma/v_mul/v_add_f64 instructions per loop body in the gfx950 ISA (tools/isa_blocks.py), x2
+FLOP_ADJ_ATTEMPT = 2 * 846       # forward sweep, one Rosenbrock23 attempt
+FLOP_ADJ_REVERSE = 2 * 755       # reverse sweep, one accepted step (re-formation 334 + adjoint 421)
+FLOP_ADJ_SAVE = 2 * 40           # loss + seeds of one save point
 
 
 def usable_cores():
@@ -67,7 +74,8 @@ def parse():
     ap.add_argument("--grad", choices=["auto", "forward", "adjoint"], default="auto",
                     help="gradient algorithm: discrete adjoint of the accepted steps (auto) or forward tangents")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=32768)
+    ap.add_argument("--cpu-sample", type=int, default=65536)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall time to spend on the CPU baseline")
     return ap.parse_args()
 
 
@@ -175,12 +183,17 @@ def main():
         k_ms = float(kms.mean())
         value = world * B * args.steps / elapsed
         ach_gbs = BYTES_PER_TRAJ * B / (k_ms * 1e-3) / 1e9
-        flops = (st["n_accept"] + st["n_reject"]) * FLOP_PRIMAL_STEP + st["n_accept"] * 25 * FLOP_COL_STEP
+        if adjoint:
+            flops = ((st["n_accept"] + st["n_reject"]) * FLOP_ADJ_ATTEMPT + st["n_accept"] * FLOP_ADJ_REVERSE
+                     + st["n_traj"] * len(ts) * FLOP_ADJ_SAVE)
+        else:
+            flops = (st["n_accept"] + st["n_reject"]) * FLOP_PRIMAL_STEP + st["n_accept"] * 25 * FLOP_COL_STEP
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md)
             try:
-                traffic = json.load(open(tpath)).get("case2_B65536_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("case2_B65536_adjoint_bytes_per_launch" if adjoint
+                                                     else "case2_B65536_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -191,16 +204,18 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "case2: 6 species + T, 3 reactions, P=25, D=50 save points on [0,50], "
-                                   f"{'Tsit5' if args.solver == 'tsit5' else 'Rosenbrock23'} atol 1e-6 rtol 1e-3, MAE loss, forward-tangent gradient, "
+                                   f"{'Tsit5' if args.solver == 'tsit5' else 'Rosenbrock23'} atol 1e-6 rtol 1e-3, MAE loss, "
+                                   f"{'discrete-adjoint' if adjoint else 'forward-tangent'} gradient of the accepted steps (= ForwardDiff's derivative), "
                                    "ExpDecay+ADAM+WeightDecay update",
                        "batch_per_gpu": B, "global_batch": B * world, "theta0": args.theta0,
                        "comm": comm if world > 1 else "none", "parallelism": f"dp{world} (ICs sharded, 1 all-reduce/step)"},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("tsit5_kernel" if args.solver == "tsit5" else "ros23_kernel") + "<6,3,T,C,L>", "kernel_ms": k_ms,
+                         "kernel": ("ros23_adj_kernel<6,3,T>" if adjoint else
+                                    ("tsit5_kernel" if args.solver == "tsit5" else "ros23_kernel") + "<6,3,T,C,L>"), "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_TRAJ * B,
-                         "note": "state lives in VGPR/LDS for the whole integration; the path is FP64-VALU/latency bound, "
-                                 "see valu_fp64 (SURVEY F8)"},
+                         "note": "state lives in VGPR/LDS for the whole integration; the path is instruction-issue bound "
+                                 "(one wavefront per SIMD at 65 536 trajectories), see valu_fp64 (SURVEY F8)"},
             # flop count and duration of the LAST timed launch (step counts drift slightly as p is updated)
             "valu_fp64": {"achieved": flops / (kms[-1] * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                           "frac": flops / (kms[-1] * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
@@ -219,13 +234,17 @@ def main():
             data_s = np.ascontiguousarray(data[:ns_].transpose(2, 1, 0))
             cores = usable_cores()
             orc.solve_batch(pb, th, u0_s[:, :256].copy(), ts, data_s[:, :, :256].copy(), dtheta=dth, nthreads=cores)  # warm-up
-            tc = time.perf_counter()
-            orc.solve_batch(pb, th, u0_s, ts, data_s, dtheta=dth, nthreads=cores)
-            tc = time.perf_counter() - tc
-            out["cpu_baseline"] = {"value": ns_ / tc, "unit": "trajectories+grads/s", "cores": cores, "kind": "port",
-                                   "sample": f"first {ns_} ICs of the same ensemble, solve+loss+gradient at the same p, "
-                                             f"C oracle with OpenMP over trajectories ({tc:.2f} s wall); "
-                                             "a C restatement, not DifferentialEquations.jl (Julia absent)"}
+            # repeat the sample until >= --cpu-seconds of wall time have been spent (bounded CPU work, stable rate)
+            tc, passes = 0.0, 0
+            while tc < args.cpu_seconds and passes < 64:
+                t1 = time.perf_counter()
+                orc.solve_batch(pb, th, u0_s, ts, data_s, dtheta=dth, nthreads=cores)
+                tc += time.perf_counter() - t1
+                passes += 1
+            out["cpu_baseline"] = {"value": ns_ * passes / tc, "unit": "trajectories+grads/s", "cores": cores, "kind": "port",
+                                   "sample": f"{passes} passes over the first {ns_} ICs of the same ensemble, solve+loss+gradient "
+                                             f"(forward tangents, ForwardDiff's arithmetic) at the same p, C oracle with OpenMP over "
+                                             f"trajectories ({tc:.1f} s wall); a C restatement, not DifferentialEquations.jl (Julia absent)"}
         # RCCL prints a version banner through C stdio (block-buffered on a pipe): flush it first so
         # that the JSON line is the LAST line of stdout.
         C.CDLL(None).fflush(None)
