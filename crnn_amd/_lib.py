@@ -14,10 +14,11 @@ MAX_NR = 16
 ABI_VERSION = 2
 UNIQUE_ID_BYTES = 128
 
-PMAP_IDENTITY, PMAP_CASE1, PMAP_CASE2, PMAP_ROBER = 0, 1, 2, 3
+PMAP_IDENTITY, PMAP_CASE1, PMAP_CASE2, PMAP_ROBER, PMAP_HYCHEM = 0, 1, 2, 3, 4
+RHS_CRNN, RHS_HYCHEM = 0, 1
 LOSS_MAE, LOSS_MSE = 0, 1
 RET_SUCCESS, RET_MAXITERS, RET_DTMIN, RET_UNSTABLE = 0, 1, 2, 3
-PRESET_CASE1, PRESET_CASE2, PRESET_ROBER = 1, 2, 3
+PRESET_CASE1, PRESET_CASE2, PRESET_ROBER, PRESET_HYCHEM = 1, 2, 3, 4
 SOLVER_ROSENBROCK23, SOLVER_TSIT5 = 0, 1
 GRAD_AUTO, GRAD_FORWARD, GRAD_ADJOINT = 0, 1, 2
 
@@ -31,9 +32,10 @@ class Config(C.Structure):
         ("abi_version", C.c_int32), ("ns", C.c_int32), ("nr", C.c_int32), ("has_temp", C.c_int32),
         ("param_map", C.c_int32), ("n_save", C.c_int32), ("loss_kind", C.c_int32), ("clamp_pred", C.c_int32),
         ("maxiters", C.c_int32), ("errnorm_sens", C.c_int32), ("device", C.c_int32), ("cols_per_lane", C.c_int32),
-        ("solver", C.c_int32), ("grad_mode", C.c_int32), ("tape_steps", C.c_int32), ("reserved0", C.c_int32),
+        ("solver", C.c_int32), ("grad_mode", C.c_int32), ("tape_steps", C.c_int32), ("rhs_kind", C.c_int32),
         ("lb", C.c_double), ("ub", C.c_double), ("inv_R", C.c_double), ("t0", C.c_double),
         ("atol", C.c_double * MAX_N), ("rtol", C.c_double * MAX_N), ("rate_scale", C.c_double * MAX_N),
+        ("mw", C.c_double * MAX_N), ("gas_const", C.c_double),
         ("gamma", C.c_double), ("qmin", C.c_double), ("qmax", C.c_double), ("beta1", C.c_double),
         ("beta2", C.c_double), ("qsteady_min", C.c_double), ("qsteady_max", C.c_double),
         ("qoldinit", C.c_double), ("dtmin", C.c_double),
@@ -74,12 +76,15 @@ SYMBOLS = {
     "crnn_config_set_solver": (C.c_int32, [C.POINTER(Config), C.c_int32]),
     "crnn_n_params": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "crnn_n_theta": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
+    "crnn_config_n_theta": (C.c_int32, [C.POINTER(Config)]),
+    "crnn_config_n_theta": (C.c_int32, [C.POINTER(Config)]),
     "crnn_p2vec": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, _DP, _DP, _DP]),
     "crnn_ctx_create": (C.c_int32, [C.POINTER(Config), C.POINTER(_CTX)]),
     "crnn_ctx_destroy": (None, [_CTX]),
     "crnn_ctx_set_stream": (C.c_int32, [_CTX, C.c_void_p]),
     "crnn_ctx_set_data": (C.c_int32, [_CTX, _DP, _DP, _DP, _DP, _IP, C.c_int32, C.c_int64]),
     "crnn_ctx_set_data_device": (C.c_int32, [_CTX, C.c_void_p, C.c_void_p, _DP, _DP, _IP, C.c_int32, C.c_int64]),
+    "crnn_ctx_set_tables": (C.c_int32, [_CTX, _DP, _DP]),
     "crnn_solve": (C.c_int32, [_CTX, _DP, _DP, C.c_int32, C.c_int64, C.c_int64, C.c_int32, _DP, _DP, _DP, _IP, _IP,
                                C.POINTER(Stats)]),
     "crnn_loss_grad": (C.c_int32, [_CTX, _DP, C.c_int64, C.c_int64, C.c_int32, _DP, _DP, C.POINTER(Stats)]),

@@ -38,9 +38,14 @@ __all__ = ["NeuralODE", "ODEProblem", "Optimiser", "p2vec", "p2vec_jac", "crnn",
 # ---------------------------------------------------------------------------
 # p2vec (host, exact reference formulas) and its Jacobian
 # ---------------------------------------------------------------------------
+def _extra_rows(pmap):
+    """feature rows of w_in beyond the species rows: case2's -1/(R T); HyChem's -1/(R T) and log T"""
+    return 1 if pmap == L.PMAP_CASE2 else (2 if pmap == L.PMAP_HYCHEM else 0)
+
+
 def _shape(pmap, ns, nr):
-    has_temp = 1 if pmap == L.PMAP_CASE2 else 0
-    return has_temp, ns + has_temp, lib.crnn_n_theta(ns, nr, has_temp), lib.crnn_n_params(pmap, ns, nr)
+    extra = _extra_rows(pmap)
+    return extra, ns + extra, lib.crnn_n_theta(ns, nr, extra), lib.crnn_n_params(pmap, ns, nr)
 
 
 def p2vec_jac(pmap: int, ns: int, nr: int, p):
@@ -65,9 +70,8 @@ def split_theta(theta, ns, nr, has_temp):
 
 def p2vec(pmap: int, ns: int, nr: int, p):
     """(w_in, w_b, w_out) exactly as the reference's p2vec returns them."""
-    has_temp = 1 if pmap == L.PMAP_CASE2 else 0
     th, _ = p2vec_jac(pmap, ns, nr, p)
-    return split_theta(th, ns, nr, has_temp)
+    return split_theta(th, ns, nr, _extra_rows(pmap))
 
 
 def crnn(du, u, weights, *, lb, ub=np.inf, inv_R=None, rate_scale=None):
@@ -140,6 +144,7 @@ class ODEProblem:
     t0: float = 0.0
     device: int = 0
     cols_per_lane: int = 0
+    mw: object = None             # HyChem: molar masses (preset: the reference's l_MW)
     grad_mode: int = 0            # GRAD_AUTO (adjoint where available) / GRAD_FORWARD (tangents) / GRAD_ADJOINT
     tape_steps: int = 0           # adjoint tape capacity per trajectory, 0 = auto
 
@@ -166,6 +171,9 @@ class ODEProblem:
         if self.rate_scale is not None:
             for i in range(cfg.ns):
                 cfg.rate_scale[i] = float(self.rate_scale[i])
+        if self.mw is not None:
+            for i in range(cfg.ns):
+                cfg.mw[i] = float(self.mw[i])
         if self.maxiters is not None:
             cfg.maxiters = int(self.maxiters)
         if self.lb is not None:
@@ -214,7 +222,7 @@ class NeuralODE:
         self.ns, self.nr, self.has_temp = self.cfg.ns, self.cfg.nr, self.cfg.has_temp
         self.n = self.ns + self.has_temp
         self.pmap = self.cfg.param_map
-        self.n_theta = lib.crnn_n_theta(self.ns, self.nr, self.has_temp)
+        self.n_theta = lib.crnn_config_n_theta(C.byref(self.cfg))
         self.n_params = lib.crnn_n_params(self.pmap, self.ns, self.nr)
         self.tsteps = np.ascontiguousarray(prob.tsteps, np.float64)
         self.D = self.tsteps.size
@@ -253,6 +261,27 @@ class NeuralODE:
               self._ctx.h)
         self.B, self.n_obs = B, n_obs
         self._u0 = u0
+
+    def set_tables(self, Tlist, Plist):
+        """HyChem: temperature [K] / pressure [Pa] tables on tsteps per experiment, Tlist[B, D], Plist[B, D]
+        (crnn_pyrolysis_mass.jl:44-47; piecewise linear in t like itpT / itpP :103-104)."""
+        T = np.asfortranarray(Tlist, np.float64)
+        P = np.asfortranarray(Plist, np.float64)
+        if T.shape != (self.B, self.D) or P.shape != (self.B, self.D):
+            raise ValueError(f"tables must be [B, D] = [{self.B}, {self.D}]")
+        check(lib.crnn_ctx_set_tables(self._ctx.h, dptr(T), dptr(P)), self._ctx.h)
+
+    def predict_n_ode(self, p, sample=None):
+        """HyChem's predict_n_ode(p, sample) (crnn_pyrolysis_mass.jl:135-140) for every experiment: pred[B, ns, D]."""
+        th, _ = p2vec_jac(self.pmap, self.ns, self.nr, p)
+        pred, _, _, ret, _ = self._solve(self._ctx, self.B, th, None, 0, self.B, sample, True)
+        if np.any(ret != 0):
+            print("ode solver failed")
+        return pred if sample is None else pred[:, :, :int(sample)]
+
+    def loss_n_ode(self, p, sample=None):
+        """HyChem's loss_n_ode(p, sample) (:143-147), per experiment."""
+        return self.losses(p, sample=sample)
 
     def _solve(self, ctx, B, theta, dtheta, first, count, sample, want_pred, want_loss=True):
         n_dir = 0 if dtheta is None else dtheta.shape[1]

@@ -15,6 +15,7 @@
 #include "p2vec.hpp"
 #include "ros23_kernel.hpp"
 #include "ros23_adj_kernel.hpp"
+#include "hychem_kernel.hpp"
 #include "tsit5_kernel.hpp"
 #include "cathode_kernel.hpp"
 
@@ -77,6 +78,12 @@ const AdjEntry kAdjKernels[] = {KADJ(6, 3, 1, 0), KADJ(3, 6, 0, 1), KADJ(5, 4, 0
 struct Ctx {
     crnn_config cfg{};
     int n = 0, n_theta = 0, n_params = 0;
+    int nfx = 0;                    // extra feature rows of w_in: has_temp (CRNN) or 2 (HyChem)
+    bool hychem = false;
+    double *d_tabs = nullptr;       // HyChem T/P tables, trajectory-major [B][2][D]
+    int64_t tabs_B = 0;
+    double *d_gacc = nullptr;       // HyChem gradient accumulators [ceil(count/64)][n_theta][64]
+    size_t gacc_cap = 0;
     bool use_scale = false;
     std::string err;
     hipStream_t stream = nullptr;
@@ -245,7 +252,11 @@ int32_t upload_consts(Ctx *c) {
     for (int i = 0; i < CRNN_MAX_N; ++i) {
         k.atol[i] = c->cfg.atol[i]; k.rtol[i] = c->cfg.rtol[i]; k.scale[i] = c->cfg.rate_scale[i];
         k.inv_yscale[i] = c->inv_yscale[i]; k.drow[i] = (double)c->drow[i];
+        k.mw[i] = c->cfg.mw[i] > 0 ? c->cfg.mw[i] : 1.0;
+        k.imw[i] = 1.0 / k.mw[i];
+        k.gsc[i] = k.mw[i] * c->cfg.rate_scale[i];
     }
+    k.Ru = c->cfg.gas_const;
     HIP_TRY(c, hipMemcpyAsync(c->d_kc, &k, sizeof(k), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // k is a stack object
     c->kc_dirty = false;
@@ -360,12 +371,98 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
     return ovf ? 1 : 0;
 }
 
+// HyChem: one kernel family (hychem_kernel.hpp).  P > 0: discrete-adjoint gradient in theta space (HBM accumulators)
+// + chain rule; P == 0: primal + loss.  A tape overflow is an error here (no forward-tangent fallback for 211 parameters).
+int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int P, int64_t first, int64_t count,
+                      int n_save_active, bool want_pred) {
+    if (c->cfg.ns != 9 || c->cfg.nr != 10) return fail(c, "crnn_solve: the HyChem kernel is instantiated for ns = 9, nr = 10");
+    if (!c->d_tabs || c->tabs_B != c->B) return fail(c, "crnn_solve: HyChem needs T/P tables (crnn_ctx_set_tables after crnn_ctx_set_data)");
+    const int nth = c->n_theta;
+    const int npart_th = nth + crnn::kExtra, npart = P + crnn::kExtra;
+    using KFn = void (*)(const crnn::SolveParams, const double *, const crnn::HyParams);
+    KFn fn = P > 0 ? (KFn)crnn::hychem_kernel<9, 10, true, kBlock> : (KFn)crnn::hychem_kernel<9, 10, false, kBlock>;
+    int occ = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, kBlock, 0));
+    if (occ < 1) occ = 1;
+    const int64_t need_blocks = (count + kBlock - 1) / kBlock;
+    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(need_blocks, (int64_t)c->num_cu * occ));
+    const size_t lanes = (size_t)nblk * kBlock;
+    const size_t recw = (size_t)c->cfg.ns + 2;
+    int64_t cap = c->cfg.tape_steps;
+    if (cap <= 0) {
+        if (c->tape_budget == 0) {
+            size_t fr = 0, tot = 0;
+            HIP_TRY(c, hipMemGetInfo(&fr, &tot));
+            c->tape_budget = std::min<size_t>(fr / 4, (size_t)16 << 30);
+        }
+        cap = std::max<int64_t>((int64_t)(c->tape_budget / (lanes * recw * sizeof(double))), 64);
+    }
+    cap = std::min<int64_t>(cap, c->cfg.maxiters);
+    if (c->tape_doubles < lanes * (size_t)cap * recw && ensure(c, &c->d_tape, &c->tape_doubles, lanes * (size_t)cap * recw)) return -1;
+    const int rblk = (int)((count + 255) / 256);
+    if (ensure(c, &c->d_partials, &c->partials_cap, (size_t)rblk * std::max(npart_th, npart))) return -1;
+    const size_t gacc_need = (size_t)((count + 63) / 64) * nth * 64;
+    if (P > 0 && ensure(c, &c->d_gacc, &c->gacc_cap, gacc_need)) return -1;
+    if (c->npart_max < npart) {
+        if (c->d_red) HIP_TRY(c, hipFree(c->d_red));
+        c->d_red = nullptr;
+        HIP_TRY(c, hipMalloc((void **)&c->d_red, sizeof(double) * npart));
+        c->npart_max = npart;
+    }
+    if (want_pred && ensure(c, &c->d_pred, &c->pred_cap, (size_t)c->cfg.n_save * c->n * c->B)) return -1;
+    crnn::SolveParams prm{};
+    fill_params(c, prm, P, first, count, n_save_active, want_pred);
+    crnn::HyParams hp{};
+    hp.tabs = c->d_tabs; hp.tape = c->d_tape; hp.tape_cap = (int32_t)cap; hp.overflow = c->d_overflow; hp.gacc = c->d_gacc;
+    hp.n_save_total = c->cfg.n_save; hp.inv_R = c->cfg.inv_R;
+    if (upload_consts(c)) return -1;
+    if (!c->flags_zeroed) {
+        HIP_TRY(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_overflow, 0, sizeof(unsigned int), c->stream));
+    }
+    c->flags_zeroed = false;
+    if (P > 0) HIP_TRY(c, hipMemsetAsync(c->d_gacc, 0, sizeof(double) * gacc_need, c->stream));
+    c->ev0 = c->ring0[c->n_launch % Ctx::kRing];
+    c->ev1 = c->ring1[c->n_launch % Ctx::kRing];
+    ++c->n_launch;
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    hipLaunchKernelGGL(fn, dim3(nblk), dim3(kBlock), 0, c->stream, prm, d_theta, hp);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    if (P > 0) {
+        hipLaunchKernelGGL(crnn::reduce_gacc_kernel, dim3(rblk), dim3(256), 0, c->stream, c->d_gacc, nth, c->n_obs, c->d_loss,
+                           c->d_ret, c->d_nsaved, c->d_nacc, c->d_nrej, first, count, c->d_partials);
+        HIP_TRY(c, hipGetLastError());
+        hipLaunchKernelGGL(crnn::reduce_project_kernel, dim3(1), dim3(256), 0, c->stream, c->d_partials, rblk, d_dtheta, nth, P,
+                           c->d_red_theta, c->d_red);
+        HIP_TRY(c, hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(crnn::reduce_traj_kernel, dim3(rblk), dim3(256), 0, c->stream, c->d_gtraj, 0, c->d_loss, c->d_ret,
+                           c->d_nacc, c->d_nrej, first, count, 256, c->d_partials);
+        HIP_TRY(c, hipGetLastError());
+        hipLaunchKernelGGL(crnn::reduce_partials_kernel, dim3(npart), dim3(256), 0, c->stream, c->d_partials, rblk, npart, c->d_red);
+        HIP_TRY(c, hipGetLastError());
+    }
+    unsigned int ovf = 0;
+    HIP_TRY(c, hipMemcpyAsync(&ovf, c->d_overflow, sizeof(ovf), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->last_npart = npart;
+    c->last_P = P;
+    if (ovf) return fail(c, "crnn_solve: a trajectory accepted more steps than the adjoint tape holds; raise crnn_config.tape_steps");
+    return 0;
+}
+
 // Launch solve (+ fixed-order reduction into c->d_red).  theta/dtheta already on device.
 int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int P, int64_t first, int64_t count,
                      int n_save_active, bool want_pred, bool want_percase) {
     if (c->B <= 0) return fail(c, "crnn_solve: no ensemble uploaded (crnn_ctx_set_data)");
     if (first < 0 || count <= 0 || first + count > c->B) return fail(c, "crnn_solve: [first, first+count) outside the ensemble");
     if (n_save_active <= 0 || n_save_active > c->cfg.n_save) return fail(c, "crnn_solve: n_save_active out of range");
+    if (c->hychem) {
+        if (P > 0 && c->cfg.grad_mode == CRNN_GRAD_FORWARD)
+            return fail(c, "crnn_solve: HyChem gradients exist as discrete adjoint only (grad_mode AUTO or ADJOINT)");
+        return launch_hychem(c, d_theta, d_dtheta, P, first, count, n_save_active, want_pred);
+    }
     if (P > 0 && c->cfg.grad_mode != CRNN_GRAD_FORWARD) {
         const AdjEntry *ka = find_adjoint(c);
         if (ka) {
@@ -533,6 +630,17 @@ int32_t crnn_config_preset(crnn_config *cfg, int32_t preset) {
         cfg->lb = 1e-8; cfg->ub = INFINITY;
         cfg->atol[0] = 1e-6; cfg->atol[1] = 1e-8; cfg->atol[2] = 1e-6;
         break;
+    case CRNN_PRESET_HYCHEM: {  // HyChem/crnn_pyrolysis_mass.jl:15-30,57-58,106-108
+        cfg->ns = 9; cfg->nr = 10; cfg->has_temp = 0; cfg->param_map = CRNN_PMAP_HYCHEM; cfg->rhs_kind = CRNN_RHS_HYCHEM;
+        cfg->n_save = 40; cfg->clamp_pred = 0; cfg->maxiters = 10000;
+        cfg->lb = 1e-8; cfg->ub = 10.0;
+        for (int i = 0; i < CRNN_MAX_N; ++i) { cfg->atol[i] = 1e-8; cfg->rtol[i] = 1e-3; }
+        cfg->inv_R = (double)(-1.0f / 1.98720425864083e-3f);   // R is a Float32 literal; -1/R is formed in Float32 (:106,128)
+        cfg->gas_const = 8.31446261815324e3;
+        const double mw[9] = {136.238, 2.016, 16.043, 26.038, 28.054, 28.014, 56.108, 1.008, 15.035};
+        for (int i = 0; i < 9; ++i) cfg->mw[i] = mw[i];
+        break;
+    }
     default:
         return fail(nullptr, "crnn_config_preset: unknown preset");
     }
@@ -558,20 +666,24 @@ int32_t crnn_opt_preset(crnn_opt_config *o, int32_t preset) {
         o->eta = 0.005; o->wd = 1e-6; o->use_expdecay = 1; o->ed_eta0 = 5e-3; o->ed_decay = 0.5;
         o->decay_step = 500 * 20; o->ed_clip = 1e-4; break;
     case CRNN_PRESET_ROBER: o->eta = 0.005; o->wd = 1e-6; o->grad_clip_norm = 10.0; break;         // rober_crnn.jl:19,29
+    case CRNN_PRESET_HYCHEM: o->eta = 0.005; o->wd = 1e-6; o->grad_clip_norm = 10.0; break;        // crnn_pyrolysis_mass.jl:20,24
     default: return fail(nullptr, "crnn_opt_preset: unknown preset");
     }
     return 0;
 }
 
-int32_t crnn_n_params(int32_t pmap, int32_t ns, int32_t nr) {
-    return crnn::n_params_of(pmap, ns, nr, pmap == CRNN_PMAP_CASE2 ? 1 : 0);
+static int extra_rows_of_pmap(int32_t pmap) { return pmap == CRNN_PMAP_CASE2 ? 1 : (pmap == CRNN_PMAP_HYCHEM ? 2 : 0); }
+int32_t crnn_n_params(int32_t pmap, int32_t ns, int32_t nr) { return crnn::n_params_of(pmap, ns, nr, extra_rows_of_pmap(pmap)); }
+int32_t crnn_config_n_theta(const crnn_config *cfg) {
+    if (!cfg) return fail(nullptr, "crnn_config_n_theta: null cfg");
+    return crnn::n_theta_of(cfg->ns, cfg->nr, cfg->rhs_kind == CRNN_RHS_HYCHEM ? 2 : cfg->has_temp);
 }
 int32_t crnn_n_theta(int32_t ns, int32_t nr, int32_t has_temp) { return crnn::n_theta_of(ns, nr, has_temp); }
 
 int32_t crnn_p2vec(int32_t pmap, int32_t ns, int32_t nr, const double *p, double *theta, double *dtheta) {
     if (!p || !theta) return fail(nullptr, "crnn_p2vec: null pointer");
     if (pmap == CRNN_PMAP_IDENTITY) return fail(nullptr, "crnn_p2vec: identity map needs no p2vec");
-    int has_temp = pmap == CRNN_PMAP_CASE2 ? 1 : 0;
+    int has_temp = extra_rows_of_pmap(pmap);
     int nth = crnn::n_theta_of(ns, nr, has_temp), P = crnn::n_params_of(pmap, ns, nr, has_temp);
     if (P < 0) return fail(nullptr, "crnn_p2vec: unknown param_map");
     if (dtheta) std::memset(dtheta, 0, sizeof(double) * (size_t)nth * P);
@@ -588,20 +700,27 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
     if (cfg->errnorm_sens != 0) return fail(nullptr, "crnn_ctx_create: errnorm_sens=1 is not implemented on device");
     if (cfg->solver != CRNN_SOLVER_ROSENBROCK23 && cfg->solver != CRNN_SOLVER_TSIT5)
         return fail(nullptr, "crnn_ctx_create: unknown solver");
+    if (cfg->rhs_kind != CRNN_RHS_CRNN && cfg->rhs_kind != CRNN_RHS_HYCHEM) return fail(nullptr, "crnn_ctx_create: unknown rhs_kind");
     if (cfg->grad_mode < CRNN_GRAD_AUTO || cfg->grad_mode > CRNN_GRAD_ADJOINT || cfg->tape_steps < 0)
         return fail(nullptr, "crnn_ctx_create: bad grad_mode / tape_steps");
     if (cfg->n_save < 1 || cfg->n_save > crnn::kMaxSave) return fail(nullptr, "crnn_ctx_create: n_save must be in [1, 256]");
     Ctx *c = new Ctx();
     c->cfg = *cfg;
     c->n = cfg->ns + cfg->has_temp;
-    c->n_theta = crnn::n_theta_of(cfg->ns, cfg->nr, cfg->has_temp);
-    c->n_params = crnn::n_params_of(cfg->param_map, cfg->ns, cfg->nr, cfg->has_temp);
+    c->hychem = cfg->rhs_kind == CRNN_RHS_HYCHEM;
+    c->nfx = c->hychem ? 2 : cfg->has_temp;
+    c->n_theta = crnn::n_theta_of(cfg->ns, cfg->nr, c->nfx);
+    c->n_params = crnn::n_params_of(cfg->param_map, cfg->ns, cfg->nr, c->nfx);
+    if (c->hychem && (cfg->has_temp != 0 || cfg->solver != CRNN_SOLVER_ROSENBROCK23 || !(cfg->gas_const > 0))) {
+        delete c;
+        return fail(nullptr, "crnn_ctx_create: HyChem needs has_temp = 0, Rosenbrock23 and gas_const > 0");
+    }
     if (c->n_params < 0) { delete c; return fail(nullptr, "crnn_ctx_create: unknown param_map"); }
     c->use_scale = false;
     for (int i = 0; i < cfg->ns; ++i) if (cfg->rate_scale[i] != 1.0) c->use_scale = true;
     // robertson-shaped problems always take the scaled kernel (one instantiation per shape)
-    if (!find_primal(c)) { c->use_scale = !c->use_scale; if (!find_primal(c)) c->use_scale = !c->use_scale; }
-    if (!find_primal(c)) {
+    if (!c->hychem && !find_primal(c)) { c->use_scale = !c->use_scale; if (!find_primal(c)) c->use_scale = !c->use_scale; }
+    if (!c->hychem && !find_primal(c)) {
         delete c;
         return fail(nullptr, "crnn_ctx_create: no gfx950 kernel instantiated for this (solver, ns, nr, has_temp)");
     }
@@ -649,7 +768,7 @@ void crnn_ctx_destroy(crnn_ctx *ctx) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->own_u0 && c->d_u0) (void)hipFree(c->d_u0);
     if (c->own_data && c->d_data) (void)hipFree(c->d_data);
-    void *ptrs[] = {c->d_tape, c->d_overflow, c->d_red_theta, c->d_queue, c->d_nacc, c->d_nrej, c->d_gtraj, c->d_kc, c->d_tsave, c->d_pred, c->d_loss, c->d_ret, c->d_nsaved, c->d_theta, c->d_dtheta,
+    void *ptrs[] = {c->d_tabs, c->d_gacc, c->d_tape, c->d_overflow, c->d_red_theta, c->d_queue, c->d_nacc, c->d_nrej, c->d_gtraj, c->d_kc, c->d_tsave, c->d_pred, c->d_loss, c->d_ret, c->d_nsaved, c->d_theta, c->d_dtheta,
                     c->d_partials, c->d_red, c->d_p, c->d_p_eval, c->d_opt, c->d_comm_buf};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < Ctx::kRing; ++i) {
@@ -765,6 +884,32 @@ int32_t crnn_ctx_set_data_device(crnn_ctx *ctx, const void *d_u0, const void *d_
     return transpose_into(c, (const double *)d_data, B);
 }
 
+int32_t crnn_ctx_set_tables(crnn_ctx *ctx, const double *T, const double *P) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return fail(nullptr, "null ctx");
+    if (!c->hychem) return fail(c, "crnn_ctx_set_tables: only the HyChem right-hand side takes T/P tables");
+    if (!T || !P) return fail(c, "crnn_ctx_set_tables: null pointer");
+    if (c->B <= 0) return fail(c, "crnn_ctx_set_tables: call crnn_ctx_set_data first");
+    const int D = c->cfg.n_save;
+    const int64_t B = c->B;
+    std::vector<double> h((size_t)B * 2 * D);
+    for (int64_t b = 0; b < B; ++b)
+        for (int j = 0; j < D; ++j) {
+            const double t_ = T[(size_t)j * B + b], p_ = P[(size_t)j * B + b];
+            if (!(t_ > 0) || !(p_ > 0)) return fail(c, "crnn_ctx_set_tables: temperatures and pressures must be positive");
+            h[((size_t)b * 2) * D + j] = t_;
+            h[((size_t)b * 2 + 1) * D + j] = p_;
+        }
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_tabs) HIP_TRY(c, hipFree(c->d_tabs));
+    c->d_tabs = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&c->d_tabs, sizeof(double) * h.size()));
+    HIP_TRY(c, hipMemcpy(c->d_tabs, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+    c->tabs_B = B;
+    return 0;
+}
+
 int32_t crnn_solve(crnn_ctx *ctx, const double *theta, const double *dtheta, int32_t n_dir, int64_t first, int64_t count,
                    int32_t n_save_active, double *pred, double *loss, double *grad, int32_t *retcode, int32_t *n_saved,
                    crnn_stats *stats) {
@@ -808,7 +953,7 @@ int32_t crnn_loss_grad(crnn_ctx *ctx, const double *p, int64_t first, int64_t co
     c->theta_current = false;
     HIP_TRY(c, hipMemcpyAsync(c->d_p_eval, p, sizeof(double) * c->n_params, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(p2vec_kernel, dim3(1), dim3(256), 0, c->stream, c->cfg.param_map, c->cfg.ns, c->cfg.nr,
-                       c->cfg.has_temp, c->d_p_eval, c->d_theta, c->d_dtheta, c->n_theta, c->n_params);
+                       c->nfx, c->d_p_eval, c->d_theta, c->d_dtheta, c->n_theta, c->n_params);
     HIP_TRY(c, hipGetLastError());
     if (launch_solve(c, c->d_theta, c->d_dtheta, P, first, count, n_save_active, false, false)) return -1;
     std::vector<double> red(c->last_npart);
@@ -868,7 +1013,7 @@ int32_t crnn_train_step_begin(crnn_ctx *ctx, int64_t first, int64_t count, int32
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     if (!c->theta_current) {
         hipLaunchKernelGGL(p2vec_kernel, dim3(1), dim3(256), 0, c->stream, c->cfg.param_map, c->cfg.ns, c->cfg.nr,
-                           c->cfg.has_temp, c->d_p, c->d_theta, c->d_dtheta, c->n_theta, c->n_params);
+                           c->nfx, c->d_p, c->d_theta, c->d_dtheta, c->n_theta, c->n_params);
         HIP_TRY(c, hipGetLastError());
     }
     c->theta_current = false;   // consumed: anything else that touches d_theta / d_p must not find a stale flag
@@ -880,7 +1025,7 @@ int32_t crnn_train_step_end(crnn_ctx *ctx, double *loss_mean) {
     if (!c) return fail(nullptr, "null ctx");
     if (!c->train_ready || c->last_npart == 0) return fail(c, "crnn_train_step_end: no step in flight");
     hipLaunchKernelGGL(opt_kernel, dim3(1), dim3(256), 0, c->stream, c->opt, c->n_params, c->last_npart, c->d_p, c->d_red,
-                       c->d_opt, c->cfg.param_map, c->cfg.ns, c->cfg.nr, c->cfg.has_temp, c->d_theta, c->d_dtheta, c->n_theta,
+                       c->d_opt, c->cfg.param_map, c->cfg.ns, c->cfg.nr, c->nfx, c->d_theta, c->d_dtheta, c->n_theta,
                        c->d_queue, c->d_overflow);
     HIP_TRY(c, hipGetLastError());
     c->theta_current = true;

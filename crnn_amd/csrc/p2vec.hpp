@@ -6,6 +6,7 @@
 //                                    w_in = clamp(-w_out, 0, 2.5)
 //   CASE2  case2/case2.jl:91-99      slope = p[end]*100, w_b = p[1:nr]*slope, Ea = |p[..]*slope|,
 //                                    w_in = [clamp(-w_out, 0, 4); Ea']
+//   HYCHEM HyChem/crnn_pyrolysis_mass.jl:78-90 (see below)
 //   ROBER  rober_crnn.jl:85-96       slope = |p[end]|, w_b = p[1:nr]*10*slope,
 //                                    w_out = -w_in_raw * 10^w_out_raw, w_in = clamp(w_in_raw, 0, 2.5)
 //
@@ -23,8 +24,9 @@
 
 namespace crnn {
 
-enum { PMAP_IDENTITY = 0, PMAP_CASE1 = 1, PMAP_CASE2 = 2, PMAP_ROBER = 3 };
+enum { PMAP_IDENTITY = 0, PMAP_CASE1 = 1, PMAP_CASE2 = 2, PMAP_ROBER = 3, PMAP_HYCHEM = 4 };
 
+// has_temp = number of extra feature rows of w_in: 0, 1 (case2: -1/(R T)) or 2 (HyChem: -1/(R T), log T)
 CRNN_HD inline int n_theta_of(int ns, int nr, int has_temp) { return nr * (ns + has_temp + 1 + ns); }
 
 CRNN_HD inline int n_params_of(int pmap, int ns, int nr, int has_temp) {
@@ -33,6 +35,7 @@ CRNN_HD inline int n_params_of(int pmap, int ns, int nr, int has_temp) {
     case PMAP_CASE1: return nr * (ns + 1);
     case PMAP_CASE2: return nr * (ns + 2) + 1;
     case PMAP_ROBER: return nr * (2 * ns + 1) + 1;
+    case PMAP_HYCHEM: return nr * (2 * ns + 3) + 1;
     default: return -1;
     }
 }
@@ -95,6 +98,34 @@ CRNN_HD inline int p2vec_eval(int pmap, int ns, int nr, int has_temp, const doub
                 const int ko = nr + i + ns * j;
                 const int ki = nr * (ns + 1) + i + ns * j;
                 const double wi_raw = p[ki], wo_raw = p[ko];
+                const double pw = pow(10.0, wo_raw);
+                th[o_out + i + ns * j] = -wi_raw * pw;
+                th[o_in + i + n * j] = clampd(wi_raw, 0.0, 2.5);
+                if (dth) {
+                    DTH(o_out + i + ns * j, ki) = -pw;
+                    DTH(o_out + i + ns * j, ko) = -wi_raw * pw * ln10;
+                    DTH(o_in + i + n * j, ki) = dclampd(wi_raw, 0.0, 2.5);
+                }
+            }
+        }
+    } else if (pmap == PMAP_HYCHEM) {
+        // HyChem/crnn_pyrolysis_mass.jl:78-90: slope = p[end]*10; w_b = p[1:nr]*slope; w_in_b = p[nr+1:2nr];
+        // w_in_Ea = p[2nr+1:3nr]*slope; w_out = -w_in_raw .* 10^w_out_raw; w_in = [clamp(w_in_raw,0,2.5); Ea'; b']
+        if (has_temp != 2) return -1;
+        const double slope = p[P - 1] * 10.0;
+        const double ln10 = 2.302585092994045684;
+        for (int j = 0; j < nr; ++j) {
+            th[o_b + j] = p[j] * slope;
+            th[o_in + (ns + 1) + n * j] = p[nr + j];
+            th[o_in + ns + n * j] = p[2 * nr + j] * slope;
+            if (dth) {
+                DTH(o_b + j, j) = slope; DTH(o_b + j, P - 1) = p[j] * 10.0;
+                DTH(o_in + (ns + 1) + n * j, nr + j) = 1.0;
+                DTH(o_in + ns + n * j, 2 * nr + j) = slope; DTH(o_in + ns + n * j, P - 1) = p[2 * nr + j] * 10.0;
+            }
+            for (int i = 0; i < ns; ++i) {
+                const int ko = 3 * nr + i + ns * j, ki = nr * (ns + 3) + i + ns * j;
+                const double wo_raw = p[ko], wi_raw = p[ki];
                 const double pw = pow(10.0, wo_raw);
                 th[o_out + i + ns * j] = -wi_raw * pw;
                 th[o_in + i + n * j] = clampd(wi_raw, 0.0, 2.5);

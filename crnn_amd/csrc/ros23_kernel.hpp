@@ -54,6 +54,10 @@ struct KConst {
     double gamma, qmin, qmax, beta1, beta2, qsteady_min, qsteady_max, qoldinit, dtmin;
     double atol[kMaxN], rtol[kMaxN], scale[kMaxN], inv_yscale[kMaxN];
     double drow[kMaxN];  // species -> row of data (as double), -1 if unobserved
+    double mw[kMaxN];    // HyChem: molar masses, their reciprocals, mw .* dydt_scale; Ru: gas constant [J/(kmol K)]
+    double imw[kMaxN];
+    double gsc[kMaxN];
+    double Ru;
 };
 constexpr int kNConst = sizeof(KConst) / sizeof(double);
 
@@ -235,15 +239,14 @@ struct Rec {
 // materialised once and serves all NS species; at one wavefront per SIMD every instruction, scalar ones included,
 // costs an issue slot.  c = min(max(u, lb), ub): a NaN state does not reach here unnoticed -- the stepper rejects
 // non-finite stage results (retcode Unstable) before they are used.
-template <int NS>
-__device__ __forceinline__ void features(const double (&u)[NS], double lb, double ub, double (&x)[NS], double (&g)[NS]) {
-    double m[NS], f[NS], r[NS], s[NS], z[NS], w[NS], t1[NS], t2[NS], dk[NS];
+// x_i = log(c_i) for N finite positive arguments at once (fdlibm e_log.c scheme, < 1 ulp), element-innermost.
+template <int N>
+__device__ __forceinline__ void flog_vec(const double (&c)[N], double (&x)[N]) {
+    double m[N], f[N], r[N], s[N], z[N], w[N], t1[N], t2[N], dk[N];
 #pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        const double c = fmin(fmax(u[i], lb), ub);
-        g[i] = (c == u[i]) ? frcp(c) : 0.0;
-        double mm = __builtin_amdgcn_frexp_mant(c);      // [0.5, 1)
-        int k = __builtin_amdgcn_frexp_exp(c);
+    for (int i = 0; i < N; ++i) {
+        double mm = __builtin_amdgcn_frexp_mant(c[i]);   // [0.5, 1)
+        int k = __builtin_amdgcn_frexp_exp(c[i]);
         const bool lo = mm < 0.70710678118654752440;
         mm = lo ? mm + mm : mm;                          // [sqrt(1/2), sqrt 2)
         k = lo ? k - 1 : k;
@@ -251,27 +254,38 @@ __device__ __forceinline__ void features(const double (&u)[NS], double lb, doubl
         dk[i] = (double)k;
     }
 #pragma unroll
-    for (int i = 0; i < NS; ++i) { f[i] = m[i] - 1.0; r[i] = frcp(2.0 + f[i]); }
+    for (int i = 0; i < N; ++i) { f[i] = m[i] - 1.0; r[i] = frcp(2.0 + f[i]); }
 #pragma unroll
-    for (int i = 0; i < NS; ++i) { s[i] = f[i] * r[i]; s[i] = fma(fma(-(2.0 + f[i]), s[i], f[i]), r[i], s[i]); }
+    for (int i = 0; i < N; ++i) { s[i] = f[i] * r[i]; s[i] = fma(fma(-(2.0 + f[i]), s[i], f[i]), r[i], s[i]); }
 #pragma unroll
-    for (int i = 0; i < NS; ++i) { z[i] = s[i] * s[i]; w[i] = z[i] * z[i]; }
+    for (int i = 0; i < N; ++i) { z[i] = s[i] * s[i]; w[i] = z[i] * z[i]; }
 #pragma unroll
-    for (int i = 0; i < NS; ++i) t1[i] = fma(w[i], 1.531383769920937332e-01, 2.222219843214978396e-01);
+    for (int i = 0; i < N; ++i) t1[i] = fma(w[i], 1.531383769920937332e-01, 2.222219843214978396e-01);
 #pragma unroll
-    for (int i = 0; i < NS; ++i) t1[i] = fma(w[i], t1[i], 3.999999999940941908e-01);
+    for (int i = 0; i < N; ++i) t1[i] = fma(w[i], t1[i], 3.999999999940941908e-01);
 #pragma unroll
-    for (int i = 0; i < NS; ++i) t2[i] = fma(w[i], 1.479819860511658591e-01, 1.818357216161805012e-01);
+    for (int i = 0; i < N; ++i) t2[i] = fma(w[i], 1.479819860511658591e-01, 1.818357216161805012e-01);
 #pragma unroll
-    for (int i = 0; i < NS; ++i) t2[i] = fma(w[i], t2[i], 2.857142874366239149e-01);
+    for (int i = 0; i < N; ++i) t2[i] = fma(w[i], t2[i], 2.857142874366239149e-01);
 #pragma unroll
-    for (int i = 0; i < NS; ++i) t2[i] = fma(w[i], t2[i], 6.666666666666735130e-01);
+    for (int i = 0; i < N; ++i) t2[i] = fma(w[i], t2[i], 6.666666666666735130e-01);
 #pragma unroll
-    for (int i = 0; i < NS; ++i) {
+    for (int i = 0; i < N; ++i) {
         const double R = fma(z[i], t2[i], w[i] * t1[i]);
         const double hfsq = 0.5 * f[i] * f[i];
         x[i] = fma(dk[i], 6.93147180369123816490e-01, -((hfsq - fma(s[i], hfsq + R, dk[i] * 1.90821492927058770002e-10)) - f[i]));
     }
+}
+
+template <int NS>
+__device__ __forceinline__ void features(const double (&u)[NS], double lb, double ub, double (&x)[NS], double (&g)[NS]) {
+    double c[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        c[i] = fmin(fmax(u[i], lb), ub);
+        g[i] = (c[i] == u[i]) ? frcp(c[i]) : 0.0;
+    }
+    flog_vec<NS>(c, x);
 }
 
 // e^z for NR arguments at once, reaction-innermost so that each constant is materialised once (see features()).

@@ -50,7 +50,14 @@ enum {
     CRNN_PMAP_IDENTITY = 0, /* p IS theta */
     CRNN_PMAP_CASE1 = 1,    /* case1/case1.jl:70-78 */
     CRNN_PMAP_CASE2 = 2,    /* case2/case2.jl:91-99 */
-    CRNN_PMAP_ROBER = 3     /* robertson/rober_crnn.jl:85-96 */
+    CRNN_PMAP_ROBER = 3,    /* robertson/rober_crnn.jl:85-96 */
+    CRNN_PMAP_HYCHEM = 4    /* HyChem/crnn_pyrolysis_mass.jl:78-90 */
+};
+/* right-hand-side families */
+enum {
+    CRNN_RHS_CRNN = 0,      /* du = scale .* (w_out exp(w_in' [log clamp(u); inv_R/T] + w_b))  (case1, case2, robertson) */
+    CRNN_RHS_HYCHEM = 1     /* HyChem/crnn_pyrolysis_mass.jl:121-131: mass fractions, density coupling, T(t)/P(t) tables;
+                               feature rows = [log clamp(C) (ns); -1/(R T); log T], w_in is (ns+2) x nr */
 };
 enum { CRNN_LOSS_MAE = 0, CRNN_LOSS_MSE = 1 };
 /* per-trajectory return codes (DiffEq retcodes Success / MaxIters / DtLessThanMin / Unstable) */
@@ -67,7 +74,7 @@ enum { CRNN_GRAD_AUTO = 0, CRNN_GRAD_FORWARD = 1, CRNN_GRAD_ADJOINT = 2 };
  * code never reaches the caller */
 enum { CRNN_RET_TAPE_OVERFLOW = 5 };
 /* presets for crnn_config_preset */
-enum { CRNN_PRESET_CASE1 = 1, CRNN_PRESET_CASE2 = 2, CRNN_PRESET_ROBER = 3 };
+enum { CRNN_PRESET_CASE1 = 1, CRNN_PRESET_CASE2 = 2, CRNN_PRESET_ROBER = 3, CRNN_PRESET_HYCHEM = 4 };
 
 /* Problem descriptor: what `ODEProblem(crnn, u0, tspan; saveat, atol, rtol)` plus
  * the script-top constants carry in the reference (case2/case2.jl:15-35,113,120-121). */
@@ -86,13 +93,15 @@ typedef struct crnn_config {
     int32_t solver;               /* CRNN_SOLVER_*; set it with crnn_config_set_solver (also sets the controller) */
     int32_t grad_mode;            /* CRNN_GRAD_* */
     int32_t tape_steps;           /* adjoint: accepted steps recordable per trajectory; 0 = auto (min(maxiters, memory budget)) */
-    int32_t reserved0;
+    int32_t rhs_kind;             /* CRNN_RHS_* */
     double lb, ub;                /* log(clamp(u, lb, ub)); ub may be +inf */
     double inv_R;                 /* -1/R (case2/case2.jl:113); unused when has_temp = 0 */
     double t0;                    /* tspan[1] */
     double atol[CRNN_MAX_N];      /* per state (robertson uses a vector, rober_crnn.jl:34) */
     double rtol[CRNN_MAX_N];
-    double rate_scale[CRNN_MAX_N];/* dydt_scale (rober_crnn.jl:82,115); 1 otherwise */
+    double rate_scale[CRNN_MAX_N];/* dydt_scale (rober_crnn.jl:82,115; crnn_pyrolysis_mass.jl:120); 1 otherwise */
+    double mw[CRNN_MAX_N];        /* HyChem: molar masses l_MW (crnn_pyrolysis_mass.jl:58) */
+    double gas_const;             /* HyChem: 8.31446261815324e3 J/(kmol K) (:108) */
     /* PI step-size controller (OrdinaryDiffEq defaults for Rosenbrock23) */
     double gamma, qmin, qmax, beta1, beta2, qsteady_min, qsteady_max, qoldinit, dtmin;
 } crnn_config;
@@ -134,6 +143,9 @@ int32_t crnn_config_set_solver(crnn_config *cfg, int32_t solver);
 
 /* ---- host-side parameter maps: p2vec and its Jacobian ------------------- */
 int32_t crnn_n_params(int32_t param_map, int32_t ns, int32_t nr);  /* length of p */
+/* length of theta for a config: nr * (ns + extra + 1 + ns), extra = has_temp (CRNN) or 2 (HyChem's -1/(RT), log T rows);
+ * crnn_n_theta(ns, nr, extra) takes that number of extra feature rows as its third argument */
+int32_t crnn_config_n_theta(const crnn_config *cfg);
 int32_t crnn_n_theta(int32_t ns, int32_t nr, int32_t has_temp);
 /* theta[n_theta]; dtheta[n_theta x n_params] column-major, may be NULL.
  * Replaces p2vec (case2/case2.jl:91-99 etc.) and the part of
@@ -155,6 +167,10 @@ int32_t crnn_ctx_set_data(crnn_ctx *ctx, const double *u0, const double *data,
 int32_t crnn_ctx_set_data_device(crnn_ctx *ctx, const void *d_u0, const void *d_data,
                                  const double *tsteps, const double *yscale,
                                  const int32_t *i_obs, int32_t n_obs, int64_t B);
+/* HyChem: per-trajectory temperature [K] and pressure [Pa] tables on the saveat grid, IC-fastest like data:
+ * T[j*B + b], j < n_save (Tlist / Plist, crnn_pyrolysis_mass.jl:44-47,103-104; piecewise linear in t).
+ * Call after crnn_ctx_set_data (B is taken from it). */
+int32_t crnn_ctx_set_tables(crnn_ctx *ctx, const double *T, const double *P);
 
 /* ---- the hot path at theta level ---------------------------------------- *
  * Integrates trajectories [first, first+count) of the uploaded ensemble with

@@ -1113,3 +1113,300 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
     if (n_saved_out) *n_saved_out = jsave;
     return retcode;
 }
+
+/* ======================================================================================================== *
+ * HyChem pyrolysis (BASELINE config 4): HyChem/crnn_pyrolysis_mass.jl
+ *   p2vec                       :78-90
+ *   Y2density, Y2C, crnn!       :107-131     (T = itpT(t), P = itpP(t): LinearInterpolation on tsteps, :103-104)
+ *   predict_n_ode / loss_n_ode  :135-147     (saveat = tsteps[1:sample], mae(pred ./ yscale, data ./ yscale))
+ *   ForwardDiff.gradient        :201
+ * Stepper: non-autonomous Rosenbrock23 (the reference's AutoTsit5(Rosenbrock23(autodiff=false)) in its stiff branch),
+ * dT = df/dt analytic on the current table segment (the reference takes a finite difference).  Tangents: complex step
+ * per direction (theta + i h dtheta_k, u + i h s_k) through the same step arithmetic with the real W factorisation,
+ * dt held real -- ForwardDiff's arithmetic, and deliberately a different mechanism from the device's analytic adjoint.
+ * PARITY UNPINNED for solver internals (no Manifest, no reference tests); pinned against Radau + sensitivities of
+ * the NumPy restatement (tests/golden/fixtures_hychem.json).
+ * theta = [ w_in ((ns+2) x nr col-major; row ns: x (-1/(R T)), row ns+1: x log T) | w_b | w_out (ns x nr) ].
+ * ======================================================================================================== */
+typedef struct orc_hychem {
+    int32_t ns, nr, maxiters, pad_;
+    double lb, ub, inv_R, Ru, atol, rtol;
+    double mw[12], scale[12], inv_yscale[12];
+    double gamma, qmin, qmax, beta1, beta2, qsteady_min, qsteady_max, qoldinit;
+} orc_hychem;
+
+int orc_sizeof_hychem(void) { return (int)sizeof(orc_hychem); }
+
+void orc_hychem_defaults(orc_hychem *c) {
+    memset(c, 0, sizeof(*c));
+    c->ns = 9; c->nr = 10; c->maxiters = 10000;                                   /* :21-23,55 */
+    c->lb = 1e-8; c->ub = 10.0; c->atol = 1e-8; c->rtol = 1e-3;                   /* :26-28,123,126 */
+    c->inv_R = (double)(-1.0f / 1.98720425864083e-3f);                            /* Float32 literal, :106,128 */
+    c->Ru = 8.31446261815324e3;                                                   /* :108 */
+    const double mw[9] = {136.238, 2.016, 16.043, 26.038, 28.054, 28.014, 56.108, 1.008, 15.035};   /* :58 */
+    for (int i = 0; i < 12; ++i) { c->mw[i] = i < 9 ? mw[i] : 1.0; c->scale[i] = 1.0; c->inv_yscale[i] = 1.0; }
+    c->gamma = 0.9; c->qmin = 0.2; c->qmax = 10.0; c->beta1 = 7.0 / 20.0; c->beta2 = 2.0 / 10.0;
+    c->qsteady_min = 1.0; c->qsteady_max = 1.2; c->qoldinit = 1e-4;
+}
+
+/* p -> theta and d theta / d p (dth[k * nth + m], zeroed here); ForwardDiff's clamp' = 1 on the closed window */
+int orc_hychem_p2vec(const double *p, int ns, int nr, double *th, double *dth) {
+    const int n = ns + 2, nth = nr * (n + 1 + ns), P = nr * (2 * ns + 3) + 1;
+    const double slope = p[P - 1] * 10.0, ln10 = log(10.0);
+    if (dth) memset(dth, 0, sizeof(double) * (size_t)nth * P);
+#define DTH(m, k) dth[(size_t)(k) * nth + (m)]
+    const int o_b = n * nr, o_out = (n + 1) * nr;
+    for (int j = 0; j < nr; ++j) {
+        th[o_b + j] = p[j] * slope;                                   /* w_b */
+        th[(ns + 1) + n * j] = p[nr + j];                             /* w_in_b -> row ns+1 */
+        th[ns + n * j] = p[2 * nr + j] * slope;                       /* w_in_Ea -> row ns */
+        if (dth) {
+            DTH(o_b + j, j) = slope; DTH(o_b + j, P - 1) = p[j] * 10.0;
+            DTH((ns + 1) + n * j, nr + j) = 1.0;
+            DTH(ns + n * j, 2 * nr + j) = slope; DTH(ns + n * j, P - 1) = p[2 * nr + j] * 10.0;
+        }
+        for (int i = 0; i < ns; ++i) {
+            const int ko = 3 * nr + i + ns * j, ki = nr * (ns + 3) + i + ns * j;
+            const double wo = p[ko], wi = p[ki], pw = pow(10.0, wo);
+            th[o_out + i + ns * j] = -wi * pw;
+            th[i + n * j] = wi < 0.0 ? 0.0 : (wi > 2.5 ? 2.5 : wi);
+            if (dth) {
+                DTH(o_out + i + ns * j, ki) = -pw;
+                DTH(o_out + i + ns * j, ko) = -wi * pw * ln10;
+                DTH(i + n * j, ki) = (wi >= 0.0 && wi <= 2.5) ? 1.0 : 0.0;
+            }
+        }
+    }
+#undef DTH
+    return 0;
+}
+
+static cplx hy_clamp(cplx x, double lo, double hi) { double re = creal(x); return re < lo ? lo : (re > hi ? hi : x); }
+
+/* table segment of t: i = max{ i : ts[i] <= t }, clipped to [0, D-2] */
+static int hy_seg(const double *ts, int D, double t) {
+    int i = 0;
+    while (i + 1 < D - 1 && ts[i + 1] <= t) ++i;
+    return i;
+}
+static void hy_tab(const double *ts, int D, const double *tab, double t, double *val, double *slope) {
+    int i = hy_seg(ts, D, t);
+    double s = (tab[i + 1] - tab[i]) / (ts[i + 1] - ts[i]);
+    *val = tab[i] + (t - ts[i]) * s;
+    if (slope) *slope = s;
+}
+
+/* f, and optionally J = df/du (col-major ns x ns) and ft = df/dt for given (T, P, dT/dt, dP/dt); complex-analytic */
+static void hy_eval(const orc_hychem *c, const cplx *th, const cplx *u, double T, double P, double Td, double Pd,
+                    cplx *f, cplx *J, cplx *ft) {
+    const int ns = c->ns, nr = c->nr, n = ns + 2;
+    const cplx *w_in = th, *w_b = th + n * nr, *w_out = th + (n + 1) * nr;
+    cplx Y[12], x[14], r[16], om[12];
+    double cY[12], cC[12];
+    cplx S = 0.0;
+    for (int i = 0; i < ns; ++i) { Y[i] = hy_clamp(u[i], c->lb, c->ub); cY[i] = (creal(u[i]) >= c->lb && creal(u[i]) <= c->ub) ? 1.0 : 0.0; S += Y[i] / c->mw[i]; }
+    const cplx rho = P / (c->Ru * T * S);
+    for (int i = 0; i < ns; ++i) {
+        cplx C = rho * (Y[i] / c->mw[i]) * 1e3;
+        cC[i] = (creal(C) >= c->lb && creal(C) <= c->ub) ? 1.0 : 0.0;
+        x[i] = clog(hy_clamp(C, c->lb, c->ub));
+    }
+    x[ns] = c->inv_R / T;
+    x[ns + 1] = log(T);
+    for (int j = 0; j < nr; ++j) {
+        cplx z = w_b[j];
+        for (int m = 0; m < n; ++m) z += w_in[m + n * j] * x[m];
+        r[j] = cexp(z);
+    }
+    for (int i = 0; i < ns; ++i) {
+        cplx a = 0.0;
+        for (int j = 0; j < nr; ++j) a += w_out[i + ns * j] * r[j];
+        om[i] = a;
+        f[i] = a * c->mw[i] / rho * c->scale[i];
+    }
+    if (J) {
+        /* d log rho / du_c = -cY_c / (mw_c S);  d x_i / du_c = cC_i (d log rho/du_c + delta_ic cY_c / Y_c) */
+        for (int cc = 0; cc < ns; ++cc) {
+            const cplx dl = -cY[cc] / (c->mw[cc] * S);
+            for (int i = 0; i < ns; ++i) {
+                cplx a = 0.0;
+                for (int j = 0; j < nr; ++j) {
+                    cplx dz = 0.0;
+                    for (int m = 0; m < ns; ++m) dz += w_in[m + n * j] * cC[m] * (dl + (m == cc ? cY[cc] / Y[cc] : 0.0));
+                    a += w_out[i + ns * j] * r[j] * dz;
+                }
+                J[i + ns * cc] = a * c->mw[i] / rho * c->scale[i] - f[i] * dl;
+            }
+        }
+    }
+    if (ft) {
+        const double ld = Pd / P - Td / T;           /* d log rho / dt */
+        for (int i = 0; i < ns; ++i) {
+            cplx a = 0.0;
+            for (int j = 0; j < nr; ++j) {
+                cplx dz = w_in[ns + n * j] * (-c->inv_R * Td / (T * T)) + w_in[ns + 1 + n * j] * (Td / T);
+                for (int m = 0; m < ns; ++m) dz += w_in[m + n * j] * cC[m] * ld;
+                a += w_out[i + ns * j] * r[j] * dz;
+            }
+            ft[i] = a * c->mw[i] / rho * c->scale[i] - f[i] * ld;
+        }
+    }
+    (void)om;
+}
+
+void orc_hychem_rhs(const orc_hychem *c, const double *th, const double *u, double T, double P, double Td, double Pd,
+                    double *f, double *J, double *ft) {
+    const int ns = c->ns, nth = c->nr * (2 * ns + 3);
+    cplx thc[256], uc[12], fc[12], Jc[144], ftc[12];
+    for (int m = 0; m < nth; ++m) thc[m] = th[m];
+    for (int i = 0; i < ns; ++i) uc[i] = u[i];
+    hy_eval(c, thc, uc, T, P, Td, Pd, fc, J ? Jc : NULL, ft ? ftc : NULL);
+    for (int i = 0; i < ns; ++i) { f[i] = creal(fc[i]); if (ft) ft[i] = creal(ftc[i]); }
+    if (J) for (int i = 0; i < ns * ns; ++i) J[i] = creal(Jc[i]);
+}
+
+static void hy_csolve(int n, const double *W, const int *piv, cplx *b) {   /* real LU applied to a complex rhs */
+    for (int k = 0; k < n; ++k) { int p = piv[k]; if (p != k) { cplx tt = b[k]; b[k] = b[p]; b[p] = tt; } }
+    for (int k = 0; k < n; ++k) { cplx a = b[k]; for (int i = k + 1; i < n; ++i) b[i] -= W[i + n * k] * a; }
+    for (int k = n - 1; k >= 0; --k) { b[k] /= W[k + n * k]; cplx a = b[k]; for (int i = 0; i < k; ++i) b[i] -= W[i + n * k] * a; }
+}
+
+/* u0 [ns]; ts, Ttab, Ptab [D]; data [ns][D] (species-major rows of length Dfull); pred [ns][Dfull] or NULL;
+ * dth [ndir][nth] or NULL; grad [ndir].  Returns the retcode. */
+int orc_hychem_solve_one(const orc_hychem *c, const double *th, const double *dth, int ndir, const double *u0,
+                         const double *ts, int D, int Dfull, const double *Ttab, const double *Ptab, const double *data,
+                         double *pred, double *loss_out, double *grad, int32_t *n_saved_out, orc_stats *st) {
+    const int ns = c->ns, nth = c->nr * (2 * ns + 3), K = ndir + 1, PR = ndir;
+    const double d = 1.0 / (2.0 + sqrt(2.0)), c32 = 6.0 + sqrt(2.0), h = 1e-30;
+    const double t0 = 0.0, tend = ts[D - 1];                          /* tspan = [0, tsteps[sample]], :137 */
+    cplx *thk = (cplx *)malloc(sizeof(cplx) * (size_t)K * nth);
+    cplx *ws = (cplx *)malloc(sizeof(cplx) * (size_t)K * ns * 6);
+    cplx *u = ws, *f0 = ws + K * ns, *k1 = ws + 2 * K * ns, *k2 = ws + 3 * K * ns, *un = ws + 4 * K * ns, *f2 = ws + 5 * K * ns;
+    double *g = (double *)calloc((size_t)(ndir > 0 ? ndir : 1), sizeof(double));
+    for (int k = 0; k < K; ++k) {
+        for (int m = 0; m < nth; ++m) thk[(size_t)k * nth + m] = th[m] + (k < ndir ? I * h * dth[(size_t)k * nth + m] : 0.0);
+        for (int i = 0; i < ns; ++i) u[k * ns + i] = u0[i];
+    }
+    double t = t0, Tn, Pn, Tdn, Pdn;
+    hy_tab(ts, Dfull, Ttab, t, &Tn, &Tdn); hy_tab(ts, Dfull, Ptab, t, &Pn, &Pdn);
+    for (int k = 0; k < K; ++k) hy_eval(c, thk + (size_t)k * nth, u + k * ns, Tn, Pn, 0, 0, f0 + k * ns, NULL, NULL);
+    double dt;
+    {   /* Hairer initial step, order 2, on the primal */
+        double sk[12], d0 = 0, d1 = 0, d2 = 0, ur[12], fr[12], f1r[12];
+        cplx u1[12], f1[12];
+        for (int i = 0; i < ns; ++i) { ur[i] = creal(u[PR * ns + i]); fr[i] = creal(f0[PR * ns + i]); sk[i] = c->atol + fabs(ur[i]) * c->rtol;
+            d0 += (ur[i] / sk[i]) * (ur[i] / sk[i]); d1 += (fr[i] / sk[i]) * (fr[i] / sk[i]); }
+        d0 = sqrt(d0 / ns); d1 = sqrt(d1 / ns);
+        const double dtmax = tend - t0;
+        double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        dt0 = fmin(dt0, dtmax);
+        for (int i = 0; i < ns; ++i) u1[i] = ur[i] + dt0 * fr[i];
+        double T1, P1; hy_tab(ts, Dfull, Ttab, t + dt0, &T1, NULL); hy_tab(ts, Dfull, Ptab, t + dt0, &P1, NULL);
+        hy_eval(c, thk + (size_t)PR * nth, u1, T1, P1, 0, 0, f1, NULL, NULL);
+        for (int i = 0; i < ns; ++i) { f1r[i] = creal(f1[i]); double e = (f1r[i] - fr[i]) / sk[i]; d2 += e * e; }
+        d2 = sqrt(d2 / ns) / dt0;
+        double dm = fmax(d1, d2);
+        double dt1 = dm <= 1e-15 ? fmax(1e-6, dt0 * 1e-3) : pow(10.0, -(2.0 + log10(dm)) / 2.0);
+        dt = fmin(fmin(100 * dt0, dt1), dtmax);
+    }
+    double qold = c->qoldinit, loss_sum = 0.0;
+    int jsave = 0, retcode = 0, iter = 0;
+#define HY_SAVE(UEXPR)                                                                                           \
+    do {                                                                                                         \
+        for (int i = 0; i < ns; ++i) {                                                                           \
+            int k = PR; cplx vp = (UEXPR);                                                                       \
+            double rr = (data[(size_t)i * Dfull + jsave] - creal(vp)) * c->inv_yscale[i];                        \
+            if (pred) pred[(size_t)i * Dfull + jsave] = creal(vp);                                               \
+            loss_sum += fabs(rr);                                                                                \
+            double w = (signbit(rr) ? 1.0 : -1.0) * c->inv_yscale[i];                                            \
+            for (k = 0; k < ndir; ++k) { cplx vk = (UEXPR); g[k] += w * cimag(vk) / h; }                         \
+        }                                                                                                        \
+        ++jsave;                                                                                                 \
+    } while (0)
+    if (ts[0] == t0) HY_SAVE(u[k * ns + i]);
+    double *W = (double *)malloc(sizeof(double) * ns * ns);
+    cplx *Jk = (cplx *)malloc(sizeof(cplx) * ns * ns);
+    int piv[12];
+    while (jsave < D) {
+        if (++iter > c->maxiters) { retcode = 1; break; }
+        int last = 0;
+        if (t + dt * (1.0 + 1e-13) >= tend) { dt = tend - t; last = 1; }
+        if (!(dt > 0.0) || t + dt == t) { retcode = 2; break; }
+        const double gam = d * dt, tm = t + 0.5 * dt, tnew = last ? tend : t + dt;
+        double Tm, Pm, T2, P2;
+        hy_tab(ts, Dfull, Ttab, t, &Tn, &Tdn); hy_tab(ts, Dfull, Ptab, t, &Pn, &Pdn);
+        hy_tab(ts, Dfull, Ttab, tm, &Tm, NULL); hy_tab(ts, Dfull, Ptab, tm, &Pm, NULL);
+        hy_tab(ts, Dfull, Ttab, tnew, &T2, NULL); hy_tab(ts, Dfull, Ptab, tnew, &P2, NULL);
+        cplx ftk[12], fdum[12];
+        hy_eval(c, thk + (size_t)PR * nth, u + PR * ns, Tn, Pn, Tdn, Pdn, fdum, Jk, ftk);
+        for (int i = 0; i < ns * ns; ++i) W[i] = ((i % ns) == (i / ns) ? 1.0 : 0.0) - gam * creal(Jk[i]);
+        if (lu_factor(ns, W, piv) != 0) { retcode = 3; break; }
+        int finite = 1;
+        double ev[12], EEst = 0.0;
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int k = 0; k < K; ++k) {
+                if (pass == 0 ? (k != PR) : !(k < ndir)) continue;
+                cplx b[12], u1[12], f1[12], tmp[12];
+                const cplx *thc = thk + (size_t)k * nth;
+                hy_eval(c, thc, u + k * ns, Tn, Pn, Tdn, Pdn, fdum, Jk, ftk);
+                for (int i = 0; i < ns; ++i) b[i] = f0[k * ns + i] + gam * ftk[i];
+                if (k != PR) for (int i = 0; i < ns; ++i) for (int cc = 0; cc < ns; ++cc)
+                    b[i] += gam * (Jk[i + ns * cc] - creal(Jk[i + ns * cc])) * creal(k1[PR * ns + cc]);
+                hy_csolve(ns, W, piv, b);
+                for (int i = 0; i < ns; ++i) { k1[k * ns + i] = b[i]; u1[i] = u[k * ns + i] + 0.5 * dt * b[i]; }
+                hy_eval(c, thc, u1, Tm, Pm, 0, 0, f1, NULL, NULL);
+                for (int i = 0; i < ns; ++i) tmp[i] = f1[i] - k1[k * ns + i];
+                if (k != PR) for (int i = 0; i < ns; ++i) for (int cc = 0; cc < ns; ++cc)
+                    tmp[i] += gam * (Jk[i + ns * cc] - creal(Jk[i + ns * cc])) * creal(k2[PR * ns + cc] - k1[PR * ns + cc]);
+                hy_csolve(ns, W, piv, tmp);
+                for (int i = 0; i < ns; ++i) { k2[k * ns + i] = tmp[i] + k1[k * ns + i]; un[k * ns + i] = u[k * ns + i] + dt * k2[k * ns + i]; }
+                hy_eval(c, thc, un + k * ns, T2, P2, 0, 0, f2 + k * ns, NULL, NULL);
+                if (k == PR) {
+                    for (int i = 0; i < ns; ++i) b[i] = f2[k * ns + i] - c32 * (k2[k * ns + i] - f1[i]) - 2.0 * (k1[k * ns + i] - f0[k * ns + i]) + dt * ftk[i];
+                    hy_csolve(ns, W, piv, b);
+                    for (int i = 0; i < ns; ++i) { ev[i] = dt / 6.0 * creal(k1[k * ns + i] - 2.0 * k2[k * ns + i] + b[i]);
+                        if (!isfinite(creal(un[k * ns + i])) || !isfinite(ev[i])) finite = 0; }
+                }
+            }
+            if (pass == 0) {
+                if (!finite) break;
+                double s_ = 0.0;
+                for (int i = 0; i < ns; ++i) { double m = fmax(fabs(creal(u[PR * ns + i])), fabs(creal(un[PR * ns + i]))); double e = ev[i] / (c->atol + c->rtol * m); s_ += e * e; }
+                EEst = sqrt(s_ / ns);
+                if (!(EEst <= 1.0) || ndir == 0) break;
+            }
+        }
+        if (!finite) { retcode = 3; break; }
+        const int accept = (EEst <= 1.0);
+        double q, q11 = 0.0;
+        if (EEst == 0.0) q = 1.0 / c->qmax;
+        else { q11 = pow(EEst, c->beta1); q = q11 / pow(qold, c->beta2); q = fmax(1.0 / c->qmax, fmin(1.0 / c->qmin, q / c->gamma)); }
+        if (accept) {
+            if (st) st->naccept++;
+            if (q >= c->qsteady_min && q <= c->qsteady_max) q = 1.0;
+            qold = fmax(EEst, c->qoldinit);
+            while (jsave < D && ts[jsave] <= tnew) {
+                const double tsv = ts[jsave];
+                if (tsv == tnew) { HY_SAVE(un[k * ns + i]); }
+                else {
+                    const double Th = (tsv - t) / dt;
+                    const double c1 = Th * (1.0 - Th) / (1.0 - 2.0 * d), c2 = Th * (Th - 2.0 * d) / (1.0 - 2.0 * d);
+                    HY_SAVE(u[k * ns + i] + dt * (c1 * k1[k * ns + i] + c2 * k2[k * ns + i]));
+                }
+            }
+            for (int k = 0; k < K; ++k) if (k == PR || k < ndir) for (int i = 0; i < ns; ++i) { u[k * ns + i] = un[k * ns + i]; f0[k * ns + i] = f2[k * ns + i]; }
+            t = tnew;
+            dt = fmin(dt / q, tend - t0);
+        } else {
+            if (st) st->nreject++;
+            dt = dt / fmin(1.0 / c->qmin, q11 / c->gamma);
+        }
+    }
+#undef HY_SAVE
+    const double den = (double)ns * (double)jsave;
+    if (loss_out) *loss_out = jsave > 0 ? loss_sum / den : 0.0;
+    if (grad) for (int k = 0; k < ndir; ++k) grad[k] = jsave > 0 ? g[k] / den : 0.0;
+    if (n_saved_out) *n_saved_out = jsave;
+    free(W); free(Jk); free(thk); free(ws); free(g);
+    return retcode;
+}

@@ -279,3 +279,67 @@ def cathode_solve_one(c, theta, ts, dbar, d2bar, want_grad=True):
                                      _dp(np.ascontiguousarray(dbar, float)), _dp(np.ascontiguousarray(d2bar, float)),
                                      _dp(hrr), C.byref(loss), _dp(grad), C.byref(ns), C.cast(st, C.c_void_p))
     return dict(hrr=hrr, loss=loss.value, grad=grad, retcode=rc, n_saved=ns.value, naccept=st[0], nreject=st[1])
+
+
+# ---------------------------------------------------------------------------- HyChem restatement
+class Hychem(C.Structure):
+    _fields_ = [("ns", C.c_int32), ("nr", C.c_int32), ("maxiters", C.c_int32), ("pad_", C.c_int32),
+                ("lb", C.c_double), ("ub", C.c_double), ("inv_R", C.c_double), ("Ru", C.c_double),
+                ("atol", C.c_double), ("rtol", C.c_double),
+                ("mw", C.c_double * 12), ("scale", C.c_double * 12), ("inv_yscale", C.c_double * 12),
+                ("gamma", C.c_double), ("qmin", C.c_double), ("qmax", C.c_double), ("beta1", C.c_double),
+                ("beta2", C.c_double), ("qsteady_min", C.c_double), ("qsteady_max", C.c_double), ("qoldinit", C.c_double)]
+
+
+def make_hychem(dydt_scale=None, yscale=None, atol=None, rtol=None, maxiters=None):
+    c = Hychem()
+    lib().orc_hychem_defaults(C.byref(c))
+    assert lib().orc_sizeof_hychem() == C.sizeof(Hychem)
+    for i in range(c.ns):
+        if dydt_scale is not None:
+            c.scale[i] = float(dydt_scale[i])
+        if yscale is not None:
+            c.inv_yscale[i] = 1.0 / float(yscale[i])
+    if atol is not None:
+        c.atol = atol
+    if rtol is not None:
+        c.rtol = rtol
+    if maxiters is not None:
+        c.maxiters = int(maxiters)
+    return c
+
+
+def hychem_p2vec(p, ns=9, nr=10):
+    nth, P = nr * (2 * ns + 3), nr * (2 * ns + 3) + 1
+    th = np.zeros(nth)
+    dth = np.zeros((P, nth))
+    lib().orc_hychem_p2vec(_dp(np.ascontiguousarray(p, float)), C.c_int(ns), C.c_int(nr), _dp(th), _dp(dth))
+    return th, dth          # dth[k, m] = d theta_m / d p_k
+
+
+def hychem_rhs(c, theta, u, T, P, Td=0.0, Pd=0.0):
+    ns = c.ns
+    f = np.zeros(ns); J = np.zeros((ns, ns), order="F"); ft = np.zeros(ns)
+    lib().orc_hychem_rhs(C.byref(c), _dp(np.ascontiguousarray(theta, float)), _dp(np.ascontiguousarray(u, float)),
+                         C.c_double(T), C.c_double(P), C.c_double(Td), C.c_double(Pd), _dp(f), _dp(J), _dp(ft))
+    return f, J, ft
+
+
+def hychem_solve_one(c, theta, u0, ts, Ttab, Ptab, data, dtheta=None, sample=None, want_pred=False):
+    """data [ns, D]; dtheta [ndir, nth] (rows = directions) or None.  Returns dict(loss, grad, pred [ns, D], ...)"""
+    ts = np.ascontiguousarray(ts, float)
+    Dfull = ts.size
+    D = Dfull if sample is None else int(sample)
+    ns = c.ns
+    ndir = 0 if dtheta is None else int(np.shape(dtheta)[0])
+    dth = None if dtheta is None else np.ascontiguousarray(dtheta, float)
+    pred = np.zeros((ns, Dfull)) if want_pred else None
+    grad = np.zeros(max(ndir, 1))
+    loss = C.c_double(0); nsv = C.c_int32(0); st = (C.c_int64 * 2)(0, 0)
+    lib().orc_hychem_solve_one.restype = C.c_int
+    rc = lib().orc_hychem_solve_one(C.byref(c), _dp(np.ascontiguousarray(theta, float)), _dp(dth), C.c_int(ndir),
+                                    _dp(np.ascontiguousarray(u0, float)), _dp(ts), C.c_int(D), C.c_int(Dfull),
+                                    _dp(np.ascontiguousarray(Ttab, float)), _dp(np.ascontiguousarray(Ptab, float)),
+                                    _dp(np.ascontiguousarray(data, float)), _dp(pred), C.byref(loss), _dp(grad),
+                                    C.byref(nsv), C.cast(st, C.c_void_p))
+    return dict(loss=loss.value, grad=grad[:ndir], pred=pred, retcode=rc, n_saved=nsv.value, naccept=st[0], nreject=st[1])

@@ -417,5 +417,58 @@ def cathode_main():
     print("wrote fixtures_cathode.json", os.path.getsize(os.path.join(OUT, "fixtures_cathode.json")))
 
 
+# ---------------------------------------------------------------------------------------------------------
+# HyChem fixtures (python tests/golden/make_fixtures.py hychem): written to fixtures_hychem.json.
+# The reference's data file is absent, so conditions come from crnn_amd/hychem.py's synthetic model (an element-
+# balanced skeleton in CRNN form); the NumPy restatement of crnn! / p2vec there follows
+# HyChem/crnn_pyrolysis_mass.jl:78-131.  Golden values: Radau (rtol 1e-11) trajectories of the CRNN at a perturbed
+# parameter vector, its loss, and d loss/d p for a subset of parameters by continuous sensitivities (complex step).
+# ---------------------------------------------------------------------------------------------------------
+def hychem_main():
+    sys.path.insert(0, os.path.join(OUT, "..", ".."))
+    from crnn_amd import hychem as hy
+    rng = np.random.Generator(np.random.PCG64(2024))
+    B = 3
+    ts, u0, Tt, Pt = hy.sample_conditions(B, rng)
+    th_true = hy.true_theta()
+    clean = np.zeros((B, hy.NS, ts.size))
+    for b in range(B):
+        f = lambda t, u: np.real(hy.crnn(u, th_true, hy.interp(t, ts, Tt[b]), hy.interp(t, ts, Pt[b]), hy.DYDT_SCALE))
+        sol = solve_ivp(f, (0, ts[-1]), u0[b], method="Radau", rtol=1e-11, atol=1e-14, t_eval=ts)
+        assert sol.success
+        clean[b] = sol.y
+    data = clean * (1.0 + 0.01 * rng.standard_normal(clean.shape))
+    yscale = np.maximum((data.max(axis=2) - data.min(axis=2)).max(axis=0), hy.LB)
+    p = hy.true_p() + 0.02 * rng.standard_normal(hy.NP)
+    p[-1] = 0.1
+    theta = hy.pack_theta(*hy.p2vec(p))
+    # subset of parameters for the golden gradient: w_b, w_in_b, w_in_Ea, w_out_raw, w_in_raw entries, slope
+    nr, ns = hy.NR, hy.NS
+    sub = [0, 2, 5, nr + 1, nr + 5, 2 * nr + 0, 2 * nr + 3, 3 * nr + 0, 3 * nr + 6 + ns * 0, 3 * nr + 4 + ns * 1,
+           nr * (ns + 3) + 0, nr * (ns + 3) + 6 + ns * 1, nr * (ns + 3) + 4 + ns * 3, nr * (ns + 3) + 1 + ns * 3, hy.NP - 1]
+    out = dict(ts=ts.tolist(), u0=u0.tolist(), Ttab=Tt.tolist(), Ptab=Pt.tolist(), data=data.tolist(), yscale=yscale.tolist(),
+               dydt_scale=hy.DYDT_SCALE.tolist(), p=p.tolist(), theta=theta.tolist(), sub=sub, traj=[])
+    for b in range(B):
+        def rhs_aug(ua, psub):
+            pc = p.astype(complex)
+            pc[sub] = psub
+            thc = hy.pack_theta(*hy.p2vec(pc))
+            t = np.real(ua[ns])
+            du = hy.crnn(ua[:ns], thc, hy.interp(t, ts, Tt[b]), hy.interp(t, ts, Pt[b]), hy.DYDT_SCALE)
+            return np.concatenate([du, [1.0 + 0 * ua[ns]]])
+        U, S = sens_solve(rhs_aug, p[sub].copy(), np.concatenate([u0[b], [0.0]]), ts, t0=0.0, method="Radau", rtol=1e-11, atol=1e-14)
+        pred = U[:ns]
+        rr = (data[b] - pred) / yscale[:, None]
+        loss = np.mean(np.abs(rr))
+        w = -np.sign(rr) / yscale[:, None] / rr.size
+        grad = np.array([(w * S[k, :ns, :]).sum() for k in range(len(sub))])
+        out["traj"].append(dict(pred=pred.tolist(), loss=float(loss), grad_sub=grad.tolist()))
+        print("hychem", b, "T0", Tt[b, 0], "loss", loss, "|grad_sub|", np.linalg.norm(grad), flush=True)
+    with open(os.path.join(OUT, "fixtures_hychem.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote fixtures_hychem.json", os.path.getsize(os.path.join(OUT, "fixtures_hychem.json")))
+
+
 if __name__ == "__main__":
-    sys.exit(cathode_main() if (len(sys.argv) > 1 and sys.argv[1] == "cathode") else main())
+    mode = sys.argv[1] if len(sys.argv) > 1 else ""
+    sys.exit(cathode_main() if mode == "cathode" else hychem_main() if mode == "hychem" else main())

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     """ctypes mirrors == the C structs the library was compiled with (also enforced at import)."""
     from crnn_amd import _lib as L
-    assert L.lib.crnn_sizeof(0) == C.sizeof(L.Config) == 16 * 4 + (4 + 36 + 9) * 8
+    assert L.lib.crnn_sizeof(0) == C.sizeof(L.Config) == 16 * 4 + (4 + 48 + 1 + 9) * 8
     assert L.lib.crnn_sizeof(1) == C.sizeof(L.Stats) == 4 * 8 + 8
     assert L.lib.crnn_sizeof(2) == C.sizeof(L.OptConfig) == 2 * 4 + 8 * 8
     assert L.lib.crnn_sizeof(3) == C.sizeof(L.CathodeConfig) == 4 * 4 + 12 * 8

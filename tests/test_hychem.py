@@ -1,0 +1,321 @@
+"""HyChem row (BASELINE config 4; HyChem/crnn_pyrolysis_mass.jl).  CPU: the C oracle pinned against NumPy restatements
+(RHS, Jacobian, p2vec, an all-complex NumPy Rosenbrock23 for the tangents) and against the golden Radau + sensitivity
+vectors of tests/golden/fixtures_hychem.json; the product's host p2vec.  GPU: the HIP kernel (discrete adjoint) against
+the oracle (complex-step forward tangents) and the golden vectors."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def hfx():
+    with open(os.path.join(HERE, "golden", "fixtures_hychem.json")) as f:
+        d = json.load(f)
+    for k in ("ts", "u0", "Ttab", "Ptab", "data", "yscale", "dydt_scale", "p", "theta"):
+        d[k] = np.array(d[k])
+    return d
+
+
+def _oracle_cfg(orc, hfx, atol=None, rtol=None, maxiters=None):
+    return orc.make_hychem(dydt_scale=hfx["dydt_scale"], yscale=hfx["yscale"], atol=atol, rtol=rtol, maxiters=maxiters)
+
+
+# ------------------------------------------------------------------ CPU
+def test_hychem_oracle_rhs_jacobian_time_derivative(orc, hfx):
+    from crnn_amd import hychem as hy
+    rng = np.random.default_rng(1)
+    c = _oracle_cfg(orc, hfx)
+    th, sc = hfx["theta"], hfx["dydt_scale"]
+    for b in range(3):
+        u = np.abs(rng.standard_normal(9)) * 0.05
+        u[5] = 0.9                       # N2: C clamps at 10
+        u[7] = 0.0                       # below lb: Y clamp active
+        T, P, Td, Pd = hfx["Ttab"][b, 3], hfx["Ptab"][b, 3], -4e3, 2e6
+        f, J, ft = orc.hychem_rhs(c, th, u, T, P, Td, Pd)
+        fn = np.real(hy.crnn(u, th, T, P, sc))
+        assert np.max(np.abs(f - fn)) < 1e-13 * np.max(np.abs(fn))
+        Jn = np.zeros((9, 9))
+        for k in range(9):
+            uc = u.astype(complex); uc[k] += 1e-30j
+            Jn[:, k] = np.imag(hy.crnn(uc, th, T, P, sc)) / 1e-30
+        assert np.max(np.abs(J - Jn)) < 1e-13 * np.max(np.abs(Jn))
+        e = 1e-7
+        ftn = (np.real(hy.crnn(u, th, T + e * Td, P + e * Pd, sc)) - np.real(hy.crnn(u, th, T - e * Td, P - e * Pd, sc))) / (2 * e)
+        assert np.max(np.abs(ft - ftn)) < 1e-6 * np.max(np.abs(ftn))
+
+
+def test_hychem_p2vec_oracle_numpy_and_product(orc, hfx):
+    from crnn_amd import PMAP_HYCHEM, hychem as hy, p2vec_jac
+    rng = np.random.default_rng(2)
+    for p in (hfx["p"], hy.init_p(rng), hy.true_p()):
+        th, dth = orc.hychem_p2vec(p)
+        assert np.max(np.abs(th - hy.pack_theta(*hy.p2vec(p)))) < 1e-15 * max(1.0, np.max(np.abs(th)))
+        th2, dth2 = p2vec_jac(PMAP_HYCHEM, 9, 10, p)            # product host code (crnn_p2vec)
+        assert np.array_equal(th2, th)
+        assert np.max(np.abs(dth2.T - dth)) <= 1e-15 * np.max(np.abs(dth))
+        for k in (0, 11, 25, 33, 95, 130, 200, 210):             # complex-step columns of the NumPy p2vec
+            pc = p.astype(complex); pc[k] += 1e-30j
+            col = np.imag(hy.pack_theta(*hy.p2vec(pc))) / 1e-30
+            assert np.max(np.abs(dth[k] - col)) < 1e-13 * max(1.0, np.max(np.abs(col)))
+    assert np.max(np.abs(hy.pack_theta(*hy.p2vec(hy.true_p())) - hy.true_theta())) == 0.0
+
+
+def test_hychem_oracle_matches_golden(orc, hfx):
+    th, dth = orc.hychem_p2vec(hfx["p"])
+    c = _oracle_cfg(orc, hfx, atol=1e-13, rtol=1e-9, maxiters=10**7)
+    for b, gtol in ((2, 2e-5), (1, 2e-3)):
+        tr = hfx["traj"][b]
+        r = orc.hychem_solve_one(c, th, hfx["u0"][b], hfx["ts"], hfx["Ttab"][b], hfx["Ptab"][b], hfx["data"][b],
+                                 dtheta=dth[hfx["sub"]], want_pred=True)
+        assert r["retcode"] == 0
+        assert np.max(np.abs(r["pred"] - np.array(tr["pred"]))) < 1e-8          # measured 2e-9 / 2e-11
+        assert abs(r["loss"] - tr["loss"]) < 1e-7 * tr["loss"]
+        # discrete tangents (ForwardDiff's arithmetic) see the clamp kinks of species starting at 0 < lb step-wise:
+        # they approach the continuous sensitivities erratically, 1e-3 for the hot cases, 6e-6 for the cold one
+        g = np.array(tr["grad_sub"])
+        assert np.max(np.abs(r["grad"] - g)) < gtol * np.max(np.abs(g))
+
+
+def test_hychem_oracle_tangents_equal_all_complex_numpy_stepper(orc, hfx):
+    """Independent statement of 'differentiate the accepted steps with dt held real': the same Rosenbrock23 loop in NumPy
+    on complex copies u + ih s_k, theta + ih dtheta_k with COMPLEX linear solves (the C code uses the real LU plus a
+    first-order correction)."""
+    from crnn_amd import hychem as hy
+    b = 1
+    ts, data, ys, sc = hfx["ts"], hfx["data"][b], hfx["yscale"], hfx["dydt_scale"]
+    Tt, Pt, u0 = hfx["Ttab"][b], hfx["Ptab"][b], hfx["u0"][b]
+    atol, rtol, h = 1e-8, 1e-3, 1e-30
+    d, e32 = 1 / (2 + np.sqrt(2)), 6 + np.sqrt(2)
+    MW = hy.MW
+
+    def tab(t):
+        i = 0
+        while i + 1 < len(ts) - 1 and ts[i + 1] <= t:
+            i += 1
+        sT, sP = (Tt[i + 1] - Tt[i]) / (ts[i + 1] - ts[i]), (Pt[i + 1] - Pt[i]) / (ts[i + 1] - ts[i])
+        return Tt[i] + (t - ts[i]) * sT, Pt[i] + (t - ts[i]) * sP, sT, sP
+
+    def full(u, th, T, P, Td, Pd):
+        w_in, w_b, w_out = hy.unpack_theta(th)
+        re = np.real(u); cY = ((re >= hy.LB) & (re <= hy.UB)).astype(float)
+        Y = hy._clamp(u, hy.LB, hy.UB); S = np.sum(Y / MW); rho = P / (hy.RU * T * S)
+        Cc = rho * Y / MW * 1e3; rc = np.real(Cc); cC = ((rc >= hy.LB) & (rc <= hy.UB)).astype(float)
+        x = np.concatenate([np.log(hy._clamp(Cc, hy.LB, hy.UB)), [hy.INV_R / T], [np.log(T)]])
+        r = np.exp(w_in.T @ x + w_b); G = MW * sc / rho; f = (w_out @ r) * G
+        sig = cY / (MW * S)
+        dx = np.diag(cC * cY / Y) - np.outer(cC, sig)
+        J = (G[:, None] * (w_out * r[None, :])) @ (w_in[:9].T @ dx) + np.outer(f, sig)
+        ld = Pd / P - Td / T
+        xd = np.concatenate([cC * ld, [-hy.INV_R * Td / T ** 2], [Td / T]])
+        return f, J, G * (w_out @ (r * (w_in.T @ xd))) - f * ld
+
+    th, dth = orc.hychem_p2vec(hfx["p"])
+    dirs = dth[hfx["sub"]]; nd = len(dirs); K = nd + 1; PR = nd
+    U = np.tile(u0.astype(complex), (K, 1))
+    TH = np.array([th + 1j * h * dirs[k] if k < nd else th.astype(complex) for k in range(K)])
+    t = 0.0
+    T, P, _, _ = tab(t)
+    f0 = np.real(full(U[PR], TH[PR], T, P, 0, 0)[0])
+    sk = atol + np.abs(u0) * rtol
+    d0, d1 = np.sqrt(np.mean((u0 / sk) ** 2)), np.sqrt(np.mean((f0 / sk) ** 2))
+    dt0 = min(1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1, ts[-1])
+    T1, P1, _, _ = tab(t + dt0)
+    f1 = np.real(full(u0 + dt0 * f0, TH[PR], T1, P1, 0, 0)[0])
+    dm = max(d1, np.sqrt(np.mean(((f1 - f0) / sk) ** 2)) / dt0)
+    dt = min(100 * dt0, max(1e-6, dt0 * 1e-3) if dm <= 1e-15 else 10 ** (-(2 + np.log10(dm)) / 2), ts[-1])
+    qold, g, loss, js, nacc = 1e-4, np.zeros(nd), 0.0, 0, 0
+
+    def save(Uv):
+        nonlocal loss, js, g
+        rr = (data[:, js] - np.real(Uv[PR])) / ys
+        loss += np.sum(np.abs(rr))
+        g += (np.imag(Uv[:nd]) / h) @ (np.where(np.signbit(rr), 1.0, -1.0) / ys)
+        js += 1
+
+    save(U)
+    while js < len(ts):
+        last = t + dt * (1 + 1e-13) >= ts[-1]
+        if last:
+            dt = ts[-1] - t
+        gam, tn = d * dt, (ts[-1] if last else t + dt)
+        T, P, Td, Pd = tab(t); Tm, Pm, _, _ = tab(t + dt / 2); T2, P2, _, _ = tab(tn)
+        K1, K2, UN = np.zeros((K, 9), complex), np.zeros((K, 9), complex), np.zeros((K, 9), complex)
+        EE = 0.0
+        for k in [PR] + list(range(nd)):
+            f0c, J, ft = full(U[k], TH[k], T, P, Td, Pd)
+            W = np.eye(9) - gam * J
+            k1 = np.linalg.solve(W, f0c + gam * ft)
+            f1c = full(U[k] + dt / 2 * k1, TH[k], Tm, Pm, 0, 0)[0]
+            k2 = k1 + np.linalg.solve(W, f1c - k1)
+            K1[k], K2[k], UN[k] = k1, k2, U[k] + dt * k2
+            if k == PR:
+                f2c = full(UN[k], TH[k], T2, P2, 0, 0)[0]
+                k3 = np.linalg.solve(W, f2c - e32 * (k2 - f1c) - 2 * (k1 - f0c) + dt * ft)
+                ev = np.real(dt / 6 * (k1 - 2 * k2 + k3))
+                EE = np.sqrt(np.mean((ev / (atol + rtol * np.maximum(np.abs(np.real(U[PR])), np.abs(np.real(UN[PR]))))) ** 2))
+                if EE > 1:
+                    break
+        q11 = EE ** 0.35
+        q = max(0.1, min(5.0, q11 / qold ** 0.2 / 0.9))
+        if EE <= 1:
+            q = 1 if 1 <= q <= 1.2 else q
+            qold = max(EE, 1e-4)
+            while js < len(ts) and ts[js] <= tn:
+                if ts[js] == tn:
+                    save(UN)
+                else:
+                    Th = (ts[js] - t) / dt
+                    save(U + dt * (Th * (1 - Th) / (1 - 2 * d) * K1 + Th * (Th - 2 * d) / (1 - 2 * d) * K2))
+            U, t, nacc = UN, tn, nacc + 1
+            dt = min(dt / q, ts[-1])
+        else:
+            dt = dt / min(5.0, q11 / 0.9)
+    r = orc.hychem_solve_one(_oracle_cfg(orc, hfx), th, u0, ts, Tt, Pt, data, dtheta=dirs)
+    assert r["naccept"] == nacc
+    assert abs(r["loss"] - loss / (9 * js)) < 1e-12 * r["loss"]
+    assert np.max(np.abs(r["grad"] - g / (9 * js))) < 1e-8 * np.max(np.abs(r["grad"]))       # measured 6e-12
+
+
+def test_hychem_preset_constants():
+    from crnn_amd import _lib as L, hychem as hy
+    cfg = L.Config()
+    L.check(L.lib.crnn_config_preset(C.byref(cfg), L.PRESET_HYCHEM))
+    assert (cfg.ns, cfg.nr, cfg.has_temp, cfg.n_save, cfg.maxiters, cfg.rhs_kind) == (9, 10, 0, 40, 10000, L.RHS_HYCHEM)   # :17-23
+    assert cfg.lb == 1e-8 and cfg.ub == 10.0 and cfg.atol[0] == 1e-8 and cfg.rtol[0] == 1e-3                                # :26-28
+    assert [cfg.mw[i] for i in range(9)] == list(hy.MW) and cfg.gas_const == hy.RU                                          # :58,108
+    assert cfg.inv_R == hy.INV_R and cfg.inv_R != -1.0 / 1.98720425864083e-3                                                 # Float32 R
+    assert L.lib.crnn_config_n_theta(C.byref(cfg)) == 210 and L.lib.crnn_n_params(L.PMAP_HYCHEM, 9, 10) == 211              # :73
+    o = L.OptConfig()
+    L.check(L.lib.crnn_opt_preset(C.byref(o), L.PRESET_HYCHEM))
+    assert (o.eta, o.wd, o.grad_clip_norm) == (0.005, 1e-6, 10.0)                                                            # :20,24
+
+
+# ------------------------------------------------------------------ GPU
+def _node(hfx, u0, data, Tt, Pt, **kw):
+    from crnn_amd import NeuralODE, ODEProblem, PRESET_HYCHEM
+    node = NeuralODE(ODEProblem(PRESET_HYCHEM, hfx["ts"], rate_scale=hfx["dydt_scale"], **kw))
+    node.set_ensemble(u0, data, hfx["yscale"])
+    node.set_tables(Tt, Pt)
+    return node
+
+
+def _synthetic(hfx, B, seed):
+    """more conditions around the fixture's (data = fixture data of trajectory b % 3, scaled)"""
+    from crnn_amd import hychem as hy
+    rng = np.random.default_rng(seed)
+    _, u0, Tt, Pt = hy.sample_conditions(B, rng)
+    data = np.stack([hfx["data"][b % 3] * (1 + 0.05 * rng.standard_normal()) for b in range(B)])
+    return u0, data, Tt, Pt
+
+
+@pytest.mark.gpu
+def test_gpu_hychem_matches_oracle_reference_tolerances(orc, hfx):
+    from crnn_amd import p2vec_jac
+    u0s, datas, Tts, Pts = _synthetic(hfx, 5, 3)
+    u0 = np.concatenate([hfx["u0"], u0s]); data = np.concatenate([hfx["data"], datas])
+    Tt = np.concatenate([hfx["Ttab"], Tts]); Pt = np.concatenate([hfx["Ptab"], Pts])
+    B = u0.shape[0]
+    node = _node(hfx, u0, data, Tt, Pt)
+    p = hfx["p"]
+    th, dth = orc.hychem_p2vec(p)
+    c = _oracle_cfg(orc, hfx)
+    pred = node.predict_n_ode(p)
+    losses = node.loss_n_ode(p)
+    th_d, dth_d = p2vec_jac(node.pmap, 9, 10, p)
+    _, _, gsum, ret, nsv = node._solve(node._ctx, B, th_d, dth_d, 0, B, None, False)
+    stats = dict(node.last_stats)
+    gref = np.zeros(211); nacc = nrej = 0
+    for b in range(B):
+        r = orc.hychem_solve_one(c, th, u0[b], hfx["ts"], Tt[b], Pt[b], data[b], dtheta=dth, want_pred=True)
+        assert r["retcode"] == ret[b] == 0 and r["n_saved"] == nsv[b] == 40
+        scale = np.abs(r["pred"]).max(axis=1, keepdims=True) + 1e-300
+        assert np.max(np.abs(pred[b] - r["pred"]) / scale) < 1e-8        # same step sequence: rounding only
+        assert abs(losses[b] - r["loss"]) < 1e-9 * r["loss"]
+        g1 = node.gradient(p, b)
+        assert np.max(np.abs(g1 - r["grad"])) < 1e-6 * np.max(np.abs(r["grad"]))
+        gref += r["grad"]; nacc += r["naccept"]; nrej += r["nreject"]
+    assert np.max(np.abs(gsum - gref)) < 1e-6 * np.max(np.abs(gref))
+    assert stats["n_accept"] == nacc and stats["n_reject"] == nrej
+    loss, grad = node.loss_and_grad(p)
+    assert abs(loss - losses.mean()) < 1e-12 * loss and np.max(np.abs(grad - gref / B)) < 1e-6 * np.max(np.abs(gref / B))
+
+
+@pytest.mark.gpu
+def test_gpu_hychem_converged_golden(hfx):
+    node = _node(hfx, hfx["u0"], hfx["data"], hfx["Ttab"], hfx["Ptab"], atol=1e-13, rtol=1e-9, maxiters=10**7, tape_steps=40000)
+    p = hfx["p"]
+    pred = node.predict_n_ode(p)
+    for b, gtol in ((2, 2e-5), (1, 2e-3), (0, 2e-3)):
+        tr = hfx["traj"][b]
+        assert np.max(np.abs(pred[b] - np.array(tr["pred"]))) < 1e-8
+        assert abs(node.loss_neuralode(p, b) - tr["loss"]) < 1e-7 * tr["loss"]
+        g = node.gradient(p, b)[hfx["sub"]]
+        gg = np.array(tr["grad_sub"])
+        assert np.max(np.abs(g - gg)) < gtol * np.max(np.abs(gg))
+
+
+@pytest.mark.gpu
+def test_gpu_hychem_sample_horizon_failures_and_errors(orc, hfx):
+    from crnn_amd import p2vec_jac
+    from crnn_amd._lib import CrnnError
+    p = hfx["p"]
+    th, dth = orc.hychem_p2vec(p)
+    node = _node(hfx, hfx["u0"], hfx["data"], hfx["Ttab"], hfx["Ptab"])
+    c = _oracle_cfg(orc, hfx)
+    th_d, dth_d = p2vec_jac(node.pmap, 9, 10, p)
+    _, loss, gsum, ret, nsv = node._solve(node._ctx, 3, th_d, dth_d, 0, 3, 33, False)        # sample = 33 (:198)
+    gref = np.zeros(211)
+    for b in range(3):
+        r = orc.hychem_solve_one(c, th, hfx["u0"][b], hfx["ts"], hfx["Ttab"][b], hfx["Ptab"][b], hfx["data"][b], dtheta=dth, sample=33)
+        assert r["n_saved"] == nsv[b] == 33 and abs(loss[b] - r["loss"]) < 1e-9 * r["loss"]
+        gref += r["grad"]
+    assert np.max(np.abs(gsum - gref)) < 1e-6 * np.max(np.abs(gref))
+    few = _node(hfx, hfx["u0"], hfx["data"], hfx["Ttab"], hfx["Ptab"], maxiters=15)
+    c15 = _oracle_cfg(orc, hfx, maxiters=15)
+    _, loss, gsum, ret, nsv = few._solve(few._ctx, 3, th_d, dth_d, 0, 3, None, False)
+    gref = np.zeros(211)
+    for b in range(3):
+        r = orc.hychem_solve_one(c15, th, hfx["u0"][b], hfx["ts"], hfx["Ttab"][b], hfx["Ptab"][b], hfx["data"][b], dtheta=dth)
+        assert r["retcode"] == ret[b] and r["n_saved"] == nsv[b] and abs(loss[b] - r["loss"]) <= 1e-9 * r["loss"]
+        gref += r["grad"]
+    assert np.any(ret == 1) and np.max(np.abs(gsum - gref)) < 1e-6 * np.max(np.abs(gref))
+    tiny = _node(hfx, hfx["u0"], hfx["data"], hfx["Ttab"], hfx["Ptab"], tape_steps=8)
+    with pytest.raises(CrnnError, match="tape"):
+        tiny.loss_and_grad(p)
+    fwd = _node(hfx, hfx["u0"], hfx["data"], hfx["Ttab"], hfx["Ptab"], grad_mode=1)
+    with pytest.raises(CrnnError, match="adjoint"):
+        fwd.loss_and_grad(p)
+    from crnn_amd import NeuralODE, ODEProblem, PRESET_HYCHEM
+    bare = NeuralODE(ODEProblem(PRESET_HYCHEM, hfx["ts"], rate_scale=hfx["dydt_scale"]))
+    bare.set_ensemble(hfx["u0"], hfx["data"], hfx["yscale"])
+    with pytest.raises(CrnnError, match="tables"):
+        bare.losses(p)
+
+
+@pytest.mark.gpu
+def test_gpu_hychem_batch_consistency_and_training(hfx):
+    """2048 experiments (the 8 base conditions tiled): identical conditions give identical rows wherever they sit;
+    a few optimiser steps from the perturbed p reduce the loss (crnn_pyrolysis_mass.jl:196-209)."""
+    from crnn_amd import Optimiser, PRESET_HYCHEM
+    u0s, datas, Tts, Pts = _synthetic(hfx, 5, 3)
+    u0 = np.concatenate([hfx["u0"], u0s]); data = np.concatenate([hfx["data"], datas])
+    Tt = np.concatenate([hfx["Ttab"], Tts]); Pt = np.concatenate([hfx["Ptab"], Pts])
+    rep = 256
+    big = _node(hfx, np.tile(u0, (rep, 1)), np.tile(data, (rep, 1, 1)), np.tile(Tt, (rep, 1)), np.tile(Pt, (rep, 1)))
+    small = _node(hfx, u0, data, Tt, Pt)
+    p = hfx["p"]
+    lb_, ls_ = big.losses(p), small.losses(p)
+    assert np.array_equal(lb_.reshape(rep, 8), np.broadcast_to(ls_, (rep, 8)))
+    Lb, Gb = big.loss_and_grad(p)
+    Ls, Gs = small.loss_and_grad(p)
+    assert abs(Lb - Ls) < 1e-12 * Ls and np.max(np.abs(Gb - Gs)) < 1e-10 * np.max(np.abs(Gs))
+    big.train_init(Optimiser(211, PRESET_HYCHEM), p)
+    l0 = big.train_step()
+    for _ in range(15):
+        l1 = big.train_step()
+    assert l1 < l0
