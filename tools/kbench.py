@@ -34,6 +34,19 @@ if args.case == "case2":
     node = NeuralODE(ODEProblem(PRESET_CASE2, ts, grad_mode=gm))
     node.set_ensemble(u0, data, cases.max_min(data, lb=1e-6))
     p = np.array(fx["case2_ckpt"]["p"])
+elif args.case == "hychem":
+    from crnn_amd import PRESET_HYCHEM, hychem as hy
+    ts, u0, Tt, Pt = hy.sample_conditions(B, rng)
+    node = NeuralODE(ODEProblem(PRESET_HYCHEM, ts, rate_scale=hy.DYDT_SCALE, grad_mode=gm))
+    node.set_ensemble(u0, np.zeros((B, 9, len(ts))), np.ones(9))
+    node.set_tables(Tt, Pt)
+    clean = node.predict_n_ode(hy.true_p())                       # synthetic data: the true mechanism, 1 % noise
+    data = clean * (1.0 + 0.01 * rng.standard_normal(clean.shape))
+    ys = np.maximum((data.max(axis=2) - data.min(axis=2)).max(axis=0), hy.LB)
+    node.set_ensemble(u0, data, ys)
+    node.set_tables(Tt, Pt)
+    p = hy.true_p() + 0.02 * np.random.Generator(np.random.PCG64(5)).standard_normal(hy.NP)
+    p[-1] = 0.1
 else:
     ts = cases.rober_tsteps()
     u0 = cases.rober_u0(B, rng)
