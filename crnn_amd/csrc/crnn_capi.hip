@@ -380,13 +380,14 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
     const int nth = c->n_theta;
     const int npart_th = nth + crnn::kExtra, npart = P + crnn::kExtra;
     using KFn = void (*)(const crnn::SolveParams, const double *, const crnn::HyParams);
-    KFn fn = P > 0 ? (KFn)crnn::hychem_kernel<9, 10, true, kBlock> : (KFn)crnn::hychem_kernel<9, 10, false, kBlock>;
+    constexpr int kHyBlock = 128;   // W's factors + parked state in LDS: ~1.1 KB per lane, one 128-lane block per CU
+    KFn fn = P > 0 ? (KFn)crnn::hychem_kernel<9, 10, true, kHyBlock> : (KFn)crnn::hychem_kernel<9, 10, false, kHyBlock>;
     int occ = 0;
-    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, kBlock, 0));
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, kHyBlock, 0));
     if (occ < 1) occ = 1;
-    const int64_t need_blocks = (count + kBlock - 1) / kBlock;
+    const int64_t need_blocks = (count + kHyBlock - 1) / kHyBlock;
     const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(need_blocks, (int64_t)c->num_cu * occ));
-    const size_t lanes = (size_t)nblk * kBlock;
+    const size_t lanes = (size_t)nblk * kHyBlock;
     const size_t recw = (size_t)c->cfg.ns + 2;
     int64_t cap = c->cfg.tape_steps;
     if (cap <= 0) {
@@ -426,7 +427,7 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
     c->ev1 = c->ring1[c->n_launch % Ctx::kRing];
     ++c->n_launch;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    hipLaunchKernelGGL(fn, dim3(nblk), dim3(kBlock), 0, c->stream, prm, d_theta, hp);
+    hipLaunchKernelGGL(fn, dim3(nblk), dim3(kHyBlock), 0, c->stream, prm, d_theta, hp);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     if (P > 0) {

@@ -24,24 +24,34 @@
 #include "ros23_adj_kernel.hpp"
 
 // theta is 210 doubles: hoisting its (loop-invariant) scalar loads out of the step loops would need 420 SGPRs and ends
-// in SGPR->VGPR->scratch spills.  Laundering the pointer through an empty asm at the top of each phase makes the
-// loads phase-local: they are re-issued from the scalar cache where they are used.
-// (used inside divergent regions: launder through VGPRs, then make the pointer wave-uniform again)
-#define HY_FRESH_THETA(ptr)                                                                   \
-    do {                                                                                      \
-        unsigned lo_ = (unsigned)(uintptr_t)(ptr), hi_ = (unsigned)((uintptr_t)(ptr) >> 32);  \
-        asm volatile("" : "+v"(lo_), "+v"(hi_));                                              \
-        lo_ = __builtin_amdgcn_readfirstlane(lo_);                                            \
-        hi_ = __builtin_amdgcn_readfirstlane(hi_);                                            \
-        (ptr) = (const double *)(((uintptr_t)hi_ << 32) | (uintptr_t)lo_);                    \
+// in SGPR->VGPR->scratch spills.  At the top of each phase the pointer is re-derived as theta + z with z an opaque
+// scalar zero (empty asm): the loads stay scalar loads from the (global, restrict) kernel argument but cannot be
+// hoisted above the asm, so they are re-issued from the scalar cache where they are used.  The LDS-staged problem
+// constants get the same treatment with an opaque vector zero (hoisted LDS loads would pin ~100 VGPRs).
+#define HY_FRESH_THETA(ptr)                     \
+    do {                                        \
+        unsigned z_ = 0;                        \
+        asm volatile("" : "+s"(z_));            \
+        (ptr) = theta + z_;                     \
     } while (0)
-// same for the problem constants staged in LDS (hoisted LDS loads would pin ~100 VGPRs for the whole kernel)
-#define HY_FRESH_KC(ptr)                                                                      \
-    do {                                                                                      \
-        unsigned lo_ = (unsigned)(uintptr_t)(ptr), hi_ = (unsigned)((uintptr_t)(ptr) >> 32);  \
-        asm volatile("" : "+v"(lo_), "+v"(hi_));                                              \
-        (ptr) = (const KConst *)(((uintptr_t)hi_ << 32) | (uintptr_t)lo_);                    \
+#define HY_FRESH_KC(ptr)                                             \
+    do {                                                             \
+        unsigned z_ = 0;                                             \
+        asm volatile("" : "+v"(z_));                                 \
+        (ptr) = reinterpret_cast<const KConst *>(kc_lds + z_);       \
     } while (0)
+
+// timing ablations of the gradient-accumulator traffic (tools/kvariants.sh): 1 = plain stores, 2 = dropped
+#ifndef HY_ABL
+#define HY_ABL 0
+#endif
+#if HY_ABL == 0
+#define HY_ACC(ptr, val) unsafeAtomicAdd((ptr), (val))
+#elif HY_ABL == 1
+#define HY_ACC(ptr, val) (*(ptr) = (val))
+#else
+#define HY_ACC(ptr, val) asm volatile("" ::"v"(val))
+#endif
 
 namespace crnn {
 
@@ -64,12 +74,128 @@ struct LayH {
     __device__ __forceinline__ static constexpr int wo(int i, int j) { return (NF + 1) * NR + i + NS * j; }
 };
 
+// Make register values opaque to the IR optimiser at a phase boundary (costs no instruction): without it the
+// unrolled contractions of adjacent phases are fused / re-associated into forms with hundreds of live values.
+template <int N>
+__device__ __forceinline__ void opaque(double (&a)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(a[i]));
+}
+__device__ __forceinline__ void opaque(double &a) { asm volatile("" : "+v"(a)); }
+
 template <int NS, int NR>
 struct HyPoint {
     double Y[NS], x[NS + 2], r[NR], f[NS];
     double irho, iS;
     unsigned cY, cC;     // bit i: u_i (C_i) inside its clamp window
 };
+
+// W's factors live in LDS (element (i,c) of a lane at As[(i*NS+c)*BLOCK]): 81 doubles per trajectory are the single
+// largest item of the live set, and they are touched in bursts (factor, 3-4 solves) -- registers are kept for the
+// vectors.  P A = L U with partial pivoting; rows are swapped in place.
+template <int NS, int BLOCK>
+__device__ __forceinline__ bool lu_factor_lds(double *As, double (&dinv)[NS], int (&piv)[NS], bool &anyp) {
+    bool ok = true;
+    anyp = false;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        int p = k;
+        double best = fabs(As[(k * NS + k) * BLOCK]);
+#pragma unroll
+        for (int i = k + 1; i < NS; ++i) {
+            const double v = fabs(As[(i * NS + k) * BLOCK]);
+            if (v > best) { best = v; p = i; }
+        }
+        piv[k] = p;
+        if (p != k) {
+            anyp = true;
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+                const double a = As[(k * NS + c) * BLOCK], b = As[(p * NS + c) * BLOCK];
+                As[(k * NS + c) * BLOCK] = b;
+                As[(p * NS + c) * BLOCK] = a;
+            }
+        }
+        double rowk[NS];
+#pragma unroll
+        for (int c = k; c < NS; ++c) rowk[c] = As[(k * NS + c) * BLOCK];
+        ok = ok && (rowk[k] != 0.0);
+        const double inv = frcp(rowk[k]);
+        dinv[k] = inv;
+#pragma unroll
+        for (int i = k + 1; i < NS; ++i) {
+            const double l = As[(i * NS + k) * BLOCK] * inv;
+            As[(i * NS + k) * BLOCK] = l;
+#pragma unroll
+            for (int c = k + 1; c < NS; ++c) As[(i * NS + c) * BLOCK] = fma(-l, rowk[c], As[(i * NS + c) * BLOCK]);
+        }
+        CRNN_SCHED_FENCE();
+    }
+    return ok;
+}
+
+template <int NS, int BLOCK>
+__device__ __forceinline__ void lu_solve_lds(const double *As, const double (&dinv)[NS], const int (&piv)[NS],
+                                             const bool wave_pivots, double (&b)[NS]) {
+    if (wave_pivots) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int p = piv[k];
+#pragma unroll
+            for (int i = k + 1; i < NS; ++i) {
+                const bool sw = (p == i);
+                const double bk = b[k], bi = b[i];
+                b[k] = sw ? bi : bk;
+                b[i] = sw ? bk : bi;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const double a = b[k];
+#pragma unroll
+        for (int i = k + 1; i < NS; ++i) b[i] = fma(-As[(i * NS + k) * BLOCK], a, b[i]);
+    }
+#pragma unroll
+    for (int k = NS - 1; k >= 0; --k) {
+        b[k] *= dinv[k];
+        const double a = b[k];
+#pragma unroll
+        for (int i = 0; i < k; ++i) b[i] = fma(-As[(i * NS + k) * BLOCK], a, b[i]);
+    }
+}
+
+// A^T x = b:  x = P^T L^-T U^-T b
+template <int NS, int BLOCK>
+__device__ __forceinline__ void lu_solve_T_lds(const double *As, const double (&dinv)[NS], const int (&piv)[NS],
+                                               const bool wave_pivots, double (&b)[NS]) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        b[k] *= dinv[k];
+        const double a = b[k];
+#pragma unroll
+        for (int i = k + 1; i < NS; ++i) b[i] = fma(-As[(k * NS + i) * BLOCK], a, b[i]);
+    }
+#pragma unroll
+    for (int k = NS - 1; k >= 0; --k) {
+        const double a = b[k];
+#pragma unroll
+        for (int i = 0; i < k; ++i) b[i] = fma(-As[(k * NS + i) * BLOCK], a, b[i]);
+    }
+    if (wave_pivots) {
+#pragma unroll
+        for (int k = NS - 1; k >= 0; --k) {
+            const int p = piv[k];
+#pragma unroll
+            for (int i = k + 1; i < NS; ++i) {
+                const bool sw = (p == i);
+                const double bk = b[k], bi = b[i];
+                b[k] = sw ? bi : bk;
+                b[i] = sw ? bk : bi;
+            }
+        }
+    }
+}
 
 // point evaluation: features, rates, f
 template <int NS, int NR>
@@ -98,13 +224,28 @@ __device__ __forceinline__ void hy_point(const double *th, const KConst *kc, con
         cl[i] = c;
     }
     cl[NS] = T;
-    flog_vec<NS + 1>(cl, lg);
+    {   // two half-width batches: the element-innermost log keeps ~6 temporaries per element alive
+        constexpr int H = (NS + 1) / 2;
+        double a_[H], la_[H], b_[NS + 1 - H], lb_[NS + 1 - H];
+#pragma unroll
+        for (int i = 0; i < H; ++i) a_[i] = cl[i];
+#pragma unroll
+        for (int i = H; i < NS + 1; ++i) b_[i - H] = cl[i];
+        flog_vec<H>(a_, la_);
+        CRNN_SCHED_FENCE();
+        flog_vec<NS + 1 - H>(b_, lb_);
+#pragma unroll
+        for (int i = 0; i < H; ++i) lg[i] = la_[i];
+#pragma unroll
+        for (int i = H; i < NS + 1; ++i) lg[i] = lb_[i - H];
+    }
 #pragma unroll
     for (int i = 0; i < NS; ++i) pt.x[i] = lg[i];
     pt.x[NS] = inv_R * frcp(T);
     pt.x[NS + 1] = lg[NS];
     pt.cY = cY;
     pt.cC = cC;
+    CRNN_SCHED_FENCE();
     double z[NR];
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
@@ -112,22 +253,40 @@ __device__ __forceinline__ void hy_point(const double *th, const KConst *kc, con
 #pragma unroll
         for (int m = 0; m < NS + 2; ++m) zz = fma(th[L_::wi(m, j)], pt.x[m], zz);
         z[j] = zz;
+        if (j & 1) CRNN_SCHED_FENCE();   // at most two columns of w_in (44 SGPRs) in flight
     }
-    fexp_vec<NR>(z, pt.r);
+    CRNN_SCHED_FENCE();
+    {
+        constexpr int H = NR / 2;
+        double a_[H], ea_[H], b_[NR - H], eb_[NR - H];
+#pragma unroll
+        for (int j = 0; j < H; ++j) a_[j] = z[j];
+#pragma unroll
+        for (int j = H; j < NR; ++j) b_[j - H] = z[j];
+        fexp_vec<H>(a_, ea_);
+        CRNN_SCHED_FENCE();
+        fexp_vec<NR - H>(b_, eb_);
+#pragma unroll
+        for (int j = 0; j < H; ++j) pt.r[j] = ea_[j];
+#pragma unroll
+        for (int j = H; j < NR; ++j) pt.r[j] = eb_[j - H];
+    }
+    CRNN_SCHED_FENCE();
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         double a = 0.0;
 #pragma unroll
         for (int j = 0; j < NR; ++j) a = fma(th[L_::wo(i, j)], pt.r[j], a);
         pt.f[i] = a * kc->gsc[i] * pt.irho;
+        if (i & 1) CRNN_SCHED_FENCE();   // at most two rows of w_out in flight
     }
 }
 
-// W = I - gam J(u_n) (dense, row-major A[i][c]) and ft = df/dt at the point
-template <int NS, int NR>
+// W = I - gam J(u_n) (dense, written to the lane's LDS matrix) and ft = df/dt at the point
+template <int NS, int NR, int BLOCK>
 __device__ __forceinline__ void hy_jac_ft(const double *th, const KConst *kc, const HyPoint<NS, NR> &pt,
                                           const double gam, const double ld, const double xEd, const double xLd,
-                                          double (&A)[NS][NS], double (&ft)[NS]) {
+                                          double *As, double (&ft)[NS]) {
     using L_ = LayH<NS, NR>;
     double gx[NS], sg[NS], Bj[NR], zd[NR];
 #pragma unroll
@@ -161,8 +320,9 @@ __device__ __forceinline__ void hy_jac_ft(const double *th, const KConst *kc, co
 #pragma unroll
             for (int j = 0; j < NR; ++j) s_ = fma(a[j], th[L_::wi(c, j)], s_);
             const double Jic = fma(gx[c], s_, -sg[c] * (tB - pt.f[i]));
-            A[i][c] = ((i == c) ? 1.0 : 0.0) - gam * Jic;
+            As[(i * NS + c) * BLOCK] = ((i == c) ? 1.0 : 0.0) - gam * Jic;
         }
+        CRNN_SCHED_FENCE();   // one row at a time: a[], its sums and nine outputs
     }
 }
 
@@ -172,9 +332,15 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
     using L_ = LayH<NS, NR>;
     constexpr int NTH = L_::NTH;
     constexpr int RECW = NS + 2;
+    constexpr int NPARK = (NS + 2) + NR + NS + 2 + 2 * NS + NR;   // x, r, Y, irho, iS of the u_n point; k1; k2 - k1; r at u_mid
+    constexpr int PK_R1 = (NS + 2) + NR + NS + 2 + 2 * NS;
     __shared__ double kc_lds[kNConst];
     __shared__ double ts_lds[kMaxSave];
+    __shared__ double A_lds[NS * NS * BLOCK];
+    __shared__ double park_lds[GRAD ? NPARK * BLOCK : 1];
     const int tid = threadIdx.x;
+    double *const As = A_lds + tid;
+    double *const park = park_lds + (GRAD ? tid : 0);
     for (int idx = tid; idx < kNConst; idx += BLOCK) kc_lds[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
     for (int idx = tid; idx < hp.n_save_total; idx += BLOCK) ts_lds[idx] = prm.tsave[idx];
     __syncthreads();
@@ -287,16 +453,17 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
                     const double tnew = last ? tend : t + dt;
                     double T, P, Td, Pd;
                     tab(t, T, P, Td, Pd);
-                    double A[NS][NS], dinv[NS], ft[NS];
+                    double dinv[NS], ft[NS];
                     int piv[NS];
-                    hy_jac_ft<NS, NR>(th, kc, p0, gam, Pd * frcp(P) - Td * frcp(T), -hp.inv_R * Td * frcp(T * T), Td * frcp(T), A, ft);
+                    hy_jac_ft<NS, NR, BLOCK>(th, kc, p0, gam, Pd * frcp(P) - Td * frcp(T), -hp.inv_R * Td * frcp(T * T), Td * frcp(T), As, ft);
                     bool anyp;
-                    const bool okf = lu_factor<NS>(A, dinv, piv, anyp);
+                    const bool okf = lu_factor_lds<NS, BLOCK>(As, dinv, piv, anyp);
                     const bool wp = __builtin_amdgcn_ballot_w64(anyp) != 0;
                     double k1[NS], dk[NS], unew[NS], f1[NS];
 #pragma unroll
                     for (int i = 0; i < NS; ++i) k1[i] = fma(gam, ft[i], p0.f[i]);
-                    lu_solve<NS>(A, dinv, piv, wp, k1);
+                    lu_solve_lds<NS, BLOCK>(As, dinv, piv, wp, k1);
+                    CRNN_SCHED_FENCE();
                     HY_FRESH_THETA(th); HY_FRESH_KC(kc);
                     {
                         double u1[NS];
@@ -308,12 +475,14 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
                         hy_point<NS, NR>(th, kc, hp.inv_R, u1, T1, P1, p1);
 #pragma unroll
                         for (int i = 0; i < NS; ++i) f1[i] = p1.f[i];
+                        opaque(f1);
                     }
 #pragma unroll
                     for (int i = 0; i < NS; ++i) dk[i] = f1[i] - k1[i];
-                    lu_solve<NS>(A, dinv, piv, wp, dk);
+                    lu_solve_lds<NS, BLOCK>(As, dinv, piv, wp, dk);
 #pragma unroll
                     for (int i = 0; i < NS; ++i) unew[i] = fma(dt, k1[i] + dk[i], u[i]);
+                    CRNN_SCHED_FENCE();
                     HyPoint<NS, NR> p2;
                     HY_FRESH_THETA(th); HY_FRESH_KC(kc);
                     {
@@ -321,13 +490,14 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
                         tab(tnew, T2, P2, a_, b_);
                         hy_point<NS, NR>(th, kc, hp.inv_R, unew, T2, P2, p2);
                     }
+                    CRNN_SCHED_FENCE();
                     double k3[NS];
 #pragma unroll
                     for (int i = 0; i < NS; ++i) {
                         const double k2i = k1[i] + dk[i];
                         k3[i] = fma(dt, ft[i], p2.f[i] - c32 * (k2i - f1[i]) - 2.0 * (k1[i] - p0.f[i]));
                     }
-                    lu_solve<NS>(A, dinv, piv, wp, k3);
+                    lu_solve_lds<NS, BLOCK>(As, dinv, piv, wp, k3);
                     double es = 0.0;
                     bool finite = okf;
 #pragma unroll
@@ -404,7 +574,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
         double tnew = t;
         int s = valid ? nacc - 1 : -1;
         double *const gacc = hp.gacc + (size_t)(wave_base >> 6) * NTH * 64 + lane;   // accumulator m at gacc[m * 64]
-#define HY_ADD(m, val) unsafeAtomicAdd(&gacc[(size_t)(m) * 64], (val))
+#define HY_ADD(m, val) HY_ACC(&gacc[(size_t)(m) * 64], (val))
         const double *const drows = prm.data + (size_t)b * prm.row_stride;
         int doff[NS];
 #pragma unroll
@@ -428,9 +598,6 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
                 double un[NS];
 #pragma unroll
                 for (int i = 0; i < NS; ++i) un[i] = ru[i];
-                double dA[NS], dB[NS];
-                load_row(jsave - 1, dA);
-                load_row(jsave - 2, dB);
                 {
                     const double *rec = tape + (size_t)(s > 0 ? s - 1 : 0) * RECW;
                     rt = rec[0]; rdt = rec[1];
@@ -445,17 +612,20 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
                 const double ld = Pd * frcp(P) - Td * frcp(T), xEd = -hp.inv_R * Td * frcp(T * T), xLd = Td * frcp(T);
                 HyPoint<NS, NR> pn, pm;
                 hy_point<NS, NR>(th, kc, hp.inv_R, un, T, P, pn);
+                // opaque to the optimiser from here: otherwise the Jacobian build is fused into the point evaluation
+                // (products of rates and weights formed early, ~200 values live)
+                opaque(pn.r); opaque(pn.Y); opaque(pn.f); opaque(pn.x); opaque(pn.irho); opaque(pn.iS);
                 HY_FRESH_THETA(th); HY_FRESH_KC(kc);
-                double A[NS][NS], dinv[NS], ft[NS];
+                double dinv[NS], ft[NS];
                 int piv[NS];
-                hy_jac_ft<NS, NR>(th, kc, pn, gam, ld, xEd, xLd, A, ft);
+                hy_jac_ft<NS, NR, BLOCK>(th, kc, pn, gam, ld, xEd, xLd, As, ft);
                 bool anyp;
-                (void)lu_factor<NS>(A, dinv, piv, anyp);
+                (void)lu_factor_lds<NS, BLOCK>(As, dinv, piv, anyp);
                 const bool wp = __builtin_amdgcn_ballot_w64(anyp) != 0;
                 double k1[NS], dk[NS];
 #pragma unroll
                 for (int i = 0; i < NS; ++i) k1[i] = fma(gam, ft[i], pn.f[i]);
-                lu_solve<NS>(A, dinv, piv, wp, k1);
+                lu_solve_lds<NS, BLOCK>(As, dinv, piv, wp, k1);
                 HY_FRESH_THETA(th); HY_FRESH_KC(kc);
                 {
                     double u1[NS], T1, P1, a_, b_;
@@ -463,10 +633,22 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
                     for (int i = 0; i < NS; ++i) u1[i] = fma(0.5 * h, k1[i], un[i]);
                     tab(tn + 0.5 * h, T1, P1, a_, b_);
                     hy_point<NS, NR>(th, kc, hp.inv_R, u1, T1, P1, pm);
+                    opaque(pm.r); opaque(pm.Y); opaque(pm.f); opaque(pm.x); opaque(pm.irho); opaque(pm.iS);
                 }
 #pragma unroll
                 for (int i = 0; i < NS; ++i) dk[i] = pm.f[i] - k1[i];
-                lu_solve<NS>(A, dinv, piv, wp, dk);
+                lu_solve_lds<NS, BLOCK>(As, dinv, piv, wp, dk);
+                const unsigned ncY = pn.cY, ncC = pn.cC;
+                if (GRAD) {   // park the u_n point: it is needed again only by the last phase of the step
+#pragma unroll
+                    for (int m = 0; m < NS + 2; ++m) park[m * BLOCK] = pn.x[m];
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) park[(NS + 2 + j) * BLOCK] = pn.r[j];
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) park[(NS + 2 + NR + i) * BLOCK] = pn.Y[i];
+                    park[(2 * NS + 2 + NR) * BLOCK] = pn.irho;
+                    park[(2 * NS + 3 + NR) * BLOCK] = pn.iS;
+                }
                 CRNN_SCHED_FENCE();
 
                 // ---- loss and seeds at the save points inside (tn, tnew]
@@ -504,51 +686,53 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
                     }
                     --jsave;
                 };
-                if (in_step()) {
-                    seed_point(dA);
-                    if (in_step()) {
-                        seed_point(dB);
-                        while (in_step()) {
-                            double dD[NS];
-                            load_row(jsave - 1, dD);
-                            seed_point(dD);
-                        }
-                    }
+                while (in_step()) {
+                    double dD[NS];
+                    load_row(jsave - 1, dD);
+                    seed_point(dD);
                 }
 
                 if (GRAD) {
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) { park[(2 * NS + 4 + NR + i) * BLOCK] = k1[i]; park[(3 * NS + 4 + NR + i) * BLOCK] = dk[i]; }
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) park[(PK_R1 + j) * BLOCK] = pm.r[j];
                     CRNN_SCHED_FENCE();
                     double kb1[NS], v[NS], ub[NS];
 #pragma unroll
                     for (int i = 0; i < NS; ++i) { v[i] = fma(h, lam[i], B2[i]); ub[i] = lam[i] + A_[i]; kb1[i] = B1[i] + v[i]; }
-                    lu_solve_T<NS>(A, dinv, piv, wp, v);
+                    lu_solve_T_lds<NS, BLOCK>(As, dinv, piv, wp, v);
 #pragma unroll
                     for (int i = 0; i < NS; ++i) kb1[i] -= v[i];
                     double vt[NS];
 #pragma unroll
                     for (int i = 0; i < NS; ++i) vt[i] = v[i] * kc->gsc[i];
+                    opaque(vt); opaque(kb1); opaque(ub);
                     CRNN_SCHED_FENCE();
                     HY_FRESH_THETA(th); HY_FRESH_KC(kc);
-                    // -------- point u_mid: adjoint of v.f
+                    // -------- point u_mid: adjoint of v.f   (a rolled loop over the reactions: 20 weights in flight)
                     {
                         double P2[NS], psi = 0.0;
 #pragma unroll
                         for (int m = 0; m < NS; ++m) P2[m] = 0.0;
-#pragma unroll
+#pragma unroll 1
                         for (int j = 0; j < NR; ++j) {
+                            const double *wo_ = th + L_::wo(0, j), *wi_ = th + L_::wi(0, j);
                             double At = 0.0;
 #pragma unroll
-                            for (int i = 0; i < NS; ++i) At = fma(vt[i], th[L_::wo(i, j)], At);
-                            const double ir = pm.irho * pm.r[j];
+                            for (int i = 0; i < NS; ++i) At = fma(vt[i], wo_[i], At);
+                            const double ir = pm.irho * park[(PK_R1 + j) * BLOCK];
                             const double Psi = At * ir;
                             psi += Psi;
-                            HY_ADD(L_::wb(j), Psi);
+                            double *gj = gacc + (size_t)L_::wi(0, j) * 64;
+                            HY_ACC(gacc + (size_t)L_::wb(j) * 64, Psi);
 #pragma unroll
-                            for (int m = 0; m < NS + 2; ++m) HY_ADD(L_::wi(m, j), Psi * pm.x[m]);
+                            for (int m = 0; m < NS + 2; ++m) HY_ACC(gj + (size_t)m * 64, Psi * pm.x[m]);
+                            double *go = gacc + (size_t)L_::wo(0, j) * 64;
 #pragma unroll
-                            for (int i = 0; i < NS; ++i) HY_ADD(L_::wo(i, j), vt[i] * ir);
+                            for (int i = 0; i < NS; ++i) HY_ACC(go + (size_t)i * 64, vt[i] * ir);
 #pragma unroll
-                            for (int m = 0; m < NS; ++m) P2[m] = fma(Psi, th[L_::wi(m, j)], P2[m]);
+                            for (int m = 0; m < NS; ++m) P2[m] = fma(Psi, wi_[m], P2[m]);
                         }
                         double scp = 0.0;
 #pragma unroll
@@ -563,11 +747,28 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
                         }
                     }
                     CRNN_SCHED_FENCE();
-                    lu_solve_T<NS>(A, dinv, piv, wp, kb1);     // kb1 = w
+                    lu_solve_T_lds<NS, BLOCK>(As, dinv, piv, wp, kb1);     // kb1 = w
+                    opaque(kb1); opaque(ub); opaque(vt);
                     CRNN_SCHED_FENCE();
                     HY_FRESH_THETA(th); HY_FRESH_KC(kc);
                     // -------- point u_n: adjoint of w.f + gam ( v.Df[(dk,0)] + w.Df[(k1,1)] )
                     {
+                        // reload the parked u_n point and the stages (through a laundered pointer: otherwise the
+                        // compiler forwards the stored values and keeps them in registers after all)
+                        unsigned zp_ = 0;
+                        asm volatile("" : "+v"(zp_));
+                        const double *pk = park + zp_;
+                        HyPoint<NS, NR> pn;
+                        double k1[NS], dk[NS];
+#pragma unroll
+                        for (int m = 0; m < NS + 2; ++m) pn.x[m] = pk[m * BLOCK];
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) pn.Y[i] = pk[(NS + 2 + NR + i) * BLOCK];
+                        pn.irho = pk[(2 * NS + 2 + NR) * BLOCK];
+                        pn.iS = pk[(2 * NS + 3 + NR) * BLOCK];
+                        pn.cY = ncY; pn.cC = ncC;
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) { k1[i] = pk[(2 * NS + 4 + NR + i) * BLOCK]; dk[i] = pk[(3 * NS + 4 + NR + i) * BLOCK]; }
                         double wt[NS];
 #pragma unroll
                         for (int i = 0; i < NS; ++i) wt[i] = kb1[i] * kc->gsc[i];
@@ -592,39 +793,39 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
                         double PE[NS], P2v[NS], P2w[NS], SE = 0.0, psiv = 0.0, psiw = 0.0;
 #pragma unroll
                         for (int m = 0; m < NS; ++m) { PE[m] = 0.0; P2v[m] = 0.0; P2w[m] = 0.0; }
-#pragma unroll
+#pragma unroll 1
                         for (int j = 0; j < NR; ++j) {
+                            const double *wo_ = th + L_::wo(0, j), *wi_ = th + L_::wi(0, j);
                             double Av = 0.0, Aw = 0.0, zv = 0.0, zw = 0.0;
 #pragma unroll
                             for (int i = 0; i < NS; ++i) {
-                                const double wo = th[L_::wo(i, j)];
-                                Av = fma(vt[i], wo, Av);
-                                Aw = fma(wt[i], wo, Aw);
+                                Av = fma(vt[i], wo_[i], Av);
+                                Aw = fma(wt[i], wo_[i], Aw);
                             }
 #pragma unroll
                             for (int m = 0; m < NS + 2; ++m) {
-                                const double wi = th[L_::wi(m, j)];
-                                zv = fma(wi, xpv[m], zv);
-                                zw = fma(wi, xpw[m], zw);
+                                zv = fma(wi_[m], xpv[m], zv);
+                                zw = fma(wi_[m], xpw[m], zw);
                             }
-                            const double ir = pn.irho * pn.r[j];
+                            const double ir = pn.irho * pk[(NS + 2 + j) * BLOCK];
                             const double Pv = Av * ir, Pw = Aw * ir;
                             const double yv = zv - lpv, yw = zw - lpw;
                             const double cw = fma(gam, yw, 1.0), cv = gam * yv;
                             const double E = fma(Pw, cw, Pv * cv);
                             SE += E; psiv += Pv; psiw += Pw;
-                            HY_ADD(L_::wb(j), E);
+                            HY_ACC(gacc + (size_t)L_::wb(j) * 64, E);
                             const double gPv = gam * Pv, gPw = gam * Pw;
+                            double *gj = gacc + (size_t)L_::wi(0, j) * 64;
 #pragma unroll
-                            for (int m = 0; m < NS + 2; ++m) HY_ADD(L_::wi(m, j), fma(E, pn.x[m], fma(gPw, xpw[m], gPv * xpv[m])));
+                            for (int m = 0; m < NS + 2; ++m) HY_ACC(gj + (size_t)m * 64, fma(E, pn.x[m], fma(gPw, xpw[m], gPv * xpv[m])));
+                            double *go = gacc + (size_t)L_::wo(0, j) * 64;
 #pragma unroll
-                            for (int i = 0; i < NS; ++i) HY_ADD(L_::wo(i, j), ir * fma(wt[i], cw, vt[i] * cv));
+                            for (int i = 0; i < NS; ++i) HY_ACC(go + (size_t)i * 64, ir * fma(wt[i], cw, vt[i] * cv));
 #pragma unroll
                             for (int m = 0; m < NS; ++m) {
-                                const double wi = th[L_::wi(m, j)];
-                                PE[m] = fma(E, wi, PE[m]);
-                                P2v[m] = fma(Pv, wi, P2v[m]);
-                                P2w[m] = fma(Pw, wi, P2w[m]);
+                                PE[m] = fma(E, wi_[m], PE[m]);
+                                P2v[m] = fma(Pv, wi_[m], P2v[m]);
+                                P2w[m] = fma(Pw, wi_[m], P2w[m]);
                             }
                         }
                         double scE = 0.0, scv = 0.0, scw = 0.0;
