@@ -23,16 +23,16 @@
 #pragma once
 #include "ros23_adj_kernel.hpp"
 
-// theta is 210 doubles: hoisting its (loop-invariant) scalar loads out of the step loops would need 420 SGPRs and ends
-// in SGPR->VGPR->scratch spills.  At the top of each phase the pointer is re-derived as theta + z with z an opaque
-// scalar zero (empty asm): the loads stay scalar loads from the (global, restrict) kernel argument but cannot be
-// hoisted above the asm, so they are re-issued from the scalar cache where they are used.  The LDS-staged problem
-// constants get the same treatment with an opaque vector zero (hoisted LDS loads would pin ~100 VGPRs).
+// theta is 210 doubles.  As scalar loads (the case2 kernels' choice) it does not work here: hoisted out of the step
+// loops it needs 420 SGPRs, and re-issued per phase the wave spends 45 % of its cycles in s_waitcnt on ~450 scalar loads
+// per step (SQ counters, profiles/).  It is staged in LDS once per block and read with broadcast ds_read; at the top of
+// each phase the pointer is re-derived with an opaque zero offset (empty asm) so that the loads are not hoisted out of
+// the loops (they would pin VGPRs for the whole kernel).  The LDS-staged problem constants get the same treatment.
 #define HY_FRESH_THETA(ptr)                     \
     do {                                        \
         unsigned z_ = 0;                        \
-        asm volatile("" : "+s"(z_));            \
-        (ptr) = theta + z_;                     \
+        asm volatile("" : "+v"(z_));            \
+        (ptr) = th_lds + z_;                    \
     } while (0)
 #define HY_FRESH_KC(ptr)                                             \
     do {                                                             \
@@ -131,6 +131,18 @@ __device__ __forceinline__ bool lu_factor_lds(double *As, double (&dinv)[NS], in
         }
         CRNN_SCHED_FENCE();
     }
+    return ok;
+}
+
+// factor in registers (independent updates pipeline in the VALU; an in-place LDS factorisation is a chain of
+// read-modify-write latencies), then park the factors in LDS for the 3-4 solves of the step
+template <int NS, int BLOCK>
+__device__ __forceinline__ bool lu_factor_to_lds(double (&A)[NS][NS], double *As, double (&dinv)[NS], int (&piv)[NS], bool &anyp) {
+    const bool ok = lu_factor<NS>(A, dinv, piv, anyp);
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int c = 0; c < NS; ++c) As[(i * NS + c) * BLOCK] = A[i][c];
     return ok;
 }
 
@@ -282,11 +294,11 @@ __device__ __forceinline__ void hy_point(const double *th, const KConst *kc, con
     }
 }
 
-// W = I - gam J(u_n) (dense, written to the lane's LDS matrix) and ft = df/dt at the point
+// W = I - gam J(u_n) (dense, in registers for the factorisation) and ft = df/dt at the point
 template <int NS, int NR, int BLOCK>
 __device__ __forceinline__ void hy_jac_ft(const double *th, const KConst *kc, const HyPoint<NS, NR> &pt,
                                           const double gam, const double ld, const double xEd, const double xLd,
-                                          double *As, double (&ft)[NS]) {
+                                          double (&A)[NS][NS], double (&ft)[NS]) {
     using L_ = LayH<NS, NR>;
     double gx[NS], sg[NS], Bj[NR], zd[NR];
 #pragma unroll
@@ -320,7 +332,7 @@ __device__ __forceinline__ void hy_jac_ft(const double *th, const KConst *kc, co
 #pragma unroll
             for (int j = 0; j < NR; ++j) s_ = fma(a[j], th[L_::wi(c, j)], s_);
             const double Jic = fma(gx[c], s_, -sg[c] * (tB - pt.f[i]));
-            As[(i * NS + c) * BLOCK] = ((i == c) ? 1.0 : 0.0) - gam * Jic;
+            A[i][c] = ((i == c) ? 1.0 : 0.0) - gam * Jic;
         }
         CRNN_SCHED_FENCE();   // one row at a time: a[], its sums and nine outputs
     }
@@ -336,6 +348,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
     constexpr int PK_R1 = (NS + 2) + NR + NS + 2 + 2 * NS;
     __shared__ double kc_lds[kNConst];
     __shared__ double ts_lds[kMaxSave];
+    __shared__ double th_lds[NTH];
     __shared__ double A_lds[NS * NS * BLOCK];
     __shared__ double park_lds[GRAD ? NPARK * BLOCK : 1];
     const int tid = threadIdx.x;
@@ -343,9 +356,10 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
     double *const park = park_lds + (GRAD ? tid : 0);
     for (int idx = tid; idx < kNConst; idx += BLOCK) kc_lds[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
     for (int idx = tid; idx < hp.n_save_total; idx += BLOCK) ts_lds[idx] = prm.tsave[idx];
+    for (int idx = tid; idx < NTH; idx += BLOCK) th_lds[idx] = theta[idx];
     __syncthreads();
     const KConst *kc = reinterpret_cast<const KConst *>(kc_lds);
-    const double *th = theta;
+    const double *th = th_lds;
 
     const double d_ = 0.29289321881345248, c32 = 7.4142135623730950, inv12d = 2.4142135623730950;
     const int nsave = prm.n_save, Dfull = hp.n_save_total;
@@ -455,9 +469,13 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
                     tab(t, T, P, Td, Pd);
                     double dinv[NS], ft[NS];
                     int piv[NS];
-                    hy_jac_ft<NS, NR, BLOCK>(th, kc, p0, gam, Pd * frcp(P) - Td * frcp(T), -hp.inv_R * Td * frcp(T * T), Td * frcp(T), As, ft);
-                    bool anyp;
-                    const bool okf = lu_factor_lds<NS, BLOCK>(As, dinv, piv, anyp);
+                    bool anyp, okf;
+                    {
+                        double A[NS][NS];
+                        hy_jac_ft<NS, NR, BLOCK>(th, kc, p0, gam, Pd * frcp(P) - Td * frcp(T), -hp.inv_R * Td * frcp(T * T), Td * frcp(T), A, ft);
+                        CRNN_SCHED_FENCE();
+                        okf = lu_factor_to_lds<NS, BLOCK>(A, As, dinv, piv, anyp);
+                    }
                     const bool wp = __builtin_amdgcn_ballot_w64(anyp) != 0;
                     double k1[NS], dk[NS], unew[NS], f1[NS];
 #pragma unroll
@@ -618,13 +636,30 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
                 HY_FRESH_THETA(th); HY_FRESH_KC(kc);
                 double dinv[NS], ft[NS];
                 int piv[NS];
-                hy_jac_ft<NS, NR, BLOCK>(th, kc, pn, gam, ld, xEd, xLd, As, ft);
                 bool anyp;
-                (void)lu_factor_lds<NS, BLOCK>(As, dinv, piv, anyp);
-                const bool wp = __builtin_amdgcn_ballot_w64(anyp) != 0;
+                unsigned ncY = 0, ncC = 0;
                 double k1[NS], dk[NS];
+                {
+                    double A[NS][NS];
+                    hy_jac_ft<NS, NR, BLOCK>(th, kc, pn, gam, ld, xEd, xLd, A, ft);
 #pragma unroll
-                for (int i = 0; i < NS; ++i) k1[i] = fma(gam, ft[i], pn.f[i]);
+                    for (int i = 0; i < NS; ++i) k1[i] = fma(gam, ft[i], pn.f[i]);
+                    ncY = pn.cY; ncC = pn.cC;
+                    if (GRAD) {   // park the u_n point: it is needed again only by the last phase of the step
+#pragma unroll
+                        for (int m = 0; m < NS + 2; ++m) park[m * BLOCK] = pn.x[m];
+#pragma unroll
+                        for (int j = 0; j < NR; ++j) park[(NS + 2 + j) * BLOCK] = pn.r[j];
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) park[(NS + 2 + NR + i) * BLOCK] = pn.Y[i];
+                        park[(2 * NS + 2 + NR) * BLOCK] = pn.irho;
+                        park[(2 * NS + 3 + NR) * BLOCK] = pn.iS;
+                    }
+                    opaque(k1);
+                    CRNN_SCHED_FENCE();
+                    (void)lu_factor_to_lds<NS, BLOCK>(A, As, dinv, piv, anyp);
+                }
+                const bool wp = __builtin_amdgcn_ballot_w64(anyp) != 0;
                 lu_solve_lds<NS, BLOCK>(As, dinv, piv, wp, k1);
                 HY_FRESH_THETA(th); HY_FRESH_KC(kc);
                 {
@@ -638,17 +673,6 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
 #pragma unroll
                 for (int i = 0; i < NS; ++i) dk[i] = pm.f[i] - k1[i];
                 lu_solve_lds<NS, BLOCK>(As, dinv, piv, wp, dk);
-                const unsigned ncY = pn.cY, ncC = pn.cC;
-                if (GRAD) {   // park the u_n point: it is needed again only by the last phase of the step
-#pragma unroll
-                    for (int m = 0; m < NS + 2; ++m) park[m * BLOCK] = pn.x[m];
-#pragma unroll
-                    for (int j = 0; j < NR; ++j) park[(NS + 2 + j) * BLOCK] = pn.r[j];
-#pragma unroll
-                    for (int i = 0; i < NS; ++i) park[(NS + 2 + NR + i) * BLOCK] = pn.Y[i];
-                    park[(2 * NS + 2 + NR) * BLOCK] = pn.irho;
-                    park[(2 * NS + 3 + NR) * BLOCK] = pn.iS;
-                }
                 CRNN_SCHED_FENCE();
 
                 // ---- loss and seeds at the save points inside (tn, tnew]
