@@ -80,11 +80,16 @@ __global__ __launch_bounds__(BLOCK) void cathode_kernel(const CathodeParams prm)
     __shared__ double db_s[kCathMaxSets * kCathMaxD];
     __shared__ double d2_s[kCathMaxSets * kCathMaxD];
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < prm.n_sets * prm.Dmax; idx += BLOCK) {
-        const int s = idx / prm.Dmax, i = idx - s * prm.Dmax;
-        ts_s[s * kCathMaxD + i] = prm.ts[idx];
-        db_s[s * kCathMaxD + i] = prm.dbar[idx];
-        d2_s[s * kCathMaxD + i] = prm.d2bar[idx];
+    // up to kCathMaxSets observation sets (the reference's five heating rates) are staged in LDS; larger ensembles of
+    // heating rates (BASELINE config 5: 256) are read in place from HBM/L2 (rows of <= 1 KB, shared by all particles)
+    const bool staged = prm.n_sets <= kCathMaxSets;
+    if (staged) {
+        for (int idx = tid; idx < prm.n_sets * prm.Dmax; idx += BLOCK) {
+            const int s = idx / prm.Dmax, i = idx - s * prm.Dmax;
+            ts_s[s * kCathMaxD + i] = prm.ts[idx];
+            db_s[s * kCathMaxD + i] = prm.dbar[idx];
+            d2_s[s * kCathMaxD + i] = prm.d2bar[idx];
+        }
     }
     __syncthreads();
 
@@ -136,7 +141,8 @@ __global__ __launch_bounds__(BLOCK) void cathode_kernel(const CathodeParams prm)
 #pragma unroll
             for (int k = 0; k < kCathNP; ++k) th[k] = prm.theta[(size_t)part * kCathNP + k];
             D = prm.D[set];
-            tsv = ts_s + set * kCathMaxD; dbv = db_s + set * kCathMaxD; d2v = d2_s + set * kCathMaxD;
+            if (staged) { tsv = ts_s + set * kCathMaxD; dbv = db_s + set * kCathMaxD; d2v = d2_s + set * kCathMaxD; }
+            else { tsv = prm.ts + (size_t)set * prm.Dmax; dbv = prm.dbar + (size_t)set * prm.Dmax; d2v = prm.d2bar + (size_t)set * prm.Dmax; }
             Tdot = prm.beta[set] * (1.0 / 60.0);
             t0 = tsv[0];
             tend = tsv[D - 1];

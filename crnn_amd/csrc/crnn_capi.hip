@@ -1217,7 +1217,7 @@ int32_t crnn_cathode_set_obs(crnn_cathode_ctx *ctx, int32_t n_sets, int32_t Dmax
     CathCtx *c = reinterpret_cast<CathCtx *>(ctx);
     if (!c) return cfail(nullptr, "null ctx");
     if (!D || !ts || !dbar || !d2bar || !beta) return cfail(c, "crnn_cathode_set_obs: null pointer");
-    if (n_sets < 1 || n_sets > CRNN_CATHODE_MAX_SETS) return cfail(c, "crnn_cathode_set_obs: n_sets must be in [1, 8]");
+    if (n_sets < 1 || n_sets > CRNN_CATHODE_MAX_SETS) return cfail(c, "crnn_cathode_set_obs: n_sets must be in [1, 4096]");
     if (Dmax < 2 || Dmax > CRNN_CATHODE_MAX_D) return cfail(c, "crnn_cathode_set_obs: Dmax must be in [2, 128]");
     for (int s = 0; s < n_sets; ++s) {
         if (D[s] < 2 || D[s] > Dmax) return cfail(c, "crnn_cathode_set_obs: D[s] out of range");

@@ -248,7 +248,7 @@ int32_t crnn_allreduce_grad(crnn_ctx *ctx, double *buf, int32_t n);
  * ======================================================================== */
 #define CRNN_CATHODE_NP 17
 #define CRNN_CATHODE_MAX_D 128
-#define CRNN_CATHODE_MAX_SETS 8
+#define CRNN_CATHODE_MAX_SETS 4096  /* heating rates per context (the first 8 are staged in LDS) */
 typedef struct crnn_cathode_config {
     int32_t abi_version, device, maxiters, reserved0;
     double lb_clamp;   /* config.yaml:6   1e-16 */

@@ -188,6 +188,43 @@ def test_gpu_cathode_many_particles_consistent(cfx):
     assert np.array_equal(grad.reshape(256, 16, 5, 17), np.broadcast_to(g0, (256, 16, 5, 17)))
 
 
+def _many_rates(cfx, n_rates):
+    """n_rates heating rates log-spaced in [2, 20] K/min (BASELINE config 5): each borrows the temperature grid and the
+    replica statistics of the nearest measured rate, its time grid follows from t = (T - 100) * 60 / beta (dataset.jl:19-23)."""
+    betas = np.exp(np.linspace(np.log(2.0), np.log(20.0), n_rates))
+    meas = np.array([s["beta"] for s in cfx["sets"]])
+    exp_data = []
+    for b in betas:
+        s = cfx["sets"][int(np.argmin(np.abs(np.log(meas) - np.log(b))))]
+        e = _two_replicas(s)
+        e[:, 0] = e[:, 0] * s["beta"] / b
+        exp_data.append(e)
+    return betas, exp_data
+
+
+@pytest.mark.gpu
+def test_gpu_cathode_many_heating_rates(orc, cfx):
+    """More heating rates than the LDS stages (8): observation rows are read in place; same results as the oracle."""
+    from crnn_amd.cathode import CathodeUQ
+    betas, exp_data = _many_rates(cfx, 24)
+    uq = CathodeUQ(exp_data, betas, cfx["theta"], normalizer=np.ones((24, 3)))
+    rng = np.random.default_rng(4)
+    p = 1 + 0.03 * rng.standard_normal((3, 17))
+    p[:, 6:9] = 0.0
+    loss, grad, hrr = uq.solve(p, want_hrr=True)
+    assert np.all(uq.last_retcode == 0)
+    ps = np.array(cfx["theta"])
+    for n in range(3):
+        for i in (0, 7, 8, 15, 23):
+            e = exp_data[i]
+            c = orc.make_cathode(betas[i])
+            r = orc.cathode_solve_one(c, p[n] * ps, e[:, 0], e[:, 1:].mean(axis=1), (e[:, 1:] ** 2).mean(axis=1))
+            D = e.shape[0]
+            assert np.max(np.abs(hrr[n, i, :D] - r["hrr"])) < 1e-9 * max(1.0, np.max(np.abs(r["hrr"])))
+            assert abs(loss[n, i] - r["loss"]) < 1e-9 * abs(r["loss"])
+            assert np.max(np.abs(grad[n, i] - r["grad"] * ps)) < 1e-7 * np.max(np.abs(r["grad"] * ps))
+
+
 @pytest.mark.gpu
 def test_gpu_cathode_maxiters_and_bad_inputs(cfx):
     from crnn_amd._lib import CrnnError
