@@ -74,6 +74,15 @@ def svgd_kernel(p, h=-1.0):
     return Kxy, dxkxy / h ** 2
 
 
+def svgd_update(p, lnpgrad, stepsize, h=-1.0):
+    """One SVGD move (crnn_cathode.jl:36-50): p + stepsize * (Kxy * lnpgrad + dxkxy) / N.
+    Returns (p_new, data_term, repulsion)."""
+    p = np.asarray(p, float)
+    Kxy, dxkxy = svgd_kernel(p, h)
+    data_term = Kxy @ np.asarray(lnpgrad, float)
+    return p + stepsize * (data_term + dxkxy) / p.shape[0], data_term, dxkxy
+
+
 class CathodeUQ:
     """exp_data: list of arrays [D_s, 1 + n_replicas] (col 0 = time in s, dataset.jl:19-23), heating_rates in K/min."""
 
@@ -149,6 +158,22 @@ class CathodeUQ:
         loss, grad, _ = self.solve(p, want_grad=True)
         g = grad[:, i_exp, :] / (self.normalizer[i_exp, NORM_COL] ** 2)
         return float(loss[:, i_exp].mean()), -g
+
+    def dlnprob_sharded(self, p, i_exp):
+        """dlnprob with the particles sharded over the ranks of the default torch.distributed group (one process per
+        GPU): each rank solves its contiguous block of particles, one all-gather of [loss | lnpgrad] rows follows, and
+        every rank returns the full (mean loss, lnpgrad[N, 17]) -- so that the replicated SVGD update stays identical."""
+        from .dist import allgather_rows, env_rank, shard_range
+        import torch.distributed as dist
+        p = np.atleast_2d(np.asarray(p, float))
+        N = p.shape[0]
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        rank = dist.get_rank() if world > 1 else 0
+        first, count = shard_range(N, rank, world)
+        loss, grad, _ = self.solve(p[first:first + count], want_grad=True)
+        rows = np.concatenate([loss[:, i_exp:i_exp + 1], -grad[:, i_exp, :] / (self.normalizer[i_exp, NORM_COL] ** 2)], axis=1)
+        full = allgather_rows(rows, N)
+        return float(full[:, 0].mean()), full[:, 1:]
 
     def close(self):
         if self.h:

@@ -125,3 +125,29 @@ class DataParallel:
     def close(self):
         if self.comm == "rccl":
             lib.crnn_comm_destroy(self.node.handle)
+
+
+def allgather_rows(local: np.ndarray, n_total: int, group=None) -> np.ndarray:
+    """Concatenate per-rank row blocks (rank r holds rows shard_range(n_total, r, world)) into the full [n_total, ...]
+    array on every rank: the exchange step of the Bayesian cathode ensemble (particles are sharded, every rank then
+    forms the full SVGD update).  Identity when torch.distributed is not initialised."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if local.shape[0] != n_total:
+            raise ValueError("single process must hold all rows")
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    first, count = shard_range(n_total, rank, world)
+    if local.shape[0] != count:
+        raise ValueError(f"rank {rank} must hold {count} rows, got {local.shape[0]}")
+    cmax = -(-n_total // world)
+    pad = np.zeros((cmax,) + local.shape[1:], dtype=np.float64)
+    pad[:count] = local
+    outs = [torch.zeros(pad.shape, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(outs, torch.from_numpy(pad), group=group)
+    full = np.empty((n_total,) + local.shape[1:], dtype=np.float64)
+    for r in range(world):
+        f, c = shard_range(n_total, r, world)
+        full[f:f + c] = outs[r].numpy()[:c]
+    return full

@@ -89,3 +89,44 @@ def test_two_rank_data_parallel_equals_single_process(orc, case2_setup):
     # the two-rank sum differs from the one-rank sum only by floating-point association
     assert np.max(np.abs(res[0][1] - p)) < 1e-12
     assert np.allclose(res[0][2], ref_losses, rtol=1e-12, atol=0)
+
+
+def _svgd_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from crnn_amd.cathode import svgd_update
+        from crnn_amd.dist import allgather_rows, shard_range
+        rng = np.random.default_rng(0)
+        N = 11                                       # not divisible by the world size
+        p = 1 + 0.05 * rng.standard_normal((N, 17))
+        for _ in range(3):
+            first, count = shard_range(N, rank, world)
+            local = np.sin(p[first:first + count] * 3.0) - 0.1 * p[first:first + count]     # stand-in for the GPU's lnpgrad rows
+            lnpgrad = allgather_rows(local, N)
+            p, _, _ = svgd_update(p, lnpgrad, 0.05)
+        q.put((rank, p))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_particle_sharding_and_svgd_update():
+    """Cathode-UQ exchange: particles sharded, one all-gather of the gradient rows, replicated SVGD move."""
+    from crnn_amd.cathode import svgd_update
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_svgd_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    rng = np.random.default_rng(0)
+    p = 1 + 0.05 * rng.standard_normal((11, 17))
+    for _ in range(3):
+        p, _, _ = svgd_update(p, np.sin(p * 3.0) - 0.1 * p, 0.05)
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][1], p)
