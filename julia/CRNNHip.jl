@@ -21,9 +21,10 @@ const MAX_N = 12
 mutable struct Config
     abi_version::Int32; ns::Int32; nr::Int32; has_temp::Int32; param_map::Int32; n_save::Int32
     loss_kind::Int32; clamp_pred::Int32; maxiters::Int32; errnorm_sens::Int32; device::Int32; cols_per_lane::Int32
-    solver::Int32; grad_mode::Int32; tape_steps::Int32; reserved0::Int32
+    solver::Int32; grad_mode::Int32; tape_steps::Int32; rhs_kind::Int32
     lb::Float64; ub::Float64; inv_R::Float64; t0::Float64
     atol::NTuple{MAX_N,Float64}; rtol::NTuple{MAX_N,Float64}; rate_scale::NTuple{MAX_N,Float64}
+    mw::NTuple{MAX_N,Float64}; gas_const::Float64
     gamma::Float64; qmin::Float64; qmax::Float64; beta1::Float64; beta2::Float64
     qsteady_min::Float64; qsteady_max::Float64; qoldinit::Float64; dtmin::Float64
     Config() = new()
@@ -40,7 +41,8 @@ mutable struct OptConfig
     OptConfig() = new()
 end
 
-const PRESET_CASE1, PRESET_CASE2, PRESET_ROBER = Int32(1), Int32(2), Int32(3)
+const PRESET_CASE1, PRESET_CASE2, PRESET_ROBER, PRESET_HYCHEM = Int32(1), Int32(2), Int32(3), Int32(4)
+const GRAD_AUTO, GRAD_FORWARD, GRAD_ADJOINT = Int32(0), Int32(1), Int32(2)   # cfg.grad_mode: how ForwardDiff.gradient is formed
 
 check(rc, ctx=C_NULL) = rc == 0 ? nothing :
     error(unsafe_string(ccall((:crnn_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx)))
@@ -83,17 +85,21 @@ function set_ensemble!(prob::Problem, u0_list::Matrix{Float64}, ode_data_list::A
     prob.B = B
 end
 
+"""HyChem (HyChem/crnn_pyrolysis_mass.jl:44-47,103-104): `Tlist[n_exp, D]`, `Plist[n_exp, D]` on `tsteps`, piecewise linear in t."""
+set_tables!(prob::Problem, Tlist::Matrix{Float64}, Plist::Matrix{Float64}) =
+    check(ccall((:crnn_ctx_set_tables, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), prob.ctx, Tlist, Plist), prob.ctx)
+
 """`w_in, w_b, w_out = p2vec(p)` (case2/case2.jl:91-99) plus the Jacobian d theta / d p."""
 function p2vec_jac(prob::Problem, p::Vector{Float64})
     c = prob.cfg
-    nth = ccall((:crnn_n_theta, LIB), Int32, (Int32, Int32, Int32), c.ns, c.nr, c.has_temp)
+    nth = ccall((:crnn_config_n_theta, LIB), Int32, (Ref{Config},), c)
     th = zeros(nth); dth = zeros(nth, length(p))
     check(ccall((:crnn_p2vec, LIB), Int32, (Int32, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
                 c.param_map, c.ns, c.nr, p, th, dth))
     return th, dth
 end
 function p2vec(prob::Problem, p)
-    c = prob.cfg; n = c.ns + c.has_temp
+    c = prob.cfg; n = c.ns + (c.rhs_kind == 1 ? 2 : c.has_temp)   # feature rows of w_in
     th, _ = p2vec_jac(prob, p)
     return reshape(th[1:n*c.nr], n, c.nr), th[n*c.nr+1:(n+1)*c.nr], reshape(th[(n+1)*c.nr+1:end], c.ns, c.nr)
 end
@@ -161,6 +167,55 @@ function train_step!(prob::Problem; idxs::UnitRange=1:prob.B, sample=length(prob
     check(ccall((:crnn_train_step, LIB), Int32, (Ptr{Cvoid}, Int64, Int64, Int32, Ref{Float64}),
                 prob.ctx, first(idxs) - 1, length(idxs), sample, loss), prob.ctx)
     return loss[]
+end
+
+# ---------------------------------------------------------------------------------------------------------
+# Bayesian cathode ensemble (Cathode_NCM333_UQ/src_333/network.jl:196-275): all particles x heating rates in one launch
+# ---------------------------------------------------------------------------------------------------------
+mutable struct CathodeConfig
+    abi_version::Int32; device::Int32; maxiters::Int32; reserved0::Int32
+    lb_clamp::Float64; T0::Float64; atol::Float64; rtol::Float64
+    gamma::Float64; qmin::Float64; qmax::Float64; beta1::Float64; beta2::Float64
+    qsteady_min::Float64; qsteady_max::Float64; qoldinit::Float64
+    CathodeConfig() = new()
+end
+
+mutable struct Cathode
+    ctx::Ptr{Cvoid}; n_sets::Int; Dmax::Int; p_scales::Vector{Float64}
+end
+
+"""`l_exp_data[i]` = [t, replicas...] per heating rate (dataset.jl:19-23), `heating_rates` in K/min, `p_scales` = the optimum the particles are scaled by."""
+function Cathode(l_exp_data::Vector{Matrix{Float64}}, heating_rates::Vector{Float64}, p_scales::Vector{Float64})
+    cfg = CathodeConfig()
+    check(ccall((:crnn_cathode_config_default, LIB), Int32, (Ref{CathodeConfig},), cfg))
+    ctx = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:crnn_cathode_create, LIB), Int32, (Ref{CathodeConfig}, Ref{Ptr{Cvoid}}), cfg, ctx))
+    ns = length(l_exp_data); D = Int32[size(e, 1) for e in l_exp_data]; Dmax = maximum(D)
+    ts = zeros(Dmax, ns); dbar = zeros(Dmax, ns); d2bar = zeros(Dmax, ns)      # column-major [Dmax, ns] = row-major [ns][Dmax]
+    for (s, e) in enumerate(l_exp_data)
+        n = size(e, 1)
+        ts[1:n, s] = e[:, 1]; ts[n+1:end, s] = e[end, 1] .+ (1:Dmax-n)
+        dbar[1:n, s] = vec(sum(e[:, 2:end], dims=2)) ./ (size(e, 2) - 1)
+        d2bar[1:n, s] = vec(sum(e[:, 2:end] .^ 2, dims=2)) ./ (size(e, 2) - 1)
+    end
+    rc = ccall((:crnn_cathode_set_obs, LIB), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+               ctx[], ns, Dmax, D, ts, dbar, d2bar, heating_rates)
+    rc == 0 || error(unsafe_string(ccall((:crnn_cathode_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx[])))
+    c = Cathode(ctx[], ns, Dmax, p_scales[1:17])
+    finalizer(x -> ccall((:crnn_cathode_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.ctx), c)
+    return c
+end
+
+"""The loop body of `dlnprob(p, i_exp)` (network.jl:227-252) for ALL particles and heating rates: loss[n_sets, N], grad_p[17, n_sets, N]."""
+function solve(c::Cathode, p::Matrix{Float64})          # p [N, 17] normalised particles
+    N = size(p, 1)
+    theta = permutedims(p[:, 1:17] .* c.p_scales')        # [17, N] column-major = row-major [N][17]
+    loss = zeros(c.n_sets, N); grad = zeros(17, c.n_sets, N); ret = zeros(Int32, c.n_sets, N); nsv = zeros(Int32, c.n_sets, N); st = Stats()
+    rc = ccall((:crnn_cathode_solve, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Ref{Stats}),
+               c.ctx, theta, N, loss, grad, C_NULL, ret, nsv, st)
+    rc == 0 || error(unsafe_string(ccall((:crnn_cathode_last_error, LIB), Cstring, (Ptr{Cvoid},), c.ctx)))
+    any(ret .!= 0) && println("ode solver failed")
+    return loss, grad .* c.p_scales                       # d loss / d p through p .* p_scales
 end
 
 # The reference's CPU baseline the north star mentions, for a Julia-equipped box (SURVEY 8(d)); also unexecuted:
