@@ -416,6 +416,12 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
     crnn::HyParams hp{};
     hp.tabs = c->d_tabs; hp.tape = c->d_tape; hp.tape_cap = (int32_t)cap; hp.overflow = c->d_overflow; hp.gacc = c->d_gacc;
     hp.n_save_total = c->cfg.n_save; hp.inv_R = c->cfg.inv_R;
+#ifdef HY_PROF
+    static unsigned long long *d_prof = nullptr;
+    if (!d_prof) HIP_TRY(c, hipMalloc((void **)&d_prof, 16 * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), c->stream));
+    hp.prof = d_prof;
+#endif
     if (upload_consts(c)) return -1;
     if (!c->flags_zeroed) {
         HIP_TRY(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), c->stream));
@@ -449,6 +455,17 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->last_npart = npart;
     c->last_P = P;
+#ifdef HY_PROF
+    {
+        unsigned long long hprof[16];
+        HIP_TRY(c, hipMemcpy(hprof, d_prof, sizeof(hprof), hipMemcpyDeviceToHost));
+        unsigned long long tot = 0;
+        for (int k = 0; k < 16; ++k) tot += hprof[k];
+        fprintf(stderr, "[hy_prof] P=%d ticks(100MHz):", P);
+        for (int k = 0; k < 16; ++k) fprintf(stderr, " %d:%.1f%%", k, 100.0 * (double)hprof[k] / (double)(tot ? tot : 1));
+        fprintf(stderr, " total %.3f ms\n", (double)tot / 1e5);
+    }
+#endif
     if (ovf) return fail(c, "crnn_solve: a trajectory accepted more steps than the adjoint tape holds; raise crnn_config.tape_steps");
     return 0;
 }

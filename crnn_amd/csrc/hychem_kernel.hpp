@@ -53,6 +53,13 @@
 #define HY_ACC(ptr, val) asm volatile("" ::"v"(val))
 #endif
 
+// phase timing (tools/kvariants.sh build prof="-DHY_PROF=1"): wave 0 of block 0 accumulates s_memtime deltas per phase
+#ifdef HY_PROF
+#define HY_T(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_readcyclecounter(); prof_acc[k] += now_ - prof_last; prof_last = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define HY_T(k) do { } while (0)
+#endif
+
 namespace crnn {
 
 struct HyParams {
@@ -63,6 +70,7 @@ struct HyParams {
     double *gacc;              // [ceil(count/64)][NTH][64], zeroed before the launch
     int32_t n_save_total;      // Dfull: length of the table / saveat grid
     double inv_R;
+    unsigned long long *prof;  // HY_PROF builds: 16 phase totals in s_memtime ticks
 };
 
 template <int NS, int NR>
@@ -368,6 +376,9 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
     const double lqinit = flog(kc->qoldinit);
     const bool start_saved = (ts0 == t0);
     const int lane = tid & 63;
+#ifdef HY_PROF
+    unsigned long long prof_acc[16] = {0}, prof_last = __builtin_readcyclecounter();
+#endif
     double *const tape = hp.tape + (size_t)((size_t)blockIdx.x * BLOCK + tid) * hp.tape_cap * RECW;
 
     while (true) {
@@ -462,6 +473,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
                 if (t + dt * (1.0 + 1e-13) >= tend) { dt = tend - t; last = true; }
                 if (rc < 0 && (!(dt > kc->dtmin) || t + dt == t)) rc = 2;
                 if (rc < 0) {
+                    HY_T(0);
                     HY_FRESH_THETA(th); HY_FRESH_KC(kc);
                     const double gam = d_ * dt;
                     const double tnew = last ? tend : t + dt;
@@ -474,14 +486,17 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
                         double A[NS][NS];
                         hy_jac_ft<NS, NR, BLOCK>(th, kc, p0, gam, Pd * frcp(P) - Td * frcp(T), -hp.inv_R * Td * frcp(T * T), Td * frcp(T), A, ft);
                         CRNN_SCHED_FENCE();
+                        HY_T(1);
                         okf = lu_factor_to_lds<NS, BLOCK>(A, As, dinv, piv, anyp);
                     }
+                    HY_T(2);
                     const bool wp = __builtin_amdgcn_ballot_w64(anyp) != 0;
                     double k1[NS], dk[NS], unew[NS], f1[NS];
 #pragma unroll
                     for (int i = 0; i < NS; ++i) k1[i] = fma(gam, ft[i], p0.f[i]);
                     lu_solve_lds<NS, BLOCK>(As, dinv, piv, wp, k1);
                     CRNN_SCHED_FENCE();
+                    HY_T(3);
                     HY_FRESH_THETA(th); HY_FRESH_KC(kc);
                     {
                         double u1[NS];
@@ -495,12 +510,14 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
                         for (int i = 0; i < NS; ++i) f1[i] = p1.f[i];
                         opaque(f1);
                     }
+                    HY_T(4);
 #pragma unroll
                     for (int i = 0; i < NS; ++i) dk[i] = f1[i] - k1[i];
                     lu_solve_lds<NS, BLOCK>(As, dinv, piv, wp, dk);
 #pragma unroll
                     for (int i = 0; i < NS; ++i) unew[i] = fma(dt, k1[i] + dk[i], u[i]);
                     CRNN_SCHED_FENCE();
+                    HY_T(5);
                     HyPoint<NS, NR> p2;
                     HY_FRESH_THETA(th); HY_FRESH_KC(kc);
                     {
@@ -509,6 +526,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
                         hy_point<NS, NR>(th, kc, hp.inv_R, unew, T2, P2, p2);
                     }
                     CRNN_SCHED_FENCE();
+                    HY_T(6);
                     double k3[NS];
 #pragma unroll
                     for (int i = 0; i < NS; ++i) {
@@ -616,13 +634,8 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
                 double un[NS];
 #pragma unroll
                 for (int i = 0; i < NS; ++i) un[i] = ru[i];
-                {
-                    const double *rec = tape + (size_t)(s > 0 ? s - 1 : 0) * RECW;
-                    rt = rec[0]; rdt = rec[1];
-#pragma unroll
-                    for (int i = 0; i < NS; ++i) ru[i] = rec[2 + i];
-                }
                 // ---- re-form the step
+                HY_T(8);
                 HY_FRESH_THETA(th); HY_FRESH_KC(kc);
                 const double gam = d_ * h;
                 double T, P, Td, Pd;
@@ -657,8 +670,10 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
                     }
                     opaque(k1);
                     CRNN_SCHED_FENCE();
+                    HY_T(9);
                     (void)lu_factor_to_lds<NS, BLOCK>(A, As, dinv, piv, anyp);
                 }
+                HY_T(10);
                 const bool wp = __builtin_amdgcn_ballot_w64(anyp) != 0;
                 lu_solve_lds<NS, BLOCK>(As, dinv, piv, wp, k1);
                 HY_FRESH_THETA(th); HY_FRESH_KC(kc);
@@ -674,6 +689,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
                 for (int i = 0; i < NS; ++i) dk[i] = pm.f[i] - k1[i];
                 lu_solve_lds<NS, BLOCK>(As, dinv, piv, wp, dk);
                 CRNN_SCHED_FENCE();
+                HY_T(11);
 
                 // ---- loss and seeds at the save points inside (tn, tnew]
                 double A_[NS], B1[NS], B2[NS];
@@ -716,6 +732,16 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
                     seed_point(dD);
                 }
 
+                HY_T(12);
+                {   // Next tape record: fetched AND awaited here, before this step's ~420 accumulator atomics are issued.
+                    // gfx9 has one vmcnt for loads, stores and atomics: a load waited for after the atomics would drain
+                    // them first (measured: 30-60 % of the reverse sweep sat in that wait).
+                    const double *rec = tape + (size_t)(s > 0 ? s - 1 : 0) * RECW;
+                    rt = rec[0]; rdt = rec[1];
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) ru[i] = rec[2 + i];
+                    opaque(rt); opaque(rdt); opaque(ru);
+                }
                 if (GRAD) {
 #pragma unroll
                     for (int i = 0; i < NS; ++i) { park[(2 * NS + 4 + NR + i) * BLOCK] = k1[i]; park[(3 * NS + 4 + NR + i) * BLOCK] = dk[i]; }
@@ -771,6 +797,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
                         }
                     }
                     CRNN_SCHED_FENCE();
+                    HY_T(13);
                     lu_solve_T_lds<NS, BLOCK>(As, dinv, piv, wp, kb1);     // kb1 = w
                     opaque(kb1); opaque(ub); opaque(vt);
                     CRNN_SCHED_FENCE();
@@ -873,6 +900,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
                         }
                     }
                 }
+                HY_T(14);
                 tnew = tn;
                 --s;
             }
@@ -900,6 +928,10 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
             prm.n_reject[b] = nrej;
         }
     }
+#ifdef HY_PROF
+    if (hp.prof && blockIdx.x == 0 && tid == 0)
+        for (int k = 0; k < 16; ++k) hp.prof[k] = prof_acc[k];
+#endif
 }
 
 // Ensemble reduction of the HBM gradient accumulators gacc[blk64][m][lane] (row r = blk64*64 + lane), each row scaled by
