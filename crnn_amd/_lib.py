@@ -111,6 +111,8 @@ SYMBOLS = {
     "crnn_cathode_last_error": (C.c_char_p, [_CTX]),
     "crnn_cathode_set_obs": (C.c_int32, [_CTX, C.c_int32, C.c_int32, _IP, _DP, _DP, _DP, _DP]),
     "crnn_cathode_solve": (C.c_int32, [_CTX, _DP, C.c_int64, _DP, _DP, _DP, _IP, _IP, C.POINTER(Stats)]),
+    "crnn_svgd_update": (C.c_int32, [C.c_int32, _DP, _DP, C.c_int64, C.c_int32, C.c_double, C.c_double, _DP,
+                                     C.POINTER(C.c_double), _DP, _DP]),
 }
 
 

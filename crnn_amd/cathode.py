@@ -83,6 +83,20 @@ def svgd_update(p, lnpgrad, stepsize, h=-1.0):
     return p + stepsize * (data_term + dxkxy) / p.shape[0], data_term, dxkxy
 
 
+def svgd_update_device(p, lnpgrad, stepsize, h=-1.0, device=0):
+    """svgd_update on the GPU (crnn_svgd_update: exact median by radix select, fused K p / K lnpgrad rows).
+    Returns (p_new, data_term, repulsion, h)."""
+    p = np.ascontiguousarray(p, np.float64)
+    g = np.ascontiguousarray(lnpgrad, np.float64)
+    if p.ndim != 2 or g.shape != p.shape:
+        raise ValueError("p and lnpgrad must be [N, dim] arrays of the same shape")
+    p_new, dt, rep = np.empty_like(p), np.empty_like(p), np.empty_like(p)
+    h_out = C.c_double(0.0)
+    check(lib.crnn_svgd_update(int(device), dptr(p), dptr(g), p.shape[0], p.shape[1], float(stepsize), float(h), dptr(p_new),
+                               C.byref(h_out), dptr(dt), dptr(rep)))
+    return p_new, dt, rep, h_out.value
+
+
 class CathodeUQ:
     """exp_data: list of arrays [D_s, 1 + n_replicas] (col 0 = time in s, dataset.jl:19-23), heating_rates in K/min."""
 

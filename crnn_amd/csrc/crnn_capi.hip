@@ -18,6 +18,7 @@
 #include "hychem_kernel.hpp"
 #include "tsit5_kernel.hpp"
 #include "cathode_kernel.hpp"
+#include "svgd_kernel.hpp"
 
 namespace {
 
@@ -1324,4 +1325,89 @@ int32_t crnn_cathode_solve(crnn_cathode_ctx *ctx, const double *theta, int64_t n
     return 0;
 }
 
-}  // extern "C"
+
+// ============================================================================ SVGD move (stateless)
+int32_t crnn_svgd_update(int32_t device, const double *p, const double *lnpgrad, int64_t N, int32_t dim, double stepsize,
+                         double h, double *p_new, double *h_out, double *data_term, double *repulsion) {
+    if (!p || !lnpgrad || !p_new) return cfail(nullptr, "crnn_svgd_update: null pointer");
+    if (N < 2 || dim < 1 || dim > crnn::kSvgdMaxDim) return cfail(nullptr, "crnn_svgd_update: need N >= 2 and 1 <= dim <= 32");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1) return cfail(nullptr, std::string("crnn_svgd_update: no HIP device (") + hipGetErrorString(e) + ")");
+    if (device < 0 || device >= ndev) return cfail(nullptr, "crnn_svgd_update: device ordinal out of range");
+    CHIP(nullptr, hipSetDevice(device));
+    const size_t nd = (size_t)N * dim;
+    const int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(64, (256 * 256 * 4) / std::max<int64_t>(N, 1)));
+    double *d_p = nullptr, *d_g = nullptr, *d_new = nullptr, *d_dt = nullptr, *d_rep = nullptr, *d_part = nullptr;
+    unsigned int *d_hist = nullptr;
+    auto cleanup = [&]() {
+        for (void *q : {(void *)d_p, (void *)d_g, (void *)d_new, (void *)d_dt, (void *)d_rep, (void *)d_part, (void *)d_hist})
+            if (q) (void)hipFree(q);
+    };
+#define SV_TRY(expr)                                                                                        \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) { cleanup(); return cfail(nullptr, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
+    } while (0)
+    SV_TRY(hipMalloc((void **)&d_p, nd * sizeof(double)));
+    SV_TRY(hipMalloc((void **)&d_g, nd * sizeof(double)));
+    SV_TRY(hipMalloc((void **)&d_new, nd * sizeof(double)));
+    SV_TRY(hipMalloc((void **)&d_dt, nd * sizeof(double)));
+    SV_TRY(hipMalloc((void **)&d_rep, nd * sizeof(double)));
+    SV_TRY(hipMalloc((void **)&d_part, (size_t)N * nchunk * (1 + 2 * dim) * sizeof(double)));
+    SV_TRY(hipMalloc((void **)&d_hist, crnn::kSvgdBins * sizeof(unsigned int)));
+    SV_TRY(hipMemcpy(d_p, p, nd * sizeof(double), hipMemcpyHostToDevice));
+    SV_TRY(hipMemcpy(d_g, lnpgrad, nd * sizeof(double), hipMemcpyHostToDevice));
+    if (h < 0) {
+        // exact median of the N(N-1)/2 distances by radix select on their bit patterns (12 + 4 x 13 bits)
+        const int64_t npairs = N * (N - 1) / 2;
+        const int hblocks = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (npairs + 255) / 256));
+        std::vector<unsigned int> hist(crnn::kSvgdBins);
+        auto select = [&](int64_t rank, double *out) -> int32_t {   // rank: 0-based order statistic
+            unsigned long long prefix = 0;
+            int prefix_shift = 64;
+            const int digits[5] = {12, 13, 13, 13, 13};
+            int shift = 64;
+            for (int pass = 0; pass < 5; ++pass) {
+                shift -= digits[pass];
+                hipError_t e1 = hipMemset(d_hist, 0, crnn::kSvgdBins * sizeof(unsigned int));
+                if (e1 != hipSuccess) return -1;
+                hipLaunchKernelGGL(crnn::svgd_hist_kernel, dim3(hblocks), dim3(256), 0, 0, d_p, N, dim, shift, digits[pass],
+                                   prefix_shift, prefix, d_hist);
+                if (hipMemcpy(hist.data(), d_hist, crnn::kSvgdBins * sizeof(unsigned int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+                const int nb = 1 << digits[pass];
+                int b = 0;
+                for (; b < nb; ++b) {
+                    if (rank < (int64_t)hist[b]) break;
+                    rank -= hist[b];
+                }
+                if (b == nb) return -2;
+                prefix = (prefix << digits[pass]) | (unsigned long long)b;
+                prefix_shift = shift;
+            }
+            long long bits = (long long)prefix;
+            std::memcpy(out, &bits, sizeof(double));
+            return 0;
+        };
+        double m_lo = 0.0, m_hi = 0.0;
+        if (select((npairs - 1) / 2, &m_lo) != 0 || select(npairs / 2, &m_hi) != 0) { cleanup(); return cfail(nullptr, "crnn_svgd_update: median selection failed"); }
+        const double med = 0.5 * (m_lo + m_hi);     // Julia's median of an even-length vector: mean of the middle pair
+        h = std::sqrt(0.5 * (med * med) / std::log((double)N + 1.0));
+    }
+    if (!(h > 0)) { cleanup(); return cfail(nullptr, "crnn_svgd_update: bandwidth h is not positive (all particles coincide?)"); }
+    if (h_out) *h_out = h;
+    dim3 grid((unsigned)((N + 255) / 256), (unsigned)nchunk);
+    hipLaunchKernelGGL(crnn::svgd_rows_kernel, grid, dim3(256), 0, 0, d_p, d_g, N, dim, 0.5 / (h * h), nchunk, d_part);
+    SV_TRY(hipGetLastError());
+    hipLaunchKernelGGL(crnn::svgd_update_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, 0, d_p, d_part, N, dim, nchunk,
+                       1.0 / (h * h), stepsize / (double)N, d_new, d_dt, d_rep);
+    SV_TRY(hipGetLastError());
+    SV_TRY(hipMemcpy(p_new, d_new, nd * sizeof(double), hipMemcpyDeviceToHost));
+    if (data_term) SV_TRY(hipMemcpy(data_term, d_dt, nd * sizeof(double), hipMemcpyDeviceToHost));
+    if (repulsion) SV_TRY(hipMemcpy(repulsion, d_rep, nd * sizeof(double), hipMemcpyDeviceToHost));
+#undef SV_TRY
+    cleanup();
+    return 0;
+}
+
+}

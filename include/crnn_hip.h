@@ -269,6 +269,14 @@ int32_t crnn_cathode_set_obs(crnn_cathode_ctx *ctx, int32_t n_sets, int32_t Dmax
 int32_t crnn_cathode_solve(crnn_cathode_ctx *ctx, const double *theta, int64_t n_part, double *loss, double *grad,
                            double *hrr, int32_t *retcode, int32_t *n_saved, crnn_stats *stats);
 
+/* The SVGD move that follows dlnprob (Cathode_NCM333_UQ/src_333/network.jl:67-87 svgd_kernel, crnn_cathode.jl:36-50):
+ *   d_ij = |p_i - p_j|; h < 0: h = sqrt(0.5 median(d_ij, i > j)^2 / log(N + 1)); K = exp(-d^2 / (2 h^2));
+ *   data = K lnpgrad; repulsion = (-K p + p .* rowsum(K)) / h^2; p_new = p + stepsize (data + repulsion) / N.
+ * p, lnpgrad, p_new, data_term, repulsion: [N x dim] row-major host arrays (dim <= 32; data_term / repulsion may be NULL);
+ * h_out receives the bandwidth used.  Stateless: runs on HIP device `device`. */
+int32_t crnn_svgd_update(int32_t device, const double *p, const double *lnpgrad, int64_t N, int32_t dim, double stepsize,
+                         double h, double *p_new, double *h_out, double *data_term, double *repulsion);
+
 #ifdef __cplusplus
 }
 #endif

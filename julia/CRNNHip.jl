@@ -218,6 +218,16 @@ function solve(c::Cathode, p::Matrix{Float64})          # p [N, 17] normalised p
     return loss, grad .* c.p_scales                       # d loss / d p through p .* p_scales
 end
 
+"""The SVGD move (network.jl:67-87 `svgd_kernel` + crnn_cathode.jl:36-50) on the device: returns p_new [N, dim] and the bandwidth h."""
+function svgd_update(p::Matrix{Float64}, lnpgrad::Matrix{Float64}, stepsize::Float64; h::Float64=-1.0, device::Integer=0)
+    N, dim = size(p)
+    pr = permutedims(p); gr = permutedims(lnpgrad)       # row-major [N][dim] for the ABI
+    pn = similar(pr); hout = Ref(0.0)
+    check(ccall((:crnn_svgd_update, LIB), Int32, (Int32, Ptr{Float64}, Ptr{Float64}, Int64, Int32, Float64, Float64, Ptr{Float64}, Ref{Float64}, Ptr{Float64}, Ptr{Float64}),
+                device, pr, gr, N, dim, stepsize, h, pn, hout, C_NULL, C_NULL))
+    return permutedims(pn), hout[]
+end
+
 # The reference's CPU baseline the north star mentions, for a Julia-equipped box (SURVEY 8(d)); also unexecuted:
 #   using OrdinaryDiffEq
 #   ens = EnsembleProblem(prob_ref; prob_func = (pr, i, _) -> remake(pr, u0 = u0_list[i, :]))

@@ -91,6 +91,40 @@ def test_svgd_kernel_properties():
     assert np.allclose(K, np.exp(-d ** 2 / h ** 2 / 2))
 
 
+def test_svgd_update_matches_reference_formulas():
+    """svgd_update = crnn_cathode.jl:36-50 written out with explicit loops."""
+    from crnn_amd.cathode import svgd_update
+    rng = np.random.default_rng(1)
+    N, dim = 9, 17
+    p = 1 + 0.1 * rng.standard_normal((N, dim)); g = rng.standard_normal((N, dim))
+    d = np.array([[np.sqrt(np.sum((p[i] - p[j]) ** 2)) for j in range(N)] for i in range(N)])
+    h = np.sqrt(0.5 * np.median([d[i, j] for i in range(N) for j in range(i)]) ** 2 / np.log(N + 1))
+    K = np.exp(-d ** 2 / h ** 2 / 2)
+    rep = np.array([[(-K[i] @ p[:, k] + p[i, k] * K[i].sum()) / h ** 2 for k in range(dim)] for i in range(N)])
+    pn, dt, rp = svgd_update(p, g, 0.02)
+    assert np.allclose(dt, K @ g, rtol=1e-13) and np.allclose(rp, rep, rtol=1e-12, atol=1e-13)
+    assert np.allclose(pn, p + 0.02 * (K @ g + rep) / N, rtol=1e-14)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,dim", [(6, 17), (257, 17), (1000, 3)])
+def test_gpu_svgd_update_matches_numpy(N, dim):
+    """N = 6: 15 pairs (odd count, single middle element); N = 257 / 1000: even counts (mean of the middle pair)."""
+    from crnn_amd.cathode import svgd_update, svgd_update_device
+    rng = np.random.default_rng(N)
+    p = 1 + 0.05 * rng.standard_normal((N, dim)); g = 50 * rng.standard_normal((N, dim))
+    pn, dt, rp = svgd_update(p, g, 0.01)
+    pd, dtd, rpd, h = svgd_update_device(p, g, 0.01)
+    d = np.sqrt(((p[:, None, :] - p[None, :, :]) ** 2).sum(-1))
+    href = np.sqrt(0.5 * np.median(d[np.tril_indices(N, -1)]) ** 2 / np.log(N + 1))
+    assert abs(h - href) <= 1e-14 * href                           # the exact median, not an approximation
+    assert np.max(np.abs(dtd - dt)) < 1e-11 * np.max(np.abs(dt))
+    assert np.max(np.abs(rpd - rp)) < 1e-10 * np.max(np.abs(rp))
+    assert np.max(np.abs(pd - pn)) < 1e-13
+    p2, _, _, h2 = svgd_update_device(p, g, 0.01, h=0.37)          # explicit bandwidth
+    assert h2 == 0.37 and np.max(np.abs(p2 - svgd_update(p, g, 0.01, h=0.37)[0])) < 1e-13
+
+
 def test_cathode_config_abi():
     import ctypes as C
     from crnn_amd import _lib as L
