@@ -51,7 +51,7 @@ class Stats(C.Structure):
 
 
 class CathodeConfig(C.Structure):
-    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("maxiters", C.c_int32), ("reserved0", C.c_int32),
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("maxiters", C.c_int32), ("grad_mode", C.c_int32),
                 ("lb_clamp", C.c_double), ("T0", C.c_double), ("atol", C.c_double), ("rtol", C.c_double),
                 ("gamma", C.c_double), ("qmin", C.c_double), ("qmax", C.c_double), ("beta1", C.c_double),
                 ("beta2", C.c_double), ("qsteady_min", C.c_double), ("qsteady_max", C.c_double), ("qoldinit", C.c_double)]

@@ -101,11 +101,11 @@ class CathodeUQ:
     """exp_data: list of arrays [D_s, 1 + n_replicas] (col 0 = time in s, dataset.jl:19-23), heating_rates in K/min."""
 
     def __init__(self, exp_data, heating_rates, p_scales, *, atol=None, rtol=None, maxiters=None, lb_clamp=None, device=0,
-                 normalizer=None):
+                 normalizer=None, grad_mode=None):
         self.cfg = CathodeConfig()
         check(lib.crnn_cathode_config_default(C.byref(self.cfg)))
         self.cfg.device = device
-        for k, v in (("atol", atol), ("rtol", rtol), ("maxiters", maxiters), ("lb_clamp", lb_clamp)):
+        for k, v in (("atol", atol), ("rtol", rtol), ("maxiters", maxiters), ("lb_clamp", lb_clamp), ("grad_mode", grad_mode)):
             if v is not None:
                 setattr(self.cfg, k, v)
         self.h = C.c_void_p()

@@ -383,4 +383,392 @@ __global__ __launch_bounds__(BLOCK) void cathode_kernel(const CathodeParams prm)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Per-particle gradient by the discrete adjoint of the accepted steps (the method of ros23_adj_kernel.hpp applied to the
+// cathode right-hand side).  f = S r with S = [[-1,0,0],[nu2,-1,0],[0,nu3,-1]], r_j = exp(z_j),
+// z_j = lnA_j + Ea_j 1e5 Rg/T + b_j ln T + n_j log clamp(u_j);  for a direction (k, tau) in (u, t):
+// z'_j = n_j g_j k_j + tau sigma_j, sigma_j = (b_j/T - Ea_j 1e5 Rg/T^2) dT/dt, and with A = S^T a, Psi_j = A_j r_j:
+//     d(a.f)/d(lnA, Ea, b, n)_j = Psi_j (1, 1e5 Rg/T, ln T, l_j),  d/d nu2 = a_1 r_0,  d/d nu3 = a_2 r_1,  d/du_j = Psi_j n_j g_j
+//     d(a.Df[(k,tau)])/d lnA_j = Psi_j y_j (y = z'),  d/d Ea_j = Psi_j (y_j 1e5 Rg/T - tau 1e5 Rg T'/T^2),
+//     d/d b_j = Psi_j (y_j ln T + tau T'/T),  d/d n_j = Psi_j (y_j l_j + g_j k_j),  d/d nu2 = a_1 r_0 y_0,  d/d nu3 = a_2 r_1 y_1,
+//     d/du_j = Psi_j n_j (y_j g_j - g_j^2 k_j)
+// The time derivative df/dt of the non-autonomous Rosenbrock23 rides along as tau = 1 of the w-direction.  Cost: two
+// primal sweeps instead of 1 + 14 tangent columns.  Work is handed out as 64 PARTICLES OF ONE HEATING RATE per wavefront
+// (nearly identical step counts: the particles are a tight cloud), so the wave-synchronous sweeps lose little to
+// divergence.  tape: (t, dt, u[3]) per accepted step and lane.
+// ---------------------------------------------------------------------------------------------------------------
+struct CathAdjParams {
+    double *tape;              // [lanes][tape_cap][5]
+    int32_t tape_cap;
+    unsigned int *overflow;
+    int64_t n_part;
+};
+
+#ifndef CRNN_CATH_ADJ_WAVES
+#define CRNN_CATH_ADJ_WAVES 1   // waves per SIMD the register allocation targets (tools/kvariants.sh experiments)
+#endif
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CRNN_CATH_ADJ_WAVES, CRNN_CATH_ADJ_WAVES))) void cathode_adj_kernel(const CathodeParams prm, const CathAdjParams adj) {
+    __shared__ double ts_s[kCathMaxSets * kCathMaxD];
+    __shared__ double db_s[kCathMaxSets * kCathMaxD];
+    __shared__ double d2_s[kCathMaxSets * kCathMaxD];
+    const int tid = threadIdx.x;
+    const bool staged = prm.n_sets <= kCathMaxSets;
+    if (staged) {
+        for (int idx = tid; idx < prm.n_sets * prm.Dmax; idx += BLOCK) {
+            const int s = idx / prm.Dmax, i = idx - s * prm.Dmax;
+            ts_s[s * kCathMaxD + i] = prm.ts[idx];
+            db_s[s * kCathMaxD + i] = prm.dbar[idx];
+            d2_s[s * kCathMaxD + i] = prm.d2bar[idx];
+        }
+    }
+    __syncthreads();
+    constexpr double d_ = 0.29289321881345248, c32 = 7.4142135623730950, inv12d = 2.4142135623730950;
+    constexpr double Rg = -1.0 / 8.314;
+    constexpr int RECW = 5;
+    const double lqinit = flog(prm.qoldinit);
+    const int lane = tid & 63;
+    double *const tape = adj.tape + (size_t)((size_t)blockIdx.x * BLOCK + tid) * adj.tape_cap * RECW;
+    const int64_t per_set = (adj.n_part + 63) / 64;              // wave batches per heating rate
+    const int64_t n_batches = per_set * prm.n_sets;
+
+    while (true) {
+        unsigned long long bq = 0;
+        if (lane == 0) bq = atomicAdd(prm.queue, 1ULL);
+        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)bq);
+        const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(bq >> 32));
+        const int64_t batch = (int64_t)(((unsigned long long)bhi << 32) | blo);
+        if (batch >= n_batches) break;
+        const int set = (int)(batch / per_set);
+        const int64_t part = (batch - (int64_t)set * per_set) * 64 + lane;
+        const bool valid = part < adj.n_part;
+        const int64_t traj = (valid ? part : 0) * prm.n_sets + set;
+
+        double th[kCathNP];
+#pragma unroll
+        for (int k = 0; k < kCathNP; ++k) th[k] = prm.theta[(size_t)(valid ? part : 0) * kCathNP + k];
+        const int D = prm.D[set];
+        const double *tsv, *dbv, *d2v;
+        if (staged) { tsv = ts_s + set * kCathMaxD; dbv = db_s + set * kCathMaxD; d2v = d2_s + set * kCathMaxD; }
+        else { tsv = prm.ts + (size_t)set * prm.Dmax; dbv = prm.dbar + (size_t)set * prm.Dmax; d2v = prm.d2bar + (size_t)set * prm.Dmax; }
+        const double Tdot = prm.beta[set] * (1.0 / 60.0);
+        const double t0 = tsv[0], tend = tsv[D - 1];
+
+        auto wfac = [&](const CathPoint &P, double gam, double (&a)[3], double (&iw)[3]) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { a[j] = P.r[j] * th[12 + j] * P.g[j]; iw[j] = frcp(fma(gam, a[j], 1.0)); }
+        };
+        auto ftime = [&](const CathPoint &P, double (&sig)[3], double (&ft)[3]) {
+            double rho[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { sig[j] = (th[6 + j] * P.it - th[3 + j] * 1e5 * Rg * P.it * P.it) * Tdot; rho[j] = P.r[j] * sig[j]; }
+            ft[0] = -rho[0]; ft[1] = fma(th[15], rho[0], -rho[1]); ft[2] = fma(th[16], rho[1], -rho[2]);
+        };
+
+        // ================================================================== forward sweep
+        double u[3] = {1.0, 0.0, 0.0}, f0[3];
+        CathPoint P0;
+        double t = t0, dt = 0.0, lqold = lqinit;
+        int iter = 0, jsave = 0, nacc = 0, nrej = 0;
+        int rc = valid ? -1 : 0;
+        cath_point(u, fma(Tdot, t0, prm.T0), th, prm.lb, P0);
+        cath_f(P0, th, f0);
+        {
+            double sk[3], d0 = 0.0, d1 = 0.0, d2 = 0.0, u1[3], f1[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                sk[i] = frcp(fma(fabs(u[i]), prm.rtol, prm.atol));
+                d0 = fma(u[i] * sk[i], u[i] * sk[i], d0);
+                d1 = fma(f0[i] * sk[i], f0[i] * sk[i], d1);
+            }
+            d0 = sqrt(d0 * (1.0 / 3.0)); d1 = sqrt(d1 * (1.0 / 3.0));
+            const double dtmax = tend - t0;
+            double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 / d1);
+            dt0 = fmin(dt0, dtmax);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) u1[i] = fma(dt0, f0[i], u[i]);
+            CathPoint q;
+            cath_point(u1, fma(Tdot, t + dt0, prm.T0), th, prm.lb, q);
+            cath_f(q, th, f1);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { const double e = (f1[i] - f0[i]) * sk[i]; d2 = fma(e, e, d2); }
+            d2 = sqrt(d2 * (1.0 / 3.0)) / dt0;
+            const double dm = fmax(d1, d2);
+            const double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : exp(-0.5 * (4.605170185988091368 + flog(dm)));
+            dt = fmin(fmin(100.0 * dt0, dt1), dtmax);
+        }
+        auto hrr_of = [&](const double (&uu)[3], double tt) -> double {
+            CathPoint q;
+            cath_point(uu, fma(Tdot, tt, prm.T0), th, prm.lb, q);
+            return fma(q.r[0], th[9], fma(q.r[1], th[10], q.r[2] * th[11]));
+        };
+        if (valid && prm.hrr) prm.hrr[(size_t)traj * prm.Dmax + 0] = hrr_of(u, t0);
+        jsave = 1;    // saveat contains tspan[1]
+
+        while (__builtin_amdgcn_ballot_w64(rc < 0) != 0) {
+            if (rc < 0) {
+                ++iter;
+                bool last = false;
+                if (jsave >= D) rc = 0;
+                else if (iter > prm.maxiters) rc = 1;
+                if (t + dt * (1.0 + 1e-13) >= tend) { dt = tend - t; last = true; }
+                if (rc < 0 && (!(dt > 0.0) || t + dt == t)) rc = 2;
+                if (rc < 0) {
+                    const double gam = d_ * dt;
+                    double a[3], iw[3], sig[3], ft[3];
+                    wfac(P0, gam, a, iw);
+                    ftime(P0, sig, ft);
+                    const double l21 = gam * th[15] * a[0], l32 = gam * th[16] * a[1];
+                    auto wsolve = [&](double (&b)[3]) {
+                        b[0] *= iw[0];
+                        b[1] = fma(l21, b[0], b[1]) * iw[1];
+                        b[2] = fma(l32, b[1], b[2]) * iw[2];
+                    };
+                    double k1[3], dk[3], k3[3], u1[3], f1[3], unew[3], f2[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) k1[i] = fma(gam, ft[i], f0[i]);
+                    wsolve(k1);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) u1[i] = fma(0.5 * dt, k1[i], u[i]);
+                    CathPoint P1, P2;
+                    cath_point(u1, fma(Tdot, t + 0.5 * dt, prm.T0), th, prm.lb, P1);
+                    cath_f(P1, th, f1);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) dk[i] = f1[i] - k1[i];
+                    wsolve(dk);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) unew[i] = fma(dt, k1[i] + dk[i], u[i]);
+                    const double tnew = last ? tend : t + dt;
+                    cath_point(unew, fma(Tdot, tnew, prm.T0), th, prm.lb, P2);
+                    cath_f(P2, th, f2);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const double k2i = k1[i] + dk[i];
+                        k3[i] = f2[i] - c32 * (k2i - f1[i]) - 2.0 * (k1[i] - f0[i]) + dt * ft[i];
+                    }
+                    wsolve(k3);
+                    double es = 0.0;
+                    bool finite = true;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const double k2i = k1[i] + dk[i];
+                        const double ev = dt * (1.0 / 6.0) * (k1[i] - 2.0 * k2i + k3[i]);
+                        const double m = fmax(fabs(u[i]), fabs(unew[i]));
+                        const double e = ev * frcp(fma(prm.rtol, m, prm.atol));
+                        es = fma(e, e, es);
+                        finite = finite && isfinite(unew[i]) && isfinite(ev);
+                    }
+                    es *= (1.0 / 3.0);
+                    if (!finite) rc = 3;
+                    else {
+                        const bool ee_zero = (es == 0.0);
+                        const double lEE = 0.5 * flog(ee_zero ? 1.0 : es);
+                        const double lq11 = prm.beta1 * lEE;
+                        double q = ee_zero ? 1.0 / prm.qmax
+                                           : fmax(1.0 / prm.qmax, fmin(1.0 / prm.qmin, exp(lq11 - prm.beta2 * lqold) / prm.gamma));
+                        if (es <= 1.0) {
+                            if (nacc >= adj.tape_cap) {
+                                rc = 5;
+                                atomicAdd(adj.overflow, 1u);
+                            } else {
+                                double *rec = tape + (size_t)nacc * RECW;
+                                rec[0] = t; rec[1] = dt; rec[2] = u[0]; rec[3] = u[1]; rec[4] = u[2];
+                                ++nacc;
+                                while (jsave < D) {
+                                    const double tsj = tsv[jsave];
+                                    if (!(tsj <= tnew)) break;
+                                    if (prm.hrr) {
+                                        const bool at_end = (tsj == tnew);
+                                        const double Th = at_end ? 1.0 : (tsj - t) / dt;
+                                        const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
+                                        const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d_) * inv12d;
+                                        double ui[3];
+#pragma unroll
+                                        for (int i = 0; i < 3; ++i) ui[i] = at_end ? unew[i] : fma(dt, fma(c1, k1[i], c2 * (k1[i] + dk[i])), u[i]);
+                                        prm.hrr[(size_t)traj * prm.Dmax + jsave] = hrr_of(ui, tsj);
+                                    }
+                                    ++jsave;
+                                }
+#pragma unroll
+                                for (int i = 0; i < 3; ++i) { u[i] = unew[i]; f0[i] = f2[i]; }
+                                P0 = P2;
+                                t = tnew;
+                                if (q >= prm.qsteady_min && q <= prm.qsteady_max) q = 1.0;
+                                lqold = ee_zero ? lqinit : fmax(lEE, lqinit);
+                                dt = fmin(dt / q, tend - t0);
+                                if (jsave >= D) rc = 0;
+                            }
+                        } else {
+                            ++nrej;
+                            dt = dt / fmin(1.0 / prm.qmin, exp(lq11) / prm.gamma);
+                        }
+                    }
+                }
+            }
+        }
+
+        // ================================================================== reverse sweep
+        const int n_saved = jsave;
+        double thb[kCathNP], lam[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < kCathNP; ++k) thb[k] = 0.0;
+        double loss_sum = 0.0, tnew = t;
+        int s = valid ? nacc - 1 : -1;
+        // observation at a save point: loss term, direct theta gradients (into thb), state seed w
+        auto observe = [&](const double (&uu)[3], double tt, int j, double (&w)[3]) {
+            CathPoint q;
+            cath_point(uu, fma(Tdot, tt, prm.T0), th, prm.lb, q);
+            const double hv = fma(q.r[0], th[9], fma(q.r[1], th[10], q.r[2] * th[11]));
+            const double db = dbv[j];
+            const double e = hv - db;
+            loss_sum += fma(e, e, d2v[j] - db * db);
+            const double e2 = 2.0 * e;
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) {
+                const double c = e2 * th[9 + jj] * q.r[jj];
+                thb[jj] += c;
+                thb[3 + jj] = fma(c * 1e5, q.rt, thb[3 + jj]);
+                thb[6 + jj] = fma(c, q.lt, thb[6 + jj]);
+                thb[9 + jj] = fma(e2, q.r[jj], thb[9 + jj]);
+                thb[12 + jj] = fma(c, q.l[jj], thb[12 + jj]);
+                w[jj] = c * th[12 + jj] * q.g[jj];
+            }
+        };
+        double rt = 0.0, rdt = 0.0, ru[3] = {0.0, 0.0, 0.0};
+        {
+            const double *rec = tape + (size_t)(s > 0 ? s : 0) * RECW;
+            rt = rec[0]; rdt = rec[1]; ru[0] = rec[2]; ru[1] = rec[3]; ru[2] = rec[4];
+        }
+        while (__builtin_amdgcn_ballot_w64(s >= 0) != 0) {
+            if (s >= 0) {
+                const double tn = rt, h = rdt;
+                const double un[3] = {ru[0], ru[1], ru[2]};
+                {
+                    const double *rec = tape + (size_t)(s > 0 ? s - 1 : 0) * RECW;
+                    rt = rec[0]; rdt = rec[1]; ru[0] = rec[2]; ru[1] = rec[3]; ru[2] = rec[4];
+                }
+                const double gam = d_ * h;
+                CathPoint Pn, Pm;
+                cath_point(un, fma(Tdot, tn, prm.T0), th, prm.lb, Pn);
+                double fn[3], a[3], iw[3], sig[3], ft[3];
+                cath_f(Pn, th, fn);
+                wfac(Pn, gam, a, iw);
+                ftime(Pn, sig, ft);
+                const double l21 = gam * th[15] * a[0], l32 = gam * th[16] * a[1];
+                auto wsolve = [&](double (&b)[3]) {
+                    b[0] *= iw[0];
+                    b[1] = fma(l21, b[0], b[1]) * iw[1];
+                    b[2] = fma(l32, b[1], b[2]) * iw[2];
+                };
+                auto wsolveT = [&](double (&b)[3]) {   // W^T is upper bidiagonal
+                    b[2] *= iw[2];
+                    b[1] = fma(l32, b[2], b[1]) * iw[1];
+                    b[0] = fma(l21, b[1], b[0]) * iw[0];
+                };
+                double k1[3], dk[3], f1[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) k1[i] = fma(gam, ft[i], fn[i]);
+                wsolve(k1);
+                {
+                    double u1[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) u1[i] = fma(0.5 * h, k1[i], un[i]);
+                    cath_point(u1, fma(Tdot, tn + 0.5 * h, prm.T0), th, prm.lb, Pm);
+                    cath_f(Pm, th, f1);
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) dk[i] = f1[i] - k1[i];
+                wsolve(dk);
+                // ---- save points inside (tn, tnew]
+                double A_[3] = {0.0, 0.0, 0.0}, B1[3] = {0.0, 0.0, 0.0}, B2[3] = {0.0, 0.0, 0.0};
+                while (jsave > 1) {
+                    const double tsj = tsv[jsave - 1];
+                    if (!(tsj > tn)) break;
+                    const bool at_end = (tsj == tnew);
+                    const double Th = at_end ? 1.0 : (tsj - tn) / h;
+                    const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
+                    const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d_) * inv12d;
+                    double ui[3], w[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) ui[i] = at_end ? fma(h, k1[i] + dk[i], un[i]) : fma(h, fma(c1, k1[i], c2 * (k1[i] + dk[i])), un[i]);
+                    observe(ui, tsj, jsave - 1, w);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        A_[i] += w[i];
+                        B1[i] = fma(w[i], h * c1, B1[i]);
+                        B2[i] = fma(w[i], h * c2, B2[i]);
+                    }
+                    --jsave;
+                }
+                if (prm.want_grad) {
+                    double v[3], kb1[3], ub[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { v[i] = fma(h, lam[i], B2[i]); ub[i] = lam[i] + A_[i]; kb1[i] = B1[i] + v[i]; }
+                    wsolveT(v);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) kb1[i] -= v[i];
+                    // A = S^T a
+                    const double Av[3] = {fma(th[15], v[1], -v[0]), fma(th[16], v[2], -v[1]), -v[2]};
+                    {   // point u_mid
+                        double um[3];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            const double Psi = Av[j] * Pm.r[j];
+                            thb[j] += Psi;
+                            thb[3 + j] = fma(Psi * 1e5, Pm.rt, thb[3 + j]);
+                            thb[6 + j] = fma(Psi, Pm.lt, thb[6 + j]);
+                            thb[12 + j] = fma(Psi, Pm.l[j], thb[12 + j]);
+                            um[j] = Psi * th[12 + j] * Pm.g[j];
+                        }
+                        thb[15] = fma(v[1], Pm.r[0], thb[15]);
+                        thb[16] = fma(v[2], Pm.r[1], thb[16]);
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) { ub[j] += um[j]; kb1[j] = fma(0.5 * h, um[j], kb1[j]); }
+                    }
+                    wsolveT(kb1);   // kb1 = w
+                    const double Aw[3] = {fma(th[15], kb1[1], -kb1[0]), fma(th[16], kb1[2], -kb1[1]), -kb1[2]};
+                    double yv0 = 0.0, yw0 = 0.0, yv1 = 0.0, yw1 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const double ng = th[12 + j] * Pn.g[j];
+                        const double yv = ng * dk[j], yw = fma(ng, k1[j], sig[j]);
+                        if (j == 0) { yv0 = yv; yw0 = yw; }
+                        if (j == 1) { yv1 = yv; yw1 = yw; }
+                        const double Pv = Av[j] * Pn.r[j], Pw = Aw[j] * Pn.r[j];
+                        const double E = fma(Pw, fma(gam, yw, 1.0), gam * Pv * yv);
+                        const double gPw = gam * Pw;
+                        const double mix = fma(Pw, k1[j], Pv * dk[j]);                 // Pw k1_j + Pv dk_j
+                        thb[j] += E;
+                        thb[3 + j] = fma(E * 1e5, Pn.rt, fma(gPw, -1e5 * Rg * Pn.it * Pn.it * Tdot, thb[3 + j]));
+                        thb[6 + j] = fma(E, Pn.lt, fma(gPw, Pn.it * Tdot, thb[6 + j]));
+                        thb[12 + j] = fma(E, Pn.l[j], fma(gam * Pn.g[j], mix, thb[12 + j]));
+                        // d/du_j: E n g + gam n h (Pw k1 + Pv dk),  h = -g^2
+                        lam[j] = ub[j] + th[12 + j] * Pn.g[j] * (E - gam * Pn.g[j] * mix);
+                    }
+                    thb[15] = fma(Pn.r[0], fma(kb1[1], fma(gam, yw0, 1.0), gam * v[1] * yv0), thb[15]);
+                    thb[16] = fma(Pn.r[1], fma(kb1[2], fma(gam, yw1, 1.0), gam * v[2] * yv1), thb[16]);
+                }
+                tnew = tn;
+                --s;
+            }
+        }
+        if (valid) {
+            double w0[3];
+            const double u00[3] = {1.0, 0.0, 0.0};
+            observe(u00, t0, 0, w0);           // the saved initial point: loss term and its direct theta gradients
+            const double invD = 1.0 / (double)D;   // the FULL row count, also for a truncated solution (network.jl:266)
+            prm.loss[traj] = loss_sum * invD;
+            prm.retcode[traj] = rc;
+            prm.n_saved[traj] = n_saved;
+            prm.n_accept[traj] = nacc;
+            prm.n_reject[traj] = nrej;
+            if (prm.grad) {
+                double *go = prm.grad + (size_t)traj * kCathNP;
+#pragma unroll
+                for (int m = 0; m < kCathNP; ++m) go[m] = thb[m] * invD;
+            }
+        }
+    }
+}
+
 }  // namespace crnn

@@ -578,6 +578,9 @@ struct CathCtx {
     double *d_theta = nullptr, *d_loss = nullptr, *d_grad = nullptr, *d_hrr = nullptr;
     int32_t *d_ret = nullptr, *d_nsv = nullptr, *d_nacc = nullptr, *d_nrej = nullptr;
     size_t cap_part = 0, cap_traj = 0, cap_hrr = 0;
+    double *d_tape = nullptr;      // adjoint step tape
+    size_t tape_doubles = 0, tape_budget = 0;
+    unsigned int *d_overflow = nullptr;
 };
 int32_t cfail(CathCtx *c, const std::string &msg) {
     g_last_error = msg;
@@ -1193,6 +1196,7 @@ int32_t crnn_cathode_create(const crnn_cathode_config *cfg, crnn_cathode_ctx **o
     *out = nullptr;
     if (cfg->abi_version != CRNN_ABI_VERSION) return cfail(nullptr, "crnn_cathode_create: abi_version mismatch");
     if (!(cfg->atol > 0) || !(cfg->rtol > 0) || cfg->maxiters < 1) return cfail(nullptr, "crnn_cathode_create: bad tolerances/maxiters");
+    if (cfg->grad_mode < CRNN_GRAD_AUTO || cfg->grad_mode > CRNN_GRAD_ADJOINT) return cfail(nullptr, "crnn_cathode_create: bad grad_mode");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev < 1) return cfail(nullptr, std::string("crnn_cathode_create: no HIP device (") + hipGetErrorString(e) + ")");
@@ -1217,7 +1221,7 @@ void crnn_cathode_destroy(crnn_cathode_ctx *ctx) {
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_ts, c->d_dbar, c->d_d2bar, c->d_beta, c->d_D, c->d_queue, c->d_theta, c->d_loss, c->d_grad,
-                    c->d_hrr, c->d_ret, c->d_nsv, c->d_nacc, c->d_nrej};
+                    c->d_hrr, c->d_ret, c->d_nsv, c->d_nacc, c->d_nrej, c->d_tape, c->d_overflow};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1297,14 +1301,50 @@ int32_t crnn_cathode_solve(crnn_cathode_ctx *ctx, const double *theta, int64_t n
     prm.gamma = c->cfg.gamma; prm.qmin = c->cfg.qmin; prm.qmax = c->cfg.qmax; prm.beta1 = c->cfg.beta1; prm.beta2 = c->cfg.beta2;
     prm.qsteady_min = c->cfg.qsteady_min; prm.qsteady_max = c->cfg.qsteady_max; prm.qoldinit = c->cfg.qoldinit;
     constexpr int kB = 256;
-    int occ = 0;
-    CHIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)crnn::cathode_kernel<kB>, kB, 0));
-    if (occ < 1) occ = 1;
-    int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((ntraj + kB - 1) / kB, (int64_t)c->num_cu * occ));
-    CHIP(c, hipEventRecord(c->ev0, c->stream));
-    hipLaunchKernelGGL(crnn::cathode_kernel<kB>, dim3(nblk), dim3(kB), 0, c->stream, prm);
-    CHIP(c, hipGetLastError());
-    CHIP(c, hipEventRecord(c->ev1, c->stream));
+    bool done = false;
+    if (grad && c->cfg.grad_mode != CRNN_GRAD_FORWARD) {
+        // discrete adjoint (cathode_adj_kernel): a wavefront takes 64 particles of one heating rate
+        int occ = 0;
+        CHIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)crnn::cathode_adj_kernel<kB>, kB, 0));
+        if (occ < 1) occ = 1;
+        const int64_t n_batches = ((n_part + 63) / 64) * c->n_sets;
+        const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((n_batches + 3) / 4, (int64_t)c->num_cu * occ));
+        const size_t lanes = (size_t)nblk * kB;
+        if (c->tape_budget == 0) {
+            size_t fr = 0, tot = 0;
+            CHIP(c, hipMemGetInfo(&fr, &tot));
+            c->tape_budget = std::min<size_t>(fr / 4, (size_t)16 << 30);
+        }
+        int64_t cap = std::max<int64_t>((int64_t)(c->tape_budget / (lanes * 5 * sizeof(double))), 64);
+        cap = std::min<int64_t>(cap, c->cfg.maxiters);
+        if (c->tape_doubles < lanes * (size_t)cap * 5) {
+            if (cgrow(c, &c->d_tape, lanes * (size_t)cap * 5)) return -1;
+            c->tape_doubles = lanes * (size_t)cap * 5;
+        }
+        if (!c->d_overflow) CHIP(c, hipMalloc((void **)&c->d_overflow, sizeof(unsigned int)));
+        CHIP(c, hipMemsetAsync(c->d_overflow, 0, sizeof(unsigned int), c->stream));
+        crnn::CathAdjParams adj{};
+        adj.tape = c->d_tape; adj.tape_cap = (int32_t)cap; adj.overflow = c->d_overflow; adj.n_part = n_part;
+        CHIP(c, hipEventRecord(c->ev0, c->stream));
+        hipLaunchKernelGGL(crnn::cathode_adj_kernel<kB>, dim3(nblk), dim3(kB), 0, c->stream, prm, adj);
+        CHIP(c, hipGetLastError());
+        CHIP(c, hipEventRecord(c->ev1, c->stream));
+        unsigned int ovf = 0;
+        CHIP(c, hipMemcpyAsync(&ovf, c->d_overflow, sizeof(ovf), hipMemcpyDeviceToHost, c->stream));
+        CHIP(c, hipStreamSynchronize(c->stream));
+        done = (ovf == 0);   // otherwise some trajectory outran the tape: repeat the call with forward tangents
+        if (!done) CHIP(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), c->stream));
+    }
+    if (!done) {
+        int occ = 0;
+        CHIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)crnn::cathode_kernel<kB>, kB, 0));
+        if (occ < 1) occ = 1;
+        int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((ntraj + kB - 1) / kB, (int64_t)c->num_cu * occ));
+        CHIP(c, hipEventRecord(c->ev0, c->stream));
+        hipLaunchKernelGGL(crnn::cathode_kernel<kB>, dim3(nblk), dim3(kB), 0, c->stream, prm);
+        CHIP(c, hipGetLastError());
+        CHIP(c, hipEventRecord(c->ev1, c->stream));
+    }
     std::vector<int32_t> h_ret((size_t)ntraj), h_nacc((size_t)ntraj), h_nrej((size_t)ntraj);
     if (loss) CHIP(c, hipMemcpyAsync(loss, c->d_loss, sizeof(double) * ntraj, hipMemcpyDeviceToHost, c->stream));
     if (grad) CHIP(c, hipMemcpyAsync(grad, c->d_grad, sizeof(double) * ntraj * CRNN_CATHODE_NP, hipMemcpyDeviceToHost, c->stream));

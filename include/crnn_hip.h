@@ -250,7 +250,8 @@ int32_t crnn_allreduce_grad(crnn_ctx *ctx, double *buf, int32_t n);
 #define CRNN_CATHODE_MAX_D 128
 #define CRNN_CATHODE_MAX_SETS 4096  /* heating rates per context (the first 8 are staged in LDS) */
 typedef struct crnn_cathode_config {
-    int32_t abi_version, device, maxiters, reserved0;
+    int32_t abi_version, device, maxiters;
+    int32_t grad_mode;  /* CRNN_GRAD_*: AUTO / ADJOINT = discrete adjoint (forward tangents if a trajectory outruns the tape) */
     double lb_clamp;   /* config.yaml:6   1e-16 */
     double T0;         /* network.jl:189  373.15 K */
     double atol, rtol; /* config.yaml:7 lb_abstol 1e-12; reltol = DiffEq default 1e-3 */

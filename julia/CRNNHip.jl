@@ -173,7 +173,7 @@ end
 # Bayesian cathode ensemble (Cathode_NCM333_UQ/src_333/network.jl:196-275): all particles x heating rates in one launch
 # ---------------------------------------------------------------------------------------------------------
 mutable struct CathodeConfig
-    abi_version::Int32; device::Int32; maxiters::Int32; reserved0::Int32
+    abi_version::Int32; device::Int32; maxiters::Int32; grad_mode::Int32
     lb_clamp::Float64; T0::Float64; atol::Float64; rtol::Float64
     gamma::Float64; qmin::Float64; qmax::Float64; beta1::Float64; beta2::Float64
     qsteady_min::Float64; qsteady_max::Float64; qoldinit::Float64

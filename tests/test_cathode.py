@@ -188,6 +188,26 @@ def test_gpu_cathode_matches_oracle_step_for_step(orc, cfx, tol):
 
 
 @pytest.mark.gpu
+def test_gpu_cathode_adjoint_equals_forward_tangents(cfx):
+    """grad_mode 0/2: reversed accepted steps; grad_mode 1: 14 tangent columns.  Same losses, gradients equal to rounding;
+    also for solutions truncated by maxiters (gradient of the saved prefix)."""
+    rng = np.random.default_rng(21)
+    p = 1 + 0.05 * rng.standard_normal((70, 17))              # more than one wavefront per heating rate
+    p[:, 6:9] = 0.0
+    for kw in (dict(), dict(maxiters=150), dict(atol=1e-10, rtol=1e-6)):
+        fwd, adj = _uq(cfx, grad_mode=1, **kw), _uq(cfx, grad_mode=2, **kw)
+        lf, gf, hf = fwd.solve(p, want_hrr=True)
+        la, ga, ha = adj.solve(p, want_hrr=True)
+        assert np.array_equal(fwd.last_retcode, adj.last_retcode) and np.array_equal(fwd.last_n_saved, adj.last_n_saved)
+        assert fwd.last_stats["n_accept"] == adj.last_stats["n_accept"]
+        assert np.max(np.abs(lf - la)) <= 1e-12 * np.max(np.abs(lf))
+        assert np.max(np.abs(hf - ha)) <= 1e-12 * np.max(np.abs(hf))
+        assert np.max(np.abs(gf - ga) / np.max(np.abs(gf), axis=2, keepdims=True)) < 1e-8
+        if "maxiters" in kw:
+            assert np.all(fwd.last_retcode == 1)
+
+
+@pytest.mark.gpu
 def test_gpu_cathode_dlnprob_and_reference_surface(orc, cfx):
     from crnn_amd.cathode import NORMALIZER, NORM_COL
     uq = _uq(cfx)
