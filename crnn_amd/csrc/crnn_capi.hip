@@ -121,6 +121,11 @@ struct Ctx {
     double *d_red_theta = nullptr;  // [n_theta + kExtra]
     int64_t n_fallback = 0;         // calls repeated with forward tangents after a tape overflow
     int adj_occ = 0;                // cached occupancy of the adjoint kernel
+    // deferred outcome of adjoint training steps (crnn_train_step): see check_pending
+    bool defer_next = false, last_deferred = false, force_forward = false;
+    struct StepArgs { int64_t first, count; int32_t n_save; };
+    std::vector<StepArgs> pending;  // steps enqueued since the host last looked
+    double *d_poison = nullptr;     // [0] sticky flag: a step was skipped; [1] number of skipped steps
     size_t tape_budget = 0;         // bytes the tape may take (auto mode), fixed at the first gradient call
     // reduction
     double *d_partials = nullptr;
@@ -188,9 +193,17 @@ __global__ void p2vec_kernel(int pmap, int ns, int nr, int has_temp, const doubl
 // counter, so that a training step is [this kernel] -> solve -> reductions.
 __global__ __launch_bounds__(256) void opt_kernel(crnn::OptCfg o, int P, int npart, double *p, const double *__restrict__ red,
                                                   double *state, int pmap, int ns, int nr, int has_temp, double *th, double *dth,
-                                                  int nth, unsigned long long *queue, unsigned int *overflow) {
+                                                  int nth, unsigned long long *queue, unsigned int *overflow, double *poison) {
     __shared__ double sh[256];
     const int tid = threadIdx.x;
+    // A poisoned gradient (NaN: some rank's adjoint tape overflowed) is not applied, and neither is any later step until
+    // the host has repeated the skipped ones in order (sticky flag): p, the optimiser state and theta stay as they are.
+    const bool skip = poison[0] != 0.0 || red[0] != red[0];
+    __syncthreads();
+    if (skip) {
+        if (tid == 0) { poison[0] = 1.0; poison[1] += 1.0; *queue = 0ULL; *overflow = 0u; }
+        return;
+    }
     const double ntraj = red[npart - 1];
     const double gscale = ntraj > 0 ? 1.0 / ntraj : 0.0;
     double *m = state, *v = state + P, *bp = state + 2 * P;
@@ -301,7 +314,7 @@ void fill_params(Ctx *c, crnn::SolveParams &prm, int P, int64_t first, int64_t c
 // reduction, then the chain rule through the P given directions.  Returns 1 (not an error) when some trajectory ran
 // out of tape: the caller repeats the call with forward tangents.
 int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const double *d_dtheta, int P, int64_t first,
-                       int64_t count, int n_save_active, bool want_pred) {
+                       int64_t count, int n_save_active, bool want_pred, bool defer) {
     const int nth = c->n_theta;
     const int npart_th = nth + crnn::kExtra, npart = P + crnn::kExtra;
     if (c->adj_occ < 1) {
@@ -362,13 +375,14 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
                        c->d_nacc, c->d_nrej, first, count, rows_per_block, c->d_partials);
     HIP_TRY(c, hipGetLastError());
     hipLaunchKernelGGL(crnn::reduce_project_kernel, dim3(1), dim3(256), 0, c->stream, c->d_partials, rblk, d_dtheta, nth, P,
-                       c->d_red_theta, c->d_red);
+                       c->d_red_theta, c->d_red, c->d_overflow);
     HIP_TRY(c, hipGetLastError());
+    c->last_npart = npart;
+    c->last_P = P;
+    if (defer) return 0;   // the device-resident training loop looks at the outcome later (check_pending)
     unsigned int ovf = 0;
     HIP_TRY(c, hipMemcpyAsync(&ovf, c->d_overflow, sizeof(ovf), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->last_npart = npart;
-    c->last_P = P;
     return ovf ? 1 : 0;
 }
 
@@ -442,7 +456,7 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
                            c->d_ret, c->d_nsaved, c->d_nacc, c->d_nrej, first, count, c->d_partials);
         HIP_TRY(c, hipGetLastError());
         hipLaunchKernelGGL(crnn::reduce_project_kernel, dim3(1), dim3(256), 0, c->stream, c->d_partials, rblk, d_dtheta, nth, P,
-                           c->d_red_theta, c->d_red);
+                           c->d_red_theta, c->d_red, (const unsigned int *)nullptr);
         HIP_TRY(c, hipGetLastError());
     } else {
         hipLaunchKernelGGL(crnn::reduce_traj_kernel, dim3(rblk), dim3(256), 0, c->stream, c->d_gtraj, 0, c->d_loss, c->d_ret,
@@ -482,10 +496,13 @@ int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int 
             return fail(c, "crnn_solve: HyChem gradients exist as discrete adjoint only (grad_mode AUTO or ADJOINT)");
         return launch_hychem(c, d_theta, d_dtheta, P, first, count, n_save_active, want_pred);
     }
-    if (P > 0 && c->cfg.grad_mode != CRNN_GRAD_FORWARD) {
+    c->last_deferred = false;
+    if (P > 0 && c->cfg.grad_mode != CRNN_GRAD_FORWARD && !c->force_forward) {
         const AdjEntry *ka = find_adjoint(c);
         if (ka) {
-            const int32_t r = launch_adjoint(c, ka, d_theta, d_dtheta, P, first, count, n_save_active, want_pred);
+            const bool defer = c->defer_next;
+            const int32_t r = launch_adjoint(c, ka, d_theta, d_dtheta, P, first, count, n_save_active, want_pred, defer);
+            c->last_deferred = defer && r == 0;
             if (r <= 0) return r;
             ++c->n_fallback;  // tape overflow: same call, forward tangents (results are overwritten)
         } else if (c->cfg.grad_mode == CRNN_GRAD_ADJOINT) {
@@ -773,6 +790,8 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
         hipMalloc((void **)&c->d_kc, sizeof(crnn::KConst)) != hipSuccess ||
         hipMalloc((void **)&c->d_queue, sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void **)&c->d_overflow, sizeof(unsigned int)) != hipSuccess ||
+        hipMalloc((void **)&c->d_poison, 2 * sizeof(double)) != hipSuccess ||
+        hipMemset(c->d_poison, 0, 2 * sizeof(double)) != hipSuccess ||
         hipMalloc((void **)&c->d_red_theta, sizeof(double) * (c->n_theta + crnn::kExtra)) != hipSuccess ||
         hipMalloc((void **)&c->d_p, sizeof(double) * c->n_params) != hipSuccess ||
         hipMalloc((void **)&c->d_p_eval, sizeof(double) * c->n_params) != hipSuccess ||
@@ -790,7 +809,7 @@ void crnn_ctx_destroy(crnn_ctx *ctx) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->own_u0 && c->d_u0) (void)hipFree(c->d_u0);
     if (c->own_data && c->d_data) (void)hipFree(c->d_data);
-    void *ptrs[] = {c->d_tabs, c->d_gacc, c->d_tape, c->d_overflow, c->d_red_theta, c->d_queue, c->d_nacc, c->d_nrej, c->d_gtraj, c->d_kc, c->d_tsave, c->d_pred, c->d_loss, c->d_ret, c->d_nsaved, c->d_theta, c->d_dtheta,
+    void *ptrs[] = {c->d_poison, c->d_tabs, c->d_gacc, c->d_tape, c->d_overflow, c->d_red_theta, c->d_queue, c->d_nacc, c->d_nrej, c->d_gtraj, c->d_kc, c->d_tsave, c->d_pred, c->d_loss, c->d_ret, c->d_nsaved, c->d_theta, c->d_dtheta,
                     c->d_partials, c->d_red, c->d_p, c->d_p_eval, c->d_opt, c->d_comm_buf};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < Ctx::kRing; ++i) {
@@ -1017,6 +1036,9 @@ int32_t crnn_train_init(crnn_ctx *ctx, const crnn_opt_config *o, const double *p
     if (!o || !p0) return fail(c, "crnn_train_init: null pointer");
     if (o->use_expdecay && o->decay_step < 1) return fail(c, "crnn_train_init: decay_step must be >= 1");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->pending.clear();             // a new training run: whatever was in flight belongs to the old one
+    HIP_TRY(c, hipMemsetAsync(c->d_poison, 0, 2 * sizeof(double), c->stream));
     c->opt = to_optcfg(o);
     std::vector<double> st(2 * c->n_params + 4);
     crnn::opt_init(c->opt, c->n_params, st.data());
@@ -1028,9 +1050,7 @@ int32_t crnn_train_init(crnn_ctx *ctx, const crnn_opt_config *o, const double *p
     return 0;
 }
 
-int32_t crnn_train_step_begin(crnn_ctx *ctx, int64_t first, int64_t count, int32_t n_save_active) {
-    Ctx *c = reinterpret_cast<Ctx *>(ctx);
-    if (!c) return fail(nullptr, "null ctx");
+static int32_t train_begin_impl(Ctx *c, int64_t first, int64_t count, int32_t n_save_active, bool defer) {
     if (!c->train_ready) return fail(c, "crnn_train_step: call crnn_train_init first");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     if (!c->theta_current) {
@@ -1039,18 +1059,19 @@ int32_t crnn_train_step_begin(crnn_ctx *ctx, int64_t first, int64_t count, int32
         HIP_TRY(c, hipGetLastError());
     }
     c->theta_current = false;   // consumed: anything else that touches d_theta / d_p must not find a stale flag
-    return launch_solve(c, c->d_theta, c->d_dtheta, c->n_params, first, count, n_save_active, false, false);
+    c->defer_next = defer;
+    const int32_t rc = launch_solve(c, c->d_theta, c->d_dtheta, c->n_params, first, count, n_save_active, false, false);
+    c->defer_next = false;
+    return rc;
 }
 
-int32_t crnn_train_step_end(crnn_ctx *ctx, double *loss_mean) {
-    Ctx *c = reinterpret_cast<Ctx *>(ctx);
-    if (!c) return fail(nullptr, "null ctx");
+static int32_t train_end_impl(Ctx *c, double *loss_mean) {
     if (!c->train_ready || c->last_npart == 0) return fail(c, "crnn_train_step_end: no step in flight");
     hipLaunchKernelGGL(opt_kernel, dim3(1), dim3(256), 0, c->stream, c->opt, c->n_params, c->last_npart, c->d_p, c->d_red,
                        c->d_opt, c->cfg.param_map, c->cfg.ns, c->cfg.nr, c->nfx, c->d_theta, c->d_dtheta, c->n_theta,
-                       c->d_queue, c->d_overflow);
+                       c->d_queue, c->d_overflow, c->d_poison);
     HIP_TRY(c, hipGetLastError());
-    c->theta_current = true;
+    c->theta_current = true;    // (a skipped step leaves p and theta as they were: still consistent)
     c->flags_zeroed = true;
     if (loss_mean) {
         double tail[5];
@@ -1061,12 +1082,60 @@ int32_t crnn_train_step_end(crnn_ctx *ctx, double *loss_mean) {
     return 0;
 }
 
+// The device-resident training loop (crnn_train_step) enqueues adjoint steps without looking at their tape-overflow
+// flag: a poisoned step is skipped on the device by every rank alike, and so is everything after it (sticky flag).
+// Here the host looks: if steps were skipped they are repeated, in order, with forward tangents.  Called before anything
+// that exposes training state (loss, parameters, statistics, synchronize) and every kMaxPending steps.
+static int32_t check_pending(Ctx *c, double *loss_mean) {
+    if (c->pending.empty()) return 0;
+    double poison[2] = {0.0, 0.0};
+    HIP_TRY(c, hipMemcpyAsync(poison, c->d_poison, sizeof(poison), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::vector<Ctx::StepArgs> steps;
+    steps.swap(c->pending);
+    if (poison[0] == 0.0) return 0;
+    const size_t nskip = std::min<size_t>((size_t)llround(poison[1]), steps.size());
+    HIP_TRY(c, hipMemsetAsync(c->d_poison, 0, 2 * sizeof(double), c->stream));
+    c->force_forward = true;
+    int32_t rc = 0;
+    for (size_t i = steps.size() - nskip; i < steps.size() && rc == 0; ++i) {
+        ++c->n_fallback;
+        rc = train_begin_impl(c, steps[i].first, steps[i].count, steps[i].n_save, false);
+        if (rc == 0 && c->comm) {
+            ncclResult_t r_ = ncclAllReduce(c->d_red, c->d_red, c->last_npart, ncclDouble, ncclSum, c->comm, c->stream);
+            if (r_ != ncclSuccess) rc = fail(c, std::string("ncclAllReduce: ") + ncclGetErrorString(r_));
+        }
+        if (rc == 0) rc = train_end_impl(c, (i + 1 == steps.size()) ? loss_mean : nullptr);
+    }
+    c->force_forward = false;
+    return rc;
+}
+constexpr size_t kMaxPending = 64;
+
+int32_t crnn_train_step_begin(crnn_ctx *ctx, int64_t first, int64_t count, int32_t n_save_active) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return fail(nullptr, "null ctx");
+    if (check_pending(c, nullptr)) return -1;
+    return train_begin_impl(c, first, count, n_save_active, false);   // split API: outcome checked before returning
+}
+
+int32_t crnn_train_step_end(crnn_ctx *ctx, double *loss_mean) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return fail(nullptr, "null ctx");
+    return train_end_impl(c, loss_mean);
+}
+
 int32_t crnn_train_step(crnn_ctx *ctx, int64_t first, int64_t count, int32_t n_save_active, double *loss_mean) {
     Ctx *c = reinterpret_cast<Ctx *>(ctx);
-    if (crnn_train_step_begin(ctx, first, count, n_save_active)) return -1;
+    if (!c) return fail(nullptr, "null ctx");
+    if (c->pending.size() >= kMaxPending && check_pending(c, nullptr)) return -1;
+    if (train_begin_impl(c, first, count, n_save_active, true)) return -1;
+    if (c->last_deferred) c->pending.push_back({first, count, n_save_active});
     if (c->comm)
         NCCL_TRY(c, ncclAllReduce(c->d_red, c->d_red, c->last_npart, ncclDouble, ncclSum, c->comm, c->stream));
-    return crnn_train_step_end(ctx, loss_mean);
+    if (train_end_impl(c, loss_mean)) return -1;
+    if (loss_mean) return check_pending(c, loss_mean);   // the caller wants this step's loss: look now
+    return 0;
 }
 
 int32_t crnn_grad_buffer(crnn_ctx *ctx, void **d_ptr, int32_t *n_doubles) {
@@ -1082,6 +1151,7 @@ int32_t crnn_get_params(crnn_ctx *ctx, double *p) {
     Ctx *c = reinterpret_cast<Ctx *>(ctx);
     if (!c || !p) return fail(c, "crnn_get_params: null");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (check_pending(c, nullptr)) return -1;
     HIP_TRY(c, hipMemcpyAsync(p, c->d_p, sizeof(double) * c->n_params, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -1091,6 +1161,7 @@ int32_t crnn_set_params(crnn_ctx *ctx, const double *p) {
     Ctx *c = reinterpret_cast<Ctx *>(ctx);
     if (!c || !p) return fail(c, "crnn_set_params: null");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (check_pending(c, nullptr)) return -1;
     c->theta_current = false;
     HIP_TRY(c, hipMemcpyAsync(c->d_p, p, sizeof(double) * c->n_params, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1101,6 +1172,7 @@ int32_t crnn_last_stats(crnn_ctx *ctx, crnn_stats *stats) {
     Ctx *c = reinterpret_cast<Ctx *>(ctx);
     if (!c || !stats) return fail(c, "crnn_last_stats: null");
     if (c->last_npart == 0) return fail(c, "crnn_last_stats: no solve has run yet");
+    if (check_pending(c, nullptr)) return -1;
     std::vector<double> red(c->last_npart);
     HIP_TRY(c, hipMemcpyAsync(red.data(), c->d_red, sizeof(double) * c->last_npart, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1124,6 +1196,7 @@ int32_t crnn_kernel_times(crnn_ctx *ctx, double *ms, int32_t n) {
 int32_t crnn_synchronize(crnn_ctx *ctx) {
     Ctx *c = reinterpret_cast<Ctx *>(ctx);
     if (!c) return fail(nullptr, "null ctx");
+    if (check_pending(c, nullptr)) return -1;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return 0;
 }

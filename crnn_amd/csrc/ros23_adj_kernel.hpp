@@ -611,7 +611,8 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
 // One block; nth + kExtra <= 256.
 __global__ __launch_bounds__(256) void reduce_project_kernel(const double *__restrict__ partials, int nblk,
                                                              const double *__restrict__ dtheta, int nth, int P,
-                                                             double *__restrict__ red_theta, double *__restrict__ out) {
+                                                             double *__restrict__ red_theta, double *__restrict__ out,
+                                                             const unsigned int *__restrict__ overflow) {
     __shared__ double sh[256];
     __shared__ double part[4][256];
     const int npart = nth + kExtra;
@@ -639,10 +640,14 @@ __global__ __launch_bounds__(256) void reduce_project_kernel(const double *__res
         __syncthreads();
     }
     __syncthreads();
+    // A trajectory that outran its tape makes this launch's gradient unusable: it is poisoned with NaN so that every
+    // consumer -- the optimiser kernel of this rank and, through the all-reduce, of every other rank -- skips it in the same
+    // way; the host repeats the step with forward tangents when it next looks (crnn_capi.hip: check_pending).
+    const bool bad = overflow && *overflow != 0;
     for (int k = tid; k < P; k += 256) {
         double a = 0.0;
         for (int m = 0; m < nth; ++m) a = fma(dtheta[(size_t)k * nth + m], sh[m], a);
-        out[k] = a;
+        out[k] = bad ? __longlong_as_double(0x7ff8000000000000LL) : a;
     }
     if (tid < kExtra) out[P + tid] = sh[nth + tid];
 }

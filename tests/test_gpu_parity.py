@@ -237,6 +237,39 @@ def test_training_step_matches_host_chain(case2_setup):
         assert np.max(np.abs(node.params() - p_host)) < 1e-12
 
 
+def test_async_adjoint_training_and_deferred_replay(rober_setup):
+    """crnn_train_step does not wait for the adjoint's tape-overflow flag: a poisoned step is skipped on the device (and
+    everything after it), and repeated in order with forward tangents when the host next looks.  End states must be
+    bit-identical to training that never used the adjoint."""
+    from crnn_amd import Optimiser, PRESET_ROBER
+    s = rober_setup
+    p0 = s["p_ckpt"]
+    samples = [20, 40, 22, 40, 25, 40, 40, 21]
+
+    def run(per_step_loss, **kw):
+        node = _node("rober", s, **kw)
+        node.train_init(Optimiser(43, PRESET_ROBER), p0)
+        losses = [node.train_step(sample=sm, want_loss=per_step_loss) for sm in samples]
+        return node.params(), losses, node
+
+    p_fwd, l_fwd, _ = run(True, grad_mode=1)
+    # (a) roomy tape: async adjoint == adjoint with a look after every step; gradients equal forward tangents to rounding
+    p_async, _, _ = run(False, grad_mode=2)
+    p_sync, l_sync, _ = run(True, grad_mode=2)
+    assert np.array_equal(p_async, p_sync)
+    assert np.max(np.abs(p_sync - p_fwd)) < 1e-9 and np.max(np.abs(np.array(l_sync) - np.array(l_fwd))) < 1e-12
+    # (b) 30 tape slots: horizons 20-25 fit, the full horizon (about 35 steps) overflows -> skipped steps are replayed
+    p_tiny, _, node = run(False, grad_mode=2, tape_steps=30)
+    p_tiny_sync, l_tiny_sync, _ = run(True, grad_mode=2, tape_steps=30)
+    assert np.array_equal(p_tiny, p_tiny_sync)
+    # from the first overflowing step on, everything was done with forward tangents (sticky skip + in-order replay)
+    assert np.max(np.abs(p_tiny - p_fwd)) < 1e-9
+    assert np.max(np.abs(np.array(l_tiny_sync) - np.array(l_fwd))) < 1e-12
+    # (c) every step overflows: pure forward-tangent training, bit for bit
+    p_all, _, _ = run(False, grad_mode=2, tape_steps=4)
+    assert np.array_equal(p_all, p_fwd)
+
+
 def test_rccl_single_rank_allreduce(case2_setup):
     """The in-library RCCL path on a 1-rank communicator (multi-rank needs >1 GPU)."""
     import ctypes as C
