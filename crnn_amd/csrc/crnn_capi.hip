@@ -340,10 +340,8 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
     if (c->tape_doubles < lanes * (size_t)cap * recw) {
         if (ensure(c, &c->d_tape, &c->tape_doubles, lanes * (size_t)cap * recw)) return -1;
     }
-    const int rows_per_block = 256;
-    const int rblk = (int)((count + rows_per_block - 1) / rows_per_block);
-    if (ensure(c, &c->d_partials, &c->partials_cap, (size_t)rblk * std::max(npart_th, npart))) return -1;
-    if (ensure(c, &c->d_gtraj, &c->gtraj_cap, (size_t)count * nth)) return -1;
+    const int nbatch = (int)((count + 63) / 64);     // one partial row per 64-trajectory batch (written by the solve kernel)
+    if (ensure(c, &c->d_partials, &c->partials_cap, (size_t)nbatch * std::max(npart_th, npart))) return -1;
     if (c->npart_max < npart) {
         if (c->d_red) HIP_TRY(c, hipFree(c->d_red));
         c->d_red = nullptr;
@@ -357,7 +355,7 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
     crnn::SolveParams prm{};
     fill_params(c, prm, P, first, count, n_save_active, want_pred);
     crnn::AdjParams adj{};
-    adj.tape = c->d_tape; adj.tape_cap = (int32_t)cap; adj.overflow = c->d_overflow;
+    adj.tape = c->d_tape; adj.tape_cap = (int32_t)cap; adj.overflow = c->d_overflow; adj.batch_partials = c->d_partials;
     if (upload_consts(c)) return -1;
     if (!c->flags_zeroed) {
         HIP_TRY(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), c->stream));
@@ -371,10 +369,7 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
     hipLaunchKernelGGL(k->fn, dim3(nblk), dim3(kBlock), 0, c->stream, prm, d_theta, adj);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    hipLaunchKernelGGL(crnn::reduce_traj_kernel, dim3(rblk), dim3(256), 0, c->stream, c->d_gtraj, nth, c->d_loss, c->d_ret,
-                       c->d_nacc, c->d_nrej, first, count, rows_per_block, c->d_partials);
-    HIP_TRY(c, hipGetLastError());
-    hipLaunchKernelGGL(crnn::reduce_project_kernel, dim3(1), dim3(256), 0, c->stream, c->d_partials, rblk, d_dtheta, nth, P,
+    hipLaunchKernelGGL(crnn::reduce_project_kernel, dim3(1), dim3(256), 0, c->stream, c->d_partials, nbatch, d_dtheta, nth, P,
                        c->d_red_theta, c->d_red, c->d_overflow);
     HIP_TRY(c, hipGetLastError());
     c->last_npart = npart;

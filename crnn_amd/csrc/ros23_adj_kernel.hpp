@@ -46,6 +46,7 @@ struct AdjParams {
     double *tape;                // [lanes][tape_cap][NS + 2]
     int32_t tape_cap;            // accepted steps a lane can record
     unsigned int *overflow;      // incremented by every trajectory that ran out of tape (host then falls back)
+    double *batch_partials;      // [ceil(count/64)][NTH + kExtra]: per 64-trajectory batch sums
 };
 
 // Solve A^T x = b with the factors of lu_factor (P A = L U): x = P^T L^-T U^-T b
@@ -119,18 +120,20 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
     constexpr int N = L_::N;
     constexpr int NTH = L_::NTH;
     constexpr int RECW = NS + 2;
+    static_assert(NTH + kExtra <= 64, "the per-batch sums use one lane per column");
     using Solver = typename SolverSel<(NR < NS), NS, NR, HAS_T, USE_SCALE>::type;
 
     __shared__ double kc_lds[kNConst];
     __shared__ double ts_lds[kMaxSave];
-    __shared__ double thb_lds[CRNN_ADJ_THB_LDS ? NTH * BLOCK : 1];
+    __shared__ double thb_lds[NTH * BLOCK];     // gradient accumulators [m][lane] (also the staging area of the batch sums)
+    __shared__ double ex_lds[kExtra * BLOCK];
     const int tid = threadIdx.x;
     for (int idx = tid; idx < kNConst; idx += BLOCK) kc_lds[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
     for (int idx = tid; idx < prm.n_save; idx += BLOCK) ts_lds[idx] = prm.tsave[idx];
     __syncthreads();
     const KConst *kc = reinterpret_cast<const KConst *>(kc_lds);
     const double *__restrict__ th = theta;
-    double *const thb_s = thb_lds + (CRNN_ADJ_THB_LDS ? tid : 0);   // accumulator m of this lane: thb_s[m * BLOCK]
+    double *const thb_s = thb_lds + tid;   // accumulator m of this lane: thb_s[m * BLOCK]
 
     const double d_ = 0.29289321881345248;    // 1/(2+sqrt 2)
     const double c32 = 7.4142135623730950;    // 6+sqrt 2
@@ -596,9 +599,32 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
             prm.n_saved[b] = n_saved;
             prm.n_accept[b] = nacc;
             prm.n_reject[b] = nrej;
-            double *grow = prm.gtraj + (size_t)traj * NTH;
+        }
+        // ---- sums over the 64 trajectories of this batch, through LDS: every lane parks its scaled accumulators and its
+        //      five scalars, then lane m of the wavefront adds up row m over the 64 lanes in lane order.  The result depends
+        //      on the batch only (not on which wavefront processed it), so the gradient stays bitwise reproducible.
+        {
+            const double denom_ = (double)prm.n_obs * (double)n_saved;
+            const double scale_ = (valid && n_saved > 0) ? 1.0 / denom_ : 0.0;
 #pragma unroll
-            for (int m = 0; m < NTH; ++m) grow[m] = (CRNN_ADJ_THB_LDS ? thb_s[m * BLOCK] : THB_REG(m)) * inv_den;
+            for (int m = 0; m < NTH; ++m) thb_s[m * BLOCK] = (CRNN_ADJ_THB_LDS ? thb_s[m * BLOCK] : THB_REG(m)) * scale_;
+            ex_lds[0 * BLOCK + tid] = valid ? loss_sum * scale_ : 0.0;
+            ex_lds[1 * BLOCK + tid] = (valid && rc == 0) ? 1.0 : 0.0;
+            ex_lds[2 * BLOCK + tid] = valid ? (double)nacc : 0.0;
+            ex_lds[3 * BLOCK + tid] = valid ? (double)nrej : 0.0;
+            ex_lds[4 * BLOCK + tid] = valid ? 1.0 : 0.0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double *prow = adj.batch_partials + (size_t)(wave_base >> 6) * (NTH + kExtra);
+            const int w0 = tid & ~63;   // first lane of this wavefront within the block
+            if (lane < NTH + kExtra) {
+                const double *src = lane < NTH ? thb_lds + lane * BLOCK + w0 : ex_lds + (lane - NTH) * BLOCK + w0;
+                double a = 0.0;
+                for (int k = 0; k < 64; ++k) a += src[k];
+                prow[lane] = a;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
 #undef THB_ADD
 #undef THB_REG
