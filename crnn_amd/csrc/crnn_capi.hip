@@ -369,7 +369,7 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
     hipLaunchKernelGGL(k->fn, dim3(nblk), dim3(kBlock), 0, c->stream, prm, d_theta, adj);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    hipLaunchKernelGGL(crnn::reduce_project_kernel, dim3(1), dim3(256), 0, c->stream, c->d_partials, nbatch, d_dtheta, nth, P,
+    hipLaunchKernelGGL(crnn::reduce_project_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_partials, nbatch, d_dtheta, nth, P,
                        c->d_red_theta, c->d_red, c->d_overflow);
     HIP_TRY(c, hipGetLastError());
     c->last_npart = npart;
@@ -450,7 +450,7 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
         hipLaunchKernelGGL(crnn::reduce_gacc_kernel, dim3(rblk), dim3(256), 0, c->stream, c->d_gacc, nth, c->n_obs, c->d_loss,
                            c->d_ret, c->d_nsaved, c->d_nacc, c->d_nrej, first, count, c->d_partials);
         HIP_TRY(c, hipGetLastError());
-        hipLaunchKernelGGL(crnn::reduce_project_kernel, dim3(1), dim3(256), 0, c->stream, c->d_partials, rblk, d_dtheta, nth, P,
+        hipLaunchKernelGGL(crnn::reduce_project_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_partials, rblk, d_dtheta, nth, P,
                            c->d_red_theta, c->d_red, (const unsigned int *)nullptr);
         HIP_TRY(c, hipGetLastError());
     } else {

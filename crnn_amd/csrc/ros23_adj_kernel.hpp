@@ -635,42 +635,43 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
 //   red_theta[m] = sum_blk partials[blk][m]   (m < nth + kExtra; the order over blk is fixed)
 //   out = [ dtheta[k,:] . red_theta[0:nth], k < P | extras ]
 // One block; nth + kExtra <= 256.
-__global__ __launch_bounds__(256) void reduce_project_kernel(const double *__restrict__ partials, int nblk,
-                                                             const double *__restrict__ dtheta, int nth, int P,
-                                                             double *__restrict__ red_theta, double *__restrict__ out,
-                                                             const unsigned int *__restrict__ overflow) {
+__global__ __launch_bounds__(1024) void reduce_project_kernel(const double *__restrict__ partials, int nblk,
+                                                              const double *__restrict__ dtheta, int nth, int P,
+                                                              double *__restrict__ red_theta, double *__restrict__ out,
+                                                              const unsigned int *__restrict__ overflow) {
     __shared__ double sh[256];
-    __shared__ double part[4][256];
+    __shared__ double part[16][64];
     const int npart = nth + kExtra;
     const int tid = threadIdx.x;
-    // columns in chunks of 64, four row lanes per column; the combination order is fixed
+    // columns in chunks of 64, sixteen row lanes per column; the combination order is fixed
     const int col = tid & 63, rl = tid >> 6;
     for (int c0 = 0; c0 < npart; c0 += 64) {
         const int k = c0 + col;
         double a0 = 0.0, a1 = 0.0;
         if (k < npart) {
             int bI = rl;
-            for (; bI + 4 < nblk; bI += 8) {
+            for (; bI + 16 < nblk; bI += 32) {
                 a0 += partials[(size_t)bI * npart + k];
-                a1 += partials[(size_t)(bI + 4) * npart + k];
+                a1 += partials[(size_t)(bI + 16) * npart + k];
             }
             if (bI < nblk) a0 += partials[(size_t)bI * npart + k];
         }
         part[rl][col] = a0 + a1;
         __syncthreads();
         if (rl == 0 && k < npart) {
-            const double a = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
+            double a = 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a += part[r][col];
             sh[k] = a;
             red_theta[k] = a;
         }
         __syncthreads();
     }
-    __syncthreads();
     // A trajectory that outran its tape makes this launch's gradient unusable: it is poisoned with NaN so that every
     // consumer -- the optimiser kernel of this rank and, through the all-reduce, of every other rank -- skips it in the same
     // way; the host repeats the step with forward tangents when it next looks (crnn_capi.hip: check_pending).
     const bool bad = overflow && *overflow != 0;
-    for (int k = tid; k < P; k += 256) {
+    for (int k = tid; k < P; k += 1024) {
         double a = 0.0;
         for (int m = 0; m < nth; ++m) a = fma(dtheta[(size_t)k * nth + m], sh[m], a);
         out[k] = bad ? __longlong_as_double(0x7ff8000000000000LL) : a;
