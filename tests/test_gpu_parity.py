@@ -237,6 +237,36 @@ def test_training_step_matches_host_chain(case2_setup):
         assert np.max(np.abs(node.params() - p_host)) < 1e-12
 
 
+def test_case1_rosenbrock23_adjoint_woodbury_4x4(orc, fx):
+    """case1 shape (5 species, 4 reactions: Woodbury with a 4x4 pivoted LU and its transposed solve) on the stiff stepper:
+    adjoint == forward tangents == oracle."""
+    from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE1, SOLVER_ROSENBROCK23, cases
+    rng = np.random.Generator(np.random.PCG64(12))
+    ts = cases.case1_tsteps()
+    u0 = np.array(fx["case1"]["u0"])
+    p = np.array(fx["case1"]["p"])
+    gen = NeuralODE(ODEProblem(PRESET_CASE1, ts, atol=1e-12, rtol=1e-10))
+    data = cases.add_noise(gen.predict_theta(u0, cases.case1_true_theta()), 0.05, rng)
+    gen.close()
+    ys = cases.max_min(data, lb=1e-5)
+    res = {}
+    for mode in (1, 2):
+        node = NeuralODE(ODEProblem(PRESET_CASE1, ts, solver=SOLVER_ROSENBROCK23, grad_mode=mode, atol=1e-7, rtol=1e-5))
+        node.set_ensemble(u0, data, ys)
+        res[mode] = node.loss_and_grad(p) + (node.last_stats["n_accept"],)
+        node.close()
+    th, dth = orc.p2vec(1, 5, 4, p)
+    pb = orc.make_problem(ns=5, nr=4, lb=1e-5, ub=10.0, atol=1e-7, rtol=1e-5, yscale=ys, clamp_pred=1, maxiters=10000, solver=0)
+    B = u0.shape[0]
+    ref = orc.solve_batch(pb, th, np.ascontiguousarray(u0.T), ts, np.ascontiguousarray(data.transpose(2, 1, 0)), dtheta=dth)
+    gref = ref["grad"] / B
+    for mode in (1, 2):
+        loss, grad, nacc = res[mode]
+        assert nacc == ref["naccept"] and abs(loss - ref["loss"].mean()) < 1e-9 * loss
+        assert np.max(np.abs(grad - gref)) < 1e-7 * np.max(np.abs(gref))
+    assert np.max(np.abs(res[1][1] - res[2][1])) < 1e-9 * np.max(np.abs(gref))
+
+
 def test_async_adjoint_training_and_deferred_replay(rober_setup):
     """crnn_train_step does not wait for the adjoint's tape-overflow flag: a poisoned step is skipped on the device (and
     everything after it), and repeated in order with forward tangents when the host next looks.  End states must be
