@@ -170,6 +170,33 @@ def test_tiny_and_ragged_batches(orc, case2_setup):
         node.close()
 
 
+def test_more_trajectories_than_lanes(case2_setup):
+    """150 001 trajectories (> 65 536 resident lanes, not a multiple of 64): wavefronts take several batches from the queue,
+    the last one is ragged.  The 8 base conditions are tiled, so every row must equal the small launch's row, the batch
+    gradient must equal the small gradient (both modes), and a sub-range must work."""
+    from crnn_amd import p2vec_jac
+    s = case2_setup
+    p = s["p_ckpt"]
+    B = 150001
+    rep = -(-B // 8)
+    big = dict(s, u0=np.tile(s["u0"], (rep, 1))[:B], data=np.tile(s["data"], (rep, 1, 1))[:B])
+    for mode in (2, 1):
+        node, small = _node(big, grad_mode=mode), _node(s, grad_mode=mode)
+        th, dth = p2vec_jac(node.pmap, 6, 3, p)
+        _, loss, gsum, ret, nsv = node._solve(node._ctx, B, th, dth, 0, B, None, False)
+        _, ls, gs, _, _ = small._solve(small._ctx, 8, th, dth, 0, 8, None, False)
+        assert np.all(ret == 0) and np.all(nsv == 50)
+        assert np.array_equal(loss, np.tile(ls, rep)[:B])
+        w = np.bincount(np.arange(B) % 8, minlength=8)                  # how often each base condition occurs
+        assert node.last_stats["n_traj"] == B
+        # per-condition gradients from one-trajectory launches of the small node, weighted
+        gref = sum(w[i] * small._solve(small._ctx, 8, th, dth, i, 1, None, False)[2] for i in range(8))
+        assert np.max(np.abs(gsum - gref)) < 1e-9 * np.max(np.abs(gref))
+        _, lsub, gsub, _, _ = node._solve(node._ctx, B, th, dth, 70001, 12345, None, False)
+        assert np.array_equal(lsub[70001:70001 + 12345], loss[70001:70001 + 12345])
+        node.close(); small.close()
+
+
 def test_observation_mask_and_mse(orc, case2_setup):
     """i_obs = [1,2,4,5,6] as in case2_missing.jl:165 (0-based here) and the MSE loss kind."""
     from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE2
