@@ -428,7 +428,6 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                     for (int i = 0; i < NS; ++i) dk[i] = f1[i] - k1[i];
                 }
                 W.solve(th, gg0, gr0, kc->scale, dk);
-                CRNN_SCHED_FENCE();
 
                 // ---- loss and its seeds at the save points inside (tn, tnew]
                 double A_[NS], B1[NS], B2[NS];
@@ -480,7 +479,6 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                     }
                 }
 
-                CRNN_SCHED_FENCE();
                 // ---- adjoint of the step
                 double kb1[NS], v[NS], ub[NS];
 #pragma unroll
@@ -501,7 +499,6 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                     for (int i = 0; i < NS; ++i) a = fma(vs[i], th[L_::wo(i, j)], a);
                     av[j] = a;
                 }
-                CRNN_SCHED_FENCE();
                 // point u_mid: d(v.f)/d(u, theta)
                 {
                     double um[NS];
@@ -527,9 +524,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                         kb1[c] = fma(0.5 * h, m, kb1[c]);
                     }
                 }
-                CRNN_SCHED_FENCE();
                 solve_T<NS, NR, HAS_T, USE_SCALE>(W, th, gg0, gr0, kc->scale, kb1);      // kb1 = w = W^-T kb1
-                CRNN_SCHED_FENCE();
                 // point u_n: d/d(u, theta) [ w.f + gam (v.J dk + w.J k1) ]
                 {
                     double ws[NS];
