@@ -39,6 +39,14 @@
 #ifndef CRNN_ADJ_THB_LDS
 #define CRNN_ADJ_THB_LDS 1
 #endif
+// 1: the tape record also holds the stages k1 and k2 - k1 of the accepted step (NS + 2 -> 3 NS + 2 doubles).  The reverse
+//    sweep then skips two right-hand sides and two solves, and -- more important at one wavefront per SIMD -- the point
+//    u_mid is known at once, so the two feature / rate evaluations of a reverse step are independent of each other.
+//    Measured (tools/kvariants.sh): no gain (case2 0.612 vs 0.618 ms, robertson 0.706 vs 0.704 ms) -- the 2.3x tape
+//    traffic eats the saved arithmetic -- so the default stays 0.
+#ifndef CRNN_ADJ_TAPE_K
+#define CRNN_ADJ_TAPE_K 0
+#endif
 
 namespace crnn {
 
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
     using L_ = Lay<NS, NR, HAS_T>;
     constexpr int N = L_::N;
     constexpr int NTH = L_::NTH;
-    constexpr int RECW = NS + 2;
+    constexpr int RECW = CRNN_ADJ_TAPE_K ? 3 * NS + 2 : NS + 2;
     static_assert(NTH + kExtra <= 64, "the per-batch sums use one lane per column");
     using Solver = typename SolverSel<(NR < NS), NS, NR, HAS_T, USE_SCALE>::type;
 
@@ -300,6 +308,10 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                                 rec[1] = dt;
 #pragma unroll
                                 for (int i = 0; i < NS; ++i) rec[2 + i] = u[i];
+#if CRNN_ADJ_TAPE_K
+#pragma unroll
+                                for (int i = 0; i < NS; ++i) { rec[2 + NS + i] = k1[i]; rec[2 + 2 * NS + i] = dk[i]; }
+#endif
                                 ++nacc;
                                 const double tnew = last ? tend : t + dt;
                                 while (jsave < nsave) {
@@ -379,11 +391,18 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
             for (int i = 0; i < NS; ++i) d[i] = (CRNN_ADJ_DBG & 2) ? 0.5 : row[doff[i]];
         };
         double rt = 0.0, rdt = 0.0, ru[NS];   // tape record s, prefetched
+#if CRNN_ADJ_TAPE_K
+        double rk1[NS], rdk[NS];
+#endif
         {
             const double *rec = tape + (size_t)(s > 0 ? s : 0) * RECW;
             rt = rec[0]; rdt = rec[1];
 #pragma unroll
             for (int i = 0; i < NS; ++i) ru[i] = rec[2 + i];
+#if CRNN_ADJ_TAPE_K
+#pragma unroll
+            for (int i = 0; i < NS; ++i) { rk1[i] = rec[2 + NS + i]; rdk[i] = rec[2 + 2 * NS + i]; }
+#endif
         }
 
         while (__builtin_amdgcn_ballot_w64(s >= 0) != 0) {
@@ -392,6 +411,11 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                 double un[NS];
 #pragma unroll
                 for (int i = 0; i < NS; ++i) un[i] = ru[i];
+#if CRNN_ADJ_TAPE_K
+                double k1[NS], dk[NS];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) { k1[i] = rk1[i]; dk[i] = rdk[i]; }
+#endif
                 double dA[NS], dB[NS], dC[NS];
                 load_row(jsave - 1, dA);
                 load_row(jsave - 2, dB);
@@ -401,19 +425,38 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                     rt = rec[0]; rdt = rec[1];
 #pragma unroll
                     for (int i = 0; i < NS; ++i) ru[i] = rec[2 + i];
+#if CRNN_ADJ_TAPE_K
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) { rk1[i] = rec[2 + NS + i]; rdk[i] = rec[2 + 2 * NS + i]; }
+#endif
                 }
                 // ---- re-form the step
-                double x0[NS], gg0[NS], rr0[NR], ff0[NS];
-                features<NS>(un, kc->lb, kc->ub, x0, gg0);
-                rates<NS, NR, HAS_T>(th, x0, bT, rr0);
-                rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, rr0, kc->scale, ff0);
+                double x0[NS], gg0[NS], rr0[NR];
                 Solver W;
                 const double gam = d_ * h;
-                double gr0[NR];
+                double gr0[NR], x1[NS], g1[NS], r1[NR];
+#if CRNN_ADJ_TAPE_K
+                {   // both points are known from the tape: two independent evaluations
+                    double u1[NS];
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) u1[i] = fma(0.5 * h, k1[i], un[i]);
+                    features<NS>(un, kc->lb, kc->ub, x0, gg0);
+                    features<NS>(u1, kc->lb, kc->ub, x1, g1);
+                    rates<NS, NR, HAS_T>(th, x0, bT, rr0);
+                    rates<NS, NR, HAS_T>(th, x1, bT, r1);
+                }
 #pragma unroll
                 for (int j = 0; j < NR; ++j) gr0[j] = gam * rr0[j];
                 (void)W.factor(th, gg0, rr0, gam, kc->scale);
-                double k1[NS], dk[NS], x1[NS], g1[NS], r1[NR];
+#else
+                double ff0[NS];
+                features<NS>(un, kc->lb, kc->ub, x0, gg0);
+                rates<NS, NR, HAS_T>(th, x0, bT, rr0);
+                rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, rr0, kc->scale, ff0);
+#pragma unroll
+                for (int j = 0; j < NR; ++j) gr0[j] = gam * rr0[j];
+                (void)W.factor(th, gg0, rr0, gam, kc->scale);
+                double k1[NS], dk[NS];
 #pragma unroll
                 for (int i = 0; i < NS; ++i) k1[i] = ff0[i];
                 W.solve(th, gg0, gr0, kc->scale, k1);
@@ -428,6 +471,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                     for (int i = 0; i < NS; ++i) dk[i] = f1[i] - k1[i];
                 }
                 W.solve(th, gg0, gr0, kc->scale, dk);
+#endif
 
                 // ---- loss and its seeds at the save points inside (tn, tnew]
                 double A_[NS], B1[NS], B2[NS];
