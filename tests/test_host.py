@@ -26,6 +26,18 @@ def test_library_exports_every_declared_symbol():
     assert raw.crnn_abi_version() == 2
 
 
+def test_header_is_plain_c99(tmp_path):
+    """The boundary is a C ABI: include/crnn_hip.h must compile as C99 (no C++-isms, no torch types)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    src = tmp_path / "h.c"
+    src.write_text('#include "crnn_hip.h"\nint main(void) { crnn_config c; crnn_cathode_config k; (void)c; (void)k; return crnn_abi_version == 0; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
+
+
 def test_struct_layouts_match_header():
     """ctypes mirrors == the C structs the library was compiled with (also enforced at import)."""
     from crnn_amd import _lib as L
