@@ -33,7 +33,7 @@ def test_header_is_plain_c99(tmp_path):
     if shutil.which("gcc") is None:
         pytest.skip("gcc not available")
     src = tmp_path / "h.c"
-    src.write_text('#include "crnn_hip.h"\nint main(void) { crnn_config c; crnn_cathode_config k; (void)c; (void)k; return crnn_abi_version == 0; }\n')
+    src.write_text('#include "crnn_hip.h"\nint main(void) { crnn_config c; crnn_cathode_config k; (void)c; (void)k; return crnn_abi_version() == 0; }\n')
     inc = os.path.join(ROOT, "include")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
 
