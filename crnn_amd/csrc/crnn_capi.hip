@@ -26,6 +26,7 @@ thread_local std::string g_last_error;
 
 struct Ctx;
 int32_t fail(Ctx *ctx, const std::string &msg);
+int32_t check_pending(Ctx *c, double *loss_mean);   // deferred outcome of adjoint training steps (defined with the training loop)
 
 #define HIP_TRY(ctx, expr)                                                                          \
     do {                                                                                            \
@@ -882,6 +883,7 @@ int32_t crnn_ctx_set_data(crnn_ctx *ctx, const double *u0, const double *data, c
     if (!c) return fail(nullptr, "null ctx");
     if (!u0 || !data) return fail(c, "crnn_ctx_set_data: null u0/data");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (check_pending(c, nullptr)) return -1;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->own_u0 && c->d_u0) HIP_TRY(c, hipFree(c->d_u0));
     if (c->own_data && c->d_data) HIP_TRY(c, hipFree(c->d_data));
@@ -907,6 +909,7 @@ int32_t crnn_ctx_set_data_device(crnn_ctx *ctx, const void *d_u0, const void *d_
     if (!c) return fail(nullptr, "null ctx");
     if (!d_u0 || !d_data) return fail(c, "crnn_ctx_set_data_device: null u0/data");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (check_pending(c, nullptr)) return -1;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->own_u0 && c->d_u0) HIP_TRY(c, hipFree(c->d_u0));
     if (c->own_data && c->d_data) HIP_TRY(c, hipFree(c->d_data));
@@ -956,6 +959,7 @@ int32_t crnn_solve(crnn_ctx *ctx, const double *theta, const double *dtheta, int
     if (n_dir > c->max_dir) return fail(c, "crnn_solve: n_dir exceeds max(n_params, n_theta)");
     if (grad && n_dir == 0) return fail(c, "crnn_solve: grad requested with n_dir = 0");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (check_pending(c, nullptr)) return -1;
     c->theta_current = false;
     HIP_TRY(c, hipMemcpyAsync(c->d_theta, theta, sizeof(double) * c->n_theta, hipMemcpyHostToDevice, c->stream));
     if (n_dir > 0)
@@ -985,6 +989,7 @@ int32_t crnn_loss_grad(crnn_ctx *ctx, const double *p, int64_t first, int64_t co
     if (!c) return fail(nullptr, "null ctx");
     if (!p) return fail(c, "crnn_loss_grad: null p");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (check_pending(c, nullptr)) return -1;
     const int P = grad_p ? c->n_params : 0;
     c->theta_current = false;
     HIP_TRY(c, hipMemcpyAsync(c->d_p_eval, p, sizeof(double) * c->n_params, hipMemcpyHostToDevice, c->stream));
@@ -1081,7 +1086,9 @@ static int32_t train_end_impl(Ctx *c, double *loss_mean) {
 // flag: a poisoned step is skipped on the device by every rank alike, and so is everything after it (sticky flag).
 // Here the host looks: if steps were skipped they are repeated, in order, with forward tangents.  Called before anything
 // that exposes training state (loss, parameters, statistics, synchronize) and every kMaxPending steps.
-static int32_t check_pending(Ctx *c, double *loss_mean) {
+}  // extern "C" (interrupted: the following helpers have C++ linkage)
+namespace {
+int32_t check_pending(Ctx *c, double *loss_mean) {
     if (c->pending.empty()) return 0;
     double poison[2] = {0.0, 0.0};
     HIP_TRY(c, hipMemcpyAsync(poison, c->d_poison, sizeof(poison), hipMemcpyDeviceToHost, c->stream));
@@ -1105,6 +1112,8 @@ static int32_t check_pending(Ctx *c, double *loss_mean) {
     c->force_forward = false;
     return rc;
 }
+}  // namespace
+extern "C" {
 constexpr size_t kMaxPending = 64;
 
 int32_t crnn_train_step_begin(crnn_ctx *ctx, int64_t first, int64_t count, int32_t n_save_active) {
