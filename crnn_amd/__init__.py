@@ -7,5 +7,5 @@ has not been built (no CPU fallback).
 """
 from . import cases, cathode, hychem  # noqa: F401
 from ._lib import (GRAD_ADJOINT, GRAD_AUTO, GRAD_FORWARD, LOSS_MAE, LOSS_MSE, PMAP_CASE1, PMAP_CASE2, PMAP_HYCHEM, PMAP_IDENTITY, PMAP_ROBER, PRESET_CASE1, PRESET_HYCHEM,  # noqa: F401
-                   PRESET_CASE2, PRESET_ROBER, RET_DTMIN, SOLVER_ROSENBROCK23, SOLVER_TSIT5, RET_MAXITERS, RET_SUCCESS, RET_UNSTABLE, CrnnError)
+                   PRESET_CASE2, PRESET_ROBER, RET_DTMIN, SOLVER_ROSENBROCK23, SOLVER_TSIT5, SOLVER_AUTOTSIT5, RET_MAXITERS, RET_SUCCESS, RET_UNSTABLE, CrnnError)
 from .api import NeuralODE, ODEProblem, Optimiser, crnn, p2vec, p2vec_jac  # noqa: F401

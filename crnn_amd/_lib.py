@@ -19,7 +19,7 @@ RHS_CRNN, RHS_HYCHEM = 0, 1
 LOSS_MAE, LOSS_MSE = 0, 1
 RET_SUCCESS, RET_MAXITERS, RET_DTMIN, RET_UNSTABLE = 0, 1, 2, 3
 PRESET_CASE1, PRESET_CASE2, PRESET_ROBER, PRESET_HYCHEM = 1, 2, 3, 4
-SOLVER_ROSENBROCK23, SOLVER_TSIT5 = 0, 1
+SOLVER_ROSENBROCK23, SOLVER_TSIT5, SOLVER_AUTOTSIT5 = 0, 1, 2
 GRAD_AUTO, GRAD_FORWARD, GRAD_ADJOINT = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -139,7 +139,7 @@ class ODEProblem:
     lb: float | None = None       # log-clamp window overrides
     ub: float | None = None
     loss_kind: int | None = None  # LOSS_MAE (reference) / LOSS_MSE
-    solver: int | None = None     # SOLVER_ROSENBROCK23 / SOLVER_TSIT5 (preset default: the reference's alg)
+    solver: int | None = None     # SOLVER_ROSENBROCK23 / SOLVER_TSIT5 / SOLVER_AUTOTSIT5 (preset default: see crnn_config_preset)
     dtmin: float | None = None
     t0: float = 0.0
     device: int = 0

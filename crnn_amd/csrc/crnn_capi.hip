@@ -17,6 +17,7 @@
 #include "ros23_adj_kernel.hpp"
 #include "hychem_kernel.hpp"
 #include "tsit5_kernel.hpp"
+#include "auto_adj_kernel.hpp"
 #include "cathode_kernel.hpp"
 #include "svgd_kernel.hpp"
 
@@ -70,12 +71,21 @@ const KernelEntry kKernels[] = {
 
 using AdjKernelFn = void (*)(const crnn::SolveParams, const double *, const crnn::AdjParams);
 struct AdjEntry {
-    int ns, nr, has_t, use_scale;
+    int solver, ns, nr, has_t, use_scale;
     AdjKernelFn fn;
 };
-#define KADJ(NS, NR, HT, SC) { NS, NR, HT, SC, (AdjKernelFn)crnn::ros23_adj_kernel<NS, NR, (HT) != 0, (SC) != 0, kBlock> }
-// discrete-adjoint gradient kernels (Rosenbrock23): one lane per trajectory
-const AdjEntry kAdjKernels[] = {KADJ(6, 3, 1, 0), KADJ(3, 6, 0, 1), KADJ(5, 4, 0, 0)};
+#define KADJ(NS, NR, HT, SC) \
+    { CRNN_SOLVER_ROSENBROCK23, NS, NR, HT, SC, (AdjKernelFn)crnn::ros23_adj_kernel<NS, NR, (HT) != 0, (SC) != 0, kBlock> }
+#define KAUTO(SOLVER, NS, NR, HT, SC, COMPOSITE) \
+    { SOLVER, NS, NR, HT, SC, (AdjKernelFn)crnn::auto_adj_kernel<NS, NR, (HT) != 0, (SC) != 0, kBlock, COMPOSITE> }
+// discrete-adjoint gradient kernels, one lane per trajectory: Rosenbrock23; Tsit5; the AutoTsit5(Rosenbrock23()) composite
+// (with a constant temperature state it never leaves Tsit5 -- auto_adj_kernel.hpp -- and shares that instantiation)
+const AdjEntry kAdjKernels[] = {
+    KADJ(6, 3, 1, 0), KADJ(3, 6, 0, 1), KADJ(5, 4, 0, 0),
+    KAUTO(CRNN_SOLVER_TSIT5, 6, 3, 1, 0, false), KAUTO(CRNN_SOLVER_TSIT5, 5, 4, 0, 0, false),
+    KAUTO(CRNN_SOLVER_AUTOTSIT5, 6, 3, 1, 0, false), KAUTO(CRNN_SOLVER_AUTOTSIT5, 5, 4, 0, 0, true),
+    KAUTO(CRNN_SOLVER_AUTOTSIT5, 3, 6, 0, 1, true),
+};
 
 struct Ctx {
     crnn_config cfg{};
@@ -289,9 +299,8 @@ int32_t ensure(Ctx *c, T **ptr, size_t *cap, size_t need) {
 }
 
 const AdjEntry *find_adjoint(const Ctx *c) {
-    if (c->cfg.solver != CRNN_SOLVER_ROSENBROCK23) return nullptr;
     for (const auto &k : kAdjKernels)
-        if (k.ns == c->cfg.ns && k.nr == c->cfg.nr && k.has_t == c->cfg.has_temp && k.use_scale == (c->use_scale ? 1 : 0))
+        if (k.solver == c->cfg.solver && k.ns == c->cfg.ns && k.nr == c->cfg.nr && k.has_t == c->cfg.has_temp && k.use_scale == (c->use_scale ? 1 : 0))
             return &k;
     return nullptr;
 }
@@ -493,6 +502,16 @@ int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int 
         return launch_hychem(c, d_theta, d_dtheta, P, first, count, n_save_active, want_pred);
     }
     c->last_deferred = false;
+    if (c->cfg.solver == CRNN_SOLVER_AUTOTSIT5) {
+        // the composite exists as a tape kernel only: primal calls run it with P = 0, and there is no forward-tangent fallback
+        if (P > 0 && c->cfg.grad_mode == CRNN_GRAD_FORWARD)
+            return fail(c, "crnn_solve: AutoTsit5 gradients exist as discrete adjoint only (grad_mode AUTO or ADJOINT)");
+        const AdjEntry *ka = find_adjoint(c);
+        if (!ka) return fail(c, "crnn_solve: no AutoTsit5 kernel instantiated for this (ns, nr, has_temp)");
+        const int32_t r = launch_adjoint(c, ka, d_theta, d_dtheta, P, first, count, n_save_active, want_pred, false);
+        if (r > 0) return fail(c, "crnn_solve: a trajectory accepted more steps than the adjoint tape holds; raise crnn_config.tape_steps");
+        return r;
+    }
     if (P > 0 && c->cfg.grad_mode != CRNN_GRAD_FORWARD && !c->force_forward) {
         const AdjEntry *ka = find_adjoint(c);
         if (ka) {
@@ -685,7 +704,10 @@ int32_t crnn_config_preset(crnn_config *cfg, int32_t preset) {
 int32_t crnn_config_set_solver(crnn_config *cfg, int32_t solver) {
     if (!cfg) return fail(nullptr, "crnn_config_set_solver: null cfg");
     if (solver == CRNN_SOLVER_ROSENBROCK23) { cfg->beta1 = 7.0 / 20.0; cfg->beta2 = 2.0 / 10.0; cfg->qsteady_max = 1.2; }
-    else if (solver == CRNN_SOLVER_TSIT5) { cfg->beta1 = 7.0 / 50.0; cfg->beta2 = 2.0 / 25.0; cfg->qsteady_max = 1.0; }
+    else if (solver == CRNN_SOLVER_TSIT5 || solver == CRNN_SOLVER_AUTOTSIT5) {
+        // the composite starts on Tsit5; its steady band is that of a non-implicit algorithm type (qsteady_max_default = 1)
+        cfg->beta1 = 7.0 / 50.0; cfg->beta2 = 2.0 / 25.0; cfg->qsteady_max = 1.0;
+    }
     else return fail(nullptr, "crnn_config_set_solver: unknown solver");
     cfg->solver = solver;
     return 0;
@@ -733,7 +755,7 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
     if (cfg->ns < 1 || cfg->nr < 1 || cfg->ns + cfg->has_temp > CRNN_MAX_N || cfg->nr > CRNN_MAX_NR)
         return fail(nullptr, "crnn_ctx_create: ns/nr out of range");
     if (cfg->errnorm_sens != 0) return fail(nullptr, "crnn_ctx_create: errnorm_sens=1 is not implemented on device");
-    if (cfg->solver != CRNN_SOLVER_ROSENBROCK23 && cfg->solver != CRNN_SOLVER_TSIT5)
+    if (cfg->solver != CRNN_SOLVER_ROSENBROCK23 && cfg->solver != CRNN_SOLVER_TSIT5 && cfg->solver != CRNN_SOLVER_AUTOTSIT5)
         return fail(nullptr, "crnn_ctx_create: unknown solver");
     if (cfg->rhs_kind != CRNN_RHS_CRNN && cfg->rhs_kind != CRNN_RHS_HYCHEM) return fail(nullptr, "crnn_ctx_create: unknown rhs_kind");
     if (cfg->grad_mode < CRNN_GRAD_AUTO || cfg->grad_mode > CRNN_GRAD_ADJOINT || cfg->tape_steps < 0)
@@ -754,8 +776,9 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
     c->use_scale = false;
     for (int i = 0; i < cfg->ns; ++i) if (cfg->rate_scale[i] != 1.0) c->use_scale = true;
     // robertson-shaped problems always take the scaled kernel (one instantiation per shape)
-    if (!c->hychem && !find_primal(c)) { c->use_scale = !c->use_scale; if (!find_primal(c)) c->use_scale = !c->use_scale; }
-    if (!c->hychem && !find_primal(c)) {
+    auto has_kernel = [&]() { return c->cfg.solver == CRNN_SOLVER_AUTOTSIT5 ? find_adjoint(c) != nullptr : find_primal(c) != nullptr; };
+    if (!c->hychem && !has_kernel()) { c->use_scale = !c->use_scale; if (!has_kernel()) c->use_scale = !c->use_scale; }
+    if (!c->hychem && !has_kernel()) {
         delete c;
         return fail(nullptr, "crnn_ctx_create: no gfx950 kernel instantiated for this (solver, ns, nr, has_temp)");
     }

@@ -62,12 +62,17 @@ enum {
 enum { CRNN_LOSS_MAE = 0, CRNN_LOSS_MSE = 1 };
 /* per-trajectory return codes (DiffEq retcodes Success / MaxIters / DtLessThanMin / Unstable) */
 enum { CRNN_RET_SUCCESS = 0, CRNN_RET_MAXITERS = 1, CRNN_RET_DTMIN = 2, CRNN_RET_UNSTABLE = 3 };
-/* time steppers (reference: alg = Rosenbrock23(...) rober_crnn.jl:33, AutoTsit5(Rosenbrock23()) case2.jl:26, Tsit5() case1.jl:28) */
-enum { CRNN_SOLVER_ROSENBROCK23 = 0, CRNN_SOLVER_TSIT5 = 1 };
+/* time steppers (reference: alg = Rosenbrock23(...) rober_crnn.jl:33, Tsit5() case1.jl:28, AutoTsit5(Rosenbrock23())
+ * case2.jl:26).  AUTOTSIT5 is OrdinaryDiffEq's stiffness-switching composite with its default AutoSwitch constants
+ * (10 stiff / 3 non-stiff steps in a row, tolerances 9/10, dt factor 2, Tsit5 stability size 3.5068); it exists for the
+ * discrete-adjoint gradient only (grad_mode AUTO or ADJOINT).  A state vector with a component that never moves -- the
+ * constant temperature of has_temp = 1 -- makes the composite's stiffness estimate NaN, so such a problem never leaves
+ * Tsit5 (crnn_amd/csrc/auto_adj_kernel.hpp). */
+enum { CRNN_SOLVER_ROSENBROCK23 = 0, CRNN_SOLVER_TSIT5 = 1, CRNN_SOLVER_AUTOTSIT5 = 2 };
 /* How the loss gradient (ForwardDiff.gradient, case2/case2.jl:195) is formed.  Both differentiate the accepted steps
  * with dt held fixed and agree to rounding:
  *   FORWARD  P tangent columns pushed through every step (cost ~ (1+P) primal solves; any stepper);
- *   ADJOINT  the accepted steps are recorded on a tape and reversed once (cost ~ 2 primal solves; Rosenbrock23);
+ *   ADJOINT  the accepted steps are recorded on a tape and reversed once (cost ~ 2 primal solves; every stepper);
  *   AUTO     ADJOINT where available, else FORWARD. */
 enum { CRNN_GRAD_AUTO = 0, CRNN_GRAD_FORWARD = 1, CRNN_GRAD_ADJOINT = 2 };
 /* internal to the adjoint path: a trajectory ran out of tape; the library then repeats the call with FORWARD and this

@@ -72,7 +72,7 @@ typedef struct orc_problem {
     int32_t loss_kind;          /* 0 = MAE, 1 = MSE */
     int32_t maxiters;
     int32_t errnorm_sens;       /* 0 primal-only norm, 1 ForwardDiff-style */
-    int32_t solver;             /* 0 Rosenbrock23, 1 Tsit5 (case1/case1.jl:28) */
+    int32_t solver;             /* 0 Rosenbrock23, 1 Tsit5 (case1/case1.jl:28), 2 AutoTsit5(Rosenbrock23) (case2/case2.jl:26) */
     int32_t pad_;
     double lb, ub;              /* log-clamp window; ub may be +inf */
     double inv_R;               /* -1/R for the Arrhenius row (has_temp) */
@@ -91,7 +91,7 @@ int orc_sizeof_problem(void) { return (int)sizeof(orc_problem); }
    exists only for the implicit family (qsteady_max = 1 for explicit methods). [UNVERIFIED-DEP] */
 void orc_set_solver(orc_problem *pb, int solver) {
     pb->solver = solver;
-    if (solver == 1) { pb->beta1 = 7.0 / 50.0; pb->beta2 = 2.0 / 25.0; pb->qsteady_max = 1.0; }
+    if (solver == 1 || solver == 2) { pb->beta1 = 7.0 / 50.0; pb->beta2 = 2.0 / 25.0; pb->qsteady_max = 1.0; }   /* composite: qsteady_max_default of a non-implicit algorithm type */
     else { pb->beta1 = 7.0 / 20.0; pb->beta2 = 2.0 / 10.0; pb->qsteady_max = 1.2; }
 }
 
@@ -776,6 +776,271 @@ static int solve_one_tsit5(const orc_problem *pb, const double *th, const double
     return retcode;
 }
 
+/* ------------------------------------------------------------------------ */
+/* AutoTsit5(Rosenbrock23()): OrdinaryDiffEq's stiffness-switching composite */
+/* (case2/case2.jl:26, HyChem/crnn_pyrolysis_mass.jl:25).  The package is   */
+/* not in the reference tree; restated from its published algorithm         */
+/* (AutoSwitch, composite_algs.jl) [UNVERIFIED-DEP]:                        */
+/*   * start on Tsit5; before every attempt after the first, test           */
+/*       stiffness = |eigen_est * dt| / 3.5068  >  9/10                      */
+/*     with dt the step size about to be tried and eigen_est from the last  */
+/*     attempt (accepted or not); count consecutive positives (+) and       */
+/*     negatives (-);                                                       */
+/*   * on Tsit5, more than 10 positives in a row: dt *= 2, switch to        */
+/*     Rosenbrock23; on Rosenbrock23, more than 3 negatives in a row:       */
+/*     dt /= 2, switch back;                                                */
+/*   * eigen_est: Tsit5 max_i |k7_i - k6_i| / |g7_i - g6_i| (Hairer II p.22 */
+/*     in the Inf norm; a component that does not move gives 0/0 = NaN,     */
+/*     which Julia's `maximum` propagates, and NaN > 9/10 is false -- so a  */
+/*     state vector with a constant component, like case2's temperature,    */
+/*     never switches); Rosenbrock23: opnorm(J(u_n), Inf);                  */
+/*   * the PI exponents follow the running algorithm (beta2 = 2/(5 order),  */
+/*     beta1 = 7/(10 order)); qold, gamma, qmin, qmax and the steady band   */
+/*     of pb are shared.                                                    */
+/* st_alg (optional): [0] Tsit5 accepted steps, [1] Rosenbrock23 accepted   */
+/* steps, [2] number of switches.                                           */
+/* ------------------------------------------------------------------------ */
+#define AS_MAXSTIFF 10
+#define AS_MAXNONSTIFF 3
+#define AS_TOL 0.9
+#define AS_DTFAC 2.0
+#define AS_STAB 3.5068
+static int solve_one_auto(const orc_problem *pb, const double *th, const double *dth, int P,
+                          const double *u0, const double *tsave, int nsave,
+                          const double *data, double *pred, double *dpred,
+                          double *loss_out, double *grad, int32_t *n_saved_out, orc_stats *st, double *ws,
+                          int64_t *st_alg) {
+    const int n = N_(pb), nobs = pb->n_obs;
+    const int nth = orc_n_theta(pb);
+    const double d = 1.0 / (2.0 + sqrt(2.0));
+    const double c32 = 6.0 + sqrt(2.0);
+    const double tend = tsave[nsave - 1];
+    double t = pb->t0;
+    double u[ORC_MAXN], k[7][ORC_MAXN];
+    double *S = NULL, *Snew = NULL, *dk = NULL, *gtr = NULL;
+    if (P > 0) {
+        memset(ws, 0, sizeof(double) * ((size_t)n * P * 9 + P));
+        S = ws; Snew = S + (size_t)n * P; dk = Snew + (size_t)n * P; gtr = ws + (size_t)n * P * 9;
+    }
+#define DK(i) (dk + (size_t)(i) * n * P)
+    memcpy(u, u0, sizeof(double) * n);
+    orc_rhs(pb, th, u, k[0]);
+    for (int c = 0; c < P; ++c) {
+        double zero[ORC_MAXN] = {0};
+        orc_rhs_jvp(pb, th, dth + (size_t)nth * c, u, zero, DK(0) + (size_t)n * c);
+    }
+    double dt = init_dt(pb, th, u, k[0], tend - pb->t0, 5);
+    double qold = pb->qoldinit;
+    int jsave = 0, retcode = 0, iter = 0;
+    int alg = 0, cnt = 0, have_est = 0;
+    double eigen_est = 0.0;
+    double loss_sum = 0.0;
+#define SAVE_POINT(uvec, svec_expr_block)                                              \
+    do {                                                                               \
+        for (int i = 0; i < n; ++i) {                                                  \
+            double v = (uvec)[i];                                                      \
+            if (pb->clamp_pred) v = clampd(v, -pb->ub, pb->ub);                        \
+            if (pred) pred[i + n * jsave] = v;                                         \
+        }                                                                              \
+        for (int io = 0; io < nobs; ++io) {                                            \
+            int i = pb->i_obs[io];                                                     \
+            double v = (uvec)[i];                                                      \
+            double mask = 1.0;                                                         \
+            if (pb->clamp_pred) { mask = dclamp(v, -pb->ub, pb->ub); v = clampd(v, -pb->ub, pb->ub); } \
+            double r_ = (data[io + nobs * jsave] - v) / pb->yscale[io];                \
+            double w_;                                                                 \
+            if (pb->loss_kind == 0) { loss_sum += fabs(r_); w_ = -dabs_(r_); }         \
+            else { loss_sum += r_ * r_; w_ = -2.0 * r_; }                              \
+            w_ *= mask / pb->yscale[io];                                               \
+            for (int c = 0; c < P; ++c) { double sv; svec_expr_block; gtr[c] += w_ * sv; \
+                if (dpred) dpred[i + n * (jsave + (size_t)nsave * c)] = mask * sv; }   \
+        }                                                                              \
+        ++jsave;                                                                       \
+    } while (0)
+    if (nsave > 0 && tsave[0] == pb->t0) SAVE_POINT(u, sv = 0.0);
+
+    double J[ORC_MAXN * ORC_MAXN], W[ORC_MAXN * ORC_MAXN], dJ[ORC_MAXN * ORC_MAXN];
+    int piv[ORC_MAXN];
+    while (jsave < nsave) {
+        if (++iter > pb->maxiters) { retcode = 1; break; }
+        /* choose_algorithm! (loopheader!) */
+        if (have_est) {
+            const double stiffness = fabs(eigen_est * dt / AS_STAB);
+            const int stiff = stiffness > AS_TOL;      /* false for NaN */
+            cnt = stiff ? (cnt < 0 ? 1 : cnt + 1) : (cnt > 0 ? -1 : cnt - 1);
+            if (alg == 0 && cnt > AS_MAXSTIFF) { dt *= AS_DTFAC; alg = 1; if (st_alg) st_alg[2]++; }
+            else if (alg == 1 && cnt < -AS_MAXNONSTIFF) { dt /= AS_DTFAC; alg = 0; if (st_alg) st_alg[2]++; }
+        }
+        const double beta1 = alg == 0 ? 7.0 / 50.0 : 7.0 / 20.0, beta2 = alg == 0 ? 2.0 / 25.0 : 2.0 / 10.0;
+        int last = 0;
+        if (t + dt * (1.0 + 1e-13) >= tend) { dt = tend - t; last = 1; }
+        if (!(dt > pb->dtmin) || t + dt == t) { retcode = 2; break; }
+        double unew[ORC_MAXN], ev[ORC_MAXN];
+        double u1[ORC_MAXN], f1[ORC_MAXN], k2[ORC_MAXN], k3[ORC_MAXN], tmp[ORC_MAXN];   /* Rosenbrock23 stages (k1 in k[1]) */
+        const double gam = d * dt;
+        if (alg == 0) {
+            double g[ORC_MAXN], g6[ORC_MAXN];
+            for (int s_ = 1; s_ < 7; ++s_) {
+                for (int i = 0; i < n; ++i) {
+                    double a = 0.0;
+                    for (int j = 0; j < s_; ++j) a += TS_A[s_][j] * k[j][i];
+                    g[i] = u[i] + dt * a;
+                }
+                if (s_ == 5) memcpy(g6, g, sizeof(double) * n);
+                if (s_ == 6) memcpy(unew, g, sizeof(double) * n);
+                orc_rhs(pb, th, g, k[s_]);
+            }
+            for (int i = 0; i < n; ++i) {
+                double a = 0.0;
+                for (int j = 0; j < 7; ++j) a += TS_BT[j] * k[j][i];
+                ev[i] = dt * a;
+            }
+            double est = 0.0; int isnan_ = 0;
+            for (int i = 0; i < n; ++i) {
+                double q_ = fabs((k[6][i] - k[5][i]) / (unew[i] - g6[i]));
+                if (q_ != q_) isnan_ = 1; else if (q_ > est) est = q_;
+            }
+            eigen_est = isnan_ ? NAN : est;
+        } else {
+            orc_jac(pb, th, u, J);
+            double est = 0.0;
+            for (int i = 0; i < n; ++i) { double a = 0.0; for (int c = 0; c < n; ++c) a += fabs(J[i + n * c]); if (a > est) est = a; }
+            eigen_est = est;
+            for (int c = 0; c < n; ++c) for (int i = 0; i < n; ++i) W[i + n * c] = (i == c ? 1.0 : 0.0) - gam * J[i + n * c];
+            if (lu_factor(n, W, piv) != 0) { retcode = 3; break; }
+            memcpy(k[1], k[0], sizeof(double) * n); lu_solve(n, W, piv, k[1]);
+            for (int i = 0; i < n; ++i) u1[i] = u[i] + 0.5 * dt * k[1][i];
+            orc_rhs(pb, th, u1, f1);
+            for (int i = 0; i < n; ++i) tmp[i] = f1[i] - k[1][i];
+            lu_solve(n, W, piv, tmp);
+            for (int i = 0; i < n; ++i) { k2[i] = tmp[i] + k[1][i]; unew[i] = u[i] + dt * k2[i]; }
+            orc_rhs(pb, th, unew, k[6]);
+            for (int i = 0; i < n; ++i) k3[i] = k[6][i] - c32 * (k2[i] - f1[i]) - 2.0 * (k[1][i] - k[0][i]);
+            lu_solve(n, W, piv, k3);
+            for (int i = 0; i < n; ++i) ev[i] = dt / 6.0 * (k[1][i] - 2.0 * k2[i] + k3[i]);
+        }
+        have_est = 1;
+        int finite = 1;
+        for (int i = 0; i < n; ++i) if (!isfinite(unew[i]) || !isfinite(ev[i])) finite = 0;
+        if (!finite) { retcode = 3; break; }
+        const double EEst = rms_scaled(pb, n, ev, u, unew);
+        const int accept = (EEst <= 1.0);
+        if (accept && P > 0) {
+            for (int c = 0; c < P; ++c) {
+                const double *dthc = dth + (size_t)nth * c;
+                const double *s = S + (size_t)n * c;
+                if (alg == 0) {
+                    double gs[ORC_MAXN], gu[ORC_MAXN];
+                    for (int s_ = 1; s_ < 7; ++s_) {
+                        for (int i = 0; i < n; ++i) {
+                            double a = 0.0, b = 0.0;
+                            for (int j = 0; j < s_; ++j) { a += TS_A[s_][j] * k[j][i]; b += TS_A[s_][j] * DK(j)[i + (size_t)n * c]; }
+                            gu[i] = u[i] + dt * a; gs[i] = s[i] + dt * b;
+                        }
+                        if (s_ == 6) memcpy(Snew + (size_t)n * c, gs, sizeof(double) * n);
+                        orc_rhs_jvp(pb, th, dthc, gu, gs, DK(s_) + (size_t)n * c);
+                    }
+                } else {
+                    double *a1 = DK(1) + (size_t)n * c, *a2 = DK(2) + (size_t)n * c, *b0 = DK(0) + (size_t)n * c;
+                    double *sn = Snew + (size_t)n * c, *b2 = DK(6) + (size_t)n * c;
+                    orc_jac_dir(pb, th, dthc, u, s, dJ);
+                    matvec(n, dJ, k[1], tmp);
+                    for (int i = 0; i < n; ++i) a1[i] = b0[i] + gam * tmp[i];
+                    lu_solve(n, W, piv, a1);
+                    double s1[ORC_MAXN], df1[ORC_MAXN], dd[ORC_MAXN], kd[ORC_MAXN];
+                    for (int i = 0; i < n; ++i) s1[i] = s[i] + 0.5 * dt * a1[i];
+                    orc_rhs_jvp(pb, th, dthc, u1, s1, df1);
+                    for (int i = 0; i < n; ++i) kd[i] = k2[i] - k[1][i];
+                    matvec(n, dJ, kd, tmp);
+                    for (int i = 0; i < n; ++i) dd[i] = df1[i] - a1[i] + gam * tmp[i];
+                    lu_solve(n, W, piv, dd);
+                    for (int i = 0; i < n; ++i) { a2[i] = a1[i] + dd[i]; sn[i] = s[i] + dt * a2[i]; }
+                    orc_rhs_jvp(pb, th, dthc, unew, sn, b2);
+                }
+            }
+        }
+        double q, q11 = 0.0;
+        if (EEst == 0.0) q = 1.0 / pb->qmax;
+        else {
+            q11 = pow(EEst, beta1);
+            q = q11 / pow(qold, beta2);
+            q = fmax(1.0 / pb->qmax, fmin(1.0 / pb->qmin, q / pb->gamma));
+        }
+        if (accept) {
+            if (st) st->naccept++;
+            if (st_alg) st_alg[alg]++;
+            if (q >= pb->qsteady_min && q <= pb->qsteady_max) q = 1.0;
+            qold = fmax(EEst, pb->qoldinit);
+            double tnew = last ? tend : t + dt;
+            while (jsave < nsave && tsave[jsave] <= tnew) {
+                double ts = tsave[jsave];
+                if (ts == tnew) {
+                    SAVE_POINT(unew, sv = Snew[i + (size_t)n * c]);
+                } else if (alg == 0) {
+                    double Th = (ts - t) / dt, bth[7], ui[ORC_MAXN];
+                    orc_tsit5_dense(Th, bth);
+                    for (int i = 0; i < n; ++i) {
+                        double a = 0.0;
+                        for (int j = 0; j < 7; ++j) a += bth[j] * k[j][i];
+                        ui[i] = u[i] + dt * a;
+                    }
+                    SAVE_POINT(ui, { double a_ = 0.0; for (int j = 0; j < 7; ++j) a_ += bth[j] * DK(j)[i + (size_t)n * c];
+                                     sv = S[i + (size_t)n * c] + dt * a_; });
+                } else {
+                    double Th = (ts - t) / dt;
+                    double c1 = Th * (1.0 - Th) / (1.0 - 2.0 * d), c2 = Th * (Th - 2.0 * d) / (1.0 - 2.0 * d);
+                    double ui[ORC_MAXN];
+                    for (int i = 0; i < n; ++i) ui[i] = u[i] + dt * (c1 * k[1][i] + c2 * k2[i]);
+                    SAVE_POINT(ui, sv = S[i + (size_t)n * c] + dt * (c1 * DK(1)[i + (size_t)n * c] + c2 * DK(2)[i + (size_t)n * c]));
+                }
+            }
+            memcpy(u, unew, sizeof(double) * n);
+            memcpy(k[0], k[6], sizeof(double) * n);
+            if (P > 0) {
+                memcpy(S, Snew, sizeof(double) * (size_t)n * P);
+                memcpy(DK(0), DK(6), sizeof(double) * (size_t)n * P);
+            }
+            t = tnew;
+            dt = dt / q;
+            double dtmax = tend - pb->t0;
+            if (dt > dtmax) dt = dtmax;
+        } else {
+            if (st) st->nreject++;
+            dt = dt / fmin(1.0 / pb->qmin, q11 / pb->gamma);
+        }
+    }
+#undef SAVE_POINT
+#undef DK
+    double denom = (double)nobs * (double)jsave;
+    double loss = jsave > 0 ? loss_sum / denom : 0.0;
+    if (loss_out) *loss_out = loss;
+    if (n_saved_out) *n_saved_out = jsave;
+    if (grad && jsave > 0) for (int c = 0; c < P; ++c) grad[c] += gtr[c] / denom;
+    return retcode;
+}
+
+static int solve_dispatch(const orc_problem *pb, const double *th, const double *dth, int P,
+                          const double *u0, const double *tsave, int nsave,
+                          const double *data, double *pred, double *dpred,
+                          double *loss_out, double *grad, int32_t *n_saved_out, orc_stats *st, double *ws) {
+    if (pb->solver == 2) return solve_one_auto(pb, th, dth, P, u0, tsave, nsave, data, pred, dpred, loss_out, grad, n_saved_out, st, ws, NULL);
+    if (pb->solver == 1) return solve_one_tsit5(pb, th, dth, P, u0, tsave, nsave, data, pred, dpred, loss_out, grad, n_saved_out, st, ws);
+    return solve_one_ws(pb, th, dth, P, u0, tsave, nsave, data, pred, dpred, loss_out, grad, n_saved_out, st, ws);
+}
+
+/* composite only: also reports how the accepted steps split between the two algorithms and the number of switches */
+int orc_solve_one_auto(const orc_problem *pb, const double *th, const double *dth, int P,
+                       const double *u0, const double *tsave, int nsave,
+                       const double *data, double *pred, double *dpred,
+                       double *loss_out, double *grad, int32_t *n_saved_out, orc_stats *st, int64_t *st_alg /*[3]*/) {
+    const int n = N_(pb);
+    double *ws = P > 0 ? (double *)malloc(sizeof(double) * ((size_t)n * P * 9 + P)) : NULL;
+    if (st_alg) st_alg[0] = st_alg[1] = st_alg[2] = 0;
+    int rc = solve_one_auto(pb, th, dth, P, u0, tsave, nsave, data, pred, dpred, loss_out, grad, n_saved_out, st, ws, st_alg);
+    free(ws);
+    return rc;
+}
+
 int orc_solve_one(const orc_problem *pb, const double *th, const double *dth, int P,
                   const double *u0, const double *tsave, int nsave,
                   const double *data, double *pred, double *dpred,
@@ -783,9 +1048,7 @@ int orc_solve_one(const orc_problem *pb, const double *th, const double *dth, in
                   int32_t *n_saved_out, orc_stats *st) {
     const int n = N_(pb);
     double *ws = P > 0 ? (double *)malloc(sizeof(double) * ((size_t)n * P * 9 + P)) : NULL;
-    int rc = pb->solver == 1
-                 ? solve_one_tsit5(pb, th, dth, P, u0, tsave, nsave, data, pred, dpred, loss_out, grad, n_saved_out, st, ws)
-                 : solve_one_ws(pb, th, dth, P, u0, tsave, nsave, data, pred, dpred, loss_out, grad, n_saved_out, st, ws);
+    int rc = solve_dispatch(pb, th, dth, P, u0, tsave, nsave, data, pred, dpred, loss_out, grad, n_saved_out, st, ws);
     free(ws);
     return rc;
 }
@@ -822,9 +1085,7 @@ int orc_solve_batch(const orc_problem *pb, const double *th, const double *dth, 
             orc_stats st = {0, 0};
             double l = 0; int32_t ns_ = 0;
             if (p_loc) memset(p_loc, 0, sizeof(double) * (size_t)n * nsave);
-            int rc = pb->solver == 1
-                         ? solve_one_tsit5(pb, th, dth, grad ? P : 0, u, tsave, nsave, d_loc, p_loc, NULL, &l, g_loc, &ns_, &st, ws)
-                         : solve_one_ws(pb, th, dth, grad ? P : 0, u, tsave, nsave, d_loc, p_loc, NULL, &l, g_loc, &ns_, &st, ws);
+            int rc = solve_dispatch(pb, th, dth, grad ? P : 0, u, tsave, nsave, d_loc, p_loc, NULL, &l, g_loc, &ns_, &st, ws);
             if (loss) loss[b] = l;
             if (retcode) retcode[b] = rc;
             if (n_saved) n_saved[b] = ns_;

@@ -171,12 +171,21 @@ def solve_one(pb, theta, u0, tsave, data, dtheta=None, want_pred=True, want_dpre
     grad = np.zeros(max(P, 1))
     nsaved = C.c_int32(0)
     st = (C.c_int64 * 2)(0, 0)
-    lib().orc_solve_one.restype = C.c_int
-    rc = lib().orc_solve_one(C.byref(pb), _dp(theta), _dp(dth), C.c_int(P), _dp(np.ascontiguousarray(u0, float)),
-                             _dp(tsave), C.c_int(nsave), _dp(dataF), _dp(pred), _dp(dpred), C.byref(loss),
-                             _dp(grad), C.byref(nsaved), C.cast(st, C.c_void_p))
+    extra = {}
+    if pb.solver == 2:   # composite: also how the accepted steps split between Tsit5 and Rosenbrock23
+        sa = (C.c_int64 * 3)(0, 0, 0)
+        lib().orc_solve_one_auto.restype = C.c_int
+        rc = lib().orc_solve_one_auto(C.byref(pb), _dp(theta), _dp(dth), C.c_int(P), _dp(np.ascontiguousarray(u0, float)),
+                                      _dp(tsave), C.c_int(nsave), _dp(dataF), _dp(pred), _dp(dpred), C.byref(loss),
+                                      _dp(grad), C.byref(nsaved), C.cast(st, C.c_void_p), C.cast(sa, C.c_void_p))
+        extra = dict(n_tsit5=sa[0], n_rosenbrock=sa[1], n_switch=sa[2])
+    else:
+        lib().orc_solve_one.restype = C.c_int
+        rc = lib().orc_solve_one(C.byref(pb), _dp(theta), _dp(dth), C.c_int(P), _dp(np.ascontiguousarray(u0, float)),
+                                 _dp(tsave), C.c_int(nsave), _dp(dataF), _dp(pred), _dp(dpred), C.byref(loss),
+                                 _dp(grad), C.byref(nsaved), C.cast(st, C.c_void_p))
     return dict(pred=pred, loss=loss.value, grad=grad[:P].copy(), retcode=rc, n_saved=nsaved.value,
-                naccept=st[0], nreject=st[1], dpred=dpred)
+                naccept=st[0], nreject=st[1], dpred=dpred, **extra)
 
 
 def solve_batch(pb, theta, u0, tsave, data, dtheta=None, want_pred=False, first=0, count=None, nthreads=0):

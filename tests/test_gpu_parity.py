@@ -393,3 +393,133 @@ def test_tsit5_case1_reference_configuration(orc, fx):
     r0 = orc.solve_one(pb, th, u0[0], ts, data[0], dtheta=dth)
     assert np.max(np.abs(g0 - r0["grad"])) < 1e-7 * np.max(np.abs(r0["grad"]))
     node.close()
+
+
+# ------------------------------------------------------------------ Tsit5 adjoint and the AutoTsit5(Rosenbrock23()) composite
+@pytest.mark.parametrize("pkey", ["p_ckpt", "p_init"])
+def test_tsit5_adjoint_equals_forward_tangents(case2_setup, pkey):
+    """Reversing the accepted Tsit5 steps gives the gradient the forward tangents give (same graph): 1e-9 relative."""
+    from crnn_amd import PRESET_CASE2
+    s = case2_setup
+    p = s[pkey]
+    fwd = _tsit5_node(PRESET_CASE2, s, grad_mode=1)
+    adj = _tsit5_node(PRESET_CASE2, s, grad_mode=2)
+    lf, gf = fwd.loss_and_grad(p)
+    la, ga = adj.loss_and_grad(p)
+    assert abs(lf - la) < 1e-13 * abs(lf)
+    assert np.max(np.abs(gf - ga)) < 1e-9 * np.max(np.abs(gf))
+    assert adj.last_stats["n_accept"] == fwd.last_stats["n_accept"] and adj.last_stats["n_reject"] == fwd.last_stats["n_reject"]
+    for i in (0, 3):
+        assert np.max(np.abs(fwd.gradient(p, i) - adj.gradient(p, i))) < 1e-9 * np.max(np.abs(gf))
+    # random horizon (rober_crnn.jl:125,218 style) goes through the same tape
+    lf, gf = fwd.loss_and_grad(p, sample=31)
+    la, ga = adj.loss_and_grad(p, sample=31)
+    assert abs(lf - la) < 1e-13 * abs(lf) and np.max(np.abs(gf - ga)) < 1e-9 * np.max(np.abs(gf))
+    fwd.close(); adj.close()
+
+
+def _auto_node(case, setup, **kw):
+    from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE2, PRESET_ROBER, SOLVER_AUTOTSIT5
+    if case == "case2":
+        prob = ODEProblem(PRESET_CASE2, setup["tsteps"], solver=SOLVER_AUTOTSIT5, **kw)
+    else:
+        prob = ODEProblem(PRESET_ROBER, setup["tsteps"], rate_scale=setup["dydt_scale"], solver=SOLVER_AUTOTSIT5, **kw)
+    node = NeuralODE(prob)
+    node.set_ensemble(setup["u0"], setup["data"], setup["yscale"])
+    return node
+
+
+def test_autotsit5_robertson_matches_oracle(orc, rober_setup):
+    """Stiff problem: the composite leaves Tsit5 after its 11th stiff step in a row and finishes on Rosenbrock23
+    (62 steps instead of Tsit5's ~19 000).  Same switching rule, same inputs: the step sequences coincide with the
+    CPU restatement's; trajectories 1e-9 of the species scale, gradient 1e-7 of max |grad|."""
+    s = rober_setup
+    p = s["p_ckpt"]
+    th, dth = orc.p2vec(3, 3, 6, p)
+    pb = oracle_problem(orc, "rober", s, solver=2)
+    ref = orc.solve_batch(pb, th, np.ascontiguousarray(s["u0"].T), s["tsteps"],
+                          np.ascontiguousarray(s["data"].transpose(2, 1, 0)), dtheta=dth, want_pred=True)
+    one = orc.solve_one(pb, th, s["u0"][0], s["tsteps"], s["data"][0])
+    assert one["n_switch"] == 1 and one["n_rosenbrock"] > one["n_tsit5"] > 10      # the case does exercise the switch
+    node = _auto_node("rober", s)
+    pred = node.predict_neuralode(s["u0"], p)
+    ref_pred = ref["pred"].transpose(2, 1, 0)
+    scale = np.abs(ref_pred).max(axis=(0, 2), keepdims=True) + 1e-300
+    assert np.max(np.abs(pred - ref_pred) / scale) < 1e-9
+    assert np.array_equal(node.last_retcode, ref["retcode"])
+    losses = node.losses(p)
+    assert np.max(np.abs(losses - ref["loss"]) / ref["loss"]) < 1e-9
+    loss, grad = node.loss_and_grad(p)
+    st = node.last_stats
+    assert st["n_accept"] == ref["naccept"] and st["n_reject"] == ref["nreject"]
+    B = len(ref["loss"])
+    assert abs(loss - ref["loss"].mean()) < 1e-9 * loss
+    assert np.max(np.abs(grad - ref["grad"] / B)) < 1e-7 * np.max(np.abs(ref["grad"] / B))
+    g0 = node.gradient(p, 2)
+    r0 = orc.solve_one(pb, th, s["u0"][2], s["tsteps"], s["data"][2], dtheta=dth)
+    assert np.max(np.abs(g0 - r0["grad"])) < 1e-7 * np.max(np.abs(r0["grad"]))
+    # against the tight-tolerance golden trajectories (independent Radau run)
+    gold = s["pred_ckpt"]
+    gscale = np.abs(gold).max(axis=(0, 2))[:, None]
+    assert np.max(np.abs(pred[:6] - gold[:6]) / gscale) < 5e-3
+    node.close()
+
+
+def test_autotsit5_with_constant_temperature_state_is_tsit5(case2_setup):
+    """case2 carries its constant temperature as a state: the composite's stiffness estimate is 0/0 there and it never
+    leaves Tsit5 (auto_adj_kernel.hpp), so AUTOTSIT5 and TSIT5 give identical numbers."""
+    from crnn_amd import PRESET_CASE2
+    s = case2_setup
+    p = s["p_ckpt"]
+    a = _auto_node("case2", s)
+    t5 = _tsit5_node(PRESET_CASE2, s, grad_mode=2)
+    la, ga = a.loss_and_grad(p)
+    lt, gt = t5.loss_and_grad(p)
+    assert la == lt and np.array_equal(ga, gt)
+    pa = a.predict_neuralode(s["u0"], p)
+    pt = t5.predict_neuralode(s["u0"], p)
+    assert np.max(np.abs(pa - pt)) < 1e-12       # tape kernel vs the primal Tsit5 kernel: same steps, same interpolant
+    assert np.array_equal(a.losses(p), t5.losses(p)) or np.max(np.abs(a.losses(p) - t5.losses(p))) < 1e-13
+    a.close(); t5.close()
+
+
+def test_autotsit5_forward_mode_and_tape_overflow_are_errors(rober_setup):
+    from crnn_amd import CrnnError
+    s = rober_setup
+    node = _auto_node("rober", s, grad_mode=1)
+    node.losses(s["p_ckpt"])                                     # primal calls do not depend on grad_mode
+    with pytest.raises(CrnnError, match="discrete adjoint only"):
+        node.loss_and_grad(s["p_ckpt"])
+    node.close()
+    node = _auto_node("rober", s, tape_steps=8)
+    with pytest.raises(CrnnError, match="tape"):
+        node.loss_and_grad(s["p_ckpt"])
+    node.close()
+
+
+def test_autotsit5_case1_matches_oracle(orc, fx):
+    """case1 shape (5 species, 4 reactions, no temperature) through the composite at the reference tolerances."""
+    from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE1, SOLVER_AUTOTSIT5, cases
+    rng = np.random.Generator(np.random.PCG64(12))
+    ts = cases.case1_tsteps()
+    u0 = np.array(fx["case1"]["u0"])
+    p = np.array(fx["case1"]["p"])
+    gen = NeuralODE(ODEProblem(PRESET_CASE1, ts, atol=1e-12, rtol=1e-10))
+    clean = gen.predict_theta(u0, cases.case1_true_theta())
+    gen.close()
+    data = cases.add_noise(clean, 0.05, rng)
+    ys = cases.max_min(data, lb=1e-5)
+    node = NeuralODE(ODEProblem(PRESET_CASE1, ts, solver=SOLVER_AUTOTSIT5))
+    node.set_ensemble(u0, data, ys)
+    th, dth = orc.p2vec(1, 5, 4, p)
+    pb = orc.make_problem(ns=5, nr=4, lb=1e-5, ub=10.0, atol=1e-5, rtol=1e-2, yscale=ys, clamp_pred=1, maxiters=10000, solver=2)
+    B = u0.shape[0]
+    ref = orc.solve_batch(pb, th, np.ascontiguousarray(u0.T), ts, np.ascontiguousarray(data.transpose(2, 1, 0)), dtheta=dth,
+                          want_pred=True)
+    pred = node.predict_neuralode(u0, p)
+    assert np.max(np.abs(pred - ref["pred"].transpose(2, 1, 0))) < 1e-9
+    loss, grad = node.loss_and_grad(p)
+    assert abs(loss - ref["loss"].mean()) < 1e-9 * loss
+    assert np.max(np.abs(grad - ref["grad"] / B)) < 1e-7 * np.max(np.abs(ref["grad"] / B))
+    assert node.last_stats["n_accept"] == ref["naccept"]
+    node.close()
