@@ -44,6 +44,7 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
     constexpr int RECW = NS + 2;
     static_assert(NTH + kExtra <= 64, "the per-batch sums use one lane per column");
     static_assert(!(COMPOSITE && HAS_T), "a constant state component never switches (see the header)");
+    constexpr bool kKeepStages = 7 * (2 * NS + NR) <= 84;   // reverse Tsit5 step: keep the features of all 7 stages in registers
     using Solver = typename SolverSel<(NR < NS), NS, NR, HAS_T, USE_SCALE>::type;
 
     __shared__ double kc_lds[kNConst];
@@ -484,23 +485,35 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
 
                 if (is_ts) {
                     // ------------------------------------------------------------ Tsit5 step: re-form the stages
-                    double k[7][NS], xs[7][NS], gs[7][NS], rs[7][NR], unew[NS];
-                    eval_point(un, xs[0], gs[0], rs[0], k[0]);
+                    // (kKeepStages = false: only the stage slopes are kept and the features of a stage are formed again where its
+                    //  adjoint needs them -- seven more evaluations, independent of each other, against ~300 spilled registers
+                    //  for case2; 1.69 -> 0.94 ms.  The robertson shape holds all 84 values in registers: 1.42 vs 1.66 ms.)
+                    constexpr int KS = kKeepStages ? 7 : 1;
+                    double k[7][NS], unew[NS], xs[KS][NS], gs[KS][NS], rs[KS][NR];
+                    if constexpr (kKeepStages) eval_point(un, xs[0], gs[0], rs[0], k[0]);
+                    else {
+                        double x[NS], g[NS], r[NR];
+                        eval_point(un, x, g, r, k[0]);
+                    }
 #pragma unroll
                     for (int st = 1; st < 7; ++st) {
-                        double g[NS];
+                        double gp[NS];
 #pragma unroll
                         for (int i = 0; i < NS; ++i) {
                             double a = 0.0;
 #pragma unroll
                             for (int j = 0; j < st; ++j) a = fma(Ts5::a(st - 1, j), k[j][i], a);
-                            g[i] = fma(h, a, un[i]);
+                            gp[i] = fma(h, a, un[i]);
                         }
                         if (st == 6) {
 #pragma unroll
-                            for (int i = 0; i < NS; ++i) unew[i] = g[i];
+                            for (int i = 0; i < NS; ++i) unew[i] = gp[i];
                         }
-                        eval_point(g, xs[st], gs[st], rs[st], k[st]);
+                        if constexpr (kKeepStages) eval_point(gp, xs[st], gs[st], rs[st], k[st]);
+                        else {
+                            double x[NS], g[NS], r[NR];
+                            eval_point(gp, x, g, r, k[st]);
+                        }
                     }
                     // loss and its seeds: v = u_n + h sum_j b_j(Th) k_j  ->  A += w, kb_j += w h b_j(Th)
                     double ub[NS], kb[7][NS];
@@ -548,16 +561,32 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                             }
                         }
                     }
-                    // adjoint of the stages, last to first
+                    // adjoint of the stages, last to first.  Without kKeepStages the stage features are formed again, with h
+                    // behind an empty asm: otherwise the compiler recognises the stage points of the re-formation above and
+                    // keeps all their features alive after all.
+                    double h2 = h;
+                    if (!kKeepStages) asm volatile("" : "+v"(h2));
 #pragma unroll
                     for (int st = 6; st >= 0; --st) {
                         double gb[NS];
-                        vjp_point(xs[st], gs[st], rs[st], kb[st], gb);
+                        if constexpr (kKeepStages) vjp_point(xs[st], gs[st], rs[st], kb[st], gb);
+                        else {
+                            double gp[NS], x[NS], g[NS], r[NR], fdump[NS];
+#pragma unroll
+                            for (int i = 0; i < NS; ++i) {
+                                double a = 0.0;
+#pragma unroll
+                                for (int j = 0; j < st; ++j) a = fma(Ts5::a(st > 0 ? st - 1 : 0, j), k[j][i], a);
+                                gp[i] = st > 0 ? fma(h2, a, un[i]) : un[i];
+                            }
+                            eval_point(gp, x, g, r, fdump);
+                            vjp_point(x, g, r, kb[st], gb);
+                        }
 #pragma unroll
                         for (int i = 0; i < NS; ++i) {
                             ub[i] += gb[i];
 #pragma unroll
-                            for (int j = 0; j < st; ++j) kb[j][i] = fma(h * Ts5::a(st - 1, j), gb[i], kb[j][i]);
+                            for (int j = 0; j < st; ++j) kb[j][i] = fma(h * Ts5::a(st > 0 ? st - 1 : 0, j), gb[i], kb[j][i]);
                         }
                     }
 #pragma unroll

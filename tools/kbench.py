@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel timing at FIXED parameters (no optimiser update): case2 checkpoint p, B initial conditions, loss+gradient
 launches; prints the median HIP-event kernel time.  CRNN_HIP_LIB selects the library build (tools/kvariants.sh).
-usage: python tools/kbench.py [--batch 65536] [--reps 12] [--grad auto|forward|adjoint] [--case case2|rober]"""
+usage: python tools/kbench.py [--batch 65536] [--reps 12] [--grad auto|forward|adjoint] [--case case2|rober|hychem] [--solver rosenbrock23|tsit5|autotsit5]"""
 import argparse
 import json
 import os
@@ -16,6 +16,7 @@ ap.add_argument("--batch", type=int, default=65536)
 ap.add_argument("--reps", type=int, default=12)
 ap.add_argument("--grad", default="auto")
 ap.add_argument("--case", default="case2")
+ap.add_argument("--solver", default=None, choices=[None, "rosenbrock23", "tsit5", "autotsit5"])
 args = ap.parse_args()
 
 from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE2, PRESET_ROBER, cases  # noqa: E402
@@ -23,6 +24,7 @@ from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE2, PRESET_ROBER, cases  #
 fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fixtures.json")))
 rng = np.random.Generator(np.random.PCG64([1234, 0]))
 gm = {"auto": 0, "forward": 1, "adjoint": 2}[args.grad]
+sv = {None: None, "rosenbrock23": 0, "tsit5": 1, "autotsit5": 2}[args.solver]
 B = args.batch
 if args.case == "case2":
     ts = cases.case2_tsteps()
@@ -31,7 +33,7 @@ if args.case == "case2":
     clean = gen.predict_theta(u0, cases.case2_true_theta())[:, :6, :]
     gen.close()
     data = cases.add_noise(clean, 0.05, rng)
-    node = NeuralODE(ODEProblem(PRESET_CASE2, ts, grad_mode=gm))
+    node = NeuralODE(ODEProblem(PRESET_CASE2, ts, grad_mode=gm, solver=sv))
     node.set_ensemble(u0, data, cases.max_min(data, lb=1e-6))
     p = np.array(fx["case2_ckpt"]["p"])
 elif args.case == "hychem":
@@ -53,7 +55,7 @@ else:
     ys = np.array(fx["rober"]["yscale"]) if "yscale" in fx.get("rober", {}) else np.array([1.0, 4e-5, 1.0])
     sc = ys / ts[-1]
     data = np.abs(rng.standard_normal((B, 3, len(ts)))) * ys[None, :, None]
-    node = NeuralODE(ODEProblem(PRESET_ROBER, ts, rate_scale=sc, grad_mode=gm))
+    node = NeuralODE(ODEProblem(PRESET_ROBER, ts, rate_scale=sc, grad_mode=gm, solver=sv))
     node.set_ensemble(u0, data, ys)
     p = np.array(fx["rober_ckpt"]["p"])
 ms = []
@@ -61,6 +63,6 @@ for _ in range(args.reps):
     loss, grad = node.loss_and_grad(p)
     ms.append(node.last_stats["kernel_ms"])
 st = node.last_stats
-print(f"lib={os.path.basename(os.environ.get('CRNN_HIP_LIB', 'libcrnn_hip.so'))} case={args.case} grad={args.grad} B={B} "
+print(f"lib={os.path.basename(os.environ.get('CRNN_HIP_LIB', 'libcrnn_hip.so'))} case={args.case} solver={args.solver} grad={args.grad} B={B} "
       f"kernel_ms median {np.median(ms[2:]):.4f} min {min(ms[2:]):.4f}  steps/traj {st['n_accept'] / st['n_traj']:.2f} "
       f"rej/traj {st['n_reject'] / st['n_traj']:.2f} loss {loss:.6e} |g| {np.linalg.norm(grad):.6e}")
