@@ -43,6 +43,8 @@ end
 
 const PRESET_CASE1, PRESET_CASE2, PRESET_ROBER, PRESET_HYCHEM = Int32(1), Int32(2), Int32(3), Int32(4)
 const GRAD_AUTO, GRAD_FORWARD, GRAD_ADJOINT = Int32(0), Int32(1), Int32(2)   # cfg.grad_mode: how ForwardDiff.gradient is formed
+# alg = Rosenbrock23() (rober_crnn.jl:33) / Tsit5() (case1.jl:28) / AutoTsit5(Rosenbrock23()) (case2.jl:26)
+const ROSENBROCK23, TSIT5, AUTOTSIT5 = Int32(0), Int32(1), Int32(2)
 
 check(rc, ctx=C_NULL) = rc == 0 ? nothing :
     error(unsafe_string(ccall((:crnn_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx)))
@@ -55,9 +57,10 @@ mutable struct Problem
     B::Int
 end
 
-function ODEProblem(preset::Integer, tsteps::AbstractVector; atol=nothing, rtol=nothing, rate_scale=nothing, device=0)
+function ODEProblem(preset::Integer, tsteps::AbstractVector; atol=nothing, rtol=nothing, rate_scale=nothing, device=0, alg=nothing)
     cfg = Config()
     check(ccall((:crnn_config_preset, LIB), Int32, (Ref{Config}, Int32), cfg, preset))
+    alg === nothing || check(ccall((:crnn_config_set_solver, LIB), Int32, (Ref{Config}, Int32), cfg, alg))   # also sets the PI exponents
     cfg.n_save = length(tsteps); cfg.device = device
     n = cfg.ns + cfg.has_temp
     atol === nothing || (cfg.atol = ntuple(i -> i <= n ? Float64(atol isa Number ? atol : atol[i]) : 0.0, MAX_N))
