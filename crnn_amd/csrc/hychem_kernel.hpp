@@ -761,6 +761,8 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
                     CRNN_SCHED_FENCE();
                     HY_FRESH_THETA(th); HY_FRESH_KC(kc);
                     // -------- point u_mid: adjoint of v.f   (a rolled loop over the reactions: 20 weights in flight)
+                    double irho_mid = pm.irho;
+                    opaque(irho_mid);
                     {
                         double P2[NS], psi = 0.0;
 #pragma unroll
@@ -775,12 +777,10 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
                             const double Psi = At * ir;
                             psi += Psi;
                             double *gj = gacc + (size_t)L_::wi(0, j) * 64;
-                            HY_ACC(gacc + (size_t)L_::wb(j) * 64, Psi);
+                            // (the w_b and w_out terms of this point, Psi_j and vt_i ir_j, are added together with those of
+                            //  the point u_n below -- 100 fewer accumulator atomics per step; they need irho_mid and the parked r1)
 #pragma unroll
                             for (int m = 0; m < NS + 2; ++m) HY_ACC(gj + (size_t)m * 64, Psi * pm.x[m]);
-                            double *go = gacc + (size_t)L_::wo(0, j) * 64;
-#pragma unroll
-                            for (int i = 0; i < NS; ++i) HY_ACC(go + (size_t)i * 64, vt[i] * ir);
 #pragma unroll
                             for (int m = 0; m < NS; ++m) P2[m] = fma(Psi, wi_[m], P2[m]);
                         }
@@ -864,14 +864,15 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
                             const double cw = fma(gam, yw, 1.0), cv = gam * yv;
                             const double E = fma(Pw, cw, Pv * cv);
                             SE += E; psiv += Pv; psiw += Pw;
-                            HY_ACC(gacc + (size_t)L_::wb(j) * 64, E);
+                            const double irm = irho_mid * pk[(PK_R1 + j) * BLOCK];   // the u_mid point's irho r_j
+                            HY_ACC(gacc + (size_t)L_::wb(j) * 64, fma(Av, irm, E));
                             const double gPv = gam * Pv, gPw = gam * Pw;
                             double *gj = gacc + (size_t)L_::wi(0, j) * 64;
 #pragma unroll
                             for (int m = 0; m < NS + 2; ++m) HY_ACC(gj + (size_t)m * 64, fma(E, pn.x[m], fma(gPw, xpw[m], gPv * xpv[m])));
                             double *go = gacc + (size_t)L_::wo(0, j) * 64;
 #pragma unroll
-                            for (int i = 0; i < NS; ++i) HY_ACC(go + (size_t)i * 64, ir * fma(wt[i], cw, vt[i] * cv));
+                            for (int i = 0; i < NS; ++i) HY_ACC(go + (size_t)i * 64, fma(vt[i], fma(ir, cv, irm), wt[i] * (ir * cw)));
 #pragma unroll
                             for (int m = 0; m < NS; ++m) {
                                 PE[m] = fma(E, wi_[m], PE[m]);
