@@ -319,3 +319,49 @@ def test_gpu_hychem_batch_consistency_and_training(hfx):
     for _ in range(15):
         l1 = big.train_step()
     assert l1 < l0
+
+
+@pytest.mark.gpu
+def test_gpu_hychem_full_share_properties():
+    """One GPU's share of BASELINE config 4 (32 768 of the 262 144 experiments, all different): size-independent
+    properties.  Loss = mean of the per-experiment losses; the batch gradient is additive over sub-ranges (what the
+    multi-GPU all-reduce relies on); it is the derivative of the batch loss (central difference along a direction, at
+    tolerances where the step sequences do not move); every trajectory succeeds."""
+    from crnn_amd import NeuralODE, ODEProblem, PRESET_HYCHEM, hychem as hy
+    B = 32768
+    rng = np.random.Generator(np.random.PCG64([77, 1]))
+    ts, u0, Tt, Pt = hy.sample_conditions(B, rng)
+    node = NeuralODE(ODEProblem(PRESET_HYCHEM, ts, rate_scale=hy.DYDT_SCALE))
+    node.set_ensemble(u0, np.zeros((B, 9, len(ts))), np.ones(9))
+    node.set_tables(Tt, Pt)
+    clean = node.predict_n_ode(hy.true_p())
+    assert np.all(node.last_retcode == 0) and np.all(np.isfinite(clean))
+    assert np.max(np.abs(clean.sum(axis=1) - 1.0)) < 1e-3          # mass fractions: the true mechanism conserves mass
+    data = clean * (1.0 + 0.01 * rng.standard_normal(clean.shape))
+    ys = np.maximum((data.max(axis=2) - data.min(axis=2)).max(axis=0), hy.LB)
+    node.set_ensemble(u0, data, ys)
+    node.set_tables(Tt, Pt)
+    p = hy.true_p() + 0.02 * np.random.Generator(np.random.PCG64(5)).standard_normal(hy.NP)
+    p[-1] = 0.1
+    losses = node.losses(p)
+    L, G = node.loss_and_grad(p)
+    st = node.last_stats
+    assert st["n_ok"] == B and st["n_traj"] == B
+    assert abs(L - losses.mean()) < 1e-12 * L
+    half = 16384 + 37                                              # ragged split: not a multiple of the wavefront
+    L1, G1 = node.loss_and_grad(p, first=0, count=half)
+    L2, G2 = node.loss_and_grad(p, first=half, count=B - half)
+    assert abs((L1 * half + L2 * (B - half)) / B - L) < 1e-12 * L
+    assert np.max(np.abs((G1 * half + G2 * (B - half)) / B - G)) < 1e-11 * np.max(np.abs(G))
+    # directional derivative on a sub-range at tight tolerances
+    tight = NeuralODE(ODEProblem(PRESET_HYCHEM, ts, rate_scale=hy.DYDT_SCALE, atol=1e-11, rtol=1e-8))
+    n = 2048
+    tight.set_ensemble(u0[:n], data[:n], ys)
+    tight.set_tables(Tt[:n], Pt[:n])
+    Lt, Gt = tight.loss_and_grad(p)
+    v = np.random.Generator(np.random.PCG64(9)).standard_normal(hy.NP)
+    v /= np.linalg.norm(v)
+    eps = 1e-6
+    fd = (tight.losses(p + eps * v).mean() - tight.losses(p - eps * v).mean()) / (2 * eps)
+    assert abs(fd - Gt @ v) < 1e-4 * max(abs(fd), 1e-3 * np.linalg.norm(Gt))
+    node.close(); tight.close()
