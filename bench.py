@@ -69,7 +69,7 @@ def parse():
     ap.add_argument("--cols", type=int, default=0, help="tangent columns per lane (0 = library default)")
     ap.add_argument("--theta0", choices=["ckpt", "init"], default="ckpt",
                     help="start from the reference's trained checkpoint p or a reference-style random init")
-    ap.add_argument("--solver", choices=["rosenbrock23", "tsit5"], default="rosenbrock23",
+    ap.add_argument("--solver", choices=["rosenbrock23", "tsit5", "autotsit5"], default="rosenbrock23",
                     help="time stepper; the headline metric is quoted on the Rosenbrock23-equivalent stepper")
     ap.add_argument("--grad", choices=["auto", "forward", "adjoint"], default="auto",
                     help="gradient algorithm: discrete adjoint of the accepted steps (auto) or forward tangents")
@@ -85,7 +85,7 @@ def main():
     import torch.distributed as dist
 
     import crnn_amd
-    from crnn_amd import NeuralODE, ODEProblem, Optimiser, PRESET_CASE2, SOLVER_ROSENBROCK23, SOLVER_TSIT5, cases
+    from crnn_amd import NeuralODE, ODEProblem, Optimiser, PRESET_CASE2, SOLVER_AUTOTSIT5, SOLVER_ROSENBROCK23, SOLVER_TSIT5, cases
     from crnn_amd._lib import check, dptr, lib
     from crnn_amd.dist import DataParallel
 
@@ -119,9 +119,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         yscale = t.cpu().numpy()
 
-    solver = SOLVER_TSIT5 if args.solver == "tsit5" else SOLVER_ROSENBROCK23
+    solver = {"rosenbrock23": SOLVER_ROSENBROCK23, "tsit5": SOLVER_TSIT5, "autotsit5": SOLVER_AUTOTSIT5}[args.solver]
     gmode = {"auto": 0, "forward": 1, "adjoint": 2}[args.grad]
-    adjoint = gmode != 1 and solver == SOLVER_ROSENBROCK23
+    adjoint = gmode != 1                      # every stepper has a discrete-adjoint kernel; forward tangents on request
+    ros = solver == SOLVER_ROSENBROCK23       # the flop model and the PMC traffic figure below are those of the headline kernels
     node = NeuralODE(ODEProblem(PRESET_CASE2, ts, device=local_rank, cols_per_lane=args.cols, solver=solver, grad_mode=gmode))
     node.set_ensemble(u0, data, yscale)          # one PCIe upload; resident in HBM from here on
     fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fixtures.json")))
@@ -183,14 +184,16 @@ def main():
         k_ms = float(kms.mean())
         value = world * B * args.steps / elapsed
         ach_gbs = BYTES_PER_TRAJ * B / (k_ms * 1e-3) / 1e9
-        if adjoint:
+        if not ros:
+            flops = None   # no instruction-count model for the Tsit5 / composite kernels
+        elif adjoint:
             flops = ((st["n_accept"] + st["n_reject"]) * FLOP_ADJ_ATTEMPT + st["n_accept"] * FLOP_ADJ_REVERSE
                      + st["n_traj"] * len(ts) * FLOP_ADJ_SAVE)
         else:
             flops = (st["n_accept"] + st["n_reject"]) * FLOP_PRIMAL_STEP + st["n_accept"] * 25 * FLOP_COL_STEP
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md)
+        if ros and os.path.exists(tpath):   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md)
             try:
                 traffic = json.load(open(tpath)).get("case2_B65536_adjoint_bytes_per_launch" if adjoint
                                                      else "case2_B65536_bytes_per_launch")
@@ -204,21 +207,21 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "case2: 6 species + T, 3 reactions, P=25, D=50 save points on [0,50], "
-                                   f"{'Tsit5' if args.solver == 'tsit5' else 'Rosenbrock23'} atol 1e-6 rtol 1e-3, MAE loss, "
+                                   f"{ {'tsit5': 'Tsit5', 'autotsit5': 'AutoTsit5(Rosenbrock23)', 'rosenbrock23': 'Rosenbrock23'}[args.solver]} atol 1e-6 rtol 1e-3, MAE loss, "
                                    f"{'discrete-adjoint' if adjoint else 'forward-tangent'} gradient of the accepted steps (= ForwardDiff's derivative), "
                                    "ExpDecay+ADAM+WeightDecay update",
                        "batch_per_gpu": B, "global_batch": B * world, "theta0": args.theta0,
                        "comm": comm if world > 1 else "none", "parallelism": f"dp{world} (ICs sharded, 1 all-reduce/step)"},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("ros23_adj_kernel<6,3,T>" if adjoint else
-                                    ("tsit5_kernel" if args.solver == "tsit5" else "ros23_kernel") + "<6,3,T,C,L>"), "kernel_ms": k_ms,
+                         "kernel": (("ros23_adj_kernel<6,3,T>" if ros else "auto_adj_kernel<6,3,T>") if adjoint else
+                                    ("ros23_kernel" if ros else "tsit5_kernel") + "<6,3,T,C,L>"), "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_TRAJ * B,
                          "note": "state lives in VGPR/LDS for the whole integration; the path is instruction-issue bound "
                                  "(one wavefront per SIMD at 65 536 trajectories), see valu_fp64 (SURVEY F8)"},
             # flop count and duration of the LAST timed launch (step counts drift slightly as p is updated)
-            "valu_fp64": {"achieved": flops / (kms[-1] * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                          "frac": flops / (kms[-1] * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+            "valu_fp64": {"achieved": None if flops is None else flops / (kms[-1] * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
+                          "unit": "TFLOP/s", "frac": None if flops is None else flops / (kms[-1] * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
                           "steps_per_traj": st["n_accept"] / max(st["n_traj"], 1),
                           "rejects_per_traj": st["n_reject"] / max(st["n_traj"], 1),
                           "n_ok": st["n_ok"], "n_traj": st["n_traj"]},
@@ -229,7 +232,7 @@ def main():
             ns_ = min(args.cpu_sample, B)
             th, dth = orc.p2vec(2, 6, 3, p0)
             pb = orc.make_problem(ns=6, nr=3, has_temp=1, lb=1e-6, ub=10.0, inv_R=cases.INV_R, atol=1e-6, rtol=1e-3,
-                                  yscale=yscale, clamp_pred=1, solver=1 if args.solver == "tsit5" else 0)
+                                  yscale=yscale, clamp_pred=1, solver={"rosenbrock23": 0, "tsit5": 1, "autotsit5": 2}[args.solver])
             u0_s = np.ascontiguousarray(u0[:ns_].T)
             data_s = np.ascontiguousarray(data[:ns_].transpose(2, 1, 0))
             cores = usable_cores()
