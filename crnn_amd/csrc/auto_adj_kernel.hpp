@@ -2,7 +2,7 @@
 // loss gradient by the DISCRETE ADJOINT of the accepted steps.
 //
 // Reference algorithms: `alg = Tsit5()` (case1/case1.jl:28,94-95) and `alg = AutoTsit5(Rosenbrock23(autodiff=false))`
-// (case2/case2.jl:26, HyChem/crnn_pyrolysis_mass.jl:25); the gradient is ForwardDiff's (case2/case2.jl:195): the
+// (case2/case2.jl:26, HyChem/crnn_pyrolysis_mass.jl:29); the gradient is ForwardDiff's (case2/case2.jl:195): the
 // derivative of the solver's arithmetic with dt, the accept/reject decisions, the algorithm choices and the saveat
 // weights held fixed.  Same wave-synchronous forward sweep / reverse sweep over a per-lane tape (t_n, dt_n, u_n) as
 // ros23_adj_kernel.hpp; a Tsit5 step is recorded with -dt_n, so the tape layout does not change.

@@ -778,7 +778,7 @@ static int solve_one_tsit5(const orc_problem *pb, const double *th, const double
 
 /* ------------------------------------------------------------------------ */
 /* AutoTsit5(Rosenbrock23()): OrdinaryDiffEq's stiffness-switching composite */
-/* (case2/case2.jl:26, HyChem/crnn_pyrolysis_mass.jl:25).  The package is   */
+/* (case2/case2.jl:26, HyChem/crnn_pyrolysis_mass.jl:29).  The package is   */
 /* not in the reference tree; restated from its published algorithm         */
 /* (AutoSwitch, composite_algs.jl) [UNVERIFIED-DEP]:                        */
 /*   * start on Tsit5; before every attempt after the first, test           */
