@@ -19,14 +19,15 @@
 // so a trajectory + gradient costs about two primal solves, independent of the number of parameters, and the result
 // equals the forward-tangent gradient up to rounding (tests/test_gpu_parity.py).  The gradient
 // is produced in theta space (w_in | w_b | w_out); the chain rule through p2vec is a [P x n_theta] product applied to
-// the batch sum (project_kernel).
+// the batch sum (reduce_project_kernel).
 //
 // MI355X mapping: ONE LANE PER TRAJECTORY (no lane groups, no redundant primal, no LDS step record).  A wavefront takes
 // 64 trajectories from the global queue, runs the forward sweep for all of them, then the reverse sweep.  The forward
-// sweep appends (t_n, dt_n, u_n) of every accepted step to a per-lane tape in HBM (lane-contiguous, so the partial
-// lines merge in L2; at 18 steps x 72 B the tape of a whole launch stays cache resident); the reverse sweep re-forms
-// J, W and the stages from the tape record instead of storing them.  The observed data are read once, by the reverse
-// sweep, where loss and seeds are formed together.  theta sits in SGPRs, the 42 (case2) gradient accumulators in VGPRs.
+// sweep appends (t_n, dt_n, u_n) of every accepted step to a per-lane tape in HBM (lane-contiguous: the partial lines
+// of a wavefront's store merge in L2; a [wavefront][step][field][lane] layout with 512-byte stores measured slower);
+// the reverse sweep re-forms J, W and the stages from the tape record instead of storing them.  The observed data are
+// read once, by the reverse sweep, where loss and seeds are formed together.  theta sits in SGPRs, the 42 (case2)
+// gradient accumulators of a lane in LDS ([m][lane], ds_add_f64), the per-batch sums are formed in the kernel.
 #pragma once
 #include "ros23_kernel.hpp"
 
