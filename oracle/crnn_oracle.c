@@ -1170,7 +1170,10 @@ typedef double complex cplx;
 typedef struct orc_cathode {
     double lb_clamp, T0, beta;      /* beta in K/min: T = T0 + beta/60 t */
     double atol, rtol;
-    int32_t maxiters, pad_;
+    int32_t maxiters;
+    int32_t solver;   /* 0 Rosenbrock23; 2 AutoTsit5 composite with Rosenbrock23 as its stiff algorithm (the reference:
+                         AutoTsit5(TRBDF2(autodiff=true)), network.jl:195 -- the explicit branch and the switching rule
+                         are restated, the stiff branch is NOT TRBDF2; see solve_one_auto above for the rule) */
     double gamma, qmin, qmax, beta1, beta2, qsteady_min, qsteady_max, qoldinit;
 } orc_cathode;
 
@@ -1241,6 +1244,8 @@ static void csolve3(const double *W, const int *piv, cplx *b) {   /* real LU app
    dbar[i] = mean_k data[i,k], d2bar[i] = mean_k data[i,k]^2, gradient wrt theta (17).
    Complex-step: for direction e_k the whole step is evaluated at theta + i*h*e_k, u + i*h*s_k with the REAL
    factorisation of W (dt and the pivots are real), which is exactly the first-order tangent. */
+_Thread_local int64_t orc_cathode_last_tsit5_steps = 0;   /* accepted Tsit5 steps of the calling thread's last solve (composite) */
+int64_t orc_cathode_tsit5_steps(void) { return orc_cathode_last_tsit5_steps; }
 int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *ts, int D,
                           const double *dbar, const double *d2bar, double *hrr /*[D] or NULL*/,
                           double *loss_out, double *grad /*[17] or NULL*/, int32_t *n_saved_out, orc_stats *st) {
@@ -1272,7 +1277,7 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
         for (int i = 0; i < 3; ++i) { double e = (f1[i] - fr[i]) / sk[i]; d2 += e * e; }
         d2 = sqrt(d2 / 3) / dt0;
         double dm = fmax(d1, d2);
-        double dt1 = dm <= 1e-15 ? fmax(1e-6, dt0 * 1e-3) : pow(10.0, -(2.0 + log10(dm)) / 2.0);
+        double dt1 = dm <= 1e-15 ? fmax(1e-6, dt0 * 1e-3) : pow(10.0, -(2.0 + log10(dm)) / (c->solver == 2 ? 5.0 : 2.0));   /* order + 1 of the starting algorithm */
         dt = fmin(fmin(100 * dt0, dt1), dtmax);
     }
     double qold = c->qoldinit, loss_sum = 0.0, g[17];
@@ -1294,20 +1299,75 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
         ++jsave;                                                                                                \
     } while (0)
     CATH_SAVE(u[k][i], t0);   /* saveat contains tspan[1] */
+    static _Thread_local cplx KT[7][18][3];   /* Tsit5 stage slopes of all copies */
+    int alg = c->solver == 2 ? 0 : 1, cnt = 0, have_est = 0;
+    int64_t n_ts5 = 0;
+    double eigen_est = 0.0;
     while (jsave < D) {
         if (++iter > c->maxiters) { retcode = 1; break; }
+        if (c->solver == 2 && have_est) {   /* choose_algorithm!, as in solve_one_auto */
+            const int stiff = fabs(eigen_est * dt / AS_STAB) > AS_TOL;
+            cnt = stiff ? (cnt < 0 ? 1 : cnt + 1) : (cnt > 0 ? -1 : cnt - 1);
+            if (alg == 0 && cnt > AS_MAXSTIFF) { dt *= AS_DTFAC; alg = 1; }
+            else if (alg == 1 && cnt < -AS_MAXNONSTIFF) { dt /= AS_DTFAC; alg = 0; }
+        }
         int last = 0;
         if (t + dt * (1.0 + 1e-13) >= tend) { dt = tend - t; last = 1; }
         if (!(dt > 0.0) || t + dt == t) { retcode = 2; break; }
         const double gam = d * dt;
         cplx Jc[9], ftc[3];
         double W[9]; int piv[3];
-        cath_jac_ft(c, thk[PR], u[PR], t, Jc, ftc);
-        for (int cc = 0; cc < 3; ++cc) for (int i = 0; i < 3; ++i) W[i + 3 * cc] = (i == cc ? 1.0 : 0.0) - gam * creal(Jc[i + 3 * cc]);
-        if (lu_factor(3, W, piv) != 0) { retcode = 3; break; }
         cplx k1[18][3], k2[18][3], k3[18][3], un[18][3], f2[18][3];
         int finite = 1;
         double ev[3], EEst = 0.0;
+        if (alg == 0 && c->solver == 2) {
+            /* ---- Tsit5 attempt (non-autonomous: stage s at t + c_s dt) ---- */
+            for (int pass = 0; pass < 2; ++pass) {
+                for (int k = 0; k <= 17; ++k) {
+                    if (pass == 0 ? (k != PR) : !(k < P)) continue;
+                    cplx g[3], g6[3] = {0, 0, 0};
+                    for (int i = 0; i < 3; ++i) KT[0][k][i] = f0[k][i];
+                    for (int s_ = 1; s_ < 7; ++s_) {
+                        for (int i = 0; i < 3; ++i) {
+                            cplx a = 0.0;
+                            for (int j = 0; j < s_; ++j) a += TS_A[s_][j] * KT[j][k][i];
+                            g[i] = u[k][i] + dt * a;
+                        }
+                        if (s_ == 5) for (int i = 0; i < 3; ++i) g6[i] = g[i];
+                        if (s_ == 6) for (int i = 0; i < 3; ++i) un[k][i] = g[i];
+                        cath_rhs(c, thk[k], g, s_ == 6 ? (last ? tend : t + dt) : t + TS_C[s_] * dt, KT[s_][k]);
+                    }
+                    for (int i = 0; i < 3; ++i) f2[k][i] = KT[6][k][i];
+                    if (k == PR) {
+                        double est = 0.0; int isnan_ = 0;
+                        for (int i = 0; i < 3; ++i) {
+                            cplx a = 0.0;
+                            for (int j = 0; j < 7; ++j) a += TS_BT[j] * KT[j][k][i];
+                            ev[i] = dt * creal(a);
+                            if (!isfinite(creal(un[k][i])) || !isfinite(ev[i])) finite = 0;
+                            double q_ = fabs(creal(KT[6][k][i] - KT[5][k][i]) / creal(un[k][i] - g6[i]));
+                            if (q_ != q_) isnan_ = 1; else if (q_ > est) est = q_;
+                        }
+                        eigen_est = isnan_ ? NAN : est;
+                    }
+                }
+                if (pass == 0) {
+                    if (!finite) break;
+                    double s_ = 0.0;
+                    for (int i = 0; i < 3; ++i) { double m = fmax(fabs(creal(u[PR][i])), fabs(creal(un[PR][i]))); double e = ev[i] / (c->atol + c->rtol * m); s_ += e * e; }
+                    EEst = sqrt(s_ / 3.0);
+                    if (!(EEst <= 1.0) || P == 0) break;
+                }
+            }
+        } else {
+        cath_jac_ft(c, thk[PR], u[PR], t, Jc, ftc);
+        {   /* eigen_est of the stiff algorithm: opnorm(J, Inf) */
+            double est = 0.0;
+            for (int i = 0; i < 3; ++i) { double a = 0.0; for (int cc = 0; cc < 3; ++cc) a += fabs(creal(Jc[i + 3 * cc])); if (a > est) est = a; }
+            eigen_est = est;
+        }
+        for (int cc = 0; cc < 3; ++cc) for (int i = 0; i < 3; ++i) W[i + 3 * cc] = (i == cc ? 1.0 : 0.0) - gam * creal(Jc[i + 3 * cc]);
+        if (lu_factor(3, W, piv) != 0) { retcode = 3; break; }
         for (int pass = 0; pass < 2; ++pass) {       /* pass 0: primal (and accept test), pass 1: tangents if accepted */
             for (int k = 0; k <= 17; ++k) {
                 if (pass == 0 ? (k != PR) : !(k < P)) continue;
@@ -1340,19 +1400,30 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
                 if (!(EEst <= 1.0) || P == 0) break;
             }
         }
+        }
+        have_est = 1;
         if (!finite) { retcode = 3; break; }
         int accept = (EEst <= 1.0);
+        const double b1_ = c->solver == 2 ? (alg == 0 ? 7.0 / 50.0 : 7.0 / 20.0) : c->beta1;
+        const double b2_ = c->solver == 2 ? (alg == 0 ? 2.0 / 25.0 : 2.0 / 10.0) : c->beta2;
         double q, q11 = 0.0;
         if (EEst == 0.0) q = 1.0 / c->qmax;
-        else { q11 = pow(EEst, c->beta1); q = q11 / pow(qold, c->beta2); q = fmax(1.0 / c->qmax, fmin(1.0 / c->qmin, q / c->gamma)); }
+        else { q11 = pow(EEst, b1_); q = q11 / pow(qold, b2_); q = fmax(1.0 / c->qmax, fmin(1.0 / c->qmin, q / c->gamma)); }
         if (accept) {
             if (st) st->naccept++;
+            if (alg == 0 && c->solver == 2) n_ts5++;
             if (q >= c->qsteady_min && q <= c->qsteady_max) q = 1.0;
             qold = fmax(EEst, c->qoldinit);
             double tnew = last ? tend : t + dt;
             while (jsave < D && ts[jsave] <= tnew) {
                 double tsv = ts[jsave];
                 if (tsv == tnew) { CATH_SAVE(un[k][i], tsv); }
+                else if (alg == 0 && c->solver == 2) {
+                    double bth[7];
+                    orc_tsit5_dense((tsv - t) / dt, bth);
+                    CATH_SAVE(u[k][i] + dt * (bth[0] * KT[0][k][i] + bth[1] * KT[1][k][i] + bth[2] * KT[2][k][i] + bth[3] * KT[3][k][i]
+                                              + bth[4] * KT[4][k][i] + bth[5] * KT[5][k][i] + bth[6] * KT[6][k][i]), tsv);
+                }
                 else {
                     double Th = (tsv - t) / dt;
                     double c1 = Th * (1.0 - Th) / (1.0 - 2.0 * d), c2 = Th * (Th - 2.0 * d) / (1.0 - 2.0 * d);
@@ -1372,6 +1443,7 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
     if (loss_out) *loss_out = loss_sum / (double)D;
     if (grad) for (int k = 0; k < 17; ++k) grad[k] = g[k] / (double)D;
     if (n_saved_out) *n_saved_out = jsave;
+    orc_cathode_last_tsit5_steps = n_ts5;
     return retcode;
 }
 

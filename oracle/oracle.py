@@ -255,16 +255,20 @@ def tsit5_dense(theta):
 # ---------------------------------------------------------------------------- Cathode-UQ restatement
 class Cathode(C.Structure):
     _fields_ = [("lb_clamp", C.c_double), ("T0", C.c_double), ("beta", C.c_double), ("atol", C.c_double),
-                ("rtol", C.c_double), ("maxiters", C.c_int32), ("pad_", C.c_int32),
+                ("rtol", C.c_double), ("maxiters", C.c_int32), ("solver", C.c_int32),
                 ("gamma", C.c_double), ("qmin", C.c_double), ("qmax", C.c_double), ("beta1", C.c_double),
                 ("beta2", C.c_double), ("qsteady_min", C.c_double), ("qsteady_max", C.c_double), ("qoldinit", C.c_double)]
 
 
-def make_cathode(beta, atol=1e-12, rtol=1e-3, maxiters=2500000, lb_clamp=1e-16):
+def make_cathode(beta, atol=1e-12, rtol=1e-3, maxiters=2500000, lb_clamp=1e-16, solver=0):
+    """solver 0: Rosenbrock23; 2: AutoTsit5 composite (Tsit5 + stiffness switch, Rosenbrock23 as the stiff algorithm)."""
     c = Cathode()
     lib().orc_cathode_defaults(C.byref(c))
     assert lib().orc_sizeof_cathode() == C.sizeof(Cathode)
     c.beta, c.atol, c.rtol, c.maxiters, c.lb_clamp = float(beta), atol, rtol, int(maxiters), lb_clamp
+    c.solver = int(solver)
+    if solver == 2:
+        c.qsteady_max = 1.0          # a composite is not an implicit algorithm type (see solve_one_auto)
     return c
 
 
@@ -287,7 +291,9 @@ def cathode_solve_one(c, theta, ts, dbar, d2bar, want_grad=True):
     rc = lib().orc_cathode_solve_one(C.byref(c), _dp(np.ascontiguousarray(theta, float)), _dp(ts), C.c_int(D),
                                      _dp(np.ascontiguousarray(dbar, float)), _dp(np.ascontiguousarray(d2bar, float)),
                                      _dp(hrr), C.byref(loss), _dp(grad), C.byref(ns), C.cast(st, C.c_void_p))
-    return dict(hrr=hrr, loss=loss.value, grad=grad, retcode=rc, n_saved=ns.value, naccept=st[0], nreject=st[1])
+    lib().orc_cathode_tsit5_steps.restype = C.c_int64
+    return dict(hrr=hrr, loss=loss.value, grad=grad, retcode=rc, n_saved=ns.value, naccept=st[0], nreject=st[1],
+                n_tsit5=int(lib().orc_cathode_tsit5_steps()))
 
 
 # ---------------------------------------------------------------------------- HyChem restatement
