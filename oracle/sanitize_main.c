@@ -83,6 +83,9 @@ int main(void) {
         orc_stats st = {0, 0};
         int rc = orc_cathode_solve_one(&c, th, ts, D, dbar, d2bar, hrr, &loss, grad, &nsv, &st);
         if (rc < 0 || rc > 3) ++fails;
+        c.solver = 2; c.qsteady_max = 1.0;     /* AutoTsit5 restatement */
+        rc = orc_cathode_solve_one(&c, th, ts, D, dbar, d2bar, hrr, &loss, grad, &nsv, &st);
+        if (rc < 0 || rc > 3) ++fails;
     }
     /* ---- HyChem ---- */
     {
