@@ -523,3 +523,35 @@ def test_autotsit5_case1_matches_oracle(orc, fx):
     assert np.max(np.abs(grad - ref["grad"] / B)) < 1e-7 * np.max(np.abs(ref["grad"] / B))
     assert node.last_stats["n_accept"] == ref["naccept"]
     node.close()
+
+
+def test_training_with_tsit5_adjoint_and_composite(case2_setup, rober_setup):
+    """The device-resident loop on the new steppers.  Tsit5 (case2): the asynchronous adjoint loop equals forward-tangent
+    training to rounding, also when the tape is too short and the skipped steps are replayed with the Tsit5 forward-tangent
+    kernel.  AutoTsit5 (robertson): train step == host loss_and_grad + update!."""
+    from crnn_amd import Optimiser, PRESET_CASE2, PRESET_ROBER
+    s = case2_setup
+    p0 = s["p_init"]
+
+    def run(**kw):
+        node = _tsit5_node(PRESET_CASE2, s, **kw)
+        node.train_init(Optimiser(25, PRESET_CASE2), p0)
+        for _ in range(5):
+            node.train_step()
+        return node.params()
+
+    p_fwd, p_adj, p_tiny = run(grad_mode=1), run(grad_mode=2), run(grad_mode=2, tape_steps=6)
+    assert np.max(np.abs(p_adj - p_fwd)) < 1e-10
+    assert np.array_equal(p_tiny, p_fwd)                      # every step overflowed -> replayed with forward tangents
+    r = rober_setup
+    node = _auto_node("rober", r)
+    opt_host = Optimiser(43, PRESET_ROBER)
+    p_host = r["p_ckpt"].copy()
+    node.train_init(Optimiser(43, PRESET_ROBER), p_host)
+    for _ in range(3):
+        loss_h, g = node.loss_and_grad(p_host)
+        opt_host.update_(p_host, g)
+        loss_d = node.train_step(want_loss=True)
+        assert abs(loss_d - loss_h) < 1e-12 * abs(loss_h)
+        assert np.max(np.abs(node.params() - p_host)) < 1e-12
+    node.close()
