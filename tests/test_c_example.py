@@ -1,0 +1,38 @@
+"""examples/case2_train.c: the C ABI driven from plain C99 (no Python, no torch) -- the compiled-host view of the boundary.
+CPU: it builds against include/crnn_hip.h and the in-tree library and fails loudly without a GPU.  GPU: it trains."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "crnn_amd", "csrc")
+
+
+def _build(tmp_path):
+    from crnn_amd import _lib  # noqa: F401  (builds / locates libcrnn_hip.so)
+    exe = str(tmp_path / "case2_train")
+    cc = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-O2", "-I" + os.path.join(ROOT, "include"),
+                         os.path.join(ROOT, "examples", "case2_train.c"), "-o", exe, "-L" + CSRC, "-lcrnn_hip", "-lm",
+                         "-Wl,-rpath," + CSRC], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    return exe
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc not available")
+def test_c_example_builds_and_needs_a_gpu(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    exe = _build(tmp_path)
+    run = subprocess.run([exe, "16", "2"], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 2 and "no HIP device" in run.stderr      # no CPU fallback
+
+
+@pytest.mark.gpu
+def test_c_example_trains_on_the_gpu(tmp_path):
+    exe = _build(tmp_path)
+    run = subprocess.run([exe, "2048", "12"], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout[-1500:] + run.stderr[-1500:]
+    assert "final mean loss" in run.stdout and "ok 2048/2048" in run.stdout
