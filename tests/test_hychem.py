@@ -365,3 +365,41 @@ def test_gpu_hychem_full_share_properties():
     fd = (tight.losses(p + eps * v).mean() - tight.losses(p - eps * v).mean()) / (2 * eps)
     assert abs(fd - Gt @ v) < 1e-4 * max(abs(fd), 1e-3 * np.linalg.norm(Gt))
     node.close(); tight.close()
+
+
+@pytest.mark.gpu
+def test_gpu_hychem_config4_as_eight_logical_shards():
+    """BASELINE config 4 at full size on one GPU: 262 144 experiments, solved once as a whole and once as the eight
+    contiguous 32 768-experiment shards an 8-GPU node would own (crnn_amd.dist.shard_range).  The all-reduce sums
+    [grad_sum | loss_sum | counts]; done here on the host, it must reproduce the single-launch mean loss and gradient to
+    reduction-order rounding, and every shard must report all of its trajectories as solved."""
+    from crnn_amd import NeuralODE, ODEProblem, PRESET_HYCHEM, hychem as hy
+    from crnn_amd.dist import shard_range
+    B, W = 262144, 8
+    rng = np.random.Generator(np.random.PCG64([78, 2]))
+    ts, u0, Tt, Pt = hy.sample_conditions(B, rng)
+    node = NeuralODE(ODEProblem(PRESET_HYCHEM, ts, rate_scale=hy.DYDT_SCALE))
+    node.set_ensemble(u0, np.zeros((B, 9, len(ts))), np.ones(9))
+    node.set_tables(Tt, Pt)
+    data = node.predict_n_ode(hy.true_p())
+    assert np.all(node.last_retcode == 0)
+    data *= 1.0 + 0.01 * rng.standard_normal(data.shape)
+    ys = np.maximum((data.max(axis=2) - data.min(axis=2)).max(axis=0), hy.LB)
+    node.set_ensemble(u0, data, ys)
+    node.set_tables(Tt, Pt)
+    p = hy.true_p() + 0.02 * np.random.Generator(np.random.PCG64(5)).standard_normal(hy.NP)
+    p[-1] = 0.1
+    L, G = node.loss_and_grad(p)
+    assert node.last_stats["n_ok"] == B
+    lsum, gsum, n = 0.0, np.zeros(hy.NP), 0
+    for r in range(W):
+        first, count = shard_range(B, r, W)
+        assert count == B // W
+        l, g = node.loss_and_grad(p, first=first, count=count)
+        st = node.last_stats
+        assert st["n_traj"] == count and st["n_ok"] == count
+        lsum += l * count; gsum += g * count; n += count
+    assert n == B
+    assert abs(lsum / B - L) < 1e-12 * L
+    assert np.max(np.abs(gsum / B - G)) < 1e-11 * np.max(np.abs(G))
+    node.close()
