@@ -36,3 +36,25 @@ def test_c_example_trains_on_the_gpu(tmp_path):
     run = subprocess.run([exe, "2048", "12"], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stdout[-1500:] + run.stderr[-1500:]
     assert "final mean loss" in run.stdout and "ok 2048/2048" in run.stdout
+
+
+@pytest.mark.gpu
+def test_reference_style_training_script_with_checkpoint_restart(tmp_path):
+    """examples/case2_train.py: per-experiment updates in random order, epoch-end losses, BSON checkpoint and restart."""
+    import sys
+    pytest.importorskip("bson")
+    ck = str(tmp_path / "mymodel.bson")
+    cmd = [sys.executable, os.path.join(ROOT, "examples", "case2_train.py"), "--checkpoint", ck, "--n-plot", "4"]
+    a = subprocess.run(cmd + ["--epochs", "8"], capture_output=True, text=True, timeout=600)
+    assert a.returncode == 0, a.stderr[-2000:]
+    lines = [ln for ln in a.stdout.splitlines() if ln.startswith("epoch")]
+    assert len(lines) == 8
+    first, last = float(lines[0].split()[4]), float(lines[-1].split()[4])
+    assert last < first                                        # it learns
+    from crnn_amd.io import load_checkpoint
+    c = load_checkpoint(ck)
+    assert int(c["iter"]) == 8 and c["p"].shape == (25,) and len(c["l_loss_train"]) == 8
+    b = subprocess.run(cmd + ["--epochs", "10", "--restart"], capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stderr[-2000:]
+    assert "restarting from" in b.stdout and len([ln for ln in b.stdout.splitlines() if ln.startswith("epoch")]) == 2
+    assert int(load_checkpoint(ck)["iter"]) == 10
