@@ -676,7 +676,7 @@ int32_t crnn_config_preset(crnn_config *cfg, int32_t preset) {
         cfg->ns = 6; cfg->nr = 3; cfg->has_temp = 1; cfg->param_map = CRNN_PMAP_CASE2;
         cfg->n_save = 50; cfg->clamp_pred = 1;
         cfg->lb = 1e-6; cfg->ub = 10.0;
-        cfg->inv_R = -1.0 / 1.98720425864083e-3;
+        cfg->inv_R = (double)(-1.0f / 1.98720425864083e-3f);   // `- 1 / 1.98720425864083f-3`: a Float32 literal, the quotient is Float32 (case2.jl:113)
         break;
     case CRNN_PRESET_ROBER:  // robertson/rober_crnn.jl:20-37
         cfg->ns = 3; cfg->nr = 6; cfg->has_temp = 0; cfg->param_map = CRNN_PMAP_ROBER;

@@ -29,7 +29,7 @@ def orc():
     return o
 
 
-INV_R = -1.0 / 1.98720425864083e-3
+INV_R = float(np.float32(-1.0) / np.float32(1.98720425864083e-3))   # Float32 literal in case2.jl:113
 
 
 @pytest.fixture(scope="session")

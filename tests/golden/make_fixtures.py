@@ -105,7 +105,7 @@ def p2vec_case1(p, ns=5, nr=4):
     return w_in, w_b, w_out
 
 
-INV_R = -1.0 / 1.98720425864083e-3
+INV_R = float(np.float32(-1.0) / np.float32(1.98720425864083e-3))   # case2.jl:113: R is a Float32 literal
 
 
 def crnn_case2(u, w_in, w_b, w_out, lb=1e-6, ub=10.0):
@@ -129,8 +129,7 @@ def true_case2(y, k):
 
 
 def arrhenius(logA, Ea, T):
-    R = 1.98720425864083e-3
-    return np.exp(logA) * np.exp(-Ea / R / T)
+    return np.exp(logA) * np.exp(Ea * INV_R / T)       # -Ea / R / T with the Float32 R of case2.jl:56
 
 
 def true_rober(y, k):

@@ -54,7 +54,7 @@ def test_presets_carry_reference_constants():
     L.check(L.lib.crnn_config_preset(C.byref(cfg), L.PRESET_CASE2))
     assert (cfg.ns, cfg.nr, cfg.has_temp, cfg.n_save, cfg.clamp_pred) == (6, 3, 1, 50, 1)          # case2.jl:18-25
     assert cfg.lb == 1e-6 and cfg.ub == 10.0 and cfg.atol[0] == 1e-6 and cfg.rtol[0] == 1e-3        # :27-35
-    assert cfg.inv_R == -1.0 / 1.98720425864083e-3                                                   # :113
+    assert cfg.inv_R == float(np.float32(-1.0) / np.float32(1.98720425864083e-3)) == -503.21954345703125   # :113, Float32 quotient
     L.check(L.lib.crnn_config_preset(C.byref(cfg), L.PRESET_ROBER))
     assert (cfg.ns, cfg.nr, cfg.has_temp, cfg.n_save, cfg.maxiters) == (3, 6, 0, 40, 10000)          # rober:20-30
     assert [cfg.atol[i] for i in range(3)] == [1e-6, 1e-8, 1e-6] and cfg.lb == 1e-8 and np.isinf(cfg.ub)
@@ -118,13 +118,13 @@ def test_host_optimiser_matches_golden_trace_and_oracle(orc, fx):
 
 def test_cpu_definition_of_crnn_matches_oracle_rhs(orc, case2_setup):
     """crnn(du,u,p,t): the CPU definition kept for ODEProblem construction equals the oracle RHS."""
-    from crnn_amd import crnn, p2vec
+    from crnn_amd import cases, crnn, p2vec
     s = case2_setup
     w = p2vec(2, 6, 3, s["p_ckpt"])
     u = np.array([0.7, 1.2, 0.3, 0.05, 1e-9, 12.0, 331.0])   # below lb and above ub included
-    du = crnn(np.zeros(7), u, w, lb=1e-6, ub=10.0, inv_R=-1.0 / 1.98720425864083e-3)
+    du = crnn(np.zeros(7), u, w, lb=1e-6, ub=10.0, inv_R=cases.INV_R)
     th, _ = orc.p2vec(2, 6, 3, s["p_ckpt"])
-    pb = orc.make_problem(ns=6, nr=3, has_temp=1, lb=1e-6, ub=10.0, inv_R=-1.0 / 1.98720425864083e-3)
+    pb = orc.make_problem(ns=6, nr=3, has_temp=1, lb=1e-6, ub=10.0, inv_R=cases.INV_R)
     assert np.max(np.abs(du - orc.rhs(pb, th, u))) < 1e-13 * np.max(np.abs(du))
     assert du[6] == 0.0
 
@@ -133,7 +133,7 @@ def test_true_mechanisms_are_exact_crnn_instances(orc, fx):
     """cases.*_true_theta reproduce the literal trueODEfunc right-hand sides (away from the clamp)."""
     from crnn_amd import cases
     y = np.array([0.9, 1.4, 0.2, 0.1, 0.05, 0.6, 330.0])
-    k = np.exp(cases.CASE2_LOGA) * np.exp(-cases.CASE2_EA / cases.R_KCAL / y[6])
+    k = np.exp(cases.CASE2_LOGA) * np.exp(cases.CASE2_EA * cases.INV_R / y[6])
     r1, r2, r3 = k[0] * y[0] * y[1], k[1] * y[2] * y[1], k[2] * y[3] * y[1]
     lit = np.array([-r1, -r1 - r2 - r3, r1 - r2, r2 - r3, r3, r1 + r2 + r3, 0.0])
     pb = orc.make_problem(ns=6, nr=3, has_temp=1, lb=1e-6, ub=10.0, inv_R=cases.INV_R)
