@@ -386,7 +386,7 @@ static double init_dt(const orc_problem *pb, const double *th, const double *u0,
     double dtmax = tspan_len;
     double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 / d1);
     dt0 = fmin(dt0, dtmax);
-    double u1[ORC_MAXN], f1[ORC_MAXN];
+    double u1[ORC_MAXN] = {0}, f1[ORC_MAXN] = {0};
     for (int i = 0; i < n; ++i) u1[i] = u0[i] + dt0 * f0[i];
     orc_rhs(pb, th, u1, f1);
     double d2 = 0;
@@ -1626,7 +1626,7 @@ int orc_hychem_solve_one(const orc_hychem *c, const double *th, const double *dt
     double dt;
     {   /* Hairer initial step, order 2, on the primal */
         double sk[12], d0 = 0, d1 = 0, d2 = 0, ur[12], fr[12], f1r[12];
-        cplx u1[12], f1[12];
+        cplx u1[12] = {0}, f1[12] = {0};
         for (int i = 0; i < ns; ++i) { ur[i] = creal(u[PR * ns + i]); fr[i] = creal(f0[PR * ns + i]); sk[i] = c->atol + fabs(ur[i]) * c->rtol;
             d0 += (ur[i] / sk[i]) * (ur[i] / sk[i]); d1 += (fr[i] / sk[i]) * (fr[i] / sk[i]); }
         d0 = sqrt(d0 / ns); d1 = sqrt(d1 / ns);
