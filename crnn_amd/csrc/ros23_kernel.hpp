@@ -98,6 +98,14 @@ __device__ __forceinline__ double frcp(double a) {
     return x;
 }
 
+// 1/a to ~2e-15 (v_rcp_f64 delivers 4.6e-8, one Newton step 2.2e-15, two 1.1e-16: tools/ubench/rcp_acc.hip).  Enough where the
+// quotient it feeds is corrected afterwards, as in flog / flog_vec.
+__device__ __forceinline__ double frcp1(double a) {
+    double x = __builtin_amdgcn_rcp(a);
+    const double e = fma(-a, x, 1.0);
+    return fma(x, e, x);
+}
+
 // log(x) for finite x > 0: fdlibm e_log.c scheme (< 1 ulp), ~35 instructions instead of
 // ocml's ~100-instruction double-double evaluation.  x is always a clamped concentration
 // (lb <= x <= ub) or a positive error norm here, so no zero / negative / inf / nan handling.
@@ -108,9 +116,9 @@ __device__ __forceinline__ double flog(double x) {
     m = lo ? m + m : m;                             // [sqrt(1/2), sqrt 2)
     k = lo ? k - 1 : k;
     const double f = m - 1.0;
-    const double r = frcp(2.0 + f);
+    const double r = frcp1(2.0 + f);
     double s = f * r;
-    s = fma(fma(-(2.0 + f), s, f), r, s);           // one correction: s = f/(2+f) to < 1 ulp
+    s = fma(fma(-(2.0 + f), s, f), r, s);           // one correction: s = f/(2+f) to < 1 ulp (error of r squared)
     const double z = s * s;
     const double w = z * z;
     const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
@@ -254,7 +262,7 @@ __device__ __forceinline__ void flog_vec(const double (&c)[N], double (&x)[N]) {
         dk[i] = (double)k;
     }
 #pragma unroll
-    for (int i = 0; i < N; ++i) { f[i] = m[i] - 1.0; r[i] = frcp(2.0 + f[i]); }
+    for (int i = 0; i < N; ++i) { f[i] = m[i] - 1.0; r[i] = frcp1(2.0 + f[i]); }
 #pragma unroll
     for (int i = 0; i < N; ++i) { s[i] = f[i] * r[i]; s[i] = fma(fma(-(2.0 + f[i]), s[i], f[i]), r[i], s[i]); }
 #pragma unroll
