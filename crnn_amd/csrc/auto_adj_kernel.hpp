@@ -243,7 +243,7 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                             for (int j = 0; j < 7; ++j) a = fma(Ts5::bt(j), k[j][i], a);
                             const double ev = dt * a;
                             const double m = fmax(fabs(u[i]), fabs(unew[i]));
-                            const double e = ev * frcp(fma(kc->rtol[i], m, kc->atol[i]));
+                            const double e = ev * frcp1(fma(kc->rtol[i], m, kc->atol[i]));
                             es = fma(e, e, es);
                             finite = finite && isfinite(unew[i]) && isfinite(ev);
                         }
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                             const double k2i = k1[i] + dk[i];
                             const double ev = dt * (1.0 / 6.0) * (k1[i] - 2.0 * k2i + k3[i]);
                             const double m = fmax(fabs(u[i]), fabs(unew[i]));
-                            const double e = ev * frcp(fma(kc->rtol[i], m, kc->atol[i]));
+                            const double e = ev * frcp1(fma(kc->rtol[i], m, kc->atol[i]));
                             es = fma(e, e, es);
                             finite = finite && isfinite(unew[i]) && isfinite(ev);
                         }

@@ -286,7 +286,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                         double k2i = k1[i] + dk[i];
                         double ev = dt * (1.0 / 6.0) * (k1[i] - 2.0 * k2i + k3[i]);
                         double m = fmax(fabs(u[i]), fabs(unew[i]));
-                        double e = ev * frcp(fma(kc->rtol[i], m, kc->atol[i]));
+                        double e = ev * frcp1(fma(kc->rtol[i], m, kc->atol[i]));
                         es = fma(e, e, es);
                         finite = finite && isfinite(unew[i]) && isfinite(ev);
                     }

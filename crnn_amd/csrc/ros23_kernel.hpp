@@ -291,7 +291,7 @@ __device__ __forceinline__ void features(const double (&u)[NS], double lb, doubl
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         c[i] = fmin(fmax(u[i], lb), ub);
-        g[i] = (c[i] == u[i]) ? frcp(c[i]) : 0.0;
+        g[i] = (c[i] == u[i]) ? frcp1(c[i]) : 0.0;   // 2e-15: W is a W-method matrix and both sweeps use the same g
     }
     flog_vec<NS>(c, x);
 }
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_kernel(const SolveParams prm, con
                 double k2i = k1[i] + dk[i];
                 double ev = dt * (1.0 / 6.0) * (k1[i] - 2.0 * k2i + k3[i]);
                 double m = fmax(fabs(u[i]), fabs(unew[i]));
-                double e = ev * frcp(fma(kc->rtol[i], m, kc->atol[i]));
+                double e = ev * frcp1(fma(kc->rtol[i], m, kc->atol[i]));
                 es = fma(e, e, es);
                 finite = finite && isfinite(unew[i]) && isfinite(ev);
             }

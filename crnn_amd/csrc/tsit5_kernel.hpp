@@ -294,7 +294,7 @@ __global__ __launch_bounds__(BLOCK) void tsit5_kernel(const SolveParams prm, con
                 for (int j = 0; j < 7; ++j) a = fma(Ts5::bt(j), k[j][i], a);
                 const double ev = dt * a;
                 const double m = fmax(fabs(u[i]), fabs(unew[i]));
-                const double e = ev * frcp(fma(kc->rtol[i], m, kc->atol[i]));
+                const double e = ev * frcp1(fma(kc->rtol[i], m, kc->atol[i]));
                 es = fma(e, e, es);
                 finite = finite && isfinite(unew[i]) && isfinite(ev);
             }
