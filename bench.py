@@ -42,8 +42,8 @@ FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X FP64 vector peak (spec); 2 flop per FM
 FLOP_PRIMAL_STEP = 2 * 1480      # one Rosenbrock23 attempt: 12 log, 6 exp, 12 rcp, J, 6x6 LU, 3 solves, error norm, controller
 FLOP_COL_STEP = 2 * 441          # one tangent column through one accepted step
 # adjoint kernel: v_fma/v_mul/v_add_f64 instructions per loop body in the gfx950 ISA (tools/isa_blocks.py), x2
-FLOP_ADJ_ATTEMPT = 2 * 846       # forward sweep, one Rosenbrock23 attempt
-FLOP_ADJ_REVERSE = 2 * 755       # reverse sweep, one accepted step (re-formation 334 + adjoint 421)
+FLOP_ADJ_ATTEMPT = 2 * 808       # forward sweep, one Rosenbrock23 attempt
+FLOP_ADJ_REVERSE = 2 * 719       # reverse sweep, one accepted step (re-formation 310 + adjoint 409)
 FLOP_ADJ_SAVE = 2 * 40           # loss + seeds of one save point
 
 
