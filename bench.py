@@ -62,8 +62,8 @@ def usable_cores():
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=65536, help="initial conditions per GPU")
     ap.add_argument("--comm", choices=["rccl", "torch"], default="rccl")
     ap.add_argument("--cols", type=int, default=0, help="tangent columns per lane (0 = library default)")
