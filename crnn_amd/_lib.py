@@ -11,7 +11,7 @@ import os
 
 MAX_N = 12
 MAX_NR = 16
-ABI_VERSION = 2
+ABI_VERSION = 3
 UNIQUE_ID_BYTES = 128
 
 PMAP_IDENTITY, PMAP_CASE1, PMAP_CASE2, PMAP_ROBER, PMAP_HYCHEM = 0, 1, 2, 3, 4
@@ -24,7 +24,9 @@ GRAD_AUTO, GRAD_FORWARD, GRAD_ADJOINT = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CRNN_HIP_LIB: load another build of the same ABI (kernel experiments, tools/); the default is the in-tree library
-LIB_PATH = os.environ.get("CRNN_HIP_LIB") or os.path.join(_HERE, "csrc", "libcrnn_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+_OVERRIDE = os.environ.get("CRNN_HIP_LIB")
+LIB_PATH = _OVERRIDE or os.path.join(CSRC, "libcrnn_hip.so")
 
 
 class Config(C.Structure):
@@ -67,8 +69,10 @@ class OptConfig(C.Structure):
 _DP = C.POINTER(C.c_double)
 _IP = C.POINTER(C.c_int32)
 _CTX = C.c_void_p
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p)   # crnn_allreduce_fn
 SYMBOLS = {
     "crnn_abi_version": (C.c_int32, []),
+    "crnn_build_info": (C.c_char_p, []),
     "crnn_sizeof": (C.c_int32, [C.c_int32]),
     "crnn_last_error": (C.c_char_p, [_CTX]),
     "crnn_config_preset": (C.c_int32, [C.POINTER(Config), C.c_int32]),
@@ -76,7 +80,6 @@ SYMBOLS = {
     "crnn_config_set_solver": (C.c_int32, [C.POINTER(Config), C.c_int32]),
     "crnn_n_params": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "crnn_n_theta": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
-    "crnn_config_n_theta": (C.c_int32, [C.POINTER(Config)]),
     "crnn_config_n_theta": (C.c_int32, [C.POINTER(Config)]),
     "crnn_p2vec": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, _DP, _DP, _DP]),
     "crnn_ctx_create": (C.c_int32, [C.POINTER(Config), C.POINTER(_CTX)]),
@@ -98,12 +101,17 @@ SYMBOLS = {
     "crnn_grad_buffer": (C.c_int32, [_CTX, C.POINTER(C.c_void_p), _IP]),
     "crnn_get_params": (C.c_int32, [_CTX, _DP]),
     "crnn_set_params": (C.c_int32, [_CTX, _DP]),
+    "crnn_get_opt_state": (C.c_int32, [_CTX, _DP]),
+    "crnn_set_opt_state": (C.c_int32, [_CTX, _DP]),
+    "crnn_train_update": (C.c_int32, [_CTX, _DP]),
     "crnn_last_stats": (C.c_int32, [_CTX, C.POINTER(Stats)]),
     "crnn_kernel_times": (C.c_int32, [_CTX, _DP, C.c_int32]),
     "crnn_synchronize": (C.c_int32, [_CTX]),
     "crnn_comm_get_unique_id": (C.c_int32, [C.c_char_p]),
     "crnn_comm_init": (C.c_int32, [_CTX, C.c_char_p, C.c_int32, C.c_int32]),
     "crnn_comm_destroy": (C.c_int32, [_CTX]),
+    "crnn_comm_set_allreduce": (C.c_int32, [_CTX, ALLREDUCE_FN, C.c_void_p]),
+    "crnn_comm_collectives": (C.c_int64, [_CTX]),
     "crnn_allreduce_grad": (C.c_int32, [_CTX, _DP, C.c_int32]),
     "crnn_cathode_config_default": (C.c_int32, [C.POINTER(CathodeConfig)]),
     "crnn_cathode_create": (C.c_int32, [C.POINTER(CathodeConfig), C.POINTER(_CTX)]),
@@ -111,21 +119,54 @@ SYMBOLS = {
     "crnn_cathode_last_error": (C.c_char_p, [_CTX]),
     "crnn_cathode_set_obs": (C.c_int32, [_CTX, C.c_int32, C.c_int32, _IP, _DP, _DP, _DP, _DP]),
     "crnn_cathode_solve": (C.c_int32, [_CTX, _DP, C.c_int64, _DP, _DP, _DP, _IP, _IP, C.POINTER(Stats)]),
+    "crnn_cathode_comm_init": (C.c_int32, [_CTX, C.c_char_p, C.c_int32, C.c_int32]),
+    "crnn_cathode_comm_destroy": (C.c_int32, [_CTX]),
+    "crnn_cathode_allgather": (C.c_int32, [_CTX, _DP, C.c_int64, C.c_int32, C.c_int64, _DP]),
     "crnn_svgd_update": (C.c_int32, [C.c_int32, _DP, _DP, C.c_int64, C.c_int32, C.c_double, C.c_double, _DP,
                                      C.POINTER(C.c_double), _DP, _DP]),
 }
 
 
+def source_hash() -> str:
+    """sha256 prefix over the sorted csrc/*.hip, *.hpp and include/crnn_hip.h -- the same digest the Makefile bakes into
+    the binary (crnn_build_info) and writes to libcrnn_hip.so.srchash."""
+    import hashlib
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp")))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(CSRC, "..", "..", "include", "crnn_hip.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def ensure_built(force: bool = False) -> str:
+    """(Re)build libcrnn_hip.so when it is missing or was not compiled from the sources next to it: a binary that
+    travelled with a snapshot must never run in place of the code it travelled with.  Returns the source hash."""
+    import shutil
+    import subprocess
+    want = source_hash()
+    side = LIB_PATH + ".srchash"
+    have = open(side).read().strip() if os.path.exists(side) else None
+    if force or not os.path.exists(LIB_PATH) or have != want:
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+            raise ImportError(f"{LIB_PATH} is missing or stale (sources {want}, binary {have}) and hipcc was not found to "
+                              "rebuild it. crnn_amd has no CPU fallback.")
+        subprocess.check_call(["make", "-C", CSRC, "-B", "-s"])
+    return want
+
+
 def _load():
-    if not os.path.exists(LIB_PATH):
-        raise ImportError(
-            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(or `make -C crnn_amd/csrc`). crnn_amd has no CPU fallback.")
+    want = None if _OVERRIDE else ensure_built()      # an explicit CRNN_HIP_LIB is the caller's responsibility
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    info = lib.crnn_build_info().decode()
+    if want is not None and f"src={want} " not in info:
+        raise ImportError(f"libcrnn_hip.so was built from other sources ({info}) than those next to it (src={want}); "
+                          "rebuild with `make -C crnn_amd/csrc -B`")
     if lib.crnn_abi_version() != ABI_VERSION:
         raise ImportError(f"libcrnn_hip.so ABI {lib.crnn_abi_version()} != binding ABI {ABI_VERSION}")
     for which, cls in enumerate((Config, Stats, OptConfig, CathodeConfig)):

@@ -375,6 +375,26 @@ class NeuralODE:
         check(lib.crnn_get_params(self._ctx.h, dptr(p)), self._ctx.h)
         return p
 
+    def update_(self, grad):
+        """update!(opt, p, grad) on the device-resident p with a caller-supplied gradient (case2/case2.jl:197)."""
+        g = np.ascontiguousarray(grad, np.float64)
+        if g.shape != (self.n_params,):
+            raise ValueError(f"grad must have {self.n_params} entries")
+        check(lib.crnn_train_update(self._ctx.h, dptr(g)), self._ctx.h)
+
+    def opt_state(self):
+        """The device-resident optimiser state [m | v | beta1^t, beta2^t, eta_expdecay, ncalls]: what `@save ... opt`
+        keeps across a restart (case2/case2.jl:213)."""
+        st = np.zeros(lib.crnn_opt_state_len(self.n_params))
+        check(lib.crnn_get_opt_state(self._ctx.h, dptr(st)), self._ctx.h)
+        return st
+
+    def set_opt_state(self, state):
+        st = np.ascontiguousarray(state, np.float64)
+        if st.shape != (lib.crnn_opt_state_len(self.n_params),):
+            raise ValueError("optimiser state has the wrong length")
+        check(lib.crnn_set_opt_state(self._ctx.h, dptr(st)), self._ctx.h)
+
     def stats(self):
         st = Stats()
         check(lib.crnn_last_stats(self._ctx.h, C.byref(st)), self._ctx.h)

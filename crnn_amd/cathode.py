@@ -7,7 +7,7 @@ crnn_cathode_* entry points.
     pred_n_ode(p, i_exp, exp_data)   network.jl:196-218
     loss_neuralode(p, i_exp)         network.jl:262-275
     dlnprob(p, i_exp)                network.jl:222-260   (loss, -grad ./ Normalizer.^2 per particle)
-    svgd_kernel(svgd, p, h)          network.jl:67-87     (host, NumPy: the "next" row N3)
+    svgd_kernel + the particle move  network.jl:67-87, crnn_cathode.jl:36-50   (svgd_update: on the device)
 
 `p` are the reference's normalised particles (one row of 17 per particle), `p_scales` the deterministic optimum
 they are scaled by; the device sees theta = p .* p_scales.  Experiments (heating rates) are 0-based here.
@@ -60,31 +60,9 @@ def HRR_getter(times, u_outputs, p_hrr, *, p_scales, beta, lb_clamp=1e-16):
     return np.exp(z) @ th[9:12]
 
 
-def svgd_kernel(p, h=-1.0):
-    """RBF kernel with the median trick and its repulsion term (network.jl:67-87)."""
-    p = np.asarray(p, float)
-    d = np.sqrt(np.maximum(((p[:, None, :] - p[None, :, :]) ** 2).sum(-1), 0.0))
-    sq_dist = d[np.tril_indices(p.shape[0], -1)]
-    pairwise = d ** 2
-    if h < 0:
-        h = np.median(sq_dist) ** 2
-        h = np.sqrt(0.5 * h / np.log(p.shape[0] + 1))
-    Kxy = np.exp(-pairwise / h ** 2 / 2)
-    dxkxy = -Kxy @ p + p * Kxy.sum(axis=1, keepdims=True)
-    return Kxy, dxkxy / h ** 2
-
-
-def svgd_update(p, lnpgrad, stepsize, h=-1.0):
-    """One SVGD move (crnn_cathode.jl:36-50): p + stepsize * (Kxy * lnpgrad + dxkxy) / N.
-    Returns (p_new, data_term, repulsion)."""
-    p = np.asarray(p, float)
-    Kxy, dxkxy = svgd_kernel(p, h)
-    data_term = Kxy @ np.asarray(lnpgrad, float)
-    return p + stepsize * (data_term + dxkxy) / p.shape[0], data_term, dxkxy
-
-
-def svgd_update_device(p, lnpgrad, stepsize, h=-1.0, device=0):
-    """svgd_update on the GPU (crnn_svgd_update: exact median by radix select, fused K p / K lnpgrad rows).
+def svgd_update(p, lnpgrad, stepsize, h=-1.0, device=0):
+    """One SVGD move (svgd_kernel network.jl:67-87 + crnn_cathode.jl:36-50) on the GPU: crnn_svgd_update -- exact
+    median by radix select, fused K p / K lnpgrad rows.  Needs an MI355X (no CPU path).
     Returns (p_new, data_term, repulsion, h)."""
     p = np.ascontiguousarray(p, np.float64)
     g = np.ascontiguousarray(lnpgrad, np.float64)
@@ -173,20 +151,45 @@ class CathodeUQ:
         g = grad[:, i_exp, :] / (self.normalizer[i_exp, NORM_COL] ** 2)
         return float(loss[:, i_exp].mean()), -g
 
+    def comm_init(self):
+        """Attach the library's own RCCL communicator for the particle-shard exchange (crnn_cathode_allgather); the unique
+        id travels through the default torch.distributed group.  One process per GPU."""
+        import torch.distributed as dist
+        rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+        uid = C.create_string_buffer(L.UNIQUE_ID_BYTES)
+        if rank == 0:
+            check(lib.crnn_comm_get_unique_id(uid))
+        if world > 1:
+            obj = [uid.raw]
+            dist.broadcast_object_list(obj, src=0)
+            uid = C.create_string_buffer(obj[0], L.UNIQUE_ID_BYTES)
+        self._check(lib.crnn_cathode_comm_init(self.h, uid, rank, world))
+        self._comm = (rank, world)
+
+    def allgather(self, rows, n_total):
+        """All ranks' row blocks -> the full [n_total, width] array on every rank (ncclAllGather on the ctx stream)."""
+        rows = np.ascontiguousarray(rows, np.float64)
+        full = np.empty((n_total, rows.shape[1]))
+        self._check(lib.crnn_cathode_allgather(self.h, dptr(rows), rows.shape[0], rows.shape[1], n_total, dptr(full)))
+        return full
+
     def dlnprob_sharded(self, p, i_exp):
         """dlnprob with the particles sharded over the ranks of the default torch.distributed group (one process per
         GPU): each rank solves its contiguous block of particles, one all-gather of [loss | lnpgrad] rows follows, and
         every rank returns the full (mean loss, lnpgrad[N, 17]) -- so that the replicated SVGD update stays identical."""
-        from .dist import allgather_rows, env_rank, shard_range
+        from .dist import allgather_rows, shard_range
         import torch.distributed as dist
         p = np.atleast_2d(np.asarray(p, float))
         N = p.shape[0]
-        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        rank = dist.get_rank() if world > 1 else 0
+        if getattr(self, "_comm", None) is not None:
+            rank, world = self._comm
+        else:
+            world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+            rank = dist.get_rank() if world > 1 else 0
         first, count = shard_range(N, rank, world)
         loss, grad, _ = self.solve(p[first:first + count], want_grad=True)
         rows = np.concatenate([loss[:, i_exp:i_exp + 1], -grad[:, i_exp, :] / (self.normalizer[i_exp, NORM_COL] ** 2)], axis=1)
-        full = allgather_rows(rows, N)
+        full = self.allgather(rows, N) if getattr(self, "_comm", None) is not None else allgather_rows(rows, N)
         return float(full[:, 0].mean()), full[:, 1:]
 
     def close(self):
@@ -199,3 +202,6 @@ class CathodeUQ:
             self.close()
         except Exception:
             pass
+
+
+svgd_update_device = svgd_update

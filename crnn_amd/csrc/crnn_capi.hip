@@ -156,12 +156,30 @@ struct Ctx {
     int rank = 0, world = 1;
     double *d_comm_buf = nullptr;
     int comm_buf_len = 0;
+    crnn_allreduce_fn host_ar = nullptr;   // caller-supplied collective (crnn_comm_set_allreduce); takes precedence over comm
+    void *host_ar_user = nullptr;
+    int64_t n_collectives = 0;             // all-reduces of the reduced vector issued by the training loop (tests count them)
 };
 
 int32_t fail(Ctx *ctx, const std::string &msg) {
     g_last_error = msg;
     if (ctx) ctx->err = msg;
     return -1;
+}
+
+// The one exchange of a training step: in-place sum of d_red over the ranks, on the ctx stream.
+int32_t allreduce_red(Ctx *c) {
+    if (c->host_ar) {
+        ++c->n_collectives;
+        if (c->host_ar(c->d_red, c->last_npart, (void *)c->stream, c->host_ar_user) != 0)
+            return fail(c, "the caller's all-reduce callback (crnn_comm_set_allreduce) reported failure");
+        return 0;
+    }
+    if (c->comm) {
+        ++c->n_collectives;
+        NCCL_TRY(c, ncclAllReduce(c->d_red, c->d_red, c->last_npart, ncclDouble, ncclSum, c->comm, c->stream));
+    }
+    return 0;
 }
 
 bool shape_match(const Ctx *c, const KernelEntry &k) {
@@ -198,7 +216,7 @@ __global__ void p2vec_kernel(int pmap, int ns, int nr, int has_temp, const doubl
     if (threadIdx.x == 0) crnn::p2vec_eval(pmap, ns, nr, has_temp, p, th, dth);
 }
 
-// red = [grad_sum(P) | pad | loss_sum, n_ok, n_accept, n_reject, n_traj]
+// red = [grad_sum(P) | n_overflow | loss_sum, n_ok, n_accept, n_reject, n_traj]   (npart = P + kTail)
 // Flux chain (p2vec.hpp opt_update) with one thread per parameter; the norm clip is a fixed-order LDS tree.
 // Tail: theta, dtheta = p2vec(updated p) for the next step and zeroing of the next launch's queue head / overflow
 // counter, so that a training step is [this kernel] -> solve -> reductions.
@@ -207,9 +225,11 @@ __global__ __launch_bounds__(256) void opt_kernel(crnn::OptCfg o, int P, int npa
                                                   int nth, unsigned long long *queue, unsigned int *overflow, double *poison) {
     __shared__ double sh[256];
     const int tid = threadIdx.x;
-    // A poisoned gradient (NaN: some rank's adjoint tape overflowed) is not applied, and neither is any later step until
-    // the host has repeated the skipped ones in order (sticky flag): p, the optimiser state and theta stay as they are.
-    const bool skip = poison[0] != 0.0 || red[0] != red[0];
+    // A gradient formed while some rank's adjoint tape overflowed (summed overflow count != 0) is not applied, and neither
+    // is any later step until the host has repeated the skipped ones in order (sticky flag): p, the optimiser state and
+    // theta stay as they are.  Only the overflow count gates this: a NaN gradient from any other cause is applied and
+    // shows up in p, as it would in the reference.
+    const bool skip = poison[0] != 0.0 || red[npart - crnn::kTail] != 0.0;
     __syncthreads();
     if (skip) {
         if (tid == 0) { poison[0] = 1.0; poison[1] += 1.0; *queue = 0ULL; *overflow = 0u; }
@@ -298,6 +318,15 @@ int32_t ensure(Ctx *c, T **ptr, size_t *cap, size_t need) {
     return 0;
 }
 
+// pred buffer [n_save x n x B], zero-filled before every launch that writes it: the kernels store the saved columns only,
+// so the trailing columns of a failed / truncated trajectory read as zero (api.py predict_neuralode documents that).
+int32_t ensure_pred(Ctx *c) {
+    const size_t need = (size_t)c->cfg.n_save * c->n * c->B;
+    if (ensure(c, &c->d_pred, &c->pred_cap, need)) return -1;
+    HIP_TRY(c, hipMemsetAsync(c->d_pred, 0, sizeof(double) * need, c->stream));
+    return 0;
+}
+
 const AdjEntry *find_adjoint(const Ctx *c) {
     for (const auto &k : kAdjKernels)
         if (k.solver == c->cfg.solver && k.ns == c->cfg.ns && k.nr == c->cfg.nr && k.has_t == c->cfg.has_temp && k.use_scale == (c->use_scale ? 1 : 0))
@@ -326,7 +355,7 @@ void fill_params(Ctx *c, crnn::SolveParams &prm, int P, int64_t first, int64_t c
 int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const double *d_dtheta, int P, int64_t first,
                        int64_t count, int n_save_active, bool want_pred, bool defer) {
     const int nth = c->n_theta;
-    const int npart_th = nth + crnn::kExtra, npart = P + crnn::kExtra;
+    const int npart_th = nth + crnn::kExtra, npart = P + crnn::kTail;
     if (c->adj_occ < 1) {
         HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->adj_occ, (const void *)k->fn, kBlock, 0));
         if (c->adj_occ < 1) c->adj_occ = 1;
@@ -358,10 +387,7 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
         HIP_TRY(c, hipMalloc((void **)&c->d_red, sizeof(double) * npart));
         c->npart_max = npart;
     }
-    if (want_pred) {
-        size_t need = (size_t)c->cfg.n_save * c->n * c->B;
-        if (ensure(c, &c->d_pred, &c->pred_cap, need)) return -1;
-    }
+    if (want_pred && ensure_pred(c)) return -1;
     crnn::SolveParams prm{};
     fill_params(c, prm, P, first, count, n_save_active, want_pred);
     crnn::AdjParams adj{};
@@ -398,7 +424,7 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
     if (c->cfg.ns != 9 || c->cfg.nr != 10) return fail(c, "crnn_solve: the HyChem kernel is instantiated for ns = 9, nr = 10");
     if (!c->d_tabs || c->tabs_B != c->B) return fail(c, "crnn_solve: HyChem needs T/P tables (crnn_ctx_set_tables after crnn_ctx_set_data)");
     const int nth = c->n_theta;
-    const int npart_th = nth + crnn::kExtra, npart = P + crnn::kExtra;
+    const int npart_th = nth + crnn::kExtra, npart = P + crnn::kTail;
     using KFn = void (*)(const crnn::SolveParams, const double *, const crnn::HyParams);
     constexpr int kHyBlock = 128;   // W's factors + parked state in LDS: ~1.1 KB per lane, one 128-lane block per CU
     KFn fn = P > 0 ? (KFn)crnn::hychem_kernel<9, 10, true, kHyBlock> : (KFn)crnn::hychem_kernel<9, 10, false, kHyBlock>;
@@ -430,7 +456,7 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
         HIP_TRY(c, hipMalloc((void **)&c->d_red, sizeof(double) * npart));
         c->npart_max = npart;
     }
-    if (want_pred && ensure(c, &c->d_pred, &c->pred_cap, (size_t)c->cfg.n_save * c->n * c->B)) return -1;
+    if (want_pred && ensure_pred(c)) return -1;
     crnn::SolveParams prm{};
     fill_params(c, prm, P, first, count, n_save_active, want_pred);
     crnn::HyParams hp{};
@@ -467,7 +493,7 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
         hipLaunchKernelGGL(crnn::reduce_traj_kernel, dim3(rblk), dim3(256), 0, c->stream, c->d_gtraj, 0, c->d_loss, c->d_ret,
                            c->d_nacc, c->d_nrej, first, count, 256, c->d_partials);
         HIP_TRY(c, hipGetLastError());
-        hipLaunchKernelGGL(crnn::reduce_partials_kernel, dim3(npart), dim3(256), 0, c->stream, c->d_partials, rblk, npart, c->d_red);
+        hipLaunchKernelGGL(crnn::reduce_partials_kernel, dim3(crnn::kExtra), dim3(256), 0, c->stream, c->d_partials, rblk, 0, 0, c->d_red);
         HIP_TRY(c, hipGetLastError());
     }
     unsigned int ovf = 0;
@@ -530,7 +556,8 @@ int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int 
     const int gpw = 64 / L;
     const int waves = kBlock / 64;
     const int ppad = C > 0 ? L * C : 0;
-    const int npart = ppad + crnn::kExtra;
+    const int npart_pad = ppad + crnn::kExtra;   // per-block partial rows (padded tangent columns)
+    const int npart = P + crnn::kTail;           // the reduced vector: the common layout of every gradient path
 
     int occ = 0;
     HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k->fn, kBlock, 0));
@@ -543,17 +570,14 @@ int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int 
     // fixed-order ensemble reduction geometry: depends on count only
     const int rows_per_block = 256;
     const int rblk = (int)((count + rows_per_block - 1) / rows_per_block);
-    if (ensure(c, &c->d_partials, &c->partials_cap, (size_t)rblk * npart)) return -1;
+    if (ensure(c, &c->d_partials, &c->partials_cap, (size_t)rblk * npart_pad)) return -1;
     if (C > 0 && ensure(c, &c->d_gtraj, &c->gtraj_cap, (size_t)count * ppad)) return -1;
     if (c->npart_max < npart) {
         if (c->d_red) HIP_TRY(c, hipFree(c->d_red));
         HIP_TRY(c, hipMalloc((void **)&c->d_red, sizeof(double) * npart));
         c->npart_max = npart;
     }
-    if (want_pred) {
-        size_t need = (size_t)c->cfg.n_save * c->n * c->B;
-        if (ensure(c, &c->d_pred, &c->pred_cap, need)) return -1;
-    }
+    if (want_pred && ensure_pred(c)) return -1;
     (void)want_percase;
 
     crnn::SolveParams prm{};
@@ -572,7 +596,7 @@ int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int 
     hipLaunchKernelGGL(crnn::reduce_traj_kernel, dim3(rblk), dim3(256), 0, c->stream, c->d_gtraj, ppad, c->d_loss, c->d_ret,
                        c->d_nacc, c->d_nrej, first, count, rows_per_block, c->d_partials);
     HIP_TRY(c, hipGetLastError());
-    hipLaunchKernelGGL(crnn::reduce_partials_kernel, dim3(npart), dim3(256), 0, c->stream, c->d_partials, rblk, npart,
+    hipLaunchKernelGGL(crnn::reduce_partials_kernel, dim3(npart_pad), dim3(256), 0, c->stream, c->d_partials, rblk, ppad, P,
                        c->d_red);
     HIP_TRY(c, hipGetLastError());
     c->last_npart = npart;
@@ -613,6 +637,11 @@ struct CathCtx {
     double *d_tape = nullptr;      // adjoint step tape
     size_t tape_doubles = 0, tape_budget = 0;
     unsigned int *d_overflow = nullptr;
+    // particle-shard exchange (crnn_cathode_allgather)
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    double *d_ag_send = nullptr, *d_ag_recv = nullptr;
+    size_t ag_send_cap = 0, ag_recv_cap = 0;
 };
 int32_t cfail(CathCtx *c, const std::string &msg) {
     g_last_error = msg;
@@ -636,6 +665,13 @@ int32_t cgrow(CathCtx *c, T **p, size_t n) {
 extern "C" {
 
 int32_t crnn_abi_version(void) { return CRNN_ABI_VERSION; }
+
+#ifndef CRNN_SRC_HASH
+#define CRNN_SRC_HASH "unknown"
+#endif
+// "src=<first 16 hex digits of sha256 over the sorted csrc sources + include/crnn_hip.h> arch=gfx950": lets a host
+// check that the loaded binary was built from the sources next to it (crnn_amd/_lib.py does, and rebuilds otherwise).
+const char *crnn_build_info(void) { return "src=" CRNN_SRC_HASH " arch=gfx950"; }
 
 int32_t crnn_sizeof(int32_t which) {
     switch (which) {
@@ -1126,13 +1162,15 @@ int32_t check_pending(Ctx *c, double *loss_mean) {
     for (size_t i = steps.size() - nskip; i < steps.size() && rc == 0; ++i) {
         ++c->n_fallback;
         rc = train_begin_impl(c, steps[i].first, steps[i].count, steps[i].n_save, false);
-        if (rc == 0 && c->comm) {
-            ncclResult_t r_ = ncclAllReduce(c->d_red, c->d_red, c->last_npart, ncclDouble, ncclSum, c->comm, c->stream);
-            if (r_ != ncclSuccess) rc = fail(c, std::string("ncclAllReduce: ") + ncclGetErrorString(r_));
-        }
+        if (rc == 0) rc = allreduce_red(c);
         if (rc == 0) rc = train_end_impl(c, (i + 1 == steps.size()) ? loss_mean : nullptr);
     }
     c->force_forward = false;
+    if (rc == 0) {   // the replay runs on forward tangents, which have no tape: the flag cannot legitimately be set again
+        HIP_TRY(c, hipMemcpyAsync(poison, c->d_poison, sizeof(poison), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (poison[0] != 0.0) return fail(c, "crnn_train_step: a replayed step was skipped again (ranks disagree on the overflow count?)");
+    }
     return rc;
 }
 }  // namespace
@@ -1158,8 +1196,7 @@ int32_t crnn_train_step(crnn_ctx *ctx, int64_t first, int64_t count, int32_t n_s
     if (c->pending.size() >= kMaxPending && check_pending(c, nullptr)) return -1;
     if (train_begin_impl(c, first, count, n_save_active, true)) return -1;
     if (c->last_deferred) c->pending.push_back({first, count, n_save_active});
-    if (c->comm)
-        NCCL_TRY(c, ncclAllReduce(c->d_red, c->d_red, c->last_npart, ncclDouble, ncclSum, c->comm, c->stream));
+    if (allreduce_red(c)) return -1;
     if (train_end_impl(c, loss_mean)) return -1;
     if (loss_mean) return check_pending(c, loss_mean);   // the caller wants this step's loss: look now
     return 0;
@@ -1193,6 +1230,51 @@ int32_t crnn_set_params(crnn_ctx *ctx, const double *p) {
     HIP_TRY(c, hipMemcpyAsync(c->d_p, p, sizeof(double) * c->n_params, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return 0;
+}
+
+int32_t crnn_get_opt_state(crnn_ctx *ctx, double *state) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c || !state) return fail(c, "crnn_get_opt_state: null");
+    if (!c->train_ready) return fail(c, "crnn_get_opt_state: call crnn_train_init first");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (check_pending(c, nullptr)) return -1;
+    HIP_TRY(c, hipMemcpyAsync(state, c->d_opt, sizeof(double) * (2 * c->n_params + 4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int32_t crnn_set_opt_state(crnn_ctx *ctx, const double *state) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c || !state) return fail(c, "crnn_set_opt_state: null");
+    if (!c->train_ready) return fail(c, "crnn_set_opt_state: call crnn_train_init first");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (check_pending(c, nullptr)) return -1;
+    HIP_TRY(c, hipMemcpyAsync(c->d_opt, state, sizeof(double) * (2 * c->n_params + 4), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int32_t crnn_train_update(crnn_ctx *ctx, const double *grad) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c || !grad) return fail(c, "crnn_train_update: null");
+    if (!c->train_ready) return fail(c, "crnn_train_update: call crnn_train_init first");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (check_pending(c, nullptr)) return -1;
+    const int P = c->n_params, npart = P + crnn::kTail;
+    if (c->npart_max < npart) {
+        if (c->d_red) HIP_TRY(c, hipFree(c->d_red));
+        c->d_red = nullptr;
+        HIP_TRY(c, hipMalloc((void **)&c->d_red, sizeof(double) * npart));
+        c->npart_max = npart;
+    }
+    std::vector<double> red(npart, 0.0);
+    for (int k = 0; k < P; ++k) red[k] = grad[k];
+    red[npart - 1] = 1.0;   // n_traj = 1: the gradient is applied as given
+    HIP_TRY(c, hipMemcpyAsync(c->d_red, red.data(), sizeof(double) * npart, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // red is a stack-lifetime vector
+    c->last_npart = npart;
+    c->last_P = P;
+    return train_end_impl(c, nullptr);
 }
 
 int32_t crnn_last_stats(crnn_ctx *ctx, crnn_stats *stats) {
@@ -1249,6 +1331,20 @@ int32_t crnn_comm_init(crnn_ctx *ctx, const char id[CRNN_UNIQUE_ID_BYTES], int32
     c->rank = rank;
     c->world = world;
     return 0;
+}
+
+int32_t crnn_comm_set_allreduce(crnn_ctx *ctx, crnn_allreduce_fn fn, void *user) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return fail(nullptr, "null ctx");
+    if (check_pending(c, nullptr)) return -1;
+    c->host_ar = fn;
+    c->host_ar_user = user;
+    return 0;
+}
+
+int64_t crnn_comm_collectives(crnn_ctx *ctx) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    return c ? c->n_collectives : -1;
 }
 
 int32_t crnn_comm_destroy(crnn_ctx *ctx) {
@@ -1320,8 +1416,9 @@ void crnn_cathode_destroy(crnn_cathode_ctx *ctx) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
     void *ptrs[] = {c->d_ts, c->d_dbar, c->d_d2bar, c->d_beta, c->d_D, c->d_queue, c->d_theta, c->d_loss, c->d_grad,
-                    c->d_hrr, c->d_ret, c->d_nsv, c->d_nacc, c->d_nrej, c->d_tape, c->d_overflow};
+                    c->d_hrr, c->d_ret, c->d_nsv, c->d_nacc, c->d_nrej, c->d_tape, c->d_overflow, c->d_ag_send, c->d_ag_recv};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1465,6 +1562,57 @@ int32_t crnn_cathode_solve(crnn_cathode_ctx *ctx, const double *theta, int64_t n
     return 0;
 }
 
+
+// ---- particle-shard exchange of the Bayesian ensemble: the particles are sharded over the ranks, every
+// rank needs all rows of [loss | lnpgrad] for the replicated SVGD move that follows dlnprob (crnn_cathode.jl:31,36-50).
+int32_t crnn_cathode_comm_init(crnn_cathode_ctx *ctx, const char id[CRNN_UNIQUE_ID_BYTES], int32_t rank, int32_t world) {
+    CathCtx *c = reinterpret_cast<CathCtx *>(ctx);
+    if (!c) return cfail(nullptr, "null ctx");
+    if (!id || world < 1 || rank < 0 || rank >= world) return cfail(c, "crnn_cathode_comm_init: bad id/rank/world");
+    CHIP(c, hipSetDevice(c->cfg.device));
+    if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    ncclResult_t r = ncclCommInitRank(&c->comm, world, uid, rank);
+    if (r != ncclSuccess) return cfail(c, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+    c->rank = rank;
+    c->world = world;
+    return 0;
+}
+
+int32_t crnn_cathode_comm_destroy(crnn_cathode_ctx *ctx) {
+    CathCtx *c = reinterpret_cast<CathCtx *>(ctx);
+    if (!c) return cfail(nullptr, "null ctx");
+    if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+    c->rank = 0; c->world = 1;
+    return 0;
+}
+
+int32_t crnn_cathode_allgather(crnn_cathode_ctx *ctx, const double *local, int64_t n_local, int32_t width, int64_t n_total,
+                               double *full) {
+    CathCtx *c = reinterpret_cast<CathCtx *>(ctx);
+    if (!c) return cfail(nullptr, "null ctx");
+    if (!local || !full || width < 1 || n_total < 1) return cfail(c, "crnn_cathode_allgather: bad arguments");
+    const int world = c->comm ? c->world : 1, rank = c->comm ? c->rank : 0;
+    const int64_t base = n_total / world, rem = n_total % world;
+    auto first_of = [&](int r) { return (int64_t)r * base + std::min<int64_t>(r, rem); };
+    auto count_of = [&](int r) { return base + (r < rem ? 1 : 0); };
+    if (n_local != count_of(rank)) return cfail(c, "crnn_cathode_allgather: this rank's block must hold rows [first, first+count) of the contiguous partition");
+    if (world == 1) { std::memcpy(full, local, sizeof(double) * (size_t)n_total * width); return 0; }
+    CHIP(c, hipSetDevice(c->cfg.device));
+    const size_t blk = (size_t)(base + (rem ? 1 : 0)) * width;    // equal, padded block per rank (ncclAllGather wants equal counts)
+    if (c->ag_send_cap < blk) { if (cgrow(c, &c->d_ag_send, blk)) return -1; c->ag_send_cap = blk; }
+    if (c->ag_recv_cap < blk * world) { if (cgrow(c, &c->d_ag_recv, blk * world)) return -1; c->ag_recv_cap = blk * world; }
+    CHIP(c, hipMemsetAsync(c->d_ag_send, 0, sizeof(double) * blk, c->stream));
+    CHIP(c, hipMemcpyAsync(c->d_ag_send, local, sizeof(double) * (size_t)n_local * width, hipMemcpyHostToDevice, c->stream));
+    ncclResult_t r = ncclAllGather(c->d_ag_send, c->d_ag_recv, blk, ncclDouble, c->comm, c->stream);
+    if (r != ncclSuccess) return cfail(c, std::string("ncclAllGather: ") + ncclGetErrorString(r));
+    for (int q = 0; q < world; ++q)
+        CHIP(c, hipMemcpyAsync(full + (size_t)first_of(q) * width, c->d_ag_recv + (size_t)q * blk,
+                               sizeof(double) * (size_t)count_of(q) * width, hipMemcpyDeviceToHost, c->stream));
+    CHIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
 
 // ============================================================================ SVGD move (stateless)
 int32_t crnn_svgd_update(int32_t device, const double *p, const double *lnpgrad, int64_t N, int32_t dim, double stepsize,

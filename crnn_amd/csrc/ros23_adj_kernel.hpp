@@ -673,7 +673,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
 
 // Fixed-order reduction of the per-block partials (theta space) followed by the chain rule through p2vec:
 //   red_theta[m] = sum_blk partials[blk][m]   (m < nth + kExtra; the order over blk is fixed)
-//   out = [ dtheta[k,:] . red_theta[0:nth], k < P | extras ]
+//   out = [ dtheta[k,:] . red_theta[0:nth], k < P | n_overflow | extras ]      (the common layout, ros23_kernel.hpp kTail)
 // One block; nth + kExtra <= 256.
 __global__ __launch_bounds__(1024) void reduce_project_kernel(const double *__restrict__ partials, int nblk,
                                                               const double *__restrict__ dtheta, int nth, int P,
@@ -707,16 +707,18 @@ __global__ __launch_bounds__(1024) void reduce_project_kernel(const double *__re
         }
         __syncthreads();
     }
-    // A trajectory that outran its tape makes this launch's gradient unusable: it is poisoned with NaN so that every
-    // consumer -- the optimiser kernel of this rank and, through the all-reduce, of every other rank -- skips it in the same
-    // way; the host repeats the step with forward tangents when it next looks (crnn_capi.hip: check_pending).
-    const bool bad = overflow && *overflow != 0;
+    // A trajectory that outran its tape makes this launch's gradient unusable.  The count travels with the gradient
+    // (slot P) -- through the all-reduce to every rank -- and the optimiser kernel of every rank skips a step whose
+    // summed count is not zero in the same way; the host repeats the step with forward tangents when it next looks
+    // (crnn_capi.hip: check_pending).  A NaN gradient from any other cause is NOT intercepted: it reaches p, as it
+    // would in the reference.
     for (int k = tid; k < P; k += 1024) {
         double a = 0.0;
         for (int m = 0; m < nth; ++m) a = fma(dtheta[(size_t)k * nth + m], sh[m], a);
-        out[k] = bad ? __longlong_as_double(0x7ff8000000000000LL) : a;
+        out[k] = a;
     }
-    if (tid < kExtra) out[P + tid] = sh[nth + tid];
+    if (tid == 0) out[P] = overflow ? (double)*overflow : 0.0;
+    if (tid < kExtra) out[P + 1 + tid] = sh[nth + tid];
 }
 
 }  // namespace crnn

@@ -47,6 +47,10 @@ namespace crnn {
 constexpr int kMaxN = 12;
 constexpr int kMaxSave = 256;  // max saveat points (LDS-staged)
 constexpr int kExtra = 5;  // loss_sum, n_ok, n_accept, n_reject, n_traj
+// The reduced vector every gradient path leaves in Ctx::d_red -- and the ranks all-reduce -- has ONE layout:
+//   [ grad_sum(P) | n_overflow | loss_sum, n_ok, n_accept, n_reject, n_traj ]      (P + kTail doubles)
+// n_overflow = trajectories that outran the adjoint tape in this launch (0 on the forward-tangent paths).
+constexpr int kTail = kExtra + 1;
 
 // Problem constants: one copy in device memory, staged to LDS by every block.
 struct KConst {
@@ -1098,12 +1102,17 @@ __global__ __launch_bounds__(256) void transpose_data_kernel(const double *__res
     }
 }
 
-// Fixed-order reduction of the per-block partials: out[k] = sum_blk partials[blk][k].
+// Fixed-order reduction of the per-block partials: sum_blk partials[blk][k], written in the common layout
+// [grad(P) | n_overflow = 0 | extras]: of the ppad = L*C gradient columns only the first P are real directions.
 // One block per column, 256 threads: strided serial sums then an LDS tree.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__restrict__ partials, int nblk, int npart,
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__restrict__ partials, int nblk, int ppad, int P,
                                                               double *__restrict__ out) {
     __shared__ double sh[256];
     const int k = blockIdx.x;
+    const int npart = ppad + kExtra;
+    if (k >= P && k < ppad) return;              // padding column (block-uniform)
+    const int dst = k < P ? k : P + 1 + (k - ppad);
+    if (k == ppad && threadIdx.x == 0) out[P] = 0.0;
     double a = 0.0;
     for (int bI = threadIdx.x; bI < nblk; bI += 256) a += partials[(size_t)bI * npart + k];
     sh[threadIdx.x] = a;
@@ -1112,7 +1121,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__re
         if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[k] = sh[0];
+    if (threadIdx.x == 0) out[dst] = sh[0];
 }
 
 }  // namespace crnn

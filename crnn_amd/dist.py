@@ -4,10 +4,13 @@ The reference has no parallelism at all; the only natural shard
 axis of the hot path is the IC axis: trajectories are independent given the
 weights.  One process per GPU; each rank owns a contiguous block of ICs that
 never moves; per optimiser step the ranks exchange exactly one small vector
-    [ sum_b d loss_b / d p  |  pad  | loss_sum, n_ok, n_accept, n_reject, n_traj ]
+    [ sum_b d loss_b / d p  |  n_overflow  | loss_sum, n_ok, n_accept, n_reject, n_traj ]      (P + 6 doubles)
 with one all-reduce (RCCL over xGMI: in-library ncclAllReduce on the ctx stream,
-or torch.distributed on the same buffer) and then apply the identical,
-deterministic optimiser update on every rank (no broadcast needed).
+torch.distributed on the same buffer, or a caller-supplied collective) and then
+apply the identical, deterministic optimiser update on every rank (no broadcast
+needed).  The layout is the same whichever gradient algorithm a rank used, so a
+rank that fell back from the adjoint to forward tangents still sums correctly;
+n_overflow != 0 after the sum makes EVERY rank skip the step and replay it.
 """
 from __future__ import annotations
 
@@ -67,8 +70,12 @@ class DataParallel:
 
     comm="rccl": the library's own communicator (crnn_comm_init; the unique id
     is broadcast through torch.distributed).  comm="torch": torch.distributed
-    all_reduce (backend nccl == RCCL) on the library's gradient buffer, with the
-    ctx bound to torch's current stream.
+    all_reduce (backend nccl == RCCL) on the library's gradient buffer between
+    crnn_train_step_begin / _end, with the ctx bound to torch's current stream.
+    comm="callback": the fused crnn_train_step (steps enqueued back to back, the
+    tape-overflow outcome looked at later) with torch.distributed's all_reduce
+    handed to the library as its collective (crnn_comm_set_allreduce); works on
+    any backend -- on gloo the 248-byte vector goes through the host.
     """
 
     def __init__(self, node, comm: str = "rccl"):
@@ -86,15 +93,35 @@ class DataParallel:
                 dist.broadcast_object_list(obj, src=0)
                 uid = C.create_string_buffer(obj[0], L.UNIQUE_ID_BYTES)
             check(lib.crnn_comm_init(node.handle, uid, self.rank, self.world), node.handle)
-        elif comm == "torch":
+        elif comm in ("torch", "callback"):
             stream = torch.cuda.current_stream().cuda_stream
             check(lib.crnn_ctx_set_stream(node.handle, C.c_void_p(stream)), node.handle)
+            if comm == "callback":
+                on_host = dist.is_initialized() and dist.get_backend() == "gloo"
+
+                def _allreduce(d_buf, n, _stream, _user):
+                    try:
+                        if self.world > 1:
+                            t = torch.as_tensor(_DevView(d_buf, n), device="cuda")
+                            if on_host:
+                                h = t.cpu()                       # orders after the solve on the (shared) current stream
+                                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                                t.copy_(h)
+                            else:
+                                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                        return 0
+                    except Exception as exc:                      # never unwind through the C frame
+                        print(f"crnn_amd.dist: all-reduce callback failed: {exc!r}", flush=True)
+                        return 1
+
+                self._cb = L.ALLREDUCE_FN(_allreduce)             # keep the trampoline alive as long as the ctx may call it
+                check(lib.crnn_comm_set_allreduce(node.handle, self._cb, None), node.handle)
         else:
-            raise ValueError("comm must be 'rccl' or 'torch'")
+            raise ValueError("comm must be 'rccl', 'torch' or 'callback'")
 
     def train_step(self, first=0, count=None, sample=None, want_loss=False):
         node = self.node
-        if self.comm == "rccl":
+        if self.comm in ("rccl", "callback"):
             return node.train_step(first, count, sample, want_loss)
         count = node.B - first if count is None else count
         sample = node.D if sample is None else int(sample)
@@ -122,9 +149,15 @@ class DataParallel:
             self._dist.all_reduce(t)
         return bool(np.array_equal(t.cpu().numpy(), want))
 
+    def collectives(self) -> int:
+        """All-reduces the library's training loop has issued on this rank (rccl / callback modes)."""
+        return int(lib.crnn_comm_collectives(self.node.handle))
+
     def close(self):
         if self.comm == "rccl":
             lib.crnn_comm_destroy(self.node.handle)
+        elif self.comm == "callback":
+            lib.crnn_comm_set_allreduce(self.node.handle, L.ALLREDUCE_FN(), None)
 
 
 def allgather_rows(local: np.ndarray, n_total: int, group=None) -> np.ndarray:
@@ -144,10 +177,13 @@ def allgather_rows(local: np.ndarray, n_total: int, group=None) -> np.ndarray:
     cmax = -(-n_total // world)
     pad = np.zeros((cmax,) + local.shape[1:], dtype=np.float64)
     pad[:count] = local
-    outs = [torch.zeros(pad.shape, dtype=torch.float64) for _ in range(world)]
-    dist.all_gather(outs, torch.from_numpy(pad), group=group)
+    # nccl (== RCCL) moves device tensors only; gloo moves host tensors
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    send = torch.from_numpy(pad).to(dev)
+    outs = [torch.zeros(pad.shape, dtype=torch.float64, device=dev) for _ in range(world)]
+    dist.all_gather(outs, send, group=group)
     full = np.empty((n_total,) + local.shape[1:], dtype=np.float64)
     for r in range(world):
         f, c = shard_range(n_total, r, world)
-        full[f:f + c] = outs[r].numpy()[:c]
+        full[f:f + c] = outs[r].cpu().numpy()[:c]
     return full

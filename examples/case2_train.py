@@ -46,16 +46,20 @@ def main():
     node = NeuralODE(ODEProblem(PRESET_CASE2, ts))
     node.set_ensemble(u0, data, yscale)
     p = cases.case2_init_p(rng)
-    l_train, l_val, it0 = [], [], 1
+    l_train, l_val, it0, opt_state = [], [], 1, None
     if args.restart and os.path.exists(args.checkpoint):
         ck = load_checkpoint(args.checkpoint)
         p, l_train, l_val, it0 = ck["p"], list(ck["l_loss_train"]), list(ck["l_loss_val"]), int(ck["iter"]) + 1
+        opt_state = ck.get("opt_state")                    # `@load ... opt`: ADAM moments, beta powers, ExpDecay eta / counter
         print(f"restarting from {args.checkpoint} at epoch {it0}")
     node.train_init(Optimiser(25, PRESET_CASE2), p)        # p and the optimiser state live on the GPU from here on
+    if opt_state is not None:
+        node.set_opt_state(opt_state)
 
     for epoch in range(it0, args.epochs + 1):
         if args.mode == "reference":
-            for i_exp in rng.permutation(n_train):          # update!(opt, p, gradient of experiment i_exp)
+            order = np.random.Generator(np.random.PCG64([args.seed, epoch])).permutation(n_train)   # randperm(n_exp_train), per epoch
+            for i_exp in order:                             # update!(opt, p, gradient of experiment i_exp)
                 node.train_step(first=int(i_exp), count=1, want_loss=False)
         else:
             node.train_step(first=0, count=n_train, want_loss=False)
@@ -65,7 +69,8 @@ def main():
         l_train.append(lt); l_val.append(lv)
         print(f"epoch {epoch:4d}  loss train {lt:.3e}  val {lv:.3e}", flush=True)
         if epoch % args.n_plot == 0 or epoch == args.epochs:
-            save_checkpoint(args.checkpoint, p=p, l_loss_train=np.array(l_train), l_loss_val=np.array(l_val), iter=epoch)
+            save_checkpoint(args.checkpoint, p=p, opt_state=node.opt_state(), l_loss_train=np.array(l_train),
+                            l_loss_val=np.array(l_val), iter=epoch)
     node.close()
     return l_train
 

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CRNN_ABI_VERSION 2
+#define CRNN_ABI_VERSION 3
 #define CRNN_MAX_N 12   /* max ODE states  */
 #define CRNN_MAX_NR 16  /* max reactions   */
 
@@ -133,6 +133,9 @@ typedef struct crnn_opt_config {
 typedef struct crnn_ctx crnn_ctx;
 
 int32_t crnn_abi_version(void);
+/* "src=<16 hex digits> arch=gfx950": sha256 prefix of the sources (the sorted .hip and .hpp files of crnn_amd/csrc, then this header)
+ * the loaded binary was compiled from -- a host can refuse (or rebuild) a stale library (crnn_amd/_lib.py does). */
+const char *crnn_build_info(void);
 /* sizeof(crnn_config) / crnn_stats / crnn_opt_config / crnn_cathode_config for which = 0 / 1 / 2 / 3: lets a binding
  * (Julia struct, ctypes.Structure) verify its mirror of the C structs at load time. */
 int32_t crnn_sizeof(int32_t which);
@@ -219,10 +222,19 @@ int32_t crnn_train_step(crnn_ctx *ctx, int64_t first, int64_t count, int32_t n_s
  * (e.g. torch.distributed) on crnn_grad_buffer() between them. */
 int32_t crnn_train_step_begin(crnn_ctx *ctx, int64_t first, int64_t count, int32_t n_save_active);
 int32_t crnn_train_step_end(crnn_ctx *ctx, double *loss_mean);
-/* device vector [grad_sum(P) | pad | loss_sum, n_ok, n_accept, n_reject, n_traj] of the step in flight */
+/* device vector [grad_sum(P) | n_overflow | loss_sum, n_ok, n_accept, n_reject, n_traj] of the step in flight: P + 6 doubles,
+ * the same layout whichever gradient algorithm produced it (also after a rank-local fall-back from the adjoint to forward
+ * tangents), so ranks can always sum it element-wise.  n_overflow = trajectories that outran the adjoint tape. */
 int32_t crnn_grad_buffer(crnn_ctx *ctx, void **d_ptr, int32_t *n_doubles);
 int32_t crnn_get_params(crnn_ctx *ctx, double *p);
 int32_t crnn_set_params(crnn_ctx *ctx, const double *p);
+/* The device-resident optimiser state [m(P) | v(P) | beta1^t, beta2^t, eta_expdecay, ncalls] (crnn_opt_state_len doubles):
+ * what the reference's `@save ... p opt ...` / `@load` keeps across a restart (case2/case2.jl:178-187,213). */
+int32_t crnn_get_opt_state(crnn_ctx *ctx, double *state);
+int32_t crnn_set_opt_state(crnn_ctx *ctx, const double *state);
+/* update!(opt, p, grad) on the device with a caller-supplied gradient [n_params] (case2/case2.jl:197): the same optimiser
+ * kernel crnn_train_step ends with. */
+int32_t crnn_train_update(crnn_ctx *ctx, const double *grad);
 int32_t crnn_last_stats(crnn_ctx *ctx, crnn_stats *stats); /* of the most recent solve; synchronises */
 /* HIP-event durations (ms) of the solve kernel of the last n launches (n <= 64), oldest first;
  * synchronises the ctx stream.  The measurement bench.py's roofline figures come from. */
@@ -234,6 +246,13 @@ int32_t crnn_synchronize(crnn_ctx *ctx);
 int32_t crnn_comm_get_unique_id(char id[CRNN_UNIQUE_ID_BYTES]);           /* rank 0, then broadcast */
 int32_t crnn_comm_init(crnn_ctx *ctx, const char id[CRNN_UNIQUE_ID_BYTES], int32_t rank, int32_t world);
 int32_t crnn_comm_destroy(crnn_ctx *ctx);
+/* A host that owns the process group (Julia MPI.jl, torch.distributed ...) can supply the collective instead: fn must
+ * sum d_buf[0..n) (device doubles) in place over all ranks, ordered after the work already enqueued on hip_stream, and
+ * return 0.  Used by crnn_train_step (also for its deferred replays) in place of the library's ncclAllReduce. */
+typedef int32_t (*crnn_allreduce_fn)(void *d_buf, int32_t n, void *hip_stream, void *user);
+int32_t crnn_comm_set_allreduce(crnn_ctx *ctx, crnn_allreduce_fn fn, void *user);
+/* number of all-reduces the training loop has issued on this ctx (every rank must report the same number) */
+int64_t crnn_comm_collectives(crnn_ctx *ctx);
 /* In-place sum of a host vector over all ranks (gradient | loss | count). */
 int32_t crnn_allreduce_grad(crnn_ctx *ctx, double *buf, int32_t n);
 
@@ -274,6 +293,15 @@ int32_t crnn_cathode_set_obs(crnn_cathode_ctx *ctx, int32_t n_sets, int32_t Dmax
  * retcode, n_saved [n_part*n_sets] or NULL */
 int32_t crnn_cathode_solve(crnn_cathode_ctx *ctx, const double *theta, int64_t n_part, double *loss, double *grad,
                            double *hrr, int32_t *retcode, int32_t *n_saved, crnn_stats *stats);
+
+/* Particle-shard exchange (after dlnprob, crnn_cathode.jl:31): the N particles are partitioned contiguously over
+ * the ranks (the first N % world ranks hold one more); every rank passes its rows [n_local x width] (e.g. [loss | lnpgrad],
+ * width 18) and receives all N rows in `full` -- one ncclAllGather on the ctx stream.  Without a communicator
+ * (single process) n_local must equal n_total and the rows are copied. */
+int32_t crnn_cathode_comm_init(crnn_cathode_ctx *ctx, const char id[CRNN_UNIQUE_ID_BYTES], int32_t rank, int32_t world);
+int32_t crnn_cathode_comm_destroy(crnn_cathode_ctx *ctx);
+int32_t crnn_cathode_allgather(crnn_cathode_ctx *ctx, const double *local, int64_t n_local, int32_t width, int64_t n_total,
+                               double *full);
 
 /* The SVGD move that follows dlnprob (Cathode_NCM333_UQ/src_333/network.jl:67-87 svgd_kernel, crnn_cathode.jl:36-50):
  *   d_ij = |p_i - p_j|; h < 0: h = sqrt(0.5 median(d_ij, i > j)^2 / log(N + 1)); K = exp(-d^2 / (2 h^2));

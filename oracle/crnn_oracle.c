@@ -1743,3 +1743,67 @@ int orc_hychem_solve_one(const orc_hychem *c, const double *th, const double *dt
     free(W); free(Jk); free(thk); free(ws); free(g);
     return retcode;
 }
+
+/* ======================================================================== */
+/* SVGD move of the Bayesian cathode ensemble.  TEST INFRASTRUCTURE.        */
+/*   svgd_kernel   Cathode_NCM333_UQ/src_333/network.jl:67-87               */
+/*   update        Cathode_NCM333_UQ/src_333/crnn_cathode.jl:36-50          */
+/* p, lnpgrad, p_new, data_term, repulsion: [N x dim] row-major.            */
+/* Scalar loops, dense N x N matrices, qsort for the median (Julia's        */
+/* `median` of an even-length vector is the mean of the middle pair).       */
+/* ======================================================================== */
+static int svgd_cmp_double(const void *a, const void *b) {
+    const double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+
+int orc_svgd_update(const double *p, const double *lnpgrad, int N, int dim, double stepsize, double h,
+                    double *p_new, double *h_out, double *data_term /* may be NULL */, double *repulsion /* may be NULL */) {
+    if (N < 2 || dim < 1) return -1;
+    double *dist = (double *)malloc(sizeof(double) * (size_t)N * N);           /* pairwise(Euclidean(), p, dims=1)   :68 */
+    double *K = (double *)malloc(sizeof(double) * (size_t)N * N);
+    double *dxk = (double *)malloc(sizeof(double) * (size_t)N * dim);
+    double *dat = (double *)malloc(sizeof(double) * (size_t)N * dim);
+    if (!dist || !K || !dxk || !dat) { free(dist); free(K); free(dxk); free(dat); return -2; }
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < dim; ++k) { const double d = p[(size_t)i * dim + k] - p[(size_t)j * dim + k]; s += d * d; }
+            dist[(size_t)i * N + j] = sqrt(s);
+        }
+    if (h < 0) {                                                                /* median trick                      :72-75 */
+        const size_t npairs = (size_t)N * (N - 1) / 2;
+        double *low = (double *)malloc(sizeof(double) * npairs);               /* strictly lower triangle           :69 */
+        if (!low) { free(dist); free(K); free(dxk); free(dat); return -2; }
+        size_t q = 0;
+        for (int j = 0; j < N; ++j) for (int i = j + 1; i < N; ++i) low[q++] = dist[(size_t)i * N + j];
+        qsort(low, npairs, sizeof(double), svgd_cmp_double);
+        const double med = (npairs & 1) ? low[npairs / 2] : 0.5 * (low[npairs / 2 - 1] + low[npairs / 2]);
+        free(low);
+        h = med * med;
+        h = sqrt(0.5 * h / log((double)N + 1.0));
+    }
+    if (h_out) *h_out = h;
+    for (size_t q = 0; q < (size_t)N * N; ++q) K[q] = exp(-(dist[q] * dist[q]) / (h * h) / 2.0);   /* Kxy       :77 */
+    for (int i = 0; i < N; ++i) {
+        double sumk = 0.0;                                                      /* sum(Kxy, dims=2)                 :80 */
+        for (int j = 0; j < N; ++j) sumk += K[(size_t)i * N + j];
+        for (int k = 0; k < dim; ++k) {
+            double kp = 0.0, kg = 0.0;
+            for (int j = 0; j < N; ++j) {
+                kp += K[(size_t)i * N + j] * p[(size_t)j * dim + k];             /* Kxy * p                          :79 */
+                kg += K[(size_t)i * N + j] * lnpgrad[(size_t)j * dim + k];       /* kxy * lnpgrad   crnn_cathode.jl:41 */
+            }
+            dxk[(size_t)i * dim + k] = (-kp + p[(size_t)i * dim + k] * sumk) / (h * h);   /* :82-85 */
+            dat[(size_t)i * dim + k] = kg;
+        }
+    }
+    for (size_t q = 0; q < (size_t)N * dim; ++q) {
+        const double gcur = (dat[q] + dxk[q]) / (double)N;                       /* grad_p_curr     crnn_cathode.jl:43 */
+        p_new[q] = p[q] + stepsize * gcur;                                       /*                 crnn_cathode.jl:49 */
+        if (data_term) data_term[q] = dat[q];
+        if (repulsion) repulsion[q] = dxk[q];
+    }
+    free(dist); free(K); free(dxk); free(dat);
+    return 0;
+}

@@ -358,3 +358,17 @@ def hychem_solve_one(c, theta, u0, ts, Ttab, Ptab, data, dtheta=None, sample=Non
                                     _dp(np.ascontiguousarray(data, float)), _dp(pred), C.byref(loss), _dp(grad),
                                     C.byref(nsv), C.cast(st, C.c_void_p))
     return dict(loss=loss.value, grad=grad[:ndir], pred=pred, retcode=rc, n_saved=nsv.value, naccept=st[0], nreject=st[1])
+
+
+def svgd_update(p, lnpgrad, stepsize, h=-1.0):
+    """SVGD move (network.jl:67-87 svgd_kernel + crnn_cathode.jl:36-50), scalar C loops.
+    Returns (p_new, data_term, repulsion, h_used)."""
+    p = np.ascontiguousarray(p, float)
+    g = np.ascontiguousarray(lnpgrad, float)
+    assert p.ndim == 2 and g.shape == p.shape
+    pn, dt, rp = np.empty_like(p), np.empty_like(p), np.empty_like(p)
+    hout = C.c_double(0.0)
+    rc = lib().orc_svgd_update(_dp(p), _dp(g), C.c_int(p.shape[0]), C.c_int(p.shape[1]), C.c_double(stepsize),
+                               C.c_double(h), _dp(pn), C.byref(hout), _dp(dt), _dp(rp))
+    assert rc == 0, rc
+    return pn, dt, rp, hout.value

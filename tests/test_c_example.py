@@ -57,4 +57,15 @@ def test_reference_style_training_script_with_checkpoint_restart(tmp_path):
     b = subprocess.run(cmd + ["--epochs", "10", "--restart"], capture_output=True, text=True, timeout=600)
     assert b.returncode == 0, b.stderr[-2000:]
     assert "restarting from" in b.stdout and len([ln for ln in b.stdout.splitlines() if ln.startswith("epoch")]) == 2
-    assert int(load_checkpoint(ck)["iter"]) == 10
+    r = load_checkpoint(ck)
+    assert int(r["iter"]) == 10 and r["opt_state"].shape == (2 * 25 + 4,)
+    # `@save ... p opt` / `@load`: the restart restores the optimiser state (ADAM moments, beta powers, ExpDecay counter),
+    # so the resumed run ends exactly where an uninterrupted one does (case2/case2.jl:178-187,213)
+    ck2 = str(tmp_path / "straight.bson")
+    cmd2 = [sys.executable, os.path.join(ROOT, "examples", "case2_train.py"), "--checkpoint", ck2, "--n-plot", "100"]
+    s = subprocess.run(cmd2 + ["--epochs", "10"], capture_output=True, text=True, timeout=600)
+    assert s.returncode == 0, s.stderr[-2000:]
+    u = load_checkpoint(ck2)
+    import numpy as np
+    assert np.array_equal(u["p"], r["p"]) and np.array_equal(u["opt_state"], r["opt_state"])
+    assert r["opt_state"][2 * 25 + 3] == 10 * 20          # ExpDecay's call counter: one update per experiment per epoch

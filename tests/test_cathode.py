@@ -79,50 +79,45 @@ def test_host_crnn_and_hrr_match_oracle_rhs(orc, cfx):
             assert np.max(np.abs(du - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
 
 
-def test_svgd_kernel_properties():
-    from crnn_amd.cathode import svgd_kernel
-    rng = np.random.default_rng(0)
-    p = rng.standard_normal((7, 17))
-    K, dK = svgd_kernel(p)
-    assert np.allclose(K, K.T) and np.allclose(np.diag(K), 1.0)
-    assert np.allclose(dK.sum(axis=0), 0.0, atol=1e-12)          # repulsion is antisymmetric in total
-    d = np.sqrt(((p[:, None] - p[None]) ** 2).sum(-1))
-    h = np.sqrt(0.5 * np.median(d[np.tril_indices(7, -1)]) ** 2 / np.log(8))
-    assert np.allclose(K, np.exp(-d ** 2 / h ** 2 / 2))
-
-
-def test_svgd_update_matches_reference_formulas():
-    """svgd_update = crnn_cathode.jl:36-50 written out with explicit loops."""
-    from crnn_amd.cathode import svgd_update
-    rng = np.random.default_rng(1)
-    N, dim = 9, 17
-    p = 1 + 0.1 * rng.standard_normal((N, dim)); g = rng.standard_normal((N, dim))
-    d = np.array([[np.sqrt(np.sum((p[i] - p[j]) ** 2)) for j in range(N)] for i in range(N)])
-    h = np.sqrt(0.5 * np.median([d[i, j] for i in range(N) for j in range(i)]) ** 2 / np.log(N + 1))
-    K = np.exp(-d ** 2 / h ** 2 / 2)
-    rep = np.array([[(-K[i] @ p[:, k] + p[i, k] * K[i].sum()) / h ** 2 for k in range(dim)] for i in range(N)])
-    pn, dt, rp = svgd_update(p, g, 0.02)
-    assert np.allclose(dt, K @ g, rtol=1e-13) and np.allclose(rp, rep, rtol=1e-12, atol=1e-13)
-    assert np.allclose(pn, p + 0.02 * (K @ g + rep) / N, rtol=1e-14)
+def test_svgd_oracle_matches_reference_formulas(orc):
+    """The oracle's SVGD move (oracle/crnn_oracle.c: orc_svgd_update) against network.jl:67-87 + crnn_cathode.jl:36-50
+    written out independently in NumPy; odd and even pair counts (Julia's median of an even-length vector is the mean of
+    the middle pair)."""
+    for N, dim, seed in ((9, 17, 1), (6, 17, 2), (40, 3, 3)):
+        rng = np.random.default_rng(seed)
+        p = 1 + 0.1 * rng.standard_normal((N, dim)); g = rng.standard_normal((N, dim))
+        d = np.array([[np.sqrt(np.sum((p[i] - p[j]) ** 2)) for j in range(N)] for i in range(N)])
+        h = np.sqrt(0.5 * np.median([d[i, j] for i in range(N) for j in range(i)]) ** 2 / np.log(N + 1))
+        K = np.exp(-d ** 2 / h ** 2 / 2)
+        assert np.allclose(K, K.T) and np.allclose(np.diag(K), 1.0)
+        rep = np.array([[(-K[i] @ p[:, k] + p[i, k] * K[i].sum()) / h ** 2 for k in range(dim)] for i in range(N)])
+        pn, dt, rp, hh = orc.svgd_update(p, g, 0.02)
+        assert abs(hh - h) <= 1e-15 * h
+        assert np.allclose(dt, K @ g, rtol=1e-13, atol=1e-14) and np.allclose(rp, rep, rtol=1e-12, atol=1e-13)
+        assert np.allclose(rp.sum(axis=0), 0.0, atol=1e-11 * np.abs(rp).max())      # the repulsion sums to zero over particles
+        assert np.allclose(pn, p + 0.02 * (K @ g + rep) / N, rtol=1e-14)
+        p2, _, _, h2 = orc.svgd_update(p, g, 0.02, h=0.37)
+        K2 = np.exp(-d ** 2 / 0.37 ** 2 / 2)
+        rep2 = (-K2 @ p + p * K2.sum(axis=1, keepdims=True)) / 0.37 ** 2
+        assert h2 == 0.37 and np.allclose(p2, p + 0.02 * (K2 @ g + rep2) / N, rtol=1e-14)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,dim", [(6, 17), (257, 17), (1000, 3)])
-def test_gpu_svgd_update_matches_numpy(N, dim):
-    """N = 6: 15 pairs (odd count, single middle element); N = 257 / 1000: even counts (mean of the middle pair)."""
-    from crnn_amd.cathode import svgd_update, svgd_update_device
+@pytest.mark.parametrize("N,dim", [(6, 17), (257, 17), (1000, 3), (4096, 17)])
+def test_gpu_svgd_update_matches_oracle(orc, N, dim):
+    """HIP svgd kernels vs the oracle's scalar C loops.  N = 6: 15 pairs (odd count, single middle element); N = 257 /
+    1000 / 4096: even counts (mean of the middle pair); 4096 x 17 is BASELINE config 5's particle count."""
+    from crnn_amd.cathode import svgd_update
     rng = np.random.default_rng(N)
     p = 1 + 0.05 * rng.standard_normal((N, dim)); g = 50 * rng.standard_normal((N, dim))
-    pn, dt, rp = svgd_update(p, g, 0.01)
-    pd, dtd, rpd, h = svgd_update_device(p, g, 0.01)
-    d = np.sqrt(((p[:, None, :] - p[None, :, :]) ** 2).sum(-1))
-    href = np.sqrt(0.5 * np.median(d[np.tril_indices(N, -1)]) ** 2 / np.log(N + 1))
+    pn, dt, rp, href = orc.svgd_update(p, g, 0.01)
+    pd, dtd, rpd, h = svgd_update(p, g, 0.01)
     assert abs(h - href) <= 1e-14 * href                           # the exact median, not an approximation
     assert np.max(np.abs(dtd - dt)) < 1e-11 * np.max(np.abs(dt))
     assert np.max(np.abs(rpd - rp)) < 1e-10 * np.max(np.abs(rp))
     assert np.max(np.abs(pd - pn)) < 1e-13
-    p2, _, _, h2 = svgd_update_device(p, g, 0.01, h=0.37)          # explicit bandwidth
-    assert h2 == 0.37 and np.max(np.abs(p2 - svgd_update(p, g, 0.01, h=0.37)[0])) < 1e-13
+    p2, _, _, h2 = svgd_update(p, g, 0.01, h=0.37)          # explicit bandwidth
+    assert h2 == 0.37 and np.max(np.abs(p2 - orc.svgd_update(p, g, 0.01, h=0.37)[0])) < 1e-13
 
 
 def test_cathode_config_abi():
@@ -277,6 +272,51 @@ def test_gpu_cathode_many_heating_rates(orc, cfx):
             assert np.max(np.abs(hrr[n, i, :D] - r["hrr"])) < 1e-9 * max(1.0, np.max(np.abs(r["hrr"])))
             assert abs(loss[n, i] - r["loss"]) < 1e-9 * abs(r["loss"])
             assert np.max(np.abs(grad[n, i] - r["grad"] * ps)) < 1e-7 * np.max(np.abs(r["grad"] * ps))
+
+
+@pytest.mark.gpu
+def test_gpu_cathode_config5_full_size(orc, cfx):
+    """BASELINE config 5 at its full size on one GPU: 4 096 particles x 256 heating rates = 1 048 576 trajectories with
+    per-particle 17-parameter gradients in ONE launch.  All retcodes 0; the 4 096 particles are 256 tiles of 16 distinct
+    ones, so every tile must be bit-identical wherever it sat in the work queue; 64 random (particle, rate) rows are
+    checked against the oracle (same stepper, reference tolerances: step for step)."""
+    from crnn_amd.cathode import CathodeUQ
+    betas, exp_data = _many_rates(cfx, 256)
+    uq = CathodeUQ(exp_data, betas, cfx["theta"], normalizer=np.ones((256, 3)))
+    rng = np.random.default_rng(55)
+    base = 1 + 1e-3 * rng.standard_normal((16, 17))           # SURVEY 8(d): particles = 1 + 1e-3 N(0,1)
+    base[:, 6:9] = 0.0
+    p = np.tile(base, (256, 1))
+    loss, grad, _ = uq.solve(p)
+    st = uq.last_stats
+    assert st["n_traj"] == 4096 * 256 == st["n_ok"] and np.all(uq.last_retcode == 0)
+    assert np.all(uq.last_n_saved == np.array([e.shape[0] for e in exp_data])[None, :])
+    L4, G4 = loss.reshape(256, 16, 256), grad.reshape(256, 16, 256, 17)
+    assert np.array_equal(L4, np.broadcast_to(L4[0], L4.shape))
+    assert np.array_equal(G4, np.broadcast_to(G4[0], G4.shape))
+    ps = np.array(cfx["theta"])
+    for _ in range(64):
+        n, i = int(rng.integers(0, 4096)), int(rng.integers(0, 256))
+        e = exp_data[i]
+        r = orc.cathode_solve_one(orc.make_cathode(betas[i]), p[n] * ps, e[:, 0], e[:, 1:].mean(axis=1), (e[:, 1:] ** 2).mean(axis=1))
+        assert r["retcode"] == 0
+        assert abs(loss[n, i] - r["loss"]) < 1e-9 * abs(r["loss"])
+        assert np.max(np.abs(grad[n, i] - r["grad"] * ps)) < 1e-7 * np.max(np.abs(r["grad"] * ps))
+    print(f"config 5 full size: kernel {st['kernel_ms']:.1f} ms, {st['n_accept'] / st['n_traj']:.0f} steps/trajectory")
+
+
+@pytest.mark.gpu
+def test_gpu_cathode_allgather_single_rank(cfx):
+    """crnn_cathode_allgather with a one-rank RCCL communicator (the N > 1 exchange needs one GPU per rank): rows come back
+    unchanged through the device staging buffers; dlnprob_sharded == dlnprob."""
+    uq = _uq(cfx)
+    uq.comm_init()
+    rows = np.random.default_rng(0).standard_normal((37, 18))
+    assert np.array_equal(uq.allgather(rows, 37), rows)
+    p = 1 + 0.02 * np.random.default_rng(1).standard_normal((5, 17))
+    l1, g1 = uq.dlnprob(p, 2)
+    l2, g2 = uq.dlnprob_sharded(p, 2)
+    assert l1 == l2 and np.array_equal(g1, g2)
 
 
 @pytest.mark.gpu

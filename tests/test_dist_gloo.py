@@ -2,7 +2,7 @@
 
 What is exercised is the product's data-parallel *host logic* (crnn_amd/dist.py:
 contiguous sharding of the IC axis, one all-reduce of the
-[grad_sum | pad | loss_sum, n_ok, n_accept, n_reject, n_traj] vector per step,
+[grad_sum | n_overflow | loss_sum, n_ok, n_accept, n_reject, n_traj] vector per step,
 identical replicated optimiser update on every rank).  There is no GPU here, so
 each rank's shard result is produced by the CPU oracle in the exact layout
 libcrnn_hip's reduction buffer has; the assertion is that two ranks reproduce
@@ -51,7 +51,7 @@ def _worker(rank, world, port, q):
         first, count = shard_range(B, rank, world)
         losses = []
         for _ in range(3):
-            buf = _shard_buffer(orc, setup, p, first, count, 25, 0)
+            buf = _shard_buffer(orc, setup, p, first, count, 25, 1)
             allreduce_sum_(buf)
             loss, grad = mean_loss_and_grad_from_sums(buf, 25)
             opt.update_(p, grad)
@@ -81,7 +81,7 @@ def test_two_rank_data_parallel_equals_single_process(orc, case2_setup):
     B = case2_setup["u0"].shape[0]
     ref_losses = []
     for _ in range(3):
-        buf = _shard_buffer(orc, case2_setup, p, 0, B, 25, 0)
+        buf = _shard_buffer(orc, case2_setup, p, 0, B, 25, 1)
         loss, grad = mean_loss_and_grad_from_sums(buf, 25)
         opt.update_(p, grad)
         ref_losses.append(loss)
@@ -96,8 +96,8 @@ def _svgd_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from crnn_amd.cathode import svgd_update
         from crnn_amd.dist import allgather_rows, shard_range
+        from oracle.oracle import svgd_update      # CPU stand-in for the device SVGD move (no GPU here)
         rng = np.random.default_rng(0)
         N = 11                                       # not divisible by the world size
         p = 1 + 0.05 * rng.standard_normal((N, 17))
@@ -105,7 +105,7 @@ def _svgd_worker(rank, world, port, q):
             first, count = shard_range(N, rank, world)
             local = np.sin(p[first:first + count] * 3.0) - 0.1 * p[first:first + count]     # stand-in for the GPU's lnpgrad rows
             lnpgrad = allgather_rows(local, N)
-            p, _, _ = svgd_update(p, lnpgrad, 0.05)
+            p = svgd_update(p, lnpgrad, 0.05)[0]
         q.put((rank, p))
     finally:
         dist.destroy_process_group()
@@ -114,7 +114,7 @@ def _svgd_worker(rank, world, port, q):
 @pytest.mark.timeout(300)
 def test_two_rank_particle_sharding_and_svgd_update():
     """Cathode-UQ exchange: particles sharded, one all-gather of the gradient rows, replicated SVGD move."""
-    from crnn_amd.cathode import svgd_update
+    from oracle.oracle import svgd_update
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 31500 + (os.getpid() % 2000)
@@ -128,5 +128,5 @@ def test_two_rank_particle_sharding_and_svgd_update():
     rng = np.random.default_rng(0)
     p = 1 + 0.05 * rng.standard_normal((11, 17))
     for _ in range(3):
-        p, _, _ = svgd_update(p, np.sin(p * 3.0) - 0.1 * p, 0.05)
+        p = svgd_update(p, np.sin(p * 3.0) - 0.1 * p, 0.05)[0]
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][1], p)
