@@ -55,11 +55,20 @@ mutable struct Problem
     ctx::Ptr{Cvoid}
     tsteps::Vector{Float64}
     B::Int
+    adhoc::Union{Nothing,Problem}      # one-IC context behind predict_neuralode(prob, u0, p)
 end
 
-function ODEProblem(preset::Integer, tsteps::AbstractVector; atol=nothing, rtol=nothing, rate_scale=nothing, device=0, alg=nothing)
-    cfg = Config()
-    check(ccall((:crnn_config_preset, LIB), Int32, (Ref{Config}, Int32), cfg, preset))
+function ODEProblem(preset::Integer, tsteps::AbstractVector; atol=nothing, rtol=nothing, rate_scale=nothing, device=0, alg=nothing,
+                    cfg::Union{Nothing,Config}=nothing, errnorm_sens=nothing)
+    if cfg === nothing
+        cfg = Config()
+        check(ccall((:crnn_config_preset, LIB), Int32, (Ref{Config}, Int32), cfg, preset))
+    else
+        cfg = deepcopy(cfg)            # a second context with the same problem constants (predict_neuralode's one-IC context)
+    end
+    # errnorm_sens = 1: the step-size controller sees ForwardDiff's dual-inclusive error norm, i.e. a gradient call
+    # takes the step sequence `ForwardDiff.gradient` through the adaptive solver takes (the reference-faithful mode)
+    errnorm_sens === nothing || (cfg.errnorm_sens = errnorm_sens)
     alg === nothing || check(ccall((:crnn_config_set_solver, LIB), Int32, (Ref{Config}, Int32), cfg, alg))   # also sets the PI exponents
     cfg.n_save = length(tsteps); cfg.device = device
     n = cfg.ns + cfg.has_temp
@@ -68,7 +77,7 @@ function ODEProblem(preset::Integer, tsteps::AbstractVector; atol=nothing, rtol=
     rate_scale === nothing || (cfg.rate_scale = ntuple(i -> i <= cfg.ns ? Float64(rate_scale[i]) : 1.0, MAX_N))
     ctx = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:crnn_ctx_create, LIB), Int32, (Ref{Config}, Ref{Ptr{Cvoid}}), cfg, ctx))
-    prob = Problem(cfg, ctx[], collect(Float64, tsteps), 0)
+    prob = Problem(cfg, ctx[], collect(Float64, tsteps), 0, nothing)
     finalizer(p -> ccall((:crnn_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), p.ctx), prob)
     return prob
 end
@@ -123,7 +132,47 @@ function _solve(prob::Problem, th, dth, first, count, sample; want_pred=false)
     return pred, loss, grad[1:ndir], ret, nsv, st
 end
 
-"""`loss_neuralode(p, i_exp)` (case2/case2.jl:132-137); `i_exp` is 1-based like the reference."""
+"""`crnn!(du, u, p, t)`: the CPU definition of the right-hand side (case2/case2.jl:114-118, case1/case1.jl:80-83,
+robertson/rober_crnn.jl:113-116) with the weights `p2vec` returns -- what a Julia host hands to DifferentialEquations.jl's
+own `ODEProblem` (the CPU reference run below); the device never calls it.  `prob` supplies lb, ub, inv_R, dydt_scale."""
+function crnn!(du::AbstractVector, u::AbstractVector, p::AbstractVector, t, prob::Problem)
+    c = prob.cfg; ns = Int(c.ns); nr = Int(c.nr)
+    w_in, w_b, w_out = p2vec(prob, collect(Float64, p))
+    z = copy(w_b)
+    for j in 1:nr
+        for i in 1:ns
+            z[j] += w_in[i, j] * log(clamp(u[i], c.lb, c.ub))
+        end
+        c.has_temp == 1 && (z[j] += w_in[ns+1, j] * (c.inv_R / u[ns+1]))
+    end
+    r = exp.(z)
+    for i in 1:ns
+        du[i] = c.rate_scale[i] * sum(w_out[i, j] * r[j] for j in 1:nr)
+    end
+    c.has_temp == 1 && (du[ns+1] = 0.0)
+    return du
+end
+
+"""`pred = predict_neuralode(u0, p)` (case2/case2.jl:124-128): `clamp.(Array(solve(prob, alg, u0=u0, p=p)), -ub, ub)`,
+[n, D]; columns beyond a failed solve's last saved point are zero and "ode solver failed" is printed
+(robertson/rober_crnn.jl:130-134).  Integrated on the device through a one-IC context created on first use."""
+function predict_neuralode(prob::Problem, u0::AbstractVector, p::AbstractVector; sample=length(prob.tsteps))
+    if prob.adhoc === nothing
+        c = prob.cfg
+        a = ODEProblem(Int32(0), prob.tsteps; cfg=c)
+        prob.adhoc = a
+    end
+    a = prob.adhoc
+    n = a.cfg.ns + a.cfg.has_temp
+    set_ensemble!(a, reshape(collect(Float64, u0), 1, n), zeros(1, Int(a.cfg.ns), length(a.tsteps)), ones(Int(a.cfg.ns)))
+    th, _ = p2vec_jac(a, collect(Float64, p))
+    pred, _, _, _, nsv, _ = _solve(a, th, nothing, 0, 1, sample; want_pred=true)
+    return reshape(pred, n, length(a.tsteps))[:, 1:nsv[1]]      # B = 1: [1, n, D] column-major = [n, D]
+end
+
+"""`loss_neuralode(p, i_exp)` (case2/case2.jl:132-137); `i_exp` is 1-based like the reference.  The reference's function
+reads `u0_list`, `ode_data_list`, `yscale` from globals; here they live behind `prob` (set_ensemble!), hence the extra
+leading argument -- the only change to the reference's signature (INTEGRATION.md)."""
 function loss_neuralode(prob::Problem, p, i_exp; sample=length(prob.tsteps))
     th, _ = p2vec_jac(prob, p)
     _, loss, = _solve(prob, th, nothing, i_exp - 1, 1, sample)
@@ -161,6 +210,37 @@ end
 update!(opt::Optimiser, p::Vector{Float64}, grad::Vector{Float64}) =
     check(ccall((:crnn_opt_update, LIB), Int32, (Ref{OptConfig}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
                 opt.cfg, length(p), p, grad, opt.state))
+
+"""`update!(opt, p, grad)` on the device-resident `p` with a caller-supplied gradient (case2/case2.jl:197)."""
+train_update!(prob::Problem, grad::Vector{Float64}) =
+    check(ccall((:crnn_train_update, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), prob.ctx, grad), prob.ctx)
+function params(prob::Problem, np::Integer)
+    p = zeros(np)
+    check(ccall((:crnn_get_params, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), prob.ctx, p), prob.ctx)
+    return p
+end
+"""The device-resident optimiser state -- what `@save "./checkpoint/mymodel.bson" p opt ...` / `@load` keep across a
+restart (case2/case2.jl:178-187,213): [m | v | beta1^t, beta2^t, eta_expdecay, ncalls]."""
+function opt_state(prob::Problem, np::Integer)
+    st = zeros(ccall((:crnn_opt_state_len, LIB), Int32, (Int32,), np))
+    check(ccall((:crnn_get_opt_state, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), prob.ctx, st), prob.ctx)
+    return st
+end
+set_opt_state!(prob::Problem, st::Vector{Float64}) =
+    check(ccall((:crnn_set_opt_state, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), prob.ctx, st), prob.ctx)
+
+"""Multi-GPU, one Julia process per GPU: either the library's own RCCL communicator (`comm_init!` with the unique id
+rank 0 obtained from `comm_unique_id()` and broadcast by the host's launcher, e.g. MPI.bcast), or the host's collective
+handed in as a C callback (`set_allreduce!(prob, @cfunction(my_allreduce, Int32, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Ptr{Cvoid})))`)."""
+function comm_unique_id()
+    id = zeros(UInt8, 128)
+    check(ccall((:crnn_comm_get_unique_id, LIB), Int32, (Ptr{UInt8},), id))
+    return id
+end
+comm_init!(prob::Problem, id::Vector{UInt8}, rank::Integer, world::Integer) =
+    check(ccall((:crnn_comm_init, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Int32, Int32), prob.ctx, id, rank, world), prob.ctx)
+set_allreduce!(prob::Problem, fn::Ptr{Cvoid}, user::Ptr{Cvoid}=C_NULL) =
+    check(ccall((:crnn_comm_set_allreduce, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), prob.ctx, fn, user), prob.ctx)
 
 """Device-resident training (p and optimiser state stay in HBM; one all-reduce per step when a communicator is attached)."""
 train_init!(prob::Problem, opt::Optimiser, p0::Vector{Float64}) =
@@ -230,10 +310,5 @@ function svgd_update(p::Matrix{Float64}, lnpgrad::Matrix{Float64}, stepsize::Flo
                 device, pr, gr, N, dim, stepsize, h, pn, hout, C_NULL, C_NULL))
     return permutedims(pn), hout[]
 end
-
-# The reference's CPU baseline the north star mentions, for a Julia-equipped box (SURVEY 8(d)); also unexecuted:
-#   using OrdinaryDiffEq
-#   ens = EnsembleProblem(prob_ref; prob_func = (pr, i, _) -> remake(pr, u0 = u0_list[i, :]))
-#   @time solve(ens, Rosenbrock23(autodiff=false), EnsembleThreads(); trajectories = size(u0_list, 1), saveat = tsteps)
 
 end # module

@@ -1,0 +1,39 @@
+# julia/cpu_baseline.jl -- the reference's CPU path, `EnsembleThreads()` over the ensemble of initial conditions, timed on
+# the host cores next to the GPU figures (north star; SURVEY 8(d)).
+#
+# STATUS: WRITTEN, NOT EXECUTED (no Julia in the build image or on the GPU boxes).  It needs the reference's own stack
+# (OrdinaryDiffEq, ForwardDiff) and is the harness a Julia-equipped box runs to obtain the true DifferentialEquations.jl
+# number; bench.py's `cpu_baseline` is the C restatement ("port") until then.
+#
+#     julia -t auto julia/cpu_baseline.jl [n_exp]
+using OrdinaryDiffEq, ForwardDiff, Random, Statistics
+include(joinpath(@__DIR__, "CRNNHip.jl"))
+using .CRNNHip
+
+n_exp = length(ARGS) >= 1 ? parse(Int, ARGS[1]) : 4096
+Random.seed!(1234)
+tsteps = collect(0.0:1.0:49.0)                                   # case2/case2.jl:18-19,67-68
+prob_dev = CRNNHip.ODEProblem(CRNNHip.PRESET_CASE2, tsteps)      # problem constants (lb, ub, inv_R, tolerances) from the preset
+p = randn(25) .* 0.1; p[1:3] .+= 0.8; p[22:24] .+= 0.8; p[25] = 0.1   # case2/case2.jl:85-89
+u0_list = zeros(n_exp, 7)
+u0_list[:, 1:2] .= rand(n_exp, 2) .* 2.0 .+ 0.2                  # case2/case2.jl:62-65
+u0_list[:, 7] .= rand(n_exp) .* 20.0 .+ 323.0
+
+rhs!(du, u, p, t) = CRNNHip.crnn!(du, u, p, t, prob_dev)
+prob_ref = OrdinaryDiffEq.ODEProblem(rhs!, u0_list[1, :], (tsteps[1], tsteps[end]), p)
+ens = EnsembleProblem(prob_ref; prob_func = (pr, i, _) -> remake(pr, u0 = u0_list[i, :]))
+alg = Rosenbrock23(autodiff = false)                             # the stiff branch of case2/case2.jl:26
+solve(ens, alg, EnsembleThreads(); trajectories = min(n_exp, 64), saveat = tsteps, abstol = 1e-6, reltol = 1e-3)   # compile
+t_solve = @elapsed solve(ens, alg, EnsembleThreads(); trajectories = n_exp, saveat = tsteps, abstol = 1e-6, reltol = 1e-3)
+
+# trajectory + gradient, as the training loop forms it (case2/case2.jl:195): ForwardDiff through the adaptive solver
+function loss_of(x, i)
+    sol = solve(remake(prob_ref, u0 = u0_list[i, :], p = x), alg; saveat = tsteps, abstol = 1e-6, reltol = 1e-3)
+    return mean(abs, clamp.(Array(sol), -10.0, 10.0))            # a data-free stand-in for mae(ode_data, pred)
+end
+ForwardDiff.gradient(x -> loss_of(x, 1), p)                      # compile
+t_grad = @elapsed Threads.@threads for i in 1:n_exp
+    ForwardDiff.gradient(x -> loss_of(x, i), p)
+end
+println("EnsembleThreads() on $(Threads.nthreads()) threads: $(n_exp / t_solve) trajectories/s, ",
+        "$(n_exp / t_grad) trajectories+gradients/s")

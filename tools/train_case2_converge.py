@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""tools/train_case2_converge.py -- do the learned rate constants converge?  (north star: "learned rate constants match")
+
+Trains the case2 CRNN on the MI355X library FROM THE REFERENCE'S INITIALISER (case2/case2.jl:85-89) with the reference's
+schedule (case2/case2.jl:20-32,190-198): 20 training + 10 validation experiments, 5 % multiplicative noise, per epoch one
+`update!` PER EXPERIMENT in random order, Flux.Optimiser(ExpDecay(5e-3, 0.5, 500*20, 1e-4), ADAMW(0.005, (0.9, 0.999), 1e-6)),
+until the epoch-end training MAE falls below --target (the reference's own checkpoint: 1.65e-2 after 3 700 epochs with the
+same noise level), then decodes the Arrhenius constants from p exactly as the reference's post-processing does
+(lnA = w_b, Ea = the temperature row of w_in; slope = p[25]*10) and prints them next to the true mechanism
+(case2/case2.jl:52-53) and next to the reference's checkpoint (tests/golden/fixtures.json: case2_ckpt).
+
+Every update is one device-resident training step on a ONE-experiment batch (that is the reference's algorithm: SGD with
+batch 1); the epoch-end evaluation is one primal launch over all 30 experiments.  Per-epoch step statistics are recorded:
+they show which solver regimes a healthy training run actually visits (bench.py's secondary figures use them).
+
+    python tools/train_case2_converge.py [--epochs 4000] [--target 2e-2] [--seed 0] [--json out.json] [--grad auto]
+Needs an MI355X."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def decode(p):
+    """(lnA[3], Ea[3]) of the learned mechanism: theta's w_b and the 1/(RT) row of w_in (case2/case2.jl:91-99)."""
+    from crnn_amd import p2vec
+    w_in, w_b, _ = p2vec(2, 6, 3, p)
+    return w_b.copy(), w_in[6].copy()
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--epochs", type=int, default=4000)
+    ap.add_argument("--target", type=float, default=2e-2)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--grad", choices=["auto", "forward", "adjoint"], default="auto")
+    ap.add_argument("--quiet", action="store_true")
+    args = ap.parse_args(argv)
+
+    from crnn_amd import NeuralODE, ODEProblem, Optimiser, PRESET_CASE2, cases
+
+    rng = np.random.Generator(np.random.PCG64(args.seed))
+    n_train, n_exp = 20, 30
+    ts = cases.case2_tsteps()
+    u0 = cases.case2_u0(n_exp, rng)
+    gen = NeuralODE(ODEProblem(PRESET_CASE2, ts, atol=1e-10, rtol=1e-8))
+    clean = gen.predict_theta(u0, cases.case2_true_theta())[:, :6, :]
+    gen.close()
+    data = cases.add_noise(clean, 0.05, rng)
+    yscale = cases.max_min(data, lb=1e-6)
+    node = NeuralODE(ODEProblem(PRESET_CASE2, ts, grad_mode={"auto": 0, "forward": 1, "adjoint": 2}[args.grad]))
+    node.set_ensemble(u0, data, yscale)
+    p = cases.case2_init_p(rng)
+    node.train_init(Optimiser(25, PRESET_CASE2), p)
+
+    t0 = time.perf_counter()
+    hist = []
+    hardest = dict(steps=0.0)
+    reached = None
+    for epoch in range(1, args.epochs + 1):
+        order = np.random.Generator(np.random.PCG64([args.seed, epoch])).permutation(n_train)
+        for i_exp in order:
+            node.train_step(first=int(i_exp), count=1, want_loss=False)
+        p = node.params()
+        losses = node.losses(p)
+        st = node.last_stats
+        lt, lv = float(losses[:n_train].mean()), float(losses[n_train:].mean())
+        spt, rpt = st["n_accept"] / st["n_traj"], st["n_reject"] / st["n_traj"]
+        hist.append((epoch, lt, lv, spt, rpt, st["n_ok"]))
+        if spt + rpt > hardest["steps"] and st["n_ok"] == st["n_traj"]:
+            hardest = dict(steps=spt + rpt, accept=spt, reject=rpt, epoch=epoch, p=p.tolist(), loss=lt)
+        if not args.quiet and (epoch % 100 == 0 or epoch <= 5):
+            print(f"epoch {epoch:5d}  loss train {lt:.3e} val {lv:.3e}  steps/traj {spt:.1f} rejects/traj {rpt:.2f} ok {st['n_ok']}/{st['n_traj']}",
+                  flush=True)
+        if lt <= args.target:
+            reached = epoch
+            break
+    wall = time.perf_counter() - t0
+    lnA, Ea = decode(p)
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fixtures.json")))
+    lnA_ck, Ea_ck = decode(np.array(fx["case2_ckpt"]["p"]))
+    out = dict(reached_epoch=reached, epochs_run=len(hist), updates=len(hist) * n_train, wall_s=wall,
+               final_loss_train=hist[-1][1], final_loss_val=hist[-1][2],
+               lnA=lnA.tolist(), Ea=Ea.tolist(), lnA_true=list(map(float, cases.CASE2_LOGA)), Ea_true=list(map(float, cases.CASE2_EA)),
+               lnA_ref_ckpt=lnA_ck.tolist(), Ea_ref_ckpt=Ea_ck.tolist(),
+               hardest_epoch=hardest, p=p.tolist(), seed=args.seed,
+               steps_per_traj_first_last=[hist[0][3], hist[-1][3]], max_rejects_per_traj=max(h[4] for h in hist))
+    if not args.quiet:
+        np.set_printoptions(precision=3, suppress=True)
+        print(f"\n{'reached' if reached else 'NOT reached'} train MAE <= {args.target:g} at epoch {reached} "
+              f"({out['updates']} updates, {wall:.1f} s wall); final train {out['final_loss_train']:.3e} val {out['final_loss_val']:.3e}")
+        print("            lnA                         Ea [kcal/mol]")
+        print(f"learned   {lnA}   {Ea}")
+        print(f"true      {np.array(out['lnA_true'])}   {np.array(out['Ea_true'])}      (case2.jl:52-53)")
+        print(f"ref ckpt  {lnA_ck}   {Ea_ck}      (case2/checkpoint/mymodel.bson, 3 700 epochs)")
+        print(f"hardest healthy epoch: {hardest.get('epoch')} with {hardest.get('accept', 0):.1f} accepted + {hardest.get('reject', 0):.1f} rejected steps per trajectory")
+    if args.json:
+        json.dump(out, open(args.json, "w"), indent=1)
+    node.close()
+    return out
+
+
+if __name__ == "__main__":
+    main()
