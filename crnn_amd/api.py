@@ -38,6 +38,14 @@ __all__ = ["NeuralODE", "ODEProblem", "Optimiser", "p2vec", "p2vec_jac", "crnn",
 # ---------------------------------------------------------------------------
 # p2vec (host, exact reference formulas) and its Jacobian
 # ---------------------------------------------------------------------------
+def fd_chunk_size(P: int) -> int:
+    """ForwardDiff.pickchunksize(P) (DEFAULT_CHUNK_THRESHOLD = 12): partials per Dual, i.e. per adaptive solve."""
+    if P <= 12:
+        return P
+    nchunks = -(-P // 12)
+    return -(-P // nchunks)
+
+
 def _extra_rows(pmap):
     """feature rows of w_in beyond the species rows: case2's -1/(R T); HyChem's -1/(R T) and log T"""
     return 1 if pmap == L.PMAP_CASE2 else (2 if pmap == L.PMAP_HYCHEM else 0)
@@ -147,6 +155,8 @@ class ODEProblem:
     mw: object = None             # HyChem: molar masses (preset: the reference's l_MW)
     grad_mode: int = 0            # GRAD_AUTO (adjoint where available) / GRAD_FORWARD (tangents) / GRAD_ADJOINT
     tape_steps: int = 0           # adjoint tape capacity per trajectory, 0 = auto
+    errnorm_sens: int = 0         # 1: ForwardDiff's dual-inclusive error norm drives the step sizes of gradient calls
+    errnorm_sens: int = 0         # 1: ForwardDiff's dual-inclusive error norm drives the step sizes of gradient calls
 
     def config(self) -> Config:
         cfg = Config()
@@ -159,6 +169,8 @@ class ODEProblem:
         cfg.cols_per_lane = int(self.cols_per_lane)
         cfg.grad_mode = int(self.grad_mode)
         cfg.tape_steps = int(self.tape_steps)
+        cfg.errnorm_sens = int(self.errnorm_sens)
+        cfg.errnorm_sens = int(self.errnorm_sens)
         n = cfg.ns + cfg.has_temp
         if self.atol is not None:
             a = np.broadcast_to(np.asarray(self.atol, float), (n,))
@@ -339,9 +351,22 @@ class NeuralODE:
         return loss[first:first + count]
 
     def gradient(self, p, i_exp, sample=None):
-        """ForwardDiff.gradient(x -> loss_neuralode(x, i_exp), p)."""
+        """ForwardDiff.gradient(x -> loss_neuralode(x, i_exp), p).  With errnorm_sens = 1 the call works through p in
+        ForwardDiff's chunks (pickchunksize: 25 -> 9 + 9 + 7 ...), each chunk its own adaptive solve whose error norm sees
+        that chunk's partials; last_chunk_stats lists the (accepted, rejected) steps of every chunk."""
         th, dth = p2vec_jac(self.pmap, self.ns, self.nr, p)
-        _, _, grad, _, _ = self._solve(self._ctx, self.B, th, dth, int(i_exp), 1, sample, False)
+        if not self.cfg.errnorm_sens:
+            _, _, grad, _, _ = self._solve(self._ctx, self.B, th, dth, int(i_exp), 1, sample, False)
+            return grad
+        P = dth.shape[1]
+        chunk = fd_chunk_size(P)
+        grad = np.zeros(P)
+        self.last_chunk_stats = []
+        for k0 in range(0, P, chunk):
+            k1 = min(P, k0 + chunk)
+            _, _, g, _, _ = self._solve(self._ctx, self.B, th, dth[:, k0:k1], int(i_exp), 1, sample, False)
+            grad[k0:k1] = g
+            self.last_chunk_stats.append((self.last_stats["n_accept"], self.last_stats["n_reject"]))
         return grad
 
     def loss_and_grad(self, p, first=0, count=None, sample=None):

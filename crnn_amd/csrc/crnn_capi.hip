@@ -15,6 +15,7 @@
 #include "p2vec.hpp"
 #include "ros23_kernel.hpp"
 #include "ros23_adj_kernel.hpp"
+#include "ros23_sens_kernel.hpp"
 #include "hychem_kernel.hpp"
 #include "tsit5_kernel.hpp"
 #include "auto_adj_kernel.hpp"
@@ -67,6 +68,15 @@ const KernelEntry kKernels[] = {
     // explicit Tsit5 (case1's reference algorithm; the non-stiff branch of case2's AutoTsit5)
     KENT5(5, 4, 0, 0, 0, 1), KENT5(5, 4, 0, 0, 4, 6), KENT5(5, 4, 0, 0, 6, 4), KENT5(5, 4, 0, 0, 8, 6),
     KENT5(6, 3, 1, 0, 0, 1), KENT5(6, 3, 1, 0, 5, 5), KENT5(6, 3, 1, 0, 7, 6),
+};
+
+// errnorm_sens = 1 (ForwardDiff's dual-inclusive error norm): one launch = one ForwardDiff chunk of at most C*L partials.
+// (C, L) are sized for ForwardDiff.pickchunksize: case2 P = 25 -> 9 + 9 + 7, robertson 43 -> 11 x 3 + 10, case1 24 -> 12 + 12.
+constexpr int kSensBlock = 128;
+#define KSENS(NS, NR, HT, SC, C, L) \
+    { CRNN_SOLVER_ROSENBROCK23, NS, NR, HT, SC, C, L, (KernelFn)crnn::ros23_sens_kernel<NS, NR, (HT) != 0, (SC) != 0, C, L, kSensBlock> }
+const KernelEntry kSensKernels[] = {
+    KSENS(6, 3, 1, 0, 3, 3), KSENS(3, 6, 0, 1, 4, 3), KSENS(5, 4, 0, 0, 4, 3),
 };
 
 using AdjKernelFn = void (*)(const crnn::SolveParams, const double *, const crnn::AdjParams);
@@ -143,6 +153,8 @@ struct Ctx {
     size_t partials_cap = 0;
     double *d_red = nullptr;  // [npart_max]
     int npart_max = 0;
+    double *d_red_asm = nullptr;    // errnorm_sens: the full [P + kTail] vector assembled from the chunk passes
+    int red_asm_len = 0;
     int last_npart = 0, last_P = 0;
     // training state
     double *d_p = nullptr, *d_opt = nullptr;
@@ -185,6 +197,19 @@ int32_t allreduce_red(Ctx *c) {
 bool shape_match(const Ctx *c, const KernelEntry &k) {
     return k.solver == c->cfg.solver && k.ns == c->cfg.ns && k.nr == c->cfg.nr && k.has_t == c->cfg.has_temp &&
            k.use_scale == (c->use_scale ? 1 : 0);
+}
+
+const KernelEntry *find_sens(const Ctx *c) {
+    for (const auto &k : kSensKernels)
+        if (shape_match(c, k)) return &k;
+    return nullptr;
+}
+
+// ForwardDiff.pickchunksize (DEFAULT_CHUNK_THRESHOLD = 12): the number of partials a Dual carries per pass
+int fd_chunk_size(int P) {
+    if (P <= 12) return P;
+    const int nchunks = (P + 11) / 12;
+    return (P + nchunks - 1) / nchunks;
 }
 
 const KernelEntry *find_primal(const Ctx *c) {
@@ -516,6 +541,97 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
     return 0;
 }
 
+int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int P, int64_t first, int64_t count,
+                     int n_save_active, bool want_pred, bool want_percase);
+
+// One ForwardDiff chunk with the dual-inclusive error norm: primal + P <= C*L tangent columns through every attempt
+// (ros23_sens_kernel.hpp), fixed-order reduction into c->d_red in the common layout.
+int32_t launch_sens_chunk(Ctx *c, const KernelEntry *k, const double *d_theta, const double *d_dtheta, int P, int64_t first,
+                          int64_t count, int n_save_active, bool want_pred) {
+    const int C = k->C, L = k->L, gpw = 64 / L, waves = kSensBlock / 64;
+    const int ppad = L * C, npart_pad = ppad + crnn::kExtra, npart = P + crnn::kTail;
+    int occ = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k->fn, kSensBlock, 0));
+    if (occ < 1) occ = 1;
+    const int64_t gpb = (int64_t)waves * gpw;
+    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((count + gpb - 1) / gpb, (int64_t)c->num_cu * occ));
+    const int rblk = (int)((count + 255) / 256);
+    if (ensure(c, &c->d_partials, &c->partials_cap, (size_t)rblk * npart_pad)) return -1;
+    if (ensure(c, &c->d_gtraj, &c->gtraj_cap, (size_t)count * ppad)) return -1;
+    if (c->npart_max < npart) {
+        if (c->d_red) HIP_TRY(c, hipFree(c->d_red));
+        c->d_red = nullptr;
+        HIP_TRY(c, hipMalloc((void **)&c->d_red, sizeof(double) * npart));
+        c->npart_max = npart;
+    }
+    if (want_pred && ensure_pred(c)) return -1;
+    crnn::SolveParams prm{};
+    fill_params(c, prm, P, first, count, n_save_active, want_pred);
+    if (upload_consts(c)) return -1;
+    c->flags_zeroed = false;
+    c->ev0 = c->ring0[c->n_launch % Ctx::kRing];
+    c->ev1 = c->ring1[c->n_launch % Ctx::kRing];
+    ++c->n_launch;
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    hipLaunchKernelGGL(k->fn, dim3(nblk), dim3(kSensBlock), 0, c->stream, prm, d_theta, d_dtheta);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    hipLaunchKernelGGL(crnn::reduce_traj_kernel, dim3(rblk), dim3(256), 0, c->stream, c->d_gtraj, ppad, c->d_loss, c->d_ret,
+                       c->d_nacc, c->d_nrej, first, count, 256, c->d_partials);
+    HIP_TRY(c, hipGetLastError());
+    hipLaunchKernelGGL(crnn::reduce_partials_kernel, dim3(npart_pad), dim3(256), 0, c->stream, c->d_partials, rblk, ppad, P, c->d_red);
+    HIP_TRY(c, hipGetLastError());
+    c->last_npart = npart;
+    c->last_P = P;
+    return 0;
+}
+
+// errnorm_sens = 1.  P <= C*L (crnn_solve: the caller's directions are ONE chunk): a single launch.  Otherwise
+// (crnn_loss_grad, crnn_train_step: the P parameters) ForwardDiff's chunking: consecutive chunks of fd_chunk_size(P)
+// partials, each its own adaptive solve, the gradient pieces concatenated; per-trajectory losses, return codes and the
+// step statistics are those of a final plain solve -- what loss_neuralode(p) evaluates (case2/case2.jl:199-201).
+int32_t launch_sens(Ctx *c, const double *d_theta, const double *d_dtheta, int P, int64_t first, int64_t count,
+                    int n_save_active, bool want_pred, bool single_chunk) {
+    const KernelEntry *k = find_sens(c);
+    if (!k) return fail(c, "crnn_solve: errnorm_sens = 1 has no kernel for this (solver, ns, nr, has_temp)");
+    const int cap = k->C * k->L;
+    if (single_chunk) {
+        if (P > cap) return fail(c, "crnn_solve: with errnorm_sens = 1 the directions of one call are one ForwardDiff chunk: n_dir <= " + std::to_string(cap));
+        return launch_sens_chunk(c, k, d_theta, d_dtheta, P, first, count, n_save_active, want_pred);
+    }
+    const int chunk = fd_chunk_size(P);
+    if (chunk > cap) return fail(c, "crnn_loss_grad: errnorm_sens = 1 chunk size exceeds the instantiated kernel");
+    const int npart = P + crnn::kTail;
+    if (c->red_asm_len < npart) {
+        if (c->d_red_asm) HIP_TRY(c, hipFree(c->d_red_asm));
+        c->d_red_asm = nullptr;
+        HIP_TRY(c, hipMalloc((void **)&c->d_red_asm, sizeof(double) * npart));
+        c->red_asm_len = npart;
+    }
+    for (int k0 = 0; k0 < P; k0 += chunk) {
+        const int Pc = std::min(chunk, P - k0);
+        if (launch_sens_chunk(c, k, d_theta, d_dtheta + (size_t)k0 * c->n_theta, Pc, first, count, n_save_active, false)) return -1;
+        HIP_TRY(c, hipMemcpyAsync(c->d_red_asm + k0, c->d_red, sizeof(double) * Pc, hipMemcpyDeviceToDevice, c->stream));
+    }
+    const int es = c->cfg.errnorm_sens;
+    c->cfg.errnorm_sens = 0;      // the plain solve
+    const int32_t rc = launch_solve(c, d_theta, d_dtheta, 0, first, count, n_save_active, want_pred, false);
+    c->cfg.errnorm_sens = es;
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_red_asm + P, c->d_red, sizeof(double) * crnn::kTail, hipMemcpyDeviceToDevice, c->stream));
+    if (c->npart_max < npart) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->d_red) HIP_TRY(c, hipFree(c->d_red));
+        c->d_red = nullptr;
+        HIP_TRY(c, hipMalloc((void **)&c->d_red, sizeof(double) * npart));
+        c->npart_max = npart;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_red, c->d_red_asm, sizeof(double) * npart, hipMemcpyDeviceToDevice, c->stream));
+    c->last_npart = npart;
+    c->last_P = P;
+    return 0;
+}
+
 // Launch solve (+ fixed-order reduction into c->d_red).  theta/dtheta already on device.
 int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int P, int64_t first, int64_t count,
                      int n_save_active, bool want_pred, bool want_percase) {
@@ -528,6 +644,7 @@ int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int 
         return launch_hychem(c, d_theta, d_dtheta, P, first, count, n_save_active, want_pred);
     }
     c->last_deferred = false;
+    if (c->cfg.errnorm_sens && P > 0) return launch_sens(c, d_theta, d_dtheta, P, first, count, n_save_active, want_pred, want_percase);
     if (c->cfg.solver == CRNN_SOLVER_AUTOTSIT5) {
         // the composite exists as a tape kernel only: primal calls run it with P = 0, and there is no forward-tangent fallback
         if (P > 0 && c->cfg.grad_mode == CRNN_GRAD_FORWARD)
@@ -790,7 +907,9 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
     if (cfg->abi_version != CRNN_ABI_VERSION) return fail(nullptr, "crnn_ctx_create: abi_version mismatch");
     if (cfg->ns < 1 || cfg->nr < 1 || cfg->ns + cfg->has_temp > CRNN_MAX_N || cfg->nr > CRNN_MAX_NR)
         return fail(nullptr, "crnn_ctx_create: ns/nr out of range");
-    if (cfg->errnorm_sens != 0) return fail(nullptr, "crnn_ctx_create: errnorm_sens=1 is not implemented on device");
+    if (cfg->errnorm_sens != 0 && cfg->errnorm_sens != 1) return fail(nullptr, "crnn_ctx_create: errnorm_sens must be 0 or 1");
+    if (cfg->errnorm_sens == 1 && (cfg->solver != CRNN_SOLVER_ROSENBROCK23 || cfg->rhs_kind != CRNN_RHS_CRNN || cfg->grad_mode == CRNN_GRAD_ADJOINT))
+        return fail(nullptr, "crnn_ctx_create: errnorm_sens = 1 exists for Rosenbrock23 with forward tangents (grad_mode AUTO or FORWARD) on the CRNN right-hand side");
     if (cfg->solver != CRNN_SOLVER_ROSENBROCK23 && cfg->solver != CRNN_SOLVER_TSIT5 && cfg->solver != CRNN_SOLVER_AUTOTSIT5)
         return fail(nullptr, "crnn_ctx_create: unknown solver");
     if (cfg->rhs_kind != CRNN_RHS_CRNN && cfg->rhs_kind != CRNN_RHS_HYCHEM) return fail(nullptr, "crnn_ctx_create: unknown rhs_kind");
@@ -817,6 +936,10 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
     if (!c->hychem && !has_kernel()) {
         delete c;
         return fail(nullptr, "crnn_ctx_create: no gfx950 kernel instantiated for this (solver, ns, nr, has_temp)");
+    }
+    if (cfg->errnorm_sens == 1 && !find_sens(c)) {
+        delete c;
+        return fail(nullptr, "crnn_ctx_create: errnorm_sens = 1 has no kernel for this (ns, nr, has_temp)");
     }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -864,7 +987,7 @@ void crnn_ctx_destroy(crnn_ctx *ctx) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->own_u0 && c->d_u0) (void)hipFree(c->d_u0);
     if (c->own_data && c->d_data) (void)hipFree(c->d_data);
-    void *ptrs[] = {c->d_poison, c->d_tabs, c->d_gacc, c->d_tape, c->d_overflow, c->d_red_theta, c->d_queue, c->d_nacc, c->d_nrej, c->d_gtraj, c->d_kc, c->d_tsave, c->d_pred, c->d_loss, c->d_ret, c->d_nsaved, c->d_theta, c->d_dtheta,
+    void *ptrs[] = {c->d_red_asm, c->d_poison, c->d_tabs, c->d_gacc, c->d_tape, c->d_overflow, c->d_red_theta, c->d_queue, c->d_nacc, c->d_nrej, c->d_gtraj, c->d_kc, c->d_tsave, c->d_pred, c->d_loss, c->d_ret, c->d_nsaved, c->d_theta, c->d_dtheta,
                     c->d_partials, c->d_red, c->d_p, c->d_p_eval, c->d_opt, c->d_comm_buf};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < Ctx::kRing; ++i) {

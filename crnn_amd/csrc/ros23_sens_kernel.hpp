@@ -1,0 +1,527 @@
+// crnn_amd/csrc/ros23_sens_kernel.hpp -- gfx950 (MI355X): Rosenbrock23 + forward tangents with the step-size controller
+// driven by ForwardDiff's DUAL-INCLUSIVE error norm (crnn_config.errnorm_sens = 1): the reference-faithful gradient mode.
+//
+// The reference forms its gradient by pushing ForwardDiff.Dual numbers through the adaptive solver
+// (case2/case2.jl:195, robertson/rober_crnn.jl:219, case1/case1.jl:147).  DiffEqBase's error norm of a Dual-valued state
+// weighs the partials together with the value, so the accept / reject decisions and the step sizes of a GRADIENT call
+// differ from those of a plain solve -- and, because ForwardDiff works through the P parameters in chunks
+// (pickchunksize: 25 -> 9 + 9 + 7, 43 -> 11 + 11 + 11 + 10, 24 -> 12 + 12), every chunk is its own adaptive solve whose
+// norm sees only that chunk's partials.  One launch of this kernel is ONE chunk: primal + the chunk's tangent columns
+// through every ATTEMPT (not only through accepted steps: the decision needs them), including the third stage's
+// tangent k3' that only the error estimate uses:
+//
+//     W k1' = f0' + gam J' k1          W (k2-k1)' = f1' - k1' + gam J' (k2-k1)         s+ = s + dt k2'
+//     W k3' = f2' - c32 (k2' - f1') - 2 (k1' - f0') + gam J' k3        e' = dt/6 (k1' - 2 k2' + k3')
+//     EEst^2 = 1/n sum_i (e_i^2 + sum_k e'_ik^2) / (atol_i + rtol_i sqrt(max(u_i^2 + sum_k s_ik^2, u+_i^2 + sum_k s+_ik^2)))^2
+//
+// ([UNVERIFIED-DEP] DiffEqBase.ODE_DEFAULT_NORM on Dual arrays -- DiffEqBase is not vendored with the reference; the initial step size uses the primal values only.)
+//
+// MI355X mapping: the lane-group layout of ros23_kernel.hpp (L lanes own one trajectory, C columns each, the primal
+// step computed redundantly, a per-group LDS step record that lane 0 of the group publishes) with three differences:
+// the seeds of the save points inside the attempted step, the new tangent columns (second LDS slot) and the gradient
+// increments are PROVISIONAL until the group has summed its lanes' norm contributions (three ds_bpermute rounds per
+// species) and taken the decision; the record also carries the u+ point and k3; trajectories are assigned by a plain
+// grid-stride loop.  This mode costs about (1 + 1.6 C L) primal attempts per attempt and three or four launches per
+// gradient: it exists for parity with the reference's step sequence, not for speed (bench.py reports its cost).
+#pragma once
+#include "ros23_kernel.hpp"
+
+namespace crnn {
+
+template <int NS, int NR>
+struct RecS {
+    static constexpr int X0 = 0;
+    static constexpr int G0 = X0 + NS;
+    static constexpr int R0 = G0 + NS;
+    static constexpr int X1 = R0 + NR;
+    static constexpr int G1 = X1 + NS;
+    static constexpr int R1 = G1 + NS;
+    static constexpr int X2 = R1 + NR;
+    static constexpr int G2 = X2 + NS;
+    static constexpr int R2 = G2 + NS;
+    static constexpr int K1 = R2 + NR;
+    static constexpr int DK = K1 + NS;
+    static constexpr int K3 = DK + NS;
+    static constexpr int C1J = K3 + NS;
+    static constexpr int CZD = C1J + NR;
+    static constexpr int CZ3 = CZD + NR;
+    static constexpr int GR0 = CZ3 + NR;
+    static constexpr int AA = GR0 + NR;
+    static constexpr int B1 = AA + NS;
+    static constexpr int B2 = B1 + NS;
+    static constexpr int NREC = B2 + NS;
+};
+
+template <int NS, int NR, bool HAS_T, bool USE_SCALE, int C, int L, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm, const double *__restrict__ theta,
+                                                           const double *__restrict__ dtheta) {
+    using L_ = Lay<NS, NR, HAS_T>;
+    using R_ = RecS<NS, NR>;
+    constexpr int N = L_::N;
+    constexpr int NTH = L_::NTH;
+    constexpr int NTHP = L_::NTHP;
+    constexpr int NREC = R_::NREC;
+    constexpr int WAVES = BLOCK / 64;
+    constexpr int GPW = 64 / L;
+    constexpr int PPAD = L * C;
+    static_assert(C > 0 && L >= 1 && L <= 64, "lane-group shape");
+    using Solver = typename SolverSel<(NR < NS), NS, NR, HAS_T, USE_SCALE>::type;
+
+    __shared__ double kc_lds[kNConst];
+    __shared__ double ts_lds[kMaxSave];
+    __shared__ double dth_lds[PPAD * NTHP];
+    __shared__ double S_lds[2 * WAVES * C * NS * 64];   // two slots per lane: committed columns / columns of the attempt
+    __shared__ double rec_lds[WAVES * NREC * GPW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = lane / L, chunk = lane - grp * L;
+    const bool lane_active = grp < GPW;
+    const bool lead = lane_active && chunk == 0;
+    const int gbase = grp * L;                           // first lane of this group
+    double *const S_base = S_lds + (size_t)wave * 2 * C * NS * 64 + lane;   // slot s, (qc, i): S_base[(s*C*NS + qc*NS + i) * 64]
+    double *const rec = rec_lds + wave * NREC * GPW + (lane_active ? grp : 0);
+
+    for (int idx = tid; idx < kNConst; idx += BLOCK) kc_lds[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
+    for (int idx = tid; idx < prm.n_save; idx += BLOCK) ts_lds[idx] = prm.tsave[idx];
+    for (int idx = tid; idx < PPAD * NTHP; idx += BLOCK) {
+        const int k = idx / NTHP, m = idx - k * NTHP;
+        dth_lds[idx] = (k < prm.P && m < NTH) ? dtheta[(size_t)k * NTH + m] : 0.0;
+    }
+    __syncthreads();
+    const KConst *kc = reinterpret_cast<const KConst *>(kc_lds);
+    const double *__restrict__ th = theta;
+
+    const double d_ = 0.29289321881345248, c32 = 7.4142135623730950, inv12d = 2.4142135623730950;
+    const int nsave = prm.n_save;
+    const double tend = ts_lds[nsave - 1], ts0 = ts_lds[0], t0 = kc->t0;
+    const double dtmax = tend - t0;
+    const double lqinit = flog(kc->qoldinit);
+
+    const int64_t ngroups = (int64_t)gridDim.x * WAVES * GPW;
+    int64_t traj = lane_active ? ((int64_t)blockIdx.x * WAVES + wave) * GPW + grp : prm.count;
+
+    // sum of v over the L lanes of this lane's group, in lane order (identical on every lane of the group)
+    auto group_sum = [&](double v) -> double {
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < L; ++q) a += __shfl(v, gbase + q);
+        return a;
+    };
+
+    for (; traj < prm.count; traj += ngroups) {
+        const int64_t b = prm.first + traj;
+        const double *const drows = prm.data + (size_t)b * prm.row_stride;
+        double u[NS], f0[NS], g0[NS], x0[NS], r0[NR], bT[NR], gtr[C];
+        double xT = 0.0, Tconst = 0.0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) u[i] = prm.u0[(size_t)i * prm.B + b];
+        if (HAS_T) {
+            Tconst = prm.u0[(size_t)NS * prm.B + b];
+            xT = kc->inv_R * frcp(Tconst);
+        }
+#pragma unroll
+        for (int j = 0; j < NR; ++j) bT[j] = HAS_T ? fma(th[L_::wi(NS, j)], xT, th[L_::wb(j)]) : th[L_::wb(j)];
+        features<NS>(u, kc->lb, kc->ub, x0, g0);
+        rates<NS, NR, HAS_T>(th, x0, bT, r0);
+        rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r0, kc->scale, f0);
+        double dt;
+        {   // Hairer initial step (primal values only)
+            double d0 = 0.0, d1 = 0.0, sk[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                sk[i] = frcp(fma(fabs(u[i]), kc->rtol[i], kc->atol[i]));
+                const double a = u[i] * sk[i], c = f0[i] * sk[i];
+                d0 = fma(a, a, d0);
+                d1 = fma(c, c, d1);
+            }
+            if (HAS_T) { const double a = Tconst * frcp(fma(fabs(Tconst), kc->rtol[NS], kc->atol[NS])); d0 = fma(a, a, d0); }
+            d0 = sqrt(d0 * (1.0 / N));
+            d1 = sqrt(d1 * (1.0 / N));
+            double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 / d1);
+            dt0 = fmin(dt0, dtmax);
+            double u1[NS], x1[NS], g1[NS], r1[NR], f1[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) u1[i] = fma(dt0, f0[i], u[i]);
+            features<NS>(u1, kc->lb, kc->ub, x1, g1);
+            rates<NS, NR, HAS_T>(th, x1, bT, r1);
+            rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r1, kc->scale, f1);
+            double d2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) { const double e = (f1[i] - f0[i]) * sk[i]; d2 = fma(e, e, d2); }
+            d2 = sqrt(d2 * (1.0 / N)) / dt0;
+            const double dm = fmax(d1, d2);
+            const double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : exp(-0.5 * (4.605170185988091368 + flog(dm)));
+            dt = fmax(kc->dtmin, fmin(fmin(100.0 * dt0, dt1), dtmax));
+        }
+        double t = t0, lqold = lqinit, loss_sum = 0.0;
+        int iter = 0, jsave = 0, nacc = 0, nrej = 0, cur = 0, rc = -1;
+#pragma unroll
+        for (int q = 0; q < C; ++q) gtr[q] = 0.0;
+#pragma unroll
+        for (int q = 0; q < 2 * C * NS; ++q) S_base[q * 64] = 0.0;
+        if (ts0 == t0) {   // save_start: a loss term without gradient
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                double v = u[i];
+                if (prm.clamp_pred) v = clampv(v, -kc->ub, kc->ub);
+                if (prm.pred && chunk == 0) prm.pred[((size_t)0 * N + i) * prm.B + b] = v;
+                const int dr = (int)kc->drow[i];
+                if (dr >= 0) {
+                    const double rr = (drows[dr] - v) * kc->inv_yscale[i];
+                    loss_sum += (prm.loss_kind == 0) ? fabs(rr) : rr * rr;
+                }
+            }
+            if (HAS_T && prm.pred && chunk == 0) {
+                double v = Tconst;
+                if (prm.clamp_pred) v = clampv(v, -kc->ub, kc->ub);
+                prm.pred[((size_t)0 * N + NS) * prm.B + b] = v;
+            }
+            jsave = 1;
+        }
+
+        while (rc < 0) {
+            ++iter;
+            bool last = false;
+            if (jsave >= nsave) { rc = 0; break; }
+            if (iter > prm.maxiters) { rc = 1; break; }
+            if (t + dt * (1.0 + 1e-13) >= tend) { dt = tend - t; last = true; }
+            if (!(dt > kc->dtmin) || t + dt == t) { rc = 2; break; }
+
+            // ============================================================ PRIMAL: one Rosenbrock23 attempt
+            Solver W;
+            const double gam = d_ * dt;
+            double gr0[NR];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) gr0[j] = gam * r0[j];
+            double k1[NS], dk[NS], k3[NS], unew[NS], f1[NS], f2[NS], g2[NS], x2[NS], r2[NR], ev[NS];
+            const bool okf = W.factor(th, g0, r0, gam, kc->scale);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) k1[i] = f0[i];
+            W.solve(th, g0, gr0, kc->scale, k1);
+            {
+                double u1[NS], x1[NS], g1[NS], r1[NR];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) u1[i] = fma(0.5 * dt, k1[i], u[i]);
+                features<NS>(u1, kc->lb, kc->ub, x1, g1);
+                rates<NS, NR, HAS_T>(th, x1, bT, r1);
+                rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r1, kc->scale, f1);
+                if (lead) {
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) { rec[(R_::X1 + i) * GPW] = x1[i]; rec[(R_::G1 + i) * GPW] = g1[i]; }
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) rec[(R_::R1 + j) * GPW] = r1[j];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NS; ++i) dk[i] = f1[i] - k1[i];
+            W.solve(th, g0, gr0, kc->scale, dk);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) unew[i] = fma(dt, k1[i] + dk[i], u[i]);
+            features<NS>(unew, kc->lb, kc->ub, x2, g2);
+            rates<NS, NR, HAS_T>(th, x2, bT, r2);
+            rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r2, kc->scale, f2);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const double k2i = k1[i] + dk[i];
+                k3[i] = f2[i] - c32 * (k2i - f1[i]) - 2.0 * (k1[i] - f0[i]);
+            }
+            W.solve(th, g0, gr0, kc->scale, k3);
+            bool finite = okf;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const double k2i = k1[i] + dk[i];
+                ev[i] = dt * (1.0 / 6.0) * (k1[i] - 2.0 * k2i + k3[i]);
+                finite = finite && isfinite(unew[i]) && isfinite(ev[i]);
+            }
+            if (!finite) { rc = 3; break; }
+
+            // ---- PROVISIONAL save points of (t, tnew]: loss terms and seeds as if the attempt were accepted
+            const double tnew = last ? tend : t + dt;
+            double A_[NS], B1[NS], B2[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) { A_[i] = 0.0; B1[i] = 0.0; B2[i] = 0.0; }
+            double loss_new = loss_sum;
+            int jnew = jsave;
+            while (jnew < nsave) {
+                const double ts = ts_lds[jnew];
+                if (!(ts <= tnew)) break;
+                const bool at_end = (ts == tnew);
+                const double Th = at_end ? 1.0 : (ts - t) / dt;
+                const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
+                const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d_) * inv12d;
+                const double *row = drows + (size_t)jnew * prm.n_obs;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    const double k2i = k1[i] + dk[i];
+                    double v = at_end ? unew[i] : fma(dt, fma(c1, k1[i], c2 * k2i), u[i]);
+                    double mask = 1.0;
+                    if (prm.clamp_pred) {
+                        mask = (v > kc->ub || v < -kc->ub) ? 0.0 : 1.0;
+                        v = clampv(v, -kc->ub, kc->ub);
+                    }
+                    // a rejected attempt's values are overwritten by the accepted step that covers this save point
+                    if (prm.pred && chunk == 0) prm.pred[((size_t)jnew * N + i) * prm.B + b] = v;
+                    const int dr = (int)kc->drow[i];
+                    if (dr >= 0) {
+                        const double iy = kc->inv_yscale[i];
+                        const double rr = (row[dr] - v) * iy;
+                        double w;
+                        if (prm.loss_kind == 0) { loss_new += fabs(rr); w = signbit(rr) ? 1.0 : -1.0; }
+                        else { loss_new = fma(rr, rr, loss_new); w = -2.0 * rr; }
+                        w *= mask * iy;
+                        A_[i] += w;
+                        B1[i] = fma(w, dt * c1, B1[i]);
+                        B2[i] = fma(w, dt * c2, B2[i]);
+                    }
+                }
+                if (HAS_T && prm.pred && chunk == 0) {
+                    double v = Tconst;
+                    if (prm.clamp_pred) v = clampv(v, -kc->ub, kc->ub);
+                    prm.pred[((size_t)jnew * N + NS) * prm.B + b] = v;
+                }
+                ++jnew;
+            }
+            // ---- publish the step record
+            {
+                double c1j[NR], czd[NR], cz3[NR];
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    double z1 = 0.0, zd = 0.0, z3 = 0.0;
+#pragma unroll
+                    for (int c = 0; c < NS; ++c) {
+                        const double wg = th[L_::wi(c, j)] * g0[c];
+                        z1 = fma(wg, k1[c], z1);
+                        zd = fma(wg, dk[c], zd);
+                        z3 = fma(wg, k3[c], z3);
+                    }
+                    c1j[j] = fma(gam, z1, 1.0);
+                    czd[j] = gam * zd;
+                    cz3[j] = gam * z3;
+                }
+                if (lead) {
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        rec[(R_::X0 + i) * GPW] = x0[i]; rec[(R_::G0 + i) * GPW] = g0[i];
+                        rec[(R_::X2 + i) * GPW] = x2[i]; rec[(R_::G2 + i) * GPW] = g2[i];
+                        rec[(R_::K1 + i) * GPW] = k1[i]; rec[(R_::DK + i) * GPW] = dk[i]; rec[(R_::K3 + i) * GPW] = k3[i];
+                        rec[(R_::AA + i) * GPW] = A_[i]; rec[(R_::B1 + i) * GPW] = B1[i]; rec[(R_::B2 + i) * GPW] = B2[i];
+                    }
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        rec[(R_::R0 + j) * GPW] = r0[j]; rec[(R_::R2 + j) * GPW] = r2[j];
+                        rec[(R_::C1J + j) * GPW] = c1j[j]; rec[(R_::CZD + j) * GPW] = czd[j]; rec[(R_::CZ3 + j) * GPW] = cz3[j];
+                        rec[(R_::GR0 + j) * GPW] = gr0[j];
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            // ============================================================ TANGENTS of the attempt, C columns per lane
+            double *const Sc = S_base + (size_t)cur * C * NS * 64;         // committed columns
+            double *const Sn = S_base + (size_t)(cur ^ 1) * C * NS * 64;   // columns after this attempt
+            double ee[NS], na[NS], nb[NS], gnew[C];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) { ee[i] = 0.0; na[i] = 0.0; nb[i] = 0.0; }
+            const double hdt = 0.5 * dt;
+#pragma unroll 1
+            for (int qc = 0; qc < C; ++qc) {
+                const double *dcol = dth_lds + (chunk * C + qc) * NTHP;
+                const double *Sq = Sc + qc * NS * 64;
+                double *Sqn = Sn + qc * NS * 64;
+                // ---- pass 1 (species-major)
+                double e0[NR], e1d[NR], e2d[NR], zp1[NR], zpd[NR], zp3[NR];
+                double gq[NS], grq[NR];
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    double e = dcol[L_::wb(j)];
+                    if (HAS_T) e = fma(dcol[L_::wi(NS, j)], xT, e);
+                    e0[j] = e; e1d[j] = e; e2d[j] = e; zp1[j] = 0.0; zpd[j] = 0.0; zp3[j] = 0.0;
+                }
+#pragma unroll
+                for (int c = 0; c < NS; ++c) {
+                    const double sc_ = Sq[c * 64];
+                    const double g = rec[(R_::G0 + c) * GPW];
+                    gq[c] = g;
+                    const double x0c = rec[(R_::X0 + c) * GPW], x1c = rec[(R_::X1 + c) * GPW], x2c = rec[(R_::X2 + c) * GPW];
+                    const double k1c = rec[(R_::K1 + c) * GPW], dkc = rec[(R_::DK + c) * GPW], k3c = rec[(R_::K3 + c) * GPW];
+                    const double gsv = g * sc_;
+                    const double hsv = -g * gsv;   // g' = -g^2 s inside the window (g = 1/u), 0 outside
+                    na[c] = fma(sc_, sc_, na[c]);
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        const double dwi = dcol[L_::wi(c, j)];
+                        const double wi = th[L_::wi(c, j)];
+                        e0[j] = fma(dwi, x0c, e0[j]);
+                        e0[j] = fma(wi, gsv, e0[j]);
+                        e1d[j] = fma(dwi, x1c, e1d[j]);
+                        e2d[j] = fma(dwi, x2c, e2d[j]);
+                        const double m = fma(dwi, g, wi * hsv);
+                        zp1[j] = fma(m, k1c, zp1[j]);
+                        zpd[j] = fma(m, dkc, zpd[j]);
+                        zp3[j] = fma(m, k3c, zp3[j]);
+                    }
+                }
+                CRNN_SCHED_FENCE();
+                // ---- pass 2 (reaction-major)
+                double rhs1[NS], w2[NS], w3[NS], f0p[NS], f1d[NS], f2d[NS];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) { rhs1[i] = 0.0; w2[i] = 0.0; w3[i] = 0.0; f0p[i] = 0.0; f1d[i] = 0.0; f2d[i] = 0.0; }
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    const double r0j = rec[(R_::R0 + j) * GPW], r1j = rec[(R_::R1 + j) * GPW], r2j = rec[(R_::R2 + j) * GPW];
+                    const double gr = rec[(R_::GR0 + j) * GPW];
+                    grq[j] = gr;
+                    const double c1 = rec[(R_::C1J + j) * GPW], cz = rec[(R_::CZD + j) * GPW], c3 = rec[(R_::CZ3 + j) * GPW];
+                    const double y1 = gr * zp1[j], yd = gr * zpd[j], y3 = gr * zp3[j];
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        const double wo = th[L_::wo(i, j)];
+                        const double dwo = dcol[L_::wo(i, j)];
+                        const double H = fma(wo, e0[j], dwo) * r0j;
+                        rhs1[i] = fma(H, c1, rhs1[i]);
+                        rhs1[i] = fma(wo, y1, rhs1[i]);
+                        w2[i] = fma(H, cz, w2[i]);
+                        w2[i] = fma(wo, yd, w2[i]);
+                        w3[i] = fma(H, c3, w3[i]);
+                        w3[i] = fma(wo, y3, w3[i]);
+                        f0p[i] += H;
+                        f1d[i] = fma(dwo, r1j, f1d[i]);
+                        f2d[i] = fma(dwo, r2j, f2d[i]);
+                    }
+                }
+                if (USE_SCALE) {
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) { const double sc = kc->scale[i]; rhs1[i] *= sc; w2[i] *= sc; w3[i] *= sc; f0p[i] *= sc; }
+                }
+                CRNN_SCHED_FENCE();
+                W.solve(th, gq, grq, kc->scale, rhs1);   // k1'
+                CRNN_SCHED_FENCE();
+                // f1' at u1 with s1 = s + dt/2 k1'
+                double f1p[NS];
+                {
+                    double gs1[NS];
+#pragma unroll
+                    for (int c = 0; c < NS; ++c) gs1[c] = rec[(R_::G1 + c) * GPW] * fma(hdt, rhs1[c], Sq[c * 64]);
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) f1p[i] = f1d[i];
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        double e = e1d[j];
+#pragma unroll
+                        for (int c = 0; c < NS; ++c) e = fma(th[L_::wi(c, j)], gs1[c], e);
+                        const double er = e * rec[(R_::R1 + j) * GPW];
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) f1p[i] = fma(th[L_::wo(i, j)], er, f1p[i]);
+                    }
+                    if (USE_SCALE) {
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) f1p[i] *= kc->scale[i];
+                    }
+                }
+                CRNN_SCHED_FENCE();
+                double rhs2[NS];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) rhs2[i] = f1p[i] - rhs1[i] + w2[i];
+                W.solve(th, gq, grq, kc->scale, rhs2);   // (k2 - k1)'
+                double k2p[NS], acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    const double si = Sq[i * 64];
+                    k2p[i] = rhs1[i] + rhs2[i];
+                    acc = fma(rec[(R_::AA + i) * GPW], si, acc);
+                    acc = fma(rec[(R_::B1 + i) * GPW], rhs1[i], acc);
+                    acc = fma(rec[(R_::B2 + i) * GPW], k2p[i], acc);
+                    const double sn = fma(dt, k2p[i], si);
+                    Sqn[i * 64] = sn;
+                    nb[i] = fma(sn, sn, nb[i]);
+                }
+                gnew[qc] = acc;
+                CRNN_SCHED_FENCE();
+                // f2' at u+ with s+ ; then W k3' = f2' - c32 (k2' - f1') - 2 (k1' - f0') + gam J' k3
+                double rhs3[NS];
+                {
+                    double gs2[NS];
+#pragma unroll
+                    for (int c = 0; c < NS; ++c) gs2[c] = rec[(R_::G2 + c) * GPW] * Sqn[c * 64];
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) rhs3[i] = f2d[i];
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        double e = e2d[j];
+#pragma unroll
+                        for (int c = 0; c < NS; ++c) e = fma(th[L_::wi(c, j)], gs2[c], e);
+                        const double er = e * rec[(R_::R2 + j) * GPW];
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) rhs3[i] = fma(th[L_::wo(i, j)], er, rhs3[i]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    const double f2p = USE_SCALE ? rhs3[i] * kc->scale[i] : rhs3[i];
+                    rhs3[i] = f2p - c32 * (k2p[i] - f1p[i]) - 2.0 * (rhs1[i] - f0p[i]) + w3[i];
+                }
+                W.solve(th, gq, grq, kc->scale, rhs3);   // k3'
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    const double de = dt * (1.0 / 6.0) * (rhs1[i] - 2.0 * k2p[i] + rhs3[i]);
+                    ee[i] = fma(de, de, ee[i]);
+                }
+            }
+            // ---- the group's dual-inclusive error norm and the decision (identical on the L lanes of the group)
+            double es = 0.0;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const double nai = fma(u[i], u[i], group_sum(na[i]));
+                const double nbi = fma(unew[i], unew[i], group_sum(nb[i]));
+                const double eei = fma(ev[i], ev[i], group_sum(ee[i]));
+                const double sc = fma(kc->rtol[i], sqrt(fmax(nai, nbi)), kc->atol[i]);
+                es += eei / (sc * sc);
+            }
+            es = es * (1.0 / N);
+            if (!isfinite(es)) { rc = 3; break; }
+            const bool ee_zero = (es == 0.0);
+            const double lEE = 0.5 * flog(ee_zero ? 1.0 : es);
+            const double lq11 = kc->beta1 * lEE;
+            double q = ee_zero ? 1.0 / kc->qmax
+                               : fmax(1.0 / kc->qmax, fmin(1.0 / kc->qmin, exp(lq11 - kc->beta2 * lqold) / kc->gamma));
+            if (es <= 1.0) {   // commit
+                ++nacc;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) { u[i] = unew[i]; f0[i] = f2[i]; g0[i] = g2[i]; x0[i] = x2[i]; }
+#pragma unroll
+                for (int j = 0; j < NR; ++j) r0[j] = r2[j];
+#pragma unroll
+                for (int qc = 0; qc < C; ++qc) gtr[qc] += gnew[qc];
+                cur ^= 1;
+                loss_sum = loss_new;
+                jsave = jnew;
+                t = tnew;
+                if (q >= kc->qsteady_min && q <= kc->qsteady_max) q = 1.0;
+                lqold = ee_zero ? lqinit : fmax(lEE, lqinit);
+                dt = fmin(dt / q, dtmax);
+                if (jsave >= nsave) rc = 0;
+            } else {
+                ++nrej;
+                dt = dt / fmin(1.0 / kc->qmin, exp(lq11) / kc->gamma);
+            }
+            __builtin_amdgcn_wave_barrier();   // the record is rewritten by the next attempt
+        }
+
+        const double denom = (double)prm.n_obs * (double)jsave;
+        const double inv_den = jsave > 0 ? 1.0 / denom : 0.0;
+        if (chunk == 0) {
+            prm.loss[b] = loss_sum * inv_den;
+            prm.retcode[b] = rc;
+            prm.n_saved[b] = jsave;
+            prm.n_accept[b] = nacc;
+            prm.n_reject[b] = nrej;
+        }
+        double *grow = prm.gtraj + (size_t)traj * PPAD + chunk * C;
+#pragma unroll
+        for (int q_ = 0; q_ < C; ++q_) grow[q_] = gtr[q_] * inv_den;
+    }
+}
+
+}  // namespace crnn

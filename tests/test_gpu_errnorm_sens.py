@@ -1,0 +1,111 @@
+"""errnorm_sens = 1 on the device: the step-size controller of a GRADIENT call sees ForwardDiff's dual-inclusive error norm
+(reference: ForwardDiff.gradient through the adaptive solver, case2/case2.jl:195, robertson/rober_crnn.jl:219), chunked the
+way ForwardDiff chunks P (25 -> 9 + 9 + 7, 43 -> 11 + 11 + 11 + 10, 24 -> 12 + 12): every chunk is its own adaptive solve.
+HIP kernel (ros23_sens_kernel.hpp) vs the oracle's errnorm_sens = 1 on the same chunk of directions: identical accepted /
+rejected step counts, gradients to 1e-7 of max |grad|.  [UNVERIFIED-DEP]: the norm itself is a restatement of
+DiffEqBase.ODE_DEFAULT_NORM on Dual arrays (oracle header)."""
+import numpy as np
+import pytest
+
+from conftest import oracle_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(case, case2_setup, rober_setup, fx):
+    from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE1, PRESET_CASE2, PRESET_ROBER, SOLVER_ROSENBROCK23, cases
+    if case == "case2":
+        s = case2_setup
+        mk = lambda **kw: NeuralODE(ODEProblem(PRESET_CASE2, s["tsteps"], **kw))
+        return s, mk, (2, 6, 3), lambda orc, **kw: oracle_problem(orc, "case2", s, **kw)
+    if case == "rober":
+        s = rober_setup
+        mk = lambda **kw: NeuralODE(ODEProblem(PRESET_ROBER, s["tsteps"], rate_scale=s["dydt_scale"], **kw))
+        return s, mk, (3, 3, 6), lambda orc, **kw: oracle_problem(orc, "rober", s, **kw)
+    rng = np.random.Generator(np.random.PCG64(12))
+    ts = cases.case1_tsteps()
+    u0 = np.array(fx["case1"]["u0"])
+    gen = NeuralODE(ODEProblem(PRESET_CASE1, ts, atol=1e-12, rtol=1e-10))
+    data = cases.add_noise(gen.predict_theta(u0, cases.case1_true_theta()), 0.05, rng)
+    gen.close()
+    ys = cases.max_min(data, lb=1e-5)
+    s = dict(u0=u0, tsteps=ts, data=data, yscale=ys, p_ckpt=np.array(fx["case1"]["p"]))
+    mk = lambda **kw: NeuralODE(ODEProblem(PRESET_CASE1, ts, solver=SOLVER_ROSENBROCK23, **kw))
+    mkpb = lambda orc, **kw: orc.make_problem(ns=5, nr=4, lb=1e-5, ub=10.0, atol=1e-5, rtol=1e-2, yscale=ys, clamp_pred=1,
+                                              maxiters=10000, solver=0, **kw)
+    return s, mk, (1, 5, 4), mkpb
+
+
+@pytest.mark.parametrize("case,pkey", [("case2", "p_ckpt"), ("case2", "p_init"), ("rober", "p_ckpt"), ("case1", "p_ckpt")])
+def test_chunked_dual_norm_gradient_matches_oracle(orc, fx, case2_setup, rober_setup, case, pkey):
+    from crnn_amd.api import fd_chunk_size
+    s, mk, (kind, ns, nr), mkpb = _setup(case, case2_setup, rober_setup, fx)
+    p = s[pkey]
+    node = mk(errnorm_sens=1)
+    node.set_ensemble(s["u0"], s["data"], s["yscale"])
+    th, dth = orc.p2vec(kind, ns, nr, p)
+    P = dth.shape[1]
+    chunk = fd_chunk_size(P)
+    assert chunk == {25: 9, 43: 11, 24: 12}[P]
+    pb1 = mkpb(orc, errnorm_sens=1)
+    B = s["u0"].shape[0]
+    differs = 0
+    for b in range(min(B, 6)):
+        g = node.gradient(p, b)
+        plain = orc.solve_one(mkpb(orc), th, s["u0"][b], s["tsteps"], s["data"][b], dtheta=None)
+        gref = np.zeros(P)
+        for c, k0 in enumerate(range(0, P, chunk)):
+            k1 = min(P, k0 + chunk)
+            r = orc.solve_one(pb1, th, s["u0"][b], s["tsteps"], s["data"][b], dtheta=dth[:, k0:k1], want_pred=False)
+            gref[k0:k1] = r["grad"]
+            assert node.last_chunk_stats[c] == (r["naccept"], r["nreject"]), (case, b, c)
+            differs += (r["naccept"], r["nreject"]) != (plain["naccept"], plain["nreject"])
+        assert np.max(np.abs(g - gref)) < 1e-7 * np.max(np.abs(gref)), (case, b)
+    assert differs > 0        # the dual-inclusive norm really changes the step sequence somewhere
+
+
+def test_loss_grad_and_training_step_assemble_the_chunks(orc, case2_setup):
+    """crnn_loss_grad / crnn_train_step with errnorm_sens = 1: gradient = concatenated chunk gradients (oracle, batched),
+    loss and step statistics = those of the plain solve (what loss_neuralode evaluates); the device training step equals
+    host gradient + update!."""
+    from crnn_amd import NeuralODE, ODEProblem, Optimiser, PRESET_CASE2
+    from crnn_amd.api import fd_chunk_size
+    s = case2_setup
+    p = s["p_init"]
+    node = NeuralODE(ODEProblem(PRESET_CASE2, s["tsteps"], errnorm_sens=1))
+    node.set_ensemble(s["u0"], s["data"], s["yscale"])
+    loss, grad = node.loss_and_grad(p)
+    th, dth = orc.p2vec(2, 6, 3, p)
+    B = s["u0"].shape[0]
+    u0T = np.ascontiguousarray(s["u0"].T); dT = np.ascontiguousarray(s["data"].transpose(2, 1, 0))
+    pb1 = oracle_problem(orc, "case2", s, errnorm_sens=1)
+    gref = np.zeros(25)
+    for k0 in range(0, 25, 9):
+        k1 = min(25, k0 + 9)
+        gref[k0:k1] = orc.solve_batch(pb1, th, u0T, s["tsteps"], dT, dtheta=dth[:, k0:k1])["grad"] / B
+    plain = orc.solve_batch(oracle_problem(orc, "case2", s), th, u0T, s["tsteps"], dT)
+    assert abs(loss - plain["loss"].mean()) < 1e-9 * abs(loss)
+    assert node.last_stats["n_accept"] == plain["naccept"] and node.last_stats["n_reject"] == plain["nreject"]
+    assert np.max(np.abs(grad - gref)) < 1e-7 * np.max(np.abs(gref))
+    # the primal-only norm gives a (slightly) different gradient: the two modes are distinguishable
+    node0 = NeuralODE(ODEProblem(PRESET_CASE2, s["tsteps"]))
+    node0.set_ensemble(s["u0"], s["data"], s["yscale"])
+    _, g0 = node0.loss_and_grad(p)
+    assert 1e-9 < np.max(np.abs(g0 - grad)) / np.max(np.abs(grad)) < 1e-1
+    # training step == host chain
+    opt_h = Optimiser(25, PRESET_CASE2); p_h = p.copy()
+    node.train_init(Optimiser(25, PRESET_CASE2), p)
+    for _ in range(3):
+        l_h, g_h = node.loss_and_grad(p_h)
+        opt_h.update_(p_h, g_h)
+        l_d = node.train_step()
+        assert abs(l_d - l_h) < 1e-12 * abs(l_h) and np.max(np.abs(node.params() - p_h)) < 1e-12
+    node.close(); node0.close()
+
+
+def test_errnorm_sens_rejects_unsupported_combinations():
+    from crnn_amd import CrnnError, NeuralODE, ODEProblem, PRESET_CASE1, PRESET_CASE2, cases
+    with pytest.raises(CrnnError, match="errnorm_sens"):
+        NeuralODE(ODEProblem(PRESET_CASE1, cases.case1_tsteps(), errnorm_sens=1))          # Tsit5
+    with pytest.raises(CrnnError, match="errnorm_sens"):
+        NeuralODE(ODEProblem(PRESET_CASE2, cases.case2_tsteps(), errnorm_sens=1, grad_mode=2))

@@ -84,12 +84,23 @@ def main(argv=None):
             break
     wall = time.perf_counter() - t0
     lnA, Ea = decode(p)
+    # the order of the learned reactions is arbitrary: match them to the true ones by the rate constant at 333 K
+    # (ln k = lnA + Ea * inv_R / T), and compare ln k over the training range 323 - 343 K (lnA and Ea compensate each other)
+    import itertools
+    lnk = lambda a, e, T: np.asarray(a) + np.asarray(e) * cases.INV_R / T
+    perm = min(itertools.permutations(range(3)),
+               key=lambda pm: float(np.sum(np.abs(lnk(lnA[list(pm)], Ea[list(pm)], 333.0) - lnk(cases.CASE2_LOGA, cases.CASE2_EA, 333.0)))))
+    perm = list(perm)
+    lnA, Ea = lnA[perm], Ea[perm]
+    dlnk = {str(T): (lnk(lnA, Ea, T) - lnk(cases.CASE2_LOGA, cases.CASE2_EA, T)).tolist() for T in (323.0, 333.0, 343.0)}
     fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fixtures.json")))
     lnA_ck, Ea_ck = decode(np.array(fx["case2_ckpt"]["p"]))
     out = dict(reached_epoch=reached, epochs_run=len(hist), updates=len(hist) * n_train, wall_s=wall,
                final_loss_train=hist[-1][1], final_loss_val=hist[-1][2],
                lnA=lnA.tolist(), Ea=Ea.tolist(), lnA_true=list(map(float, cases.CASE2_LOGA)), Ea_true=list(map(float, cases.CASE2_EA)),
                lnA_ref_ckpt=lnA_ck.tolist(), Ea_ref_ckpt=Ea_ck.tolist(),
+               reaction_order=perm, dlnk_vs_true=dlnk,
+               dlnk_ref_ckpt_vs_true={str(T): (lnk(lnA_ck, Ea_ck, T) - lnk(cases.CASE2_LOGA, cases.CASE2_EA, T)).tolist() for T in (323.0, 333.0, 343.0)},
                hardest_epoch=hardest, p=p.tolist(), seed=args.seed,
                steps_per_traj_first_last=[hist[0][3], hist[-1][3]], max_rejects_per_traj=max(h[4] for h in hist))
     if not args.quiet:
@@ -100,6 +111,8 @@ def main(argv=None):
         print(f"learned   {lnA}   {Ea}")
         print(f"true      {np.array(out['lnA_true'])}   {np.array(out['Ea_true'])}      (case2.jl:52-53)")
         print(f"ref ckpt  {lnA_ck}   {Ea_ck}      (case2/checkpoint/mymodel.bson, 3 700 epochs)")
+        print(f"ln k(T) - ln k_true(T), learned:  " + "  ".join(f"{T} K {np.array(v)}" for T, v in dlnk.items()))
+        print(f"ln k(T) - ln k_true(T), ref ckpt: " + "  ".join(f"{T} K {np.array(v)}" for T, v in out["dlnk_ref_ckpt_vs_true"].items()))
         print(f"hardest healthy epoch: {hardest.get('epoch')} with {hardest.get('accept', 0):.1f} accepted + {hardest.get('reject', 0):.1f} rejected steps per trajectory")
     if args.json:
         json.dump(out, open(args.json, "w"), indent=1)
