@@ -139,6 +139,10 @@ struct Ctx {
     double *d_tape = nullptr;
     size_t tape_doubles = 0;
     unsigned int *d_overflow = nullptr;
+    // queue order of ensembles larger than the resident lanes (sort_steps_kernel): by the step counts of the previous launch
+    int32_t *d_perm = nullptr, *d_perm_tmp = nullptr;
+    size_t perm_cap = 0, perm_tmp_cap = 0;
+    int64_t steps_first = 0, steps_count = 0;   // [first, first+count) whose d_nacc / d_nrej hold a completed launch's counts
     double *d_red_theta = nullptr;  // [n_theta + kExtra]
     int64_t n_fallback = 0;         // calls repeated with forward tangents after a tape overflow
     int adj_occ = 0;                // cached occupancy of the adjoint kernel
@@ -417,6 +421,19 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
     fill_params(c, prm, P, first, count, n_save_active, want_pred);
     crnn::AdjParams adj{};
     adj.tape = c->d_tape; adj.tape_cap = (int32_t)cap; adj.overflow = c->d_overflow; adj.batch_partials = c->d_partials;
+    adj.perm = nullptr;
+    // more trajectories than resident lanes: wavefronts take several batches from the queue one after the other; queue the
+    // trajectories by their last known step counts so that batches are homogeneous (the counts of the previous launch over
+    // the same range: in training p moves little from step to step)
+    const bool sortable = k->solver == CRNN_SOLVER_ROSENBROCK23 && (size_t)count > lanes && count < ((int64_t)1 << 31) &&
+                          first >= c->steps_first && first + count <= c->steps_first + c->steps_count;
+    if (sortable) {
+        if (ensure(c, &c->d_perm, &c->perm_cap, (size_t)count) || ensure(c, &c->d_perm_tmp, &c->perm_tmp_cap, (size_t)count)) return -1;
+        hipLaunchKernelGGL(crnn::sort_steps_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_nacc, c->d_nrej, first, (int)count,
+                           c->d_perm, c->d_perm_tmp);
+        HIP_TRY(c, hipGetLastError());
+        adj.perm = c->d_perm;
+    }
     if (upload_consts(c)) return -1;
     if (!c->flags_zeroed) {
         HIP_TRY(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), c->stream));
@@ -435,6 +452,7 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
     HIP_TRY(c, hipGetLastError());
     c->last_npart = npart;
     c->last_P = P;
+    c->steps_first = first; c->steps_count = count;     // d_nacc / d_nrej of this range are current once the launch has run
     if (defer) return 0;   // the device-resident training loop looks at the outcome later (check_pending)
     unsigned int ovf = 0;
     HIP_TRY(c, hipMemcpyAsync(&ovf, c->d_overflow, sizeof(ovf), hipMemcpyDeviceToHost, c->stream));
@@ -987,7 +1005,7 @@ void crnn_ctx_destroy(crnn_ctx *ctx) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->own_u0 && c->d_u0) (void)hipFree(c->d_u0);
     if (c->own_data && c->d_data) (void)hipFree(c->d_data);
-    void *ptrs[] = {c->d_red_asm, c->d_poison, c->d_tabs, c->d_gacc, c->d_tape, c->d_overflow, c->d_red_theta, c->d_queue, c->d_nacc, c->d_nrej, c->d_gtraj, c->d_kc, c->d_tsave, c->d_pred, c->d_loss, c->d_ret, c->d_nsaved, c->d_theta, c->d_dtheta,
+    void *ptrs[] = {c->d_perm, c->d_perm_tmp, c->d_red_asm, c->d_poison, c->d_tabs, c->d_gacc, c->d_tape, c->d_overflow, c->d_red_theta, c->d_queue, c->d_nacc, c->d_nrej, c->d_gtraj, c->d_kc, c->d_tsave, c->d_pred, c->d_loss, c->d_ret, c->d_nsaved, c->d_theta, c->d_dtheta,
                     c->d_partials, c->d_red, c->d_p, c->d_p_eval, c->d_opt, c->d_comm_buf};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < Ctx::kRing; ++i) {
@@ -1037,6 +1055,7 @@ static int32_t set_data_common(Ctx *c, const double *tsteps, const double *yscal
     }
     c->n_obs = n_obs;
     c->kc_dirty = true;
+    c->steps_first = 0; c->steps_count = 0;     // a new ensemble: no step counts known yet
     for (int j = 1; j < c->cfg.n_save; ++j)
         if (!(tsteps[j] > tsteps[j - 1])) return fail(c, "crnn_ctx_set_data: tsteps must be strictly increasing");
     if (tsteps[0] < c->cfg.t0) return fail(c, "crnn_ctx_set_data: tsteps[0] < t0");

@@ -56,6 +56,7 @@ struct AdjParams {
     int32_t tape_cap;            // accepted steps a lane can record
     unsigned int *overflow;      // incremented by every trajectory that ran out of tape (host then falls back)
     double *batch_partials;      // [ceil(count/64)][NTH + kExtra]: per 64-trajectory batch sums
+    const int32_t *perm;         // ros23_adj_kernel: position in the queue -> trajectory (relative to first); null = identity
 };
 
 // Solve A^T x = b with the factors of lu_factor (P A = L U): x = P^T L^-T U^-T b
@@ -168,7 +169,10 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
         if (wave_base >= prm.count) break;
         const int64_t traj = wave_base + lane;
         const bool valid = traj < prm.count;
-        const int64_t b = prm.first + (valid ? traj : 0);
+        // Ensembles larger than the resident lanes are queued in the order of their last known step counts, longest
+        // first (sort_steps_kernel): the 64 trajectories of a batch then take nearly the same number of steps, and a
+        // wavefront is busy for its batch's mean rather than for its slowest member.
+        const int64_t b = prm.first + (valid ? (adj.perm ? (int64_t)adj.perm[traj] : traj) : 0);
 
         // ================================================================== forward sweep
         double u[NS], f0[NS], g0[NS], r0[NR], bT[NR];
@@ -668,6 +672,68 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
         }
 #undef THB_ADD
 #undef THB_REG
+    }
+}
+
+// Queue order for ensembles larger than the resident lanes: perm = trajectories [0, count) sorted by the step count
+// (accepted + rejected) of their previous launch, longest first; ties keep their index order (stable), so the order -- and
+// with it the composition of every 64-trajectory batch and the rounding of the batch sums -- is a deterministic function
+// of the previous launch.  One block: two passes of a 5-bit LSD counting sort over keys clamped to 1023, every thread
+// owning a contiguous chunk (stability), per-thread digit counts in LDS.
+__global__ __launch_bounds__(1024) void sort_steps_kernel(const int32_t *__restrict__ n_accept, const int32_t *__restrict__ n_reject,
+                                                          int64_t first, int count, int32_t *__restrict__ perm,
+                                                          int32_t *__restrict__ tmp) {
+    __shared__ int hist[32 * 1024];    // [digit][thread]
+    __shared__ int tsum[1024];
+    const int tid = threadIdx.x;
+    const int cs = (count + 1023) / 1024;
+    const int lo = min(tid * cs, count), hi = min(lo + cs, count);
+    auto key_of = [&](int k) -> int {
+        const int steps = n_accept[first + k] + n_reject[first + k];
+        return 1023 - min(max(steps, 0), 1023);      // descending in steps
+    };
+    for (int pass = 0; pass < 2; ++pass) {
+        const int shift = 5 * pass;
+        const int32_t *src = pass == 0 ? nullptr : tmp;
+        int32_t *dst = pass == 0 ? tmp : perm;
+        int h[32];
+#pragma unroll
+        for (int d = 0; d < 32; ++d) h[d] = 0;
+        for (int k = lo; k < hi; ++k) {
+            const int e = src ? src[k] : k;
+            const int d = (key_of(e) >> shift) & 31;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) h[q] += (q == d);
+        }
+#pragma unroll
+        for (int d = 0; d < 32; ++d) hist[d * 1024 + tid] = h[d];
+        __syncthreads();
+        // exclusive prefix over the flattened [digit][thread] table: thread t owns entries [32 t, 32 t + 32)
+        int loc = 0;
+        for (int q = 0; q < 32; ++q) loc += hist[tid * 32 + q];
+        tsum[tid] = loc;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int v = tid >= off ? tsum[tid - off] : 0;
+            __syncthreads();
+            tsum[tid] += v;
+            __syncthreads();
+        }
+        int run = tsum[tid] - loc;
+        for (int q = 0; q < 32; ++q) { const int v = hist[tid * 32 + q]; hist[tid * 32 + q] = run; run += v; }
+        __syncthreads();
+#pragma unroll
+        for (int d = 0; d < 32; ++d) h[d] = hist[d * 1024 + tid];
+        for (int k = lo; k < hi; ++k) {
+            const int e = src ? src[k] : k;
+            const int d = (key_of(e) >> shift) & 31;
+            int o = 0;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) { o = (q == d) ? h[q] : o; h[q] += (q == d); }
+            dst[o] = e;
+        }
+        __threadfence();
+        __syncthreads();
     }
 }
 

@@ -311,3 +311,36 @@ def test_two_gpu_data_parallel_bench_when_available():
     line = json.loads(run.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 16384 and line["value"] > 0
     assert line["config"]["comm"] in ("rccl", "torch")
+
+
+def test_ensemble_larger_than_the_resident_lanes_is_queued_by_step_count(orc, fx):
+    """B = 3 x 65 536 (three generations of wavefronts on a 256-CU part): from the second gradient launch over the same
+    range on, the queue is ordered by the previous launch's step counts (sort_steps_kernel: stable, longest first), so every
+    64-trajectory batch is homogeneous.  The order changes which trajectories share a batch sum, nothing else: per-
+    trajectory results are bit-identical, the batch gradient equal to rounding, and -- the order being a deterministic
+    function of the previous launch -- the sorted launch itself is bitwise reproducible."""
+    B = 3 * B_FULL
+    ts, u0, data, ys = _case2_ensemble(B, seed=77)
+    s = dict(tsteps=ts, u0=u0, data=data, yscale=ys)
+    p = np.array(fx["case2_ckpt"]["p"])
+    node = _node(s)
+    loss1, grad1 = node.loss_and_grad(p)            # no step counts known yet: index order
+    ms1 = node.last_stats["kernel_ms"]
+    st1 = dict(node.last_stats)
+    loss2, grad2 = node.loss_and_grad(p)            # queued by the counts of launch 1
+    ms2 = node.last_stats["kernel_ms"]
+    loss3, grad3 = node.loss_and_grad(p)
+    assert node.last_stats["n_accept"] == st1["n_accept"] and node.last_stats["n_ok"] == B
+    assert abs(loss2 - loss1) < 1e-13 * loss1 and np.max(np.abs(grad2 - grad1)) < 1e-11 * np.max(np.abs(grad1))
+    assert loss3 == loss2 and np.array_equal(grad3, grad2)
+    losses = node.losses(p)
+    assert abs(losses.mean() - loss2) < 1e-13 * loss2
+    idx = np.random.default_rng(3).choice(B, 24, replace=False)
+    th, dth = orc.p2vec(2, 6, 3, p)
+    pb = oracle_problem(orc, "case2", s)
+    for i in idx:
+        r = orc.solve_one(pb, th, u0[i], ts, data[i], dtheta=None, want_pred=False)
+        assert abs(losses[i] - r["loss"]) < 1e-9 * r["loss"]
+    print(f"B = {B}: kernel {ms1:.3f} ms in index order, {ms2:.3f} ms queued by step count")
+    assert ms2 < ms1                                # homogeneous batches are the point
+    node.close()
