@@ -9,7 +9,7 @@ One "step" = one pass of the hot path over the rank's batch, with the ensemble
 already resident in HBM: solve + loss + gradient kernel (65 536 trajectories;
 --grad adjoint: forward sweep + reversed accepted steps, one lane per trajectory;
 --grad forward: P tangent columns on lane groups) -> fixed-order gradient
-reduction + chain rule through p2vec -> all-reduce of the (P+5)-vector over ranks
+reduction + chain rule through p2vec -> all-reduce of the (P+6)-vector over ranks
 (RCCL) -> Flux-style ExpDecay/ADAM/WeightDecay update of p on the device (the same
 kernel forms p2vec of the new p).  Weak scaling: every rank owns its own 65 536 ICs.
 
@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--grad", choices=["auto", "forward", "adjoint"], default="auto",
                     help="gradient algorithm: discrete adjoint of the accepted steps (auto) or forward tangents")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (other configs / regimes, N = 1 only)")
     ap.add_argument("--cpu-sample", type=int, default=65536)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall time to spend on the CPU baseline")
     return ap.parse_args()
@@ -248,6 +249,49 @@ def main():
                                    "sample": f"{passes} passes over the first {ns_} ICs of the same ensemble, solve+loss+gradient "
                                              f"(forward tangents, ForwardDiff's arithmetic) at the same p, C oracle with OpenMP over "
                                              f"trajectories ({tc:.1f} s wall); a C restatement, not DifferentialEquations.jl (Julia absent)"}
+        # ---- secondary figures (N = 1): the same hot path at FIXED parameters on the other regimes / BASELINE configs ----
+        if world == 1 and not args.no_secondary:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_secondary as bs
+            sec = {}
+            ck = np.array(fx["case2_ckpt"]["p"])
+            p_init = cases.case2_init_p(np.random.Generator(np.random.PCG64(7)))
+            p_hard = np.array(json.load(open(os.path.join(ROOT, "tests", "golden", "case2_hard_p.json")))["p"])
+            note = "case2, 65 536 ICs of the headline ensemble, Rosenbrock23 atol 1e-6 rtol 1e-3, adjoint gradient, fixed p: "
+            sec["case2_reference_init_p"] = bs.case2_fixed(u0, data, yscale, p_init, {"workload": note + "the reference's random initialiser (case2.jl:85-89)"})
+            sec["case2_early_training_p"] = bs.case2_fixed(u0, data, yscale, p_hard, {
+                "workload": note + "p after epoch 2 of a reference-schedule training run from that initialiser -- the hardest state a healthy run "
+                                   "visits (tests/golden/case2_hard_p.json, tools/train_case2_converge.py)"})
+            # 30 FULL-BATCH ADAM steps from the initialiser (what --theta0 init times): after four such updates the
+            # network sits in a sliding mode on the kink of log(clamp(u, lb, ub)) -- about 10 % of the trajectories alternate
+            # accepted and rejected steps thousands of times and their tangents overflow (1e175), ADAM's second moment swallows
+            # the update and training stalls at loss 0.237.  The CPU restatement reproduces all of it step for step; it is a
+            # diverged training state of this schedule (the reference updates per experiment), timed here for the record.
+            nd = NeuralODE(ODEProblem(PRESET_CASE2, ts, device=local_rank))
+            nd.set_ensemble(u0, data, yscale)
+            nd.train_init(Optimiser(25, PRESET_CASE2), p_init)
+            for _ in range(30):
+                nd.train_step(want_loss=False)
+            p_deg = nd.params()
+            nd.close()
+            sec["case2_after_30_full_batch_adam_steps_from_init"] = bs.case2_fixed(u0, data, yscale, p_deg, {
+                "workload": note + "p after 30 full-batch ADAM steps from the initialiser: a diverged (sliding-mode) state, launch time = the longest "
+                                   "trajectory's thousands of attempts; see DESIGN.md"}, reps=3)
+            sec["case2_errnorm_sens1"] = bs.case2_fixed(u0, data, yscale, ck, {
+                "workload": note + "errnorm_sens = 1 (ForwardDiff's dual-inclusive error norm, chunks 9 + 9 + 7, forward tangents through every "
+                                   "attempt) + the plain solve for the loss: the reference-faithful gradient mode; kernel_ms is the LAST launch only, "
+                                   "call_ms the whole loss+gradient call"}, reps=3, errnorm_sens=1)
+            sec["case2_errnorm_sens1"]["value"] = B / (sec["case2_errnorm_sens1"]["call_ms"] * 1e-3)
+            ub_, db_, yb_ = bs.case2_ensemble(262144, [1234, 99], device=local_rank)
+            for nb in (131072, 262144):
+                sec[f"case2_B{nb}"] = bs.case2_fixed(ub_[:nb], db_[:nb], yb_, ck, {
+                    "workload": f"case2, {nb} ICs on one GPU (more than the 65 536 resident lanes: queued by the previous launch's step counts), "
+                                "checkpoint p, adjoint gradient"})
+            del ub_, db_
+            sec["robertson_B65536"] = bs.robertson(device=local_rank)
+            sec["hychem_B32768"] = bs.hychem(device=local_rank)
+            sec["cathode_4096x256"] = bs.cathode(device=local_rank)
+            out["secondary"] = sec
         # RCCL prints a version banner through C stdio (block-buffered on a pipe): flush it first so
         # that the JSON line is the LAST line of stdout.
         C.CDLL(None).fflush(None)

@@ -1,0 +1,135 @@
+"""Secondary measured figures for bench.py's JSON line (rank 0, N = 1 only): the same hot path at fixed parameters on the
+other BASELINE configurations and regimes.  Every entry: kernel time = median HIP-event duration of the solve kernel over
+`reps` loss+gradient calls (crnn_stats.kernel_ms), value = trajectories+gradients per second of that kernel, `roofline` =
+algorithmic HBM bytes per trajectory x trajectories / kernel time against 8 TB/s, plus the step statistics
+the kernel reports.  Ensembles are synthetic and seeded; nothing here reads /root/reference.
+"""
+import json
+import os
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HBM_PEAK_GBS = 8000.0
+# 8 * [n (u0) + n_obs * D (data) + loss + (retcode, n_saved)] bytes per trajectory (+ 8 P for per-trajectory gradients)
+BYTES = {"case2": 8 * (7 + 6 * 50 + 2), "robertson": 8 * (3 + 3 * 40 + 2), "hychem": 8 * (9 + 9 * 40 + 2),
+         "cathode": 8 * (3 + 17 + 64 + 2 + 17)}
+
+
+def _entry(kind, B, kms, st, extra=None, wall_ms=None):
+    k = float(np.median(kms))
+    gbs = BYTES[kind] * B / (k * 1e-3) / 1e9
+    e = {"trajectories": int(B), "kernel_ms": k, "value": B / (k * 1e-3), "unit": "trajectories+grads/s",
+         "steps_per_traj": st["n_accept"] / max(st["n_traj"], 1), "rejects_per_traj": st["n_reject"] / max(st["n_traj"], 1),
+         "n_ok": int(st["n_ok"]),
+         "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                      "algorithmic_bytes_per_traj": BYTES[kind]}}
+    if wall_ms is not None:
+        e["call_ms"] = wall_ms
+    if extra:
+        e.update(extra)
+    return e
+
+
+def _time_calls(node, p, reps):
+    kms, walls = [], []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        node.loss_and_grad(p)
+        walls.append((time.perf_counter() - t0) * 1e3)
+        kms.append(node.last_stats["kernel_ms"])
+    return kms[1:], float(np.median(walls[1:])), node.last_stats
+
+
+def case2_fixed(u0, data, yscale, p, label_extra=None, reps=6, device=0, **probkw):
+    """case2 at a fixed p (no optimiser update) on a caller-supplied ensemble."""
+    from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE2, cases
+    node = NeuralODE(ODEProblem(PRESET_CASE2, cases.case2_tsteps(), device=device, **probkw))
+    node.set_ensemble(u0, data, yscale)
+    kms, wall, st = _time_calls(node, p, reps)
+    node.close()
+    return _entry("case2", u0.shape[0], kms, st, label_extra, wall)
+
+
+def case2_ensemble(B, seed, device=0):
+    from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE2, cases
+    rng = np.random.Generator(np.random.PCG64(seed))
+    ts = cases.case2_tsteps()
+    u0 = cases.case2_u0(B, rng)
+    gen = NeuralODE(ODEProblem(PRESET_CASE2, ts, atol=1e-10, rtol=1e-8, device=device))
+    clean = gen.predict_theta(u0, cases.case2_true_theta())[:, :6, :]
+    gen.close()
+    data = cases.add_noise(clean, 0.05, rng)
+    return u0, data, cases.max_min(data, lb=1e-6)
+
+
+def robertson(B=65536, reps=6, device=0):
+    """BASELINE config 3: robertson CRNN (3 species, 6 reactions, P = 43, stiffness 1e11), checkpoint p."""
+    from crnn_amd import NeuralODE, ODEProblem, PRESET_ROBER, cases
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fixtures.json")))
+    rng = np.random.Generator(np.random.PCG64([1234, 3]))
+    ts = cases.rober_tsteps()
+    u0 = cases.rober_u0(B, rng)
+    rb = fx["robertson"]
+    ys, sc = np.array(rb["yscale"]), np.array(rb["dydt_scale"])
+    gen = NeuralODE(ODEProblem(PRESET_ROBER, ts, rate_scale=sc, device=device))
+    p = np.array(fx["rober_ckpt"]["p"])
+    clean = gen.predict_neuralode(u0, p)                      # data: the checkpoint CRNN itself + the reference's 1e-4 noise
+    gen.close()
+    data = cases.add_noise(clean, 1e-4, rng)
+    node = NeuralODE(ODEProblem(PRESET_ROBER, ts, rate_scale=sc, device=device))
+    node.set_ensemble(u0, data, ys)
+    kms, wall, st = _time_calls(node, p, reps)
+    node.close()
+    return _entry("robertson", B, kms, st, {"workload": "robertson CRNN, 65 536 ICs, Rosenbrock23 atol [1e-6,1e-8,1e-6] rtol 1e-3, adjoint gradient (P = 43)",
+                                            "kernel": "ros23_adj_kernel<3,6,scaled>"}, wall)
+
+
+def hychem(B=32768, reps=4, device=0):
+    """BASELINE config 4, one GPU's share (262 144 / 8): HyChem pyrolysis CRNN, 9 species, 10 reactions, P = 211."""
+    from crnn_amd import NeuralODE, ODEProblem, PRESET_HYCHEM, hychem as hy
+    rng = np.random.Generator(np.random.PCG64([1234, 4]))
+    ts, u0, Tt, Pt = hy.sample_conditions(B, rng)
+    node = NeuralODE(ODEProblem(PRESET_HYCHEM, ts, rate_scale=hy.DYDT_SCALE, device=device))
+    node.set_ensemble(u0, np.zeros((B, 9, len(ts))), np.ones(9))
+    node.set_tables(Tt, Pt)
+    clean = node.predict_n_ode(hy.true_p())
+    data = clean * (1.0 + 0.01 * rng.standard_normal(clean.shape))
+    ys = np.maximum((data.max(axis=2) - data.min(axis=2)).max(axis=0), hy.LB)
+    node.set_ensemble(u0, data, ys)
+    node.set_tables(Tt, Pt)
+    p = hy.true_p() + 0.02 * np.random.Generator(np.random.PCG64(5)).standard_normal(hy.NP)
+    p[-1] = 0.1
+    kms, wall, st = _time_calls(node, p, reps)
+    node.close()
+    return _entry("hychem", B, kms, st, {"workload": "HyChem pyrolysis CRNN, 32 768 ICs (one GPU's share of 262 144), T(t)/P(t) tables, "
+                                                     "Rosenbrock23 atol 1e-8 rtol 1e-3, adjoint gradient (P = 211)",
+                                         "kernel": "hychem_kernel<9,10,GRAD,128>"}, wall)
+
+
+def cathode(n_part=4096, n_rates=256, reps=3, device=0):
+    """BASELINE config 5 on one GPU: 4 096 particles x 256 heating rates, per-particle 17-parameter gradients."""
+    from crnn_amd.cathode import CathodeUQ
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fixtures_cathode.json")))
+    betas = np.exp(np.linspace(np.log(2.0), np.log(20.0), n_rates))
+    meas = np.array([s["beta"] for s in fx["sets"]])
+    exp_data = []
+    for b in betas:
+        s = fx["sets"][int(np.argmin(np.abs(np.log(meas) - np.log(b))))]
+        dbar, d2bar = np.array(s["dbar"]), np.array(s["d2bar"])
+        sd = np.sqrt(np.maximum(d2bar - dbar ** 2, 0.0))
+        exp_data.append(np.stack([np.array(s["ts"]) * s["beta"] / b, dbar + sd, dbar - sd], axis=1))
+    uq = CathodeUQ(exp_data, betas, fx["theta"], normalizer=np.ones((n_rates, 3)), device=device)
+    rng = np.random.default_rng(0)
+    p = 1 + 1e-3 * rng.standard_normal((n_part, 17))
+    p[:, 6:9] = 0.0
+    kms = []
+    for _ in range(reps):
+        uq.solve(p)
+        kms.append(uq.last_stats["kernel_ms"])
+    st = uq.last_stats
+    uq.close()
+    return _entry("cathode", n_part * n_rates, kms[1:], st,
+                  {"workload": "Cathode-UQ: 4 096 particles x 256 heating rates, non-autonomous Rosenbrock23 atol 1e-12 rtol 1e-3, "
+                               "per-particle adjoint gradients (17 parameters each)", "kernel": "cathode_adj_kernel<256>"})
