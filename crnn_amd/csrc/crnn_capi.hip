@@ -140,8 +140,8 @@ struct Ctx {
     size_t tape_doubles = 0;
     unsigned int *d_overflow = nullptr;
     // queue order of ensembles larger than the resident lanes (sort_steps_kernel): by the step counts of the previous launch
-    int32_t *d_perm = nullptr, *d_perm_tmp = nullptr;
-    size_t perm_cap = 0, perm_tmp_cap = 0;
+    int32_t *d_perm = nullptr;
+    size_t perm_cap = 0;
     int64_t steps_first = 0, steps_count = 0;   // [first, first+count) whose d_nacc / d_nrej hold a completed launch's counts
     double *d_red_theta = nullptr;  // [n_theta + kExtra]
     int64_t n_fallback = 0;         // calls repeated with forward tangents after a tape overflow
@@ -428,9 +428,9 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
     const bool sortable = k->solver == CRNN_SOLVER_ROSENBROCK23 && (size_t)count > lanes && count < ((int64_t)1 << 31) &&
                           first >= c->steps_first && first + count <= c->steps_first + c->steps_count;
     if (sortable) {
-        if (ensure(c, &c->d_perm, &c->perm_cap, (size_t)count) || ensure(c, &c->d_perm_tmp, &c->perm_tmp_cap, (size_t)count)) return -1;
-        hipLaunchKernelGGL(crnn::sort_steps_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_nacc, c->d_nrej, first, (int)count,
-                           c->d_perm, c->d_perm_tmp);
+        if (ensure(c, &c->d_perm, &c->perm_cap, (size_t)count)) return -1;
+        hipLaunchKernelGGL(crnn::sort_steps_kernel, dim3((unsigned)((count + 1023) / 1024)), dim3(1024), 0, c->stream, c->d_nacc, c->d_nrej,
+                           first, (int)count, c->d_perm);
         HIP_TRY(c, hipGetLastError());
         adj.perm = c->d_perm;
     }
@@ -1005,7 +1005,7 @@ void crnn_ctx_destroy(crnn_ctx *ctx) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->own_u0 && c->d_u0) (void)hipFree(c->d_u0);
     if (c->own_data && c->d_data) (void)hipFree(c->d_data);
-    void *ptrs[] = {c->d_perm, c->d_perm_tmp, c->d_red_asm, c->d_poison, c->d_tabs, c->d_gacc, c->d_tape, c->d_overflow, c->d_red_theta, c->d_queue, c->d_nacc, c->d_nrej, c->d_gtraj, c->d_kc, c->d_tsave, c->d_pred, c->d_loss, c->d_ret, c->d_nsaved, c->d_theta, c->d_dtheta,
+    void *ptrs[] = {c->d_perm, c->d_red_asm, c->d_poison, c->d_tabs, c->d_gacc, c->d_tape, c->d_overflow, c->d_red_theta, c->d_queue, c->d_nacc, c->d_nrej, c->d_gtraj, c->d_kc, c->d_tsave, c->d_pred, c->d_loss, c->d_ret, c->d_nsaved, c->d_theta, c->d_dtheta,
                     c->d_partials, c->d_red, c->d_p, c->d_p_eval, c->d_opt, c->d_comm_buf};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < Ctx::kRing; ++i) {

@@ -675,65 +675,49 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
     }
 }
 
-// Queue order for ensembles larger than the resident lanes: perm = trajectories [0, count) sorted by the step count
-// (accepted + rejected) of their previous launch, longest first; ties keep their index order (stable), so the order -- and
-// with it the composition of every 64-trajectory batch and the rounding of the batch sums -- is a deterministic function
-// of the previous launch.  One block: two passes of a 5-bit LSD counting sort over keys clamped to 1023, every thread
-// owning a contiguous chunk (stability), per-thread digit counts in LDS.
+// Queue order for ensembles larger than the resident lanes.  Homogeneous 64-trajectory batches are all that is needed, not
+// a global order: every block sorts its own run of 1024 consecutive trajectories by the step count (accepted + rejected)
+// of their previous launch, longest first, ties by index (the sort key carries the index, so the order -- and with it the
+// composition of every batch and the rounding of the batch sums -- is a deterministic function of the previous launch),
+// the runs' batches are then interleaved (see the end of the kernel).  Bitonic sort of 1024 keys in LDS, ~10 us for any
+// ensemble size (one block per run).
 __global__ __launch_bounds__(1024) void sort_steps_kernel(const int32_t *__restrict__ n_accept, const int32_t *__restrict__ n_reject,
-                                                          int64_t first, int count, int32_t *__restrict__ perm,
-                                                          int32_t *__restrict__ tmp) {
-    __shared__ int hist[32 * 1024];    // [digit][thread]
-    __shared__ int tsum[1024];
+                                                          int64_t first, int count, int32_t *__restrict__ perm) {
+    __shared__ unsigned key[1024];
     const int tid = threadIdx.x;
-    const int cs = (count + 1023) / 1024;
-    const int lo = min(tid * cs, count), hi = min(lo + cs, count);
-    auto key_of = [&](int k) -> int {
-        const int steps = n_accept[first + k] + n_reject[first + k];
-        return 1023 - min(max(steps, 0), 1023);      // descending in steps
-    };
-    for (int pass = 0; pass < 2; ++pass) {
-        const int shift = 5 * pass;
-        const int32_t *src = pass == 0 ? nullptr : tmp;
-        int32_t *dst = pass == 0 ? tmp : perm;
-        int h[32];
-#pragma unroll
-        for (int d = 0; d < 32; ++d) h[d] = 0;
-        for (int k = lo; k < hi; ++k) {
-            const int e = src ? src[k] : k;
-            const int d = (key_of(e) >> shift) & 31;
-#pragma unroll
-            for (int q = 0; q < 32; ++q) h[q] += (q == d);
-        }
-#pragma unroll
-        for (int d = 0; d < 32; ++d) hist[d * 1024 + tid] = h[d];
-        __syncthreads();
-        // exclusive prefix over the flattened [digit][thread] table: thread t owns entries [32 t, 32 t + 32)
-        int loc = 0;
-        for (int q = 0; q < 32; ++q) loc += hist[tid * 32 + q];
-        tsum[tid] = loc;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const int v = tid >= off ? tsum[tid - off] : 0;
-            __syncthreads();
-            tsum[tid] += v;
+    const int base = blockIdx.x * 1024;
+    const int e = base + tid;
+    unsigned k = 0xFFFFFFFFu;                                  // beyond the ensemble: sorts to the end of the run
+    if (e < count) {
+        const int steps = n_accept[first + e] + n_reject[first + e];
+        k = ((unsigned)(1023 - min(max(steps, 0), 1023)) << 10) | (unsigned)tid;     // descending in steps, ascending in index
+    }
+    key[tid] = k;
+    __syncthreads();
+    for (int size = 2; size <= 1024; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const int partner = tid ^ stride;
+            if (partner > tid) {
+                const unsigned a = key[tid], b = key[partner];
+                const bool up = (tid & size) == 0;             // ascending sub-sequence
+                if ((a > b) == up) { key[tid] = b; key[partner] = a; }
+            }
             __syncthreads();
         }
-        int run = tsum[tid] - loc;
-        for (int q = 0; q < 32; ++q) { const int v = hist[tid * 32 + q]; hist[tid * 32 + q] = run; run += v; }
-        __syncthreads();
-#pragma unroll
-        for (int d = 0; d < 32; ++d) h[d] = hist[d * 1024 + tid];
-        for (int k = lo; k < hi; ++k) {
-            const int e = src ? src[k] : k;
-            const int d = (key_of(e) >> shift) & 31;
-            int o = 0;
-#pragma unroll
-            for (int q = 0; q < 32; ++q) { o = (q == d) ? h[q] : o; h[q] += (q == d); }
-            dst[o] = e;
-        }
-        __threadfence();
-        __syncthreads();
+    }
+    // Queue position of the k-th trajectory of run r: batches (64 consecutive ranks) of all runs interleaved, batch-major --
+    // the longest batch of every run first, then every run's second longest ... -- so the queue is approximately
+    // longest-first as a whole (with a handful of batches per wavefront the tail of the launch matters).  Only the last run
+    // can be short; its last batch can be partial, the positions behind it close the gap.
+    const int NR = gridDim.x, r = blockIdx.x;
+    const int nv_last = count - (NR - 1) * 1024;               // trajectories in the last run (1 .. 1024)
+    const int nb_last = (nv_last + 63) / 64, rem = nv_last & 63;
+    if (e < count) {                                            // rank tid of this run is a real trajectory
+        const int j = tid >> 6, l = tid & 63;
+        const int idx = (j < nb_last) ? j * NR + r : nb_last * NR + (j - nb_last) * (NR - 1) + r;
+        int pos = 64 * idx + l;
+        if (rem != 0 && idx > nb_last * NR - 1) pos -= 64 - rem;
+        perm[pos] = base + (int)(key[tid] & 1023u);
     }
 }
 

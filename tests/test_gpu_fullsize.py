@@ -344,3 +344,25 @@ def test_ensemble_larger_than_the_resident_lanes_is_queued_by_step_count(orc, fx
     print(f"B = {B}: kernel {ms1:.3f} ms in index order, {ms2:.3f} ms queued by step count")
     assert ms2 < ms1                                # homogeneous batches are the point
     node.close()
+
+
+def test_step_count_queue_with_a_ragged_ensemble_size(fx):
+    """B = 70 001: one trajectory more than a multiple of 64 and a last sort run of 369 -- the position map of the queue
+    (interleaved runs, partial last batch) must stay a permutation: every trajectory integrated exactly once."""
+    B = 70001
+    ts, u0, data, ys = _case2_ensemble(B, seed=5)
+    s = dict(tsteps=ts, u0=u0, data=data, yscale=ys)
+    p = np.array(fx["case2_ckpt"]["p"])
+    node = _node(s)
+    l1, g1 = node.loss_and_grad(p)
+    n1 = dict(node.last_stats)
+    l2, g2 = node.loss_and_grad(p)              # sorted queue
+    n2 = dict(node.last_stats)
+    assert n1["n_traj"] == n2["n_traj"] == B and n2["n_ok"] == B and n1["n_accept"] == n2["n_accept"]
+    assert abs(l2 - l1) < 1e-13 * l1 and np.max(np.abs(g2 - g1)) < 1e-11 * np.max(np.abs(g1))
+    # a sub-range launch after a full one: its own queue order over [first, first + count)
+    l3, g3 = node.loss_and_grad(p, first=1000, count=68000)
+    node2 = _node(dict(s, u0=u0[1000:69000], data=data[1000:69000]))
+    l4, g4 = node2.loss_and_grad(p)
+    assert abs(l3 - l4) < 1e-13 * l4 and np.max(np.abs(g3 - g4)) < 1e-11 * np.max(np.abs(g4))
+    node.close(); node2.close()
