@@ -290,6 +290,9 @@ def main():
             del ub_, db_
             sec["robertson_B65536"] = bs.robertson(device=local_rank)
             sec["hychem_B32768"] = bs.hychem(device=local_rank)
+            sec["hychem_B262144_one_gpu"] = bs.hychem(B=262144, reps=3, device=local_rank)
+            sec["hychem_B262144_one_gpu"]["workload"] = ("HyChem pyrolysis CRNN, ALL 262 144 ICs of BASELINE config 4 on ONE GPU (eight generations of "
+                                                         "wavefronts, queued by the previous launch's step counts), adjoint gradient (P = 211)")
             sec["cathode_4096x256"] = bs.cathode(device=local_rank)
             out["secondary"] = sec
         # RCCL prints a version banner through C stdio (block-buffered on a pipe): flush it first so

@@ -86,7 +86,8 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
         if (wave_base >= prm.count) break;
         const int64_t traj = wave_base + lane;
         const bool valid = traj < prm.count;
-        const int64_t b = prm.first + (valid ? traj : 0);
+        // queue order by last known step counts for ensembles larger than the resident lanes (sort_steps_kernel)
+        const int64_t b = prm.first + (valid ? (adj.perm ? (int64_t)adj.perm[traj] : traj) : 0);
 
         double bT[NR];
         double xT = 0.0, Tconst = 0.0;

@@ -378,6 +378,23 @@ void fill_params(Ctx *c, crnn::SolveParams &prm, int P, int64_t first, int64_t c
     prm.queue = c->d_queue;
 }
 
+// More trajectories than resident lanes: wavefronts take several 64-trajectory batches from the queue one after the other.
+// Queue the trajectories by their last known step counts (those of the previous launch over a range that covers this one:
+// in training p moves little from step to step) so that batches are homogeneous and the queue roughly longest-first.
+// *perm stays null (index order) when the ensemble fits the resident lanes or no counts are known yet.
+int32_t queue_by_steps(Ctx *c, size_t lanes, int64_t first, int64_t count, const int32_t **perm) {
+    *perm = nullptr;
+    const bool sortable = (size_t)count > lanes && count < ((int64_t)1 << 31) && first >= c->steps_first &&
+                          first + count <= c->steps_first + c->steps_count;
+    if (!sortable) return 0;
+    if (ensure(c, &c->d_perm, &c->perm_cap, (size_t)count)) return -1;
+    hipLaunchKernelGGL(crnn::sort_steps_kernel, dim3((unsigned)((count + 1023) / 1024)), dim3(1024), 0, c->stream, c->d_nacc, c->d_nrej,
+                       first, (int)count, c->d_perm);
+    HIP_TRY(c, hipGetLastError());
+    *perm = c->d_perm;
+    return 0;
+}
+
 // Gradient by the discrete adjoint (ros23_adj_kernel.hpp): theta-space gradient per trajectory, fixed-order batch
 // reduction, then the chain rule through the P given directions.  Returns 1 (not an error) when some trajectory ran
 // out of tape: the caller repeats the call with forward tangents.
@@ -425,15 +442,7 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
     // more trajectories than resident lanes: wavefronts take several batches from the queue one after the other; queue the
     // trajectories by their last known step counts so that batches are homogeneous (the counts of the previous launch over
     // the same range: in training p moves little from step to step)
-    const bool sortable = k->solver == CRNN_SOLVER_ROSENBROCK23 && (size_t)count > lanes && count < ((int64_t)1 << 31) &&
-                          first >= c->steps_first && first + count <= c->steps_first + c->steps_count;
-    if (sortable) {
-        if (ensure(c, &c->d_perm, &c->perm_cap, (size_t)count)) return -1;
-        hipLaunchKernelGGL(crnn::sort_steps_kernel, dim3((unsigned)((count + 1023) / 1024)), dim3(1024), 0, c->stream, c->d_nacc, c->d_nrej,
-                           first, (int)count, c->d_perm);
-        HIP_TRY(c, hipGetLastError());
-        adj.perm = c->d_perm;
-    }
+    if (queue_by_steps(c, lanes, first, count, &adj.perm)) return -1;
     if (upload_consts(c)) return -1;
     if (!c->flags_zeroed) {
         HIP_TRY(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), c->stream));
@@ -505,6 +514,7 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
     crnn::HyParams hp{};
     hp.tabs = c->d_tabs; hp.tape = c->d_tape; hp.tape_cap = (int32_t)cap; hp.overflow = c->d_overflow; hp.gacc = c->d_gacc;
     hp.n_save_total = c->cfg.n_save; hp.inv_R = c->cfg.inv_R;
+    if (queue_by_steps(c, lanes, first, count, &hp.perm)) return -1;
 #ifdef HY_PROF
     static unsigned long long *d_prof = nullptr;
     if (!d_prof) HIP_TRY(c, hipMalloc((void **)&d_prof, 16 * sizeof(unsigned long long)));
@@ -527,7 +537,7 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     if (P > 0) {
         hipLaunchKernelGGL(crnn::reduce_gacc_kernel, dim3(rblk), dim3(256), 0, c->stream, c->d_gacc, nth, c->n_obs, c->d_loss,
-                           c->d_ret, c->d_nsaved, c->d_nacc, c->d_nrej, first, count, c->d_partials);
+                           c->d_ret, c->d_nsaved, c->d_nacc, c->d_nrej, first, count, hp.perm, c->d_partials);
         HIP_TRY(c, hipGetLastError());
         hipLaunchKernelGGL(crnn::reduce_project_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_partials, rblk, d_dtheta, nth, P,
                            c->d_red_theta, c->d_red, (const unsigned int *)nullptr);
@@ -544,6 +554,7 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->last_npart = npart;
     c->last_P = P;
+    c->steps_first = first; c->steps_count = count;
 #ifdef HY_PROF
     {
         unsigned long long hprof[16];

@@ -71,6 +71,7 @@ struct HyParams {
     int32_t n_save_total;      // Dfull: length of the table / saveat grid
     double inv_R;
     unsigned long long *prof;  // HY_PROF builds: 16 phase totals in s_memtime ticks
+    const int32_t *perm;       // position in the queue -> trajectory (relative to first); null = identity (sort_steps_kernel)
 };
 
 template <int NS, int NR>
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_kernel(const SolveParams prm, co
         if (wave_base >= prm.count) break;
         const int64_t traj = wave_base + lane;
         const bool valid = traj < prm.count;
-        const int64_t b = prm.first + (valid ? traj : 0);
+        const int64_t b = prm.first + (valid ? (hp.perm ? (int64_t)hp.perm[traj] : traj) : 0);
         const double *const tabT = hp.tabs + (size_t)b * 2 * Dfull;
         const double *const tabP = tabT + Dfull;
 
@@ -942,7 +943,7 @@ __global__ __launch_bounds__(256) void reduce_gacc_kernel(const double *__restri
                                                           const int32_t *__restrict__ n_saved,
                                                           const int32_t *__restrict__ n_accept,
                                                           const int32_t *__restrict__ n_reject, int64_t first, int64_t count,
-                                                          double *__restrict__ partials) {
+                                                          const int32_t *__restrict__ perm, double *__restrict__ partials) {
     __shared__ double sh[4][256];
     __shared__ double ex[256];
     const int npart = nth + kExtra;
@@ -950,8 +951,8 @@ __global__ __launch_bounds__(256) void reduce_gacc_kernel(const double *__restri
     const int64_t r = (int64_t)blockIdx.x * 256 + tid;            // this thread's trajectory row
     double *out = partials + (size_t)blockIdx.x * npart;
     double scale = 0.0;
-    if (r < count) {
-        const int ns_ = n_saved[first + r];
+    if (r < count) {   // accumulator row r belongs to the trajectory queued at position r
+        const int ns_ = n_saved[first + (perm ? (int64_t)perm[r] : r)];
         scale = ns_ > 0 ? 1.0 / ((double)n_obs * (double)ns_) : 0.0;
     }
     const double *g = gacc + (size_t)(r >> 6) * nth * 64 + lane;
