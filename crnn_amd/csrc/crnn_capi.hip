@@ -16,6 +16,7 @@
 #include "ros23_kernel.hpp"
 #include "ros23_adj_kernel.hpp"
 #include "ros23_sens_kernel.hpp"
+#include "tsit5_sens_kernel.hpp"
 #include "hychem_kernel.hpp"
 #include "tsit5_kernel.hpp"
 #include "auto_adj_kernel.hpp"
@@ -75,8 +76,11 @@ const KernelEntry kKernels[] = {
 constexpr int kSensBlock = 128;
 #define KSENS(NS, NR, HT, SC, C, L) \
     { CRNN_SOLVER_ROSENBROCK23, NS, NR, HT, SC, C, L, (KernelFn)crnn::ros23_sens_kernel<NS, NR, (HT) != 0, (SC) != 0, C, L, kSensBlock> }
+#define KSENS5(NS, NR, HT, SC, C, L) \
+    { CRNN_SOLVER_TSIT5, NS, NR, HT, SC, C, L, (KernelFn)crnn::tsit5_sens_kernel<NS, NR, (HT) != 0, (SC) != 0, C, L, kSensBlock> }
 const KernelEntry kSensKernels[] = {
     KSENS(6, 3, 1, 0, 3, 3), KSENS(3, 6, 0, 1, 4, 3), KSENS(5, 4, 0, 0, 4, 3),
+    KSENS5(5, 4, 0, 0, 4, 3), KSENS5(6, 3, 1, 0, 3, 3),      // case1's Tsit5 (case1.jl:28); the non-stiff branch of case2's AutoTsit5
 };
 
 using AdjKernelFn = void (*)(const crnn::SolveParams, const double *, const crnn::AdjParams);
@@ -937,8 +941,8 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
     if (cfg->ns < 1 || cfg->nr < 1 || cfg->ns + cfg->has_temp > CRNN_MAX_N || cfg->nr > CRNN_MAX_NR)
         return fail(nullptr, "crnn_ctx_create: ns/nr out of range");
     if (cfg->errnorm_sens != 0 && cfg->errnorm_sens != 1) return fail(nullptr, "crnn_ctx_create: errnorm_sens must be 0 or 1");
-    if (cfg->errnorm_sens == 1 && (cfg->solver != CRNN_SOLVER_ROSENBROCK23 || cfg->rhs_kind != CRNN_RHS_CRNN || cfg->grad_mode == CRNN_GRAD_ADJOINT))
-        return fail(nullptr, "crnn_ctx_create: errnorm_sens = 1 exists for Rosenbrock23 with forward tangents (grad_mode AUTO or FORWARD) on the CRNN right-hand side");
+    if (cfg->errnorm_sens == 1 && (cfg->solver == CRNN_SOLVER_AUTOTSIT5 || cfg->rhs_kind != CRNN_RHS_CRNN || cfg->grad_mode == CRNN_GRAD_ADJOINT))
+        return fail(nullptr, "crnn_ctx_create: errnorm_sens = 1 exists for Rosenbrock23 and Tsit5 with forward tangents (grad_mode AUTO or FORWARD) on the CRNN right-hand side");
     if (cfg->solver != CRNN_SOLVER_ROSENBROCK23 && cfg->solver != CRNN_SOLVER_TSIT5 && cfg->solver != CRNN_SOLVER_AUTOTSIT5)
         return fail(nullptr, "crnn_ctx_create: unknown solver");
     if (cfg->rhs_kind != CRNN_RHS_CRNN && cfg->rhs_kind != CRNN_RHS_HYCHEM) return fail(nullptr, "crnn_ctx_create: unknown rhs_kind");

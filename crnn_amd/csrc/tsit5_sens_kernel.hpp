@@ -1,0 +1,400 @@
+// crnn_amd/csrc/tsit5_sens_kernel.hpp -- gfx950 (MI355X): Tsit5 + forward tangents with the step-size controller driven by
+// ForwardDiff's DUAL-INCLUSIVE error norm (crnn_config.errnorm_sens = 1) -- the reference-faithful gradient mode of the
+// problems the reference integrates explicitly: case1 (`Tsit5()`, case1/case1.jl:28,147) and, while it never leaves its
+// non-stiff branch, case2's `AutoTsit5(Rosenbrock23())` (case2/case2.jl:26,195; auto_adj_kernel.hpp on why it stays there).
+// Same contract as ros23_sens_kernel.hpp: one launch = ONE ForwardDiff chunk (primal + the chunk's tangent columns through
+// every ATTEMPT, because the accept / reject decision needs them),
+//
+//     k_s' = f_u(g_s) (s + dt sum_j a_sj k_j') + f_theta(g_s) dtheta      s = 1..7          s+ = s + dt sum_j a_7j k_j'
+//     e'   = dt sum_j btilde_j k_j'
+//     EEst^2 = 1/n sum_i (e_i^2 + sum_k e'_ik^2) / (atol_i + rtol_i sqrt(max(u_i^2 + sum_k s_ik^2, u+_i^2 + sum_k s+_ik^2)))^2
+//
+// ([UNVERIFIED-DEP] DiffEqBase.ODE_DEFAULT_NORM on Dual arrays; the initial step size uses the primal values only.)
+// Lane groups (L lanes per trajectory, C columns each), a per-group LDS record with the seven stage areas (x, g, r) that
+// lane 0 of the group publishes, provisional save-point seeds / tangent columns / gradient increments until the group has
+// summed its lanes' norm contributions; trajectories by a plain grid-stride loop.
+#pragma once
+#include "tsit5_kernel.hpp"
+
+namespace crnn {
+
+template <int NS, int NR>
+struct RecTS {
+    static constexpr int SA = 2 * NS + NR;          // one stage area: X, G, R
+    static constexpr int XO = 0, GO = NS, RO = 2 * NS;
+    static constexpr int AA = 7 * SA;
+    static constexpr int BB = AA + NS;              // B_j at BB + j*NS
+    static constexpr int NREC = BB + 7 * NS;
+};
+
+template <int NS, int NR, bool HAS_T, bool USE_SCALE, int C, int L, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm, const double *__restrict__ theta,
+                                                           const double *__restrict__ dtheta) {
+    using L_ = Lay<NS, NR, HAS_T>;
+    using R_ = RecTS<NS, NR>;
+    constexpr int N = L_::N;
+    constexpr int NTH = L_::NTH;
+    constexpr int NTHP = L_::NTHP;
+    constexpr int NREC = R_::NREC;
+    constexpr int WAVES = BLOCK / 64;
+    constexpr int GPW = 64 / L;
+    constexpr int PPAD = L * C;
+    static_assert(C > 0 && L >= 1 && L <= 64, "lane-group shape");
+
+    __shared__ double kc_lds[kNConst];
+    __shared__ double ts_lds[kMaxSave];
+    __shared__ double dth_lds[PPAD * NTHP];
+    __shared__ double S_lds[2 * WAVES * C * NS * 64];   // two slots per lane: committed columns / columns of the attempt
+    __shared__ double rec_lds[WAVES * NREC * GPW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = lane / L, chunk = lane - grp * L;
+    const bool lane_active = grp < GPW;
+    const bool lead = lane_active && chunk == 0;
+    const int gbase = grp * L;
+    double *const S_base = S_lds + (size_t)wave * 2 * C * NS * 64 + lane;
+    double *const rec = rec_lds + wave * NREC * GPW + (lane_active ? grp : 0);
+
+    for (int idx = tid; idx < kNConst; idx += BLOCK) kc_lds[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
+    for (int idx = tid; idx < prm.n_save; idx += BLOCK) ts_lds[idx] = prm.tsave[idx];
+    for (int idx = tid; idx < PPAD * NTHP; idx += BLOCK) {
+        const int k = idx / NTHP, m = idx - k * NTHP;
+        dth_lds[idx] = (k < prm.P && m < NTH) ? dtheta[(size_t)k * NTH + m] : 0.0;
+    }
+    __syncthreads();
+    const KConst *kc = reinterpret_cast<const KConst *>(kc_lds);
+    const double *__restrict__ th = theta;
+
+    const int nsave = prm.n_save;
+    const double tend = ts_lds[nsave - 1], ts0 = ts_lds[0], t0 = kc->t0;
+    const double dtmax = tend - t0;
+    const double lqinit = flog(kc->qoldinit);
+    const int64_t ngroups = (int64_t)gridDim.x * WAVES * GPW;
+    int64_t traj = lane_active ? ((int64_t)blockIdx.x * WAVES + wave) * GPW + grp : prm.count;
+
+    auto group_sum = [&](double v) -> double {
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < L; ++q) a += __shfl(v, gbase + q);
+        return a;
+    };
+
+    for (; traj < prm.count; traj += ngroups) {
+        const int64_t b = prm.first + traj;
+        const double *const drows = prm.data + (size_t)b * prm.row_stride;
+        double u[NS], k1[NS], x1[NS], g1[NS], r1[NR], bT[NR], gtr[C];
+        double xT = 0.0, Tconst = 0.0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) u[i] = prm.u0[(size_t)i * prm.B + b];
+        if (HAS_T) {
+            Tconst = prm.u0[(size_t)NS * prm.B + b];
+            xT = kc->inv_R * frcp(Tconst);
+        }
+#pragma unroll
+        for (int j = 0; j < NR; ++j) bT[j] = HAS_T ? fma(th[L_::wi(NS, j)], xT, th[L_::wb(j)]) : th[L_::wb(j)];
+        features<NS>(u, kc->lb, kc->ub, x1, g1);
+        rates<NS, NR, HAS_T>(th, x1, bT, r1);
+        rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r1, kc->scale, k1);
+        double dt;
+        {   // Hairer initial step, order 5 (primal values only)
+            double d0 = 0.0, d1 = 0.0, sk[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                sk[i] = frcp(fma(fabs(u[i]), kc->rtol[i], kc->atol[i]));
+                const double a = u[i] * sk[i], c = k1[i] * sk[i];
+                d0 = fma(a, a, d0);
+                d1 = fma(c, c, d1);
+            }
+            if (HAS_T) { const double a = Tconst * frcp(fma(fabs(Tconst), kc->rtol[NS], kc->atol[NS])); d0 = fma(a, a, d0); }
+            d0 = sqrt(d0 * (1.0 / N));
+            d1 = sqrt(d1 * (1.0 / N));
+            double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 / d1);
+            dt0 = fmin(dt0, dtmax);
+            double ua[NS], xa[NS], ga[NS], ra[NR], fa[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) ua[i] = fma(dt0, k1[i], u[i]);
+            features<NS>(ua, kc->lb, kc->ub, xa, ga);
+            rates<NS, NR, HAS_T>(th, xa, bT, ra);
+            rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, ra, kc->scale, fa);
+            double d2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) { const double e = (fa[i] - k1[i]) * sk[i]; d2 = fma(e, e, d2); }
+            d2 = sqrt(d2 * (1.0 / N)) / dt0;
+            const double dm = fmax(d1, d2);
+            // 10^(-(2 + log10 dm)/5) = exp(-(ln 100 + ln dm)/5)
+            const double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : exp(-0.2 * (4.605170185988091368 + flog(dm)));
+            dt = fmax(kc->dtmin, fmin(fmin(100.0 * dt0, dt1), dtmax));
+        }
+        double t = t0, lqold = lqinit, loss_sum = 0.0;
+        int iter = 0, jsave = 0, nacc = 0, nrej = 0, cur = 0, rc = -1;
+#pragma unroll
+        for (int q = 0; q < C; ++q) gtr[q] = 0.0;
+#pragma unroll
+        for (int q = 0; q < 2 * C * NS; ++q) S_base[q * 64] = 0.0;
+        if (ts0 == t0) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                double v = u[i];
+                if (prm.clamp_pred) v = clampv(v, -kc->ub, kc->ub);
+                if (prm.pred && chunk == 0) prm.pred[((size_t)0 * N + i) * prm.B + b] = v;
+                const int dr = (int)kc->drow[i];
+                if (dr >= 0) {
+                    const double rr = (drows[dr] - v) * kc->inv_yscale[i];
+                    loss_sum += (prm.loss_kind == 0) ? fabs(rr) : rr * rr;
+                }
+            }
+            if (HAS_T && prm.pred && chunk == 0) {
+                double v = Tconst;
+                if (prm.clamp_pred) v = clampv(v, -kc->ub, kc->ub);
+                prm.pred[((size_t)0 * N + NS) * prm.B + b] = v;
+            }
+            jsave = 1;
+        }
+
+        while (rc < 0) {
+            ++iter;
+            bool last = false;
+            if (jsave >= nsave) { rc = 0; break; }
+            if (iter > prm.maxiters) { rc = 1; break; }
+            if (t + dt * (1.0 + 1e-13) >= tend) { dt = tend - t; last = true; }
+            if (!(dt > kc->dtmin) || t + dt == t) { rc = 2; break; }
+
+            // ============================================================ PRIMAL: one Tsit5 attempt
+            double k[7][NS], unew[NS], x7[NS], g7[NS], r7[NR], ev[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) k[0][i] = k1[i];
+            if (lead) {
+#pragma unroll
+                for (int i = 0; i < NS; ++i) { rec[(R_::XO + i) * GPW] = x1[i]; rec[(R_::GO + i) * GPW] = g1[i]; }
+#pragma unroll
+                for (int j = 0; j < NR; ++j) rec[(R_::RO + j) * GPW] = r1[j];
+            }
+#pragma unroll
+            for (int s = 1; s < 7; ++s) {
+                double g[NS], x[NS], gg[NS], r[NR];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int j = 0; j < s; ++j) a = fma(Ts5::a(s - 1, j), k[j][i], a);
+                    g[i] = fma(dt, a, u[i]);
+                }
+                features<NS>(g, kc->lb, kc->ub, x, gg);
+                rates<NS, NR, HAS_T>(th, x, bT, r);
+                rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r, kc->scale, k[s]);
+                if (lead) {
+                    const int o = s * R_::SA;
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) { rec[(o + R_::XO + i) * GPW] = x[i]; rec[(o + R_::GO + i) * GPW] = gg[i]; }
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) rec[(o + R_::RO + j) * GPW] = r[j];
+                }
+                if (s == 6) {
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) { unew[i] = g[i]; x7[i] = x[i]; g7[i] = gg[i]; }
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) r7[j] = r[j];
+                }
+            }
+            bool finite = true;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                double a = 0.0;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) a = fma(Ts5::bt(j), k[j][i], a);
+                ev[i] = dt * a;
+                finite = finite && isfinite(unew[i]) && isfinite(ev[i]);
+            }
+            if (!finite) { rc = 3; break; }
+
+            // ---- PROVISIONAL save points of (t, tnew]
+            const double tnew = last ? tend : t + dt;
+            double A_[NS], Bs[7][NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                A_[i] = 0.0;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) Bs[j][i] = 0.0;
+            }
+            double loss_new = loss_sum;
+            int jnew = jsave;
+            while (jnew < nsave) {
+                const double ts = ts_lds[jnew];
+                if (!(ts <= tnew)) break;
+                const bool at_end = (ts == tnew);
+                double bth[7];
+                Ts5::dense(at_end ? 1.0 : (ts - t) / dt, bth);
+                const double *row = drows + (size_t)jnew * prm.n_obs;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) a = fma(bth[j], k[j][i], a);
+                    double v = at_end ? unew[i] : fma(dt, a, u[i]);
+                    double mask = 1.0;
+                    if (prm.clamp_pred) {
+                        mask = (v > kc->ub || v < -kc->ub) ? 0.0 : 1.0;
+                        v = clampv(v, -kc->ub, kc->ub);
+                    }
+                    if (prm.pred && chunk == 0) prm.pred[((size_t)jnew * N + i) * prm.B + b] = v;
+                    const int dr = (int)kc->drow[i];
+                    if (dr >= 0) {
+                        const double iy = kc->inv_yscale[i];
+                        const double rr = (row[dr] - v) * iy;
+                        double w;
+                        if (prm.loss_kind == 0) { loss_new += fabs(rr); w = signbit(rr) ? 1.0 : -1.0; }
+                        else { loss_new = fma(rr, rr, loss_new); w = -2.0 * rr; }
+                        w *= mask * iy;
+                        A_[i] += w;
+#pragma unroll
+                        for (int j = 0; j < 7; ++j) Bs[j][i] = fma(w * dt, at_end ? (j < 6 ? Ts5::a(5, j) : 0.0) : bth[j], Bs[j][i]);
+                    }
+                }
+                if (HAS_T && prm.pred && chunk == 0) {
+                    double v = Tconst;
+                    if (prm.clamp_pred) v = clampv(v, -kc->ub, kc->ub);
+                    prm.pred[((size_t)jnew * N + NS) * prm.B + b] = v;
+                }
+                ++jnew;
+            }
+            if (lead) {
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    rec[(R_::AA + i) * GPW] = A_[i];
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) rec[(R_::BB + j * NS + i) * GPW] = Bs[j][i];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            // ============================================================ TANGENTS of the attempt
+            double *const Sc = S_base + (size_t)cur * C * NS * 64;
+            double *const Sn = S_base + (size_t)(cur ^ 1) * C * NS * 64;
+            double ee[NS], na[NS], nb[NS], gnew[C];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) { ee[i] = 0.0; na[i] = 0.0; nb[i] = 0.0; }
+#pragma unroll 1
+            for (int qc = 0; qc < C; ++qc) {
+                const double *dcol = dth_lds + (chunk * C + qc) * NTHP;
+                const double *Sq = Sc + qc * NS * 64;
+                double *Sqn = Sn + qc * NS * 64;
+                double dth_r[NTH];
+#pragma unroll
+                for (int m = 0; m < NTH; ++m) dth_r[m] = dcol[m];
+                double s[NS], kp[6][NS], de[NS];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) { s[i] = Sq[i * 64]; na[i] = fma(s[i], s[i], na[i]); de[i] = 0.0; }
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) acc = fma(rec[(R_::AA + i) * GPW], s[i], acc);
+#pragma unroll
+                for (int st = 0; st < 7; ++st) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int o = st * R_::SA;
+                    double gs[NS];
+#pragma unroll
+                    for (int c = 0; c < NS; ++c) {
+                        double a = 0.0;
+#pragma unroll
+                        for (int j = 0; j < st; ++j) a = fma(Ts5::a(st - 1, j), kp[j][c], a);
+                        gs[c] = rec[(o + R_::GO + c) * GPW] * (st == 0 ? s[c] : fma(dt, a, s[c]));
+                    }
+                    double kps[NS];
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) kps[i] = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        double e = dth_r[L_::wb(j)];
+                        if (HAS_T) e = fma(dth_r[L_::wi(NS, j)], xT, e);
+#pragma unroll
+                        for (int c = 0; c < NS; ++c) {
+                            e = fma(dth_r[L_::wi(c, j)], rec[(o + R_::XO + c) * GPW], e);
+                            e = fma(th[L_::wi(c, j)], gs[c], e);
+                        }
+                        const double rj = rec[(o + R_::RO + j) * GPW];
+                        const double er = e * rj;
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) {
+                            kps[i] = fma(dth_r[L_::wo(i, j)], rj, kps[i]);
+                            kps[i] = fma(th[L_::wo(i, j)], er, kps[i]);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        if (USE_SCALE) kps[i] *= kc->scale[i];
+                        acc = fma(rec[(R_::BB + st * NS + i) * GPW], kps[i], acc);
+                        de[i] = fma(Ts5::bt(st), kps[i], de[i]);
+                        if (st < 6) kp[st][i] = kps[i];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) a = fma(Ts5::a(5, j), kp[j][i], a);
+                    const double sn = fma(dt, a, s[i]);
+                    Sqn[i * 64] = sn;
+                    nb[i] = fma(sn, sn, nb[i]);
+                    const double d = dt * de[i];
+                    ee[i] = fma(d, d, ee[i]);
+                }
+                gnew[qc] = acc;
+            }
+            // ---- the group's dual-inclusive error norm and the decision
+            double es = 0.0;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const double nai = fma(u[i], u[i], group_sum(na[i]));
+                const double nbi = fma(unew[i], unew[i], group_sum(nb[i]));
+                const double eei = fma(ev[i], ev[i], group_sum(ee[i]));
+                const double sc = fma(kc->rtol[i], sqrt(fmax(nai, nbi)), kc->atol[i]);
+                es += eei / (sc * sc);
+            }
+            es = es * (1.0 / N);
+            if (!isfinite(es)) { rc = 3; break; }
+            const bool ee_zero = (es == 0.0);
+            const double lEE = 0.5 * flog(ee_zero ? 1.0 : es);
+            const double lq11 = kc->beta1 * lEE;
+            double q = ee_zero ? 1.0 / kc->qmax
+                               : fmax(1.0 / kc->qmax, fmin(1.0 / kc->qmin, exp(lq11 - kc->beta2 * lqold) / kc->gamma));
+            if (es <= 1.0) {
+                ++nacc;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) { u[i] = unew[i]; k1[i] = k[6][i]; x1[i] = x7[i]; g1[i] = g7[i]; }
+#pragma unroll
+                for (int j = 0; j < NR; ++j) r1[j] = r7[j];
+#pragma unroll
+                for (int qc = 0; qc < C; ++qc) gtr[qc] += gnew[qc];
+                cur ^= 1;
+                loss_sum = loss_new;
+                jsave = jnew;
+                t = tnew;
+                if (q >= kc->qsteady_min && q <= kc->qsteady_max) q = 1.0;
+                lqold = ee_zero ? lqinit : fmax(lEE, lqinit);
+                dt = fmin(dt / q, dtmax);
+                if (jsave >= nsave) rc = 0;
+            } else {
+                ++nrej;
+                dt = dt / fmin(1.0 / kc->qmin, exp(lq11) / kc->gamma);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        const double denom = (double)prm.n_obs * (double)jsave;
+        const double inv_den = jsave > 0 ? 1.0 / denom : 0.0;
+        if (chunk == 0) {
+            prm.loss[b] = loss_sum * inv_den;
+            prm.retcode[b] = rc;
+            prm.n_saved[b] = jsave;
+            prm.n_accept[b] = nacc;
+            prm.n_reject[b] = nrej;
+        }
+        double *grow = prm.gtraj + (size_t)traj * PPAD + chunk * C;
+#pragma unroll
+        for (int q_ = 0; q_ < C; ++q_) grow[q_] = gtr[q_] * inv_den;
+    }
+}
+
+}  // namespace crnn

@@ -707,7 +707,10 @@ static int solve_one_tsit5(const orc_problem *pb, const double *th, const double
         if (!finite) { retcode = 3; break; }
         double EEst = rms_scaled(pb, n, ev, u, unew);
         int accept = (EEst <= 1.0);
-        if (accept && P > 0) {
+        /* Primal-only norm: tangents lazily, for accepted steps only.  ForwardDiff-style norm (errnorm_sens = 1):
+           they are needed before the test, for every attempt. */
+        const int sens_norm = (pb->errnorm_sens && P > 0);
+        if ((accept || sens_norm) && P > 0) {
             for (int c = 0; c < P; ++c) {
                 const double *dthc = dth + (size_t)nth * c;
                 const double *s = S + (size_t)n * c;
@@ -721,6 +724,25 @@ static int solve_one_tsit5(const orc_problem *pb, const double *th, const double
                     if (s_ == 6) memcpy(Snew + (size_t)n * c, gs, sizeof(double) * n);
                     orc_rhs_jvp(pb, th, dthc, gu, gs, DK(s_) + (size_t)n * c);
                 }
+            }
+            if (sens_norm) {
+                /* [UNVERIFIED-DEP] DiffEqBase norm on Dual arrays, as in the Rosenbrock23 stepper above: value and
+                   partials enter the sum of squares, the per-component scale uses the 2-norm of (value, partials);
+                   the error estimate's partials are dt sum_j btilde_j k_j'. */
+                double ssum = 0.0;
+                for (int i = 0; i < n; ++i) {
+                    double na = u[i] * u[i], nb = unew[i] * unew[i], ee = ev[i] * ev[i];
+                    for (int c = 0; c < P; ++c) {
+                        double s_ = S[i + (size_t)n * c], sn_ = Snew[i + (size_t)n * c], a = 0.0;
+                        for (int j = 0; j < 7; ++j) a += TS_BT[j] * DK(j)[i + (size_t)n * c];
+                        na += s_ * s_; nb += sn_ * sn_; ee += (dt * a) * (dt * a);
+                    }
+                    double sc = pb->atol[i] + pb->rtol[i] * sqrt(fmax(na, nb));
+                    ssum += ee / (sc * sc);
+                }
+                EEst = sqrt(ssum / n);
+                if (!isfinite(EEst)) { retcode = 3; break; }
+                accept = (EEst <= 1.0);
             }
         }
         double q, q11 = 0.0;

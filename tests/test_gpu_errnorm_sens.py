@@ -13,11 +13,15 @@ pytestmark = pytest.mark.gpu
 
 
 def _setup(case, case2_setup, rober_setup, fx):
-    from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE1, PRESET_CASE2, PRESET_ROBER, SOLVER_ROSENBROCK23, cases
+    from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE1, PRESET_CASE2, PRESET_ROBER, SOLVER_ROSENBROCK23, SOLVER_TSIT5, cases
     if case == "case2":
         s = case2_setup
         mk = lambda **kw: NeuralODE(ODEProblem(PRESET_CASE2, s["tsteps"], **kw))
         return s, mk, (2, 6, 3), lambda orc, **kw: oracle_problem(orc, "case2", s, **kw)
+    if case == "case2-tsit5":      # the non-stiff branch of case2's AutoTsit5(Rosenbrock23()) (case2.jl:26)
+        s = case2_setup
+        mk = lambda **kw: NeuralODE(ODEProblem(PRESET_CASE2, s["tsteps"], solver=SOLVER_TSIT5, **kw))
+        return s, mk, (2, 6, 3), lambda orc, **kw: oracle_problem(orc, "case2", s, solver=1, **kw)
     if case == "rober":
         s = rober_setup
         mk = lambda **kw: NeuralODE(ODEProblem(PRESET_ROBER, s["tsteps"], rate_scale=s["dydt_scale"], **kw))
@@ -30,13 +34,15 @@ def _setup(case, case2_setup, rober_setup, fx):
     gen.close()
     ys = cases.max_min(data, lb=1e-5)
     s = dict(u0=u0, tsteps=ts, data=data, yscale=ys, p_ckpt=np.array(fx["case1"]["p"]))
-    mk = lambda **kw: NeuralODE(ODEProblem(PRESET_CASE1, ts, solver=SOLVER_ROSENBROCK23, **kw))
+    sv = 1 if case == "case1-tsit5" else 0           # case1's own algorithm is Tsit5 (case1.jl:28)
+    mk = lambda **kw: NeuralODE(ODEProblem(PRESET_CASE1, ts, solver=SOLVER_TSIT5 if sv else SOLVER_ROSENBROCK23, **kw))
     mkpb = lambda orc, **kw: orc.make_problem(ns=5, nr=4, lb=1e-5, ub=10.0, atol=1e-5, rtol=1e-2, yscale=ys, clamp_pred=1,
-                                              maxiters=10000, solver=0, **kw)
+                                              maxiters=10000, solver=sv, **kw)
     return s, mk, (1, 5, 4), mkpb
 
 
-@pytest.mark.parametrize("case,pkey", [("case2", "p_ckpt"), ("case2", "p_init"), ("rober", "p_ckpt"), ("case1", "p_ckpt")])
+@pytest.mark.parametrize("case,pkey", [("case2", "p_ckpt"), ("case2", "p_init"), ("rober", "p_ckpt"), ("case1", "p_ckpt"),
+                                       ("case1-tsit5", "p_ckpt"), ("case2-tsit5", "p_ckpt"), ("case2-tsit5", "p_init")])
 def test_chunked_dual_norm_gradient_matches_oracle(orc, fx, case2_setup, rober_setup, case, pkey):
     from crnn_amd.api import fd_chunk_size
     s, mk, (kind, ns, nr), mkpb = _setup(case, case2_setup, rober_setup, fx)
@@ -104,8 +110,8 @@ def test_loss_grad_and_training_step_assemble_the_chunks(orc, case2_setup):
 
 
 def test_errnorm_sens_rejects_unsupported_combinations():
-    from crnn_amd import CrnnError, NeuralODE, ODEProblem, PRESET_CASE1, PRESET_CASE2, cases
+    from crnn_amd import CrnnError, NeuralODE, ODEProblem, PRESET_CASE2, SOLVER_AUTOTSIT5, cases
     with pytest.raises(CrnnError, match="errnorm_sens"):
-        NeuralODE(ODEProblem(PRESET_CASE1, cases.case1_tsteps(), errnorm_sens=1))          # Tsit5
+        NeuralODE(ODEProblem(PRESET_CASE2, cases.case2_tsteps(), errnorm_sens=1, solver=SOLVER_AUTOTSIT5))   # composite: tape kernel only
     with pytest.raises(CrnnError, match="errnorm_sens"):
         NeuralODE(ODEProblem(PRESET_CASE2, cases.case2_tsteps(), errnorm_sens=1, grad_mode=2))
