@@ -215,6 +215,11 @@ def main():
                        "comm": comm if world > 1 else "none", "parallelism": f"dp{world} (ICs sharded, 1 all-reduce/step)"},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         # traffic: PMC figure of the committed rocprofv3 passes (profiles/traffic.json; counters cannot be read
+                         # inside this process).  traffic_model: the same quantity from THIS run's step counts -- algorithmic bytes +
+                         # the adjoint's step tape, 64 B per accepted step written at 1.27x its payload (lane-strided partial
+                         # lines, profiles/r02_fetch_write_calibration.txt) and read back once.
+                         "traffic_model": (BYTES_PER_TRAJ * B + st["n_accept"] * 64 * (1.27 + 1.0)) if (ros and adjoint) else None,
                          "kernel": (("ros23_adj_kernel<6,3,T>" if ros else "auto_adj_kernel<6,3,T>") if adjoint else
                                     ("ros23_kernel" if ros else "tsit5_kernel") + "<6,3,T,C,L>"), "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_TRAJ * B,
