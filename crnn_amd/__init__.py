@@ -1,6 +1,7 @@
 """crnn_amd -- MI355X-native (gfx950) implementation of the neural-ODE hot path of
-DENG-MIT/CRNN: batched stiff CRNN solve (Rosenbrock23) + forward-tangent gradient
-+ Flux-style ADAM update, behind the C ABI in include/crnn_hip.h.
+DENG-MIT/CRNN: batched stiff CRNN solve (Rosenbrock23 / Tsit5 / AutoTsit5) + the gradient
+ForwardDiff.gradient returns (discrete adjoint or forward tangents) + Flux-style ADAM
+update, behind the C ABI in include/crnn_hip.h.
 
 Importing this package loads crnn_amd/csrc/libcrnn_hip.so and fails loudly if it
 has not been built (no CPU fallback).

@@ -78,7 +78,9 @@ enum { CRNN_GRAD_AUTO = 0, CRNN_GRAD_FORWARD = 1, CRNN_GRAD_ADJOINT = 2 };
 /* internal to the adjoint path: a trajectory ran out of tape; the library then repeats the call with FORWARD and this
  * code never reaches the caller */
 enum { CRNN_RET_TAPE_OVERFLOW = 5 };
-/* presets for crnn_config_preset */
+/* presets for crnn_config_preset.  NOTE on CASE2: the reference script asks for AutoTsit5(Rosenbrock23(autodiff=false))
+ * (case2/case2.jl:26); the preset selects CRNN_SOLVER_ROSENBROCK23, the stepper BASELINE.json's headline is quoted on.
+ * crnn_config_set_solver(cfg, CRNN_SOLVER_AUTOTSIT5) selects the composite (on case2 it never leaves Tsit5: see above). */
 enum { CRNN_PRESET_CASE1 = 1, CRNN_PRESET_CASE2 = 2, CRNN_PRESET_ROBER = 3, CRNN_PRESET_HYCHEM = 4 };
 
 /* Problem descriptor: what `ODEProblem(crnn, u0, tspan; saveat, atol, rtol)` plus
@@ -92,7 +94,14 @@ typedef struct crnn_config {
     int32_t loss_kind;            /* CRNN_LOSS_* */
     int32_t clamp_pred;           /* pred = clamp.(Array(sol), -ub, ub) (case1/2) */
     int32_t maxiters;             /* solver iterations (accepted+rejected) per trajectory */
-    int32_t errnorm_sens;         /* 0: primal-only error norm; 1: reserved (ForwardDiff-style) */
+    int32_t errnorm_sens;         /* error norm of the step-size controller in GRADIENT calls.  0: primal values only (a gradient
+                                     call takes the step sequence of a plain solve; every gradient algorithm).  1: ForwardDiff's
+                                     dual-inclusive norm, chunked like ForwardDiff.pickchunksize -- what the reference's
+                                     ForwardDiff.gradient through the adaptive solver does (case2/case2.jl:195); Rosenbrock23 and
+                                     Tsit5, forward tangents (grad_mode AUTO or FORWARD), CRNN right-hand side.  crnn_solve then
+                                     treats its n_dir directions as ONE chunk (n_dir <= 9 case2, 12 case1 / robertson);
+                                     crnn_loss_grad / crnn_train_step run ForwardDiff's chunks, loss and statistics from a
+                                     final plain solve. */
     int32_t device;               /* HIP device ordinal */
     int32_t cols_per_lane;        /* kernel tuning: tangent columns per lane, 0 = auto */
     int32_t solver;               /* CRNN_SOLVER_*; set it with crnn_config_set_solver (also sets the controller) */

@@ -12,6 +12,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+    config.addinivalue_line("markers", "needs_reference: reads /root/reference (build container only; never joins the -m gpu session)")
 
 
 def _gpu_present():
@@ -31,7 +32,7 @@ def pytest_collection_modifyitems(config, items):
     if not _gpu_present():
         return
     for it in items:
-        if it.get_closest_marker("gpu") is None:
+        if it.get_closest_marker("gpu") is None and it.get_closest_marker("needs_reference") is None:
             it.add_marker(pytest.mark.gpu)
 
 

@@ -22,6 +22,7 @@ def test_checkpoint_roundtrip(tmp_path):
     assert np.array_equal(d["l_loss_train"], [0.5, 0.25])
 
 
+@pytest.mark.needs_reference       # CPU-container only: never part of the GPU box's `-m gpu` session (tests/conftest.py)
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF, "case2", "checkpoint", "mymodel.bson")), reason="reference tree not mounted")
 def test_reads_the_reference_checkpoints(fx):
     pytest.importorskip("bson")
@@ -41,10 +42,14 @@ def test_load_exp_converts_temperature_to_time(tmp_path):
     e = load_exp(path, 5.0)
     assert np.array_equal(e[:, 0], [0.0, 120.0, 360.0])                   # (T - 100) * 60 / beta, duplicates dropped
     assert np.array_equal(e[:, 1:], [[1.0, 2.0], [3.0, 4.0], [5.0, 6.0]])
+
+
+@pytest.mark.needs_reference
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "Cathode_NCM333_UQ", "exp_data", "UNCERT_cath_1_5.csv")), reason="reference tree not mounted")
+def test_committed_cathode_fixture_was_reduced_from_the_reference_csv():
+    from crnn_amd.io import load_exp
     with open(os.path.join(HERE, "golden", "fixtures_cathode.json")) as f:
         cfx = json.load(f)
-    csv = os.path.join(REF, "Cathode_NCM333_UQ", "exp_data", "UNCERT_cath_1_5.csv")
-    if os.path.exists(csv):                                               # the committed fixture was reduced from this file
-        e = load_exp(csv, 5.0)
-        s = cfx["sets"][1]
-        assert np.allclose(e[:, 0], s["ts"]) and np.allclose(e[:, 1:].mean(axis=1), s["dbar"])
+    e = load_exp(os.path.join(REF, "Cathode_NCM333_UQ", "exp_data", "UNCERT_cath_1_5.csv"), 5.0)
+    s = cfx["sets"][1]
+    assert np.allclose(e[:, 0], s["ts"]) and np.allclose(e[:, 1:].mean(axis=1), s["dbar"])
