@@ -21,7 +21,7 @@
 // Tsit5: dt *= 2 and switch to Rosenbrock23; more than 3 negatives in a row on Rosenbrock23: dt /= 2 and switch back.
 // eigen_est is max_i |k7_i - k6_i| / |g7_i - g6_i| after a Tsit5 attempt and the Inf-norm of J(u_n) after a
 // Rosenbrock23 attempt.  A state vector with a component that never moves (case2 carries its constant temperature as
-// the 7th state) gives 0/0 = NaN there, Julia's `maximum` propagates it and NaN > 9/10 is false: such a problem stays
+// the 7th state) gives 0/0 = NaN there, Julia's `maximum` propagates it and NaN > 9/10 is false ([UNVERIFIED-DEP]): such a problem stays
 // on Tsit5 for ever, so HAS_T shapes are instantiated with COMPOSITE = false.  The PI exponents follow the running
 // algorithm (beta1 = 7/(10 order), beta2 = 2/(5 order)); gamma, qmin, qmax, the steady band and qold are shared.
 #pragma once

@@ -65,9 +65,10 @@ enum { CRNN_RET_SUCCESS = 0, CRNN_RET_MAXITERS = 1, CRNN_RET_DTMIN = 2, CRNN_RET
 /* time steppers (reference: alg = Rosenbrock23(...) rober_crnn.jl:33, Tsit5() case1.jl:28, AutoTsit5(Rosenbrock23())
  * case2.jl:26).  AUTOTSIT5 is OrdinaryDiffEq's stiffness-switching composite with its default AutoSwitch constants
  * (10 stiff / 3 non-stiff steps in a row, tolerances 9/10, dt factor 2, Tsit5 stability size 3.5068); it exists for the
- * discrete-adjoint gradient only (grad_mode AUTO or ADJOINT).  A state vector with a component that never moves -- the
- * constant temperature of has_temp = 1 -- makes the composite's stiffness estimate NaN, so such a problem never leaves
- * Tsit5 (crnn_amd/csrc/auto_adj_kernel.hpp). */
+ * discrete-adjoint gradient only (grad_mode AUTO or ADJOINT).  [UNVERIFIED-DEP: the switching rule is restated from
+ * OrdinaryDiffEq's published algorithm, the package is not in the reference tree.]  Under that restatement a state vector
+ * with a component that never moves -- the constant temperature of has_temp = 1 -- makes the stiffness estimate 0/0 = NaN,
+ * and such a problem never leaves Tsit5 (crnn_amd/csrc/auto_adj_kernel.hpp). */
 enum { CRNN_SOLVER_ROSENBROCK23 = 0, CRNN_SOLVER_TSIT5 = 1, CRNN_SOLVER_AUTOTSIT5 = 2 };
 /* How the loss gradient (ForwardDiff.gradient, case2/case2.jl:195) is formed.  Both differentiate the accepted steps
  * with dt held fixed and agree to rounding:
