@@ -259,10 +259,14 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_secondary as bs
             sec = {}
+
+            def progress(msg):
+                print(f"[bench] secondary: {msg}", file=sys.stderr, flush=True)
             ck = np.array(fx["case2_ckpt"]["p"])
             p_init = cases.case2_init_p(np.random.Generator(np.random.PCG64(7)))
             p_hard = np.array(json.load(open(os.path.join(ROOT, "tests", "golden", "case2_hard_p.json")))["p"])
             note = "case2, 65 536 ICs of the headline ensemble, Rosenbrock23 atol 1e-6 rtol 1e-3, adjoint gradient, fixed p: "
+            progress("case2 at fixed p (init / early training / diverged / errnorm_sens)")
             sec["case2_reference_init_p"] = bs.case2_fixed(u0, data, yscale, p_init, {"workload": note + "the reference's random initialiser (case2.jl:85-89)"})
             sec["case2_early_training_p"] = bs.case2_fixed(u0, data, yscale, p_hard, {
                 "workload": note + "p after epoch 2 of a reference-schedule training run from that initialiser -- the hardest state a healthy run "
@@ -287,18 +291,24 @@ def main():
                                    "attempt) + the plain solve for the loss: the reference-faithful gradient mode; kernel_ms is the LAST launch only, "
                                    "call_ms the whole loss+gradient call"}, reps=3, errnorm_sens=1)
             sec["case2_errnorm_sens1"]["value"] = B / (sec["case2_errnorm_sens1"]["call_ms"] * 1e-3)
+            progress("case2 B = 131072 / 262144")
             ub_, db_, yb_ = bs.case2_ensemble(262144, [1234, 99], device=local_rank)
             for nb in (131072, 262144):
                 sec[f"case2_B{nb}"] = bs.case2_fixed(ub_[:nb], db_[:nb], yb_, ck, {
                     "workload": f"case2, {nb} ICs on one GPU (more than the 65 536 resident lanes: queued by the previous launch's step counts), "
                                 "checkpoint p, adjoint gradient"})
             del ub_, db_
+            progress("robertson")
             sec["robertson_B65536"] = bs.robertson(device=local_rank)
+            progress("hychem 32768")
             sec["hychem_B32768"] = bs.hychem(device=local_rank)
+            progress("hychem 262144")
             sec["hychem_B262144_one_gpu"] = bs.hychem(B=262144, reps=3, device=local_rank)
             sec["hychem_B262144_one_gpu"]["workload"] = ("HyChem pyrolysis CRNN, ALL 262 144 ICs of BASELINE config 4 on ONE GPU (eight generations of "
                                                          "wavefronts, queued by the previous launch's step counts), adjoint gradient (P = 211)")
+            progress("cathode 4096 x 256")
             sec["cathode_4096x256"] = bs.cathode(device=local_rank)
+            progress("done")
             out["secondary"] = sec
         # RCCL prints a version banner through C stdio (block-buffered on a pipe): flush it first so
         # that the JSON line is the LAST line of stdout.

@@ -29,6 +29,11 @@ def pytest_collection_modifyitems(config, items):
     in one go: golden vectors -> oracle (test_oracle_golden, the CPU halves of test_cathode / test_hychem, test_host) ->
     HIP kernels.  Without a GPU nothing changes: `-m "not gpu"` runs the CPU tests, the GPU tests stay deselected.
     (tryfirst: this runs before the mark plugin evaluates -m.)"""
+    # no test may hang a session: a default per-test limit wherever pytest-timeout is installed (explicit marks win)
+    if config.pluginmanager.hasplugin("timeout"):
+        for it in items:
+            if it.get_closest_marker("timeout") is None:
+                it.add_marker(pytest.mark.timeout(900))
     if not _gpu_present():
         return
     for it in items:

@@ -18,6 +18,13 @@ import torch.multiprocessing as mp
 from conftest import ROOT, oracle_problem
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _shard_buffer(orc, setup, p, first, count, P, pad):
     th, dth = orc.p2vec(2, 6, 3, p)
     pb = oracle_problem(orc, "case2", setup)
@@ -35,7 +42,8 @@ def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     try:
         import json
         from crnn_amd import Optimiser, PRESET_CASE2
@@ -67,14 +75,20 @@ def test_two_rank_data_parallel_equals_single_process(orc, case2_setup):
     from crnn_amd.dist import mean_loss_and_grad_from_sums
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q), daemon=True) for r in range(2)]
     for pr in procs:
         pr.start()
-    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
-    for pr in procs:
-        pr.join(60)
-        assert pr.exitcode == 0
+    try:
+        res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+        for pr in procs:
+            pr.join(60)
+            assert pr.exitcode == 0
+    finally:
+        for pr in procs:
+            if pr.is_alive():
+                pr.kill()
+                pr.join(30)
     # single-process reference (whole ensemble, same oracle stand-in)
     p = case2_setup["p_init"].copy()
     opt = Optimiser(25, PRESET_CASE2)
@@ -94,7 +108,8 @@ def test_two_rank_data_parallel_equals_single_process(orc, case2_setup):
 def _svgd_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     try:
         from crnn_amd.dist import allgather_rows, shard_range
         from oracle.oracle import svgd_update      # CPU stand-in for the device SVGD move (no GPU here)
@@ -117,14 +132,20 @@ def test_two_rank_particle_sharding_and_svgd_update():
     from oracle.oracle import svgd_update
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_svgd_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = _free_port()
+    procs = [ctx.Process(target=_svgd_worker, args=(r, 2, port, q), daemon=True) for r in range(2)]
     for pr in procs:
         pr.start()
-    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
-    for pr in procs:
-        pr.join(60)
-        assert pr.exitcode == 0
+    try:
+        res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+        for pr in procs:
+            pr.join(60)
+            assert pr.exitcode == 0
+    finally:
+        for pr in procs:
+            if pr.is_alive():
+                pr.kill()
+                pr.join(30)
     rng = np.random.default_rng(0)
     p = 1 + 0.05 * rng.standard_normal((11, 17))
     for _ in range(3):

@@ -30,8 +30,10 @@ def _worker(rank, world, port, mode, tape1, q):
 
     import torch
     import torch.distributed as dist
+    import datetime
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # a collective whose partner died must fail, not wait for ever
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     try:
         from crnn_amd import NeuralODE, ODEProblem, Optimiser, PRESET_ROBER
         from crnn_amd.dist import DataParallel, shard_range
@@ -55,18 +57,31 @@ def _worker(rank, world, port, mode, tape1, q):
         dist.destroy_process_group()
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _run(mode, tape1):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + (os.getpid() % 2000) + (abs(hash((mode, tape1))) % 37)   # one port per (mode, tape) run
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, tape1, q)) for r in range(2)]
+    port = _free_port()                                    # a fresh port per run (a reused one may still be in TIME_WAIT)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, tape1, q), daemon=True) for r in range(2)]
     for pr in procs:
         pr.start()
-    res = sorted([q.get(timeout=400) for _ in procs], key=lambda t: t[0])
-    for pr in procs:
-        pr.join(120)
-        assert pr.exitcode == 0
+    try:
+        res = sorted([q.get(timeout=400) for _ in procs], key=lambda t: t[0])
+        for pr in procs:
+            pr.join(120)
+            assert pr.exitcode == 0
+    finally:
+        for pr in procs:          # never leave a rank behind (it would block the interpreter's exit)
+            if pr.is_alive():
+                pr.kill()
+                pr.join(30)
     return res
 
 
