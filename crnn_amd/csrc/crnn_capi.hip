@@ -688,7 +688,16 @@ int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int 
         if (r > 0) return fail(c, "crnn_solve: a trajectory accepted more steps than the adjoint tape holds; raise crnn_config.tape_steps");
         return r;
     }
-    if (P > 0 && c->cfg.grad_mode != CRNN_GRAD_FORWARD && !c->force_forward) {
+    // Tiny ensembles (the reference's own schedule is one experiment per update): with most lanes idle anyway, one tangent
+    // column per lane -- a whole lane group per trajectory, a single sweep -- has the shorter critical path than the
+    // adjoint's forward + reverse sweeps (case2, B = 1: 0.28 vs 0.33 ms per launch, 0.33 vs 0.42 ms per call; the break-even
+    // is where the lane groups fill the chip).  grad_mode AUTO only; the gradient is the same derivative either way.
+    const KernelEntry *k_small = nullptr;
+    if (P > 0 && c->cfg.grad_mode == CRNN_GRAD_AUTO && !c->force_forward) {
+        for (const auto &ke : kKernels)
+            if (shape_match(c, ke) && ke.C == 1 && ke.L >= P && count <= (int64_t)c->num_cu * 4 * (64 / ke.L)) k_small = &ke;
+    }
+    if (P > 0 && c->cfg.grad_mode != CRNN_GRAD_FORWARD && !c->force_forward && !k_small) {
         const AdjEntry *ka = find_adjoint(c);
         if (ka) {
             const bool defer = c->defer_next;
@@ -700,7 +709,7 @@ int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int 
             return fail(c, "crnn_solve: grad_mode = ADJOINT but no adjoint kernel exists for this (solver, ns, nr, has_temp)");
         }
     }
-    const KernelEntry *k = pick_kernel(c, P);
+    const KernelEntry *k = k_small ? k_small : pick_kernel(c, P);
     if (!k) return fail(c, "crnn_solve: no gfx950 kernel instantiated for this (ns, nr, has_temp, n_dir) shape");
     const int C = k->C, L = k->L;
     const int gpw = 64 / L;
