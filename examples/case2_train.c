@@ -20,6 +20,15 @@
         if (rc_ != 0) { fprintf(stderr, "%s -> %d: %s\n", #call, (int)rc_, crnn_last_error(ctx)); return 1; } \
     } while (0)
 
+/* The host's own collective handed to the library (crnn_comm_set_allreduce): a one-process host has nothing to add, a
+ * multi-process one would call MPI_Allreduce(MPI_IN_PLACE, d_buf, n, MPI_DOUBLE, MPI_SUM, comm) on the device pointer here. */
+static int n_collectives_seen = 0;
+static int32_t host_allreduce(void *d_buf, int32_t n, void *hip_stream, void *user) {
+    (void)d_buf; (void)hip_stream; (void)user;
+    n_collectives_seen += (n == 25 + 6);      /* [grad(P) | n_overflow | loss_sum, n_ok, n_accept, n_reject, n_traj] */
+    return 0;
+}
+
 static double urand(unsigned long long *s) {
     *s ^= *s >> 12; *s ^= *s << 25; *s ^= *s >> 27;
     return (double)((*s * 2685821657736338717ULL) >> 11) / 9007199254740992.0;
@@ -84,8 +93,15 @@ int main(int argc, char **argv) {
     crnn_opt_config opt;
     CHECK(crnn_opt_preset(&opt, CRNN_PRESET_CASE2));
     CHECK(crnn_train_init(ctx, &opt, p0));
+    CHECK(crnn_comm_set_allreduce(ctx, host_allreduce, NULL));
+    printf("library build: %s\n", crnn_build_info());
     double loss_first = 0.0, loss = 0.0;
+    double p_ck[P], st_ck[2 * P + 4];
     for (int it = 0; it < n_steps; ++it) {
+        if (it == n_steps / 2) {   /* `@save ... p opt`: parameters + optimiser state (ADAM moments, beta powers, ExpDecay) */
+            CHECK(crnn_get_params(ctx, p_ck));
+            CHECK(crnn_get_opt_state(ctx, st_ck));
+        }
         CHECK(crnn_train_step(ctx, 0, B, D, &loss));
         if (it == 0) loss_first = loss;
         crnn_stats st;
@@ -95,6 +111,20 @@ int main(int argc, char **argv) {
     }
     double p_end[P], l_mean = 0.0, g[P];
     CHECK(crnn_get_params(ctx, p_end));
+    if (crnn_opt_state_len(P) != 2 * P + 4 || n_collectives_seen != n_steps || crnn_comm_collectives(ctx) != n_steps) {
+        fprintf(stderr, "collective / state bookkeeping is off: %d %lld\n", n_collectives_seen, (long long)crnn_comm_collectives(ctx));
+        return 4;
+    }
+    {   /* `@load` and resume: from the mid-run checkpoint the second half repeats bit for bit */
+        double p_re[P];
+        CHECK(crnn_set_params(ctx, p_ck));
+        CHECK(crnn_set_opt_state(ctx, st_ck));
+        for (int it = n_steps / 2; it < n_steps; ++it) CHECK(crnn_train_step(ctx, 0, B, D, NULL));
+        CHECK(crnn_get_params(ctx, p_re));
+        for (int k = 0; k < P; ++k)
+            if (p_re[k] != p_end[k]) { fprintf(stderr, "restart diverged at p[%d]\n", k); return 5; }
+        printf("restart from the mid-run checkpoint reproduces the final parameters bit for bit\n");
+    }
     CHECK(crnn_loss_grad(ctx, p_end, 0, B, D, &l_mean, g, NULL));       /* epoch-end loss (case2.jl:199-201) + gradient */
     double gn = 0.0;
     for (int k = 0; k < P; ++k) gn += g[k] * g[k];

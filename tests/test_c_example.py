@@ -36,6 +36,7 @@ def test_c_example_trains_on_the_gpu(tmp_path):
     run = subprocess.run([exe, "2048", "12"], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stdout[-1500:] + run.stderr[-1500:]
     assert "final mean loss" in run.stdout and "ok 2048/2048" in run.stdout
+    assert "library build: src=" in run.stdout and "restart from the mid-run checkpoint reproduces" in run.stdout
 
 
 @pytest.mark.gpu
