@@ -291,7 +291,7 @@ def test_theta_level_directions(orc, case2_setup):
 
 
 def test_two_gpu_data_parallel_bench_when_available():
-    """The N > 1 path end to end (one process per GPU, RCCL all-reduce of the 30-double vector per step): only on a node
+    """The N > 1 path end to end (one process per GPU, RCCL all-reduce of the 31-double vector per step): only on a node
     that shows at least two GPUs -- the boxes gpurun hands out have one, where this self-skips and the N > 1 logic is
     covered by the gloo tests (tests/test_dist_gloo.py) and the 1-rank RCCL test."""
     import json

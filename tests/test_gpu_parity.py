@@ -268,7 +268,7 @@ def test_case1_rosenbrock23_adjoint_woodbury_4x4(orc, fx):
 
 
 def test_async_adjoint_training_and_deferred_replay(rober_setup):
-    """crnn_train_step does not wait for the adjoint's tape-overflow flag: a poisoned step is skipped on the device (and
+    """crnn_train_step does not wait for the adjoint's tape-overflow flag: a step whose overflow count is not zero is skipped on the device (and
     everything after it), and repeated in order with forward tangents when the host next looks.  End states must be
     bit-identical to training that never used the adjoint."""
     from crnn_amd import Optimiser, PRESET_ROBER
