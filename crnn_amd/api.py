@@ -155,8 +155,10 @@ class ODEProblem:
     mw: object = None             # HyChem: molar masses (preset: the reference's l_MW)
     grad_mode: int = 0            # GRAD_AUTO (adjoint where available) / GRAD_FORWARD (tangents) / GRAD_ADJOINT
     tape_steps: int = 0           # adjoint tape capacity per trajectory, 0 = auto
-    errnorm_sens: int = 0         # 1: ForwardDiff's dual-inclusive error norm drives the step sizes of gradient calls
-    errnorm_sens: int = 0         # 1: ForwardDiff's dual-inclusive error norm drives the step sizes of gradient calls
+    errnorm_sens: int = 0         # 1 / 2: ForwardDiff's dual-inclusive error norm drives the step sizes of gradient calls
+                                  # (1: squared norm / length(u), Julia-1.6-era DiffEqBase; 2: / totallength(u), later versions)
+    errnorm_sens: int = 0         # 1 / 2: ForwardDiff's dual-inclusive error norm drives the step sizes of gradient calls
+                                  # (1: squared norm / length(u), Julia-1.6-era DiffEqBase; 2: / totallength(u), later versions)
 
     def config(self) -> Config:
         cfg = Config()
@@ -364,8 +366,10 @@ class NeuralODE:
         self.last_chunk_stats = []
         for k0 in range(0, P, chunk):
             k1 = min(P, k0 + chunk)
-            _, _, g, _, _ = self._solve(self._ctx, self.B, th, dth[:, k0:k1], int(i_exp), 1, sample, False)
-            grad[k0:k1] = g
+            cols = np.zeros((dth.shape[0], chunk), order="F")     # every Dual carries `chunk` partials: the last chunk's
+            cols[:, :k1 - k0] = dth[:, k0:k1]                      # surplus ones are zero (they count in errnorm_sens = 2)
+            _, _, g, _, _ = self._solve(self._ctx, self.B, th, cols, int(i_exp), 1, sample, False)
+            grad[k0:k1] = g[:k1 - k0]
             self.last_chunk_stats.append((self.last_stats["n_accept"], self.last_stats["n_reject"]))
         return grad
 

@@ -580,7 +580,7 @@ int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int 
 // One ForwardDiff chunk with the dual-inclusive error norm: primal + P <= C*L tangent columns through every attempt
 // (ros23_sens_kernel.hpp), fixed-order reduction into c->d_red in the common layout.
 int32_t launch_sens_chunk(Ctx *c, const KernelEntry *k, const double *d_theta, const double *d_dtheta, int P, int64_t first,
-                          int64_t count, int n_save_active, bool want_pred) {
+                          int64_t count, int n_save_active, bool want_pred, int dual_partials) {
     const int C = k->C, L = k->L, gpw = 64 / L, waves = kSensBlock / 64;
     const int ppad = L * C, npart_pad = ppad + crnn::kExtra, npart = P + crnn::kTail;
     int occ = 0;
@@ -600,6 +600,7 @@ int32_t launch_sens_chunk(Ctx *c, const KernelEntry *k, const double *d_theta, c
     if (want_pred && ensure_pred(c)) return -1;
     crnn::SolveParams prm{};
     fill_params(c, prm, P, first, count, n_save_active, want_pred);
+    prm.norm_cols = c->cfg.errnorm_sens == 2 ? dual_partials : 0;
     if (upload_consts(c)) return -1;
     c->flags_zeroed = false;
     c->ev0 = c->ring0[c->n_launch % Ctx::kRing];
@@ -630,7 +631,7 @@ int32_t launch_sens(Ctx *c, const double *d_theta, const double *d_dtheta, int P
     const int cap = k->C * k->L;
     if (single_chunk) {
         if (P > cap) return fail(c, "crnn_solve: with errnorm_sens = 1 the directions of one call are one ForwardDiff chunk: n_dir <= " + std::to_string(cap));
-        return launch_sens_chunk(c, k, d_theta, d_dtheta, P, first, count, n_save_active, want_pred);
+        return launch_sens_chunk(c, k, d_theta, d_dtheta, P, first, count, n_save_active, want_pred, P);
     }
     const int chunk = fd_chunk_size(P);
     if (chunk > cap) return fail(c, "crnn_loss_grad: errnorm_sens = 1 chunk size exceeds the instantiated kernel");
@@ -643,7 +644,8 @@ int32_t launch_sens(Ctx *c, const double *d_theta, const double *d_dtheta, int P
     }
     for (int k0 = 0; k0 < P; k0 += chunk) {
         const int Pc = std::min(chunk, P - k0);
-        if (launch_sens_chunk(c, k, d_theta, d_dtheta + (size_t)k0 * c->n_theta, Pc, first, count, n_save_active, false)) return -1;
+        // every Dual of a chunked ForwardDiff.gradient carries `chunk` partials, the last chunk's surplus ones are zero
+        if (launch_sens_chunk(c, k, d_theta, d_dtheta + (size_t)k0 * c->n_theta, Pc, first, count, n_save_active, false, chunk)) return -1;
         HIP_TRY(c, hipMemcpyAsync(c->d_red_asm + k0, c->d_red, sizeof(double) * Pc, hipMemcpyDeviceToDevice, c->stream));
     }
     const int es = c->cfg.errnorm_sens;
@@ -949,9 +951,9 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
     if (cfg->abi_version != CRNN_ABI_VERSION) return fail(nullptr, "crnn_ctx_create: abi_version mismatch");
     if (cfg->ns < 1 || cfg->nr < 1 || cfg->ns + cfg->has_temp > CRNN_MAX_N || cfg->nr > CRNN_MAX_NR)
         return fail(nullptr, "crnn_ctx_create: ns/nr out of range");
-    if (cfg->errnorm_sens != 0 && cfg->errnorm_sens != 1) return fail(nullptr, "crnn_ctx_create: errnorm_sens must be 0 or 1");
-    if (cfg->errnorm_sens == 1 && (cfg->solver == CRNN_SOLVER_AUTOTSIT5 || cfg->rhs_kind != CRNN_RHS_CRNN || cfg->grad_mode == CRNN_GRAD_ADJOINT))
-        return fail(nullptr, "crnn_ctx_create: errnorm_sens = 1 exists for Rosenbrock23 and Tsit5 with forward tangents (grad_mode AUTO or FORWARD) on the CRNN right-hand side");
+    if (cfg->errnorm_sens < 0 || cfg->errnorm_sens > 2) return fail(nullptr, "crnn_ctx_create: errnorm_sens must be 0, 1 or 2");
+    if (cfg->errnorm_sens != 0 && (cfg->solver == CRNN_SOLVER_AUTOTSIT5 || cfg->rhs_kind != CRNN_RHS_CRNN || cfg->grad_mode == CRNN_GRAD_ADJOINT))
+        return fail(nullptr, "crnn_ctx_create: errnorm_sens = 1 / 2 exists for Rosenbrock23 and Tsit5 with forward tangents (grad_mode AUTO or FORWARD) on the CRNN right-hand side");
     if (cfg->solver != CRNN_SOLVER_ROSENBROCK23 && cfg->solver != CRNN_SOLVER_TSIT5 && cfg->solver != CRNN_SOLVER_AUTOTSIT5)
         return fail(nullptr, "crnn_ctx_create: unknown solver");
     if (cfg->rhs_kind != CRNN_RHS_CRNN && cfg->rhs_kind != CRNN_RHS_HYCHEM) return fail(nullptr, "crnn_ctx_create: unknown rhs_kind");
@@ -979,7 +981,7 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
         delete c;
         return fail(nullptr, "crnn_ctx_create: no gfx950 kernel instantiated for this (solver, ns, nr, has_temp)");
     }
-    if (cfg->errnorm_sens == 1 && !find_sens(c)) {
+    if (cfg->errnorm_sens != 0 && !find_sens(c)) {
         delete c;
         return fail(nullptr, "crnn_ctx_create: errnorm_sens = 1 has no kernel for this (ns, nr, has_temp)");
     }

@@ -352,7 +352,8 @@ __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm
                 const double sc = fma(kc->rtol[i], sqrt(fmax(nai, nbi)), kc->atol[i]);
                 es += eei / (sc * sc);
             }
-            es = es * (1.0 / N);
+            // / length(u) (errnorm_sens = 1) or / totallength(u) = n (1 + partials per Dual) (errnorm_sens = 2)
+            es = es / ((double)N * (1.0 + (double)prm.norm_cols));
             if (!isfinite(es)) { rc = 3; break; }
             const bool ee_zero = (es == 0.0);
             const double lEE = 0.5 * flog(ee_zero ? 1.0 : es);

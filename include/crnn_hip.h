@@ -102,7 +102,10 @@ typedef struct crnn_config {
                                      Tsit5, forward tangents (grad_mode AUTO or FORWARD), CRNN right-hand side.  crnn_solve then
                                      treats its n_dir directions as ONE chunk (n_dir <= 9 case2, 12 case1 / robertson);
                                      crnn_loss_grad / crnn_train_step run ForwardDiff's chunks, loss and statistics from a
-                                     final plain solve. */
+                                     final plain solve.  The squared norm is divided by length(u) -- DiffEqBase of the Julia-1.6
+                                     era the reference's README names for case1 / case2 / robertson.  2: the same with
+                                     totallength(u) = n (1 + partials per Dual) as divisor, the form later DiffEqBase versions
+                                     use (the reference pins no version for these scripts: pick the one your Manifest has). */
     int32_t device;               /* HIP device ordinal */
     int32_t cols_per_lane;        /* kernel tuning: tangent columns per lane, 0 = auto */
     int32_t solver;               /* CRNN_SOLVER_*; set it with crnn_config_set_solver (also sets the controller) */

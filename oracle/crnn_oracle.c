@@ -71,7 +71,7 @@ typedef struct orc_problem {
     int32_t clamp_pred;         /* pred = clamp(sol, -ub, ub)  (case1/case2) */
     int32_t loss_kind;          /* 0 = MAE, 1 = MSE */
     int32_t maxiters;
-    int32_t errnorm_sens;       /* 0 primal-only norm, 1 ForwardDiff-style */
+    int32_t errnorm_sens;       /* 0 primal-only norm, 1 ForwardDiff-style (/ length(u)), 2 ForwardDiff-style (/ totallength(u)) */
     int32_t solver;             /* 0 Rosenbrock23, 1 Tsit5 (case1/case1.jl:28), 2 AutoTsit5(Rosenbrock23) (case2/case2.jl:26) */
     int32_t pad_;
     double lb, ub;              /* log-clamp window; ub may be +inf */
@@ -540,7 +540,11 @@ static int solve_one_ws(const orc_problem *pb, const double *th, const double *d
                     double sc = pb->atol[i] + pb->rtol[i] * sqrt(fmax(na, nb));
                     ssum += ee / (sc * sc);
                 }
-                EEst = sqrt(ssum / n);
+                /* errnorm_sens 1: sqrt(sum(sse, u) / length(u)) -- DiffEqBase of the Julia-1.6 era (case1, case2, robertson name no
+                   versions: README.md:15-21); 2: / totallength(u) = n (1 + partials per Dual), the form later DiffEqBase
+                   versions use (the cathode Manifest pins 6.189).  P counts every partial of the Dual: a caller passes the
+                   zero-padded directions of ForwardDiff's last chunk too. */
+                EEst = sqrt(ssum / (pb->errnorm_sens == 2 ? (double)n * (1.0 + (double)P) : (double)n));
                 if (!isfinite(EEst)) { retcode = 3; break; }
                 accept = (EEst <= 1.0);
             }
@@ -740,7 +744,11 @@ static int solve_one_tsit5(const orc_problem *pb, const double *th, const double
                     double sc = pb->atol[i] + pb->rtol[i] * sqrt(fmax(na, nb));
                     ssum += ee / (sc * sc);
                 }
-                EEst = sqrt(ssum / n);
+                /* errnorm_sens 1: sqrt(sum(sse, u) / length(u)) -- DiffEqBase of the Julia-1.6 era (case1, case2, robertson name no
+                   versions: README.md:15-21); 2: / totallength(u) = n (1 + partials per Dual), the form later DiffEqBase
+                   versions use (the cathode Manifest pins 6.189).  P counts every partial of the Dual: a caller passes the
+                   zero-padded directions of ForwardDiff's last chunk too. */
+                EEst = sqrt(ssum / (pb->errnorm_sens == 2 ? (double)n * (1.0 + (double)P) : (double)n));
                 if (!isfinite(EEst)) { retcode = 3; break; }
                 accept = (EEst <= 1.0);
             }

@@ -41,19 +41,21 @@ def _setup(case, case2_setup, rober_setup, fx):
     return s, mk, (1, 5, 4), mkpb
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("case,pkey", [("case2", "p_ckpt"), ("case2", "p_init"), ("rober", "p_ckpt"), ("case1", "p_ckpt"),
                                        ("case1-tsit5", "p_ckpt"), ("case2-tsit5", "p_ckpt"), ("case2-tsit5", "p_init")])
-def test_chunked_dual_norm_gradient_matches_oracle(orc, fx, case2_setup, rober_setup, case, pkey):
+def test_chunked_dual_norm_gradient_matches_oracle(orc, fx, case2_setup, rober_setup, case, pkey, mode):
     from crnn_amd.api import fd_chunk_size
     s, mk, (kind, ns, nr), mkpb = _setup(case, case2_setup, rober_setup, fx)
     p = s[pkey]
-    node = mk(errnorm_sens=1)
+    # mode 1: squared norm / length(u) (DiffEqBase of the Julia-1.6 era); mode 2: / totallength(u) = n (1 + partials per Dual)
+    node = mk(errnorm_sens=mode)
     node.set_ensemble(s["u0"], s["data"], s["yscale"])
     th, dth = orc.p2vec(kind, ns, nr, p)
     P = dth.shape[1]
     chunk = fd_chunk_size(P)
     assert chunk == {25: 9, 43: 11, 24: 12}[P]
-    pb1 = mkpb(orc, errnorm_sens=1)
+    pb1 = mkpb(orc, errnorm_sens=mode)
     B = s["u0"].shape[0]
     differs = 0
     for b in range(min(B, 6)):
@@ -62,12 +64,16 @@ def test_chunked_dual_norm_gradient_matches_oracle(orc, fx, case2_setup, rober_s
         gref = np.zeros(P)
         for c, k0 in enumerate(range(0, P, chunk)):
             k1 = min(P, k0 + chunk)
-            r = orc.solve_one(pb1, th, s["u0"][b], s["tsteps"], s["data"][b], dtheta=dth[:, k0:k1], want_pred=False)
-            gref[k0:k1] = r["grad"]
+            cols = np.zeros((dth.shape[0], chunk), order="F")      # the Dual carries `chunk` partials, the surplus ones zero
+            cols[:, :k1 - k0] = dth[:, k0:k1]
+            r = orc.solve_one(pb1, th, s["u0"][b], s["tsteps"], s["data"][b], dtheta=cols, want_pred=False)
+            gref[k0:k1] = r["grad"][:k1 - k0]
             assert node.last_chunk_stats[c] == (r["naccept"], r["nreject"]), (case, b, c)
             differs += (r["naccept"], r["nreject"]) != (plain["naccept"], plain["nreject"])
         assert np.max(np.abs(g - gref)) < 1e-7 * np.max(np.abs(gref)), (case, b)
-    assert differs > 0        # the dual-inclusive norm really changes the step sequence somewhere
+    if mode == 1:
+        assert differs > 0    # the dual-inclusive norm really changes the step sequence somewhere (mode 2 divides by n (1 + N):
+                              # there the sequence may coincide with the plain one on an easy problem)
 
 
 def test_loss_grad_and_training_step_assemble_the_chunks(orc, case2_setup):
