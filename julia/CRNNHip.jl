@@ -67,7 +67,8 @@ function ODEProblem(preset::Integer, tsteps::AbstractVector; atol=nothing, rtol=
         cfg = deepcopy(cfg)            # a second context with the same problem constants (predict_neuralode's one-IC context)
     end
     # errnorm_sens = 1: the step-size controller sees ForwardDiff's dual-inclusive error norm, i.e. a gradient call
-    # takes the step sequence `ForwardDiff.gradient` through the adaptive solver takes (the reference-faithful mode)
+    # takes the step sequence `ForwardDiff.gradient` through the adaptive solver takes (the reference-faithful mode;
+    # squared norm / length(u), DiffEqBase of the Julia-1.6 era).  errnorm_sens = 2: / totallength(u), later DiffEqBase.
     errnorm_sens === nothing || (cfg.errnorm_sens = errnorm_sens)
     alg === nothing || check(ccall((:crnn_config_set_solver, LIB), Int32, (Ref{Config}, Int32), cfg, alg))   # also sets the PI exponents
     cfg.n_save = length(tsteps); cfg.device = device
