@@ -14,7 +14,8 @@
 //     W k3' = f2' - c32 (k2' - f1') - 2 (k1' - f0') + gam J' k3        e' = dt/6 (k1' - 2 k2' + k3')
 //     EEst^2 = 1/n sum_i (e_i^2 + sum_k e'_ik^2) / (atol_i + rtol_i sqrt(max(u_i^2 + sum_k s_ik^2, u+_i^2 + sum_k s+_ik^2)))^2
 //
-// ([UNVERIFIED-DEP] DiffEqBase.ODE_DEFAULT_NORM on Dual arrays -- DiffEqBase is not vendored with the reference; the initial step size uses the primal values only.)
+// ([UNVERIFIED-DEP] DiffEqBase.ODE_DEFAULT_NORM on Dual arrays -- DiffEqBase is not vendored with the reference.  The
+// initial step size uses the same norm: f0 and f1 carry the partials of p -- sens_init_dt below.)
 //
 // MI355X mapping: the lane-group layout of ros23_kernel.hpp (L lanes own one trajectory, C columns each, the primal
 // step computed redundantly, a per-group LDS step record that lane 0 of the group publishes) with three differences:
@@ -51,6 +52,101 @@ struct RecS {
     static constexpr int B2 = B1 + NS;
     static constexpr int NREC = B2 + NS;
 };
+
+// Hairer's initial step (OrdinaryDiffEq ode_determine_initdt) when the state carries partials: u0 is promoted to Duals with
+// zero partials, f0 = f(u0, p) and f1 = f(u0 + dt0 f0, p) carry the partials of p, and every internalnorm is the dual-
+// inclusive one -- d1 and d2 grow by the partials, d0 only shares the divisor ([UNVERIFIED-DEP] like the norm itself).
+// Every lane of the group calls this with the same primal point (x0, r0, f0) and its own C columns; the partial sums are
+// combined over the group's L lanes in lane order.  Stmp: the lane's LDS slot (C * NS doubles, stride 64) parks f0'.
+template <int NS, int NR, bool HAS_T, bool USE_SCALE, int C, int L, int ORDER>
+__device__ __forceinline__ double sens_init_dt(const double *__restrict__ th, const KConst *kc, const double *dcols, const int pitch,
+                                               double *Stmp, const double (&u)[NS], const double (&f0)[NS], const double (&x0)[NS],
+                                               const double (&r0)[NR], const double (&bT)[NR], const double xT, const double Tconst,
+                                               const double dtmax, const int norm_cols, const int gbase) {
+    using L_ = Lay<NS, NR, HAS_T>;
+    constexpr int N = L_::N;
+    auto group_sum = [&](double v) -> double {
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < L; ++q) a += __shfl(v, gbase + q);
+        return a;
+    };
+    const double idiv = 1.0 / ((double)N * (1.0 + (double)norm_cols));
+    double sk[NS], d0 = 0.0, d1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        sk[i] = frcp(fma(fabs(u[i]), kc->rtol[i], kc->atol[i]));
+        const double a = u[i] * sk[i], c = f0[i] * sk[i];
+        d0 = fma(a, a, d0);
+        d1 = fma(c, c, d1);
+    }
+    if (HAS_T) { const double a = Tconst * frcp(fma(fabs(Tconst), kc->rtol[NS], kc->atol[NS])); d0 = fma(a, a, d0); }
+    double d1p = 0.0;
+#pragma unroll 1
+    for (int qc = 0; qc < C; ++qc) {
+        const double *dcol = dcols + qc * pitch;
+        double f0p[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) f0p[i] = 0.0;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            double e = dcol[L_::wb(j)];
+            if (HAS_T) e = fma(dcol[L_::wi(NS, j)], xT, e);
+#pragma unroll
+            for (int c = 0; c < NS; ++c) e = fma(dcol[L_::wi(c, j)], x0[c], e);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) f0p[i] = fma(fma(th[L_::wo(i, j)], e, dcol[L_::wo(i, j)]), r0[j], f0p[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            if (USE_SCALE) f0p[i] *= kc->scale[i];
+            Stmp[(qc * NS + i) * 64] = f0p[i];
+            const double c = f0p[i] * sk[i];
+            d1p = fma(c, c, d1p);
+        }
+    }
+    d1 += group_sum(d1p);
+    d0 = sqrt(d0 * idiv);
+    d1 = sqrt(d1 * idiv);
+    double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 / d1);
+    dt0 = fmin(dt0, dtmax);
+    double u1[NS], x1[NS], g1[NS], r1[NR], f1[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) u1[i] = fma(dt0, f0[i], u[i]);
+    features<NS>(u1, kc->lb, kc->ub, x1, g1);
+    rates<NS, NR, HAS_T>(th, x1, bT, r1);
+    rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r1, kc->scale, f1);
+    double d2 = 0.0, d2p = 0.0;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { const double e = (f1[i] - f0[i]) * sk[i]; d2 = fma(e, e, d2); }
+#pragma unroll 1
+    for (int qc = 0; qc < C; ++qc) {
+        const double *dcol = dcols + qc * pitch;
+        double gs1[NS], f1p[NS];
+#pragma unroll
+        for (int c = 0; c < NS; ++c) { gs1[c] = g1[c] * (dt0 * Stmp[(qc * NS + c) * 64]); f1p[c] = 0.0; }
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            double e = dcol[L_::wb(j)];
+            if (HAS_T) e = fma(dcol[L_::wi(NS, j)], xT, e);
+#pragma unroll
+            for (int c = 0; c < NS; ++c) { e = fma(dcol[L_::wi(c, j)], x1[c], e); e = fma(th[L_::wi(c, j)], gs1[c], e); }
+#pragma unroll
+            for (int i = 0; i < NS; ++i) f1p[i] = fma(fma(th[L_::wo(i, j)], e, dcol[L_::wo(i, j)]), r1[j], f1p[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            if (USE_SCALE) f1p[i] *= kc->scale[i];
+            const double e = (f1p[i] - Stmp[(qc * NS + i) * 64]) * sk[i];
+            d2p = fma(e, e, d2p);
+        }
+    }
+    d2 = sqrt((d2 + group_sum(d2p)) * idiv) / dt0;
+    const double dm = fmax(d1, d2);
+    // 10^(-(2 + log10 dm)/order) = exp(-(ln 100 + ln dm)/order)
+    const double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : exp((-1.0 / ORDER) * (4.605170185988091368 + flog(dm)));
+    return fmax(kc->dtmin, fmin(fmin(100.0 * dt0, dt1), dtmax));
+}
 
 template <int NS, int NR, bool HAS_T, bool USE_SCALE, int C, int L, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm, const double *__restrict__ theta,
@@ -124,35 +220,11 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
         features<NS>(u, kc->lb, kc->ub, x0, g0);
         rates<NS, NR, HAS_T>(th, x0, bT, r0);
         rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r0, kc->scale, f0);
-        double dt;
-        {   // Hairer initial step (primal values only)
-            double d0 = 0.0, d1 = 0.0, sk[NS];
-#pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                sk[i] = frcp(fma(fabs(u[i]), kc->rtol[i], kc->atol[i]));
-                const double a = u[i] * sk[i], c = f0[i] * sk[i];
-                d0 = fma(a, a, d0);
-                d1 = fma(c, c, d1);
-            }
-            if (HAS_T) { const double a = Tconst * frcp(fma(fabs(Tconst), kc->rtol[NS], kc->atol[NS])); d0 = fma(a, a, d0); }
-            d0 = sqrt(d0 * (1.0 / N));
-            d1 = sqrt(d1 * (1.0 / N));
-            double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 / d1);
-            dt0 = fmin(dt0, dtmax);
-            double u1[NS], x1[NS], g1[NS], r1[NR], f1[NS];
-#pragma unroll
-            for (int i = 0; i < NS; ++i) u1[i] = fma(dt0, f0[i], u[i]);
-            features<NS>(u1, kc->lb, kc->ub, x1, g1);
-            rates<NS, NR, HAS_T>(th, x1, bT, r1);
-            rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r1, kc->scale, f1);
-            double d2 = 0.0;
-#pragma unroll
-            for (int i = 0; i < NS; ++i) { const double e = (f1[i] - f0[i]) * sk[i]; d2 = fma(e, e, d2); }
-            d2 = sqrt(d2 * (1.0 / N)) / dt0;
-            const double dm = fmax(d1, d2);
-            const double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : exp(-0.5 * (4.605170185988091368 + flog(dm)));
-            dt = fmax(kc->dtmin, fmin(fmin(100.0 * dt0, dt1), dtmax));
-        }
+        // Hairer initial step with the dual-inclusive norms (the Sn slot parks f0' meanwhile; it is zeroed below)
+        const double dt0_ = sens_init_dt<NS, NR, HAS_T, USE_SCALE, C, L, 2>(th, kc, dth_lds + (chunk * C) * NTHP, NTHP,
+                                                                              S_base + (size_t)C * NS * 64, u, f0, x0, r0, bT, xT,
+                                                                              Tconst, dtmax, prm.norm_cols, gbase);
+        double dt = dt0_;
         double t = t0, lqold = lqinit, loss_sum = 0.0;
         int iter = 0, jsave = 0, nacc = 0, nrej = 0, cur = 0, rc = -1;
 #pragma unroll

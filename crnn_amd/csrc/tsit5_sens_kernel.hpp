@@ -9,12 +9,13 @@
 //     e'   = dt sum_j btilde_j k_j'
 //     EEst^2 = 1/n sum_i (e_i^2 + sum_k e'_ik^2) / (atol_i + rtol_i sqrt(max(u_i^2 + sum_k s_ik^2, u+_i^2 + sum_k s+_ik^2)))^2
 //
-// ([UNVERIFIED-DEP] DiffEqBase.ODE_DEFAULT_NORM on Dual arrays; the initial step size uses the primal values only.)
+// ([UNVERIFIED-DEP] DiffEqBase.ODE_DEFAULT_NORM on Dual arrays; the initial step size uses the same norm.)
 // Lane groups (L lanes per trajectory, C columns each), a per-group LDS record with the seven stage areas (x, g, r) that
 // lane 0 of the group publishes, provisional save-point seeds / tangent columns / gradient increments until the group has
 // summed its lanes' norm contributions; trajectories by a plain grid-stride loop.
 #pragma once
 #include "tsit5_kernel.hpp"
+#include "ros23_sens_kernel.hpp"
 
 namespace crnn {
 
@@ -95,36 +96,10 @@ __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm
         features<NS>(u, kc->lb, kc->ub, x1, g1);
         rates<NS, NR, HAS_T>(th, x1, bT, r1);
         rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r1, kc->scale, k1);
-        double dt;
-        {   // Hairer initial step, order 5 (primal values only)
-            double d0 = 0.0, d1 = 0.0, sk[NS];
-#pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                sk[i] = frcp(fma(fabs(u[i]), kc->rtol[i], kc->atol[i]));
-                const double a = u[i] * sk[i], c = k1[i] * sk[i];
-                d0 = fma(a, a, d0);
-                d1 = fma(c, c, d1);
-            }
-            if (HAS_T) { const double a = Tconst * frcp(fma(fabs(Tconst), kc->rtol[NS], kc->atol[NS])); d0 = fma(a, a, d0); }
-            d0 = sqrt(d0 * (1.0 / N));
-            d1 = sqrt(d1 * (1.0 / N));
-            double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 / d1);
-            dt0 = fmin(dt0, dtmax);
-            double ua[NS], xa[NS], ga[NS], ra[NR], fa[NS];
-#pragma unroll
-            for (int i = 0; i < NS; ++i) ua[i] = fma(dt0, k1[i], u[i]);
-            features<NS>(ua, kc->lb, kc->ub, xa, ga);
-            rates<NS, NR, HAS_T>(th, xa, bT, ra);
-            rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, ra, kc->scale, fa);
-            double d2 = 0.0;
-#pragma unroll
-            for (int i = 0; i < NS; ++i) { const double e = (fa[i] - k1[i]) * sk[i]; d2 = fma(e, e, d2); }
-            d2 = sqrt(d2 * (1.0 / N)) / dt0;
-            const double dm = fmax(d1, d2);
-            // 10^(-(2 + log10 dm)/5) = exp(-(ln 100 + ln dm)/5)
-            const double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : exp(-0.2 * (4.605170185988091368 + flog(dm)));
-            dt = fmax(kc->dtmin, fmin(fmin(100.0 * dt0, dt1), dtmax));
-        }
+        // Hairer initial step (order 5) with the dual-inclusive norms: ros23_sens_kernel.hpp sens_init_dt
+        double dt = sens_init_dt<NS, NR, HAS_T, USE_SCALE, C, L, 5>(th, kc, dth_lds + (chunk * C) * NTHP, NTHP,
+                                                                      S_base + (size_t)C * NS * 64, u, k1, x1, r1, bT, xT, Tconst,
+                                                                      dtmax, prm.norm_cols, gbase);
         double t = t0, lqold = lqinit, loss_sum = 0.0;
         int iter = 0, jsave = 0, nacc = 0, nrej = 0, cur = 0, rc = -1;
 #pragma unroll

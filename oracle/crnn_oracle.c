@@ -397,6 +397,41 @@ static double init_dt(const orc_problem *pb, const double *th, const double *u0,
     return fmax(pb->dtmin, fmin(fmin(100.0 * dt0, dt1), dtmax));
 }
 
+/* The same initial step when the state carries partials (errnorm_sens != 0, P directions): OrdinaryDiffEq promotes u0
+   to Dual numbers with zero partials, f0 = f(u0, p) and f1 = f(u0 + dt0 f0, p) carry the partials of p, and every
+   `internalnorm` of ode_determine_initdt is the dual-inclusive one -- d1 and d2 grow by the partials, d0 does not (but
+   shares the divisor).  df0: n x P tangents of f0.  [UNVERIFIED-DEP] like the norm itself. */
+static double init_dt_sens(const orc_problem *pb, const double *th, const double *dth, int P, const double *u0,
+                           const double *f0, const double *df0, double tspan_len, int order) {
+    const int n = N_(pb), nth = orc_n_theta(pb);
+    const double div = pb->errnorm_sens == 2 ? (double)n * (1.0 + (double)P) : (double)n;
+    double sk[ORC_MAXN], d0 = 0, d1 = 0;
+    for (int i = 0; i < n; ++i) {
+        sk[i] = pb->atol[i] + fabs(u0[i]) * pb->rtol[i];
+        d0 += (u0[i] / sk[i]) * (u0[i] / sk[i]);
+        d1 += (f0[i] / sk[i]) * (f0[i] / sk[i]);
+        for (int k = 0; k < P; ++k) { double e = df0[i + (size_t)n * k] / sk[i]; d1 += e * e; }
+    }
+    d0 = sqrt(d0 / div); d1 = sqrt(d1 / div);
+    const double dtmax = tspan_len;
+    double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 / d1);
+    dt0 = fmin(dt0, dtmax);
+    double u1[ORC_MAXN] = {0}, f1[ORC_MAXN] = {0}, s1[ORC_MAXN], df1[ORC_MAXN];
+    for (int i = 0; i < n; ++i) u1[i] = u0[i] + dt0 * f0[i];
+    orc_rhs(pb, th, u1, f1);
+    double d2 = 0;
+    for (int i = 0; i < n; ++i) { double e = (f1[i] - f0[i]) / sk[i]; d2 += e * e; }
+    for (int k = 0; k < P; ++k) {
+        for (int i = 0; i < n; ++i) s1[i] = dt0 * df0[i + (size_t)n * k];
+        orc_rhs_jvp(pb, th, dth + (size_t)nth * k, u1, s1, df1);
+        for (int i = 0; i < n; ++i) { double e = (df1[i] - df0[i + (size_t)n * k]) / sk[i]; d2 += e * e; }
+    }
+    d2 = sqrt(d2 / div) / dt0;
+    const double dm = fmax(d1, d2);
+    const double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : pow(10.0, -(2.0 + log10(dm)) / (double)order);
+    return fmax(pb->dtmin, fmin(fmin(100.0 * dt0, dt1), dtmax));
+}
+
 /* ------------------------------------------------------------------------ */
 /* One trajectory: adaptive Rosenbrock23 + forward tangents + loss.         */
 /*   u0[n], tsave[nsave] (ascending, tsave[nsave-1] = end of tspan),        */
@@ -433,7 +468,8 @@ static int solve_one_ws(const orc_problem *pb, const double *th, const double *d
         double zero[ORC_MAXN] = {0};
         orc_rhs_jvp(pb, th, dth + (size_t)nth * k, u, zero, df0 + (size_t)n * k);
     }
-    double dt = init_dt(pb, th, u, f0, tend - pb->t0, 2);
+    double dt = (pb->errnorm_sens && P > 0) ? init_dt_sens(pb, th, dth, P, u, f0, df0, tend - pb->t0, 2)
+                                           : init_dt(pb, th, u, f0, tend - pb->t0, 2);
     double qold = pb->qoldinit;
     int jsave = 0, retcode = 0, iter = 0;
     double loss_sum = 0.0;
@@ -657,7 +693,8 @@ static int solve_one_tsit5(const orc_problem *pb, const double *th, const double
         double zero[ORC_MAXN] = {0};
         orc_rhs_jvp(pb, th, dth + (size_t)nth * c, u, zero, DK(0) + (size_t)n * c);
     }
-    double dt = init_dt(pb, th, u, k[0], tend - pb->t0, 5);
+    double dt = (pb->errnorm_sens && P > 0) ? init_dt_sens(pb, th, dth, P, u, k[0], DK(0), tend - pb->t0, 5)
+                                           : init_dt(pb, th, u, k[0], tend - pb->t0, 5);
     double qold = pb->qoldinit;
     int jsave = 0, retcode = 0, iter = 0;
     double loss_sum = 0.0;
