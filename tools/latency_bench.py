@@ -12,7 +12,8 @@ u0 = np.array(c2["u0"]); ts = np.array(c2["tsteps"]); data = np.array(c2["data"]
 p = np.array(fx["case2_ckpt"]["p"])
 for B in (1, 8, 32):
     for name, kw in (("adjoint", dict(grad_mode=2)), ("forward C=1 L=25", dict(grad_mode=1, cols_per_lane=1)), ("forward C=7 L=4", dict(grad_mode=1, cols_per_lane=7)),
-                     ("forward C=5 L=5", dict(grad_mode=1, cols_per_lane=5))):
+                     ("forward C=5 L=5", dict(grad_mode=1, cols_per_lane=5)), ("auto", dict()),
+                     ("tsit5 adjoint", dict(grad_mode=2, solver=1)), ("tsit5 fwd C=1 L=25", dict(grad_mode=1, cols_per_lane=1, solver=1)), ("tsit5 auto", dict(solver=1))):
         node = NeuralODE(ODEProblem(PRESET_CASE2, ts, **kw))
         node.set_ensemble(u0[:B], data[:B], ys)
         ks, ws = [], []
