@@ -140,9 +140,15 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
     const int tid = threadIdx.x;
     for (int idx = tid; idx < kNConst; idx += BLOCK) kc_lds[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
     for (int idx = tid; idx < prm.n_save; idx += BLOCK) ts_lds[idx] = prm.tsave[idx];
-    __syncthreads();
     const KConst *kc = reinterpret_cast<const KConst *>(kc_lds);
-    const double *__restrict__ th = theta;
+    // theta is read from LDS (broadcast ds_read), not through scalar loads: with 42-43 parameters live across the forward
+    // AND the reverse sweep the SGPR file overflows (247 SGPR spills -> v_readlane/v_writelane churn, s_load + s_waitcnt
+    // in the adjoint contraction).  Measured: case2 -1.5 %, robertson -10 %, B = 131 072 -4 % (identical results).  The
+    // forward-tangent kernels are the other way round (theta * C columns: +35 % with LDS theta) and keep the scalar path.
+    __shared__ double th_lds[NTH];
+    for (int idx = tid; idx < NTH; idx += BLOCK) th_lds[idx] = theta[idx];
+    __syncthreads();
+    const double *th = th_lds;
     double *const thb_s = thb_lds + tid;   // accumulator m of this lane: thb_s[m * BLOCK]
 
     const double d_ = 0.29289321881345248;    // 1/(2+sqrt 2)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel timing at FIXED parameters (no optimiser update): case2 checkpoint p, B initial conditions, loss+gradient
 launches; prints the median HIP-event kernel time.  CRNN_HIP_LIB selects the library build (tools/kvariants.sh).
-usage: python tools/kbench.py [--batch 65536] [--reps 12] [--grad auto|forward|adjoint] [--case case2|rober|hychem] [--solver rosenbrock23|tsit5|autotsit5]"""
+usage: python tools/kbench.py [--batch 65536] [--reps 12] [--grad auto|forward|adjoint] [--case case2|case1|rober|hychem] [--errnorm-sens 0|1|2] [--solver rosenbrock23|tsit5|autotsit5]"""
 import argparse
 import json
 import os
@@ -17,9 +17,10 @@ ap.add_argument("--reps", type=int, default=12)
 ap.add_argument("--grad", default="auto")
 ap.add_argument("--case", default="case2")
 ap.add_argument("--solver", default=None, choices=[None, "rosenbrock23", "tsit5", "autotsit5"])
+ap.add_argument("--errnorm-sens", type=int, default=0)
 args = ap.parse_args()
 
-from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE2, PRESET_ROBER, cases  # noqa: E402
+from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE1, PRESET_CASE2, PRESET_ROBER, cases  # noqa: E402
 
 fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fixtures.json")))
 rng = np.random.Generator(np.random.PCG64([1234, 0]))
@@ -33,9 +34,19 @@ if args.case == "case2":
     clean = gen.predict_theta(u0, cases.case2_true_theta())[:, :6, :]
     gen.close()
     data = cases.add_noise(clean, 0.05, rng)
-    node = NeuralODE(ODEProblem(PRESET_CASE2, ts, grad_mode=gm, solver=sv))
+    node = NeuralODE(ODEProblem(PRESET_CASE2, ts, grad_mode=gm, solver=sv, errnorm_sens=args.errnorm_sens))
     node.set_ensemble(u0, data, cases.max_min(data, lb=1e-6))
     p = np.array(fx["case2_ckpt"]["p"])
+elif args.case == "case1":
+    ts = cases.case1_tsteps()
+    u0 = cases.case1_u0(B, rng)
+    gen = NeuralODE(ODEProblem(PRESET_CASE1, ts, atol=1e-10, rtol=1e-8, solver=0))
+    clean = gen.predict_theta(u0, cases.case1_true_theta())
+    gen.close()
+    data = cases.add_noise(clean, 0.05, rng)
+    node = NeuralODE(ODEProblem(PRESET_CASE1, ts, grad_mode=gm, solver=sv, errnorm_sens=args.errnorm_sens))
+    node.set_ensemble(u0, data, cases.max_min(data, lb=1e-5))
+    p = np.array(fx["case1"]["p"])
 elif args.case == "hychem":
     from crnn_amd import PRESET_HYCHEM, hychem as hy
     ts, u0, Tt, Pt = hy.sample_conditions(B, rng)
