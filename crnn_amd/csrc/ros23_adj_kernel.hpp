@@ -26,7 +26,7 @@
 // sweep appends (t_n, dt_n, u_n) of every accepted step to a per-lane tape in HBM (lane-contiguous: the partial lines
 // of a wavefront's store merge in L2; a [wavefront][step][field][lane] layout with 512-byte stores measured slower);
 // the reverse sweep re-forms J, W and the stages from the tape record instead of storing them.  The observed data are
-// read once, by the reverse sweep, where loss and seeds are formed together.  theta sits in SGPRs, the 42 (case2)
+// read once, by the reverse sweep, where loss and seeds are formed together.  theta sits in LDS (see below), the 42 (case2)
 // gradient accumulators of a lane in LDS ([m][lane], ds_add_f64), the per-batch sums are formed in the kernel.
 #pragma once
 #include "ros23_kernel.hpp"
@@ -145,6 +145,9 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
     // AND the reverse sweep the SGPR file overflows (247 SGPR spills -> v_readlane/v_writelane churn, s_load + s_waitcnt
     // in the adjoint contraction).  Measured: case2 -1.5 %, robertson -10 %, B = 131 072 -4 % (identical results).  The
     // forward-tangent kernels are the other way round (theta * C columns: +35 % with LDS theta) and keep the scalar path.
+    // The compiler loads theta once and parks it in AGPRs (two v_accvgpr_read per use); forcing a fresh LDS read per
+    // phase instead (pointer laundered through an empty asm) removes 10 % of the VALU instructions and is SLOWER (case2
+    // +4 %, robertson +15 %): at one wavefront per SIMD the exposed lgkmcnt waits cost more than the issue slots saved.
     __shared__ double th_lds[NTH];
     for (int idx = tid; idx < NTH; idx += BLOCK) th_lds[idx] = theta[idx];
     __syncthreads();
