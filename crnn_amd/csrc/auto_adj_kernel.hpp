@@ -402,6 +402,9 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
         double lam[NS];
 #pragma unroll
         for (int i = 0; i < NS; ++i) lam[i] = 0.0;
+        double wbb[NR];              // d/d w_b of THIS trajectory, in registers; its temperature row is xT times the same sum
+#pragma unroll
+        for (int j = 0; j < NR; ++j) wbb[j] = 0.0;
         double loss_sum = 0.0;
         double tnew = t;             // end time of the step being reversed
         int s = valid ? nacc - 1 : -1;
@@ -431,9 +434,12 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
         };
         // reverse accumulation through one right-hand-side evaluation k = f(point) with features (x, g, r):
         //   gb = f_u^T kb,   thb += f_theta^T kb
-        auto vjp_point = [&](const double (&x)[NS], const double (&g)[NS], const double (&r)[NR], const double (&kb)[NS],
-                             double (&gb)[NS]) {
-            double vs[NS], um[NS];
+        // The theta terms are NOT added where they arise: an LDS atomic costs a wavefront ~40 cycles here, so vjp_core only
+        // returns the two factors (rho_j = (kb.w_out[:,j]) r_j, vs = sc .* kb) and the caller adds the terms of TWO points
+        // with one ds_add_f64 per accumulator (vjp_flush2); the w_b terms go to the trajectory's register sums.
+        auto vjp_core = [&](const double (&g)[NS], const double (&r)[NR], const double (&kb)[NS], double (&gb)[NS],
+                            double (&rho)[NR], double (&vs)[NS]) {
+            double um[NS];
 #pragma unroll
             for (int i = 0; i < NS; ++i) { vs[i] = USE_SCALE ? kb[i] * kc->scale[i] : kb[i]; um[i] = 0.0; }
 #pragma unroll
@@ -441,19 +447,32 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                 double a = 0.0;
 #pragma unroll
                 for (int i = 0; i < NS; ++i) a = fma(vs[i], th[L_::wo(i, j)], a);
-                const double rho = a * r[j];
-                THB_ADD(L_::wb(j), rho);
-                if (HAS_T) THB_ADD(L_::wi(NS, j), rho * xT);
+                rho[j] = a * r[j];
+                wbb[j] += rho[j];
 #pragma unroll
-                for (int c = 0; c < NS; ++c) {
-                    THB_ADD(L_::wi(c, j), rho * x[c]);
-                    um[c] = fma(rho, th[L_::wi(c, j)], um[c]);
-                }
-#pragma unroll
-                for (int i = 0; i < NS; ++i) THB_ADD(L_::wo(i, j), vs[i] * r[j]);
+                for (int c = 0; c < NS; ++c) um[c] = fma(rho[j], th[L_::wi(c, j)], um[c]);
             }
 #pragma unroll
             for (int c = 0; c < NS; ++c) gb[c] = um[c] * g[c];
+        };
+        auto vjp_flush1 = [&](const double (&x)[NS], const double (&r)[NR], const double (&rho)[NR], const double (&vs)[NS]) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+#pragma unroll
+                for (int c = 0; c < NS; ++c) THB_ADD(L_::wi(c, j), rho[j] * x[c]);
+#pragma unroll
+                for (int i = 0; i < NS; ++i) THB_ADD(L_::wo(i, j), vs[i] * r[j]);
+            }
+        };
+        auto vjp_flush2 = [&](const double (&xa)[NS], const double (&ra)[NR], const double (&rhoa)[NR], const double (&vsa)[NS],
+                              const double (&xb)[NS], const double (&rb)[NR], const double (&rhob)[NR], const double (&vsb)[NS]) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+#pragma unroll
+                for (int c = 0; c < NS; ++c) THB_ADD(L_::wi(c, j), fma(rhoa[j], xa[c], rhob[j] * xb[c]));
+#pragma unroll
+                for (int i = 0; i < NS; ++i) THB_ADD(L_::wo(i, j), fma(vsa[i], ra[j], vsb[i] * rb[j]));
+            }
         };
 
         double rt = 0.0, rdt = 0.0, ru[NS];   // tape record s, prefetched
@@ -567,12 +586,13 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                     // keeps all their features alive after all.
                     double h2 = h;
                     if (!kKeepStages) asm volatile("" : "+v"(h2));
+                    double rho_p[NR], vs_p[NS], x_p[NS], r_p[NR];   // the stage whose theta terms are still to be added
 #pragma unroll
                     for (int st = 6; st >= 0; --st) {
-                        double gb[NS];
-                        if constexpr (kKeepStages) vjp_point(xs[st], gs[st], rs[st], kb[st], gb);
-                        else {
-                            double gp[NS], x[NS], g[NS], r[NR], fdump[NS];
+                        double gb[NS], rho[NR], vs[NS];
+                        double xl[NS], gl[NS], rl[NR];
+                        if constexpr (!kKeepStages) {
+                            double gp[NS], fdump[NS];
 #pragma unroll
                             for (int i = 0; i < NS; ++i) {
                                 double a = 0.0;
@@ -580,9 +600,19 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                                 for (int j = 0; j < st; ++j) a = fma(Ts5::a(st > 0 ? st - 1 : 0, j), k[j][i], a);
                                 gp[i] = st > 0 ? fma(h2, a, un[i]) : un[i];
                             }
-                            eval_point(gp, x, g, r, fdump);
-                            vjp_point(x, g, r, kb[st], gb);
+                            eval_point(gp, xl, gl, rl, fdump);
                         }
+                        const double (&x)[NS] = kKeepStages ? xs[kKeepStages ? st : 0] : xl;
+                        const double (&g)[NS] = kKeepStages ? gs[kKeepStages ? st : 0] : gl;
+                        const double (&r)[NR] = kKeepStages ? rs[kKeepStages ? st : 0] : rl;
+                        vjp_core(g, r, kb[st], gb, rho, vs);
+                        if (st == 0) vjp_flush1(x, r, rho, vs);                       // seven stages: the first one is left over
+                        else if ((st & 1) == 0) {                                     // st = 6, 4, 2: wait for the next stage
+#pragma unroll
+                            for (int j = 0; j < NR; ++j) { rho_p[j] = rho[j]; r_p[j] = r[j]; }
+#pragma unroll
+                            for (int i = 0; i < NS; ++i) { vs_p[i] = vs[i]; x_p[i] = x[i]; }
+                        } else vjp_flush2(x_p, r_p, rho_p, vs_p, x, r, rho, vs);      // st = 5, 3, 1
 #pragma unroll
                         for (int i = 0; i < NS; ++i) {
                             ub[i] += gb[i];
@@ -673,9 +703,10 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                         for (int i = 0; i < NS; ++i) a = fma(vs[i], th[L_::wo(i, j)], a);
                         av[j] = a;
                     }
+                    double rho1[NR], vs_dump[NS];   // the u_mid point's theta terms are folded into the u_n point's addends
                     {   // point u_mid
                         double gb[NS];
-                        vjp_point(x1, g1, r1, v, gb);
+                        vjp_core(g1, r1, v, gb, rho1, vs_dump);
 #pragma unroll
                         for (int c = 0; c < NS; ++c) {
                             ub[c] += gb[c];
@@ -706,18 +737,18 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                             const double pw = aw * rr0[j];
                             const double gpw = gam * pw;
                             const double beta = fma(pw, c1j, pv * qd);
-                            THB_ADD(L_::wb(j), beta);
-                            if (HAS_T) THB_ADD(L_::wi(NS, j), beta * xT);
+                            wbb[j] += beta;
 #pragma unroll
                             for (int c = 0; c < NS; ++c) {
                                 const double m = fma(pv, dk[c], gpw * k1[c]);
-                                THB_ADD(L_::wi(c, j), fma(beta, x0[c], gg0[c] * m));
+                                THB_ADD(L_::wi(c, j), fma(rho1[j], x1[c], fma(beta, x0[c], gg0[c] * m)));
                                 const double wi = th[L_::wi(c, j)];
                                 s1[c] = fma(beta, wi, s1[c]);
                                 s2[c] = fma(wi, m, s2[c]);
                             }
+                            const double ca = fma(rr0[j], czd, r1[j]), cb = rr0[j] * c1j;
 #pragma unroll
-                            for (int i = 0; i < NS; ++i) THB_ADD(L_::wo(i, j), rr0[j] * fma(ws[i], c1j, vs[i] * czd));
+                            for (int i = 0; i < NS; ++i) THB_ADD(L_::wo(i, j), fma(vs[i], ca, ws[i] * cb));
                         }
 #pragma unroll
                         for (int c = 0; c < NS; ++c) {
@@ -757,6 +788,11 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
         {
             const double denom_ = (double)prm.n_obs * (double)n_saved;
             const double scale_ = (valid && n_saved > 0) ? 1.0 / denom_ : 0.0;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                THB_ADD(L_::wb(j), wbb[j]);
+                if (HAS_T) THB_ADD(L_::wi(NS, j), wbb[j] * xT);
+            }
 #pragma unroll
             for (int m = 0; m < NTH; ++m) thb_s[m * BLOCK] = thb_s[m * BLOCK] * scale_;
             ex_lds[0 * BLOCK + tid] = valid ? loss_sum * scale_ : 0.0;
