@@ -45,6 +45,13 @@
 //    u_mid is known at once, so the two feature / rate evaluations of a reverse step are independent of each other.
 //    Measured (tools/kvariants.sh): no gain (case2 0.612 vs 0.618 ms, robertson 0.706 vs 0.704 ms) -- the 2.3x tape
 //    traffic eats the saved arithmetic -- so the default stays 0.
+// 1: lane-private LDS accumulators are updated with ds_add_f64 (fire and forget); 0: ds_read + add + ds_write.  In isolation
+//    (tools/ubench/lds_acc.hip) the atomic costs a wavefront 22-30 cycles and the plain sequence 6-8; inside the kernels the
+//    read's latency is exposed and the plain sequence is 2-8 % SLOWER (case2 0.558 vs 0.548 ms, AutoTsit5 robertson 1.35 vs
+//    1.24 ms) -- so: atomics, and as few of them as possible (see the folded addends below).
+#ifndef CRNN_ADJ_THB_ATOMIC
+#define CRNN_ADJ_THB_ATOMIC 1
+#endif
 #ifndef CRNN_ADJ_TAPE_K
 #define CRNN_ADJ_TAPE_K 0
 #endif
@@ -377,7 +384,11 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
 #if CRNN_ADJ_THB_LDS
 #pragma unroll
         for (int m = 0; m < NTH; ++m) thb_s[m * BLOCK] = 0.0;
+#if CRNN_ADJ_THB_ATOMIC
 #define THB_ADD(m, val) unsafeAtomicAdd(&thb_s[(m) * BLOCK], (val))
+#else
+#define THB_ADD(m, val) thb_s[(m) * BLOCK] += (val)
+#endif
 #define THB_REG(m) 0.0
 #else
         double thb[NTH];
