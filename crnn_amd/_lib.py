@@ -105,6 +105,7 @@ SYMBOLS = {
     "crnn_set_opt_state": (C.c_int32, [_CTX, _DP]),
     "crnn_train_update": (C.c_int32, [_CTX, _DP]),
     "crnn_last_stats": (C.c_int32, [_CTX, C.POINTER(Stats)]),
+    "crnn_last_step_counts": (C.c_int32, [_CTX, C.c_int64, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "crnn_kernel_times": (C.c_int32, [_CTX, _DP, C.c_int32]),
     "crnn_synchronize": (C.c_int32, [_CTX]),
     "crnn_comm_get_unique_id": (C.c_int32, [C.c_char_p]),

@@ -429,6 +429,14 @@ class NeuralODE:
         check(lib.crnn_last_stats(self._ctx.h, C.byref(st)), self._ctx.h)
         return st.asdict()
 
+    def step_counts(self, first=0, count=None):
+        """(naccept, nreject) of every trajectory in [first, first+count) of the most recent solve -- `sol.destats` of
+        each `solve` of the ensemble (case2/case2.jl:126)."""
+        count = self.B - first if count is None else count
+        na, nr = np.zeros(count, np.int32), np.zeros(count, np.int32)
+        check(lib.crnn_last_step_counts(self._ctx.h, first, count, iptr(na), iptr(nr)), self._ctx.h)
+        return na, nr
+
     @property
     def handle(self):
         return self._ctx.h

@@ -443,6 +443,14 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
     crnn::AdjParams adj{};
     adj.tape = c->d_tape; adj.tape_cap = (int32_t)cap; adj.overflow = c->d_overflow; adj.batch_partials = c->d_partials;
     adj.perm = nullptr;
+    {   // Reverse sweep aligned by step index or by physical time (ros23_adj_kernel.hpp): by index when the save grid is
+        // front-loaded like the steps behind a stiff transient (robertson's logarithmic grid: half of the points lie in the
+        // first quarter of the horizon), by time on a uniform grid (case1 / case2).  Either way the results are the same.
+        const int D = n_save_active;
+        const double t_lo = c->cfg.t0, t_hi = c->tsave[D - 1];
+        adj.align_rev = (D >= 4 && c->tsave[D / 2] - t_lo < 0.25 * (t_hi - t_lo)) ? 1 : 0;
+        if (const char *e = getenv("CRNN_ADJ_ALIGN_REV")) { if (*e) adj.align_rev = atoi(e) != 0; }   // measurement override
+    }
     // more trajectories than resident lanes: wavefronts take several batches from the queue one after the other; queue the
     // trajectories by their last known step counts so that batches are homogeneous (the counts of the previous launch over
     // the same range: in training p moves little from step to step)
@@ -617,6 +625,7 @@ int32_t launch_sens_chunk(Ctx *c, const KernelEntry *k, const double *d_theta, c
     HIP_TRY(c, hipGetLastError());
     c->last_npart = npart;
     c->last_P = P;
+    c->steps_first = first; c->steps_count = count;
     return 0;
 }
 
@@ -664,6 +673,7 @@ int32_t launch_sens(Ctx *c, const double *d_theta, const double *d_dtheta, int P
     HIP_TRY(c, hipMemcpyAsync(c->d_red, c->d_red_asm, sizeof(double) * npart, hipMemcpyDeviceToDevice, c->stream));
     c->last_npart = npart;
     c->last_P = P;
+    c->steps_first = first; c->steps_count = count;
     return 0;
 }
 
@@ -762,6 +772,7 @@ int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int 
     HIP_TRY(c, hipGetLastError());
     c->last_npart = npart;
     c->last_P = P;
+    c->steps_first = first; c->steps_count = count;
     return 0;
 }
 
@@ -1454,6 +1465,19 @@ int32_t crnn_last_stats(crnn_ctx *ctx, crnn_stats *stats) {
     HIP_TRY(c, hipMemcpyAsync(red.data(), c->d_red, sizeof(double) * c->last_npart, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return fill_stats(c, red.data(), c->last_npart, stats);
+}
+
+int32_t crnn_last_step_counts(crnn_ctx *ctx, int64_t first, int64_t count, int32_t *n_accept, int32_t *n_reject) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return fail(c, "crnn_last_step_counts: null");
+    if (c->last_npart == 0) return fail(c, "crnn_last_step_counts: no solve has run yet");
+    if (check_pending(c, nullptr)) return -1;
+    if (count < 0 || first < c->steps_first || first + count > c->steps_first + c->steps_count)
+        return fail(c, "crnn_last_step_counts: [first, first+count) is not inside the range of the most recent solve");
+    if (n_accept) HIP_TRY(c, hipMemcpyAsync(n_accept, c->d_nacc + first, sizeof(int32_t) * count, hipMemcpyDeviceToHost, c->stream));
+    if (n_reject) HIP_TRY(c, hipMemcpyAsync(n_reject, c->d_nrej + first, sizeof(int32_t) * count, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 int32_t crnn_kernel_times(crnn_ctx *ctx, double *ms, int32_t n) {

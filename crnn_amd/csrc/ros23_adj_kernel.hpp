@@ -62,6 +62,7 @@ struct AdjParams {
     double *tape;                // [lanes][tape_cap][NS + 2]
     int32_t tape_cap;            // accepted steps a lane can record
     unsigned int *overflow;      // incremented by every trajectory that ran out of tape (host then falls back)
+    int32_t align_rev;           // ros23_adj_kernel: reverse sweep aligned by step index (see the kernel)
     double *batch_partials;      // [ceil(count/64)][NTH + kExtra]: per 64-trajectory batch sums
     const int32_t *perm;         // ros23_adj_kernel: position in the queue -> trajectory (relative to first); null = identity
 };
@@ -435,8 +436,26 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
 #endif
         }
 
+        // Which lanes reverse together.  All lanes start with their LAST step (lag 0: the lanes of an iteration are at about
+        // the same physical time) or, align_rev, a trajectory with fewer steps than the longest of its wavefront starts
+        // later, so that the lanes of an iteration are at the same step INDEX.  The wavefront runs max(n_accept) iterations
+        // either way; what differs is how many save points the lanes of one iteration have inside their steps -- every
+        // iteration pays for the maximum over its lanes.  Steps grow geometrically behind a stiff transient: on a uniform
+        // save grid the count follows the physical time (case2: lag 0 is 24 % faster), on a geometric grid the step index
+        // (robertson: aligned is 7 % faster).  The host picks by the shape of the grid (crnn_capi.hip).
+        int lag = 0;
+        if (adj.align_rev) {
+            int smax = s;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) smax = max(smax, __shfl_xor(smax, m));
+            lag = smax - s;
+        }
+        int it_rev = 0;
+
         while (__builtin_amdgcn_ballot_w64(s >= 0) != 0) {
-            if (s >= 0) {
+            const bool go = (it_rev >= lag);
+            ++it_rev;
+            if (s >= 0 && go) {
                 const double tn = rt, h = rdt;
                 double un[NS];
 #pragma unroll

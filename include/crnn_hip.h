@@ -249,6 +249,10 @@ int32_t crnn_set_opt_state(crnn_ctx *ctx, const double *state);
  * kernel crnn_train_step ends with. */
 int32_t crnn_train_update(crnn_ctx *ctx, const double *grad);
 int32_t crnn_last_stats(crnn_ctx *ctx, crnn_stats *stats); /* of the most recent solve; synchronises */
+/* Per-trajectory step counts of the most recent solve over [first, first+count): what `sol.destats.naccept / nreject`
+ * report for each `solve` of the ensemble (case2/case2.jl:126).  Either pointer may be NULL; the range must lie inside
+ * the range that solve covered; synchronises. */
+int32_t crnn_last_step_counts(crnn_ctx *ctx, int64_t first, int64_t count, int32_t *n_accept, int32_t *n_reject);
 /* HIP-event durations (ms) of the solve kernel of the last n launches (n <= 64), oldest first;
  * synchronises the ctx stream.  The measurement bench.py's roofline figures come from. */
 int32_t crnn_kernel_times(crnn_ctx *ctx, double *ms, int32_t n);

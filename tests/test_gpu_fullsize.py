@@ -164,9 +164,18 @@ def test_tiny_and_ragged_batches(orc, case2_setup):
         assert abs(loss - np.mean([r["loss"] for r in ref[:B]])) < 1e-9 * loss
         g = np.mean([r["grad"] for r in ref[:B]], axis=0)
         assert np.max(np.abs(grad - g)) < 1e-7 * np.max(np.abs(g))
+        # per-trajectory step counts (`sol.destats`): those of the oracle's solves, whichever kernel produced them
+        na, nr = node.step_counts()
+        assert list(na) == [r["naccept"] for r in ref[:B]] and list(nr) == [r["nreject"] for r in ref[:B]]
+        assert na.sum() == node.last_stats["n_accept"] and nr.sum() == node.last_stats["n_reject"]
         # last element alone
         l1, g1 = node.loss_and_grad(p, first=B - 1, count=1)
         assert abs(l1 - ref[B - 1]["loss"]) < 1e-9 * l1
+        na1, _ = node.step_counts(first=B - 1, count=1)
+        assert na1[0] == ref[B - 1]["naccept"]
+        if B > 1:
+            with pytest.raises(Exception):
+                node.step_counts(first=0, count=B)        # outside the range of the most recent solve
         node.close()
 
 
