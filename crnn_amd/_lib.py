@@ -21,6 +21,7 @@ RET_SUCCESS, RET_MAXITERS, RET_DTMIN, RET_UNSTABLE = 0, 1, 2, 3
 PRESET_CASE1, PRESET_CASE2, PRESET_ROBER, PRESET_HYCHEM = 1, 2, 3, 4
 SOLVER_ROSENBROCK23, SOLVER_TSIT5, SOLVER_AUTOTSIT5 = 0, 1, 2
 GRAD_AUTO, GRAD_FORWARD, GRAD_ADJOINT = 0, 1, 2
+QUEUE_AUTO, QUEUE_INDEX = 0, 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CRNN_HIP_LIB: load another build of the same ABI (kernel experiments, tools/); the default is the in-tree library
@@ -105,6 +106,7 @@ SYMBOLS = {
     "crnn_set_opt_state": (C.c_int32, [_CTX, _DP]),
     "crnn_train_update": (C.c_int32, [_CTX, _DP]),
     "crnn_last_stats": (C.c_int32, [_CTX, C.POINTER(Stats)]),
+    "crnn_ctx_set_queue_order": (C.c_int32, [_CTX, C.c_int32]),
     "crnn_last_step_counts": (C.c_int32, [_CTX, C.c_int64, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "crnn_kernel_times": (C.c_int32, [_CTX, _DP, C.c_int32]),
     "crnn_synchronize": (C.c_int32, [_CTX]),

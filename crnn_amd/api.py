@@ -429,6 +429,11 @@ class NeuralODE:
         check(lib.crnn_last_stats(self._ctx.h, C.byref(st)), self._ctx.h)
         return st.asdict()
 
+    def set_queue_order(self, order):
+        """QUEUE_AUTO (default: trajectories queued by the previous launch's step counts) or QUEUE_INDEX (index order: batch
+        sums are a function of the call's inputs alone, bit for bit) -- include/crnn_hip.h: crnn_ctx_set_queue_order."""
+        check(lib.crnn_ctx_set_queue_order(self._ctx.h, int(order)), self._ctx.h)
+
     def step_counts(self, first=0, count=None):
         """(naccept, nreject) of every trajectory in [first, first+count) of the most recent solve -- `sol.destats` of
         each `solve` of the ensemble (case2/case2.jl:126)."""

@@ -146,6 +146,7 @@ struct Ctx {
     // queue order of ensembles larger than the resident lanes (sort_steps_kernel): by the step counts of the previous launch
     int32_t *d_perm = nullptr;
     size_t perm_cap = 0;
+    int queue_order = CRNN_QUEUE_AUTO;
     int64_t steps_first = 0, steps_count = 0;   // [first, first+count) whose d_nacc / d_nrej hold a completed launch's counts
     double *d_red_theta = nullptr;  // [n_theta + kExtra]
     int64_t n_fallback = 0;         // calls repeated with forward tangents after a tape overflow
@@ -388,8 +389,10 @@ void fill_params(Ctx *c, crnn::SolveParams &prm, int P, int64_t first, int64_t c
 // *perm stays null (index order) when the ensemble fits the resident lanes or no counts are known yet.
 int32_t queue_by_steps(Ctx *c, size_t lanes, int64_t first, int64_t count, const int32_t **perm) {
     *perm = nullptr;
-    const bool sortable = (size_t)count > lanes && count < ((int64_t)1 << 31) && first >= c->steps_first &&
-                          first + count <= c->steps_first + c->steps_count;
+    // also when the ensemble fits the resident lanes: homogeneous wavefronts keep the save points of an iteration's steps
+    // coherent (crnn_hip.h: crnn_ctx_set_queue_order); below two runs of 1024 the sort is not worth its launch
+    const bool sortable = c->queue_order == CRNN_QUEUE_AUTO && ((size_t)count > lanes || count >= 2048) && count < ((int64_t)1 << 31) &&
+                          first >= c->steps_first && first + count <= c->steps_first + c->steps_count;
     if (!sortable) return 0;
     if (ensure(c, &c->d_perm, &c->perm_cap, (size_t)count)) return -1;
     hipLaunchKernelGGL(crnn::sort_steps_kernel, dim3((unsigned)((count + 1023) / 1024)), dim3(1024), 0, c->stream, c->d_nacc, c->d_nrej,
@@ -1465,6 +1468,14 @@ int32_t crnn_last_stats(crnn_ctx *ctx, crnn_stats *stats) {
     HIP_TRY(c, hipMemcpyAsync(red.data(), c->d_red, sizeof(double) * c->last_npart, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return fill_stats(c, red.data(), c->last_npart, stats);
+}
+
+int32_t crnn_ctx_set_queue_order(crnn_ctx *ctx, int32_t order) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return fail(c, "crnn_ctx_set_queue_order: null");
+    if (order != CRNN_QUEUE_AUTO && order != CRNN_QUEUE_INDEX) return fail(c, "crnn_ctx_set_queue_order: order must be CRNN_QUEUE_AUTO or CRNN_QUEUE_INDEX");
+    c->queue_order = order;
+    return 0;
 }
 
 int32_t crnn_last_step_counts(crnn_ctx *ctx, int64_t first, int64_t count, int32_t *n_accept, int32_t *n_reject) {

@@ -94,6 +94,9 @@ int main(int argc, char **argv) {
     CHECK(crnn_opt_preset(&opt, CRNN_PRESET_CASE2));
     CHECK(crnn_train_init(ctx, &opt, p0));
     CHECK(crnn_comm_set_allreduce(ctx, host_allreduce, NULL));
+    /* index order: the batch sums are then a function of (p, data) alone, which is what the bit-for-bit restart check below
+     * needs; the default (queued by the previous step's step counts) is 10-20 % faster at this size and differs in the last bits */
+    CHECK(crnn_ctx_set_queue_order(ctx, CRNN_QUEUE_INDEX));
     printf("library build: %s\n", crnn_build_info());
     double loss_first = 0.0, loss = 0.0;
     double p_ck[P], st_ck[2 * P + 4];

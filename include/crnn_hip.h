@@ -192,6 +192,16 @@ int32_t crnn_ctx_set_data_device(crnn_ctx *ctx, const void *d_u0, const void *d_
  * T[j*B + b], j < n_save (Tlist / Plist, crnn_pyrolysis_mass.jl:44-47,103-104; piecewise linear in t).
  * Call after crnn_ctx_set_data (B is taken from it). */
 int32_t crnn_ctx_set_tables(crnn_ctx *ctx, const double *T, const double *P);
+/* In which order the adjoint kernels take the ensemble's trajectories from their queue (one lane per trajectory, 64 per
+ * wavefront).  AUTO (default): once a launch over the range has run, by that launch's step counts, longest first -- the
+ * 64 trajectories of a wavefront then take about the same number of steps, and the steps of one iteration hold about the
+ * same number of save points (case2 at 65 536: -7 % kernel time, at 4 096-32 768: -10...-20 %, AutoTsit5 robertson -25 %,
+ * HyChem -12 %; ensembles larger than the resident lanes: -30 %).  Per-trajectory results do not depend on the order; the
+ * batch sums (gradient, mean loss) do, in their last bits, through the composition of the 64-trajectory partial sums.
+ * INDEX: always in index order -- the sums are then a function of the call's inputs alone (a run and its restart from a
+ * checkpoint agree bit for bit: examples/case2_train.c). */
+enum { CRNN_QUEUE_AUTO = 0, CRNN_QUEUE_INDEX = 1 };
+int32_t crnn_ctx_set_queue_order(crnn_ctx *ctx, int32_t order);
 
 /* ---- the hot path at theta level ---------------------------------------- *
  * Integrates trajectories [first, first+count) of the uploaded ensemble with

@@ -102,6 +102,20 @@ end
 set_tables!(prob::Problem, Tlist::Matrix{Float64}, Plist::Matrix{Float64}) =
     check(ccall((:crnn_ctx_set_tables, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), prob.ctx, Tlist, Plist), prob.ctx)
 
+"""Queue order of the adjoint kernels: `QUEUE_AUTO = 0` (by the previous launch's step counts, the default) or
+`QUEUE_INDEX = 1` (index order: batch sums depend on the call's inputs alone, bit for bit).  include/crnn_hip.h."""
+const QUEUE_AUTO = Int32(0); const QUEUE_INDEX = Int32(1)
+set_queue_order!(prob::Problem, order::Integer) =
+    check(ccall((:crnn_ctx_set_queue_order, LIB), Int32, (Ptr{Cvoid}, Int32), prob.ctx, Int32(order)), prob.ctx)
+
+"""`sol.destats.naccept / nreject` of every `solve` of the most recent ensemble launch over `first .+ (0:count-1)` (0-based)."""
+function last_step_counts(prob::Problem, first::Integer = 0, count::Integer = prob.B - first)
+    na = zeros(Int32, count); nr = zeros(Int32, count)
+    check(ccall((:crnn_last_step_counts, LIB), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Int32}, Ptr{Int32}),
+                prob.ctx, Int64(first), Int64(count), na, nr), prob.ctx)
+    return na, nr
+end
+
 """`w_in, w_b, w_out = p2vec(p)` (case2/case2.jl:91-99) plus the Jacobian d theta / d p."""
 function p2vec_jac(prob::Problem, p::Vector{Float64})
     c = prob.cfg

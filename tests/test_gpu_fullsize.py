@@ -50,9 +50,17 @@ def test_case2_full_batch_properties(orc, full_case2):
     assert 20 < st["n_accept"] / B_FULL < 45 and st["n_reject"] < 0.05 * st["n_accept"]
     # the learned checkpoint explains data made from the true mechanism + 5 % noise: MAE of the order of the noise
     assert 0.005 < loss < 0.05
-    # determinism: bitwise identical on repetition
+    # determinism: the second launch is queued by the first one's step counts (other 64-trajectory partial sums: equal to
+    # rounding), from then on bitwise identical on repetition; in index order bitwise identical to the first launch
     loss2, grad2 = node.loss_and_grad(p)
-    assert loss2 == loss and np.array_equal(grad, grad2)
+    assert abs(loss2 - loss) < 1e-13 * loss and np.max(np.abs(grad2 - grad)) < 1e-11 * np.max(np.abs(grad))
+    loss3, grad3 = node.loss_and_grad(p)
+    assert loss3 == loss2 and np.array_equal(grad3, grad2)
+    from crnn_amd import QUEUE_AUTO, QUEUE_INDEX
+    node.set_queue_order(QUEUE_INDEX)
+    loss4, grad4 = node.loss_and_grad(p)
+    assert loss4 == loss and np.array_equal(grad4, grad)
+    node.set_queue_order(QUEUE_AUTO)
     # additivity over sub-ranges (sums of the same per-trajectory terms, different association)
     acc_l, acc_g = 0.0, np.zeros(25)
     q = B_FULL // 4
@@ -352,6 +360,43 @@ def test_ensemble_larger_than_the_resident_lanes_is_queued_by_step_count(orc, fx
         assert abs(losses[i] - r["loss"]) < 1e-9 * r["loss"]
     print(f"B = {B}: kernel {ms1:.3f} ms in index order, {ms2:.3f} ms queued by step count")
     assert ms2 < ms1                                # homogeneous batches are the point
+    node.close()
+
+
+def test_queue_order_auto_and_index_below_the_resident_lanes(fx):
+    """B = 8 192 (fits the resident lanes).  QUEUE_AUTO: from the second launch on the queue follows the previous launch's
+    step counts -- per-trajectory results and step counts bit-identical, batch sums equal to rounding, and faster (the
+    steps of an iteration hold about the same number of save points).  QUEUE_INDEX: every launch in index order, batch
+    sums bit-identical from launch to launch whatever ran before."""
+    from crnn_amd import QUEUE_AUTO, QUEUE_INDEX
+    B = 8192
+    ts, u0, data, ys = _case2_ensemble(B, seed=11)
+    s = dict(tsteps=ts, u0=u0, data=data, yscale=ys)
+    p = np.array(fx["case2_ckpt"]["p"])
+    node = _node(s)
+    l1, g1 = node.loss_and_grad(p)                  # no counts known yet: index order
+    na1, nr1 = node.step_counts()
+    ms1 = node.last_stats["kernel_ms"]
+    l2, g2 = node.loss_and_grad(p)                  # by the counts of launch 1
+    na2, nr2 = node.step_counts()
+    ms2 = min(node.last_stats["kernel_ms"], *(node.loss_and_grad(p) and node.last_stats["kernel_ms"] for _ in range(3)))
+    assert np.array_equal(na1, na2) and np.array_equal(nr1, nr2)
+    assert abs(l2 - l1) < 1e-13 * l1 and np.max(np.abs(g2 - g1)) < 1e-11 * np.max(np.abs(g1))
+    losses_auto = node.losses(p)
+    print(f"B = {B}: kernel {ms1:.3f} ms in index order, {ms2:.3f} ms queued by step count")
+    assert ms2 < ms1
+    node.set_queue_order(QUEUE_INDEX)
+    l3, g3 = node.loss_and_grad(p)
+    assert l3 == l1 and np.array_equal(g3, g1)      # the first launch was in index order too
+    node.loss_and_grad(p * 1.001)                   # some other launch in between
+    l4, g4 = node.loss_and_grad(p)
+    assert l4 == l1 and np.array_equal(g4, g1)
+    assert np.array_equal(node.losses(p), losses_auto)
+    node.set_queue_order(QUEUE_AUTO)
+    l5, g5 = node.loss_and_grad(p)                  # counts of the launch before: the same p, the same order as launch 2
+    assert l5 == l2 and np.array_equal(g5, g2)
+    with pytest.raises(Exception):
+        node.set_queue_order(7)
     node.close()
 
 
