@@ -147,6 +147,8 @@ struct Ctx {
     int32_t *d_perm = nullptr;
     size_t perm_cap = 0;
     int queue_order = CRNN_QUEUE_AUTO;
+    bool perm_ready = false;                    // d_perm holds the queue order for the next launch over [perm_first, +perm_count)
+    int64_t perm_first = 0, perm_count = 0;
     int64_t steps_first = 0, steps_count = 0;   // [first, first+count) whose d_nacc / d_nrej hold a completed launch's counts
     double *d_red_theta = nullptr;  // [n_theta + kExtra]
     int64_t n_fallback = 0;         // calls repeated with forward tangents after a tape overflow
@@ -395,6 +397,11 @@ int32_t queue_by_steps(Ctx *c, size_t lanes, int64_t first, int64_t count, const
                           first >= c->steps_first && first + count <= c->steps_first + c->steps_count;
     if (!sortable) return 0;
     if (ensure(c, &c->d_perm, &c->perm_cap, (size_t)count)) return -1;
+    if (c->perm_ready && c->perm_first == first && c->perm_count == count) {   // sorted by the previous launch's reduction kernel
+        c->perm_ready = false;
+        *perm = c->d_perm;
+        return 0;
+    }
     hipLaunchKernelGGL(crnn::sort_steps_kernel, dim3((unsigned)((count + 1023) / 1024)), dim3(1024), 0, c->stream, c->d_nacc, c->d_nrej,
                        first, (int)count, c->d_perm);
     HIP_TRY(c, hipGetLastError());
@@ -471,8 +478,20 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
     hipLaunchKernelGGL(k->fn, dim3(nblk), dim3(kBlock), 0, c->stream, prm, d_theta, adj);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    hipLaunchKernelGGL(crnn::reduce_project_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_partials, nbatch, d_dtheta, nth, P,
-                       c->d_red_theta, c->d_red, c->d_overflow);
+    // the next launch over this range will want the queue ordered by this launch's step counts (queue_by_steps): sort
+    // them in the same launch as the reduction
+    const bool sort_next = c->queue_order == CRNN_QUEUE_AUTO && ((size_t)count > lanes || count >= 2048) && count < ((int64_t)1 << 31);
+    if (sort_next && ensure(c, &c->d_perm, &c->perm_cap, (size_t)count)) return -1;
+    if (sort_next) {
+        hipLaunchKernelGGL(crnn::reduce_project_sort_kernel, dim3(1 + (unsigned)((count + 1023) / 1024)), dim3(1024), 0, c->stream,
+                           c->d_partials, nbatch, d_dtheta, nth, P, c->d_red_theta, c->d_red, c->d_overflow, c->d_nacc, c->d_nrej,
+                           first, (int)count, c->d_perm);
+        c->perm_ready = true; c->perm_first = first; c->perm_count = count;
+    } else {
+        hipLaunchKernelGGL(crnn::reduce_project_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_partials, nbatch, d_dtheta, nth, P,
+                           c->d_red_theta, c->d_red, c->d_overflow);
+        c->perm_ready = false;
+    }
     HIP_TRY(c, hipGetLastError());
     c->last_npart = npart;
     c->last_P = P;
@@ -1096,6 +1115,7 @@ static int32_t set_data_common(Ctx *c, const double *tsteps, const double *yscal
     c->n_obs = n_obs;
     c->kc_dirty = true;
     c->steps_first = 0; c->steps_count = 0;     // a new ensemble: no step counts known yet
+    c->perm_ready = false;
     for (int j = 1; j < c->cfg.n_save; ++j)
         if (!(tsteps[j] > tsteps[j - 1])) return fail(c, "crnn_ctx_set_data: tsteps must be strictly increasing");
     if (tsteps[0] < c->cfg.t0) return fail(c, "crnn_ctx_set_data: tsteps[0] < t0");

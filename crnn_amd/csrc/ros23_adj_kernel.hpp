@@ -728,11 +728,11 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
 // composition of every batch and the rounding of the batch sums -- is a deterministic function of the previous launch),
 // the runs' batches are then interleaved (see the end of the kernel).  Bitonic sort of 1024 keys in LDS, ~10 us for any
 // ensemble size (one block per run).
-__global__ __launch_bounds__(1024) void sort_steps_kernel(const int32_t *__restrict__ n_accept, const int32_t *__restrict__ n_reject,
-                                                          int64_t first, int count, int32_t *__restrict__ perm) {
-    __shared__ unsigned key[1024];
+__device__ __forceinline__ void sort_steps_run(const int32_t *__restrict__ n_accept, const int32_t *__restrict__ n_reject,
+                                               int64_t first, int count, int32_t *__restrict__ perm, const int r, const int NR,
+                                               unsigned *key) {   // run r of NR; key: 1024 words of LDS
     const int tid = threadIdx.x;
-    const int base = blockIdx.x * 1024;
+    const int base = r * 1024;
     const int e = base + tid;
     unsigned k = 0xFFFFFFFFu;                                  // beyond the ensemble: sorts to the end of the run
     if (e < count) {
@@ -756,7 +756,6 @@ __global__ __launch_bounds__(1024) void sort_steps_kernel(const int32_t *__restr
     // the longest batch of every run first, then every run's second longest ... -- so the queue is approximately
     // longest-first as a whole (with a handful of batches per wavefront the tail of the launch matters).  Only the last run
     // can be short; its last batch can be partial, the positions behind it close the gap.
-    const int NR = gridDim.x, r = blockIdx.x;
     const int nv_last = count - (NR - 1) * 1024;               // trajectories in the last run (1 .. 1024)
     const int nb_last = (nv_last + 63) / 64, rem = nv_last & 63;
     if (e < count) {                                            // rank tid of this run is a real trajectory
@@ -767,17 +766,20 @@ __global__ __launch_bounds__(1024) void sort_steps_kernel(const int32_t *__restr
         perm[pos] = base + (int)(key[tid] & 1023u);
     }
 }
+__global__ __launch_bounds__(1024) void sort_steps_kernel(const int32_t *__restrict__ n_accept, const int32_t *__restrict__ n_reject,
+                                                          int64_t first, int count, int32_t *__restrict__ perm) {
+    __shared__ unsigned key[1024];
+    sort_steps_run(n_accept, n_reject, first, count, perm, (int)blockIdx.x, (int)gridDim.x, key);
+}
 
 // Fixed-order reduction of the per-block partials (theta space) followed by the chain rule through p2vec:
 //   red_theta[m] = sum_blk partials[blk][m]   (m < nth + kExtra; the order over blk is fixed)
 //   out = [ dtheta[k,:] . red_theta[0:nth], k < P | n_overflow | extras ]      (the common layout, ros23_kernel.hpp kTail)
 // One block; nth + kExtra <= 256.
-__global__ __launch_bounds__(1024) void reduce_project_kernel(const double *__restrict__ partials, int nblk,
-                                                              const double *__restrict__ dtheta, int nth, int P,
-                                                              double *__restrict__ red_theta, double *__restrict__ out,
-                                                              const unsigned int *__restrict__ overflow) {
-    __shared__ double sh[256];
-    __shared__ double part[16][64];
+__device__ __forceinline__ void reduce_project_body(const double *__restrict__ partials, int nblk,
+                                                    const double *__restrict__ dtheta, int nth, int P,
+                                                    double *__restrict__ red_theta, double *__restrict__ out,
+                                                    const unsigned int *__restrict__ overflow, double *sh, double (*part)[64]) {
     const int npart = nth + kExtra;
     const int tid = threadIdx.x;
     // columns in chunks of 64, sixteen row lanes per column; the combination order is fixed
@@ -816,6 +818,30 @@ __global__ __launch_bounds__(1024) void reduce_project_kernel(const double *__re
     }
     if (tid == 0) out[P] = overflow ? (double)*overflow : 0.0;
     if (tid < kExtra) out[P + 1 + tid] = sh[nth + tid];
+}
+__global__ __launch_bounds__(1024) void reduce_project_kernel(const double *__restrict__ partials, int nblk,
+                                                              const double *__restrict__ dtheta, int nth, int P,
+                                                              double *__restrict__ red_theta, double *__restrict__ out,
+                                                              const unsigned int *__restrict__ overflow) {
+    __shared__ double sh[256];
+    __shared__ double part[16][64];
+    reduce_project_body(partials, nblk, dtheta, nth, P, red_theta, out, overflow, sh, part);
+}
+// The two in one launch: block 0 reduces this launch's partial sums, blocks 1 .. nruns sort its step counts into the queue
+// order of the NEXT launch over the same range (the solve kernel that read `perm` has finished: same stream).  One launch
+// and one inter-kernel gap less per training step (~16 us of 0.53 ms).
+__global__ __launch_bounds__(1024) void reduce_project_sort_kernel(const double *__restrict__ partials, int nblk,
+                                                                   const double *__restrict__ dtheta, int nth, int P,
+                                                                   double *__restrict__ red_theta, double *__restrict__ out,
+                                                                   const unsigned int *__restrict__ overflow,
+                                                                   const int32_t *__restrict__ n_accept,
+                                                                   const int32_t *__restrict__ n_reject, int64_t first, int count,
+                                                                   int32_t *__restrict__ perm) {
+    __shared__ double sh[256];
+    __shared__ double part[16][64];
+    __shared__ unsigned key[1024];
+    if (blockIdx.x == 0) reduce_project_body(partials, nblk, dtheta, nth, P, red_theta, out, overflow, sh, part);
+    else sort_steps_run(n_accept, n_reject, first, count, perm, (int)blockIdx.x - 1, (int)gridDim.x - 1, key);
 }
 
 }  // namespace crnn
