@@ -147,6 +147,7 @@ struct Ctx {
     int32_t *d_perm = nullptr;
     size_t perm_cap = 0;
     int queue_order = CRNN_QUEUE_AUTO;
+    bool fuse_opt = false, opt_fused = false;   // crnn_train_step: the optimiser update rides in the reduction launch / did so
     bool perm_ready = false;                    // d_perm holds the queue order for the next launch over [perm_first, +perm_count)
     int64_t perm_first = 0, perm_count = 0;
     int64_t steps_first = 0, steps_count = 0;   // [first, first+count) whose d_nacc / d_nrej hold a completed launch's counts
@@ -256,10 +257,12 @@ __global__ void p2vec_kernel(int pmap, int ns, int nr, int has_temp, const doubl
 // Flux chain (p2vec.hpp opt_update) with one thread per parameter; the norm clip is a fixed-order LDS tree.
 // Tail: theta, dtheta = p2vec(updated p) for the next step and zeroing of the next launch's queue head / overflow
 // counter, so that a training step is [this kernel] -> solve -> reductions.
-__global__ __launch_bounds__(256) void opt_kernel(crnn::OptCfg o, int P, int npart, double *p, const double *__restrict__ red,
-                                                  double *state, int pmap, int ns, int nr, int has_temp, double *th, double *dth,
-                                                  int nth, unsigned long long *queue, unsigned int *overflow, double *poison) {
-    __shared__ double sh[256];
+// (device function: called by opt_kernel and, when no collective sits between the reduction and the update, by block 0 of
+// reduce_opt_sort_kernel; NT = threads of the block, sh = NT doubles of LDS)
+template <int NT>
+__device__ __forceinline__ void opt_body(const crnn::OptCfg &o, int P, int npart, double *p, const double *red,
+                                         double *state, int pmap, int ns, int nr, int has_temp, double *th, double *dth,
+                                         int nth, unsigned long long *queue, unsigned int *overflow, double *poison, double *sh) {
     const int tid = threadIdx.x;
     // A gradient formed while some rank's adjoint tape overflowed (summed overflow count != 0) is not applied, and neither
     // is any later step until the host has repeated the skipped ones in order (sticky flag): p, the optimiser state and
@@ -279,10 +282,10 @@ __global__ __launch_bounds__(256) void opt_kernel(crnn::OptCfg o, int P, int npa
     bool clip = false;
     if (o.grad_clip_norm > 0) {
         double a = 0.0;
-        for (int k = tid; k < P; k += 256) { const double g = red[k] * gscale; a = fma(g, g, a); }
+        for (int k = tid; k < P; k += NT) { const double g = red[k] * gscale; a = fma(g, g, a); }
         sh[tid] = a;
         __syncthreads();
-        for (int s_ = 128; s_ > 0; s_ >>= 1) {
+        for (int s_ = NT / 2; s_ > 0; s_ >>= 1) {
             if (tid < s_) sh[tid] += sh[tid + s_];
             __syncthreads();
         }
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(256) void opt_kernel(crnn::OptCfg o, int P, int npa
         if (tid == 0) { *ncalls = nc; *ed_eta = e; }
     }
     const double b1t = bp[0], b2t = bp[1];
-    for (int k = tid; k < P; k += 256) {
+    for (int k = tid; k < P; k += NT) {
         double g = red[k] * gscale;
         if (clip) g = g / gn * o.grad_clip_norm;
         g *= eta_ed;
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(256) void opt_kernel(crnn::OptCfg o, int P, int npa
         delta += o.wd * p[k];
         p[k] -= delta;
     }
-    for (int i = tid; i < nth * P; i += 256) dth[i] = 0.0;
+    for (int i = tid; i < nth * P; i += NT) dth[i] = 0.0;
     __syncthreads();
     if (tid == 0) {
         bp[0] = b1t * o.beta1;
@@ -319,6 +322,37 @@ __global__ __launch_bounds__(256) void opt_kernel(crnn::OptCfg o, int P, int npa
         crnn::p2vec_eval(pmap, ns, nr, has_temp, p, th, dth);
         *queue = 0ULL;
         *overflow = 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void opt_kernel(crnn::OptCfg o, int P, int npart, double *p, const double *__restrict__ red,
+                                                  double *state, int pmap, int ns, int nr, int has_temp, double *th, double *dth,
+                                                  int nth, unsigned long long *queue, unsigned int *overflow, double *poison) {
+    __shared__ double sh[256];
+    opt_body<256>(o, P, npart, p, red, state, pmap, ns, nr, has_temp, th, dth, nth, queue, overflow, poison, sh);
+}
+
+// One launch for the tail of a training step that needs no collective: block 0 = reduction + chain rule, then the
+// optimiser update + p2vec of the new p; blocks 1 ... = the step-count sort for the next launch (ros23_adj_kernel.hpp).
+__global__ __launch_bounds__(1024) void reduce_opt_sort_kernel(const double *__restrict__ partials, int nblk,
+                                                               const double *dtheta_in, int nth, int P,       // = dth, = overflow:
+                                                               double *__restrict__ red_theta, double *red,   // no restrict
+                                                               const unsigned int *overflow_in,
+                                                               const int32_t *__restrict__ n_accept, const int32_t *__restrict__ n_reject,
+                                                               int64_t first, int count, int32_t *__restrict__ perm,
+                                                               crnn::OptCfg o, int npart, double *p, double *state, int pmap, int ns,
+                                                               int nr, int has_temp, double *th, double *dth,
+                                                               unsigned long long *queue, unsigned int *overflow, double *poison) {
+    __shared__ double sh[1024];
+    __shared__ double part[16][64];
+    __shared__ unsigned key[1024];
+    if (blockIdx.x == 0) {
+        crnn::reduce_project_body(partials, nblk, dtheta_in, nth, P, red_theta, red, overflow_in, sh, part);
+        __threadfence_block();
+        __syncthreads();          // red[] is complete and visible to the whole block; dtheta_in is not read any more
+        opt_body<1024>(o, P, npart, p, red, state, pmap, ns, nr, has_temp, th, dth, nth, queue, overflow, poison, sh);
+    } else if (perm) {
+        crnn::sort_steps_run(n_accept, n_reject, first, count, perm, (int)blockIdx.x - 1, (int)gridDim.x - 1, key);
     }
 }
 
@@ -482,7 +516,14 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
     // them in the same launch as the reduction
     const bool sort_next = c->queue_order == CRNN_QUEUE_AUTO && ((size_t)count > lanes || count >= 2048) && count < ((int64_t)1 << 31);
     if (sort_next && ensure(c, &c->d_perm, &c->perm_cap, (size_t)count)) return -1;
-    if (sort_next) {
+    if (c->fuse_opt && defer) {   // crnn_train_step without a communicator: reduction, optimiser update and the next launch's sort in one
+        hipLaunchKernelGGL(reduce_opt_sort_kernel, dim3(1 + (sort_next ? (unsigned)((count + 1023) / 1024) : 0u)), dim3(1024), 0, c->stream,
+                           c->d_partials, nbatch, d_dtheta, nth, P, c->d_red_theta, c->d_red, c->d_overflow, c->d_nacc, c->d_nrej,
+                           first, (int)count, sort_next ? c->d_perm : nullptr, c->opt, npart, c->d_p, c->d_opt, c->cfg.param_map,
+                           c->cfg.ns, c->cfg.nr, c->nfx, c->d_theta, c->d_dtheta, c->d_queue, c->d_overflow, c->d_poison);
+        c->opt_fused = true;
+        c->perm_ready = sort_next; c->perm_first = first; c->perm_count = count;
+    } else if (sort_next) {
         hipLaunchKernelGGL(crnn::reduce_project_sort_kernel, dim3(1 + (unsigned)((count + 1023) / 1024)), dim3(1024), 0, c->stream,
                            c->d_partials, nbatch, d_dtheta, nth, P, c->d_red_theta, c->d_red, c->d_overflow, c->d_nacc, c->d_nrej,
                            first, (int)count, c->d_perm);
@@ -1328,10 +1369,12 @@ static int32_t train_begin_impl(Ctx *c, int64_t first, int64_t count, int32_t n_
 
 static int32_t train_end_impl(Ctx *c, double *loss_mean) {
     if (!c->train_ready || c->last_npart == 0) return fail(c, "crnn_train_step_end: no step in flight");
+    if (!c->opt_fused)
     hipLaunchKernelGGL(opt_kernel, dim3(1), dim3(256), 0, c->stream, c->opt, c->n_params, c->last_npart, c->d_p, c->d_red,
                        c->d_opt, c->cfg.param_map, c->cfg.ns, c->cfg.nr, c->nfx, c->d_theta, c->d_dtheta, c->n_theta,
                        c->d_queue, c->d_overflow, c->d_poison);
     HIP_TRY(c, hipGetLastError());
+    c->opt_fused = false;
     c->theta_current = true;    // (a skipped step leaves p and theta as they were: still consistent)
     c->flags_zeroed = true;
     if (loss_mean) {
@@ -1396,7 +1439,13 @@ int32_t crnn_train_step(crnn_ctx *ctx, int64_t first, int64_t count, int32_t n_s
     Ctx *c = reinterpret_cast<Ctx *>(ctx);
     if (!c) return fail(nullptr, "null ctx");
     if (c->pending.size() >= kMaxPending && check_pending(c, nullptr)) return -1;
-    if (train_begin_impl(c, first, count, n_save_active, true)) return -1;
+    // nothing between the reduction and the update (no communicator, no callback), the parameters the launch differentiates
+    // with respect to are the optimiser's own: one launch for both (launch_adjoint)
+    c->fuse_opt = !c->comm && !c->host_ar;
+    c->opt_fused = false;
+    const int32_t rc_begin = train_begin_impl(c, first, count, n_save_active, true);
+    c->fuse_opt = false;
+    if (rc_begin) return -1;
     if (c->last_deferred) c->pending.push_back({first, count, n_save_active});
     if (allreduce_red(c)) return -1;
     if (train_end_impl(c, loss_mean)) return -1;

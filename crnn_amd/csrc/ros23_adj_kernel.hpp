@@ -788,12 +788,15 @@ __device__ __forceinline__ void reduce_project_body(const double *__restrict__ p
         const int k = c0 + col;
         double a0 = 0.0, a1 = 0.0;
         if (k < npart) {
-            int bI = rl;
-            for (; bI + 16 < nblk; bI += 32) {
-                a0 += partials[(size_t)bI * npart + k];
-                a1 += partials[(size_t)(bI + 16) * npart + k];
+            // rows rl, rl + 16, rl + 32, ... ; eight loads in flight per step of the loop (the sum order stays fixed: even
+            // positions of the row sequence into a0, odd ones into a1)
+            for (int bI = rl; bI < nblk; bI += 128) {
+                double v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = (bI + 16 * q < nblk) ? partials[(size_t)(bI + 16 * q) * npart + k] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) { a0 += v[q]; a1 += v[q + 1]; }
             }
-            if (bI < nblk) a0 += partials[(size_t)bI * npart + k];
         }
         part[rl][col] = a0 + a1;
         __syncthreads();
