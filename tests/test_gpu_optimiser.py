@@ -57,24 +57,27 @@ def _oracle_mean_grad(orc, pb, kind, ns, nr, p, u0, ts, data, sample=None):
     return r["loss"].mean(), r["grad"] / B
 
 
+@pytest.mark.parametrize("gm", [0, 2], ids=["auto", "adjoint"])
 @pytest.mark.parametrize("case", ["case2", "rober"])
-def test_training_loop_matches_oracle_chain(orc, case2_setup, rober_setup, case):
+def test_training_loop_matches_oracle_chain(orc, case2_setup, rober_setup, case, gm):
     """12 device training steps (crnn_train_init / crnn_train_step / crnn_get_params) from the reference's initial p
     (case2) / checkpoint p (robertson, random horizons as rober_crnn.jl:218) against: oracle loss + gradient at the
     oracle's own current p -> oracle optimiser.  Both chains start from the same p and never exchange anything, so
     this is the whole A7 + A8 loop, device vs oracle.  ADAM's first updates are sign-like (m / sqrt(v) = +-1), which
-    keeps the comparison tight: 1e-9 on the parameters after every step."""
+    keeps the comparison tight: 1e-9 on the parameters after every step.  grad_mode AUTO takes the forward-tangent kernels at
+    this ensemble size (reduction, then `opt_kernel`), ADJOINT the tape kernel whose tail is ONE launch without a communicator
+    (`reduce_opt_sort_kernel`: reduction + chain rule + optimiser + p2vec) -- the same chain either way."""
     from crnn_amd import NeuralODE, ODEProblem, Optimiser, PRESET_CASE2, PRESET_ROBER
     if case == "case2":
         s, preset, kind, ns, nr, P = case2_setup, PRESET_CASE2, 2, 6, 3, 25
         p0 = s["p_init"]
-        node = NeuralODE(ODEProblem(preset, s["tsteps"]))
+        node = NeuralODE(ODEProblem(preset, s["tsteps"], grad_mode=gm))
         okw = dict(eta=0.005, wd=1e-6, expdecay=(5e-3, 0.5, 500 * 20, 1e-4))
         samples = [None] * 12
     else:
         s, preset, kind, ns, nr, P = rober_setup, PRESET_ROBER, 3, 3, 6, 43
         p0 = s["p_ckpt"]
-        node = NeuralODE(ODEProblem(preset, s["tsteps"], rate_scale=s["dydt_scale"]))
+        node = NeuralODE(ODEProblem(preset, s["tsteps"], rate_scale=s["dydt_scale"], grad_mode=gm))
         okw = dict(eta=0.005, wd=1e-6, grad_clip_norm=10.0)
         samples = [20, 40, 22, 40, 25, 40, 40, 21, 33, 40, 28, 40]
     node.set_ensemble(s["u0"], s["data"], s["yscale"])
