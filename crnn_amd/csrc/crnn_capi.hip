@@ -499,6 +499,11 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
     // trajectories by their last known step counts so that batches are homogeneous (the counts of the previous launch over
     // the same range: in training p moves little from step to step)
     if (queue_by_steps(c, lanes, first, count, &adj.perm)) return -1;
+#ifdef CRNN_ADJ_PROF
+    static unsigned long long *d_aprof = nullptr;
+    if (!d_aprof) HIP_TRY(c, hipMalloc((void **)&d_aprof, 16 * sizeof(unsigned long long)));
+    adj.prof = d_aprof;
+#endif
     if (upload_consts(c)) return -1;
     if (!c->flags_zeroed) {
         HIP_TRY(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), c->stream));
@@ -537,6 +542,17 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
     c->last_npart = npart;
     c->last_P = P;
     c->steps_first = first; c->steps_count = count;     // d_nacc / d_nrej of this range are current once the launch has run
+#ifdef CRNN_ADJ_PROF
+    {
+        unsigned long long hp_[16];
+        HIP_TRY(c, hipMemcpy(hp_, d_aprof, sizeof(hp_), hipMemcpyDeviceToHost));
+        double tot = 0;
+        for (int k = 0; k < 16; ++k) tot += (double)hp_[k];
+        fprintf(stderr, "[adj_prof] wave 0 ticks %.0f:", tot);
+        for (int k = 0; k < 14; ++k) fprintf(stderr, " %d:%.1f%%", k, 100.0 * (double)hp_[k] / (tot > 0 ? tot : 1));
+        fprintf(stderr, "\n");
+    }
+#endif
     if (defer) return 0;   // the device-resident training loop looks at the outcome later (check_pending)
     unsigned int ovf = 0;
     HIP_TRY(c, hipMemcpyAsync(&ovf, c->d_overflow, sizeof(ovf), hipMemcpyDeviceToHost, c->stream));

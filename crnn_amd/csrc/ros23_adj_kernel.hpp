@@ -31,7 +31,9 @@
 #pragma once
 #include "ros23_kernel.hpp"
 
-// kernel-timing ablations (tools/adj_ablate.sh): 1 = no reverse sweep, 2 = no observed-data loads, 4 = no tape stores
+// kernel-timing ablations (tools/kvariants.sh): 1 = no reverse sweep, 2 = no observed-data loads, 4 = no tape stores,
+// 8 = no loss / seeds in the reverse sweep.  Round 2 (queued by step count, case2 65 536, 0.514 ms): forward sweep 57 % of an
+// index-order launch, tape stores 8 %, observed rows 4.5 %, loss + seeds 17 % (robertson 9 %)
 #ifndef CRNN_ADJ_DBG
 #define CRNN_ADJ_DBG 0
 #endif
@@ -56,6 +58,15 @@
 #define CRNN_ADJ_TAPE_K 0
 #endif
 
+// phase timing (tools/kvariants.sh build prof="-DCRNN_ADJ_PROF=1"; the library then prints the shares of wave 0 of block 0 to
+// stderr after every launch): s_memtime deltas per phase, with scheduling fences at the phase boundaries (the fenced
+// kernel is ~30 % slower than the real one: the shares are a guide, the ablations above the measurement)
+#ifdef CRNN_ADJ_PROF
+#define ADJ_T(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_readcyclecounter(); prof_acc[k] += now_ - prof_last; prof_last = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define ADJ_T(k) do { } while (0)
+#endif
+
 namespace crnn {
 
 struct AdjParams {
@@ -65,6 +76,7 @@ struct AdjParams {
     int32_t align_rev;           // ros23_adj_kernel: reverse sweep aligned by step index (see the kernel)
     double *batch_partials;      // [ceil(count/64)][NTH + kExtra]: per 64-trajectory batch sums
     const int32_t *perm;         // ros23_adj_kernel: position in the queue -> trajectory (relative to first); null = identity
+    unsigned long long *prof;    // CRNN_ADJ_PROF builds: 16 phase totals in s_memtime ticks
 };
 
 // Solve A^T x = b with the factors of lu_factor (P A = L U): x = P^T L^-T U^-T b
@@ -174,6 +186,9 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
     const bool start_saved = (ts0 == t0);
 
     const int lane = tid & 63;
+#ifdef CRNN_ADJ_PROF
+    unsigned long long prof_acc[16] = {0}, prof_last = __builtin_readcyclecounter();
+#endif
     double *const tape = adj.tape + (size_t)((size_t)blockIdx.x * BLOCK + tid) * adj.tape_cap * RECW;
 
     while (true) {
@@ -264,6 +279,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                 if (t + dt * (1.0 + 1e-13) >= tend) { dt = tend - t; last = true; }
                 if (rc < 0 && (!(dt > kc->dtmin) || t + dt == t)) rc = 2;
                 if (rc < 0) {
+                    ADJ_T(0);   // loop control, step-size bookkeeping
                     Solver W;
                     const double gam = d_ * dt;
                     double gr0[NR];
@@ -274,6 +290,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
 #pragma unroll
                     for (int i = 0; i < NS; ++i) k1[i] = f0[i];
                     W.solve(th, g0, gr0, kc->scale, k1);
+                    ADJ_T(1);   // factor + first solve
                     {
                         double u1[NS], x1[NS], g1[NS], r1[NR];
 #pragma unroll
@@ -282,17 +299,20 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                         rates<NS, NR, HAS_T>(th, x1, bT, r1);
                         rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r1, kc->scale, f1);
                     }
+                    ADJ_T(2);   // evaluation at u_mid
 #pragma unroll
                     for (int i = 0; i < NS; ++i) dk[i] = f1[i] - k1[i];
                     W.solve(th, g0, gr0, kc->scale, dk);
 #pragma unroll
                     for (int i = 0; i < NS; ++i) unew[i] = fma(dt, k1[i] + dk[i], u[i]);
+                    ADJ_T(3);   // second solve
                     {
                         double x2[NS];
                         features<NS>(unew, kc->lb, kc->ub, x2, g2);
                         rates<NS, NR, HAS_T>(th, x2, bT, r2);
                         rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r2, kc->scale, f2);
                     }
+                    ADJ_T(4);   // evaluation at u_new
                     double k3[NS];
 #pragma unroll
                     for (int i = 0; i < NS; ++i) {
@@ -300,6 +320,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                         k3[i] = f2[i] - c32 * (k2i - f1[i]) - 2.0 * (k1[i] - f0[i]);
                     }
                     W.solve(th, g0, gr0, kc->scale, k3);
+                    ADJ_T(5);   // third solve
                     double es = 0.0;
                     bool finite = okf;
 #pragma unroll
@@ -312,6 +333,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                         finite = finite && isfinite(unew[i]) && isfinite(ev);
                     }
                     es = es * (1.0 / N);
+                    ADJ_T(6);   // error norm
                     if (!finite) rc = 3;
                     else {
                         // PI controller (OrdinaryDiffEq PIController), in log space
@@ -320,6 +342,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                         const double lq11 = kc->beta1 * lEE;
                         double q = ee_zero ? 1.0 / kc->qmax
                                            : fmax(1.0 / kc->qmax, fmin(1.0 / kc->qmin, exp(lq11 - kc->beta2 * lqold) / kc->gamma));
+                        ADJ_T(7);   // controller (log, exp, divisions)
                         if (es <= 1.0) {
                             if (nacc >= adj.tape_cap) {
                                 rc = 5;  // out of tape: the host re-runs the call with forward tangents
@@ -369,6 +392,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                                 lqold = ee_zero ? lqinit : fmax(lEE, lqinit);
                                 dt = fmin(dt / q, dtmax);
                                 if (jsave >= nsave) rc = 0;
+                                ADJ_T(8);   // tape record, save-point loop, FSAL copy
                             }
                         } else {
                             ++nrej;
@@ -522,6 +546,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                 W.solve(th, gg0, gr0, kc->scale, dk);
 #endif
 
+                ADJ_T(9);    // reverse: prefetches + re-formation of the step
                 // ---- loss and its seeds at the save points inside (tn, tnew]
                 double A_[NS], B1[NS], B2[NS];
 #pragma unroll
@@ -557,7 +582,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                     }
                     --jsave;
                 };
-                if (in_step()) {
+                if (!(CRNN_ADJ_DBG & 8) && in_step()) {   // ablation 8: no loss / seeds at all (timing only)
                     seed_point(dA);
                     if (in_step()) {
                         seed_point(dB);
@@ -572,6 +597,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                     }
                 }
 
+                ADJ_T(10);   // reverse: loss + seeds
                 // ---- adjoint of the step
                 double kb1[NS], v[NS], ub[NS];
 #pragma unroll
@@ -661,8 +687,10 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                 }
                 tnew = tn;
                 --s;
+                ADJ_T(11);   // reverse: adjoint of the step
             }
         }
+        ADJ_T(12);
 
         // ---- outputs
         if (valid) {
@@ -719,7 +747,12 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
         }
 #undef THB_ADD
 #undef THB_REG
+        ADJ_T(13);   // outputs + batch sums
     }
+#ifdef CRNN_ADJ_PROF
+    if (adj.prof && blockIdx.x == 0 && tid == 0)
+        for (int k = 0; k < 16; ++k) adj.prof[k] = prof_acc[k];
+#endif
 }
 
 // Queue order for ensembles larger than the resident lanes.  Homogeneous 64-trajectory batches are all that is needed, not
