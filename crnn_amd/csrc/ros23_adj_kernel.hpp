@@ -445,6 +445,8 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
 #pragma unroll
             for (int i = 0; i < NS; ++i) d[i] = (CRNN_ADJ_DBG & 2) ? 0.5 : row[doff[i]];
         };
+        double ts_cur = (jsave - 1 >= jlo) ? ts_lds[jsave - 1] : -INFINITY;   // save point jsave-1 (none: -inf, never inside a step)
+        double ts_nxt = (jsave - 2 >= jlo) ? ts_lds[jsave - 2] : -INFINITY;
         double rt = 0.0, rdt = 0.0, ru[NS];   // tape record s, prefetched
 #if CRNN_ADJ_TAPE_K
         double rk1[NS], rdk[NS];
@@ -551,9 +553,14 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                 double A_[NS], B1[NS], B2[NS];
 #pragma unroll
                 for (int i = 0; i < NS; ++i) { A_[i] = 0.0; B1[i] = 0.0; B2[i] = 0.0; }
-                auto in_step = [&]() -> bool { return jsave > jlo && ts_lds[jsave - 1] > tn; };
+                // the times of the next two save points (backwards) sit in registers: the test "is it inside this step" and the
+                // seed itself do not wait for LDS, the read for the one after next has a whole seed to complete (case2 -2.5 %;
+                // the same in the forward sweep's save-point loop gains nothing: two more registers live across that loop)
+                auto in_step = [&]() -> bool { return ts_cur > tn; };
                 auto seed_point = [&](const double (&dobs)[NS]) {
-                    const double ts = ts_lds[jsave - 1];
+                    const double ts = ts_cur;
+                    ts_cur = ts_nxt;
+                    ts_nxt = (jsave - 3 >= jlo) ? ts_lds[jsave - 3] : -INFINITY;
                     const bool at_end = (ts == tnew);
                     const double Th = at_end ? 1.0 : (ts - tn) / h;
                     const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
