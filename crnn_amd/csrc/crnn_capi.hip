@@ -199,7 +199,7 @@ int32_t allreduce_red(Ctx *c) {
             return fail(c, "the caller's all-reduce callback (crnn_comm_set_allreduce) reported failure");
         return 0;
     }
-    if (c->comm) {
+    if (c->comm && c->world > 1) {   // a one-rank communicator has nothing to add
         ++c->n_collectives;
         NCCL_TRY(c, ncclAllReduce(c->d_red, c->d_red, c->last_npart, ncclDouble, ncclSum, c->comm, c->stream));
     }
@@ -1455,9 +1455,9 @@ int32_t crnn_train_step(crnn_ctx *ctx, int64_t first, int64_t count, int32_t n_s
     Ctx *c = reinterpret_cast<Ctx *>(ctx);
     if (!c) return fail(nullptr, "null ctx");
     if (c->pending.size() >= kMaxPending && check_pending(c, nullptr)) return -1;
-    // nothing between the reduction and the update (no communicator, no callback), the parameters the launch differentiates
+    // nothing between the reduction and the update (no communicator of more than one rank, no callback), the parameters the launch differentiates
     // with respect to are the optimiser's own: one launch for both (launch_adjoint)
-    c->fuse_opt = !c->comm && !c->host_ar;
+    c->fuse_opt = !(c->comm && c->world > 1) && !c->host_ar;
     c->opt_fused = false;
     const int32_t rc_begin = train_begin_impl(c, first, count, n_save_active, true);
     c->fuse_opt = false;
