@@ -545,6 +545,7 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
 #ifdef CRNN_ADJ_PROF
     {
         unsigned long long hp_[16];
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, hipMemcpy(hp_, d_aprof, sizeof(hp_), hipMemcpyDeviceToHost));
         double tot = 0;
         for (int k = 0; k < 16; ++k) tot += (double)hp_[k];
