@@ -144,18 +144,43 @@ def source_hash() -> str:
 
 def ensure_built(force: bool = False) -> str:
     """(Re)build libcrnn_hip.so when it is missing or was not compiled from the sources next to it: a binary that
-    travelled with a snapshot must never run in place of the code it travelled with.  Returns the source hash."""
+    travelled with a snapshot must never run in place of the code it travelled with.  Returns the source hash.
+    One process builds (file lock; torchrun ranks import at the same moment), into a temporary name that is moved into
+    place, so that nobody maps a half-written library."""
+    import fcntl
     import shutil
     import subprocess
     want = source_hash()
     side = LIB_PATH + ".srchash"
-    have = open(side).read().strip() if os.path.exists(side) else None
-    if force or not os.path.exists(LIB_PATH) or have != want:
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        if not (os.path.exists(hipcc) or shutil.which(hipcc)):
-            raise ImportError(f"{LIB_PATH} is missing or stale (sources {want}, binary {have}) and hipcc was not found to "
-                              "rebuild it. crnn_amd has no CPU fallback.")
-        subprocess.check_call(["make", "-C", CSRC, "-B", "-s"])
+
+    def stale():
+        have = open(side).read().strip() if os.path.exists(side) else None
+        return (not os.path.exists(LIB_PATH) or have != want), have
+
+    need, have = stale()
+    if not (force or need):
+        return want
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        raise ImportError(f"{LIB_PATH} is missing or stale (sources {want}, binary {have}) and hipcc was not found to "
+                          "rebuild it. crnn_amd has no CPU fallback.")
+    try:
+        lock = open(os.path.join(CSRC, ".build.lock"), "w")
+    except OSError as e:
+        raise ImportError(f"{LIB_PATH} is missing or stale (sources {want}, binary {have}) and {CSRC} is not writable: "
+                          "build it with `make -C crnn_amd/csrc` where it is") from e
+    with lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or stale()[0]:                      # re-read under the lock: another rank may have built it meanwhile
+            tmp = f"libcrnn_hip.so.tmp{os.getpid()}"
+            try:
+                subprocess.check_call(["make", "-C", CSRC, "-B", "-s", f"OUT={tmp}"])
+                os.replace(os.path.join(CSRC, tmp), LIB_PATH)
+                os.replace(os.path.join(CSRC, tmp + ".srchash"), side)
+            finally:
+                for f in (tmp, tmp + ".srchash"):
+                    if os.path.exists(os.path.join(CSRC, f)):
+                        os.remove(os.path.join(CSRC, f))
     return want
 
 

@@ -157,8 +157,6 @@ class ODEProblem:
     tape_steps: int = 0           # adjoint tape capacity per trajectory, 0 = auto
     errnorm_sens: int = 0         # 1 / 2: ForwardDiff's dual-inclusive error norm drives the step sizes of gradient calls
                                   # (1: squared norm / length(u), Julia-1.6-era DiffEqBase; 2: / totallength(u), later versions)
-    errnorm_sens: int = 0         # 1 / 2: ForwardDiff's dual-inclusive error norm drives the step sizes of gradient calls
-                                  # (1: squared norm / length(u), Julia-1.6-era DiffEqBase; 2: / totallength(u), later versions)
 
     def config(self) -> Config:
         cfg = Config()
@@ -171,7 +169,6 @@ class ODEProblem:
         cfg.cols_per_lane = int(self.cols_per_lane)
         cfg.grad_mode = int(self.grad_mode)
         cfg.tape_steps = int(self.tape_steps)
-        cfg.errnorm_sens = int(self.errnorm_sens)
         cfg.errnorm_sens = int(self.errnorm_sens)
         n = cfg.ns + cfg.has_temp
         if self.atol is not None:

@@ -1005,13 +1005,17 @@ int32_t crnn_opt_preset(crnn_opt_config *o, int32_t preset) {
     if (!o) return fail(nullptr, "crnn_opt_preset: null");
     std::memset(o, 0, sizeof(*o));
     o->beta1 = 0.9; o->beta2 = 0.999;
+    // The reference writes the decay as a Float32 literal (`1.f-6`, `1.f-8`) and Flux's WeightDecay keeps it as one: the
+    // factor that multiplies the Float64 p is the Float32 value (9.999999974752427e-07, not 1e-6).  The checkpoints hold it
+    // that way (case2/checkpoint/mymodel.bson: WeightDecay(Float32); tests/golden/fixtures_ckpt_opt.json).
+    const double wd6 = (double)1e-6f, wd8 = (double)1e-8f;
     switch (preset) {
-    case CRNN_PRESET_CASE1: o->eta = 0.001; o->wd = 1e-8; break;                                  // case1.jl:18
+    case CRNN_PRESET_CASE1: o->eta = 0.001; o->wd = wd8; break;                                   // case1.jl:18
     case CRNN_PRESET_CASE2:                                                                        // case2.jl:31-32
-        o->eta = 0.005; o->wd = 1e-6; o->use_expdecay = 1; o->ed_eta0 = 5e-3; o->ed_decay = 0.5;
+        o->eta = 0.005; o->wd = wd6; o->use_expdecay = 1; o->ed_eta0 = 5e-3; o->ed_decay = 0.5;
         o->decay_step = 500 * 20; o->ed_clip = 1e-4; break;
-    case CRNN_PRESET_ROBER: o->eta = 0.005; o->wd = 1e-6; o->grad_clip_norm = 10.0; break;         // rober_crnn.jl:19,29
-    case CRNN_PRESET_HYCHEM: o->eta = 0.005; o->wd = 1e-6; o->grad_clip_norm = 10.0; break;        // crnn_pyrolysis_mass.jl:20,24
+    case CRNN_PRESET_ROBER: o->eta = 0.005; o->wd = wd6; o->grad_clip_norm = 10.0; break;          // rober_crnn.jl:19,29
+    case CRNN_PRESET_HYCHEM: o->eta = 0.005; o->wd = wd6; o->grad_clip_norm = 10.0; break;         // crnn_pyrolysis_mass.jl:20,24
     default: return fail(nullptr, "crnn_opt_preset: unknown preset");
     }
     return 0;
@@ -1443,6 +1447,7 @@ int32_t crnn_train_step_begin(crnn_ctx *ctx, int64_t first, int64_t count, int32
     Ctx *c = reinterpret_cast<Ctx *>(ctx);
     if (!c) return fail(nullptr, "null ctx");
     if (check_pending(c, nullptr)) return -1;
+    c->opt_fused = false;
     return train_begin_impl(c, first, count, n_save_active, false);   // split API: outcome checked before returning
 }
 
@@ -1462,9 +1467,14 @@ int32_t crnn_train_step(crnn_ctx *ctx, int64_t first, int64_t count, int32_t n_s
     c->opt_fused = false;
     const int32_t rc_begin = train_begin_impl(c, first, count, n_save_active, true);
     c->fuse_opt = false;
-    if (rc_begin) return -1;
-    if (c->last_deferred) c->pending.push_back({first, count, n_save_active});
-    if (allreduce_red(c)) return -1;
+    if (rc_begin) { c->opt_fused = false; return -1; }   // (a failed launch must not leave "the update already ran" behind)
+    // The replay bookkeeping must be the same on every rank.  With a collective attached the skip decision is taken on the
+    // SUMMED overflow count, so a rank that itself ran forward tangents (grad_mode AUTO picks them from the LOCAL count:
+    // shards of 2049 and 2048 trajectories straddle case2's threshold) is skipped too when another rank's tape overflowed:
+    // it has to look at d_poison and replay like everybody else, or its next all-reduce pairs with the others' replay.
+    const bool collective = (c->comm && c->world > 1) || c->host_ar;
+    if (c->last_deferred || collective) c->pending.push_back({first, count, n_save_active});
+    if (allreduce_red(c)) { c->opt_fused = false; return -1; }
     if (train_end_impl(c, loss_mean)) return -1;
     if (loss_mean) return check_pending(c, loss_mean);   // the caller wants this step's loss: look now
     return 0;
@@ -1528,6 +1538,7 @@ int32_t crnn_train_update(crnn_ctx *ctx, const double *grad) {
     if (!c->train_ready) return fail(c, "crnn_train_update: call crnn_train_init first");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     if (check_pending(c, nullptr)) return -1;
+    c->opt_fused = false;
     const int P = c->n_params, npart = P + crnn::kTail;
     if (c->npart_max < npart) {
         if (c->d_red) HIP_TRY(c, hipFree(c->d_red));

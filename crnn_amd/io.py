@@ -2,9 +2,13 @@
 
     load_checkpoint(path)         the reference's `@save "./checkpoint/mymodel.bson" p opt l_loss_train ... iter`
                                   (case2/case2.jl:178-184, robertson/rober_crnn.jl:205-207): BSON.jl documents; returns the
-                                  numeric entries (p, loss lists, iter) so that training can resume from a reference run.
-    save_checkpoint(path, ...)    writes p / loss lists / iter in the same BSON.jl array encoding (the Flux optimiser
-                                  object of the reference's files is not reproduced).
+                                  numeric entries (p, loss lists, iter) so that training can resume from a reference run,
+                                  and -- when the file holds the reference's Flux optimiser object -- `opt` (its decoded
+                                  fields, load_flux_opt) and `opt_state` (the same state in the library's layout
+                                  [m(P) | v(P) | beta1^t, beta2^t | ExpDecay eta, update count], crnn_set_opt_state).
+    load_flux_opt(doc)            the `opt` entry of such a document: Flux.Optimise.Optimiser([ExpDecay,] ADAM, WeightDecay)
+    save_checkpoint(path, ...)    writes p / loss lists / iter / opt_state in the same BSON.jl array encoding (a Flux
+                                  optimiser *object* is not written).
     load_exp(filename, beta)      Cathode_NCM333_UQ/src_333/dataset.jl:5-23: CSV [T, replicas...] -> unique rows, time grid
                                   t = (T - 100) * 60 / beta.
 
@@ -64,8 +68,88 @@ def load_checkpoint(path):
         try:
             out[k] = conv(v)
         except (TypeError, KeyError, ValueError):
-            pass                          # non-numeric entry (e.g. the Flux optimiser struct)
+            pass                          # non-numeric entry (e.g. the Flux optimiser struct: decoded below)
+    if isinstance(d.get("opt"), dict) and "p" in out:
+        try:
+            out["opt"] = load_flux_opt(d)
+            out["opt_state"] = flux_opt_state(out["opt"], np.asarray(out["p"]).size)
+        except (TypeError, KeyError, ValueError, IndexError):
+            pass                          # some other optimiser object
     return out
+
+
+def load_flux_opt(doc):
+    """Decode the `opt` entry of a reference checkpoint (`@save ... opt`, case2/case2.jl:178, robertson/rober_crnn.jl:201):
+    `Flux.Optimiser(ExpDecay(...), ADAMW(...))` = Optimiser([ExpDecay, Optimiser([ADAM, WeightDecay])]) (case2/case2.jl:31-32)
+    or `ADAMW(...)` = Optimiser([ADAM, WeightDecay]) (rober_crnn.jl:19).  Flux <= 0.12 keeps the state in IdDicts keyed by
+    the parameter array: ADAM -> (m, v, (beta1^t, beta2^t)), ExpDecay -> update count.
+    -> dict(adam=dict(eta, beta1, beta2, m, v, beta1_pow, beta2_pow), wd=float,
+            expdecay=None | dict(eta, decay, decay_step, clip, count))
+    `wd` comes back as the Float64 value of the Float32 literal the reference writes (`1.f-6`)."""
+    refs = doc.get("_backrefs", [])
+
+    def res(x):
+        while isinstance(x, dict) and x.get("tag") == "backref":
+            x = refs[x["ref"] - 1]
+        return x
+
+    def num(v):
+        v = res(v)
+        if isinstance(v, dict) and v.get("tag") == "struct":      # boxed Float32 / Float64
+            name = res(v["type"])["name"][-1]
+            return float(np.frombuffer(v["data"], dtype=_DT[name])[0])
+        if isinstance(v, (int, float)):
+            return v
+        raise TypeError(type(v))
+
+    def arr(x):
+        x = res(x)
+        name = res(x["type"])["name"][-1]
+        return np.frombuffer(x["data"], dtype=_DT[name]).astype(np.float64)
+
+    def tname(x):
+        return res(res(x)["type"])["name"][-1]
+
+    def iddict_first_value(x):          # IdDict{Any,Any}: data = [[keys...], [values...]] with one entry (the vector p)
+        return res(res(x)["data"][1][0])
+
+    out = dict(adam=None, wd=0.0, expdecay=None)
+
+    def walk(o):
+        o = res(o)
+        t = tname(o)
+        f = o["data"]
+        if t == "Optimiser":
+            for member in res(f[0]):
+                walk(member)
+        elif t == "ExpDecay":           # ExpDecay(eta, decay, step, clip, current::IdDict)
+            out["expdecay"] = dict(eta=num(f[0]), decay=num(f[1]), decay_step=int(num(f[2])), clip=num(f[3]),
+                                   count=int(num(iddict_first_value(f[4]))))
+        elif t == "ADAM":               # ADAM(eta, beta::Tuple, state::IdDict)
+            b = res(f[1])["data"]
+            st = iddict_first_value(f[2])["data"]
+            bp = res(st[2])["data"]
+            out["adam"] = dict(eta=num(f[0]), beta1=num(b[0]), beta2=num(b[1]), m=arr(st[0]), v=arr(st[1]),
+                               beta1_pow=num(bp[0]), beta2_pow=num(bp[1]))
+        elif t == "WeightDecay":
+            out["wd"] = num(f[0])
+        else:
+            raise TypeError(t)
+
+    walk(doc["opt"])
+    if out["adam"] is None:
+        raise TypeError("no ADAM member")
+    return out
+
+
+def flux_opt_state(opt, n_params):
+    """The decoded Flux state in the library's layout (include/crnn_hip.h crnn_opt_state_len):
+    [m(P) | v(P) | beta1^t, beta2^t | ExpDecay eta, number of updates]."""
+    a, e = opt["adam"], opt["expdecay"]
+    if a["m"].size != n_params or a["v"].size != n_params:
+        raise ValueError("optimiser state does not belong to p")
+    tail = [a["beta1_pow"], a["beta2_pow"], e["eta"] if e else 0.0, float(e["count"]) if e else 0.0]   # as crnn_opt_init leaves them
+    return np.concatenate([a["m"], a["v"], np.array(tail)])
 
 
 def save_checkpoint(path, **entries):

@@ -125,11 +125,15 @@ function p2vec_jac(prob::Problem, p::Vector{Float64})
                 c.param_map, c.ns, c.nr, p, th, dth))
     return th, dth
 end
-function p2vec(prob::Problem, p)
+"""theta = [vec(w_in); w_b; vec(w_out)] (column-major, as the library packs it) -> the three arrays `p2vec` returns."""
+function split_theta(prob::Problem, th::AbstractVector)
     c = prob.cfg; n = c.ns + (c.rhs_kind == 1 ? 2 : c.has_temp)   # feature rows of w_in
-    th, _ = p2vec_jac(prob, p)
     return reshape(th[1:n*c.nr], n, c.nr), th[n*c.nr+1:(n+1)*c.nr], reshape(th[(n+1)*c.nr+1:end], c.ns, c.nr)
 end
+p2vec(prob::Problem, p::AbstractVector{<:AbstractFloat}) = split_theta(prob, p2vec_jac(prob, collect(Float64, p))[1])
+# A number type that carries derivatives (ForwardDiff.Dual when `ForwardDiff.gradient` differentiates through a CPU solve of
+# `crnn!`) needs its own method: theta(value.(p)) from the library and d theta / d p (p2vec_jac) pushed through the
+# partials.  julia/cpu_baseline.jl adds it for ForwardDiff.Dual; this module itself does not depend on ForwardDiff.
 
 function _solve(prob::Problem, th, dth, first, count, sample; want_pred=false)
     n = prob.cfg.ns + prob.cfg.has_temp; D = length(prob.tsteps); B = prob.B
@@ -152,8 +156,8 @@ robertson/rober_crnn.jl:113-116) with the weights `p2vec` returns -- what a Juli
 own `ODEProblem` (the CPU reference run below); the device never calls it.  `prob` supplies lb, ub, inv_R, dydt_scale."""
 function crnn!(du::AbstractVector, u::AbstractVector, p::AbstractVector, t, prob::Problem)
     c = prob.cfg; ns = Int(c.ns); nr = Int(c.nr)
-    w_in, w_b, w_out = p2vec(prob, collect(Float64, p))
-    z = copy(w_b)
+    w_in, w_b, w_out = p2vec(prob, p)                 # eltype(p) may be a Dual (p2vec above)
+    z = Vector{promote_type(eltype(w_b), eltype(u))}(w_b)
     for j in 1:nr
         for i in 1:ns
             z[j] += w_in[i, j] * log(clamp(u[i], c.lb, c.ub))
@@ -164,7 +168,7 @@ function crnn!(du::AbstractVector, u::AbstractVector, p::AbstractVector, t, prob
     for i in 1:ns
         du[i] = c.rate_scale[i] * sum(w_out[i, j] * r[j] for j in 1:nr)
     end
-    c.has_temp == 1 && (du[ns+1] = 0.0)
+    c.has_temp == 1 && (du[ns+1] = zero(eltype(du)))
     return du
 end
 

@@ -19,6 +19,15 @@ u0_list = zeros(n_exp, 7)
 u0_list[:, 1:2] .= rand(n_exp, 2) .* 2.0 .+ 0.2                  # case2/case2.jl:62-65
 u0_list[:, 7] .= rand(n_exp) .* 20.0 .+ 323.0
 
+# `ForwardDiff.gradient` pushes Duals through `crnn!`: p2vec of a Dual-valued p = the library's theta(value.(p)) with
+# d theta / d p (crnn_p2vec's Jacobian) applied to the partials -- ForwardDiff's own chain rule, clamp / abs conventions
+# included (p2vec.hpp follows them).
+function CRNNHip.p2vec(prob::CRNNHip.Problem, p::AbstractVector{D}) where {D<:ForwardDiff.Dual}
+    th, dth = CRNNHip.p2vec_jac(prob, collect(Float64, ForwardDiff.value.(p)))
+    thd = [D(th[k], sum(dth[k, m] * ForwardDiff.partials(p[m]) for m in eachindex(p))) for k in eachindex(th)]
+    return CRNNHip.split_theta(prob, thd)
+end
+
 rhs!(du, u, p, t) = CRNNHip.crnn!(du, u, p, t, prob_dev)
 prob_ref = OrdinaryDiffEq.ODEProblem(rhs!, u0_list[1, :], (tsteps[1], tsteps[end]), p)
 ens = EnsembleProblem(prob_ref; prob_func = (pr, i, _) -> remake(pr, u0 = u0_list[i, :]))

@@ -57,6 +57,9 @@ def orc():
 
 
 INV_R = float(np.float32(-1.0) / np.float32(1.98720425864083e-3))   # Float32 literal in case2.jl:113
+# ADAMW's decay is a Float32 literal too (`1.f-6` case2.jl:32, rober_crnn.jl:19; `1.f-8` case1.jl:18): the optimiser presets carry
+# these values, pinned by the reference's checkpoints (tests/test_ckpt_opt_pin.py)
+WD6, WD8 = float(np.float32(1e-6)), float(np.float32(1e-8))
 
 
 @pytest.fixture(scope="session")

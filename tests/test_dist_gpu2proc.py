@@ -42,7 +42,10 @@ def _worker(rank, world, port, mode, tape1, q):
         u0, ts, data, ys = np.array(rb["u0"]), np.array(rb["tsteps"]), np.array(rb["data"]), np.array(rb["yscale"])
         p0 = np.array(fx["rober_ckpt"]["p"])
         first, count = shard_range(u0.shape[0], rank, world)
-        kw = dict(grad_mode=1) if mode.endswith("forward") else dict(grad_mode=2, tape_steps=(tape1 if rank == 1 else 0))
+        if mode.endswith("forward") or (mode.endswith("mixed") and rank == 0):
+            kw = dict(grad_mode=1)     # "mixed": rank 0 on forward tangents (what grad_mode AUTO picks for a small LOCAL shard)
+        else:
+            kw = dict(grad_mode=2, tape_steps=(tape1 if rank == 1 else 0))
         node = NeuralODE(ODEProblem(PRESET_ROBER, ts, rate_scale=np.array(rb["dydt_scale"]), **kw))
         node.set_ensemble(u0[first:first + count], data[first:first + count], ys)      # this rank's shard only
         node.train_init(Optimiser(43, PRESET_ROBER), p0)
@@ -102,6 +105,18 @@ def test_one_rank_overflows_deferred_skip_and_replay_stay_in_lockstep():
     allo = _run("callback", 4)
     assert np.array_equal(allo[0][1], allo[1][1]) and allo[0][2] == allo[1][2] == 12
     assert np.array_equal(allo[0][1], ref[0][1])
+
+
+@pytest.mark.timeout(900)
+def test_forward_rank_replays_with_the_overflowing_adjoint_rank():
+    """the ranks need not run the same algorithm (grad_mode AUTO picks forward tangents from the LOCAL count).
+    Rank 0 on forward tangents never defers anything itself, but the summed overflow count makes its optimiser kernel skip
+    the step like rank 1's: it must look at the sticky flag and replay too, or the collectives pair up wrongly."""
+    ref = _run("callback-forward", 0)
+    mixed = _run("callback-mixed", 30)             # rank 1: adjoint, tape of 30 steps -> overflows on the full horizon
+    assert np.array_equal(mixed[0][1], mixed[1][1]), "the ranks' replicated parameters diverged"
+    assert mixed[0][2] == mixed[1][2] == 6 + 5, (mixed[0][2], mixed[1][2])
+    assert np.max(np.abs(mixed[0][1] - ref[0][1])) < 1e-9
 
 
 @pytest.mark.timeout(900)

@@ -11,7 +11,7 @@ against the ORACLE's optimiser (oracle/crnn_oracle.c: orc_opt_update) and agains
 import numpy as np
 import pytest
 
-from conftest import oracle_problem
+from conftest import WD6, WD8, oracle_problem
 
 pytestmark = pytest.mark.gpu
 
@@ -72,13 +72,13 @@ def test_training_loop_matches_oracle_chain(orc, case2_setup, rober_setup, case,
         s, preset, kind, ns, nr, P = case2_setup, PRESET_CASE2, 2, 6, 3, 25
         p0 = s["p_init"]
         node = NeuralODE(ODEProblem(preset, s["tsteps"], grad_mode=gm))
-        okw = dict(eta=0.005, wd=1e-6, expdecay=(5e-3, 0.5, 500 * 20, 1e-4))
+        okw = dict(eta=0.005, wd=WD6, expdecay=(5e-3, 0.5, 500 * 20, 1e-4))
         samples = [None] * 12
     else:
         s, preset, kind, ns, nr, P = rober_setup, PRESET_ROBER, 3, 3, 6, 43
         p0 = s["p_ckpt"]
         node = NeuralODE(ODEProblem(preset, s["tsteps"], rate_scale=s["dydt_scale"], grad_mode=gm))
-        okw = dict(eta=0.005, wd=1e-6, grad_clip_norm=10.0)
+        okw = dict(eta=0.005, wd=WD6, grad_clip_norm=10.0)
         samples = [20, 40, 22, 40, 25, 40, 40, 21, 33, 40, 28, 40]
     node.set_ensemble(s["u0"], s["data"], s["yscale"])
     node.train_init(Optimiser(P, preset), p0)
@@ -112,7 +112,7 @@ def test_training_loop_case1_tsit5_matches_oracle_chain(orc, fx):
     node.set_ensemble(u0, data, ys)
     node.train_init(Optimiser(24, PRESET_CASE1), p0)
     pb = orc.make_problem(ns=5, nr=4, lb=1e-5, ub=10.0, atol=1e-5, rtol=1e-2, yscale=ys, clamp_pred=1, maxiters=10000, solver=1)
-    oopt = orc.Optimiser(24, eta=0.001, wd=1e-8)
+    oopt = orc.Optimiser(24, eta=0.001, wd=WD8)
     po = p0.copy()
     for it in range(10):
         loss_d = node.train_step(want_loss=True)

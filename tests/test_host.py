@@ -65,7 +65,7 @@ def test_presets_carry_reference_constants():
     assert L.lib.crnn_config_preset(C.byref(cfg), 99) != 0
     o = L.OptConfig()
     L.check(L.lib.crnn_opt_preset(C.byref(o), L.PRESET_CASE2))
-    assert (o.use_expdecay, o.decay_step, o.eta, o.wd, o.ed_clip) == (1, 10000, 0.005, 1e-6, 1e-4)   # case2.jl:31-32
+    assert (o.use_expdecay, o.decay_step, o.eta, o.wd, o.ed_clip) == (1, 10000, 0.005, float(np.float32(1e-6)), 1e-4)   # case2.jl:31-32 (`1.f-6`)
     L.check(L.lib.crnn_opt_preset(C.byref(o), L.PRESET_ROBER))
     assert o.grad_clip_norm == 10.0 and o.use_expdecay == 0                                         # rober:19,29
 
@@ -100,13 +100,15 @@ def test_host_p2vec_checkpoint_golden(fx):
 
 
 def test_host_optimiser_matches_golden_trace_and_oracle(orc, fx):
-    from crnn_amd import Optimiser, PRESET_CASE1, PRESET_ROBER
+    from crnn_amd import Optimiser
     o = fx["optim"]
     g = np.array(o["grads"]); p0 = np.array(o["p0"])
     cases_ = (("case2", Optimiser(25, eta=0.005, wd=1e-6, expdecay=(5e-3, 0.5, 5, 1e-4)),
                orc.Optimiser(25, eta=0.005, wd=1e-6, expdecay=(5e-3, 0.5, 5, 1e-4))),
-              ("rober", Optimiser(25, PRESET_ROBER), orc.Optimiser(25, eta=0.005, wd=1e-6, grad_clip_norm=10.0)),
-              ("case1", Optimiser(25, PRESET_CASE1), orc.Optimiser(25, eta=0.001, wd=1e-8)))
+              # (the trace was formed with the Float64 decays 1e-6 / 1e-8; the presets carry the reference's Float32 literals
+              #  `1.f-6` / `1.f-8` -- tests/test_ckpt_opt_pin.py -- so the chains are spelled out here)
+              ("rober", Optimiser(25, eta=0.005, wd=1e-6, grad_clip_norm=10.0), orc.Optimiser(25, eta=0.005, wd=1e-6, grad_clip_norm=10.0)),
+              ("case1", Optimiser(25, eta=0.001, wd=1e-8), orc.Optimiser(25, eta=0.001, wd=1e-8)))
     for key, opt, oopt in cases_:
         p = p0.copy(); po = p0.copy()
         for i in range(g.shape[0]):

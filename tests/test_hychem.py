@@ -192,7 +192,7 @@ def test_hychem_preset_constants():
     assert L.lib.crnn_config_n_theta(C.byref(cfg)) == 210 and L.lib.crnn_n_params(L.PMAP_HYCHEM, 9, 10) == 211              # :73
     o = L.OptConfig()
     L.check(L.lib.crnn_opt_preset(C.byref(o), L.PRESET_HYCHEM))
-    assert (o.eta, o.wd, o.grad_clip_norm) == (0.005, 1e-6, 10.0)                                                            # :20,24
+    assert (o.eta, o.wd, o.grad_clip_norm) == (0.005, float(np.float32(1e-6)), 10.0)                                                            # :20,24
 
 
 # ------------------------------------------------------------------ GPU
