@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Cross-build bit-identity check of the gradient kernels.
+
+A kernel whose results move when the optimisation level, an unrelated macro or a printf changes has undefined behaviour
+somewhere (an uninitialised value read on a divergent path, an out-of-range LDS / tape index on an inactive lane, a
+convergent operation after a divergent loop tail) -- or sits on a miscompile.  The library is compiled with
+`-ffp-contract=on` (crnn_amd/csrc/Makefile): a*b+c is fused where the SOURCE says so (one expression / an explicit fma),
+never across statements at the optimiser's discretion, so correct code gives the same bits at every optimisation level.
+This tool builds the library several ways and asserts exactly that:
+
+    python tools/crossbuild.py build           # here or on the GPU box: crnn_amd/csrc/dbg/libcrnn_xb_<variant>.so
+    python tools/crossbuild.py run [--json f]  # GPU: every problem through every build, all outputs compared bit for bit
+    python tools/crossbuild.py worker          # (internal: one build, prints digests)
+
+Variants: O3 (the shipped flags), O2, O1, O3 + -DCRNN_ADJ_PROF (phase timers in the adjoint kernels: different register
+allocation and schedule, same arithmetic).  Problems: the AutoTsit5(Rosenbrock23) composite on robertson (switches
+algorithm mid-run), Tsit5 adjoint on case1 and on case2, Rosenbrock23 adjoint on case2 (headline kernel) and robertson,
+forward tangents on case2 -- per-trajectory losses, return codes, saved counts, accepted / rejected steps and the batch
+gradient in index order (crnn_ctx_set_queue_order(INDEX): the batch sum is then a function of the inputs alone).
+tests/test_gpu_crossbuild.py runs `run` on every GPU session.
+"""
+import argparse
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "crnn_amd", "csrc")
+DBG = os.path.join(CSRC, "dbg")
+VARIANTS = {"O3": "-O3", "O2": "-O2", "O1": "-O1", "O3prof": "-O3 -DCRNN_ADJ_PROF"}
+BASE = "-std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on -Wno-unused-result"
+LINK = "-shared -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib"
+
+
+def lib_path(name):
+    return os.path.join(DBG, f"libcrnn_xb_{name}.so")
+
+
+def source_hash():
+    h = hashlib.sha256()
+    for f in sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))):
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "crnn_hip.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def build(names=None, force=False):
+    """Builds the variants (in parallel) unless a build of the current sources is already there."""
+    os.makedirs(DBG, exist_ok=True)
+    want = source_hash()
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    procs = []
+    for name in (names or VARIANTS):
+        out, side = lib_path(name), lib_path(name) + ".srchash"
+        if not force and os.path.exists(out) and os.path.exists(side) and open(side).read().strip() == want:
+            continue
+        cmd = f"{hipcc} {VARIANTS[name]} {BASE} -DCRNN_SRC_HASH='\"{want}\"' -o {out} {CSRC}/crnn_capi.hip {LINK} && echo {want} > {side}"
+        procs.append((name, subprocess.Popen(cmd, shell=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for name, pr in procs:
+        out = pr.communicate()[0]
+        if pr.returncode != 0:
+            raise RuntimeError(f"build of variant {name} failed:\n{out[-4000:]}")
+    return [lib_path(n) for n in (names or VARIANTS)]
+
+
+# ------------------------------------------------------------------------------------------------------------ worker
+def _problems():
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE1, PRESET_CASE2, PRESET_ROBER, cases
+    from crnn_amd import _lib as L
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fixtures.json")))
+    rng = np.random.Generator(np.random.PCG64([77, 1]))
+    out = []
+
+    def case2(B):
+        ts = cases.case2_tsteps()
+        u0 = cases.case2_u0(B, rng)
+        data = np.abs(rng.standard_normal((B, 6, len(ts)))) * 0.5
+        return ts, u0, data, cases.max_min(data, lb=1e-6), np.array(fx["case2_ckpt"]["p"])
+
+    def rober(B):
+        ts = cases.rober_tsteps()
+        u0 = cases.rober_u0(B, rng)
+        ys = np.array(fx["robertson"]["yscale"])
+        data = np.abs(rng.standard_normal((B, 3, len(ts)))) * ys[None, :, None]
+        return ts, u0, data, ys, np.array(fx["rober_ckpt"]["p"])
+
+    def case1(B):
+        ts = cases.case1_tsteps()
+        u0 = cases.case1_u0(B, rng)
+        data = np.abs(rng.standard_normal((B, 5, len(ts)))) * 0.5
+        return ts, u0, data, cases.max_min(data, lb=1e-5), np.array(fx["case1"]["p"])
+
+    B = 1024 + 37    # ragged: the last wavefront is partly empty
+    c2, rb, c1 = case2(B), rober(B), case1(B)
+    sc = np.array(fx["robertson"]["dydt_scale"])
+    specs = [
+        ("rober_autotsit5_adjoint", PRESET_ROBER, rb, dict(rate_scale=sc, solver=L.SOLVER_AUTOTSIT5, grad_mode=2)),
+        ("case1_tsit5_adjoint", PRESET_CASE1, c1, dict(solver=L.SOLVER_TSIT5, grad_mode=2)),
+        ("case1_autotsit5_adjoint", PRESET_CASE1, c1, dict(solver=L.SOLVER_AUTOTSIT5, grad_mode=2)),
+        ("case2_tsit5_adjoint", PRESET_CASE2, c2, dict(solver=L.SOLVER_TSIT5, grad_mode=2)),
+        ("case2_ros23_adjoint", PRESET_CASE2, c2, dict(grad_mode=2)),
+        ("rober_ros23_adjoint", PRESET_ROBER, rb, dict(rate_scale=sc, grad_mode=2)),
+        ("case2_ros23_forward", PRESET_CASE2, c2, dict(grad_mode=1)),
+    ]
+    for name, preset, (ts, u0, data, ys, p), kw in specs:
+        node = NeuralODE(ODEProblem(preset, ts, **kw))
+        node.set_queue_order(L.QUEUE_INDEX)
+        node.set_ensemble(u0, data, ys)
+        out.append((name, node, p))
+    return out
+
+
+def worker():
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from crnn_amd.api import p2vec_jac
+    res = {}
+    for name, node, p in _problems():
+        th, dth = p2vec_jac(node.pmap, node.ns, node.nr, p)
+        _, loss, grad, ret, nsv = node._solve(node._ctx, node.B, th, dth, 0, node.B, None, False)
+        na, nr = node.step_counts()
+        h = hashlib.sha256()
+        for a in (loss, grad, ret, nsv, na, nr):
+            h.update(np.ascontiguousarray(a).tobytes())
+        res[name] = dict(digest=h.hexdigest()[:24], loss_sum=float(loss.sum()).hex(), grad0=float(grad[0]).hex(),
+                         gnorm=float(np.linalg.norm(grad)).hex(), n_accept=int(na.sum()), n_reject=int(nr.sum()),
+                         n_fail=int((ret != 0).sum()), loss=[float(x).hex() for x in loss[:8]])
+        node.close()
+    print("XBRESULT " + json.dumps(res))
+
+
+def run(json_out=None, names=None, timeout=900):
+    libs = build(names)
+    results = {}
+    for name, lib in zip(names or VARIANTS, libs):
+        env = dict(os.environ, CRNN_HIP_LIB=lib)
+        pr = subprocess.run([sys.executable, os.path.abspath(__file__), "worker"], env=env, capture_output=True, text=True, timeout=timeout)
+        line = [l for l in pr.stdout.splitlines() if l.startswith("XBRESULT ")]
+        if pr.returncode != 0 or not line:
+            results[name] = dict(error=f"rc {pr.returncode}", tail=(pr.stdout + pr.stderr)[-1500:])
+        else:
+            results[name] = json.loads(line[0][len("XBRESULT "):])
+    ref_name = next(iter(results))
+    ref = results[ref_name]
+    mismatches = []
+    for name, r in results.items():
+        if "error" in r:
+            mismatches.append((name, "*", r["error"], r.get("tail", "")))
+            continue
+        for prob, v in r.items():
+            if "error" in ref or v["digest"] != ref[prob]["digest"]:
+                mismatches.append((name, prob, v, ref.get(prob)))
+    if json_out:
+        with open(json_out, "w") as f:
+            json.dump(dict(source=source_hash(), variants={k: VARIANTS[k] for k in results}, results=results,
+                           identical=not mismatches), f, indent=1)
+    return results, mismatches
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("cmd", choices=["build", "run", "worker"])
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--variants", default=None, help="comma-separated subset of " + ",".join(VARIANTS))
+    ap.add_argument("--force", action="store_true")
+    a = ap.parse_args()
+    names = a.variants.split(",") if a.variants else None
+    if a.cmd == "build":
+        print("\n".join(build(names, a.force)))
+    elif a.cmd == "worker":
+        worker()
+    else:
+        results, mism = run(a.json, names)
+        for name, r in results.items():
+            if "error" in r:
+                print(f"{name:8s} ERROR {r['error']}\n{r.get('tail', '')}")
+                continue
+            for prob, v in r.items():
+                print(f"{name:8s} {prob:28s} {v['digest']} acc {v['n_accept']} rej {v['n_reject']} fail {v['n_fail']} loss_sum {float.fromhex(v['loss_sum']):.17g}")
+        print("IDENTICAL" if not mism else f"MISMATCH: {[(m[0], m[1]) for m in mism]}")
+        sys.exit(1 if mism else 0)
