@@ -74,6 +74,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_voi
 SYMBOLS = {
     "crnn_abi_version": (C.c_int32, []),
     "crnn_build_info": (C.c_char_p, []),
+    "crnn_debug_bounds": (C.c_int32, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "crnn_sizeof": (C.c_int32, [C.c_int32]),
     "crnn_last_error": (C.c_char_p, [_CTX]),
     "crnn_config_preset": (C.c_int32, [C.POINTER(Config), C.c_int32]),

@@ -25,6 +25,17 @@
 // on Tsit5 for ever, so HAS_T shapes are instantiated with COMPOSITE = false.  The PI exponents follow the running
 // algorithm (beta1 = 7/(10 order), beta2 = 2/(5 order)); gamma, qmin, qmax, the steady band and qold are shared.
 #pragma once
+#ifndef CRNN_AUTO_THETA_LDS
+#define CRNN_AUTO_THETA_LDS 3   // where theta lives: see the kernel preamble (3 measured fastest AND leanest, round 3)
+#endif
+#ifndef CRNN_AUTO_FENCES
+#define CRNN_AUTO_FENCES 0
+#endif
+#if CRNN_AUTO_FENCES
+#define CRNN_AUTO_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define CRNN_AUTO_FENCE() ((void)0)
+#endif
 #include "ros23_adj_kernel.hpp"
 #include "tsit5_kernel.hpp"
 
@@ -56,7 +67,26 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
     for (int idx = tid; idx < prm.n_save; idx += BLOCK) ts_lds[idx] = prm.tsave[idx];
     __syncthreads();
     const KConst *kc = reinterpret_cast<const KConst *>(kc_lds);
+    // Where theta lives (CRNN_AUTO_THETA_LDS):
+    //   0  wave-uniform scalar loads, hoisted by the compiler: theta sits in ~88 SGPRs for the whole kernel
+    //   1  LDS, broadcast ds_read, hoisted: theta sits in VGPRs / AGPRs for the whole kernel
+    //   2  LDS, read afresh by every right-hand-side evaluation / adjoint contraction / Rosenbrock23 body (pointer with
+    //      an opaque zero offset: the loads cannot be hoisted out of the step loops)
+    //   3  scalar loads re-issued per phase the same way (a handful of s_load_dwordx16 per evaluation, issued ahead of the
+    //      logarithms that precede theta's first use)
+#if CRNN_AUTO_THETA_LDS == 1 || CRNN_AUTO_THETA_LDS == 2
+    __shared__ double th_lds[NTH];
+    for (int idx = tid; idx < NTH; idx += BLOCK) th_lds[idx] = theta[idx];
+    __syncthreads();
+    const double *th = th_lds;
+#define CRNN_TH_FRESH() (CRNN_AUTO_THETA_LDS == 2 ? th_lds + opaque_zero() : th)
+#elif CRNN_AUTO_THETA_LDS == 3
+    const double *th = theta;
+#define CRNN_TH_FRESH() (theta + opaque_zero_s())
+#else
     const double *__restrict__ th = theta;
+#define CRNN_TH_FRESH() th
+#endif
     double *const thb_s = thb_lds + tid;
 #if CRNN_ADJ_THB_ATOMIC
 #define THB_ADD(m, val) unsafeAtomicAdd(&thb_s[(m) * BLOCK], (val))
@@ -92,19 +122,22 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
         const bool valid = traj < prm.count;
         // queue order by last known step counts for ensembles larger than the resident lanes (sort_steps_kernel)
         const int64_t b = prm.first + (valid ? (adj.perm ? (int64_t)adj.perm[traj] : traj) : 0);
+        CRNN_CHK(b >= 0 && b < prm.B && traj >= 0, 1);
 
         double bT[NR];
         double xT = 0.0, Tconst = 0.0;
         auto eval_point = [&](const double (&uu)[NS], double (&x)[NS], double (&g)[NS], double (&r)[NR], double (&f)[NS]) {
+            const double *tq = CRNN_TH_FRESH();
             features<NS>(uu, kc->lb, kc->ub, x, g);
-            rates<NS, NR, HAS_T>(th, x, bT, r);
-            rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r, kc->scale, f);
+            rates<NS, NR, HAS_T>(tq, x, bT, r);
+            rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(tq, r, kc->scale, f);
         };
         auto write_pred = [&](int j, const double (&v)[NS]) {
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
                 double w = v[i];
                 if (prm.clamp_pred) w = clampv(w, -kc->ub, kc->ub);
+                CRNN_CHK((int64_t)j * prm.n_obs < prm.row_stride && j >= 0, 9);
                 prm.pred[((size_t)j * N + i) * prm.B + b] = w;
             }
             if (HAS_T) {
@@ -202,6 +235,7 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                             atomicAdd(adj.overflow, 1u);
                             return false;
                         }
+                        CRNN_CHK(nacc >= 0 && nacc < adj.tape_cap, 5);
                         double *rec = tape + (size_t)nacc * RECW;
                         rec[0] = t;
                         rec[1] = dt_signed;
@@ -217,6 +251,7 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                         for (int i = 0; i < NS; ++i) k[0][i] = f0[i];
 #pragma unroll
                         for (int s = 1; s < 7; ++s) {
+                            CRNN_AUTO_FENCE();
                             double g[NS];
 #pragma unroll
                             for (int i = 0; i < NS; ++i) {
@@ -270,6 +305,7 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                             if (record(-dt)) {
                                 accepted = true;
                                 while (jsave < nsave) {
+                                    CRNN_CHK(jsave >= 0 && jsave < nsave, 6);
                                     const double ts = ts_lds[jsave];
                                     if (!(ts <= tnew)) break;
                                     if (prm.pred) {
@@ -295,6 +331,7 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                     } else if (COMPOSITE) {
                         // ---------------------------------------------------------------- Rosenbrock23 attempt
                         Solver W;
+                        const double *tr = CRNN_TH_FRESH();
                         const double gam = d_ * dt;
                         double gr0[NR];
 #pragma unroll
@@ -308,7 +345,7 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                                 for (int c = 0; c < NS; ++c) {
                                     double a = 0.0;
 #pragma unroll
-                                    for (int j = 0; j < NR; ++j) a = fma(th[L_::wo(i, j)] * r0[j], th[L_::wi(c, j)], a);
+                                    for (int j = 0; j < NR; ++j) a = fma(tr[L_::wo(i, j)] * r0[j], tr[L_::wi(c, j)], a);
                                     row += fabs(a * g0[c]);
                                 }
                                 est = fmax(est, USE_SCALE ? row * fabs(kc->scale[i]) : row);
@@ -317,10 +354,10 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                             have_eig = true;
                         }
                         double k1[NS], dk[NS], f1[NS];
-                        const bool okf = W.factor(th, g0, r0, gam, kc->scale);
+                        const bool okf = W.factor(tr, g0, r0, gam, kc->scale);
 #pragma unroll
                         for (int i = 0; i < NS; ++i) k1[i] = f0[i];
-                        W.solve(th, g0, gr0, kc->scale, k1);
+                        W.solve(tr, g0, gr0, kc->scale, k1);
                         {
                             double u1[NS], x1[NS], g1[NS], r1[NR];
 #pragma unroll
@@ -329,7 +366,7 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                         }
 #pragma unroll
                         for (int i = 0; i < NS; ++i) dk[i] = f1[i] - k1[i];
-                        W.solve(th, g0, gr0, kc->scale, dk);
+                        W.solve(tr, g0, gr0, kc->scale, dk);
 #pragma unroll
                         for (int i = 0; i < NS; ++i) unew[i] = fma(dt, k1[i] + dk[i], u[i]);
                         {
@@ -342,7 +379,7 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                             const double k2i = k1[i] + dk[i];
                             k3[i] = f2[i] - c32 * (k2i - f1[i]) - 2.0 * (k1[i] - f0[i]);
                         }
-                        W.solve(th, g0, gr0, kc->scale, k3);
+                        W.solve(tr, g0, gr0, kc->scale, k3);
                         finite = okf;
 #pragma unroll
                         for (int i = 0; i < NS; ++i) {
@@ -359,6 +396,7 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                             if (record(dt)) {
                                 accepted = true;
                                 while (jsave < nsave) {
+                                    CRNN_CHK(jsave >= 0 && jsave < nsave, 6);
                                     const double ts = ts_lds[jsave];
                                     if (!(ts <= tnew)) break;
                                     if (prm.pred) {
@@ -418,6 +456,7 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
 #pragma unroll
         for (int i = 0; i < NS; ++i) { const int dr = (int)kc->drow[i]; doff[i] = dr >= 0 ? dr : 0; }
         auto load_row = [&](int j, double (&d)[NS]) {
+            CRNN_CHK((int64_t)(j > 0 ? j : 0) * prm.n_obs < prm.row_stride, 2);
             const double *row = drows + (size_t)(j > 0 ? j : 0) * prm.n_obs;
 #pragma unroll
             for (int i = 0; i < NS; ++i) d[i] = row[doff[i]];
@@ -444,17 +483,18 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
         auto vjp_core = [&](const double (&g)[NS], const double (&r)[NR], const double (&kb)[NS], double (&gb)[NS],
                             double (&rho)[NR], double (&vs)[NS]) {
             double um[NS];
+            const double *tq = CRNN_TH_FRESH();
 #pragma unroll
             for (int i = 0; i < NS; ++i) { vs[i] = USE_SCALE ? kb[i] * kc->scale[i] : kb[i]; um[i] = 0.0; }
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
                 double a = 0.0;
 #pragma unroll
-                for (int i = 0; i < NS; ++i) a = fma(vs[i], th[L_::wo(i, j)], a);
+                for (int i = 0; i < NS; ++i) a = fma(vs[i], tq[L_::wo(i, j)], a);
                 rho[j] = a * r[j];
                 wbb[j] += rho[j];
 #pragma unroll
-                for (int c = 0; c < NS; ++c) um[c] = fma(rho[j], th[L_::wi(c, j)], um[c]);
+                for (int c = 0; c < NS; ++c) um[c] = fma(rho[j], tq[L_::wi(c, j)], um[c]);
             }
 #pragma unroll
             for (int c = 0; c < NS; ++c) gb[c] = um[c] * g[c];
@@ -479,8 +519,13 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
             }
         };
 
+        // the times of the next two save points (backwards) sit in registers: the test "is it inside this step" and the seed
+        // itself do not wait for LDS (ros23_adj_kernel.hpp)
+        double ts_cur = (jsave - 1 >= jlo) ? ts_lds[jsave - 1] : -INFINITY;   // none left: -inf, never inside a step
+        double ts_nxt = (jsave - 2 >= jlo) ? ts_lds[jsave - 2] : -INFINITY;
         double rt = 0.0, rdt = 0.0, ru[NS];   // tape record s, prefetched
         {
+            CRNN_CHK(s < adj.tape_cap, 3);
             const double *rec = tape + (size_t)(s > 0 ? s : 0) * RECW;
             rt = rec[0]; rdt = rec[1];
 #pragma unroll
@@ -500,12 +545,21 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                 load_row(jsave - 2, dB);
                 load_row(jsave - 3, dC);
                 {   // prefetch the next record (s-1)
+                    CRNN_CHK(s - 1 < adj.tape_cap, 7);
                     const double *rec = tape + (size_t)(s > 0 ? s - 1 : 0) * RECW;
                     rt = rec[0]; rdt = rec[1];
 #pragma unroll
                     for (int i = 0; i < NS; ++i) ru[i] = rec[2 + i];
                 }
-                auto in_step = [&]() -> bool { return jsave > jlo && ts_lds[jsave - 1] > tn; };
+                auto in_step = [&]() -> bool { return ts_cur > tn; };
+                const double inv_h = frcp(h);      // one reciprocal per step instead of a division per save point
+                auto next_ts = [&]() -> double {   // consumes save point jsave-1 (the caller decrements jsave afterwards)
+                    const double ts = ts_cur;
+                    CRNN_CHK(jsave - 1 >= jlo && jsave - 1 < nsave, 8);
+                    ts_cur = ts_nxt;
+                    ts_nxt = (jsave - 3 >= jlo) ? ts_lds[jsave - 3] : -INFINITY;
+                    return ts;
+                };
 
                 if (is_ts) {
                     // ------------------------------------------------------------ Tsit5 step: re-form the stages
@@ -521,6 +575,7 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                     }
 #pragma unroll
                     for (int st = 1; st < 7; ++st) {
+                        CRNN_AUTO_FENCE();
                         double gp[NS];
 #pragma unroll
                         for (int i = 0; i < NS; ++i) {
@@ -549,10 +604,10 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                         kb[6][i] = 0.0;
                     }
                     auto seed_point = [&](const double (&dobs)[NS]) {
-                        const double ts = ts_lds[jsave - 1];
+                        const double ts = next_ts();
                         const bool at_end = (ts == tnew);
                         double bth[7];
-                        Ts5::dense(at_end ? 1.0 : (ts - tn) / h, bth);
+                        Ts5::dense(at_end ? 1.0 : (ts - tn) * inv_h, bth);
 #pragma unroll
                         for (int i = 0; i < NS; ++i) {
                             const int dr = (int)kc->drow[i];
@@ -593,6 +648,7 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                     double rho_p[NR], vs_p[NS], x_p[NS], r_p[NR];   // the stage whose theta terms are still to be added
 #pragma unroll
                     for (int st = 6; st >= 0; --st) {
+                        CRNN_AUTO_FENCE();
                         double gb[NS], rho[NR], vs[NS];
                         double xl[NS], gl[NS], rl[NR];
                         if constexpr (!kKeepStages) {
@@ -629,17 +685,18 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                 } else if (COMPOSITE) {
                     // ------------------------------------------------------------ Rosenbrock23 step (ros23_adj_kernel.hpp)
                     double x0[NS], gg0[NS], rr0[NR], ff0[NS];
+                    const double *tr = CRNN_TH_FRESH();
                     Solver W;
                     const double gam = d_ * h;
                     double gr0[NR], x1[NS], g1[NS], r1[NR];
                     eval_point(un, x0, gg0, rr0, ff0);
 #pragma unroll
                     for (int j = 0; j < NR; ++j) gr0[j] = gam * rr0[j];
-                    (void)W.factor(th, gg0, rr0, gam, kc->scale);
+                    (void)W.factor(tr, gg0, rr0, gam, kc->scale);
                     double k1[NS], dk[NS];
 #pragma unroll
                     for (int i = 0; i < NS; ++i) k1[i] = ff0[i];
-                    W.solve(th, gg0, gr0, kc->scale, k1);
+                    W.solve(tr, gg0, gr0, kc->scale, k1);
                     {
                         double u1[NS], f1[NS];
 #pragma unroll
@@ -648,15 +705,15 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
 #pragma unroll
                         for (int i = 0; i < NS; ++i) dk[i] = f1[i] - k1[i];
                     }
-                    W.solve(th, gg0, gr0, kc->scale, dk);
+                    W.solve(tr, gg0, gr0, kc->scale, dk);
 
                     double A_[NS], B1[NS], B2[NS];
 #pragma unroll
                     for (int i = 0; i < NS; ++i) { A_[i] = 0.0; B1[i] = 0.0; B2[i] = 0.0; }
                     auto seed_point = [&](const double (&dobs)[NS]) {
-                        const double ts = ts_lds[jsave - 1];
+                        const double ts = next_ts();
                         const bool at_end = (ts == tnew);
-                        const double Th = at_end ? 1.0 : (ts - tn) / h;
+                        const double Th = at_end ? 1.0 : (ts - tn) * inv_h;
                         const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
                         const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d_) * inv12d;
 #pragma unroll
@@ -693,7 +750,7 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                     for (int i = 0; i < NS; ++i) { v[i] = fma(h, lam[i], B2[i]); ub[i] = lam[i] + A_[i]; }
 #pragma unroll
                     for (int i = 0; i < NS; ++i) kb1[i] = B1[i] + v[i];
-                    solve_T<NS, NR, HAS_T, USE_SCALE>(W, th, gg0, gr0, kc->scale, v);        // v = W^-T kb2
+                    solve_T<NS, NR, HAS_T, USE_SCALE>(W, tr, gg0, gr0, kc->scale, v);        // v = W^-T kb2
 #pragma unroll
                     for (int i = 0; i < NS; ++i) kb1[i] -= v[i];
                     double vs[NS];
@@ -704,7 +761,7 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                     for (int j = 0; j < NR; ++j) {
                         double a = 0.0;
 #pragma unroll
-                        for (int i = 0; i < NS; ++i) a = fma(vs[i], th[L_::wo(i, j)], a);
+                        for (int i = 0; i < NS; ++i) a = fma(vs[i], tr[L_::wo(i, j)], a);
                         av[j] = a;
                     }
                     double rho1[NR], vs_dump[NS];   // the u_mid point's theta terms are folded into the u_n point's addends
@@ -717,7 +774,7 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                             kb1[c] = fma(0.5 * h, gb[c], kb1[c]);
                         }
                     }
-                    solve_T<NS, NR, HAS_T, USE_SCALE>(W, th, gg0, gr0, kc->scale, kb1);      // kb1 = w = W^-T kb1
+                    solve_T<NS, NR, HAS_T, USE_SCALE>(W, tr, gg0, gr0, kc->scale, kb1);      // kb1 = w = W^-T kb1
                     {   // point u_n: d/d(u, theta) [ w.f + gam (v.J dk + w.J k1) ]
                         double ws[NS];
 #pragma unroll
@@ -729,10 +786,10 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                         for (int j = 0; j < NR; ++j) {
                             double aw = 0.0, q1 = 0.0, qd = 0.0;
 #pragma unroll
-                            for (int i = 0; i < NS; ++i) aw = fma(ws[i], th[L_::wo(i, j)], aw);
+                            for (int i = 0; i < NS; ++i) aw = fma(ws[i], tr[L_::wo(i, j)], aw);
 #pragma unroll
                             for (int c = 0; c < NS; ++c) {
-                                const double wg = th[L_::wi(c, j)] * gg0[c];
+                                const double wg = tr[L_::wi(c, j)] * gg0[c];
                                 q1 = fma(wg, k1[c], q1);
                                 qd = fma(wg, dk[c], qd);
                             }
@@ -746,7 +803,7 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
                             for (int c = 0; c < NS; ++c) {
                                 const double m = fma(pv, dk[c], gpw * k1[c]);
                                 THB_ADD(L_::wi(c, j), fma(rho1[j], x1[c], fma(beta, x0[c], gg0[c] * m)));
-                                const double wi = th[L_::wi(c, j)];
+                                const double wi = tr[L_::wi(c, j)];
                                 s1[c] = fma(beta, wi, s1[c]);
                                 s2[c] = fma(wi, m, s2[c]);
                             }
@@ -807,6 +864,7 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            CRNN_CHK((wave_base >> 6) < ((prm.count + 63) >> 6), 4);
             double *prow = adj.batch_partials + (size_t)(wave_base >> 6) * (NTH + kExtra);
             const int w0 = tid & ~63;
             if (lane < NTH + kExtra) {
@@ -819,6 +877,7 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
         }
     }
 #undef THB_ADD
+#undef CRNN_TH_FRESH
 }
 
 }  // namespace crnn

@@ -925,6 +925,22 @@ int32_t crnn_abi_version(void) { return CRNN_ABI_VERSION; }
 // check that the loaded binary was built from the sources next to it (crnn_amd/_lib.py does, and rebuilds otherwise).
 const char *crnn_build_info(void) { return "src=" CRNN_SRC_HASH " arch=gfx950"; }
 
+int32_t crnn_debug_bounds(uint32_t *violations, uint32_t *first_site) {
+#ifdef CRNN_BOUNDS_CHECK
+    unsigned int v[2] = {0u, 0u}, zero[2] = {0u, 0u};
+    if (hipDeviceSynchronize() != hipSuccess) return fail(nullptr, "crnn_debug_bounds: hipDeviceSynchronize failed (a kernel faulted?)");
+    if (hipMemcpyFromSymbol(v, HIP_SYMBOL(crnn::g_bounds), sizeof(v)) != hipSuccess ||
+        hipMemcpyToSymbol(HIP_SYMBOL(crnn::g_bounds), zero, sizeof(zero)) != hipSuccess)
+        return fail(nullptr, "crnn_debug_bounds: cannot read the violation counters");
+    if (violations) *violations = v[0];
+    if (first_site) *first_site = v[1];
+    return 0;
+#else
+    (void)violations; (void)first_site;
+    return -1;
+#endif
+}
+
 int32_t crnn_sizeof(int32_t which) {
     switch (which) {
     case 0: return (int32_t)sizeof(crnn_config);

@@ -69,6 +69,17 @@
 
 namespace crnn {
 
+// Bounds-checked build (-DCRNN_BOUNDS_CHECK; tools/crossbuild.py variant "O3chk"): every indexed access of the adjoint kernels
+// -- tape records, save times in LDS, observed rows, u0 / pred / per-trajectory outputs, the queue permutation, the batch
+// partial rows -- is checked against its extent on the lanes that perform it; violations are counted in g_bounds[0], the site
+// code of the first one is kept in g_bounds[1] (crnn_debug_bounds reads the pair).  Release builds compile the checks away.
+#ifdef CRNN_BOUNDS_CHECK
+__device__ unsigned int g_bounds[2];
+#define CRNN_CHK(cond, code) do { if (!(cond)) { if (atomicAdd(&g_bounds[0], 1u) == 0u) g_bounds[1] = (unsigned)(code); } } while (0)
+#else
+#define CRNN_CHK(cond, code) ((void)0)
+#endif
+
 struct AdjParams {
     double *tape;                // [lanes][tape_cap][NS + 2]
     int32_t tape_cap;            // accepted steps a lane can record
@@ -109,6 +120,20 @@ __device__ __forceinline__ void lu_solve_T(const double (&A)[NS][NS], const doub
             }
         }
     }
+}
+
+// an integer zero the optimiser cannot see through (no instruction): `ptr + opaque_zero()` re-derives an LDS pointer so that
+// loads through it are neither hoisted out of loops nor merged with earlier ones
+__device__ __forceinline__ int opaque_zero() {
+    int z = 0;
+    asm volatile("" : "+v"(z));
+    return z;
+}
+
+__device__ __forceinline__ int opaque_zero_s() {   // the same in a scalar register: the derived pointer stays wave-uniform
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    return z;
 }
 
 // b <- W^-T b for the two W representations of ros23_kernel.hpp
@@ -205,6 +230,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
         // first (sort_steps_kernel): the 64 trajectories of a batch then take nearly the same number of steps, and a
         // wavefront is busy for its batch's mean rather than for its slowest member.
         const int64_t b = prm.first + (valid ? (adj.perm ? (int64_t)adj.perm[traj] : traj) : 0);
+        CRNN_CHK(b >= 0 && b < prm.B && traj >= 0, 1);
 
         // ================================================================== forward sweep
         double u[NS], f0[NS], g0[NS], r0[NR], bT[NR];
@@ -348,6 +374,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                                 rc = 5;  // out of tape: the host re-runs the call with forward tangents
                                 atomicAdd(adj.overflow, 1u);
                             } else {
+                                CRNN_CHK(nacc >= 0 && nacc < adj.tape_cap, 5);
                                 double *rec = tape + (size_t)((CRNN_ADJ_DBG & 4) ? 0 : nacc) * RECW;
                                 rec[0] = t;
                                 rec[1] = dt;
@@ -360,6 +387,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                                 ++nacc;
                                 const double tnew = last ? tend : t + dt;
                                 while (jsave < nsave) {
+                                    CRNN_CHK(jsave >= 0 && jsave < nsave, 6);
                                     const double ts = ts_lds[jsave];
                                     if (!(ts <= tnew)) break;
                                     if (prm.pred) {
@@ -441,6 +469,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
 #pragma unroll
         for (int i = 0; i < NS; ++i) { const int dr = (int)kc->drow[i]; doff[i] = dr >= 0 ? dr : 0; }
         auto load_row = [&](int j, double (&d)[NS]) {
+            CRNN_CHK((int64_t)(j > 0 ? j : 0) * prm.n_obs < prm.row_stride, 2);
             const double *row = drows + (size_t)(j > 0 ? j : 0) * prm.n_obs;
 #pragma unroll
             for (int i = 0; i < NS; ++i) d[i] = (CRNN_ADJ_DBG & 2) ? 0.5 : row[doff[i]];
@@ -452,6 +481,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
         double rk1[NS], rdk[NS];
 #endif
         {
+            CRNN_CHK(s < adj.tape_cap, 3);
             const double *rec = tape + (size_t)(s > 0 ? s : 0) * RECW;
             rt = rec[0]; rdt = rec[1];
 #pragma unroll
@@ -496,6 +526,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                 load_row(jsave - 2, dB);
                 load_row(jsave - 3, dC);
                 {   // prefetch the next record (s-1)
+                    CRNN_CHK(s - 1 < adj.tape_cap, 7);
                     const double *rec = tape + (size_t)(s > 0 ? s - 1 : 0) * RECW;
                     rt = rec[0]; rdt = rec[1];
 #pragma unroll
@@ -560,6 +591,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                 auto in_step = [&]() -> bool { return ts_cur > tn; };
                 auto seed_point = [&](const double (&dobs)[NS]) {
                     const double ts = ts_cur;
+                    CRNN_CHK(jsave - 1 >= jlo && jsave - 1 < nsave, 8);
                     ts_cur = ts_nxt;
                     ts_nxt = (jsave - 3 >= jlo) ? ts_lds[jsave - 3] : -INFINITY;
                     const bool at_end = (ts == tnew);
@@ -743,6 +775,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            CRNN_CHK((wave_base >> 6) < ((prm.count + 63) >> 6), 4);
             double *prow = adj.batch_partials + (size_t)(wave_base >> 6) * (NTH + kExtra);
             const int w0 = tid & ~63;   // first lane of this wavefront within the block
             if (lane < NTH + kExtra) {

@@ -149,6 +149,10 @@ int32_t crnn_abi_version(void);
 /* "src=<16 hex digits> arch=gfx950": sha256 prefix of the sources (the sorted .hip and .hpp files of crnn_amd/csrc, then this header)
  * the loaded binary was compiled from -- a host can refuse (or rebuild) a stale library (crnn_amd/_lib.py does). */
 const char *crnn_build_info(void);
+/* Diagnostic builds only (-DCRNN_BOUNDS_CHECK: every indexed access of the adjoint kernels checked against its extent, see
+ * ros23_adj_kernel.hpp): number of violations since the library was loaded and the site code of the first one; resets both.
+ * A release build has no checks compiled in and returns -1 without touching the outputs. */
+int32_t crnn_debug_bounds(uint32_t *violations, uint32_t *first_site);
 /* sizeof(crnn_config) / crnn_stats / crnn_opt_config / crnn_cathode_config for which = 0 / 1 / 2 / 3: lets a binding
  * (Julia struct, ctypes.Structure) verify its mirror of the C structs at load time. */
 int32_t crnn_sizeof(int32_t which);

@@ -116,6 +116,14 @@ function last_step_counts(prob::Problem, first::Integer = 0, count::Integer = pr
     return na, nr
 end
 
+"""`(violations, first_site) = debug_bounds()`: diagnostic builds of the library (-DCRNN_BOUNDS_CHECK) count out-of-range
+accesses of the adjoint kernels; `nothing` on a release build."""
+function debug_bounds()
+    v = Ref{UInt32}(0); s = Ref{UInt32}(0)
+    rc = ccall((:crnn_debug_bounds, LIB), Int32, (Ref{UInt32}, Ref{UInt32}), v, s)
+    return rc == 0 ? (v[], s[]) : nothing
+end
+
 """`w_in, w_b, w_out = p2vec(p)` (case2/case2.jl:91-99) plus the Jacobian d theta / d p."""
 function p2vec_jac(prob::Problem, p::Vector{Float64})
     c = prob.cfg

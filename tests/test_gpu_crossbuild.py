@@ -31,4 +31,7 @@ def test_gradient_kernels_are_bit_identical_across_builds():
         # the composite really switches on robertson (Tsit5 start, Rosenbrock23 after the detector fires): it takes a small
         # multiple of Rosenbrock23's step count, not Tsit5's ~19 000 per trajectory
         assert r["rober_autotsit5_adjoint"]["n_accept"] < 4 * r["rober_ros23_adjoint"]["n_accept"]
+    chk = results["O3chk"]      # the bounds-checked build: checks compiled in, none fired, same bits as the release build
+    assert all(v["bounds_checked"] and v["bounds_violations"] == 0 for v in chk.values()), chk
+    assert not any(v["bounds_checked"] for v in results["O3"].values())
     assert not mismatches, [(m[0], m[1]) for m in mismatches]

@@ -13,7 +13,9 @@ This tool builds the library several ways and asserts exactly that:
     python tools/crossbuild.py worker          # (internal: one build, prints digests)
 
 Variants: O3 (the shipped flags), O2, O1, O3 + -DCRNN_ADJ_PROF (phase timers in the adjoint kernels: different register
-allocation and schedule, same arithmetic).  Problems: the AutoTsit5(Rosenbrock23) composite on robertson (switches
+allocation and schedule, same arithmetic), O3 + -DCRNN_BOUNDS_CHECK (every indexed access of the adjoint kernels checked
+against its extent -- the stand-in for a device address sanitizer, whose instrumented runtime this image lacks; the build
+must also report ZERO violations).  Problems: the AutoTsit5(Rosenbrock23) composite on robertson (switches
 algorithm mid-run), Tsit5 adjoint on case1 and on case2, Rosenbrock23 adjoint on case2 (headline kernel) and robertson,
 forward tangents on case2 -- per-trajectory losses, return codes, saved counts, accepted / rejected steps and the batch
 gradient in index order (crnn_ctx_set_queue_order(INDEX): the batch sum is then a function of the inputs alone).
@@ -29,7 +31,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "crnn_amd", "csrc")
 DBG = os.path.join(CSRC, "dbg")
-VARIANTS = {"O3": "-O3", "O2": "-O2", "O1": "-O1", "O3prof": "-O3 -DCRNN_ADJ_PROF"}
+VARIANTS = {"O3": "-O3", "O2": "-O2", "O1": "-O1", "O3prof": "-O3 -DCRNN_ADJ_PROF", "O3chk": "-O3 -DCRNN_BOUNDS_CHECK"}
 BASE = "-std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on -Wno-unused-result"
 LINK = "-shared -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib"
 
@@ -116,7 +118,9 @@ def _problems():
 
 def worker():
     import numpy as np
+    import ctypes as C
     sys.path.insert(0, ROOT)
+    from crnn_amd import _lib as L
     from crnn_amd.api import p2vec_jac
     res = {}
     for name, node, p in _problems():
@@ -126,7 +130,9 @@ def worker():
         h = hashlib.sha256()
         for a in (loss, grad, ret, nsv, na, nr):
             h.update(np.ascontiguousarray(a).tobytes())
-        res[name] = dict(digest=h.hexdigest()[:24], loss_sum=float(loss.sum()).hex(), grad0=float(grad[0]).hex(),
+        viol, site = C.c_uint32(0), C.c_uint32(0)
+        chk = L.lib.crnn_debug_bounds(C.byref(viol), C.byref(site))     # -1: no checks compiled into this build
+        res[name] = dict(digest=h.hexdigest()[:24], bounds_checked=(chk == 0), bounds_violations=int(viol.value), bounds_site=int(site.value), loss_sum=float(loss.sum()).hex(), grad0=float(grad[0]).hex(),
                          gnorm=float(np.linalg.norm(grad)).hex(), n_accept=int(na.sum()), n_reject=int(nr.sum()),
                          n_fail=int((ret != 0).sum()), loss=[float(x).hex() for x in loss[:8]])
         node.close()
@@ -152,7 +158,7 @@ def run(json_out=None, names=None, timeout=900):
             mismatches.append((name, "*", r["error"], r.get("tail", "")))
             continue
         for prob, v in r.items():
-            if "error" in ref or v["digest"] != ref[prob]["digest"]:
+            if "error" in ref or v["digest"] != ref[prob]["digest"] or v["bounds_violations"] != 0:
                 mismatches.append((name, prob, v, ref.get(prob)))
     if json_out:
         with open(json_out, "w") as f:
