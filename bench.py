@@ -11,7 +11,8 @@ already resident in HBM: solve + loss + gradient kernel (65 536 trajectories;
 --grad forward: P tangent columns on lane groups) -> fixed-order gradient
 reduction + chain rule through p2vec -> all-reduce of the (P+6)-vector over ranks
 (RCCL) -> Flux-style ExpDecay/ADAM/WeightDecay update of p on the device (the same
-kernel forms p2vec of the new p).  Weak scaling: every rank owns its own 65 536 ICs.
+kernel forms p2vec of the new p).  --scaling weak (default): every rank owns its own 65 536 ICs; --scaling strong: 65 536
+ICs in total, 65 536 / N per rank.  With N > 1 both are timed and the other one is reported under "other_scaling".
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -45,6 +46,12 @@ FLOP_COL_STEP = 2 * 441          # one tangent column through one accepted step
 FLOP_ADJ_ATTEMPT = 2 * 808       # forward sweep, one Rosenbrock23 attempt
 FLOP_ADJ_REVERSE = 2 * 719       # reverse sweep, one accepted step (re-formation 310 + adjoint 409)
 FLOP_ADJ_SAVE = 2 * 40           # loss + seeds of one save point
+# two-lanes-per-trajectory kernel (ros23_adj2_kernel<6,3,T>; tools/kisa.py): per LANE 602 / 530 / 20 such instructions per
+# attempt / reverse step / save point, two lanes per trajectory (the replicated part -- LU of the 3x3 matrix, controller,
+# exponentials -- is executed by both and counted for both)
+FLOP_ADJ2_ATTEMPT = 2 * 2 * 602
+FLOP_ADJ2_REVERSE = 2 * 2 * 530
+FLOP_ADJ2_SAVE = 2 * 2 * 20
 
 
 def usable_cores():
@@ -73,6 +80,9 @@ def parse():
                     help="time stepper; the headline metric is quoted on the Rosenbrock23-equivalent stepper")
     ap.add_argument("--grad", choices=["auto", "forward", "adjoint"], default="auto",
                     help="gradient algorithm: discrete adjoint of the accepted steps (auto) or forward tangents")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): --batch ICs PER RANK; strong: --batch ICs in total, split over the ranks.  Whichever is "
+                         "chosen, the other mode is timed too (same K, W) and reported under 'other_scaling' when N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (other configs / regimes, N = 1 only)")
     ap.add_argument("--cpu-sample", type=int, default=65536)
@@ -160,36 +170,54 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        dp.train_step()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        dp.train_step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        te = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    # Per-rank share of a step.  weak: the rank's whole resident ensemble (B ICs per rank, global batch N * B);
+    # strong: the GLOBAL batch is B -- BASELINE's "case2 batch 65k, 1/2/4/8 MI355X" read literally -- and every rank takes
+    # B / N of it (the first B / N of its resident ICs: the ranks' ensembles are drawn from the same distribution).
+    def timed(count):
+        for _ in range(args.warmup):
+            dp.train_step(0, count)
+        sync_all()
+        t0_ = time.perf_counter()
+        for _ in range(args.steps):
+            dp.train_step(0, count)
+        sync_all()
+        el = time.perf_counter() - t0_
+        if world > 1:
+            te = torch.tensor([el], device="cuda", dtype=torch.float64)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            el = float(te.item())
+        return el
+
+    count_of = {"weak": B, "strong": max(1, B // world)}
+    other = "strong" if args.scaling == "weak" else "weak"
+    other_line = None
+    if world > 1:      # the mode that is not the headline of this run, first (the kernel timings read below are the main loop's)
+        el_o = timed(count_of[other])
+        other_line = {"scaling": other, "batch_per_gpu": count_of[other], "global_batch": count_of[other] * world,
+                      "ms_per_step": el_o / args.steps * 1e3, "value": world * count_of[other] * args.steps / el_o,
+                      "unit": "trajectories+grads/s"}
+    B_rank = count_of[args.scaling]
+    elapsed = timed(B_rank)
 
     # ---- per-launch kernel durations over the timed region (HIP events on the ctx stream) ----
     nk = min(args.steps, 64)
     kms = np.zeros(nk)
     check(lib.crnn_kernel_times(node.handle, dptr(kms), nk), node.handle)
     st = node.stats()          # last step: n_traj, n_ok, n_accept, n_reject
+    lanes_used = node.last_lanes_per_traj() if adjoint and ros else 0
     p_now = node.params()
 
     out = None
     if rank == 0:
         k_ms = float(kms.mean())
-        value = world * B * args.steps / elapsed
-        ach_gbs = BYTES_PER_TRAJ * B / (k_ms * 1e-3) / 1e9
+        value = world * B_rank * args.steps / elapsed
+        ach_gbs = BYTES_PER_TRAJ * B_rank / (k_ms * 1e-3) / 1e9
         if not ros:
             flops = None   # no instruction-count model for the Tsit5 / composite kernels
         elif adjoint:
-            flops = ((st["n_accept"] + st["n_reject"]) * FLOP_ADJ_ATTEMPT + st["n_accept"] * FLOP_ADJ_REVERSE
-                     + st["n_traj"] * len(ts) * FLOP_ADJ_SAVE)
+            fa, fr, fs = ((FLOP_ADJ2_ATTEMPT, FLOP_ADJ2_REVERSE, FLOP_ADJ2_SAVE) if lanes_used == 2 else
+                          (FLOP_ADJ_ATTEMPT, FLOP_ADJ_REVERSE, FLOP_ADJ_SAVE))
+            flops = (st["n_accept"] + st["n_reject"]) * fa + st["n_accept"] * fr + st["n_traj"] * len(ts) * fs
         else:
             flops = (st["n_accept"] + st["n_reject"]) * FLOP_PRIMAL_STEP + st["n_accept"] * 25 * FLOP_COL_STEP
         traffic = None
@@ -205,13 +233,13 @@ def main():
             "value": value, "unit": "trajectories+grads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "case2: 6 species + T, 3 reactions, P=25, D=50 save points on [0,50], "
                                    f"{ {'tsit5': 'Tsit5', 'autotsit5': 'AutoTsit5(Rosenbrock23)', 'rosenbrock23': 'Rosenbrock23'}[args.solver]} atol 1e-6 rtol 1e-3, MAE loss, "
                                    f"{'discrete-adjoint' if adjoint else 'forward-tangent'} gradient of the accepted steps (= ForwardDiff's derivative), "
                                    "ExpDecay+ADAM+WeightDecay update",
-                       "batch_per_gpu": B, "global_batch": B * world, "theta0": args.theta0,
+                       "batch_per_gpu": B_rank, "global_batch": B_rank * world, "theta0": args.theta0,
                        "comm": comm if world > 1 else "none", "parallelism": f"dp{world} (ICs sharded, 1 all-reduce/step)"},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
@@ -219,12 +247,14 @@ def main():
                          # inside this process).  traffic_model: the same quantity from THIS run's step counts -- algorithmic bytes +
                          # the adjoint's step tape, 64 B per accepted step written at 1.27x its payload (lane-strided partial
                          # lines, profiles/r02_fetch_write_calibration.txt) and read back once.
-                         "traffic_model": (BYTES_PER_TRAJ * B + st["n_accept"] * 64 * (1.27 + 1.0)) if (ros and adjoint) else None,
-                         "kernel": (("ros23_adj_kernel<6,3,T>" if ros else "auto_adj_kernel<6,3,T>") if adjoint else
+                         "traffic_model": (BYTES_PER_TRAJ * B_rank + st["n_accept"] * 64 * (1.27 + 1.0)) if (ros and adjoint) else None,
+                         "kernel": (((("ros23_adj2_kernel<6,3,T> (two lanes per trajectory)" if lanes_used == 2 else "ros23_adj_kernel<6,3,T>")) if ros
+                                     else "auto_adj_kernel<6,3,T>") if adjoint else
                                     ("ros23_kernel" if ros else "tsit5_kernel") + "<6,3,T,C,L>"), "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_launch": BYTES_PER_TRAJ * B,
+                         "algorithmic_bytes_per_launch": BYTES_PER_TRAJ * B_rank,
+                         "lanes_per_traj": lanes_used,
                          "note": "state lives in VGPR/LDS for the whole integration; the path is instruction-issue bound "
-                                 "(one wavefront per SIMD at 65 536 trajectories), see valu_fp64 (SURVEY F8)"},
+                                 "(one wavefront per SIMD), see valu_fp64 (SURVEY F8)"},
             # flop count and duration of the LAST timed launch (step counts drift slightly as p is updated)
             "valu_fp64": {"achieved": None if flops is None else flops / (kms[-1] * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
                           "unit": "TFLOP/s", "frac": None if flops is None else flops / (kms[-1] * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
@@ -232,6 +262,8 @@ def main():
                           "rejects_per_traj": st["n_reject"] / max(st["n_traj"], 1),
                           "n_ok": st["n_ok"], "n_traj": st["n_traj"]},
         }
+        if other_line is not None:
+            out["other_scaling"] = other_line
         # ---- CPU baseline: the C oracle ("port", OpenMP over trajectories) on a bounded sample ----
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as orc
@@ -251,6 +283,8 @@ def main():
                 tc += time.perf_counter() - t1
                 passes += 1
             out["cpu_baseline"] = {"value": ns_ * passes / tc, "unit": "trajectories+grads/s", "cores": cores, "kind": "port",
+                                   "algorithm": "forward tangents, 1 + 25 columns per trajectory (ForwardDiff's arithmetic): about 8x the "
+                                                "operations of the GPU's discrete adjoint for the same gradient",
                                    "sample": f"{passes} passes over the first {ns_} ICs of the same ensemble, solve+loss+gradient "
                                              f"(forward tangents, ForwardDiff's arithmetic) at the same p, C oracle with OpenMP over "
                                              f"trajectories ({tc:.1f} s wall); a C restatement, not DifferentialEquations.jl (Julia absent)"}

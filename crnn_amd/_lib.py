@@ -108,6 +108,8 @@ SYMBOLS = {
     "crnn_train_update": (C.c_int32, [_CTX, _DP]),
     "crnn_last_stats": (C.c_int32, [_CTX, C.POINTER(Stats)]),
     "crnn_ctx_set_queue_order": (C.c_int32, [_CTX, C.c_int32]),
+    "crnn_ctx_set_lanes_per_traj": (C.c_int32, [_CTX, C.c_int32]),
+    "crnn_last_lanes_per_traj": (C.c_int32, [_CTX]),
     "crnn_last_step_counts": (C.c_int32, [_CTX, C.c_int64, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "crnn_kernel_times": (C.c_int32, [_CTX, _DP, C.c_int32]),
     "crnn_synchronize": (C.c_int32, [_CTX]),

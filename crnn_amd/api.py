@@ -431,6 +431,15 @@ class NeuralODE:
         sums are a function of the call's inputs alone, bit for bit) -- include/crnn_hip.h: crnn_ctx_set_queue_order."""
         check(lib.crnn_ctx_set_queue_order(self._ctx.h, int(order)), self._ctx.h)
 
+    def set_lanes_per_traj(self, lanes):
+        """0 (AUTO, default) / 1 / 2 lanes per trajectory in the Rosenbrock23 adjoint kernel -- include/crnn_hip.h:
+        crnn_ctx_set_lanes_per_traj.  2 = an adjacent lane pair per trajectory (shards smaller than the chip)."""
+        check(lib.crnn_ctx_set_lanes_per_traj(self._ctx.h, int(lanes)), self._ctx.h)
+
+    def last_lanes_per_traj(self):
+        """Lanes per trajectory of the most recent adjoint gradient launch (1 or 2; 0: none yet)."""
+        return int(lib.crnn_last_lanes_per_traj(self._ctx.h))
+
     def step_counts(self, first=0, count=None):
         """(naccept, nreject) of every trajectory in [first, first+count) of the most recent solve -- `sol.destats` of
         each `solve` of the ensemble (case2/case2.jl:126)."""

@@ -20,6 +20,7 @@
 #include "hychem_kernel.hpp"
 #include "tsit5_kernel.hpp"
 #include "auto_adj_kernel.hpp"
+#include "ros23_adj2_kernel.hpp"
 #include "cathode_kernel.hpp"
 #include "svgd_kernel.hpp"
 
@@ -87,11 +88,26 @@ using AdjKernelFn = void (*)(const crnn::SolveParams, const double *, const crnn
 struct AdjEntry {
     int solver, ns, nr, has_t, use_scale;
     AdjKernelFn fn;
+    int max_gen = 1;   // two-lane entries: AUTO uses the kernel while count <= max_gen * (resident lane pairs)
 };
 #define KADJ(NS, NR, HT, SC) \
     { CRNN_SOLVER_ROSENBROCK23, NS, NR, HT, SC, (AdjKernelFn)crnn::ros23_adj_kernel<NS, NR, (HT) != 0, (SC) != 0, kBlock> }
 #define KAUTO(SOLVER, NS, NR, HT, SC, COMPOSITE) \
     { SOLVER, NS, NR, HT, SC, (AdjKernelFn)crnn::auto_adj_kernel<NS, NR, (HT) != 0, (SC) != 0, kBlock, COMPOSITE> }
+// Rosenbrock23 discrete adjoint with TWO lanes per trajectory (ros23_adj2_kernel.hpp): shapes with nr < ns, no rate scaling.
+// Two instantiations per shape: at most 512 registers per lane (one wavefront per SIMD) and at most 256 (two per SIMD).
+#ifndef CRNN_ADJ2_OCC
+#define CRNN_ADJ2_OCC 1
+#endif
+// max_gen (measured, tools/kbench.py --lanes 1|2, MI355X): while the pairs fit the resident lanes the two-lane kernel always
+// wins (case2 4 096-32 768 trajectories: 0.28-0.32 ms against 0.48; case1's shape with Rosenbrock23, 16 384: 0.139 against
+// 0.176).  With TWO generations of pairs (32 769-65 536 trajectories) it still wins where step counts spread widely -- case2,
+// longest 48 steps against a mean of 29: the queue is longest-first, so the second generation is the short trajectories:
+// 49 152: 0.405 against 0.486 ms, 65 536: 0.483 against 0.503, 81 920: 0.61 against 0.63, 98 304: 0.68 against 0.66 -- and
+// loses where every trajectory takes the same few steps (case1 65 536: 0.304 against 0.215).
+#define KADJ2(NS, NR, HT, MAXGEN) \
+    { CRNN_SOLVER_ROSENBROCK23, NS, NR, HT, 0, (AdjKernelFn)crnn::ros23_adj2_kernel<NS, NR, (HT) != 0, kBlock, CRNN_ADJ2_OCC>, MAXGEN }
+const AdjEntry kAdj2Kernels[] = { KADJ2(6, 3, 1, 2), KADJ2(5, 4, 0, 1) };
 // discrete-adjoint gradient kernels, one lane per trajectory: Rosenbrock23; Tsit5; the AutoTsit5(Rosenbrock23()) composite
 // (with a constant temperature state it never leaves Tsit5 -- auto_adj_kernel.hpp -- and shares that instantiation)
 const AdjEntry kAdjKernels[] = {
@@ -154,6 +170,9 @@ struct Ctx {
     double *d_red_theta = nullptr;  // [n_theta + kExtra]
     int64_t n_fallback = 0;         // calls repeated with forward tangents after a tape overflow
     int adj_occ = 0;                // cached occupancy of the adjoint kernel
+    int adj2_occ = 0;               // ... of the two-lanes-per-trajectory variant
+    int lanes_per_traj = 0;         // crnn_ctx_set_lanes_per_traj: 0 = AUTO, 1, 2
+    int last_lanes = 0;             // lanes per trajectory of the most recent adjoint launch (0: another kernel family ran)
     // deferred outcome of adjoint training steps (crnn_train_step): see check_pending
     bool defer_next = false, last_deferred = false, force_forward = false;
     struct StepArgs { int64_t first, count; int32_t n_save; };
@@ -404,6 +423,13 @@ const AdjEntry *find_adjoint(const Ctx *c) {
     return nullptr;
 }
 
+const AdjEntry *find_adjoint2(const Ctx *c) {
+    if (c->use_scale) return nullptr;
+    for (const auto &k : kAdj2Kernels)
+        if (k.solver == c->cfg.solver && k.ns == c->cfg.ns && k.nr == c->cfg.nr && k.has_t == c->cfg.has_temp) return &k;
+    return nullptr;
+}
+
 void fill_params(Ctx *c, crnn::SolveParams &prm, int P, int64_t first, int64_t count, int n_save_active, bool want_pred) {
     prm.u0 = c->d_u0; prm.data = c->d_data; prm.tsave = c->d_tsave;
     prm.row_stride = (int64_t)c->cfg.n_save * c->n_obs;
@@ -454,10 +480,25 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
         HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->adj_occ, (const void *)k->fn, kBlock, 0));
         if (c->adj_occ < 1) c->adj_occ = 1;
     }
-    const int occ = c->adj_occ;
-    const int64_t need_blocks = (count + kBlock - 1) / kBlock;
+    // Two lanes per trajectory (ros23_adj2_kernel.hpp) where the pairs still fit the resident lanes: a shard smaller than
+    // the chip then uses its idle lanes to shorten every step instead of leaving them empty (lanes_per_traj = AUTO), or
+    // wherever the caller asks for it (crnn_ctx_set_lanes_per_traj).
+    int G = 1;
+    if (const AdjEntry *k2 = (k->solver == CRNN_SOLVER_ROSENBROCK23 && c->lanes_per_traj != 1) ? find_adjoint2(c) : nullptr) {
+        if (c->adj2_occ < 1) {
+            HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->adj2_occ, (const void *)k2->fn, kBlock, 0));
+            if (c->adj2_occ < 1) c->adj2_occ = 1;
+        }
+        const int64_t resident_pairs = (int64_t)c->num_cu * c->adj2_occ * (kBlock / 2);
+        if (c->lanes_per_traj == 2 || count <= (int64_t)k2->max_gen * resident_pairs) { G = 2; k = k2; }
+    }
+    c->last_lanes = G;
+    const int occ = G == 2 ? c->adj2_occ : c->adj_occ;
+    const int tpb = kBlock / G;                                  // trajectories per block
+    const int tpw = 64 / G;                                      // trajectories per wavefront = per batch row
+    const int64_t need_blocks = (count + tpb - 1) / tpb;
     const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(need_blocks, (int64_t)c->num_cu * occ));
-    const size_t lanes = (size_t)nblk * kBlock;
+    const size_t lanes = (size_t)nblk * tpb;                     // tape slots (one per resident trajectory)
     const size_t recw = CRNN_ADJ_TAPE_K ? (size_t)3 * c->cfg.ns + 2 : (size_t)c->cfg.ns + 2;
     int64_t cap = c->cfg.tape_steps;
     if (cap <= 0) {  // auto: what fits in min(free/4, 16 GiB), at most maxiters (no trajectory accepts more steps)
@@ -473,7 +514,7 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
     if (c->tape_doubles < lanes * (size_t)cap * recw) {
         if (ensure(c, &c->d_tape, &c->tape_doubles, lanes * (size_t)cap * recw)) return -1;
     }
-    const int nbatch = (int)((count + 63) / 64);     // one partial row per 64-trajectory batch (written by the solve kernel)
+    const int nbatch = (int)((count + tpw - 1) / tpw);   // one partial row per batch of a wavefront (written by the solve kernel)
     if (ensure(c, &c->d_partials, &c->partials_cap, (size_t)nbatch * std::max(npart_th, npart))) return -1;
     if (c->npart_max < npart) {
         if (c->d_red) HIP_TRY(c, hipFree(c->d_red));
@@ -784,8 +825,12 @@ int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int 
     // column per lane -- a whole lane group per trajectory, a single sweep -- has the shorter critical path than the
     // adjoint's forward + reverse sweeps (case2, B = 1: 0.28 vs 0.33 ms per launch, 0.33 vs 0.42 ms per call; the break-even
     // is where the lane groups fill the chip).  grad_mode AUTO only; the gradient is the same derivative either way.
+    // (Round 3: where a two-lanes-per-trajectory adjoint kernel exists it is faster still on tiny ensembles -- case2, one
+    //  trajectory: 0.196 ms per launch against 0.279 for one column per lane and 0.307 for the one-lane adjoint; 32: 0.209 /
+    //  0.312 / 0.358 -- so those shapes stay on the adjoint; robertson keeps the column-per-lane path.)
     const KernelEntry *k_small = nullptr;
-    if (P > 0 && c->cfg.grad_mode == CRNN_GRAD_AUTO && !c->force_forward) {
+    const bool two_lane_adjoint = c->cfg.solver == CRNN_SOLVER_ROSENBROCK23 && c->lanes_per_traj != 1 && find_adjoint2(c) != nullptr;
+    if (P > 0 && c->cfg.grad_mode == CRNN_GRAD_AUTO && !c->force_forward && !two_lane_adjoint) {
         for (const auto &ke : kKernels)
             if (shape_match(c, ke) && ke.C == 1 && ke.L >= P && count <= (int64_t)c->num_cu * 4 * (64 / ke.L)) k_small = &ke;
     }
@@ -1588,6 +1633,21 @@ int32_t crnn_ctx_set_queue_order(crnn_ctx *ctx, int32_t order) {
     if (!c) return fail(c, "crnn_ctx_set_queue_order: null");
     if (order != CRNN_QUEUE_AUTO && order != CRNN_QUEUE_INDEX) return fail(c, "crnn_ctx_set_queue_order: order must be CRNN_QUEUE_AUTO or CRNN_QUEUE_INDEX");
     c->queue_order = order;
+    return 0;
+}
+
+int32_t crnn_last_lanes_per_traj(const crnn_ctx *ctx) {
+    const Ctx *c = reinterpret_cast<const Ctx *>(ctx);
+    return c ? c->last_lanes : -1;
+}
+
+int32_t crnn_ctx_set_lanes_per_traj(crnn_ctx *ctx, int32_t lanes) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return fail(c, "crnn_ctx_set_lanes_per_traj: null");
+    if (lanes < 0 || lanes > 2) return fail(c, "crnn_ctx_set_lanes_per_traj: lanes must be 0 (auto), 1 or 2");
+    if (lanes == 2 && (c->hychem || c->cfg.solver != CRNN_SOLVER_ROSENBROCK23 || !find_adjoint2(c)))
+        return fail(c, "crnn_ctx_set_lanes_per_traj: no two-lane kernel for this problem (Rosenbrock23, nr < ns, no rate scaling)");
+    c->lanes_per_traj = lanes;
     return 0;
 }
 

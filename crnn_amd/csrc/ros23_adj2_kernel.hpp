@@ -1,0 +1,653 @@
+// crnn_amd/csrc/ros23_adj2_kernel.hpp -- gfx950 (MI355X): the Rosenbrock23 discrete-adjoint gradient kernel with TWO LANES
+// PER TRAJECTORY (round 3).
+//
+// Same mathematics, same tape, same outputs as ros23_adj_kernel.hpp (reference: solve + loss + ForwardDiff.gradient,
+// case2/case2.jl:124-137,195; case1/case1.jl) -- what changes is the mapping.  ros23_adj_kernel gives a trajectory one
+// lane: at 65 536 trajectories that is exactly one wavefront per SIMD, a launch lasts as long as the longest wavefront's
+// chain of ~2 900 instructions per step pair, and below 65 536 trajectories the chip is partly empty while the launch
+// takes just as long (0.466 ms from 4 096 to 32 768 trajectories: DESIGN.md 5) -- a shard of a strongly-scaled batch
+// gains nothing from its idle lanes.  Here an adjacent lane pair (2g, 2g+1) owns one trajectory:
+//
+//   * lane m of the pair holds species m*H .. m*H+H-1 (H = ceil(NS/2)): u, f, k1, dk, lambda, the rows of w_in / w_out that
+//     belong to them (in registers: the two lanes of a pair need different weights, so they cannot be scalar operands) and
+//     the gradient accumulators of exactly those rows -- 2*H*NR registers-doubles, no LDS atomics at all;
+//   * the logarithms (one per species) and the O(NS*NR) contractions split in half; everything that couples the species
+//     goes through ONE cross-lane step: s = a + dpp_quad_perm[1,0,3,2](a) -- both lanes form a+b / b+a, the same bits, so
+//     reaction rates, the NR x NR Woodbury matrix, the error norm, the step-size controller and every branch decision are
+//     replicated exactly and the pair never diverges;
+//   * the wave takes 32 trajectories from the queue; its batch sums (one partial row per 32 trajectories) go through an
+//     LDS staging area in fixed order like the one-lane kernel's.
+//
+// Per step pair a lane executes ~55-60 % of the one-lane kernel's instructions (the replicated part -- LU of the NR x NR
+// matrix, controller, save-point bookkeeping -- does not shrink) with about half its registers.  The host uses it where the
+// pairs still fit the resident lanes (crnn_capi.hip launch_adjoint; crnn_ctx_set_lanes_per_traj).
+// Shapes: nr < ns (Woodbury form of W: case1, case2), no rate scaling.  Robertson (ns = 3 < nr = 6, dense W) keeps one lane.
+#pragma once
+#include "ros23_adj_kernel.hpp"
+
+namespace crnn {
+
+// a + (the other lane of the pair's a): one DPP step per 32-bit half; identical bits in both lanes (a+b == b+a)
+__device__ __forceinline__ double pair_sum(double a) {
+    const int lo = __double2loint(a), hi = __double2hiint(a);
+    const int plo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    const int phi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false);
+    return a + __hiloint2double(phi, plo);
+}
+__device__ __forceinline__ int pair_and(int a) { return a & __builtin_amdgcn_update_dpp(0, a, 0xB1, 0xF, 0xF, false); }
+
+template <int NS, int NR, bool HAS_T, int BLOCK, int OCC>
+__global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParams prm, const double *__restrict__ theta,
+                                                                const AdjParams adj) {
+    using L_ = Lay<NS, NR, HAS_T>;
+    constexpr int N = L_::N;
+    constexpr int NTH = L_::NTH;
+    constexpr int H = (NS + 1) / 2;        // species per lane (the second lane's last one is padding when NS is odd)
+    constexpr int RECW = NS + 2;
+    constexpr int GPB = BLOCK / 2;         // trajectories (lane pairs) per block
+    static_assert(NR < NS, "Woodbury form of W only (nr < ns)");
+    static_assert(NTH + kExtra <= 64, "the per-batch sums use one lane per column");
+
+    __shared__ double kc_lds[kNConst];
+    __shared__ double ts_lds[kMaxSave];
+    __shared__ double stage_lds[(NTH + kExtra) * GPB];    // batch sums: [column][pair of this block]
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < kNConst; idx += BLOCK) kc_lds[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
+    for (int idx = tid; idx < prm.n_save; idx += BLOCK) ts_lds[idx] = prm.tsave[idx];
+    __syncthreads();
+    const KConst *kc = reinterpret_cast<const KConst *>(kc_lds);
+
+    const int lane = tid & 63;
+    const int m = lane & 1;                 // which half of the species this lane owns
+    const int gib = tid >> 1;               // pair index within the block
+    const int giw = lane >> 1;              // pair index within the wavefront (0..31)
+
+    // ---- this lane's weights and per-species constants, in registers for the whole kernel
+    double wi[H][NR], wo[H][NR], wT[NR], wb_[NR];
+    double atl[H], rtl[H], iys[H];
+    int dro[H];                             // data column of the species, -1 if unobserved (or padding)
+    bool own[H];
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+        const int c = m * H + i;
+        own[i] = c < NS;
+        const int cc = own[i] ? c : 0;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            wi[i][j] = own[i] ? theta[L_::wi(cc, j)] : 0.0;
+            wo[i][j] = own[i] ? theta[L_::wo(cc, j)] : 0.0;
+        }
+        atl[i] = own[i] ? kc->atol[cc] : 1.0;
+        rtl[i] = own[i] ? kc->rtol[cc] : 0.0;
+        iys[i] = own[i] ? kc->inv_yscale[cc] : 0.0;
+        dro[i] = own[i] ? (int)kc->drow[cc] : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        wT[j] = HAS_T ? theta[L_::wi(NS, j)] : 0.0;
+        wb_[j] = theta[L_::wb(j)];
+    }
+
+    const double d_ = 0.29289321881345248;    // 1/(2+sqrt 2)
+    const double c32 = 7.4142135623730950;    // 6+sqrt 2
+    const double inv12d = 2.4142135623730950; // 1/(1-2d)
+    const int nsave = prm.n_save;
+    const double tend = ts_lds[nsave - 1];
+    const double ts0 = ts_lds[0];
+    const double t0 = kc->t0;
+    const double dtmax = tend - t0;
+    const double lqinit = flog(kc->qoldinit);
+    const bool start_saved = (ts0 == t0);
+
+    double *const tape = adj.tape + (size_t)((size_t)blockIdx.x * GPB + gib) * adj.tape_cap * RECW;
+
+    while (true) {
+        // ---- next 32 trajectories for this wavefront
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(prm.queue, 32ULL);
+        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base);
+        const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+        const int64_t wave_base = (int64_t)(((unsigned long long)bhi << 32) | blo);
+        if (wave_base >= prm.count) break;
+        const int64_t traj = wave_base + giw;
+        const bool valid = traj < prm.count;
+        const int64_t b = prm.first + (valid ? (adj.perm ? (int64_t)adj.perm[traj] : traj) : 0);
+        CRNN_CHK(b >= 0 && b < prm.B && traj >= 0, 21);
+
+        double bT[NR];
+        double xT = 0.0, Tconst = 0.0;
+        // point evaluation: x = log clamp(u), g = dx/du (this lane's species); r (replicated); f (this lane's species)
+        auto eval_point = [&](const double (&uu)[H], double (&x)[H], double (&g)[H], double (&r)[NR], double (&f)[H]) {
+            features<H>(uu, kc->lb, kc->ub, x, g);
+            double z[NR];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                double a = 0.0;
+#pragma unroll
+                for (int i = 0; i < H; ++i) a = fma(wi[i][j], x[i], a);
+                z[j] = pair_sum(a) + bT[j];
+            }
+            fexp_vec<NR>(z, r);
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+                double a = 0.0;
+#pragma unroll
+                for (int j = 0; j < NR; ++j) a = fma(wo[i][j], r[j], a);
+                f[i] = a;
+            }
+        };
+        // W = I - gam J in Woodbury form: M = I_nr - gam B^T A (replicated), pivoted LU
+        double M[NR][NR], dinv[NR];
+        int piv[NR];
+        bool wave_pivots = false;
+        auto factor = [&](const double (&g)[H], const double (&r)[NR], const double gam) -> bool {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                double tj[H];
+#pragma unroll
+                for (int i = 0; i < H; ++i) tj[i] = wi[i][j] * g[i];
+#pragma unroll
+                for (int l = 0; l < NR; ++l) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int i = 0; i < H; ++i) a = fma(tj[i], wo[i][l], a);
+                    M[j][l] = ((j == l) ? 1.0 : 0.0) - (gam * r[l]) * pair_sum(a);
+                }
+            }
+            bool anyp;
+            const bool ok = lu_factor<NR>(M, dinv, piv, anyp);
+            wave_pivots = __builtin_amdgcn_ballot_w64(anyp) != 0;
+            return ok;
+        };
+        // b <- W^-1 b = b + w_out (gr .* M^-1 (w_in^T (g .* b)))
+        auto solve = [&](const double (&g)[H], const double (&gr)[NR], double (&bb)[H]) {
+            double y[NR];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                double a = 0.0;
+#pragma unroll
+                for (int i = 0; i < H; ++i) a = fma(wi[i][j], g[i] * bb[i], a);
+                y[j] = pair_sum(a);
+            }
+            lu_solve<NR>(M, dinv, piv, wave_pivots, y);
+#pragma unroll
+            for (int j = 0; j < NR; ++j) y[j] *= gr[j];
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+                double a = 0.0;
+#pragma unroll
+                for (int j = 0; j < NR; ++j) a = fma(wo[i][j], y[j], a);
+                bb[i] += a;
+            }
+        };
+        // b <- W^-T b = b + g .* (w_in (M^-T (gr .* (w_out^T b))))
+        auto solve_Tr = [&](const double (&g)[H], const double (&gr)[NR], double (&bb)[H]) {
+            double y[NR];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                double a = 0.0;
+#pragma unroll
+                for (int i = 0; i < H; ++i) a = fma(wo[i][j], bb[i], a);
+                y[j] = pair_sum(a) * gr[j];
+            }
+            lu_solve_T<NR>(M, dinv, piv, wave_pivots, y);
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+                double a = 0.0;
+#pragma unroll
+                for (int j = 0; j < NR; ++j) a = fma(wi[i][j], y[j], a);
+                bb[i] = fma(a, g[i], bb[i]);
+            }
+        };
+
+        // ================================================================== forward sweep
+        double u[H], f0[H], g0[H], r0[NR];
+        double t = t0, dt = 0.0, lqold = lqinit;
+        int iter = 0, jsave = 0, nacc = 0, nrej = 0;
+        int rc = valid ? -1 : 0;
+#pragma unroll
+        for (int i = 0; i < H; ++i) u[i] = own[i] ? prm.u0[(size_t)(m * H + i) * prm.B + b] : 1.0;
+        if (HAS_T) {
+            Tconst = prm.u0[(size_t)NS * prm.B + b];
+            xT = kc->inv_R * frcp(Tconst);
+        }
+#pragma unroll
+        for (int j = 0; j < NR; ++j) bT[j] = HAS_T ? fma(wT[j], xT, wb_[j]) : wb_[j];
+        {
+            double x0[H];
+            eval_point(u, x0, g0, r0, f0);
+            // Hairer initial step (OrdinaryDiffEq ode_determine_initdt, order 2)
+            double d0 = 0.0, d1 = 0.0, sk[H];
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+                sk[i] = own[i] ? frcp(fma(fabs(u[i]), rtl[i], atl[i])) : 0.0;
+                const double a = u[i] * sk[i], c = f0[i] * sk[i];
+                d0 = fma(a, a, d0);
+                d1 = fma(c, c, d1);
+            }
+            d0 = pair_sum(d0);
+            d1 = pair_sum(d1);
+            if (HAS_T) { const double a = Tconst * frcp(fma(fabs(Tconst), kc->rtol[NS], kc->atol[NS])); d0 = fma(a, a, d0); }
+            d0 = sqrt(d0 * (1.0 / N));
+            d1 = sqrt(d1 * (1.0 / N));
+            double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 / d1);
+            dt0 = fmin(dt0, dtmax);
+            double u1[H], x1[H], g1[H], r1[NR], f1[H];
+#pragma unroll
+            for (int i = 0; i < H; ++i) u1[i] = fma(dt0, f0[i], u[i]);
+            eval_point(u1, x1, g1, r1, f1);
+            double d2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < H; ++i) { const double e = (f1[i] - f0[i]) * sk[i]; d2 = fma(e, e, d2); }
+            d2 = sqrt(pair_sum(d2) * (1.0 / N)) / dt0;
+            const double dm = fmax(d1, d2);
+            const double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : exp(-0.5 * (4.605170185988091368 + flog(dm)));
+            dt = fmax(kc->dtmin, fmin(fmin(100.0 * dt0, dt1), dtmax));
+        }
+        auto write_pred = [&](int j, const double (&v)[H]) {
+            CRNN_CHK((int64_t)j * prm.n_obs < prm.row_stride && j >= 0, 29);
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+                if (own[i]) {
+                    double w = v[i];
+                    if (prm.clamp_pred) w = clampv(w, -kc->ub, kc->ub);
+                    prm.pred[((size_t)j * N + (m * H + i)) * prm.B + b] = w;
+                }
+            }
+            if (HAS_T && m == 0) {
+                double w = Tconst;
+                if (prm.clamp_pred) w = clampv(w, -kc->ub, kc->ub);
+                prm.pred[((size_t)j * N + NS) * prm.B + b] = w;
+            }
+        };
+        if (start_saved) {  // save_start: saveat contains tspan[1]
+            if (valid && prm.pred) write_pred(0, u);
+            jsave = 1;
+        }
+
+        while (__builtin_amdgcn_ballot_w64(rc < 0) != 0) {
+            if (rc < 0) {
+                ++iter;
+                bool last = false;
+                if (jsave >= nsave) rc = 0;
+                else if (iter > prm.maxiters) rc = 1;
+                if (t + dt * (1.0 + 1e-13) >= tend) { dt = tend - t; last = true; }
+                if (rc < 0 && (!(dt > kc->dtmin) || t + dt == t)) rc = 2;
+                if (rc < 0) {
+                    const double gam = d_ * dt;
+                    double gr0[NR];
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) gr0[j] = gam * r0[j];
+                    double k1[H], dk[H], unew[H], f1[H], f2[H], g2[H], r2[NR];
+                    const bool okf = factor(g0, r0, gam);
+#pragma unroll
+                    for (int i = 0; i < H; ++i) k1[i] = f0[i];
+                    solve(g0, gr0, k1);
+                    {
+                        double u1[H], x1[H], g1[H], r1[NR];
+#pragma unroll
+                        for (int i = 0; i < H; ++i) u1[i] = fma(0.5 * dt, k1[i], u[i]);
+                        eval_point(u1, x1, g1, r1, f1);
+                    }
+#pragma unroll
+                    for (int i = 0; i < H; ++i) dk[i] = f1[i] - k1[i];
+                    solve(g0, gr0, dk);
+#pragma unroll
+                    for (int i = 0; i < H; ++i) unew[i] = fma(dt, k1[i] + dk[i], u[i]);
+                    {
+                        double x2[H];
+                        eval_point(unew, x2, g2, r2, f2);
+                    }
+                    double k3[H];
+#pragma unroll
+                    for (int i = 0; i < H; ++i) {
+                        const double k2i = k1[i] + dk[i];
+                        k3[i] = f2[i] - c32 * (k2i - f1[i]) - 2.0 * (k1[i] - f0[i]);
+                    }
+                    solve(g0, gr0, k3);
+                    double es = 0.0;
+                    bool finite = okf;
+#pragma unroll
+                    for (int i = 0; i < H; ++i) {
+                        const double k2i = k1[i] + dk[i];
+                        const double ev = dt * (1.0 / 6.0) * (k1[i] - 2.0 * k2i + k3[i]);
+                        const double mx = fmax(fabs(u[i]), fabs(unew[i]));
+                        const double e = ev * frcp1(fma(rtl[i], mx, atl[i]));
+                        es = fma(e, e, es);
+                        finite = finite && isfinite(unew[i]) && isfinite(ev);
+                    }
+                    es = pair_sum(es) * (1.0 / N);
+                    finite = pair_and(finite ? 1 : 0) != 0;
+                    if (!finite) rc = 3;
+                    else {
+                        // PI controller (OrdinaryDiffEq PIController), in log space
+                        const bool ee_zero = (es == 0.0);
+                        const double lEE = 0.5 * flog(ee_zero ? 1.0 : es);
+                        const double lq11 = kc->beta1 * lEE;
+                        double q = ee_zero ? 1.0 / kc->qmax
+                                           : fmax(1.0 / kc->qmax, fmin(1.0 / kc->qmin, exp(lq11 - kc->beta2 * lqold) / kc->gamma));
+                        if (es <= 1.0) {
+                            if (nacc >= adj.tape_cap) {
+                                rc = 5;  // out of tape: the host re-runs the call with forward tangents
+                                if (m == 0) atomicAdd(adj.overflow, 1u);
+                            } else {
+                                CRNN_CHK(nacc >= 0 && nacc < adj.tape_cap, 25);
+                                double *rec = tape + (size_t)nacc * RECW;
+                                if (m == 0) { rec[0] = t; rec[1] = dt; }
+#pragma unroll
+                                for (int i = 0; i < H; ++i)
+                                    if (own[i]) rec[2 + m * H + i] = u[i];
+                                ++nacc;
+                                const double tnew = last ? tend : t + dt;
+                                while (jsave < nsave) {
+                                    CRNN_CHK(jsave >= 0 && jsave < nsave, 26);
+                                    const double ts = ts_lds[jsave];
+                                    if (!(ts <= tnew)) break;
+                                    if (prm.pred) {
+                                        const bool at_end = (ts == tnew);
+                                        const double Th = at_end ? 1.0 : (ts - t) / dt;
+                                        const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
+                                        const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d_) * inv12d;
+                                        double v[H];
+#pragma unroll
+                                        for (int i = 0; i < H; ++i) {
+                                            const double k2i = k1[i] + dk[i];
+                                            v[i] = at_end ? unew[i] : fma(dt, fma(c1, k1[i], c2 * k2i), u[i]);
+                                        }
+                                        write_pred(jsave, v);
+                                    }
+                                    ++jsave;
+                                }
+#pragma unroll
+                                for (int i = 0; i < H; ++i) { u[i] = unew[i]; f0[i] = f2[i]; g0[i] = g2[i]; }
+#pragma unroll
+                                for (int j = 0; j < NR; ++j) r0[j] = r2[j];
+                                t = tnew;
+                                // step_accept_controller
+                                if (q >= kc->qsteady_min && q <= kc->qsteady_max) q = 1.0;
+                                lqold = ee_zero ? lqinit : fmax(lEE, lqinit);
+                                dt = fmin(dt / q, dtmax);
+                                if (jsave >= nsave) rc = 0;
+                            }
+                        } else {
+                            ++nrej;
+                            dt = dt / fmin(1.0 / kc->qmin, exp(lq11) / kc->gamma);
+                        }
+                    }
+                }
+            }
+        }
+
+        // ================================================================== reverse sweep
+        const int n_saved = jsave;
+        const int jlo = start_saved ? 1 : 0;
+        double awi[H][NR], awo[H][NR];     // d loss / d (this lane's rows of w_in, w_out): registers, no atomics
+#pragma unroll
+        for (int i = 0; i < H; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j) { awi[i][j] = 0.0; awo[i][j] = 0.0; }
+        double lam[H];
+#pragma unroll
+        for (int i = 0; i < H; ++i) lam[i] = 0.0;
+        double wbb[NR];                    // d/d w_b (replicated); the temperature row of w_in is xT times the same sum
+#pragma unroll
+        for (int j = 0; j < NR; ++j) wbb[j] = 0.0;
+        double loss_sum = 0.0;             // this lane's species only; the pair's sum is formed at the end
+        double tnew = t;
+        int s = valid ? nacc - 1 : -1;
+
+        const double *const drows = prm.data + (size_t)b * prm.row_stride;
+        int doff[H];
+#pragma unroll
+        for (int i = 0; i < H; ++i) doff[i] = dro[i] >= 0 ? dro[i] : 0;
+        auto load_row = [&](int j, double (&d)[H]) {
+            CRNN_CHK((int64_t)(j > 0 ? j : 0) * prm.n_obs < prm.row_stride, 22);
+            const double *row = drows + (size_t)(j > 0 ? j : 0) * prm.n_obs;
+#pragma unroll
+            for (int i = 0; i < H; ++i) d[i] = row[doff[i]];
+        };
+        double ts_cur = (jsave - 1 >= jlo) ? ts_lds[jsave - 1] : -INFINITY;
+        double ts_nxt = (jsave - 2 >= jlo) ? ts_lds[jsave - 2] : -INFINITY;
+        double rt = 0.0, rdt = 0.0, ru[H];   // tape record s, prefetched
+        auto load_rec = [&](int idx) {
+            CRNN_CHK(idx < adj.tape_cap, 23);
+            const double *rec = tape + (size_t)(idx > 0 ? idx : 0) * RECW;
+            rt = rec[0]; rdt = rec[1];
+#pragma unroll
+            for (int i = 0; i < H; ++i) ru[i] = own[i] ? rec[2 + m * H + i] : 1.0;
+        };
+        load_rec(s);
+
+        while (__builtin_amdgcn_ballot_w64(s >= 0) != 0) {
+            if (s >= 0) {
+                const double tn = rt, h = rdt;
+                double un[H];
+#pragma unroll
+                for (int i = 0; i < H; ++i) un[i] = ru[i];
+                double dA[H], dB[H], dC[H];
+                load_row(jsave - 1, dA);
+                load_row(jsave - 2, dB);
+                load_row(jsave - 3, dC);
+                load_rec(s - 1);   // prefetch the next record
+                // ---- re-form the step
+                double x0[H], gg0[H], rr0[NR], ff0[H];
+                const double gam = d_ * h;
+                double gr0[NR], x1[H], g1[H], r1[NR];
+                eval_point(un, x0, gg0, rr0, ff0);
+#pragma unroll
+                for (int j = 0; j < NR; ++j) gr0[j] = gam * rr0[j];
+                (void)factor(gg0, rr0, gam);
+                double k1[H], dk[H];
+#pragma unroll
+                for (int i = 0; i < H; ++i) k1[i] = ff0[i];
+                solve(gg0, gr0, k1);
+                {
+                    double u1[H], f1[H];
+#pragma unroll
+                    for (int i = 0; i < H; ++i) u1[i] = fma(0.5 * h, k1[i], un[i]);
+                    eval_point(u1, x1, g1, r1, f1);
+#pragma unroll
+                    for (int i = 0; i < H; ++i) dk[i] = f1[i] - k1[i];
+                }
+                solve(gg0, gr0, dk);
+
+                // ---- loss and its seeds at the save points inside (tn, tnew]
+                double A_[H], B1[H], B2[H];
+#pragma unroll
+                for (int i = 0; i < H; ++i) { A_[i] = 0.0; B1[i] = 0.0; B2[i] = 0.0; }
+                const double inv_h = frcp(h);
+                auto in_step = [&]() -> bool { return ts_cur > tn; };
+                auto seed_point = [&](const double (&dobs)[H]) {
+                    const double ts = ts_cur;
+                    CRNN_CHK(jsave - 1 >= jlo && jsave - 1 < nsave, 28);
+                    ts_cur = ts_nxt;
+                    ts_nxt = (jsave - 3 >= jlo) ? ts_lds[jsave - 3] : -INFINITY;
+                    const bool at_end = (ts == tnew);
+                    const double Th = at_end ? 1.0 : (ts - tn) * inv_h;
+                    const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
+                    const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d_) * inv12d;
+#pragma unroll
+                    for (int i = 0; i < H; ++i) {
+                        if (dro[i] >= 0) {
+                            const double k2i = k1[i] + dk[i];
+                            double v = at_end ? fma(h, k2i, un[i]) : fma(h, fma(c1, k1[i], c2 * k2i), un[i]);
+                            double mask = 1.0;
+                            if (prm.clamp_pred) {
+                                mask = (v > kc->ub || v < -kc->ub) ? 0.0 : 1.0;
+                                v = clampv(v, -kc->ub, kc->ub);
+                            }
+                            const double rr = (dobs[i] - v) * iys[i];
+                            double w;
+                            if (prm.loss_kind == 0) { loss_sum += fabs(rr); w = signbit(rr) ? 1.0 : -1.0; }
+                            else { loss_sum = fma(rr, rr, loss_sum); w = -2.0 * rr; }
+                            w *= mask * iys[i];
+                            A_[i] += w;
+                            B1[i] = fma(w, h * c1, B1[i]);
+                            B2[i] = fma(w, h * c2, B2[i]);
+                        }
+                    }
+                    --jsave;
+                };
+                if (in_step()) {
+                    seed_point(dA);
+                    if (in_step()) {
+                        seed_point(dB);
+                        if (in_step()) {
+                            seed_point(dC);
+                            while (in_step()) {
+                                double dD[H];
+                                load_row(jsave - 1, dD);
+                                seed_point(dD);
+                            }
+                        }
+                    }
+                }
+
+                // ---- adjoint of the step (ros23_adj_kernel.hpp, same formulas; sums over species cross the pair once)
+                double kb1[H], v[H], ub[H];
+#pragma unroll
+                for (int i = 0; i < H; ++i) { v[i] = fma(h, lam[i], B2[i]); ub[i] = lam[i] + A_[i]; }
+#pragma unroll
+                for (int i = 0; i < H; ++i) kb1[i] = B1[i] + v[i];
+                solve_Tr(gg0, gr0, v);                 // v = W^-T kb2
+#pragma unroll
+                for (int i = 0; i < H; ++i) kb1[i] -= v[i];
+                double av[NR];
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int i = 0; i < H; ++i) a = fma(v[i], wo[i][j], a);
+                    av[j] = pair_sum(a);
+                }
+                double rho1[NR];   // av_j r_j(u_mid)
+                {
+                    double um[H];
+#pragma unroll
+                    for (int i = 0; i < H; ++i) um[i] = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        const double rho = av[j] * r1[j];
+                        rho1[j] = rho;
+#pragma unroll
+                        for (int i = 0; i < H; ++i) um[i] = fma(rho, wi[i][j], um[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < H; ++i) {
+                        const double mm = um[i] * g1[i];
+                        ub[i] += mm;
+                        kb1[i] = fma(0.5 * h, mm, kb1[i]);
+                    }
+                }
+                solve_Tr(gg0, gr0, kb1);               // kb1 = w = W^-T kb1
+                {
+                    double s1[H], s2[H];
+#pragma unroll
+                    for (int i = 0; i < H; ++i) { s1[i] = 0.0; s2[i] = 0.0; }
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        double aw = 0.0, q1 = 0.0, qd = 0.0;
+#pragma unroll
+                        for (int i = 0; i < H; ++i) {
+                            aw = fma(kb1[i], wo[i][j], aw);
+                            const double wg = wi[i][j] * gg0[i];
+                            q1 = fma(wg, k1[i], q1);
+                            qd = fma(wg, dk[i], qd);
+                        }
+                        aw = pair_sum(aw);
+                        q1 = pair_sum(q1);
+                        qd = pair_sum(qd);
+                        const double c1j = fma(gam, q1, 1.0), czd = gam * qd;
+                        const double pv = av[j] * gr0[j];        // gam a^v_j r_j
+                        const double pw = aw * rr0[j];           // a^w_j r_j
+                        const double gpw = gam * pw;
+                        const double beta = fma(pw, c1j, pv * qd);
+                        wbb[j] += beta + rho1[j];
+                        const double ca = fma(rr0[j], czd, r1[j]), cb = rr0[j] * c1j;
+#pragma unroll
+                        for (int i = 0; i < H; ++i) {
+                            const double mm = fma(pv, dk[i], gpw * k1[i]);
+                            awi[i][j] += fma(rho1[j], x1[i], fma(beta, x0[i], gg0[i] * mm));
+                            s1[i] = fma(beta, wi[i][j], s1[i]);
+                            s2[i] = fma(wi[i][j], mm, s2[i]);
+                            awo[i][j] += fma(v[i], ca, kb1[i] * cb);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < H; ++i) {
+                        const double g = gg0[i];
+                        lam[i] = ub[i] + g * (s1[i] - g * s2[i]);   // g' = -g^2 inside the window, 0 outside
+                    }
+                }
+                tnew = tn;
+                --s;
+            }
+        }
+
+        // ---- outputs
+        if (start_saved && n_saved >= 1) {  // the saved initial point: a loss term without gradient
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+                if (dro[i] >= 0) {
+                    double v = prm.u0[(size_t)(m * H + i) * prm.B + b];
+                    if (prm.clamp_pred) v = clampv(v, -kc->ub, kc->ub);
+                    const double rr = (drows[doff[i]] - v) * iys[i];
+                    loss_sum += (prm.loss_kind == 0) ? fabs(rr) : rr * rr;
+                }
+            }
+        }
+        const double loss_tot = pair_sum(loss_sum);
+        const double denom = (double)prm.n_obs * (double)n_saved;
+        if (valid && m == 0) {
+            prm.loss[b] = loss_tot * (n_saved > 0 ? 1.0 / denom : 0.0);
+            prm.retcode[b] = rc;
+            prm.n_saved[b] = n_saved;
+            prm.n_accept[b] = nacc;
+            prm.n_reject[b] = nrej;
+        }
+        // ---- sums over the 32 trajectories of this batch: every pair parks its scaled accumulators (each lane the rows it
+        //      owns) and the five scalars in LDS, then lane k of the wavefront adds up column k over the 32 pairs in pair order.
+        //      The result depends on the batch only, not on which wavefront processed it.
+        {
+            const double scale_ = (valid && n_saved > 0) ? 1.0 / denom : 0.0;
+            double *const st = stage_lds + gib;      // column k of this pair: st[k * GPB]
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+                if (own[i]) {
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        st[L_::wi(m * H + i, j) * GPB] = awi[i][j] * scale_;
+                        st[L_::wo(m * H + i, j) * GPB] = awo[i][j] * scale_;
+                    }
+                }
+            }
+            if (m == 0) {
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    st[L_::wb(j) * GPB] = wbb[j] * scale_;
+                    if (HAS_T) st[L_::wi(NS, j) * GPB] = (wbb[j] * xT) * scale_;
+                }
+                st[(NTH + 0) * GPB] = valid ? loss_tot * scale_ : 0.0;
+                st[(NTH + 1) * GPB] = (valid && rc == 0) ? 1.0 : 0.0;
+                st[(NTH + 2) * GPB] = valid ? (double)nacc : 0.0;
+                st[(NTH + 3) * GPB] = valid ? (double)nrej : 0.0;
+                st[(NTH + 4) * GPB] = valid ? 1.0 : 0.0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            CRNN_CHK((wave_base >> 5) < ((prm.count + 31) >> 5), 24);
+            double *prow = adj.batch_partials + (size_t)(wave_base >> 5) * (NTH + kExtra);
+            const int g0w = (tid & ~63) >> 1;        // first pair of this wavefront within the block
+            if (lane < NTH + kExtra) {
+                const double *src = stage_lds + lane * GPB + g0w;
+                double a = 0.0;
+                for (int k = 0; k < 32; ++k) a += src[k];
+                prow[lane] = a;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+}  // namespace crnn

@@ -73,6 +73,9 @@ namespace crnn {
 // -- tape records, save times in LDS, observed rows, u0 / pred / per-trajectory outputs, the queue permutation, the batch
 // partial rows -- is checked against its extent on the lanes that perform it; violations are counted in g_bounds[0], the site
 // code of the first one is kept in g_bounds[1] (crnn_debug_bounds reads the pair).  Release builds compile the checks away.
+#ifndef CRNN_ADJ_THETA
+#define CRNN_ADJ_THETA 0     // 0: theta staged in LDS (broadcast reads, parked in AGPRs); 3: scalar loads re-issued per step
+#endif
 #ifdef CRNN_BOUNDS_CHECK
 __device__ unsigned int g_bounds[2];
 #define CRNN_CHK(cond, code) do { if (!(cond)) { if (atomicAdd(&g_bounds[0], 1u) == 0u) g_bounds[1] = (unsigned)(code); } } while (0)
@@ -193,10 +196,20 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
     // The compiler loads theta once and parks it in AGPRs (two v_accvgpr_read per use); forcing a fresh LDS read per
     // phase instead (pointer laundered through an empty asm) removes 10 % of the VALU instructions and is SLOWER (case2
     // +4 %, robertson +15 %): at one wavefront per SIMD the exposed lgkmcnt waits cost more than the issue slots saved.
+#if CRNN_ADJ_THETA == 3
+    // experiment (round 3): wave-uniform scalar loads RE-ISSUED at the top of every forward attempt / reverse step (pointer
+    // with an opaque SGPR zero offset), theta as SGPR operands of the FMAs -- what auto_adj_kernel.hpp ships
+    __syncthreads();
+    const double *th = theta;
+#define CRNN_ADJ_TH_FRESH() (theta + opaque_zero_s())
+#else
     __shared__ double th_lds[NTH];
     for (int idx = tid; idx < NTH; idx += BLOCK) th_lds[idx] = theta[idx];
     __syncthreads();
     const double *th = th_lds;
+#define CRNN_ADJ_TH_FRESH() th_outer
+#endif
+    const double *const th_outer = th;
     double *const thb_s = thb_lds + tid;   // accumulator m of this lane: thb_s[m * BLOCK]
 
     const double d_ = 0.29289321881345248;    // 1/(2+sqrt 2)
@@ -306,6 +319,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                 if (rc < 0 && (!(dt > kc->dtmin) || t + dt == t)) rc = 2;
                 if (rc < 0) {
                     ADJ_T(0);   // loop control, step-size bookkeeping
+                    const double *th = CRNN_ADJ_TH_FRESH();
                     Solver W;
                     const double gam = d_ * dt;
                     double gr0[NR];
@@ -537,6 +551,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
 #endif
                 }
                 // ---- re-form the step
+                const double *th = CRNN_ADJ_TH_FRESH();
                 double x0[NS], gg0[NS], rr0[NR];
                 Solver W;
                 const double gam = d_ * h;

@@ -206,6 +206,18 @@ int32_t crnn_ctx_set_tables(crnn_ctx *ctx, const double *T, const double *P);
  * checkpoint agree bit for bit: examples/case2_train.c). */
 enum { CRNN_QUEUE_AUTO = 0, CRNN_QUEUE_INDEX = 1 };
 int32_t crnn_ctx_set_queue_order(crnn_ctx *ctx, int32_t order);
+/* How many lanes work on one trajectory in the Rosenbrock23 adjoint kernel.  1: one lane per trajectory (ros23_adj_kernel:
+ * the least total work, the kernel for ensembles that fill the chip).  2: an adjacent lane pair per trajectory
+ * (ros23_adj2_kernel: each lane holds half of the species, their weight rows and their gradient accumulators; species sums
+ * cross the pair with one DPP step; ~45 % fewer instructions on a step's critical path) -- for shards smaller than the
+ * chip, e.g. one GPU's share of a strongly-scaled batch, where the second lane of a pair would otherwise be idle.
+ * 0 = AUTO (default): 2 where a two-lane instantiation exists for the shape (nr < ns, no rate scaling: case1, case2) and the
+ * pairs fit the resident lanes -- for case2, whose step counts spread widely, up to two generations of pairs (65 536
+ * trajectories on 256 CUs: the queue is longest-first, the second generation is the short trajectories) -- else 1.  Same derivative either way; results agree to rounding (the species
+ * sums are formed in a different order), per-trajectory outputs do not depend on the launch geometry. */
+int32_t crnn_ctx_set_lanes_per_traj(crnn_ctx *ctx, int32_t lanes);
+/* Lanes per trajectory the most recent adjoint gradient launch used (1 or 2; 0 if no adjoint launch has run, -1 for a null ctx). */
+int32_t crnn_last_lanes_per_traj(const crnn_ctx *ctx);
 
 /* ---- the hot path at theta level ---------------------------------------- *
  * Integrates trajectories [first, first+count) of the uploaded ensemble with

@@ -107,6 +107,11 @@ set_tables!(prob::Problem, Tlist::Matrix{Float64}, Plist::Matrix{Float64}) =
 const QUEUE_AUTO = Int32(0); const QUEUE_INDEX = Int32(1)
 set_queue_order!(prob::Problem, order::Integer) =
     check(ccall((:crnn_ctx_set_queue_order, LIB), Int32, (Ptr{Cvoid}, Int32), prob.ctx, Int32(order)), prob.ctx)
+"""Lanes per trajectory in the Rosenbrock23 adjoint kernel: 0 = auto (default), 1, 2 (a lane pair per trajectory: shards
+smaller than the chip, e.g. one GPU's share of a strongly-scaled batch)."""
+last_lanes_per_traj(prob::Problem) = ccall((:crnn_last_lanes_per_traj, LIB), Int32, (Ptr{Cvoid},), prob.ctx)
+set_lanes_per_traj!(prob::Problem, lanes::Integer) =
+    check(ccall((:crnn_ctx_set_lanes_per_traj, LIB), Int32, (Ptr{Cvoid}, Int32), prob.ctx, Int32(lanes)), prob.ctx)
 
 """`sol.destats.naccept / nreject` of every `solve` of the most recent ensemble launch over `first .+ (0:count-1)` (0-based)."""
 function last_step_counts(prob::Problem, first::Integer = 0, count::Integer = prob.B - first)

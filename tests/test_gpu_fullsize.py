@@ -197,8 +197,10 @@ def test_more_trajectories_than_lanes(case2_setup):
     B = 150001
     rep = -(-B // 8)
     big = dict(s, u0=np.tile(s["u0"], (rep, 1))[:B], data=np.tile(s["data"], (rep, 1, 1))[:B])
-    for mode in (2, 1):
+    for mode, lanes in ((2, 1), (2, 2), (1, 0)):   # adjoint with one / two lanes per trajectory (same kernel for both sizes), forward tangents
         node, small = _node(big, grad_mode=mode), _node(s, grad_mode=mode)
+        if lanes:
+            node.set_lanes_per_traj(lanes); small.set_lanes_per_traj(lanes)
         th, dth = p2vec_jac(node.pmap, 6, 3, p)
         _, loss, gsum, ret, nsv = node._solve(node._ctx, B, th, dth, 0, B, None, False)
         _, ls, gs, _, _ = small._solve(small._ctx, 8, th, dth, 0, 8, None, False)

@@ -16,7 +16,8 @@ Variants: O3 (the shipped flags), O2, O1, O3 + -DCRNN_ADJ_PROF (phase timers in 
 allocation and schedule, same arithmetic), O3 + -DCRNN_BOUNDS_CHECK (every indexed access of the adjoint kernels checked
 against its extent -- the stand-in for a device address sanitizer, whose instrumented runtime this image lacks; the build
 must also report ZERO violations).  Problems: the AutoTsit5(Rosenbrock23) composite on robertson (switches
-algorithm mid-run), Tsit5 adjoint on case1 and on case2, Rosenbrock23 adjoint on case2 (headline kernel) and robertson,
+algorithm mid-run), Tsit5 adjoint on case1 and on case2, Rosenbrock23 adjoint on case2 (one lane and two lanes per trajectory),
+case1's shape (two lanes, odd species count) and robertson,
 forward tangents on case2 -- per-trajectory losses, return codes, saved counts, accepted / rejected steps and the batch
 gradient in index order (crnn_ctx_set_queue_order(INDEX): the batch sum is then a function of the inputs alone).
 tests/test_gpu_crossbuild.py runs `run` on every GPU session.
@@ -104,12 +105,17 @@ def _problems():
         ("case1_tsit5_adjoint", PRESET_CASE1, c1, dict(solver=L.SOLVER_TSIT5, grad_mode=2)),
         ("case1_autotsit5_adjoint", PRESET_CASE1, c1, dict(solver=L.SOLVER_AUTOTSIT5, grad_mode=2)),
         ("case2_tsit5_adjoint", PRESET_CASE2, c2, dict(solver=L.SOLVER_TSIT5, grad_mode=2)),
-        ("case2_ros23_adjoint", PRESET_CASE2, c2, dict(grad_mode=2)),
+        ("case2_ros23_adjoint", PRESET_CASE2, c2, dict(grad_mode=2, lanes=1)),
+        ("case2_ros23_adjoint_2lanes", PRESET_CASE2, c2, dict(grad_mode=2, lanes=2)),
+        ("case1_ros23_adjoint_2lanes", PRESET_CASE1, c1, dict(solver=L.SOLVER_ROSENBROCK23, grad_mode=2, lanes=2)),
         ("rober_ros23_adjoint", PRESET_ROBER, rb, dict(rate_scale=sc, grad_mode=2)),
         ("case2_ros23_forward", PRESET_CASE2, c2, dict(grad_mode=1)),
     ]
     for name, preset, (ts, u0, data, ys, p), kw in specs:
+        lanes = kw.pop("lanes", None)
         node = NeuralODE(ODEProblem(preset, ts, **kw))
+        if lanes is not None:
+            node.set_lanes_per_traj(lanes)
         node.set_queue_order(L.QUEUE_INDEX)
         node.set_ensemble(u0, data, ys)
         out.append((name, node, p))
