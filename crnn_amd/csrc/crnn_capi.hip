@@ -101,13 +101,14 @@ struct AdjEntry {
 #endif
 // max_gen (measured, tools/kbench.py --lanes 1|2, MI355X): while the pairs fit the resident lanes the two-lane kernel always
 // wins (case2 4 096-32 768 trajectories: 0.28-0.32 ms against 0.48; case1's shape with Rosenbrock23, 16 384: 0.139 against
-// 0.176).  With TWO generations of pairs (32 769-65 536 trajectories) it still wins where step counts spread widely -- case2,
-// longest 48 steps against a mean of 29: the queue is longest-first, so the second generation is the short trajectories:
-// 49 152: 0.405 against 0.486 ms, 65 536: 0.483 against 0.503, 81 920: 0.61 against 0.63, 98 304: 0.68 against 0.66 -- and
-// loses where every trajectory takes the same few steps (case1 65 536: 0.304 against 0.215).
+// 0.176).  With TWO generations of pairs (32 769-65 536 trajectories) it depends on how widely the step counts spread -- the
+// queue is longest-first, so the second generation is the short trajectories: case2 at the trained parameters (longest 48
+// steps, mean 29): 49 152: 0.405 against 0.486 ms, 65 536: 0.483 against 0.503; at the reference's initialiser (22.6 steps,
+// nearly uniform) 65 536: 0.373 against 0.33; case1 (6 steps each) 65 536: 0.304 against 0.215.  AUTO therefore stops at
+// one generation; a host that knows its step counts spread asks for two lanes itself (crnn_ctx_set_lanes_per_traj).
 #define KADJ2(NS, NR, HT, MAXGEN) \
     { CRNN_SOLVER_ROSENBROCK23, NS, NR, HT, 0, (AdjKernelFn)crnn::ros23_adj2_kernel<NS, NR, (HT) != 0, kBlock, CRNN_ADJ2_OCC>, MAXGEN }
-const AdjEntry kAdj2Kernels[] = { KADJ2(6, 3, 1, 2), KADJ2(5, 4, 0, 1) };
+const AdjEntry kAdj2Kernels[] = { KADJ2(6, 3, 1, 1), KADJ2(5, 4, 0, 1) };
 // discrete-adjoint gradient kernels, one lane per trajectory: Rosenbrock23; Tsit5; the AutoTsit5(Rosenbrock23()) composite
 // (with a constant temperature state it never leaves Tsit5 -- auto_adj_kernel.hpp -- and shares that instantiation)
 const AdjEntry kAdjKernels[] = {

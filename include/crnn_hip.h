@@ -212,8 +212,9 @@ int32_t crnn_ctx_set_queue_order(crnn_ctx *ctx, int32_t order);
  * cross the pair with one DPP step; ~45 % fewer instructions on a step's critical path) -- for shards smaller than the
  * chip, e.g. one GPU's share of a strongly-scaled batch, where the second lane of a pair would otherwise be idle.
  * 0 = AUTO (default): 2 where a two-lane instantiation exists for the shape (nr < ns, no rate scaling: case1, case2) and the
- * pairs fit the resident lanes -- for case2, whose step counts spread widely, up to two generations of pairs (65 536
- * trajectories on 256 CUs: the queue is longest-first, the second generation is the short trajectories) -- else 1.  Same derivative either way; results agree to rounding (the species
+ * pairs fit the resident lanes (32 768 trajectories on 256 CUs), else 1.  Beyond that size two lanes still pay where step
+ * counts spread widely (case2 at trained parameters, 65 536 trajectories: -4 %) and cost where they do not (-13 % at the
+ * reference's initialiser): the host's call.  Same derivative either way; results agree to rounding (the species
  * sums are formed in a different order), per-trajectory outputs do not depend on the launch geometry. */
 int32_t crnn_ctx_set_lanes_per_traj(crnn_ctx *ctx, int32_t lanes);
 /* Lanes per trajectory the most recent adjoint gradient launch used (1 or 2; 0 if no adjoint launch has run, -1 for a null ctx). */
