@@ -45,6 +45,10 @@
  * control uses the primal values only (errnorm_sens = 0) or, optionally, the
  * ForwardDiff-style norm that includes the partials (errnorm_sens = 1,
  * [UNVERIFIED-DEP] DiffEqBase ODE_DEFAULT_NORM for Dual arrays).
+ * grad_adjoint = 1 (Rosenbrock23, errnorm_sens = 0) forms the SAME derivative
+ * backwards -- the discrete adjoint of the accepted steps, the algorithm the GPU
+ * kernels run -- with dense matrices; the two agree to 1e-15 of max |grad|
+ * (tests/test_oracle_golden.py) and bench.py times both as the CPU baseline.
  *
  * Layout conventions (identical to the C ABI in include/crnn_hip.h):
  *   theta = [ w_in (n x nr, column-major) | w_b (nr) | w_out (ns x nr, col-major) ]
@@ -73,7 +77,9 @@ typedef struct orc_problem {
     int32_t maxiters;
     int32_t errnorm_sens;       /* 0 primal-only norm, 1 ForwardDiff-style (/ length(u)), 2 ForwardDiff-style (/ totallength(u)) */
     int32_t solver;             /* 0 Rosenbrock23, 1 Tsit5 (case1/case1.jl:28), 2 AutoTsit5(Rosenbrock23) (case2/case2.jl:26) */
-    int32_t pad_;
+    int32_t grad_adjoint;       /* 1: Rosenbrock23 gradients by the discrete adjoint of the accepted steps (solve_one_adj) instead
+                                   of forward tangents -- the SAME derivative, the algorithm the GPU runs; CPU-baseline timing
+                                   and an independent check of the adjoint formulas (bench.py, tests/test_oracle_golden.py) */
     double lb, ub;              /* log-clamp window; ub may be +inf */
     double inv_R;               /* -1/R for the Arrhenius row (has_temp) */
     double rate_scale[ORC_MAXN];/* dydt_scale (robertson), else 1 */
@@ -441,6 +447,20 @@ static double init_dt_sens(const orc_problem *pb, const double *th, const double
 /* ------------------------------------------------------------------------ */
 typedef struct orc_stats { int64_t naccept, nreject; } orc_stats;
 
+/* step tape of the adjoint path: (t, dt, u[n]) of every accepted step, appended by solve_one_ws when armed */
+typedef struct orc_tape { double *rec; size_t n_rec, cap; int width; double t_end; } orc_tape;
+static _Thread_local orc_tape *g_tape = NULL;
+static void tape_push(orc_tape *tp, double t, double dt, const double *u, int n) {
+    if (tp->n_rec == tp->cap) {
+        tp->cap = tp->cap ? 2 * tp->cap : 64;
+        tp->rec = (double *)realloc(tp->rec, sizeof(double) * tp->cap * (size_t)tp->width);
+    }
+    double *r = tp->rec + tp->n_rec * (size_t)tp->width;
+    r[0] = t; r[1] = dt;
+    memcpy(r + 2, u, sizeof(double) * (size_t)n);
+    tp->n_rec++;
+}
+
 /* workspace: n*P*7 + P doubles (zeroed here) */
 static int solve_one_ws(const orc_problem *pb, const double *th, const double *dth, int P,
                         const double *u0, const double *tsave, int nsave,
@@ -598,6 +618,7 @@ static int solve_one_ws(const orc_problem *pb, const double *th, const double *d
             if (q >= pb->qsteady_min && q <= pb->qsteady_max) q = 1.0;
             qold = fmax(EEst, pb->qoldinit);
             double tnew = last ? tend : t + dt;
+            if (g_tape) { tape_push(g_tape, t, dt, u, n); g_tape->t_end = tnew; }
             /* saveat via the Rosenbrock23 dense output:
                u(t+Theta dt) = u + dt (c1 k1 + c2 k2), c1 = Th(1-Th)/(1-2d), c2 = Th(Th-2d)/(1-2d) */
             while (jsave < nsave && tsave[jsave] <= tnew) {
@@ -1086,12 +1107,162 @@ static int solve_one_auto(const orc_problem *pb, const double *th, const double 
     return retcode;
 }
 
+/* ------------------------------------------------------------------------ */
+/* Rosenbrock23 gradient by the DISCRETE ADJOINT of the accepted steps: the  */
+/* same derivative as the forward tangents of solve_one_ws (dt, the accept / */
+/* reject decisions and the saveat weights held fixed), formed backwards.   */
+/* Forward sweep = solve_one_ws without tangents, recording (t, dt, u) per   */
+/* accepted step; reverse sweep, per step with lam = d loss / d u_{n+1}:     */
+/*   re-form k1 = W^-1 f(u_n), u_mid, dk = W^-1 (f(u_mid) - k1);             */
+/*   seeds of the save points inside the step: A, B1, B2 (d/d u_n, k1, k2);  */
+/*   kb2 = dt lam + B2, v = W^-T kb2, kb1 = B1 + kb2 - v;                    */
+/*   u_mid: gb = f_u(u_mid)^T v, thb += f_theta(u_mid)^T v, kb1 += dt/2 gb;  */
+/*   w = W^-T kb1;                                                           */
+/*   u_n: lam <- lam + A + gb + d/du [w.f + gam (v.J dk + w.J k1)],          */
+/*        thb += d/dtheta [ the same bracket ]                               */
+/* with J = D_sc W_out D_r W_in^T D_g, so every contraction is O(n nr).      */
+/* This is what crnn_amd/csrc/ros23_adj_kernel.hpp runs on the GPU; here it  */
+/* is written with dense n x n matrices and the temperature as a state.      */
+/* ------------------------------------------------------------------------ */
+static void rates_at(const orc_problem *pb, const double *th, const double *u, double *x, double *g, double *h, double *r, double *f) {
+    const int n = N_(pb), ns = pb->ns, nr = pb->nr;
+    const double *w_in = W_IN(pb, th), *w_b = W_B(pb, th), *w_out = W_OUT(pb, th);
+    feat(pb, u, x, g, h);
+    for (int j = 0; j < nr; ++j) {
+        double z = w_b[j];
+        for (int i = 0; i < n; ++i) z += w_in[i + n * j] * x[i];
+        r[j] = exp(z);
+    }
+    for (int i = 0; i < n; ++i) f[i] = 0.0;
+    for (int i = 0; i < ns; ++i) {
+        double a = 0.0;
+        for (int j = 0; j < nr; ++j) a += w_out[i + ns * j] * r[j];
+        f[i] = a * pb->rate_scale[i];
+    }
+}
+
+static int solve_one_adj(const orc_problem *pb, const double *th, const double *dth, int P,
+                         const double *u0, const double *tsave, int nsave, const double *data, double *pred,
+                         double *loss_out, double *grad /* [P] accumulated += */, int32_t *n_saved_out, orc_stats *st) {
+    const int n = N_(pb), ns = pb->ns, nr = pb->nr, nobs = pb->n_obs, nth = orc_n_theta(pb);
+    const double d = 1.0 / (2.0 + sqrt(2.0));
+    const double *w_in = W_IN(pb, th), *w_out = W_OUT(pb, th);
+    orc_tape tp = {NULL, 0, 0, n + 2, pb->t0};
+    int32_t jsave_end = 0;
+    double loss = 0.0;
+    g_tape = &tp;
+    const int rc = solve_one_ws(pb, th, NULL, 0, u0, tsave, nsave, data, pred, NULL, &loss, NULL, &jsave_end, st, NULL);
+    g_tape = NULL;
+    if (loss_out) *loss_out = loss;
+    if (n_saved_out) *n_saved_out = jsave_end;
+    if (P > 0 && grad && jsave_end > 0 && tp.n_rec > 0) {
+        double thb[ORC_MAXTH];
+        for (int m = 0; m < nth; ++m) thb[m] = 0.0;
+        double *b_in = thb, *b_b = thb + n * nr, *b_out = thb + (n + 1) * nr;
+        double lam[ORC_MAXN] = {0};
+        int jsave = jsave_end;
+        const int jlo = (nsave > 0 && tsave[0] == pb->t0) ? 1 : 0;   /* the saved initial point carries no gradient */
+        double tnew = tp.t_end;
+        for (long s = (long)tp.n_rec - 1; s >= 0; --s) {
+            const double *rec = tp.rec + (size_t)s * tp.width;
+            const double tn = rec[0], h = rec[1], *un = rec + 2;
+            const double gam = d * h;
+            double x0[ORC_MAXN], g0[ORC_MAXN], h0[ORC_MAXN], r0[ORC_MAXR], f0[ORC_MAXN];
+            double x1[ORC_MAXN], g1[ORC_MAXN], h1[ORC_MAXN], r1[ORC_MAXR], f1[ORC_MAXN];
+            double J[ORC_MAXN * ORC_MAXN], W[ORC_MAXN * ORC_MAXN], Wt[ORC_MAXN * ORC_MAXN];
+            int piv[ORC_MAXN], pivt[ORC_MAXN];
+            rates_at(pb, th, un, x0, g0, h0, r0, f0);
+            orc_jac(pb, th, un, J);
+            for (int c = 0; c < n; ++c) for (int i = 0; i < n; ++i) {
+                W[i + n * c] = (i == c ? 1.0 : 0.0) - gam * J[i + n * c];
+                Wt[c + n * i] = W[i + n * c];
+            }
+            if (lu_factor(n, W, piv) != 0 || lu_factor(n, Wt, pivt) != 0) break;
+            double k1[ORC_MAXN], dk[ORC_MAXN], u1[ORC_MAXN];
+            memcpy(k1, f0, sizeof(double) * n); lu_solve(n, W, piv, k1);
+            for (int i = 0; i < n; ++i) u1[i] = un[i] + 0.5 * h * k1[i];
+            rates_at(pb, th, u1, x1, g1, h1, r1, f1);
+            for (int i = 0; i < n; ++i) dk[i] = f1[i] - k1[i];
+            lu_solve(n, W, piv, dk);
+            /* loss seeds of the save points inside (tn, tnew] */
+            double A[ORC_MAXN] = {0}, B1[ORC_MAXN] = {0}, B2[ORC_MAXN] = {0};
+            while (jsave > jlo && tsave[jsave - 1] > tn) {
+                const double ts = tsave[jsave - 1];
+                const int at_end = (ts == tnew);
+                const double Th = at_end ? 1.0 : (ts - tn) / h;
+                const double c1 = at_end ? 0.0 : Th * (1.0 - Th) / (1.0 - 2.0 * d);
+                const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d) / (1.0 - 2.0 * d);
+                for (int io = 0; io < nobs; ++io) {
+                    const int i = pb->i_obs[io];
+                    double v = un[i] + h * (c1 * k1[i] + c2 * (k1[i] + dk[i]));
+                    double mask = 1.0;
+                    if (pb->clamp_pred) { mask = dclamp(v, -pb->ub, pb->ub); v = clampd(v, -pb->ub, pb->ub); }
+                    const double r_ = (data[io + nobs * (jsave - 1)] - v) / pb->yscale[io];
+                    double w_ = (pb->loss_kind == 0) ? -dabs_(r_) : -2.0 * r_;
+                    w_ *= mask / pb->yscale[io];
+                    A[i] += w_; B1[i] += w_ * h * c1; B2[i] += w_ * h * c2;
+                }
+                --jsave;
+            }
+            /* adjoint of the step */
+            double v[ORC_MAXN], ub[ORC_MAXN], kb1[ORC_MAXN];
+            for (int i = 0; i < n; ++i) { v[i] = h * lam[i] + B2[i]; ub[i] = lam[i] + A[i]; kb1[i] = B1[i] + v[i]; }
+            lu_solve(n, Wt, pivt, v);
+            for (int i = 0; i < n; ++i) kb1[i] -= v[i];
+            double av[ORC_MAXR], rho1[ORC_MAXR];
+            for (int j = 0; j < nr; ++j) {
+                double a = 0.0;
+                for (int i = 0; i < ns; ++i) a += v[i] * pb->rate_scale[i] * w_out[i + ns * j];
+                av[j] = a; rho1[j] = a * r1[j];
+            }
+            for (int c = 0; c < n; ++c) {
+                double um = 0.0;
+                for (int j = 0; j < nr; ++j) um += rho1[j] * w_in[c + n * j];
+                const double gb = um * g1[c];
+                ub[c] += gb; kb1[c] += 0.5 * h * gb;
+            }
+            lu_solve(n, Wt, pivt, kb1);     /* w */
+            double s1[ORC_MAXN] = {0}, s2[ORC_MAXN] = {0};
+            for (int j = 0; j < nr; ++j) {
+                double aw = 0.0, q1 = 0.0, qd = 0.0;
+                for (int i = 0; i < ns; ++i) aw += kb1[i] * pb->rate_scale[i] * w_out[i + ns * j];
+                for (int c = 0; c < n; ++c) { const double wg = w_in[c + n * j] * g0[c]; q1 += wg * k1[c]; qd += wg * dk[c]; }
+                const double c1j = 1.0 + gam * q1, czd = gam * qd;
+                const double pv = av[j] * gam * r0[j], pw = aw * r0[j], gpw = gam * pw;
+                const double beta = pw * c1j + pv * qd;
+                b_b[j] += beta + rho1[j];
+                for (int c = 0; c < n; ++c) {
+                    const double mm = pv * dk[c] + gpw * k1[c];
+                    b_in[c + n * j] += rho1[j] * x1[c] + beta * x0[c] + g0[c] * mm;
+                    s1[c] += beta * w_in[c + n * j];
+                    s2[c] += w_in[c + n * j] * mm;
+                }
+                const double ca = r0[j] * czd + r1[j], cb = r0[j] * c1j;
+                for (int i = 0; i < ns; ++i)
+                    b_out[i + ns * j] += pb->rate_scale[i] * (v[i] * ca + kb1[i] * cb);
+            }
+            for (int c = 0; c < n; ++c) lam[c] = ub[c] + g0[c] * s1[c] + h0[c] * s2[c];
+            tnew = tn;
+        }
+        const double denom = (double)nobs * (double)jsave_end;
+        for (int k = 0; k < P; ++k) {
+            double a = 0.0;
+            for (int m = 0; m < nth; ++m) a += dth[m + (size_t)nth * k] * thb[m];
+            grad[k] += a / denom;
+        }
+    }
+    free(tp.rec);
+    return rc;
+}
+
 static int solve_dispatch(const orc_problem *pb, const double *th, const double *dth, int P,
                           const double *u0, const double *tsave, int nsave,
                           const double *data, double *pred, double *dpred,
                           double *loss_out, double *grad, int32_t *n_saved_out, orc_stats *st, double *ws) {
     if (pb->solver == 2) return solve_one_auto(pb, th, dth, P, u0, tsave, nsave, data, pred, dpred, loss_out, grad, n_saved_out, st, ws, NULL);
     if (pb->solver == 1) return solve_one_tsit5(pb, th, dth, P, u0, tsave, nsave, data, pred, dpred, loss_out, grad, n_saved_out, st, ws);
+    if (pb->grad_adjoint && P > 0 && !pb->errnorm_sens && !dpred)
+        return solve_one_adj(pb, th, dth, P, u0, tsave, nsave, data, pred, loss_out, grad, n_saved_out, st);
     return solve_one_ws(pb, th, dth, P, u0, tsave, nsave, data, pred, dpred, loss_out, grad, n_saved_out, st, ws);
 }
 
