@@ -39,6 +39,14 @@ int main(void) {
             int rc = solver == 2 ? orc_solve_one_auto(&pb, th, dth, P, u0, ts, D, data, pred, NULL, &loss, grad, &nsv, &st, sa)
                                  : orc_solve_one(&pb, th, dth, P, u0, ts, D, data, pred, NULL, &loss, grad, &nsv, &st);
             if (rc < 0 || rc > 3 || nsv < 1 || !(loss == loss)) ++fails;
+            if (solver == 0) {   /* the discrete-adjoint gradient path (grad_adjoint = 1): step tape, transposed solves */
+                double grad2[64] = {0}, loss2 = 0;
+                pb.grad_adjoint = 1;
+                const int rc2 = orc_solve_one(&pb, th, dth, P, u0, ts, D, data, pred, NULL, &loss2, grad2, &nsv, &st);
+                pb.grad_adjoint = 0;
+                if (rc2 != rc || loss2 != loss) ++fails;
+                for (int k = 0; k < P; ++k) if (!(fabs(grad2[k] - grad[k]) <= 1e-9 * (1.0 + fabs(grad[k])))) { ++fails; break; }
+            }
             (void)n;
             free(dth);
         }
