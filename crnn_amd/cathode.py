@@ -151,6 +151,31 @@ class CathodeUQ:
         g = grad[:, i_exp, :] / (self.normalizer[i_exp, NORM_COL] ** 2)
         return float(loss[:, i_exp].mean()), -g
 
+    # ---- device-resident SVGD loop (crnn_cathode.jl:36-50) ----
+    def set_particles(self, p):
+        """Upload the normalised particles p [N, 17]; they stay on the device between svgd_step calls."""
+        p = np.ascontiguousarray(np.atleast_2d(np.asarray(p, float))[:, :17])
+        self._check(lib.crnn_cathode_set_particles(self.h, dptr(p), dptr(np.ascontiguousarray(self.p_scales)), p.shape[0]))
+        self._n_particles = p.shape[0]
+
+    def svgd_step(self, i_exp, stepsize, h=-1.0, look=True):
+        """One iteration of the reference loop for heating rate i_exp on the device-resident particles: dlnprob (solve +
+        per-particle gradients, one launch) and the SVGD move, enqueued back to back.  look=True returns
+        (mean loss, h, {solve_ms, svgd_ms}); look=False reads nothing back (the step stays enqueued)."""
+        norm2 = np.ascontiguousarray(self.normalizer[i_exp, NORM_COL] ** 2, np.float64)     # Normalizer[i_exp, column of p_k]^2
+        if not look:
+            self._check(lib.crnn_cathode_svgd_step(self.h, int(i_exp), dptr(norm2), float(stepsize), float(h), None, None, None))
+            return None
+        loss, hh = C.c_double(0.0), C.c_double(0.0)
+        ms = np.zeros(2)
+        self._check(lib.crnn_cathode_svgd_step(self.h, int(i_exp), dptr(norm2), float(stepsize), float(h), C.byref(loss), C.byref(hh), dptr(ms)))
+        return loss.value, hh.value, dict(solve_ms=float(ms[0]), svgd_ms=float(ms[1]))
+
+    def particles(self):
+        p = np.zeros((self._n_particles, 17))
+        self._check(lib.crnn_cathode_get_particles(self.h, dptr(p)))
+        return p
+
     def comm_init(self):
         """Attach the library's own RCCL communicator for the particle-shard exchange (crnn_cathode_allgather); the unique
         id travels through the default torch.distributed group.  One process per GPU."""

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -918,6 +919,27 @@ int32_t fill_stats(Ctx *c, const double *red_host, int npart, crnn_stats *st) {
 
 // ---- cathode-UQ context (entry points at the end of the file) ----
 namespace {
+// Workspace of an SVGD move (device buffers sized for N x dim), kept between calls: crnn_svgd_update caches one per device,
+// a cathode ctx owns one for its device-resident loop.  Nothing is allocated in steady state.
+struct SvgdWs {
+    int64_t N = 0;
+    int dim = 0, nchunk = 0;
+    double *d_p = nullptr, *d_g = nullptr, *d_new = nullptr, *d_dt = nullptr, *d_rep = nullptr, *d_part = nullptr;
+    unsigned int *d_hist = nullptr;
+    crnn::SvgdSel *d_sel = nullptr;
+    double *d_dist = nullptr;              // the N (N - 1) / 2 pair distances (null: too many to store -- recomputed per pass)
+    unsigned long long *d_cnt = nullptr;   // svgd_next_kernel's { #less, #equal, min above }
+    void release() {
+        for (void *q : {(void *)d_p, (void *)d_g, (void *)d_new, (void *)d_dt, (void *)d_rep, (void *)d_part, (void *)d_hist, (void *)d_sel,
+                        (void *)d_dist, (void *)d_cnt})
+            if (q) (void)hipFree(q);
+        *this = SvgdWs{};
+    }
+};
+
+hipError_t svgd_ws_reserve(SvgdWs &w, int64_t N, int dim, bool io_buffers);
+hipError_t svgd_enqueue(SvgdWs &w, hipStream_t stream, const double *d_p, const double *d_g, int64_t N, int dim, double stepsize,
+                        double h, double *d_new, double *d_dt, double *d_rep);
 struct CathCtx {
     crnn_cathode_config cfg{};
     std::string err;
@@ -940,6 +962,14 @@ struct CathCtx {
     int rank = 0, world = 1;
     double *d_ag_send = nullptr, *d_ag_recv = nullptr;
     size_t ag_send_cap = 0, ag_recv_cap = 0;
+    int adj_occ = 0, fwd_occ = 0;
+    // device-resident SVGD loop (crnn_cathode_set_particles / crnn_cathode_svgd_step)
+    double *d_pn = nullptr, *d_pn2 = nullptr, *d_lnp = nullptr, *d_pscales = nullptr;   // particles (current / moved), lnpgrad, [p_scales(17) | mean loss, n_failed]
+    size_t cap_pn = 0;
+    int64_t n_particles = 0;
+    double h_norm2[CRNN_CATHODE_NP] = {};
+    hipEvent_t ev2 = nullptr, ev3 = nullptr;
+    SvgdWs svgd;
 };
 int32_t cfail(CathCtx *c, const std::string &msg) {
     g_last_error = msg;
@@ -1795,10 +1825,14 @@ void crnn_cathode_destroy(crnn_cathode_ctx *ctx) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
     void *ptrs[] = {c->d_ts, c->d_dbar, c->d_d2bar, c->d_beta, c->d_D, c->d_queue, c->d_theta, c->d_loss, c->d_grad,
-                    c->d_hrr, c->d_ret, c->d_nsv, c->d_nacc, c->d_nrej, c->d_tape, c->d_overflow, c->d_ag_send, c->d_ag_recv};
+                    c->d_hrr, c->d_ret, c->d_nsv, c->d_nacc, c->d_nrej, c->d_tape, c->d_overflow, c->d_ag_send, c->d_ag_recv,
+                    c->d_pn, c->d_pn2, c->d_lnp, c->d_pscales};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    c->svgd.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev2) (void)hipEventDestroy(c->ev2);
+    if (c->ev3) (void)hipEventDestroy(c->ev3);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1838,18 +1872,14 @@ int32_t crnn_cathode_set_obs(crnn_cathode_ctx *ctx, int32_t n_sets, int32_t Dmax
     return 0;
 }
 
-int32_t crnn_cathode_solve(crnn_cathode_ctx *ctx, const double *theta, int64_t n_part, double *loss, double *grad,
-                           double *hrr, int32_t *retcode, int32_t *n_saved, crnn_stats *stats) {
-    CathCtx *c = reinterpret_cast<CathCtx *>(ctx);
-    if (!c) return cfail(nullptr, "null ctx");
-    if (!theta || n_part < 1) return cfail(c, "crnn_cathode_solve: bad theta / n_part");
-    if (c->n_sets < 1) return cfail(c, "crnn_cathode_solve: no observation sets (crnn_cathode_set_obs)");
-    CHIP(c, hipSetDevice(c->cfg.device));
-    const int64_t ntraj = n_part * c->n_sets;
-    if ((size_t)n_part > c->cap_part) {
-        if (cgrow(c, &c->d_theta, (size_t)n_part * CRNN_CATHODE_NP)) return -1;
-        c->cap_part = (size_t)n_part;
-    }
+}  // extern "C" (interrupted)
+namespace {
+// Device-level run: theta [n_part][17] already in c->d_theta; integrates every particle for the observation sets
+// [set_first, set_first + set_count) (trajectory tr = particle * set_count + (set - set_first)) and leaves loss / grad / hrr /
+// retcode / n_saved / step counts in the ctx's device buffers.  Adjoint first (unless grad_mode says forward); a trajectory
+// that outruns the tape makes the call repeat with forward tangents (one 4-byte read-back decides).
+int32_t cath_run(CathCtx *c, int64_t n_part, int set_first, int set_count, bool want_grad, bool want_hrr) {
+    const int64_t ntraj = n_part * set_count;
     if ((size_t)ntraj > c->cap_traj) {
         if (cgrow(c, &c->d_loss, (size_t)ntraj) || cgrow(c, &c->d_grad, (size_t)ntraj * CRNN_CATHODE_NP) ||
             cgrow(c, &c->d_ret, (size_t)ntraj) || cgrow(c, &c->d_nsv, (size_t)ntraj) || cgrow(c, &c->d_nacc, (size_t)ntraj) ||
@@ -1857,32 +1887,34 @@ int32_t crnn_cathode_solve(crnn_cathode_ctx *ctx, const double *theta, int64_t n
             return -1;
         c->cap_traj = (size_t)ntraj;
     }
-    if (hrr && (size_t)ntraj * c->Dmax > c->cap_hrr) {
+    if (want_hrr && (size_t)ntraj * c->Dmax > c->cap_hrr) {
         if (cgrow(c, &c->d_hrr, (size_t)ntraj * c->Dmax)) return -1;
         c->cap_hrr = (size_t)ntraj * c->Dmax;
     }
-    CHIP(c, hipMemcpyAsync(c->d_theta, theta, sizeof(double) * (size_t)n_part * CRNN_CATHODE_NP, hipMemcpyHostToDevice, c->stream));
     CHIP(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), c->stream));
-    if (hrr) CHIP(c, hipMemsetAsync(c->d_hrr, 0, sizeof(double) * (size_t)ntraj * c->Dmax, c->stream));
+    if (want_hrr) CHIP(c, hipMemsetAsync(c->d_hrr, 0, sizeof(double) * (size_t)ntraj * c->Dmax, c->stream));
     crnn::CathodeParams prm{};
-    prm.theta = c->d_theta; prm.ts = c->d_ts; prm.dbar = c->d_dbar; prm.d2bar = c->d_d2bar; prm.beta = c->d_beta; prm.D = c->d_D;
-    prm.loss = c->d_loss; prm.grad = c->d_grad; prm.hrr = hrr ? c->d_hrr : nullptr;
+    prm.theta = c->d_theta;
+    prm.ts = c->d_ts + (size_t)set_first * c->Dmax; prm.dbar = c->d_dbar + (size_t)set_first * c->Dmax;
+    prm.d2bar = c->d_d2bar + (size_t)set_first * c->Dmax; prm.beta = c->d_beta + set_first; prm.D = c->d_D + set_first;
+    prm.loss = c->d_loss; prm.grad = c->d_grad; prm.hrr = want_hrr ? c->d_hrr : nullptr;
     prm.retcode = c->d_ret; prm.n_saved = c->d_nsv; prm.n_accept = c->d_nacc; prm.n_reject = c->d_nrej;
     prm.queue = c->d_queue;
-    prm.n_traj = ntraj; prm.n_sets = c->n_sets; prm.Dmax = c->Dmax; prm.maxiters = c->cfg.maxiters;
-    prm.want_grad = grad ? 1 : 0;
+    prm.n_traj = ntraj; prm.n_sets = set_count; prm.Dmax = c->Dmax; prm.maxiters = c->cfg.maxiters;
+    prm.want_grad = want_grad ? 1 : 0;
     prm.lb = c->cfg.lb_clamp; prm.T0 = c->cfg.T0; prm.atol = c->cfg.atol; prm.rtol = c->cfg.rtol;
     prm.gamma = c->cfg.gamma; prm.qmin = c->cfg.qmin; prm.qmax = c->cfg.qmax; prm.beta1 = c->cfg.beta1; prm.beta2 = c->cfg.beta2;
     prm.qsteady_min = c->cfg.qsteady_min; prm.qsteady_max = c->cfg.qsteady_max; prm.qoldinit = c->cfg.qoldinit;
     constexpr int kB = 256;
     bool done = false;
-    if (grad && c->cfg.grad_mode != CRNN_GRAD_FORWARD) {
+    if (want_grad && c->cfg.grad_mode != CRNN_GRAD_FORWARD) {
         // discrete adjoint (cathode_adj_kernel): a wavefront takes 64 particles of one heating rate
-        int occ = 0;
-        CHIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)crnn::cathode_adj_kernel<kB>, kB, 0));
-        if (occ < 1) occ = 1;
-        const int64_t n_batches = ((n_part + 63) / 64) * c->n_sets;
-        const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((n_batches + 3) / 4, (int64_t)c->num_cu * occ));
+        if (c->adj_occ < 1) {
+            CHIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->adj_occ, (const void *)crnn::cathode_adj_kernel<kB>, kB, 0));
+            if (c->adj_occ < 1) c->adj_occ = 1;
+        }
+        const int64_t n_batches = ((n_part + 63) / 64) * set_count;
+        const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((n_batches + 3) / 4, (int64_t)c->num_cu * c->adj_occ));
         const size_t lanes = (size_t)nblk * kB;
         if (c->tape_budget == 0) {
             size_t fr = 0, tot = 0;
@@ -1910,15 +1942,61 @@ int32_t crnn_cathode_solve(crnn_cathode_ctx *ctx, const double *theta, int64_t n
         if (!done) CHIP(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), c->stream));
     }
     if (!done) {
-        int occ = 0;
-        CHIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)crnn::cathode_kernel<kB>, kB, 0));
-        if (occ < 1) occ = 1;
-        int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((ntraj + kB - 1) / kB, (int64_t)c->num_cu * occ));
+        if (c->fwd_occ < 1) {
+            CHIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->fwd_occ, (const void *)crnn::cathode_kernel<kB>, kB, 0));
+            if (c->fwd_occ < 1) c->fwd_occ = 1;
+        }
+        int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((ntraj + kB - 1) / kB, (int64_t)c->num_cu * c->fwd_occ));
         CHIP(c, hipEventRecord(c->ev0, c->stream));
         hipLaunchKernelGGL(crnn::cathode_kernel<kB>, dim3(nblk), dim3(kB), 0, c->stream, prm);
         CHIP(c, hipGetLastError());
         CHIP(c, hipEventRecord(c->ev1, c->stream));
     }
+    return 0;
+}
+
+// theta = p .* p_scales (network.jl:152-157: parameters pre-multiplied by p_scales) for the device-resident particles
+__global__ void cath_theta_kernel(const double *__restrict__ p, const double *__restrict__ p_scales, int64_t n, double *__restrict__ theta) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx < n) theta[idx] = p[idx] * p_scales[idx % CRNN_CATHODE_NP];
+}
+// lnpgrad[:, k] = -(d loss / d p_k) / normalizer2[k] = -(d loss / d theta_k) p_scales[k] / normalizer2[k]  (dlnprob, network.jl:234-250);
+// block 0 also forms the mean loss and the number of failed solves in fixed order: out2 = { mean loss, n_failed }
+__global__ __launch_bounds__(256) void cath_lnpgrad_kernel(const double *__restrict__ grad, const double *__restrict__ p_scales, int64_t n_part,
+                                                           const double *__restrict__ norm2, double *__restrict__ lnp, const double *__restrict__ loss,
+                                                           const int32_t *__restrict__ ret, double *out2) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx < n_part * CRNN_CATHODE_NP) lnp[idx] = -(grad[idx] * p_scales[idx % CRNN_CATHODE_NP]) / norm2[idx % CRNN_CATHODE_NP];
+    if (blockIdx.x == 0) {
+        __shared__ double sh[256], shf[256];
+        double a = 0.0, f = 0.0;
+        for (int64_t i = threadIdx.x; i < n_part; i += 256) { a += loss[i]; f += ret[i] != 0 ? 1.0 : 0.0; }
+        sh[threadIdx.x] = a; shf[threadIdx.x] = f;
+        __syncthreads();
+        for (int s_ = 128; s_ > 0; s_ >>= 1) {
+            if ((int)threadIdx.x < s_) { sh[threadIdx.x] += sh[threadIdx.x + s_]; shf[threadIdx.x] += shf[threadIdx.x + s_]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { out2[0] = sh[0] / (double)n_part; out2[1] = shf[0]; }
+    }
+}
+}  // namespace
+extern "C" {
+
+int32_t crnn_cathode_solve(crnn_cathode_ctx *ctx, const double *theta, int64_t n_part, double *loss, double *grad,
+                           double *hrr, int32_t *retcode, int32_t *n_saved, crnn_stats *stats) {
+    CathCtx *c = reinterpret_cast<CathCtx *>(ctx);
+    if (!c) return cfail(nullptr, "null ctx");
+    if (!theta || n_part < 1) return cfail(c, "crnn_cathode_solve: bad theta / n_part");
+    if (c->n_sets < 1) return cfail(c, "crnn_cathode_solve: no observation sets (crnn_cathode_set_obs)");
+    CHIP(c, hipSetDevice(c->cfg.device));
+    const int64_t ntraj = n_part * c->n_sets;
+    if ((size_t)n_part > c->cap_part) {
+        if (cgrow(c, &c->d_theta, (size_t)n_part * CRNN_CATHODE_NP)) return -1;
+        c->cap_part = (size_t)n_part;
+    }
+    CHIP(c, hipMemcpyAsync(c->d_theta, theta, sizeof(double) * (size_t)n_part * CRNN_CATHODE_NP, hipMemcpyHostToDevice, c->stream));
+    if (cath_run(c, n_part, 0, c->n_sets, grad != nullptr, hrr != nullptr)) return -1;
     std::vector<int32_t> h_ret((size_t)ntraj), h_nacc((size_t)ntraj), h_nrej((size_t)ntraj);
     if (loss) CHIP(c, hipMemcpyAsync(loss, c->d_loss, sizeof(double) * ntraj, hipMemcpyDeviceToHost, c->stream));
     if (grad) CHIP(c, hipMemcpyAsync(grad, c->d_grad, sizeof(double) * ntraj * CRNN_CATHODE_NP, hipMemcpyDeviceToHost, c->stream));
@@ -1935,6 +2013,88 @@ int32_t crnn_cathode_solve(crnn_cathode_ctx *ctx, const double *theta, int64_t n
         float ms = 0.f;
         CHIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
         stats->kernel_ms = ms;
+    }
+    return 0;
+}
+
+// ---- device-resident SVGD loop of the Bayesian ensemble (crnn_cathode.jl:36-50): particles, gradients and the move stay on
+// the device; per iteration one solve launch over the particles of ONE heating rate (the reference draws i_exp at random)
+// and the SVGD move, enqueued back to back.
+int32_t crnn_cathode_set_particles(crnn_cathode_ctx *ctx, const double *p, const double *p_scales, int64_t n_part) {
+    CathCtx *c = reinterpret_cast<CathCtx *>(ctx);
+    if (!c) return cfail(nullptr, "null ctx");
+    if (!p || !p_scales || n_part < 2) return cfail(c, "crnn_cathode_set_particles: bad arguments (n_part >= 2)");
+    CHIP(c, hipSetDevice(c->cfg.device));
+    CHIP(c, hipStreamSynchronize(c->stream));
+    if ((size_t)n_part > c->cap_part) {
+        if (cgrow(c, &c->d_theta, (size_t)n_part * CRNN_CATHODE_NP)) return -1;
+        c->cap_part = (size_t)n_part;
+    }
+    if ((size_t)n_part > c->cap_pn) {
+        if (cgrow(c, &c->d_pn, (size_t)n_part * CRNN_CATHODE_NP) || cgrow(c, &c->d_pn2, (size_t)n_part * CRNN_CATHODE_NP) ||
+            cgrow(c, &c->d_lnp, (size_t)n_part * CRNN_CATHODE_NP))
+            return -1;
+        c->cap_pn = (size_t)n_part;
+    }
+    if (!c->d_pscales) CHIP(c, hipMalloc((void **)&c->d_pscales, sizeof(double) * (2 * CRNN_CATHODE_NP + 2)));   // [p_scales | mean loss, n_failed | normalizer2]
+    CHIP(c, svgd_ws_reserve(c->svgd, n_part, CRNN_CATHODE_NP, false));
+    CHIP(c, hipMemcpyAsync(c->d_pn, p, sizeof(double) * (size_t)n_part * CRNN_CATHODE_NP, hipMemcpyHostToDevice, c->stream));
+    CHIP(c, hipMemcpyAsync(c->d_pscales, p_scales, sizeof(double) * CRNN_CATHODE_NP, hipMemcpyHostToDevice, c->stream));
+    CHIP(c, hipStreamSynchronize(c->stream));
+    c->n_particles = n_part;
+    return 0;
+}
+
+int32_t crnn_cathode_get_particles(crnn_cathode_ctx *ctx, double *p) {
+    CathCtx *c = reinterpret_cast<CathCtx *>(ctx);
+    if (!c) return cfail(nullptr, "null ctx");
+    if (!p || c->n_particles < 2) return cfail(c, "crnn_cathode_get_particles: no particles on the device (crnn_cathode_set_particles)");
+    CHIP(c, hipSetDevice(c->cfg.device));
+    CHIP(c, hipMemcpyAsync(p, c->d_pn, sizeof(double) * (size_t)c->n_particles * CRNN_CATHODE_NP, hipMemcpyDeviceToHost, c->stream));
+    CHIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int32_t crnn_cathode_svgd_step(crnn_cathode_ctx *ctx, int32_t i_set, const double *normalizer2 /*[17]*/, double stepsize, double h,
+                               double *loss_mean, double *h_out, double *ms /* [2]: solve kernel, SVGD move; may be NULL */) {
+    CathCtx *c = reinterpret_cast<CathCtx *>(ctx);
+    if (!c) return cfail(nullptr, "null ctx");
+    if (c->n_particles < 2) return cfail(c, "crnn_cathode_svgd_step: no particles on the device (crnn_cathode_set_particles)");
+    if (i_set < 0 || i_set >= c->n_sets) return cfail(c, "crnn_cathode_svgd_step: i_set out of range");
+    if (!normalizer2) return cfail(c, "crnn_cathode_svgd_step: normalizer2 is null");
+    for (int k = 0; k < CRNN_CATHODE_NP; ++k)
+        if (!(normalizer2[k] > 0)) return cfail(c, "crnn_cathode_svgd_step: normalizer2 must be positive");
+    CHIP(c, hipSetDevice(c->cfg.device));
+    const int64_t N = c->n_particles, nd = N * CRNN_CATHODE_NP;
+    std::memcpy(c->h_norm2, normalizer2, sizeof(c->h_norm2));   // (stable host copy for the asynchronous upload)
+    CHIP(c, hipMemcpyAsync(c->d_pscales + CRNN_CATHODE_NP + 2, c->h_norm2, sizeof(c->h_norm2), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(cath_theta_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, c->stream, c->d_pn, c->d_pscales, nd, c->d_theta);
+    CHIP(c, hipGetLastError());
+    if (cath_run(c, N, i_set, 1, true, false)) return -1;
+    if (!c->ev2) { CHIP(c, hipEventCreate(&c->ev2)); CHIP(c, hipEventCreate(&c->ev3)); }
+    hipLaunchKernelGGL(cath_lnpgrad_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, c->stream, c->d_grad, c->d_pscales, N,
+                       c->d_pscales + CRNN_CATHODE_NP + 2, c->d_lnp, c->d_loss, c->d_ret, c->d_pscales + CRNN_CATHODE_NP);
+    CHIP(c, hipGetLastError());
+    CHIP(c, hipEventRecord(c->ev2, c->stream));
+    CHIP(c, svgd_enqueue(c->svgd, c->stream, c->d_pn, c->d_lnp, N, CRNN_CATHODE_NP, stepsize, h, c->d_pn2, nullptr, nullptr));
+    CHIP(c, hipEventRecord(c->ev3, c->stream));
+    std::swap(c->d_pn, c->d_pn2);      // the moved particles are the current ones
+    if (loss_mean || h_out || ms) {    // the caller looks: read back (otherwise the step stays enqueued)
+        double out2[2] = {0.0, 0.0};
+        crnn::SvgdSel sel{};
+        CHIP(c, hipMemcpyAsync(out2, c->d_pscales + CRNN_CATHODE_NP, sizeof(out2), hipMemcpyDeviceToHost, c->stream));
+        CHIP(c, hipMemcpyAsync(&sel, c->svgd.d_sel, sizeof(sel), hipMemcpyDeviceToHost, c->stream));
+        CHIP(c, hipStreamSynchronize(c->stream));
+        if (out2[1] != 0.0) printf("ode solver failed\n");     // network.jl:214
+        if (!(sel.h > 0)) return cfail(c, "crnn_cathode_svgd_step: bandwidth h is not positive (all particles coincide?)");
+        if (loss_mean) *loss_mean = out2[0];
+        if (h_out) *h_out = sel.h;
+        if (ms) {
+            float a = 0.f, b2 = 0.f;
+            CHIP(c, hipEventElapsedTime(&a, c->ev0, c->ev1));
+            CHIP(c, hipEventElapsedTime(&b2, c->ev2, c->ev3));
+            ms[0] = a; ms[1] = b2;
+        }
     }
     return 0;
 }
@@ -1991,7 +2151,96 @@ int32_t crnn_cathode_allgather(crnn_cathode_ctx *ctx, const double *local, int64
     return 0;
 }
 
-// ============================================================================ SVGD move (stateless)
+// ============================================================================ SVGD move
+// Workspace of a move (device buffers sized for N x dim), kept between calls: crnn_svgd_update caches one per device, a
+// cathode ctx owns one for its device-resident loop.  Nothing is allocated in steady state.
+}  // extern "C" (interrupted: helpers with C++ linkage)
+namespace {
+hipError_t svgd_ws_reserve(SvgdWs &w, int64_t N, int dim, bool io_buffers) {
+    const int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(64, (256 * 256 * 4) / std::max<int64_t>(N, 1)));
+    if (w.N == N && w.dim == dim && w.d_part && (!io_buffers || w.d_p)) return hipSuccess;
+    w.release();
+    const size_t nd = (size_t)N * dim;
+    hipError_t e = hipSuccess;
+    auto get = [&](void **q, size_t bytes) { if (e == hipSuccess) e = hipMalloc(q, bytes); };
+    if (io_buffers) {
+        get((void **)&w.d_p, nd * sizeof(double)); get((void **)&w.d_g, nd * sizeof(double)); get((void **)&w.d_new, nd * sizeof(double));
+        get((void **)&w.d_dt, nd * sizeof(double)); get((void **)&w.d_rep, nd * sizeof(double));
+    }
+    get((void **)&w.d_part, (size_t)N * nchunk * (1 + 2 * dim) * sizeof(double));
+    get((void **)&w.d_hist, crnn::kSvgdBins * sizeof(unsigned int));
+    get((void **)&w.d_sel, sizeof(crnn::SvgdSel));
+    get((void **)&w.d_cnt, 3 * sizeof(unsigned long long));
+    const size_t npairs = (size_t)N * (size_t)(N - 1) / 2;
+    if (npairs * sizeof(double) <= ((size_t)8 << 30)) get((void **)&w.d_dist, npairs * sizeof(double));   // 4 096 particles: 67 MB
+    if (e == hipSuccess) e = hipMemset(w.d_hist, 0, crnn::kSvgdBins * sizeof(unsigned int));   // the pick kernel keeps it zeroed from here on
+    if (e != hipSuccess) { w.release(); return e; }
+    w.N = N; w.dim = dim; w.nchunk = nchunk;
+    return hipSuccess;
+}
+
+// The whole move on `stream`, device buffers in and out, no host round trip: two order statistics of the pair distances by
+// radix select (12 + 4 x 13 bits, state in device memory), bandwidth, row sums, update.  h >= 0: given bandwidth.
+hipError_t svgd_enqueue(SvgdWs &w, hipStream_t stream, const double *d_p, const double *d_g, int64_t N, int dim, double stepsize,
+                        double h, double *d_new, double *d_dt, double *d_rep) {
+    if (h < 0 && w.d_dist) {
+        // distances once, lower middle order statistic by radix select over the stored values, upper one by one more pass
+        const int64_t npairs = N * (N - 1) / 2;
+        const int hblocks = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (npairs + 255) / 256));
+        const int digits[5] = {12, 13, 13, 13, 13};
+        const int64_t T = (N + 63) / 64;
+        if (dim == CRNN_CATHODE_NP)
+            hipLaunchKernelGGL(crnn::svgd_pairdist_kernel<CRNN_CATHODE_NP>, dim3((unsigned)(T * (T + 1) / 2)), dim3(256), 0, stream, d_p, N, dim, w.d_dist);
+        else
+            hipLaunchKernelGGL(crnn::svgd_pairdist_kernel<0>, dim3((unsigned)(T * (T + 1) / 2)), dim3(256), 0, stream, d_p, N, dim, w.d_dist);
+        hipLaunchKernelGGL(crnn::svgd_sel_init_kernel, dim3(1), dim3(1), 0, stream, w.d_sel, (long long)((npairs - 1) / 2));
+        int shift = 64;
+        for (int pass = 0; pass < 5; ++pass) {
+            shift -= digits[pass];
+            hipLaunchKernelGGL(crnn::svgd_hist_buf_kernel, dim3(hblocks), dim3(256), 0, stream, (const double *)w.d_dist, npairs, shift,
+                               digits[pass], (const crnn::SvgdSel *)w.d_sel, w.d_hist);
+            hipLaunchKernelGGL(crnn::svgd_pick_kernel, dim3(1), dim3(1024), 0, stream, w.d_hist, digits[pass], shift, w.d_sel, pass == 4 ? 0 : -1);
+        }
+        hipLaunchKernelGGL(crnn::svgd_next_init_kernel, dim3(1), dim3(1), 0, stream, w.d_cnt);
+        hipLaunchKernelGGL(crnn::svgd_next_kernel, dim3(hblocks), dim3(256), 0, stream, (const double *)w.d_dist, npairs,
+                           (const crnn::SvgdSel *)w.d_sel, w.d_cnt);
+        hipLaunchKernelGGL(crnn::svgd_next_pick_kernel, dim3(1), dim3(1), 0, stream, w.d_sel, (const unsigned long long *)w.d_cnt, (long long)(npairs / 2));
+    } else if (h < 0) {
+        const int64_t npairs = N * (N - 1) / 2;
+        const int hblocks = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (npairs + 255) / 256));
+        const int digits[5] = {12, 13, 13, 13, 13};
+        const int64_t ranks[2] = {(npairs - 1) / 2, npairs / 2};
+        for (int which = 0; which < 2; ++which) {
+            hipLaunchKernelGGL(crnn::svgd_sel_init_kernel, dim3(1), dim3(1), 0, stream, w.d_sel, (long long)ranks[which]);
+            int shift = 64;
+            for (int pass = 0; pass < 5; ++pass) {
+                shift -= digits[pass];
+                hipLaunchKernelGGL(crnn::svgd_hist_dev_kernel, dim3(hblocks), dim3(256), 0, stream, d_p, N, dim, shift, digits[pass],
+                                   (const crnn::SvgdSel *)w.d_sel, w.d_hist);
+                hipLaunchKernelGGL(crnn::svgd_pick_kernel, dim3(1), dim3(1024), 0, stream, w.d_hist, digits[pass], shift, w.d_sel,
+                                   pass == 4 ? which : -1);
+            }
+        }
+    }
+    hipLaunchKernelGGL(crnn::svgd_bandwidth_kernel, dim3(1), dim3(1), 0, stream, w.d_sel, std::log((double)N + 1.0), h);
+    dim3 grid((unsigned)((N + 255) / 256), (unsigned)w.nchunk);
+    if (dim == CRNN_CATHODE_NP)
+        hipLaunchKernelGGL(crnn::svgd_rows_dim_kernel<CRNN_CATHODE_NP>, grid, dim3(256), 0, stream, d_p, d_g, N,
+                           (const crnn::SvgdSel *)w.d_sel, w.nchunk, w.d_part);
+    else
+        hipLaunchKernelGGL(crnn::svgd_rows_dev_kernel, grid, dim3(256), 0, stream, d_p, d_g, N, dim, (const crnn::SvgdSel *)w.d_sel,
+                           w.nchunk, w.d_part);
+    hipLaunchKernelGGL(crnn::svgd_update_dev_kernel, dim3((unsigned)(((size_t)N * dim + 255) / 256)), dim3(256), 0, stream, d_p,
+                       (const double *)w.d_part, N, dim, w.nchunk, (const crnn::SvgdSel *)w.d_sel, stepsize / (double)N, d_new, d_dt, d_rep);
+    return hipGetLastError();
+}
+
+std::mutex g_svgd_mutex;
+SvgdWs g_svgd_ws[16];   // one cached workspace per device ordinal (crnn_svgd_update)
+}  // namespace
+extern "C" {
+
+// stateless entry point: host arrays in and out; the device workspace of the previous call on this device is reused
 int32_t crnn_svgd_update(int32_t device, const double *p, const double *lnpgrad, int64_t N, int32_t dim, double stepsize,
                          double h, double *p_new, double *h_out, double *data_term, double *repulsion) {
     if (!p || !lnpgrad || !p_new) return cfail(nullptr, "crnn_svgd_update: null pointer");
@@ -1999,79 +2248,23 @@ int32_t crnn_svgd_update(int32_t device, const double *p, const double *lnpgrad,
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev < 1) return cfail(nullptr, std::string("crnn_svgd_update: no HIP device (") + hipGetErrorString(e) + ")");
-    if (device < 0 || device >= ndev) return cfail(nullptr, "crnn_svgd_update: device ordinal out of range");
+    if (device < 0 || device >= ndev || device >= 16) return cfail(nullptr, "crnn_svgd_update: device ordinal out of range");
     CHIP(nullptr, hipSetDevice(device));
+    std::lock_guard<std::mutex> lock(g_svgd_mutex);
+    SvgdWs &w = g_svgd_ws[device];
+    CHIP(nullptr, svgd_ws_reserve(w, N, dim, true));
     const size_t nd = (size_t)N * dim;
-    const int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(64, (256 * 256 * 4) / std::max<int64_t>(N, 1)));
-    double *d_p = nullptr, *d_g = nullptr, *d_new = nullptr, *d_dt = nullptr, *d_rep = nullptr, *d_part = nullptr;
-    unsigned int *d_hist = nullptr;
-    auto cleanup = [&]() {
-        for (void *q : {(void *)d_p, (void *)d_g, (void *)d_new, (void *)d_dt, (void *)d_rep, (void *)d_part, (void *)d_hist})
-            if (q) (void)hipFree(q);
-    };
-#define SV_TRY(expr)                                                                                        \
-    do {                                                                                                    \
-        hipError_t e_ = (expr);                                                                             \
-        if (e_ != hipSuccess) { cleanup(); return cfail(nullptr, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
-    } while (0)
-    SV_TRY(hipMalloc((void **)&d_p, nd * sizeof(double)));
-    SV_TRY(hipMalloc((void **)&d_g, nd * sizeof(double)));
-    SV_TRY(hipMalloc((void **)&d_new, nd * sizeof(double)));
-    SV_TRY(hipMalloc((void **)&d_dt, nd * sizeof(double)));
-    SV_TRY(hipMalloc((void **)&d_rep, nd * sizeof(double)));
-    SV_TRY(hipMalloc((void **)&d_part, (size_t)N * nchunk * (1 + 2 * dim) * sizeof(double)));
-    SV_TRY(hipMalloc((void **)&d_hist, crnn::kSvgdBins * sizeof(unsigned int)));
-    SV_TRY(hipMemcpy(d_p, p, nd * sizeof(double), hipMemcpyHostToDevice));
-    SV_TRY(hipMemcpy(d_g, lnpgrad, nd * sizeof(double), hipMemcpyHostToDevice));
-    if (h < 0) {
-        // exact median of the N(N-1)/2 distances by radix select on their bit patterns (12 + 4 x 13 bits)
-        const int64_t npairs = N * (N - 1) / 2;
-        const int hblocks = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (npairs + 255) / 256));
-        std::vector<unsigned int> hist(crnn::kSvgdBins);
-        auto select = [&](int64_t rank, double *out) -> int32_t {   // rank: 0-based order statistic
-            unsigned long long prefix = 0;
-            int prefix_shift = 64;
-            const int digits[5] = {12, 13, 13, 13, 13};
-            int shift = 64;
-            for (int pass = 0; pass < 5; ++pass) {
-                shift -= digits[pass];
-                hipError_t e1 = hipMemset(d_hist, 0, crnn::kSvgdBins * sizeof(unsigned int));
-                if (e1 != hipSuccess) return -1;
-                hipLaunchKernelGGL(crnn::svgd_hist_kernel, dim3(hblocks), dim3(256), 0, 0, d_p, N, dim, shift, digits[pass],
-                                   prefix_shift, prefix, d_hist);
-                if (hipMemcpy(hist.data(), d_hist, crnn::kSvgdBins * sizeof(unsigned int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-                const int nb = 1 << digits[pass];
-                int b = 0;
-                for (; b < nb; ++b) {
-                    if (rank < (int64_t)hist[b]) break;
-                    rank -= hist[b];
-                }
-                if (b == nb) return -2;
-                prefix = (prefix << digits[pass]) | (unsigned long long)b;
-                prefix_shift = shift;
-            }
-            long long bits = (long long)prefix;
-            std::memcpy(out, &bits, sizeof(double));
-            return 0;
-        };
-        double m_lo = 0.0, m_hi = 0.0;
-        if (select((npairs - 1) / 2, &m_lo) != 0 || select(npairs / 2, &m_hi) != 0) { cleanup(); return cfail(nullptr, "crnn_svgd_update: median selection failed"); }
-        const double med = 0.5 * (m_lo + m_hi);     // Julia's median of an even-length vector: mean of the middle pair
-        h = std::sqrt(0.5 * (med * med) / std::log((double)N + 1.0));
-    }
-    if (!(h > 0)) { cleanup(); return cfail(nullptr, "crnn_svgd_update: bandwidth h is not positive (all particles coincide?)"); }
-    if (h_out) *h_out = h;
-    dim3 grid((unsigned)((N + 255) / 256), (unsigned)nchunk);
-    hipLaunchKernelGGL(crnn::svgd_rows_kernel, grid, dim3(256), 0, 0, d_p, d_g, N, dim, 0.5 / (h * h), nchunk, d_part);
-    SV_TRY(hipGetLastError());
-    hipLaunchKernelGGL(crnn::svgd_update_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, 0, d_p, d_part, N, dim, nchunk,
-                       1.0 / (h * h), stepsize / (double)N, d_new, d_dt, d_rep);
-    SV_TRY(hipGetLastError());
-    SV_TRY(hipMemcpy(p_new, d_new, nd * sizeof(double), hipMemcpyDeviceToHost));
-    if (data_term) SV_TRY(hipMemcpy(data_term, d_dt, nd * sizeof(double), hipMemcpyDeviceToHost));
-    if (repulsion) SV_TRY(hipMemcpy(repulsion, d_rep, nd * sizeof(double), hipMemcpyDeviceToHost));
-#undef SV_TRY
-    cleanup();
+    CHIP(nullptr, hipMemcpyAsync(w.d_p, p, nd * sizeof(double), hipMemcpyHostToDevice, nullptr));
+    CHIP(nullptr, hipMemcpyAsync(w.d_g, lnpgrad, nd * sizeof(double), hipMemcpyHostToDevice, nullptr));
+    CHIP(nullptr, svgd_enqueue(w, nullptr, w.d_p, w.d_g, N, dim, stepsize, h, w.d_new, w.d_dt, w.d_rep));
+    crnn::SvgdSel sel{};
+    CHIP(nullptr, hipMemcpyAsync(&sel, w.d_sel, sizeof(sel), hipMemcpyDeviceToHost, nullptr));
+    CHIP(nullptr, hipMemcpyAsync(p_new, w.d_new, nd * sizeof(double), hipMemcpyDeviceToHost, nullptr));
+    if (data_term) CHIP(nullptr, hipMemcpyAsync(data_term, w.d_dt, nd * sizeof(double), hipMemcpyDeviceToHost, nullptr));
+    if (repulsion) CHIP(nullptr, hipMemcpyAsync(repulsion, w.d_rep, nd * sizeof(double), hipMemcpyDeviceToHost, nullptr));
+    CHIP(nullptr, hipStreamSynchronize(nullptr));
+    if (!(sel.h > 0)) return cfail(nullptr, "crnn_svgd_update: bandwidth h is not positive (all particles coincide?)");
+    if (h_out) *h_out = sel.h;
     return 0;
 }
 

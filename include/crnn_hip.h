@@ -351,9 +351,27 @@ int32_t crnn_cathode_allgather(crnn_cathode_ctx *ctx, const double *local, int64
  *   d_ij = |p_i - p_j|; h < 0: h = sqrt(0.5 median(d_ij, i > j)^2 / log(N + 1)); K = exp(-d^2 / (2 h^2));
  *   data = K lnpgrad; repulsion = (-K p + p .* rowsum(K)) / h^2; p_new = p + stepsize (data + repulsion) / N.
  * p, lnpgrad, p_new, data_term, repulsion: [N x dim] row-major host arrays (dim <= 32; data_term / repulsion may be NULL);
- * h_out receives the bandwidth used.  Stateless: runs on HIP device `device`. */
+ * h_out receives the bandwidth used.  Stateless towards the caller: runs on HIP device `device`; the device workspace of the
+ * previous call on that device is reused (nothing is allocated in steady state), the median is selected on the device (no
+ * host round trip between the passes). */
 int32_t crnn_svgd_update(int32_t device, const double *p, const double *lnpgrad, int64_t N, int32_t dim, double stepsize,
                          double h, double *p_new, double *h_out, double *data_term, double *repulsion);
+
+/* Device-resident SVGD loop (crnn_cathode.jl:36-50: `for i_exp in randperm(...)  lnpgrad = dlnprob(p, i_exp); p = svgd update`):
+ * the particles live on the device between iterations.
+ *   crnn_cathode_set_particles   p [n_part x 17] normalised particles (row-major), p_scales [17]
+ *                                (theta = p .* p_scales, network.jl:152-157); n_part >= 2
+ *   crnn_cathode_svgd_step       one iteration for observation set (heating rate) i_set: every particle is integrated for that
+ *                                rate with per-particle adjoint gradients (one launch), lnpgrad[:, k] = -(d loss / d p_k) / normalizer2[k]
+ *                                (dlnprob, network.jl:234-250), then the SVGD move in place -- solve, chain rule, median select,
+ *                                kernel sums and update are enqueued back to back on the ctx stream.  h < 0: median trick.
+ *                                loss_mean / h_out / ms (kernel times in ms: {solve, SVGD move}) may all be NULL: then nothing is
+ *                                read back beyond the 4-byte tape-overflow flag of the adjoint launch.
+ *   crnn_cathode_get_particles   copies the current particles out */
+int32_t crnn_cathode_set_particles(crnn_cathode_ctx *ctx, const double *p, const double *p_scales, int64_t n_part);
+int32_t crnn_cathode_svgd_step(crnn_cathode_ctx *ctx, int32_t i_set, const double *normalizer2 /* [17] */, double stepsize, double h,
+                               double *loss_mean, double *h_out, double *ms);
+int32_t crnn_cathode_get_particles(crnn_cathode_ctx *ctx, double *p);
 
 #ifdef __cplusplus
 }

@@ -343,4 +343,27 @@ function svgd_update(p::Matrix{Float64}, lnpgrad::Matrix{Float64}, stepsize::Flo
     return permutedims(pn), hout[]
 end
 
+"""Device-resident SVGD loop (crnn_cathode.jl:36-50): `set_particles!(c, p)` uploads the normalised particles p [N, 17];
+`svgd_step!(c, i_exp, normalizer2, stepsize)` runs dlnprob for heating rate i_exp and the SVGD move on the device
+(returns the mean loss and the bandwidth); `particles(c)` copies them out."""
+function set_particles!(c::Cathode, p::Matrix{Float64})
+    pr = permutedims(p)                                   # row-major [N][17] for the ABI
+    rc = ccall((:crnn_cathode_set_particles, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64), c.ctx, pr, c.p_scales, size(p, 1))
+    rc == 0 || error(unsafe_string(ccall((:crnn_cathode_last_error, LIB), Cstring, (Ptr{Cvoid},), c.ctx)))
+    return size(p, 1)
+end
+function svgd_step!(c::Cathode, i_exp::Integer, normalizer2::Vector{Float64}, stepsize::Float64; h::Float64=-1.0)   # normalizer2[k] = Normalizer[i_exp, col(k)]^2, 17 entries
+    loss = Ref(0.0); hout = Ref(0.0)
+    rc = ccall((:crnn_cathode_svgd_step, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Float64, Float64, Ref{Float64}, Ref{Float64}, Ptr{Float64}),
+               c.ctx, Int32(i_exp - 1), normalizer2, stepsize, h, loss, hout, C_NULL)
+    rc == 0 || error(unsafe_string(ccall((:crnn_cathode_last_error, LIB), Cstring, (Ptr{Cvoid},), c.ctx)))
+    return loss[], hout[]
+end
+function particles(c::Cathode, N::Integer)
+    pr = zeros(17, N)
+    rc = ccall((:crnn_cathode_get_particles, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), c.ctx, pr)
+    rc == 0 || error(unsafe_string(ccall((:crnn_cathode_last_error, LIB), Cstring, (Ptr{Cvoid},), c.ctx)))
+    return permutedims(pr)
+end
+
 end # module

@@ -1685,6 +1685,38 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
     return retcode;
 }
 
+/* AutoSwitch census (round 3): every (particle, heating rate) trajectory of an ensemble through the composite restatement
+   (c0->solver = 2), primal only, OpenMP over trajectories.  out = { trajectories, those whose accepted steps were ALL
+   Tsit5 steps (the stiff branch never ran), failed solves, sum of accepted steps, sum of accepted Tsit5 steps, largest
+   accepted-step count }.  tools/cathode_autoswitch_census.py runs it on BASELINE config 5's 4 096 x 256 ensemble. */
+int orc_cathode_census(const orc_cathode *c0, const double *theta /*[n_part][17]*/, int64_t n_part, const double *beta /*[n_sets]*/,
+                       int n_sets, const double *ts /*[n_sets][Dmax]*/, const int32_t *D, int Dmax, int64_t *out /*[6]*/, int nthreads) {
+    int64_t n_never = 0, n_fail = 0, s_acc = 0, s_ts5 = 0, m_acc = 0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    double *zero = (double *)calloc((size_t)Dmax, sizeof(double));
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : n_never, n_fail, s_acc, s_ts5) reduction(max : m_acc)
+    for (int64_t tr = 0; tr < n_part * n_sets; ++tr) {
+        const int64_t ip = tr / n_sets;
+        const int is = (int)(tr % n_sets);
+        orc_cathode c = *c0;
+        c.beta = beta[is];
+        double loss = 0;
+        int32_t nsv = 0;
+        orc_stats st = {0, 0};
+        const int rc = orc_cathode_solve_one(&c, theta + 17 * ip, ts + (size_t)is * Dmax, D[is], zero, zero, NULL, &loss, NULL, &nsv, &st);
+        const int64_t t5 = orc_cathode_last_tsit5_steps;
+        if (rc != 0) ++n_fail;
+        if (t5 == st.naccept) ++n_never;
+        s_acc += st.naccept; s_ts5 += t5;
+        if (st.naccept > m_acc) m_acc = st.naccept;
+    }
+    free(zero);
+    out[0] = n_part * n_sets; out[1] = n_never; out[2] = n_fail; out[3] = s_acc; out[4] = s_ts5; out[5] = m_acc;
+    return 0;
+}
+
 /* ======================================================================================================== *
  * HyChem pyrolysis (BASELINE config 4): HyChem/crnn_pyrolysis_mass.jl
  *   p2vec                       :78-90

@@ -297,6 +297,17 @@ def cathode_solve_one(c, theta, ts, dbar, d2bar, want_grad=True):
                 n_tsit5=int(lib().orc_cathode_tsit5_steps()))
 
 
+def cathode_census(c, theta, beta, ts, D, nthreads=0):
+    """AutoSwitch census (orc_cathode_census): theta [n_part, 17], beta [n_sets], ts [n_sets, Dmax], D [n_sets]."""
+    theta = np.ascontiguousarray(theta, float); beta = np.ascontiguousarray(beta, float); ts = np.ascontiguousarray(ts, float)
+    D = np.ascontiguousarray(D, np.int32)
+    out = np.zeros(6, np.int64)
+    lib().orc_cathode_census(C.byref(c), _dp(theta), C.c_int64(theta.shape[0]), _dp(beta), C.c_int(beta.size), _dp(ts), _ip(D),
+                             C.c_int(ts.shape[1]), out.ctypes.data_as(C.POINTER(C.c_int64)), C.c_int(nthreads))
+    return dict(trajectories=int(out[0]), never_left_tsit5=int(out[1]), failed=int(out[2]), accepted=int(out[3]),
+                accepted_tsit5=int(out[4]), max_accepted=int(out[5]))
+
+
 # ---------------------------------------------------------------------------- HyChem restatement
 class Hychem(C.Structure):
     _fields_ = [("ns", C.c_int32), ("nr", C.c_int32), ("maxiters", C.c_int32), ("pad_", C.c_int32),

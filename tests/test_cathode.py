@@ -354,3 +354,44 @@ def test_oracle_cathode_autotsit5_restatement_stays_on_tsit5(orc, cfx):
         assert np.max(np.abs(a["hrr"] - b["hrr"])) < 1e-8 * np.max(np.abs(b["hrr"]))
         worst = max(worst, np.max(np.abs(a["grad"] - b["grad"])) / np.max(np.abs(b["grad"])))
     assert worst > 1.0      # the instability described above is there (if this ever fails, revisit the choice of stepper)
+
+
+@pytest.mark.gpu
+def test_gpu_device_resident_svgd_loop_matches_host_driven_loop(orc, cfx):
+    """crnn_cathode_set_particles / crnn_cathode_svgd_step (particles, per-particle gradients, median select and move all on the
+    device, one heating rate per iteration as crnn_cathode.jl:36-50 draws them) against the same iterations driven from the
+    host through the entry points the other tests pin to the oracle: dlnprob (crnn_cathode_solve) + crnn_svgd_update, and the
+    first move against the oracle's SVGD (orc_svgd_update).  Same kernels, same order: particles agree to 1e-12 after
+    six iterations; the bandwidth is the exact median every time (1e-14)."""
+    uq_dev, uq_host = _uq(cfx), _uq(cfx)
+    rng = np.random.default_rng(11)
+    N = 96
+    p0 = 1 + 2e-2 * rng.standard_normal((N, 17))
+    p0[:, 6:9] = 0.0
+    order = [2, 0, 4, 1, 3, 2]
+    step = 2e-3
+    uq_dev.set_particles(p0)
+    p = p0.copy()
+    for it, i_exp in enumerate(order):
+        loss_d, h_d, ms = uq_dev.svgd_step(i_exp, step)
+        loss_h, lnp = uq_host.dlnprob(p, i_exp)
+        if it == 0:
+            pn_o, _, _, h_o = orc.svgd_update(p, lnp, step)
+        from crnn_amd.cathode import svgd_update
+        p, _, _, h_h = svgd_update(p, lnp, step)
+        assert abs(loss_d - loss_h) <= 1e-12 * abs(loss_h) and abs(h_d - h_h) <= 1e-14 * h_h
+        assert ms["solve_ms"] > 0 and ms["svgd_ms"] > 0
+        pd = uq_dev.particles()
+        assert np.max(np.abs(pd - p)) < 1e-12, it
+        if it == 0:
+            assert abs(h_d - h_o) <= 1e-14 * h_o and np.max(np.abs(pd - pn_o)) < 1e-12
+    # without looking: steps stay enqueued, the particles are the same
+    uq_a, uq_b = _uq(cfx), _uq(cfx)
+    uq_a.set_particles(p0); uq_b.set_particles(p0)
+    for i_exp in order[:3]:
+        uq_a.svgd_step(i_exp, step, look=False)
+        uq_b.svgd_step(i_exp, step)
+    assert np.array_equal(uq_a.particles(), uq_b.particles())
+    for u in (uq_dev, uq_host, uq_a, uq_b):
+        u.close()
+

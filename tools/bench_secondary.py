@@ -129,7 +129,18 @@ def cathode(n_part=4096, n_rates=256, reps=3, device=0):
         uq.solve(p)
         kms.append(uq.last_stats["kernel_ms"])
     st = uq.last_stats
+    # the reference's own iteration (crnn_cathode.jl:36-50): ONE heating rate per SVGD move, particles resident on the device --
+    # solve of n_part trajectories + chain rule + exact-median select + kernel sums + update, enqueued back to back
+    uq.set_particles(p)
+    sv, so = [], []
+    for it in range(8):
+        _, _, ms = uq.svgd_step((37 * it) % n_rates, 1e-3)
+        sv.append(ms["svgd_ms"]); so.append(ms["solve_ms"])
     uq.close()
     return _entry("cathode", n_part * n_rates, kms[1:], st,
                   {"workload": "Cathode-UQ: 4 096 particles x 256 heating rates, non-autonomous Rosenbrock23 atol 1e-12 rtol 1e-3, "
-                               "per-particle adjoint gradients (17 parameters each)", "kernel": "cathode_adj_kernel<256>"})
+                               "per-particle adjoint gradients (17 parameters each)", "kernel": "cathode_adj_kernel<256>",
+                   "svgd_move_ms": float(np.median(sv[2:])), "svgd_iteration_solve_ms": float(np.median(so[2:])),
+                   "svgd_note": "device-resident SVGD iteration (crnn_cathode_svgd_step): svgd_iteration_solve_ms = the solve kernel "
+                                "over the 4 096 particles of ONE heating rate, svgd_move_ms = median select + kernel sums + move "
+                                "(HIP events on the ctx stream)"})
