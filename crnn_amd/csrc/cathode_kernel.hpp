@@ -407,11 +407,18 @@ struct CathAdjParams {
 #ifndef CRNN_CATH_ADJ_WAVES
 #define CRNN_CATH_ADJ_WAVES 1   // waves per SIMD the register allocation targets (tools/kvariants.sh experiments)
 #endif
-template <int BLOCK>
+// KCP > 1 (round 3): CHECKPOINTED tape.  The forward sweep records dt of every accepted step (8 B) and (t, u) of every KCP-th
+// (32 B) instead of (t, dt, u) of every step (40 B); the reverse sweep works through the steps in blocks of KCP: from the
+// block's checkpoint it forms the states of the block's steps again (KCP - 1 forward re-formations, parked per lane in LDS),
+// then reverses them.  Same arithmetic as the forward sweep, so the re-formed states are the recorded ones; the tape
+// shrinks from 40 to 8 + 32 / KCP bytes per step (KCP = 4: 16 B, 2.5x less HBM traffic) for KCP - 1 extra re-formations
+// per KCP steps.
+template <int BLOCK, int KCP>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CRNN_CATH_ADJ_WAVES, CRNN_CATH_ADJ_WAVES))) void cathode_adj_kernel(const CathodeParams prm, const CathAdjParams adj) {
     __shared__ double ts_s[kCathMaxSets * kCathMaxD];
     __shared__ double db_s[kCathMaxSets * kCathMaxD];
     __shared__ double d2_s[kCathMaxSets * kCathMaxD];
+    __shared__ double blk_s[KCP > 1 ? KCP * 4 * BLOCK : 1];      // states (t, u) of the steps of the block being reversed, per lane
     const int tid = threadIdx.x;
     const bool staged = prm.n_sets <= kCathMaxSets;
     if (staged) {
@@ -428,7 +435,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CRNN_CATH
     constexpr int RECW = 5;
     const double lqinit = flog(prm.qoldinit);
     const int lane = tid & 63;
-    double *const tape = adj.tape + (size_t)((size_t)blockIdx.x * BLOCK + tid) * adj.tape_cap * RECW;
+    // KCP == 1: [tape_cap][5] records; KCP > 1: [tape_cap] step sizes, then [ceil(tape_cap / KCP)][4] checkpoints
+    const size_t lane_stride = KCP > 1 ? (size_t)adj.tape_cap + 4 * (((size_t)adj.tape_cap + KCP - 1) / KCP) : (size_t)adj.tape_cap * RECW;
+    double *const tape = adj.tape + (size_t)((size_t)blockIdx.x * BLOCK + tid) * lane_stride;
+    // KCP > 1: the wavefront's step sizes and checkpoints are interleaved over its lanes ([step][lane], [checkpoint][field][lane]):
+    // a wavefront's store of one dt per lane is 512 contiguous bytes (lane-strided 8-byte stores cost 4-8x their payload in
+    // HBM write granules: measured 8.0 GB against 4.3 GB of payload), and the particles of one heating rate take nearly the
+    // same number of steps, so the reverse sweep's reads fall into the same rows too
+    double *const wtape = adj.tape + (size_t)(((size_t)blockIdx.x * BLOCK + tid) >> 6) * 64 * lane_stride + lane;
+    double *const wck = wtape + (size_t)64 * adj.tape_cap;
+#define CATH_DT(step) wtape[(size_t)(step) * 64]
+#define CATH_CK(k, c) wck[((size_t)(k) * 4 + (c)) * 64]
     const int64_t per_set = (adj.n_part + 63) / 64;              // wave batches per heating rate
     const int64_t n_batches = per_set * prm.n_sets;
 
@@ -571,8 +588,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CRNN_CATH
                                 rc = 5;
                                 atomicAdd(adj.overflow, 1u);
                             } else {
-                                double *rec = tape + (size_t)nacc * RECW;
-                                rec[0] = t; rec[1] = dt; rec[2] = u[0]; rec[3] = u[1]; rec[4] = u[2];
+                                if constexpr (KCP > 1) {
+                                    CATH_DT(nacc) = dt;
+                                    if (nacc % KCP == 0) {
+                                        const int kk = nacc / KCP;
+                                        CATH_CK(kk, 0) = t; CATH_CK(kk, 1) = u[0]; CATH_CK(kk, 2) = u[1]; CATH_CK(kk, 3) = u[2];
+                                    }
+                                } else {
+                                    double *rec = tape + (size_t)nacc * RECW;
+                                    rec[0] = t; rec[1] = dt; rec[2] = u[0]; rec[3] = u[1]; rec[4] = u[2];
+                                }
                                 ++nacc;
                                 while (jsave < D) {
                                     const double tsj = tsv[jsave];
@@ -635,18 +660,70 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CRNN_CATH
             }
         };
         double rt = 0.0, rdt = 0.0, ru[3] = {0.0, 0.0, 0.0};
-        {
+        if constexpr (KCP == 1) {
             const double *rec = tape + (size_t)(s > 0 ? s : 0) * RECW;
             rt = rec[0]; rdt = rec[1]; ru[0] = rec[2]; ru[1] = rec[3]; ru[2] = rec[4];
         }
+        double *const bs = blk_s + (KCP > 1 ? tid : 0);    // state c of the block's step i: bs[(i * 4 + c) * BLOCK]
+        int s_lo = s + 1;                                   // first step of the block being reversed (KCP > 1)
+        // Block boundaries must coincide across the lanes of the wavefront: otherwise SOME lane re-forms a block in every
+        // iteration and the wave pays the KCP - 1 re-formations every time (measured: +63 % at KCP = 4).  The top block of a lane
+        // holds 1..KCP steps; a lane whose top block is short sits out the first KCP - (its size) iterations, after which all
+        // lanes start their blocks in the same iterations (at most KCP - 1 idle iterations per wavefront).
+        const int lag = (KCP > 1 && s >= 0) ? KCP - (s - (s / KCP) * KCP + 1) : 0;
+        int it_rev = 0;
         while (__builtin_amdgcn_ballot_w64(s >= 0) != 0) {
-            if (s >= 0) {
-                const double tn = rt, h = rdt;
-                const double un[3] = {ru[0], ru[1], ru[2]};
-                {
+            const bool go = it_rev >= lag;
+            ++it_rev;
+            if constexpr (KCP > 1) {
+                // a new block: re-form the states of its steps from the checkpoint
+                if (go && s >= 0 && s < s_lo) {
+                    const int blk = s / KCP;
+                    s_lo = blk * KCP;
+                    const int ns = s - s_lo + 1;
+                    double tt = CATH_CK(blk, 0), uu[3] = {CATH_CK(blk, 1), CATH_CK(blk, 2), CATH_CK(blk, 3)};
+                    for (int i = 0; i < ns; ++i) {
+                        bs[(i * 4 + 0) * BLOCK] = tt; bs[(i * 4 + 1) * BLOCK] = uu[0]; bs[(i * 4 + 2) * BLOCK] = uu[1]; bs[(i * 4 + 3) * BLOCK] = uu[2];
+                        if (i + 1 < ns) {   // the forward sweep's arithmetic, step s_lo + i
+                            const double hh = CATH_DT(s_lo + i);
+                            const double gam_ = d_ * hh;
+                            CathPoint Pa, Pb;
+                            cath_point(uu, fma(Tdot, tt, prm.T0), th, prm.lb, Pa);
+                            double fa[3], a_[3], iw_[3], sig_[3], ft_[3], k1_[3], dk_[3], fb[3], ua[3];
+                            cath_f(Pa, th, fa);
+                            wfac(Pa, gam_, a_, iw_);
+                            ftime(Pa, sig_, ft_);
+                            const double m21 = gam_ * th[15] * a_[0], m32 = gam_ * th[16] * a_[1];
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) k1_[c] = fma(gam_, ft_[c], fa[c]);
+                            k1_[0] *= iw_[0]; k1_[1] = fma(m21, k1_[0], k1_[1]) * iw_[1]; k1_[2] = fma(m32, k1_[1], k1_[2]) * iw_[2];
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) ua[c] = fma(0.5 * hh, k1_[c], uu[c]);
+                            cath_point(ua, fma(Tdot, tt + 0.5 * hh, prm.T0), th, prm.lb, Pb);
+                            cath_f(Pb, th, fb);
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) dk_[c] = fb[c] - k1_[c];
+                            dk_[0] *= iw_[0]; dk_[1] = fma(m21, dk_[0], dk_[1]) * iw_[1]; dk_[2] = fma(m32, dk_[1], dk_[2]) * iw_[2];
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) uu[c] = fma(hh, k1_[c] + dk_[c], uu[c]);
+                            tt = tt + hh;
+                        }
+                    }
+                }
+            }
+            if (go && s >= 0) {
+                double tn_, h_, un_[3];
+                if constexpr (KCP > 1) {
+                    const int i = s - s_lo;
+                    tn_ = bs[(i * 4 + 0) * BLOCK]; un_[0] = bs[(i * 4 + 1) * BLOCK]; un_[1] = bs[(i * 4 + 2) * BLOCK]; un_[2] = bs[(i * 4 + 3) * BLOCK];
+                    h_ = CATH_DT(s);
+                } else {
+                    tn_ = rt; h_ = rdt; un_[0] = ru[0]; un_[1] = ru[1]; un_[2] = ru[2];
                     const double *rec = tape + (size_t)(s > 0 ? s - 1 : 0) * RECW;
                     rt = rec[0]; rdt = rec[1]; ru[0] = rec[2]; ru[1] = rec[3]; ru[2] = rec[4];
                 }
+                const double tn = tn_, h = h_;
+                const double un[3] = {un_[0], un_[1], un_[2]};
                 const double gam = d_ * h;
                 CathPoint Pn, Pm;
                 cath_point(un, fma(Tdot, tn, prm.T0), th, prm.lb, Pn);
@@ -769,6 +846,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CRNN_CATH
             }
         }
     }
+#undef CATH_DT
+#undef CATH_CK
 }
 
 }  // namespace crnn

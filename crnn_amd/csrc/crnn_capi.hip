@@ -940,6 +940,9 @@ struct SvgdWs {
 hipError_t svgd_ws_reserve(SvgdWs &w, int64_t N, int dim, bool io_buffers);
 hipError_t svgd_enqueue(SvgdWs &w, hipStream_t stream, const double *d_p, const double *d_g, int64_t N, int dim, double stepsize,
                         double h, double *d_new, double *d_dt, double *d_rep);
+#ifndef CRNN_CATH_TAPE_EVERY
+#define CRNN_CATH_TAPE_EVERY 1
+#endif
 struct CathCtx {
     crnn_cathode_config cfg{};
     std::string err;
@@ -963,6 +966,7 @@ struct CathCtx {
     double *d_ag_send = nullptr, *d_ag_recv = nullptr;
     size_t ag_send_cap = 0, ag_recv_cap = 0;
     int adj_occ = 0, fwd_occ = 0;
+    int tape_every = CRNN_CATH_TAPE_EVERY;   // adjoint tape: 1 = every step in full, 4 / 8 = checkpoint every 4th / 8th step
     // device-resident SVGD loop (crnn_cathode_set_particles / crnn_cathode_svgd_step)
     double *d_pn = nullptr, *d_pn2 = nullptr, *d_lnp = nullptr, *d_pscales = nullptr;   // particles (current / moved), lnpgrad, [p_scales(17) | mean loss, n_failed]
     size_t cap_pn = 0;
@@ -1814,6 +1818,10 @@ int32_t crnn_cathode_create(const crnn_cathode_config *cfg, crnn_cathode_ctx **o
         return cfail(nullptr, "crnn_cathode_create: HIP initialisation failed");
     }
     c->num_cu = prop.multiProcessorCount;
+    if (const char *e = getenv("CRNN_CATH_TAPE_EVERY")) {   // measurement override (tools/cathode_bench.py)
+        const int v = atoi(e);
+        if (v == 1 || v == 4 || v == 8) c->tape_every = v;
+    }
     *out = reinterpret_cast<crnn_cathode_ctx *>(c);
     return 0;
 }
@@ -1909,8 +1917,13 @@ int32_t cath_run(CathCtx *c, int64_t n_part, int set_first, int set_count, bool 
     bool done = false;
     if (want_grad && c->cfg.grad_mode != CRNN_GRAD_FORWARD) {
         // discrete adjoint (cathode_adj_kernel): a wavefront takes 64 particles of one heating rate
+        // tape layout: every step in full (40 B) or checkpointed every kcp-th step (8 + 32 / kcp B per step; cathode_kernel.hpp)
+        const int kcp = c->tape_every;
+        using AdjFn = void (*)(const crnn::CathodeParams, const crnn::CathAdjParams);
+        const AdjFn adj_fn = kcp == 4 ? (AdjFn)crnn::cathode_adj_kernel<kB, 4> : kcp == 8 ? (AdjFn)crnn::cathode_adj_kernel<kB, 8>
+                                                                                          : (AdjFn)crnn::cathode_adj_kernel<kB, 1>;
         if (c->adj_occ < 1) {
-            CHIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->adj_occ, (const void *)crnn::cathode_adj_kernel<kB>, kB, 0));
+            CHIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->adj_occ, (const void *)adj_fn, kB, 0));
             if (c->adj_occ < 1) c->adj_occ = 1;
         }
         const int64_t n_batches = ((n_part + 63) / 64) * set_count;
@@ -1921,18 +1934,20 @@ int32_t cath_run(CathCtx *c, int64_t n_part, int set_first, int set_count, bool 
             CHIP(c, hipMemGetInfo(&fr, &tot));
             c->tape_budget = std::min<size_t>(fr / 4, (size_t)16 << 30);
         }
-        int64_t cap = std::max<int64_t>((int64_t)(c->tape_budget / (lanes * 5 * sizeof(double))), 64);
+        const double per_step = kcp > 1 ? 1.0 + 4.0 / kcp : 5.0;     // doubles per recorded step
+        int64_t cap = std::max<int64_t>((int64_t)((double)c->tape_budget / ((double)lanes * per_step * sizeof(double))) - kcp, 64);
         cap = std::min<int64_t>(cap, c->cfg.maxiters);
-        if (c->tape_doubles < lanes * (size_t)cap * 5) {
-            if (cgrow(c, &c->d_tape, lanes * (size_t)cap * 5)) return -1;
-            c->tape_doubles = lanes * (size_t)cap * 5;
+        const size_t lane_doubles = kcp > 1 ? (size_t)cap + 4 * (((size_t)cap + kcp - 1) / kcp) : (size_t)cap * 5;
+        if (c->tape_doubles < lanes * lane_doubles) {
+            if (cgrow(c, &c->d_tape, lanes * lane_doubles)) return -1;
+            c->tape_doubles = lanes * lane_doubles;
         }
         if (!c->d_overflow) CHIP(c, hipMalloc((void **)&c->d_overflow, sizeof(unsigned int)));
         CHIP(c, hipMemsetAsync(c->d_overflow, 0, sizeof(unsigned int), c->stream));
         crnn::CathAdjParams adj{};
         adj.tape = c->d_tape; adj.tape_cap = (int32_t)cap; adj.overflow = c->d_overflow; adj.n_part = n_part;
         CHIP(c, hipEventRecord(c->ev0, c->stream));
-        hipLaunchKernelGGL(crnn::cathode_adj_kernel<kB>, dim3(nblk), dim3(kB), 0, c->stream, prm, adj);
+        hipLaunchKernelGGL(adj_fn, dim3(nblk), dim3(kB), 0, c->stream, prm, adj);
         CHIP(c, hipGetLastError());
         CHIP(c, hipEventRecord(c->ev1, c->stream));
         unsigned int ovf = 0;
@@ -2020,6 +2035,14 @@ int32_t crnn_cathode_solve(crnn_cathode_ctx *ctx, const double *theta, int64_t n
 // ---- device-resident SVGD loop of the Bayesian ensemble (crnn_cathode.jl:36-50): particles, gradients and the move stay on
 // the device; per iteration one solve launch over the particles of ONE heating rate (the reference draws i_exp at random)
 // and the SVGD move, enqueued back to back.
+int32_t crnn_cathode_set_tape_every(crnn_cathode_ctx *ctx, int32_t every) {
+    CathCtx *c = reinterpret_cast<CathCtx *>(ctx);
+    if (!c) return cfail(nullptr, "null ctx");
+    if (every != 1 && every != 4 && every != 8) return cfail(c, "crnn_cathode_set_tape_every: every must be 1, 4 or 8");
+    if (every != c->tape_every) { c->tape_every = every; c->adj_occ = 0; }
+    return 0;
+}
+
 int32_t crnn_cathode_set_particles(crnn_cathode_ctx *ctx, const double *p, const double *p_scales, int64_t n_part) {
     CathCtx *c = reinterpret_cast<CathCtx *>(ctx);
     if (!c) return cfail(nullptr, "null ctx");

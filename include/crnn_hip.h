@@ -369,6 +369,12 @@ int32_t crnn_svgd_update(int32_t device, const double *p, const double *lnpgrad,
  *                                read back beyond the 4-byte tape-overflow flag of the adjoint launch.
  *   crnn_cathode_get_particles   copies the current particles out */
 int32_t crnn_cathode_set_particles(crnn_cathode_ctx *ctx, const double *p, const double *p_scales, int64_t n_part);
+/* Layout of the adjoint's step tape.  1 (default): (t, dt, u) of every accepted step, 40 B per step -- the fastest.  4 / 8:
+ * CHECKPOINTED: dt of every step and (t, u) of every 4th / 8th (16 / 12 B per step); the reverse sweep re-forms the states
+ * in between (same arithmetic as the forward sweep, gradients agree to rounding).  BASELINE config 5 on one MI355X
+ * (4 096 x 256 trajectories, 338 steps each): HBM traffic 31 -> 9.4 GB per launch, tape capacity per trajectory 3.3x, kernel
+ * time 35.7 -> 40.3 ms (the kernel is issue-bound, not bandwidth-bound: profiles/r03e_*). */
+int32_t crnn_cathode_set_tape_every(crnn_cathode_ctx *ctx, int32_t every);
 int32_t crnn_cathode_svgd_step(crnn_cathode_ctx *ctx, int32_t i_set, const double *normalizer2 /* [17] */, double stepsize, double h,
                                double *loss_mean, double *h_out, double *ms);
 int32_t crnn_cathode_get_particles(crnn_cathode_ctx *ctx, double *p);

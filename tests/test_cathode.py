@@ -183,14 +183,17 @@ def test_gpu_cathode_matches_oracle_step_for_step(orc, cfx, tol):
 
 
 @pytest.mark.gpu
-def test_gpu_cathode_adjoint_equals_forward_tangents(cfx):
+@pytest.mark.parametrize("tape_every", [1, 4, 8])
+def test_gpu_cathode_adjoint_equals_forward_tangents(cfx, tape_every):
     """grad_mode 0/2: reversed accepted steps; grad_mode 1: 14 tangent columns.  Same losses, gradients equal to rounding;
-    also for solutions truncated by maxiters (gradient of the saved prefix)."""
+    also for solutions truncated by maxiters (gradient of the saved prefix).  tape_every = 4 / 8: the checkpointed tape
+    (crnn_cathode_set_tape_every: states between checkpoints re-formed in the reverse sweep; step counts that are and are not
+    multiples of the interval, ragged wavefronts)."""
     rng = np.random.default_rng(21)
     p = 1 + 0.05 * rng.standard_normal((70, 17))              # more than one wavefront per heating rate
     p[:, 6:9] = 0.0
-    for kw in (dict(), dict(maxiters=150), dict(atol=1e-10, rtol=1e-6)):
-        fwd, adj = _uq(cfx, grad_mode=1, **kw), _uq(cfx, grad_mode=2, **kw)
+    for kw in (dict(), dict(maxiters=150), dict(maxiters=7), dict(atol=1e-10, rtol=1e-6)):
+        fwd, adj = _uq(cfx, grad_mode=1, **kw), _uq(cfx, grad_mode=2, tape_every=tape_every, **kw)
         lf, gf, hf = fwd.solve(p, want_hrr=True)
         la, ga, ha = adj.solve(p, want_hrr=True)
         assert np.array_equal(fwd.last_retcode, adj.last_retcode) and np.array_equal(fwd.last_n_saved, adj.last_n_saved)
