@@ -19,6 +19,7 @@
 #include "ros23_sens_kernel.hpp"
 #include "tsit5_sens_kernel.hpp"
 #include "hychem_kernel.hpp"
+#include "hychem2_kernel.hpp"
 #include "tsit5_kernel.hpp"
 #include "auto_adj_kernel.hpp"
 #include "ros23_adj2_kernel.hpp"
@@ -425,6 +426,11 @@ const AdjEntry *find_adjoint(const Ctx *c) {
     return nullptr;
 }
 
+// HyChem, AUTO lanes per trajectory: the lane-pair kernel while the ensemble is at most this many generations of resident
+// trajectories (128 per CU); measured in DESIGN.md section 3.3
+#ifndef CRNN_HY2_MAX_GEN
+#define CRNN_HY2_MAX_GEN 1
+#endif
 const AdjEntry *find_adjoint2(const Ctx *c) {
     if (c->use_scale) return nullptr;
     for (const auto &k : kAdj2Kernels)
@@ -613,14 +619,20 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
     const int nth = c->n_theta;
     const int npart_th = nth + crnn::kExtra, npart = P + crnn::kTail;
     using KFn = void (*)(const crnn::SolveParams, const double *, const crnn::HyParams);
-    constexpr int kHyBlock = 128;   // W's factors + parked state in LDS: ~1.1 KB per lane, one 128-lane block per CU
-    KFn fn = P > 0 ? (KFn)crnn::hychem_kernel<9, 10, true, kHyBlock> : (KFn)crnn::hychem_kernel<9, 10, false, kHyBlock>;
+    // W's factors + parked state in LDS: ~1.1 KB per TRAJECTORY, 128 trajectories per CU either way: one lane each in a 128-lane
+    // block (hychem_kernel) or a lane pair each in a 256-lane block (hychem2_kernel.hpp: the step's critical path split over the pair)
+    int G = c->lanes_per_traj == 1 ? 1 : 2;
+    if (c->lanes_per_traj == 0 && count > (int64_t)c->num_cu * 128 * CRNN_HY2_MAX_GEN) G = 1;   // AUTO: see CRNN_HY2_MAX_GEN
+    c->last_lanes = G;
+    const int kHyBlock = 128 * G;
+    KFn fn = G == 2 ? (P > 0 ? (KFn)crnn::hychem2_kernel<9, 10, true, 256> : (KFn)crnn::hychem2_kernel<9, 10, false, 256>)
+                    : (P > 0 ? (KFn)crnn::hychem_kernel<9, 10, true, 128> : (KFn)crnn::hychem_kernel<9, 10, false, 128>);
     int occ = 0;
     HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, kHyBlock, 0));
     if (occ < 1) occ = 1;
-    const int64_t need_blocks = (count + kHyBlock - 1) / kHyBlock;
+    const int64_t need_blocks = (count + 127) / 128;
     const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(need_blocks, (int64_t)c->num_cu * occ));
-    const size_t lanes = (size_t)nblk * kHyBlock;
+    const size_t lanes = (size_t)nblk * 128;      // resident trajectories = tape slots
     const size_t recw = (size_t)c->cfg.ns + 2;
     int64_t cap = c->cfg.tape_steps;
     if (cap <= 0) {
@@ -1680,7 +1692,7 @@ int32_t crnn_ctx_set_lanes_per_traj(crnn_ctx *ctx, int32_t lanes) {
     Ctx *c = reinterpret_cast<Ctx *>(ctx);
     if (!c) return fail(c, "crnn_ctx_set_lanes_per_traj: null");
     if (lanes < 0 || lanes > 2) return fail(c, "crnn_ctx_set_lanes_per_traj: lanes must be 0 (auto), 1 or 2");
-    if (lanes == 2 && (c->hychem || c->cfg.solver != CRNN_SOLVER_ROSENBROCK23 || !find_adjoint2(c)))
+    if (lanes == 2 && !c->hychem && (c->cfg.solver != CRNN_SOLVER_ROSENBROCK23 || !find_adjoint2(c)))
         return fail(c, "crnn_ctx_set_lanes_per_traj: no two-lane kernel for this problem (Rosenbrock23, nr < ns, no rate scaling)");
     c->lanes_per_traj = lanes;
     return 0;

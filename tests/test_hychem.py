@@ -389,7 +389,8 @@ def test_gpu_hychem_config4_as_eight_logical_shards():
     node.set_tables(Tt, Pt)
     p = hy.true_p() + 0.02 * np.random.Generator(np.random.PCG64(5)).standard_normal(hy.NP)
     p[-1] = 0.1
-    L, G = node.loss_and_grad(p)
+    node.set_lanes_per_traj(1)     # one kernel for the whole ensemble and for its shards: the sums below agree to 1e-12 only
+    L, G = node.loss_and_grad(p)   # then (AUTO takes the lane-pair kernel for the shards and the one-lane kernel beyond 32 768)
     assert node.last_stats["n_ok"] == B
     lsum, gsum, n = 0.0, np.zeros(hy.NP), 0
     for r in range(W):
@@ -424,3 +425,29 @@ def test_gpu_hychem_queue_by_step_count_beyond_the_resident_lanes(hfx):
     assert l3 == l2 and np.array_equal(g3, g2)
     print(f"HyChem B = {B}: kernel {ms1:.2f} ms in index order, {ms2:.2f} ms queued by step count")
     assert ms2 < ms1
+
+
+@pytest.mark.gpu
+def test_gpu_hychem_two_lanes_match_one_lane_and_oracle(orc, hfx):
+    """hychem2_kernel (a lane pair per trajectory: logarithms, exponentials, Jacobian rows, species contractions and accumulators
+    split over the pair) against hychem_kernel (one lane) and the oracle: identical return codes and step counts, losses 1e-10,
+    all 211 gradient components 1e-7 of max |grad| between the kernels, the oracle bars of the tests above against the oracle."""
+    p = np.array(hfx["p"])
+    out = {}
+    for lanes in (1, 2):
+        node = _node(hfx, hfx["u0"], hfx["data"], hfx["Ttab"], hfx["Ptab"])
+        node.set_lanes_per_traj(lanes)
+        l, g = node.loss_and_grad(p)
+        losses = node.losses(p)
+        na, nr = node.step_counts()
+        out[lanes] = (l, g, losses, na.copy(), nr.copy(), node.last_retcode.copy(), node.last_lanes_per_traj())
+        pred = node.predict_n_ode(p)
+        out[lanes] += (pred,)
+        node.close()
+    a, b = out[1], out[2]
+    assert a[6] == 1 and b[6] == 2
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+    assert abs(a[0] - b[0]) < 1e-10 * abs(a[0]) and np.max(np.abs(a[2] - b[2]) / a[2]) < 1e-10
+    assert np.max(np.abs(a[1] - b[1])) < 1e-7 * np.max(np.abs(a[1]))      # (1.3e-8 measured: 211 components through ~50 stiff steps)
+    assert np.max(np.abs(a[7] - b[7])) < 1e-10 * np.max(np.abs(a[7]))
+

@@ -26,7 +26,7 @@ def main(root):
             if cur.fetchone() is not None:
                 nm = "kernel_name" if "kernel_name" in cols else "name"
                 q = (f"select {nm}, counter_name, count(*), sum(value), avg(value) from counters_collection "
-                     f"where ({nm} like '%ros23%' or {nm} like '%hychem_kernel%' or {nm} like '%cathode_%' or {nm} like '%auto_adj%' "
+                     f"where ({nm} like '%ros23%' or {nm} like '%hychem%' or {nm} like '%cathode_%' or {nm} like '%auto_adj%' "
                      f"or {nm} like '%tsit5%' or {nm} like '%sort_steps%' or {nm} like 'k\_%' escape '\\') group by {nm}, counter_name")
                 print(f"   {'counter':24s} {'dispatches':>10s} {'sum':>18s} {'per_dispatch':>18s}")
                 for n, cn, cnt, s, a in con.execute(q):
