@@ -426,11 +426,6 @@ const AdjEntry *find_adjoint(const Ctx *c) {
     return nullptr;
 }
 
-// HyChem, AUTO lanes per trajectory: the lane-pair kernel while the ensemble is at most this many generations of resident
-// trajectories (128 per CU); measured in DESIGN.md section 3.3
-#ifndef CRNN_HY2_MAX_GEN
-#define CRNN_HY2_MAX_GEN 1
-#endif
 const AdjEntry *find_adjoint2(const Ctx *c) {
     if (c->use_scale) return nullptr;
     for (const auto &k : kAdj2Kernels)
@@ -621,8 +616,9 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
     using KFn = void (*)(const crnn::SolveParams, const double *, const crnn::HyParams);
     // W's factors + parked state in LDS: ~1.1 KB per TRAJECTORY, 128 trajectories per CU either way: one lane each in a 128-lane
     // block (hychem_kernel) or a lane pair each in a 256-lane block (hychem2_kernel.hpp: the step's critical path split over the pair)
-    int G = c->lanes_per_traj == 1 ? 1 : 2;
-    if (c->lanes_per_traj == 0 && count > (int64_t)c->num_cu * 128 * CRNN_HY2_MAX_GEN) G = 1;   // AUTO: see CRNN_HY2_MAX_GEN
+    // AUTO = the pair at every size: both kernels hold 128 trajectories per CU, the pair works through each of them faster
+    // (32 768: 8.12 -> 6.71 ms, 65 536: 8.97 -> 7.95, all 262 144 of config 4 on one GPU: 35.3 -> 31.8 ms)
+    const int G = c->lanes_per_traj == 1 ? 1 : 2;
     c->last_lanes = G;
     const int kHyBlock = 128 * G;
     KFn fn = G == 2 ? (P > 0 ? (KFn)crnn::hychem2_kernel<9, 10, true, 256> : (KFn)crnn::hychem2_kernel<9, 10, false, 256>)

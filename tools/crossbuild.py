@@ -17,7 +17,7 @@ allocation and schedule, same arithmetic), O3 + -DCRNN_BOUNDS_CHECK (every index
 against its extent -- the stand-in for a device address sanitizer, whose instrumented runtime this image lacks; the build
 must also report ZERO violations).  Problems: the AutoTsit5(Rosenbrock23) composite on robertson (switches
 algorithm mid-run), Tsit5 adjoint on case1 and on case2, Rosenbrock23 adjoint on case2 (one lane and two lanes per trajectory),
-case1's shape (two lanes, odd species count) and robertson,
+case1's shape (two lanes, odd species count), robertson, HyChem (one lane and a lane pair),
 forward tangents on case2 -- per-trajectory losses, return codes, saved counts, accepted / rejected steps and the batch
 gradient in index order (crnn_ctx_set_queue_order(INDEX): the batch sum is then a function of the inputs alone).
 tests/test_gpu_crossbuild.py runs `run` on every GPU session.
@@ -111,6 +111,20 @@ def _problems():
         ("rober_ros23_adjoint", PRESET_ROBER, rb, dict(rate_scale=sc, grad_mode=2)),
         ("case2_ros23_forward", PRESET_CASE2, c2, dict(grad_mode=1)),
     ]
+    # HyChem (its own kernels: one lane and a lane pair per trajectory), 300 trajectories, 211 parameters
+    from crnn_amd import PRESET_HYCHEM, hychem as hy
+    hrng = np.random.Generator(np.random.PCG64([77, 4]))
+    hts, hu0, hT, hP = hy.sample_conditions(300, hrng)
+    hdata = np.abs(hrng.standard_normal((300, 9, len(hts)))) * 0.05
+    hp = hy.true_p() + 0.02 * hrng.standard_normal(hy.NP)
+    hp[-1] = 0.1
+    for lanes in (1, 2):
+        node = NeuralODE(ODEProblem(PRESET_HYCHEM, hts, rate_scale=hy.DYDT_SCALE, grad_mode=2))
+        node.set_queue_order(L.QUEUE_INDEX)
+        node.set_ensemble(hu0, hdata, np.ones(9))
+        node.set_tables(hT, hP)
+        node.set_lanes_per_traj(lanes)
+        out.append((f"hychem_adjoint_{lanes}lane", node, hp))
     for name, preset, (ts, u0, data, ys, p), kw in specs:
         lanes = kw.pop("lanes", None)
         node = NeuralODE(ODEProblem(preset, ts, **kw))
