@@ -337,6 +337,15 @@ def main():
                                    "attempt) + the plain solve for the loss: the reference-faithful gradient mode; kernel_ms is the LAST launch only, "
                                    "call_ms the whole loss+gradient call"}, reps=3, errnorm_sens=1)
             sec["case2_errnorm_sens1"]["value"] = B / (sec["case2_errnorm_sens1"]["call_ms"] * 1e-3)
+            progress("case2 strong-scaling shares (8 192 / 16 384 / 32 768 of the 65 536)")
+            for nb in (8192, 16384, 32768):
+                sec[f"case2_B{nb}_share"] = bs.case2_fixed(u0[:nb], data[:nb], yscale, ck, {
+                    "workload": f"case2, {nb} ICs = one GPU's share of the 65 536 batch on {65536 // nb} GPUs (strong scaling), checkpoint p, adjoint gradient; "
+                                "AUTO takes the lane-pair kernel (ros23_adj2_kernel) below 32 769 trajectories"})
+                sec[f"case2_B{nb}_share_one_lane"] = bs.case2_fixed(u0[:nb], data[:nb], yscale, ck, {
+                    "workload": f"the same with one lane per trajectory (crnn_ctx_set_lanes_per_traj(1): round 2's kernel)"}, lanes=1)
+            sec["case2_B65536_two_lanes"] = bs.case2_fixed(u0, data, yscale, ck, {
+                "workload": note + "checkpoint p, TWO lanes per trajectory forced (two generations of pairs, longest first)"}, lanes=2)
             progress("case2 B = 131072 / 262144")
             ub_, db_, yb_ = bs.case2_ensemble(262144, [1234, 99], device=local_rank)
             for nb in (131072, 262144):

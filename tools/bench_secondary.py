@@ -17,14 +17,22 @@ BYTES = {"case2": 8 * (7 + 6 * 50 + 2), "robertson": 8 * (3 + 3 * 40 + 2), "hych
          "cathode": 8 * (3 + 17 + 64 + 2 + 17)}
 
 
-def _entry(kind, B, kms, st, extra=None, wall_ms=None):
+def _traffic(key):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json: secondary_bytes_per_launch), or None."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["secondary_bytes_per_launch"].get(key)
+    except Exception:
+        return None
+
+
+def _entry(kind, B, kms, st, extra=None, wall_ms=None, traffic_key=None):
     k = float(np.median(kms))
     gbs = BYTES[kind] * B / (k * 1e-3) / 1e9
     e = {"trajectories": int(B), "kernel_ms": k, "value": B / (k * 1e-3), "unit": "trajectories+grads/s",
          "steps_per_traj": st["n_accept"] / max(st["n_traj"], 1), "rejects_per_traj": st["n_reject"] / max(st["n_traj"], 1),
          "n_ok": int(st["n_ok"]),
          "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                      "algorithmic_bytes_per_traj": BYTES[kind]}}
+                      "algorithmic_bytes_per_traj": BYTES[kind], "traffic": _traffic(traffic_key) if traffic_key else None}}
     if wall_ms is not None:
         e["call_ms"] = wall_ms
     if extra:
@@ -42,14 +50,20 @@ def _time_calls(node, p, reps):
     return kms[1:], float(np.median(walls[1:])), node.last_stats
 
 
-def case2_fixed(u0, data, yscale, p, label_extra=None, reps=6, device=0, **probkw):
-    """case2 at a fixed p (no optimiser update) on a caller-supplied ensemble."""
+def case2_fixed(u0, data, yscale, p, label_extra=None, reps=6, device=0, lanes=None, **probkw):
+    """case2 at a fixed p (no optimiser update) on a caller-supplied ensemble.  lanes: crnn_ctx_set_lanes_per_traj (None = AUTO)."""
     from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE2, cases
     node = NeuralODE(ODEProblem(PRESET_CASE2, cases.case2_tsteps(), device=device, **probkw))
     node.set_ensemble(u0, data, yscale)
+    if lanes is not None:
+        node.set_lanes_per_traj(lanes)
     kms, wall, st = _time_calls(node, p, reps)
+    e = _entry("case2", u0.shape[0], kms, st, label_extra, wall)
+    e["lanes_per_traj"] = node.last_lanes_per_traj()
+    if e["lanes_per_traj"] == 2 and u0.shape[0] in (8192, 32768):
+        e["roofline"]["traffic"] = _traffic(f"case2_B{u0.shape[0]}_lane_pair")
     node.close()
-    return _entry("case2", u0.shape[0], kms, st, label_extra, wall)
+    return e
 
 
 def case2_ensemble(B, seed, device=0):
@@ -83,7 +97,7 @@ def robertson(B=65536, reps=6, device=0):
     kms, wall, st = _time_calls(node, p, reps)
     node.close()
     return _entry("robertson", B, kms, st, {"workload": "robertson CRNN, 65 536 ICs, Rosenbrock23 atol [1e-6,1e-8,1e-6] rtol 1e-3, adjoint gradient (P = 43)",
-                                            "kernel": "ros23_adj_kernel<3,6,scaled>"}, wall)
+                                            "kernel": "ros23_adj_kernel<3,6,scaled>"}, wall, traffic_key="robertson_B65536" if B == 65536 else None)
 
 
 def hychem(B=32768, reps=4, device=0):
@@ -105,7 +119,8 @@ def hychem(B=32768, reps=4, device=0):
     node.close()
     return _entry("hychem", B, kms, st, {"workload": "HyChem pyrolysis CRNN, 32 768 ICs (one GPU's share of 262 144), T(t)/P(t) tables, "
                                                      "Rosenbrock23 atol 1e-8 rtol 1e-3, adjoint gradient (P = 211)",
-                                         "kernel": "hychem_kernel<9,10,GRAD,128>"}, wall)
+                                         "kernel": "hychem2_kernel<9,10,GRAD,256> (a lane pair per trajectory)"}, wall,
+                  traffic_key="hychem_B32768_lane_pair" if B == 32768 else None)
 
 
 def cathode(n_part=4096, n_rates=256, reps=3, device=0):
@@ -143,4 +158,4 @@ def cathode(n_part=4096, n_rates=256, reps=3, device=0):
                    "svgd_move_ms": float(np.median(sv[2:])), "svgd_iteration_solve_ms": float(np.median(so[2:])),
                    "svgd_note": "device-resident SVGD iteration (crnn_cathode_svgd_step): svgd_iteration_solve_ms = the solve kernel "
                                 "over the 4 096 particles of ONE heating rate, svgd_move_ms = median select + kernel sums + move "
-                                "(HIP events on the ctx stream)"})
+                                "(HIP events on the ctx stream)"}, traffic_key="cathode_4096x256_full_tape" if (n_part, n_rates) == (4096, 256) else None)
