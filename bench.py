@@ -222,10 +222,13 @@ def main():
             flops = (st["n_accept"] + st["n_reject"]) * FLOP_PRIMAL_STEP + st["n_accept"] * 25 * FLOP_COL_STEP
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if ros and os.path.exists(tpath):   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md)
-            try:
-                traffic = json.load(open(tpath)).get("case2_B65536_adjoint_bytes_per_launch" if adjoint
-                                                     else "case2_B65536_bytes_per_launch")
+        if ros and os.path.exists(tpath):   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md):
+            try:                            # only for the launch shapes the passes were taken on, else null
+                tj = json.load(open(tpath))
+                if B_rank == 65536 and (not adjoint or lanes_used == 1):
+                    traffic = tj.get("case2_B65536_adjoint_bytes_per_launch" if adjoint else "case2_B65536_bytes_per_launch")
+                elif adjoint and lanes_used == 2:
+                    traffic = tj.get("secondary_bytes_per_launch", {}).get(f"case2_B{B_rank}_lane_pair")
             except Exception:
                 traffic = None
         out = {
