@@ -1,26 +1,26 @@
 // crnn_amd/csrc/hychem2_kernel.hpp -- gfx950 (MI355X): the HyChem pyrolysis CRNN (HyChem/crnn_pyrolysis_mass.jl) with TWO LANES
-// PER TRAJECTORY (round 3).  Same mathematics, tape, accumulators and outputs as hychem_kernel.hpp (read that header first:
-// the RHS with its density coupling, the non-autonomous Rosenbrock23 step, the adjoint formulas); what changes is the mapping.
+// PER TRAJECTORY (round 3, second form).  Same mathematics, tape, accumulators and outputs as hychem_kernel.hpp (read that
+// header first: the RHS with its density coupling, the non-autonomous Rosenbrock23 step, the adjoint formulas); what changes
+// is the mapping.
 //
-// hychem_kernel gives a trajectory one lane and needs 1.1 KB of LDS for it (W's factors, the parked u_n point): 128
-// trajectories per CU, two wavefronts on four SIMDs, and a launch that lasts as long as its longest wavefront's chain of
-// ~25 000 instructions per step pair (one GPU's share of BASELINE config 4, 32 768 trajectories, is exactly one generation
-// of such wavefronts).  Here an adjacent lane pair owns the trajectory and its LDS slot:
-//   * replicated in both lanes (identical instructions on identical operands, so identical bits: the pair never diverges):
-//     the state vectors u, k1, dk, lambda ..., the clamped mass fractions, density, the rates r, the step-size controller,
-//     the LU factorisation (both lanes factor the same 9 x 9 matrix and write the same factors to the pair's LDS slot) and
-//     the triangular solves -- together ~10 % of a step;
-//   * split over the pair, lane m owning species 5m .. 5m+4 (lane 1: four species, its fifth slot takes log T): the
-//     logarithms, the exponentials (five each, exchanged), the rows of the Jacobian (each lane builds its rows of W straight
-//     into the pair's LDS slot), every contraction over the species and the gradient accumulators of the species' rows of
-//     w_in / w_out (global atomics as before, half as many per lane);
-//   * what crosses the pair: sums over the species (one DPP step: a + quad_perm[1,0,3,2](a), the same bits in both lanes)
-//     and "gathers" of a species-distributed vector into the replicated full-length one (one DPP move per element).
-// The pair's 64-lane wavefront takes 32 trajectories from the queue; a 256-lane block (128 pairs) uses the same 146 KB of LDS
-// as the one-lane kernel's 128-lane block, so all four SIMDs of a CU work.
+// hychem_kernel gives a trajectory one lane and parks W's 81 factors in LDS: 1.1 KB per trajectory, 128 trajectories per CU
+// on two of its four SIMDs, ~25 000 instructions per step pair on the critical path of every wavefront.  Here an adjacent
+// lane pair owns the trajectory and EVERYTHING of length ns is distributed over the pair, species 2 i + m in slot i of lane m
+// (cyclic: the trailing rows of the LU stay balanced; lane 1's fifth slot is padding and carries log T through the logarithm):
+//   * state, stages, adjoints (u, k1, dk, lambda, the seeds ...): five values per lane;
+//   * W = I - gam J: each lane builds and keeps ITS FIVE ROWS IN REGISTERS (45 doubles), through the factorisation and the
+//     solves -- no LDS for the matrix, so the block is not LDS-bound any more and all four SIMDs hold a wavefront;
+//   * LU with partial pivoting, row-distributed: the pivot row reaches the other lane by DPP (quad_perm [1,0,3,2]), each lane
+//     eliminates its own rows; the pivot search is a local scan + one exchange, a row swap (rare) a chain of selects;
+//   * W x = b in axpy form (x_k broadcast, each lane updates its rows: the one-lane kernel's operation order, same bits);
+//     W^T x = b in dot form (each lane's partial dot product over ITS rows, summed over the pair);
+//   * contractions over the species: partial sums + pair_sum; the ten rates are replicated (five exponentials per lane,
+//     exchanged), as are the step-size controller and the scalars.
+// What remains replicated is the controller arithmetic and the rates; a step pair costs each lane ~40 % of the one-lane
+// kernel's instructions.  The pair's 64-lane wavefront takes 32 trajectories from the queue.
 #pragma once
 #include "hychem_kernel.hpp"
-#include "ros23_adj2_kernel.hpp"   // pair_sum
+#include "ros23_adj2_kernel.hpp"   // pair_sum, pair_and
 
 namespace crnn {
 
@@ -30,90 +30,107 @@ __device__ __forceinline__ double pair_other(double a) {   // the other lane of 
     const int phi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false);
     return __hiloint2double(phi, plo);
 }
+__device__ __forceinline__ int pair_other_i(int a) { return __builtin_amdgcn_update_dpp(0, a, 0xB1, 0xF, 0xF, false); }
 
-// species-distributed (lane m holds species H m + i in own[i]) -> full-length, replicated
+// the value held by the pair's lane `owner_odd`, in both lanes
+__device__ __forceinline__ double pair_pick(const double mine, const bool owner_odd, const bool m1) {
+    const double oth = pair_other(mine);
+    return (m1 == owner_odd) ? mine : oth;
+}
+
+// species-distributed (lane m holds species 2 i + m in own[i]) -> full-length, replicated
 template <int NS, int H>
 __device__ __forceinline__ void pair_gather(const double (&own)[H], const bool m1, double (&full)[NS]) {
     double oth[H];
 #pragma unroll
     for (int i = 0; i < H; ++i) oth[i] = pair_other(own[i]);
 #pragma unroll
-    for (int c = 0; c < NS; ++c) {
-        const int i = c < H ? c : c - H;
-        full[c] = (c < H) ? (m1 ? oth[i] : own[i]) : (m1 ? own[i] : oth[i]);
-    }
+    for (int c = 0; c < NS; ++c) full[c] = (m1 == ((c & 1) != 0)) ? own[c >> 1] : oth[c >> 1];
 }
 // full-length, replicated -> this lane's species
 template <int NS, int H>
 __device__ __forceinline__ void pair_own(const double (&full)[NS], const bool m1, double (&own)[H]) {
 #pragma unroll
-    for (int i = 0; i < H; ++i) own[i] = m1 ? (H + i < NS ? full[H + i < NS ? H + i : 0] : 0.0) : full[i];
+    for (int i = 0; i < H; ++i) own[i] = m1 ? (2 * i + 1 < NS ? full[2 * i + 1 < NS ? 2 * i + 1 : 0] : 0.0) : full[2 * i];
 }
 
 template <int NS, int NR>
 struct HyPoint2 {
     static constexpr int H = (NS + 1) / 2;
-    double Y[NS];          // clamp(u) (replicated)
+    double Yo[H];          // clamp(u) of this lane's species
     double xo[H];          // log clamp(C) of this lane's species
+    double fo[H];          // right-hand side, this lane's species
     double xE, xL;         // -1/(R T), log T (replicated)
-    double r[NR];          // rates (replicated)
-    double f[NS], fo[H];   // right-hand side: replicated, and this lane's species
-    double irho, iS;
-    unsigned cY, cC;       // bit i: u_i (C_i) inside its clamp window (replicated)
+    double irho, iS;       // (the ten rates go to the lane's LDS frame: hy_point2's rf)
+    unsigned cY, cC;       // bit c: u_c (C_c) inside its clamp window (all species, replicated)
 };
 
-// point evaluation.  ci[i] = species index of this lane's slot i (0 for the padding slot), ow[i] = slot holds a species.
-template <int NS, int NR>
-__device__ __forceinline__ void hy_point2(const double *th, const KConst *kc, const double inv_R, const double (&u)[NS], const double T,
-                                          const double P, const bool m1, const int (&ci)[(NS + 1) / 2], const bool (&ow)[(NS + 1) / 2],
-                                          HyPoint2<NS, NR> &pt) {
+// what a lane knows about its slots: species index (0 for the padding slot), whether the slot holds a species, 1/mw, gsc
+template <int H>
+struct HyLane {
+    int ci[H];
+    bool ow[H];
+};
+// 1/mw and gsc of the lane's slots come from the LDS-staged constants at each use (the padding slot reads species 0: every use
+// of it is masked by ow or multiplies a zero) -- 20 VGPRs less than keeping them
+
+// point evaluation on species-distributed u; the rates are left in the lane's LDS frame (rf[j * STRIDE], rf == nullptr: dropped)
+template <int NS, int NR, int STRIDE>
+__device__ __forceinline__ void hy_point2(const double *th, const KConst *kc, const double inv_R, const double (&uo)[(NS + 1) / 2],
+                                          const double T, const double P, const bool m1, const HyLane<(NS + 1) / 2> &ln,
+                                          HyPoint2<NS, NR> &pt, double *rf) {
     using L_ = LayH<NS, NR>;
     constexpr int H = (NS + 1) / 2;
     static_assert(NR == 2 * H, "the exponentials are split H + H");
     double S = 0.0;
     unsigned cY = 0, cC = 0;
 #pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        const double c = fmin(fmax(u[i], kc->lb), kc->ub);
-        cY |= (c == u[i]) ? (1u << i) : 0u;
-        pt.Y[i] = c;
-        S = fma(c, kc->imw[i], S);
+    for (int i = 0; i < H; ++i) {
+        const double c = fmin(fmax(uo[i], kc->lb), kc->ub);
+        cY |= (ln.ow[i] && c == uo[i]) ? (1u << (2 * i)) : 0u;
+        pt.Yo[i] = ln.ow[i] ? c : 0.0;
+        S = fma(pt.Yo[i], kc->imw[ln.ci[i]], S);
     }
+    S = pair_sum(S);
     const double RTS = kc->Ru * T * S;
     const double rho = P * frcp(RTS);
     pt.irho = RTS * frcp(P);
     pt.iS = frcp(S);
-    double cl[NS];
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        const double C = rho * (pt.Y[i] * kc->imw[i]) * 1e3;
-        const double c = fmin(fmax(C, kc->lb), kc->ub);
-        cC |= (c == C) ? (1u << i) : 0u;
-        cl[i] = c;
-    }
-    pt.cY = cY;
-    pt.cC = cC;
-    {   // H logarithms per lane: lane 0 species 0 .. H-1, lane 1 species H .. NS-1 and T
+    {   // H logarithms per lane: its species; lane 1's padding slot takes T
         double a_[H], la_[H];
 #pragma unroll
-        for (int i = 0; i < H; ++i) a_[i] = m1 ? (H + i < NS ? cl[H + i < NS ? H + i : 0] : T) : cl[i];
+        for (int i = 0; i < H; ++i) {
+            const double C = rho * (pt.Yo[i] * kc->imw[ln.ci[i]]) * 1e3;
+            const double c = fmin(fmax(C, kc->lb), kc->ub);
+            cC |= (ln.ow[i] && c == C) ? (1u << (2 * i)) : 0u;
+            a_[i] = ln.ow[i] ? c : T;
+        }
         flog_vec<H>(a_, la_);
 #pragma unroll
         for (int i = 0; i < H; ++i) pt.xo[i] = la_[i];
         const double lt_other = pair_other(la_[H - 1]);
         pt.xL = m1 ? la_[H - 1] : lt_other;
     }
+    {
+        const unsigned sh = m1 ? 1u : 0u;
+        cY <<= sh; cC <<= sh;
+        pt.cY = cY | (unsigned)pair_other_i((int)cY);
+        pt.cC = cC | (unsigned)pair_other_i((int)cC);
+    }
     pt.xE = inv_R * frcp(T);
     CRNN_SCHED_FENCE();
-    double z[NR];
+    double z[NR], xz[H];
+#pragma unroll
+    for (int i = 0; i < H; ++i) xz[i] = ln.ow[i] ? pt.xo[i] : 0.0;   // the padding slot (log T) drops out of the species' sum
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         double a = 0.0;
 #pragma unroll
-        for (int i = 0; i < H; ++i) a = fma(ow[i] ? th[L_::wi(0, j) + ci[i]] : 0.0, pt.xo[i], a);
+        for (int i = 0; i < H; ++i) a = fma(th[L_::wi(0, j) + ln.ci[i]], xz[i], a);
         z[j] = pair_sum(a) + fma(th[L_::wi(NS, j)], pt.xE, fma(th[L_::wi(NS + 1, j)], pt.xL, th[L_::wb(j)]));
     }
     CRNN_SCHED_FENCE();
+    double r[NR];
     {   // H exponentials per lane, exchanged
         double a_[H], e_[H], o_[H];
 #pragma unroll
@@ -122,66 +139,255 @@ __device__ __forceinline__ void hy_point2(const double *th, const KConst *kc, co
 #pragma unroll
         for (int k = 0; k < H; ++k) o_[k] = pair_other(e_[k]);
 #pragma unroll
-        for (int k = 0; k < H; ++k) { pt.r[k] = m1 ? o_[k] : e_[k]; pt.r[H + k] = m1 ? e_[k] : o_[k]; }
+        for (int k = 0; k < H; ++k) { r[k] = m1 ? o_[k] : e_[k]; r[H + k] = m1 ? e_[k] : o_[k]; }
+    }
+    if (rf) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) rf[j * STRIDE] = r[j];
     }
     CRNN_SCHED_FENCE();
 #pragma unroll
     for (int i = 0; i < H; ++i) {
         double a = 0.0;
 #pragma unroll
-        for (int j = 0; j < NR; ++j) a = fma(th[L_::wo(0, j) + ci[i]], pt.r[j], a);
-        pt.fo[i] = ow[i] ? a * kc->gsc[ci[i]] * pt.irho : 0.0;
+        for (int j = 0; j < NR; ++j) a = fma(th[L_::wo(0, j) + ln.ci[i]], r[j], a);
+        pt.fo[i] = ln.ow[i] ? a * kc->gsc[ln.ci[i]] * pt.irho : 0.0;
     }
-    pair_gather<NS, H>(pt.fo, m1, pt.f);
 }
 
-// This lane's rows of W = I - gam J(u_n), written straight into the pair's LDS slot (element (i, c) at As[(i NS + c) GPB]),
-// and ft = df/dt at the point (replicated).
-template <int NS, int NR, int GPB>
-__device__ __forceinline__ void hy_jac_ft2(const double *th, const KConst *kc, const HyPoint2<NS, NR> &pt, const double gam, const double ld,
-                                           const double xEd, const double xLd, const bool m1, const int (&ci)[(NS + 1) / 2],
-                                           const bool (&ow)[(NS + 1) / 2], double *As, double (&ft)[NS]) {
+// This lane's rows of W = I - gam J(u_n) (row of slot i in A[i][0 .. NS-1]) and its species of ft = df/dt at the point.
+template <int NS, int NR, int STRIDE>
+__device__ __forceinline__ void hy_jac_ft2(const double *th, const KConst *kc, const HyPoint2<NS, NR> &pt, const double *rf, const double gam,
+                                           const double ld, const double xEd, const double xLd, const bool m1, const HyLane<(NS + 1) / 2> &ln,
+                                           double (&A)[(NS + 1) / 2][NS], double (&fto)[(NS + 1) / 2]) {
     using L_ = LayH<NS, NR>;
     constexpr int H = (NS + 1) / 2;
     double gx[NS], sg[NS], Bj[NR], zd[NR];
+    {
+        double gxo[H], sgo[H];
 #pragma unroll
-    for (int c = 0; c < NS; ++c) {
-        const bool iy = (pt.cY >> c) & 1u, ic = (pt.cC >> c) & 1u;
-        gx[c] = (iy && ic) ? frcp(pt.Y[c]) : 0.0;
-        sg[c] = iy ? kc->imw[c] * pt.iS : 0.0;
+        for (int i = 0; i < H; ++i) {
+            const bool iy = ln.ow[i] && ((pt.cY >> ln.ci[i]) & 1u), ic = (pt.cC >> ln.ci[i]) & 1u;
+            gxo[i] = (iy && ic) ? frcp(pt.Yo[i]) : 0.0;
+            sgo[i] = iy ? kc->imw[ln.ci[i]] * pt.iS : 0.0;
+        }
+        pair_gather<NS, H>(gxo, m1, gx);
+        pair_gather<NS, H>(sgo, m1, sg);
     }
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         double b = 0.0;
 #pragma unroll
-        for (int i = 0; i < H; ++i) b += (ow[i] && ((pt.cC >> ci[i]) & 1u)) ? th[L_::wi(0, j) + ci[i]] : 0.0;
+        for (int i = 0; i < H; ++i) b += (ln.ow[i] && ((pt.cC >> ln.ci[i]) & 1u)) ? th[L_::wi(0, j) + ln.ci[i]] : 0.0;
         b = pair_sum(b);
         Bj[j] = b;
         zd[j] = fma(b, ld, fma(th[L_::wi(NS, j)], xEd, th[L_::wi(NS + 1, j)] * xLd));
     }
-    double fto[H];
 #pragma unroll
     for (int i = 0; i < H; ++i) {
-        const double Gi = kc->gsc[ci[i]] * pt.irho;
+        // theta re-read row by row (90 broadcast ds_reads): merged across the rows it would pin 180 VGPRs
+        unsigned z_ = 0;
+        asm volatile("" : "+v"(z_));
+        const double *const thr = th + z_;
+        const double Gi = ln.ow[i] ? kc->gsc[ln.ci[i]] * pt.irho : 0.0;
         double a[NR], tB = 0.0, tz = 0.0;
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
-            a[j] = Gi * th[L_::wo(0, j) + ci[i]] * pt.r[j];
+            a[j] = Gi * thr[L_::wo(0, j) + ln.ci[i]] * rf[j * STRIDE + z_];
             tB = fma(a[j], Bj[j], tB);
             tz = fma(a[j], zd[j], tz);
         }
-        fto[i] = ow[i] ? fma(-pt.fo[i], ld, tz) : 0.0;
+        fto[i] = ln.ow[i] ? fma(-pt.fo[i], ld, tz) : 0.0;
 #pragma unroll
         for (int c = 0; c < NS; ++c) {
             double s_ = 0.0;
 #pragma unroll
-            for (int j = 0; j < NR; ++j) s_ = fma(a[j], th[L_::wi(c, j)], s_);
+            for (int j = 0; j < NR; ++j) s_ = fma(a[j], thr[L_::wi(c, j)], s_);
             const double Jic = fma(gx[c], s_, -sg[c] * (tB - pt.fo[i]));
-            if (ow[i]) As[(size_t)(ci[i] * NS + c) * GPB] = ((ci[i] == c) ? 1.0 : 0.0) - gam * Jic;
+            const bool diag = (c == 2 * i) ? !m1 : ((c == 2 * i + 1) ? m1 : false);
+            A[i][c] = (diag ? 1.0 : 0.0) - gam * Jic;
+            if (c % 3 == 2) CRNN_SCHED_FENCE();   // the scheduler would issue the row's 90 theta reads up front (180 VGPRs)
         }
-        CRNN_SCHED_FENCE();   // one row at a time
+        // one row at a time: the row's entries are pinned here (volatile asm keeps its order with the next row's z_), or the
+        // optimiser sinks all 450 multiply-adds below all 450 theta reads and spills the operands
+        opaque(A[i]);
+        CRNN_SCHED_FENCE();
     }
-    pair_gather<NS, H>(fto, m1, ft);
+}
+
+// P A = L U, rows distributed (slot i of lane m = row 2 i + m), in place in registers; ros23_kernel.hpp's lu_factor operation
+// for operation (first maximum as pivot, l = a_ik / a_kk by reciprocal, fma(-l, a_kc, a_ic)), so the factors carry its bits.
+template <int NS>
+__device__ __forceinline__ bool lu2_factor(double (&A)[(NS + 1) / 2][NS], const bool m1, double (&dinv)[NS], unsigned long long &piv, bool &anyp) {
+    constexpr int H = (NS + 1) / 2;
+    const int mo = m1 ? 1 : 0;
+    static_assert(NS <= 16, "pivot rows are packed four bits each");
+    bool ok = true;
+    anyp = false;
+    piv = 0;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int ks = k >> 1;
+        const bool kodd = (k & 1) != 0;
+        double best = fabs(pair_pick(A[ks][k], kodd, m1));
+        int p = k;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            if (2 * i + 1 <= k) continue;                    // neither lane's row is below the pivot row
+            if (2 * i >= NS) continue;
+            bool act = (2 * i > k) ? true : m1;              // 2 i == k: lane 0's slot is the pivot row itself
+            if (2 * i + 1 >= NS) act = act && !m1;           // lane 1's padding slot
+            const double v = fabs(A[i][k]);
+            if (act && v > best) { best = v; p = 2 * i + mo; }
+        }
+        {
+            const double ob = pair_other(best);
+            const int op = pair_other_i(p);
+            if (ob > best || (ob == best && op < p)) { best = ob; p = op; }
+        }
+        piv |= (unsigned long long)(unsigned)p << (4 * k);
+        const bool need = (p != k);
+        anyp = anyp || need;
+#ifndef HY2_NO_SWAP
+        if (__builtin_amdgcn_ballot_w64(need) != 0) {        // rare: skipped by the whole wave when no pair swaps
+            if (need) {
+#pragma unroll
+                for (int c = 0; c < NS; ++c) {
+                    const double rk = pair_pick(A[ks][c], kodd, m1);
+                    double mine_p = 0.0;
+#pragma unroll
+                    for (int i = 0; i < H; ++i) mine_p = (2 * i + mo == p) ? A[i][c] : mine_p;
+                    const double oth_p = pair_other(mine_p);
+                    const double rp = ((p & 1) == mo) ? mine_p : oth_p;
+                    A[ks][c] = (m1 == kodd) ? rp : A[ks][c];
+#pragma unroll
+                    for (int i = 0; i < H; ++i) A[i][c] = (2 * i + mo == p) ? rk : A[i][c];
+                }
+            }
+        }
+#endif
+        double rowk[NS];
+#pragma unroll
+        for (int c = k; c < NS; ++c) rowk[c] = pair_pick(A[ks][c], kodd, m1);
+        ok = ok && (rowk[k] != 0.0);
+        const double inv = frcp(rowk[k]);
+        dinv[k] = inv;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            if (2 * i + 1 <= k) continue;
+            if (2 * i >= NS) continue;
+            const double l = A[i][k] * inv;
+            if (2 * i > k) {
+                A[i][k] = l;
+#pragma unroll
+                for (int c = k + 1; c < NS; ++c) A[i][c] = fma(-l, rowk[c], A[i][c]);
+            } else if (2 * i + 1 < NS && m1) {               // 2 i == k: only lane 1's row (k + 1) is below the pivot row
+                A[i][k] = l;
+#pragma unroll
+                for (int c = k + 1; c < NS; ++c) A[i][c] = fma(-l, rowk[c], A[i][c]);
+            }
+        }
+        CRNN_SCHED_FENCE();
+    }
+    return ok;
+}
+
+// b <- P b (fwd) or P^T b (!fwd) on a distributed vector: rare (a pivoting wave), done on a gathered copy
+template <int NS>
+__device__ __forceinline__ void lu2_permute(const unsigned long long piv, const bool fwd, const bool m1, double (&b)[(NS + 1) / 2]) {
+    constexpr int H = (NS + 1) / 2;
+    double f[NS];
+    pair_gather<NS, H>(b, m1, f);
+    if (fwd) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int p = (int)((piv >> (4 * k)) & 15u);
+#pragma unroll
+            for (int i = k + 1; i < NS; ++i) {
+                const bool sw = (p == i);
+                const double bk = f[k], bi = f[i];
+                f[k] = sw ? bi : bk;
+                f[i] = sw ? bk : bi;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = NS - 1; k >= 0; --k) {
+            const int p = (int)((piv >> (4 * k)) & 15u);
+#pragma unroll
+            for (int i = k + 1; i < NS; ++i) {
+                const bool sw = (p == i);
+                const double bk = f[k], bi = f[i];
+                f[k] = sw ? bi : bk;
+                f[i] = sw ? bk : bi;
+            }
+        }
+    }
+    pair_own<NS, H>(f, m1, b);
+}
+
+// W x = b, axpy form (hychem_kernel.hpp's lu_solve_lds operation for operation)
+template <int NS>
+__device__ __forceinline__ void lu2_solve(const double (&A)[(NS + 1) / 2][NS], const double (&dinv)[NS], const unsigned long long piv,
+                                          const bool wave_pivots, const bool m1, double (&b)[(NS + 1) / 2]) {
+    constexpr int H = (NS + 1) / 2;
+    if (wave_pivots) lu2_permute<NS>(piv, true, m1, b);
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const double a = pair_pick(b[k >> 1], (k & 1) != 0, m1);
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            if (2 * i + 1 <= k || 2 * i >= NS) continue;
+            if (2 * i > k) b[i] = fma(-A[i][k], a, b[i]);
+            else b[i] = m1 ? fma(-A[i][k], a, b[i]) : b[i];
+        }
+    }
+#pragma unroll
+    for (int k = NS - 1; k >= 0; --k) {
+        const bool kodd = (k & 1) != 0;
+        const double a = pair_pick(b[k >> 1], kodd, m1) * dinv[k];
+        b[k >> 1] = (m1 == kodd) ? a : b[k >> 1];
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            if (2 * i >= k) continue;                        // neither lane's row is above row k
+            if (2 * i + 1 < k) b[i] = fma(-A[i][k], a, b[i]);
+            else b[i] = m1 ? b[i] : fma(-A[i][k], a, b[i]);  // 2 i + 1 == k: lane 1's slot is row k itself
+        }
+    }
+}
+
+// W^T x = b:  x = P^T L^-T U^-T b, dot form -- each lane sums over ITS rows, the pair adds the two partial sums
+template <int NS>
+__device__ __forceinline__ void lu2_solve_T(const double (&A)[(NS + 1) / 2][NS], const double (&dinv)[NS], const unsigned long long piv,
+                                            const bool wave_pivots, const bool m1, double (&b)[(NS + 1) / 2]) {
+    constexpr int H = (NS + 1) / 2;
+#pragma unroll
+    for (int c = 0; c < NS; ++c) {                           // U^T y = b: y_c = (b_c - sum_{k < c} U_kc y_k) / U_cc
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            if (2 * i >= c) continue;
+            if (2 * i + 1 < c) s = fma(A[i][c], b[i], s);
+            else s = m1 ? s : fma(A[i][c], b[i], s);         // 2 i + 1 == c: lane 1's slot is row c itself
+        }
+        if (c > 0) s = pair_sum(s);
+        const double y = (b[c >> 1] - s) * dinv[c];
+        b[c >> 1] = (m1 == ((c & 1) != 0)) ? y : b[c >> 1];
+    }
+#pragma unroll
+    for (int c = NS - 2; c >= 0; --c) {                      // L^T x = y: x_c = y_c - sum_{k > c} L_kc x_k
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            if (2 * i + 1 <= c || 2 * i >= NS) continue;
+            if (2 * i > c) { if (2 * i + 1 < NS) s = fma(A[i][c], b[i], s); else s = m1 ? s : fma(A[i][c], b[i], s); }
+            else s = m1 ? fma(A[i][c], b[i], s) : s;         // 2 i == c: lane 0's slot is row c itself
+        }
+        s = pair_sum(s);
+        const double x = b[c >> 1] - s;
+        b[c >> 1] = (m1 == ((c & 1) != 0)) ? x : b[c >> 1];
+    }
+    if (wave_pivots) lu2_permute<NS>(piv, false, m1, b);
 }
 
 template <int NS, int NR, bool GRAD, int BLOCK>
@@ -191,36 +397,33 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
     constexpr int H = (NS + 1) / 2;
     constexpr int GPB = BLOCK / 2;
     constexpr int RECW = NS + 2;
-    constexpr int NPARK = (NS + 2) + NR + NS + 2 + 2 * NS + NR;   // x, r, Y, irho, iS of the u_n point; k1; k2 - k1; r at u_mid
-    constexpr int PK_R1 = (NS + 2) + NR + NS + 2 + 2 * NS;
     __shared__ double kc_lds[kNConst];
     __shared__ double ts_lds[kMaxSave];
     __shared__ double th_lds[NTH];
-    __shared__ double A_lds[NS * NS * GPB];
-    __shared__ double park_lds[GRAD ? NPARK * GPB : 1];
+    // the lane's LDS frame (slot k at fr[k BLOCK]; nobody else touches the column): what a step needs again much later is
+    // parked here instead of being carried in registers -- the rates of the FSAL point / of u_n (0-9) and of the new point /
+    // u_mid (10-19); reverse sweep: x, Y of the two points (20-39), k1, k2 - k1 (40-49), their scalars (50-57)
+    constexpr int NFR = GRAD ? 58 : 20;
+    __shared__ double fr_lds[NFR * BLOCK];
     const int tid = threadIdx.x;
+    double *const fr = fr_lds + tid;
+#define FR(k_) fr[(k_) * BLOCK]
     const int lane = tid & 63;
     const bool m1 = (lane & 1) != 0;
     const int gib = tid >> 1, giw = lane >> 1;
-    double *const As = A_lds + gib;
-    double *const park = park_lds + (GRAD ? gib : 0);
     for (int idx = tid; idx < kNConst; idx += BLOCK) kc_lds[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
     for (int idx = tid; idx < hp.n_save_total; idx += BLOCK) ts_lds[idx] = prm.tsave[idx];
     for (int idx = tid; idx < NTH; idx += BLOCK) th_lds[idx] = theta[idx];
     __syncthreads();
     const KConst *kc = reinterpret_cast<const KConst *>(kc_lds);
     const double *th = th_lds;
-    int ci[H];
-    bool ow[H];
+    HyLane<H> ln;
 #pragma unroll
-    for (int i = 0; i < H; ++i) { const int c = (m1 ? H : 0) + i; ow[i] = c < NS; ci[i] = ow[i] ? c : 0; }
-    // wave-level ordering of the pair's LDS traffic (one lane's stores, the other lane's loads)
-#define HY2_LDS_SYNC()                                                   \
-    do {                                                                 \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");           \
-        __builtin_amdgcn_wave_barrier();                                 \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");           \
-    } while (0)
+    for (int i = 0; i < H; ++i) {
+        const int c = 2 * i + (m1 ? 1 : 0);
+        ln.ow[i] = c < NS;
+        ln.ci[i] = ln.ow[i] ? c : 0;
+    }
 
     const double d_ = 0.29289321881345248, c32 = 7.4142135623730950, inv12d = 2.4142135623730950;
     const int nsave = prm.n_save, Dfull = hp.n_save_total;
@@ -229,6 +432,9 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
     const double lqinit = flog(kc->qoldinit);
     const bool start_saved = (ts0 == t0);
     double *const tape = hp.tape + (size_t)((size_t)blockIdx.x * GPB + gib) * hp.tape_cap * RECW;
+#ifdef HY_PROF
+    unsigned long long prof_acc[16] = {0}, prof_last = __builtin_readcyclecounter();
+#endif
 
     while (true) {
         unsigned long long base = 0;
@@ -260,65 +466,55 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
             T = fma(tq - tsa, Td, Ta);
             P = fma(tq - tsa, Pd, Pa);
         };
-        // factor the pair's W (both lanes: the same matrix, the same factors) and park the factors in the pair's LDS slot
-        auto factor = [&](double (&dinv)[NS], int (&piv)[NS], bool &anyp) -> bool {
-            HY2_LDS_SYNC();            // both lanes' rows are in LDS
-            double A[NS][NS];
-#pragma unroll
-            for (int i = 0; i < NS; ++i)
-#pragma unroll
-                for (int c = 0; c < NS; ++c) A[i][c] = As[(i * NS + c) * GPB];
-            HY2_LDS_SYNC();            // both lanes have read W before either overwrites it with factors
-            const bool ok = lu_factor_to_lds<NS, GPB>(A, As, dinv, piv, anyp);
-            HY2_LDS_SYNC();
-            return ok;
-        };
 
         // ================================================================== forward sweep
-        double u[NS];
+        double u[H];
         HyPoint2<NS, NR> p0;     // FSAL point (u, t)
         double t = t0, dt = 0.0, lqold = lqinit;
         int iter = 0, jsave = 0, nacc = 0, nrej = 0;
         int rc = valid ? -1 : 0;
+        int rsl = 0;             // frame slot of the FSAL point's rates (0 or 10; the new point's go to the other one)
 #pragma unroll
-        for (int i = 0; i < NS; ++i) u[i] = prm.u0[(size_t)i * prm.B + b];
+        for (int i = 0; i < H; ++i) u[i] = ln.ow[i] ? prm.u0[(size_t)ln.ci[i] * prm.B + b] : 0.0;
         {
             double T, P, Td, Pd;
             tab(t0, T, P, Td, Pd);
-            hy_point2<NS, NR>(th, kc, hp.inv_R, u, T, P, m1, ci, ow, p0);
-            double d0 = 0.0, d1 = 0.0, sk[NS];
+            hy_point2<NS, NR, BLOCK>(th, kc, hp.inv_R, u, T, P, m1, ln, p0, fr);
+            double d0 = 0.0, d1 = 0.0, sk[H];
 #pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                sk[i] = frcp(fma(fabs(u[i]), kc->rtol[i], kc->atol[i]));
-                const double a = u[i] * sk[i], c = p0.f[i] * sk[i];
+            for (int i = 0; i < H; ++i) {
+                sk[i] = ln.ow[i] ? frcp(fma(fabs(u[i]), kc->rtol[ln.ci[i]], kc->atol[ln.ci[i]])) : 0.0;
+                const double a = u[i] * sk[i], c = p0.fo[i] * sk[i];
                 d0 = fma(a, a, d0);
                 d1 = fma(c, c, d1);
             }
-            d0 = sqrt(d0 * (1.0 / NS));
-            d1 = sqrt(d1 * (1.0 / NS));
+            d0 = sqrt(pair_sum(d0) * (1.0 / NS));
+            d1 = sqrt(pair_sum(d1) * (1.0 / NS));
             double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 / d1);
             dt0 = fmin(dt0, dtmax);
-            double u1[NS];
+            double u1[H];
 #pragma unroll
-            for (int i = 0; i < NS; ++i) u1[i] = fma(dt0, p0.f[i], u[i]);
+            for (int i = 0; i < H; ++i) u1[i] = fma(dt0, p0.fo[i], u[i]);
             HyPoint2<NS, NR> p1;
             tab(t0 + dt0, T, P, Td, Pd);
-            hy_point2<NS, NR>(th, kc, hp.inv_R, u1, T, P, m1, ci, ow, p1);
+            hy_point2<NS, NR, BLOCK>(th, kc, hp.inv_R, u1, T, P, m1, ln, p1, nullptr);
             double d2 = 0.0;
 #pragma unroll
-            for (int i = 0; i < NS; ++i) { const double e = (p1.f[i] - p0.f[i]) * sk[i]; d2 = fma(e, e, d2); }
-            d2 = sqrt(d2 * (1.0 / NS)) / dt0;
+            for (int i = 0; i < H; ++i) { const double e = (p1.fo[i] - p0.fo[i]) * sk[i]; d2 = fma(e, e, d2); }
+            d2 = sqrt(pair_sum(d2) * (1.0 / NS)) / dt0;
             const double dm = fmax(d1, d2);
             const double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : exp(-0.5 * (4.605170185988091368 + flog(dm)));
             dt = fmax(kc->dtmin, fmin(fmin(100.0 * dt0, dt1), dtmax));
         }
         if (start_saved) {
-            if (valid && prm.pred && !m1) {
+            if (valid && prm.pred) {
 #pragma unroll
-                for (int i = 0; i < NS; ++i) {
-                    double v = u[i];
-                    if (prm.clamp_pred) v = clampv(v, -kc->ub, kc->ub);
-                    prm.pred[((size_t)0 * NS + i) * prm.B + b] = v;
+                for (int i = 0; i < H; ++i) {
+                    if (ln.ow[i]) {
+                        double v = u[i];
+                        if (prm.clamp_pred) v = clampv(v, -kc->ub, kc->ub);
+                        prm.pred[((size_t)0 * NS + ln.ci[i]) * prm.B + b] = v;
+                    }
                 }
             }
             jsave = 1;
@@ -338,64 +534,73 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                     const double tnew = last ? tend : t + dt;
                     double T, P, Td, Pd;
                     tab(t, T, P, Td, Pd);
-                    double dinv[NS], ft[NS];
-                    int piv[NS];
+                    double A[H][NS], dinv[NS], ft[H];
+                    unsigned long long piv;
                     bool anyp;
-                    hy_jac_ft2<NS, NR, GPB>(th, kc, p0, gam, Pd * frcp(P) - Td * frcp(T), -hp.inv_R * Td * frcp(T * T), Td * frcp(T), m1, ci, ow, As, ft);
+                    HY_T(0);
+                    hy_jac_ft2<NS, NR, BLOCK>(th, kc, p0, fr + rsl * BLOCK, gam, Pd * frcp(P) - Td * frcp(T), -hp.inv_R * Td * frcp(T * T), Td * frcp(T), m1, ln, A, ft);
                     CRNN_SCHED_FENCE();
-                    const bool okf = factor(dinv, piv, anyp);
+                    HY_T(1);
+                    const bool okf = lu2_factor<NS>(A, m1, dinv, piv, anyp);
                     const bool wp = __builtin_amdgcn_ballot_w64(anyp) != 0;
-                    double k1[NS], dk[NS], unew[NS], f1[NS];
+                    HY_T(2);
+                    double k1[H], dk[H], unew[H], f1[H];
 #pragma unroll
-                    for (int i = 0; i < NS; ++i) k1[i] = fma(gam, ft[i], p0.f[i]);
-                    lu_solve_lds<NS, GPB>(As, dinv, piv, wp, k1);
+                    for (int i = 0; i < H; ++i) k1[i] = fma(gam, ft[i], p0.fo[i]);
+                    lu2_solve<NS>(A, dinv, piv, wp, m1, k1);
                     CRNN_SCHED_FENCE();
+                    HY_T(3);
                     HY_FRESH_THETA(th); HY_FRESH_KC(kc);
                     {
-                        double u1[NS];
+                        double u1[H];
 #pragma unroll
-                        for (int i = 0; i < NS; ++i) u1[i] = fma(0.5 * dt, k1[i], u[i]);
+                        for (int i = 0; i < H; ++i) u1[i] = fma(0.5 * dt, k1[i], u[i]);
                         HyPoint2<NS, NR> p1;
                         double T1, P1, a_, b_;
                         tab(t + 0.5 * dt, T1, P1, a_, b_);
-                        hy_point2<NS, NR>(th, kc, hp.inv_R, u1, T1, P1, m1, ci, ow, p1);
+                        hy_point2<NS, NR, BLOCK>(th, kc, hp.inv_R, u1, T1, P1, m1, ln, p1, nullptr);
 #pragma unroll
-                        for (int i = 0; i < NS; ++i) f1[i] = p1.f[i];
+                        for (int i = 0; i < H; ++i) f1[i] = p1.fo[i];
                         opaque(f1);
                     }
 #pragma unroll
-                    for (int i = 0; i < NS; ++i) dk[i] = f1[i] - k1[i];
-                    lu_solve_lds<NS, GPB>(As, dinv, piv, wp, dk);
+                    for (int i = 0; i < H; ++i) dk[i] = f1[i] - k1[i];
+                    HY_T(4);
+                    lu2_solve<NS>(A, dinv, piv, wp, m1, dk);
+                    HY_T(3);
 #pragma unroll
-                    for (int i = 0; i < NS; ++i) unew[i] = fma(dt, k1[i] + dk[i], u[i]);
+                    for (int i = 0; i < H; ++i) unew[i] = fma(dt, k1[i] + dk[i], u[i]);
                     CRNN_SCHED_FENCE();
                     HyPoint2<NS, NR> p2;
                     HY_FRESH_THETA(th); HY_FRESH_KC(kc);
                     {
                         double T2, P2, a_, b_;
                         tab(tnew, T2, P2, a_, b_);
-                        hy_point2<NS, NR>(th, kc, hp.inv_R, unew, T2, P2, m1, ci, ow, p2);
+                        hy_point2<NS, NR, BLOCK>(th, kc, hp.inv_R, unew, T2, P2, m1, ln, p2, fr + (10 - rsl) * BLOCK);
                     }
                     CRNN_SCHED_FENCE();
-                    double k3[NS];
+                    HY_T(4);
+                    double k3[H];
 #pragma unroll
-                    for (int i = 0; i < NS; ++i) {
+                    for (int i = 0; i < H; ++i) {
                         const double k2i = k1[i] + dk[i];
-                        k3[i] = fma(dt, ft[i], p2.f[i] - c32 * (k2i - f1[i]) - 2.0 * (k1[i] - p0.f[i]));
+                        k3[i] = fma(dt, ft[i], p2.fo[i] - c32 * (k2i - f1[i]) - 2.0 * (k1[i] - p0.fo[i]));
                     }
-                    lu_solve_lds<NS, GPB>(As, dinv, piv, wp, k3);
+                    lu2_solve<NS>(A, dinv, piv, wp, m1, k3);
+                    HY_T(3);
                     double es = 0.0;
-                    bool finite = okf;
+                    int fin = okf ? 1 : 0;
 #pragma unroll
-                    for (int i = 0; i < NS; ++i) {
+                    for (int i = 0; i < H; ++i) {
                         const double k2i = k1[i] + dk[i];
                         const double ev = dt * (1.0 / 6.0) * (k1[i] - 2.0 * k2i + k3[i]);
                         const double mx = fmax(fabs(u[i]), fabs(unew[i]));
-                        const double e = ev * frcp(fma(kc->rtol[i], mx, kc->atol[i]));
+                        const double e = ln.ow[i] ? ev * frcp(fma(kc->rtol[ln.ci[i]], mx, kc->atol[ln.ci[i]])) : 0.0;
                         es = fma(e, e, es);
-                        finite = finite && isfinite(unew[i]) && isfinite(ev);
+                        fin &= (!ln.ow[i] || (isfinite(unew[i]) && isfinite(ev))) ? 1 : 0;
                     }
-                    es = es * (1.0 / NS);
+                    es = pair_sum(es) * (1.0 / NS);
+                    const bool finite = pair_and(fin) != 0;
                     if (!finite) rc = 3;
                     else {
                         const bool ee_zero = (es == 0.0);
@@ -412,29 +617,32 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                                 if (!m1) { rec[0] = t; rec[1] = dt; }
 #pragma unroll
                                 for (int i = 0; i < H; ++i)
-                                    if (ow[i]) rec[2 + ci[i]] = m1 ? u[H + i < NS ? H + i : 0] : u[i];
+                                    if (ln.ow[i]) rec[2 + ln.ci[i]] = u[i];
                                 ++nacc;
                                 while (jsave < nsave) {
                                     const double ts = ts_lds[jsave];
                                     if (!(ts <= tnew)) break;
-                                    if (prm.pred && !m1) {
+                                    if (prm.pred) {
                                         const bool at_end = (ts == tnew);
                                         const double Th = at_end ? 1.0 : (ts - t) / dt;
                                         const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
                                         const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d_) * inv12d;
 #pragma unroll
-                                        for (int i = 0; i < NS; ++i) {
-                                            const double k2i = k1[i] + dk[i];
-                                            double v = at_end ? unew[i] : fma(dt, fma(c1, k1[i], c2 * k2i), u[i]);
-                                            if (prm.clamp_pred) v = clampv(v, -kc->ub, kc->ub);
-                                            prm.pred[((size_t)jsave * NS + i) * prm.B + b] = v;
+                                        for (int i = 0; i < H; ++i) {
+                                            if (ln.ow[i]) {
+                                                const double k2i = k1[i] + dk[i];
+                                                double v = at_end ? unew[i] : fma(dt, fma(c1, k1[i], c2 * k2i), u[i]);
+                                                if (prm.clamp_pred) v = clampv(v, -kc->ub, kc->ub);
+                                                prm.pred[((size_t)jsave * NS + ln.ci[i]) * prm.B + b] = v;
+                                            }
                                         }
                                     }
                                     ++jsave;
                                 }
 #pragma unroll
-                                for (int i = 0; i < NS; ++i) u[i] = unew[i];
+                                for (int i = 0; i < H; ++i) u[i] = unew[i];
                                 p0 = p2;
+                                rsl = 10 - rsl;
                                 t = tnew;
                                 if (q >= kc->qsteady_min && q <= kc->qsteady_max) q = 1.0;
                                 lqold = ee_zero ? lqinit : fmax(lEE, lqinit);
@@ -453,34 +661,39 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
         // ================================================================== reverse sweep: loss (+ adjoint)
         const int n_saved = jsave;
         const int jlo = start_saved ? 1 : 0;
-        double lam[NS];
+        double lam[H];
 #pragma unroll
-        for (int i = 0; i < NS; ++i) lam[i] = 0.0;
+        for (int i = 0; i < H; ++i) lam[i] = 0.0;
         double loss_sum = 0.0;            // this lane's species only; the pair's sum is formed at the end
         double tnew = t;
         int s = valid ? nacc - 1 : -1;
-        // accumulator m of queue position r = wave_base + giw: gacc[(r >> 6) NTH 64 + m 64 + (r & 63)] (reduce_gacc_kernel's layout)
-        double *const gacc = hp.gacc + (size_t)((wave_base + giw) >> 6) * NTH * 64 + ((wave_base + giw) & 63);
+        // accumulator m of queue position r = wave_base + giw: gacc[(r >> 6) NTH 64 + m 64 + (r & 63)] (reduce_gacc_kernel's layout),
+        // addressed as uniform base (hp.gacc + m 64, SGPRs) + 32-bit byte offset of the lane (the host bounds the buffer to 4 GiB)
+        const unsigned goff_lane = (unsigned)((((wave_base + giw) >> 6) * NTH * 64 + ((wave_base + giw) & 63)) * 8);
+        unsigned goff_own[H];
+#pragma unroll
+        for (int i = 0; i < H; ++i) goff_own[i] = goff_lane + (unsigned)ln.ci[i] * 512u;
+#define HY2_ACC(m_, off_, val_) HY_ACC(reinterpret_cast<double *>(reinterpret_cast<char *>(hp.gacc) + (size_t)(m_) * 512 + (off_)), (val_))
         const double *const drows = prm.data + (size_t)b * prm.row_stride;
         int doff[H];
         bool obs[H];
 #pragma unroll
-        for (int i = 0; i < H; ++i) { const int dr = ow[i] ? (int)kc->drow[ci[i]] : -1; obs[i] = dr >= 0; doff[i] = obs[i] ? dr : 0; }
-        double rt = 0.0, rdt = 0.0, ru[NS];
+        for (int i = 0; i < H; ++i) { const int dr = ln.ow[i] ? (int)kc->drow[ln.ci[i]] : -1; obs[i] = dr >= 0; doff[i] = obs[i] ? dr : 0; }
+        double rt = 0.0, rdt = 0.0, ru[H];
         auto load_rec = [&](int idx) {
             const double *rec = tape + (size_t)(idx > 0 ? idx : 0) * RECW;
             rt = rec[0]; rdt = rec[1];
 #pragma unroll
-            for (int i = 0; i < NS; ++i) ru[i] = rec[2 + i];
+            for (int i = 0; i < H; ++i) { const double v = rec[2 + ln.ci[i]]; ru[i] = ln.ow[i] ? v : 0.0; }
         };
         load_rec(s);
 
         while (__builtin_amdgcn_ballot_w64(s >= 0) != 0) {
             if (s >= 0) {
                 const double tn = rt, h = rdt;
-                double un[NS];
+                double un[H];
 #pragma unroll
-                for (int i = 0; i < NS; ++i) un[i] = ru[i];
+                for (int i = 0; i < H; ++i) un[i] = ru[i];
                 // ---- re-form the step
                 HY_FRESH_THETA(th); HY_FRESH_KC(kc);
                 const double gam = d_ * h;
@@ -488,43 +701,61 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                 tab(tn, T, P, Td, Pd);
                 const double ld = Pd * frcp(P) - Td * frcp(T), xEd = -hp.inv_R * Td * frcp(T * T), xLd = Td * frcp(T);
                 HyPoint2<NS, NR> pn, pm;
-                hy_point2<NS, NR>(th, kc, hp.inv_R, un, T, P, m1, ci, ow, pn);
-                opaque(pn.r); opaque(pn.Y); opaque(pn.f); opaque(pn.fo); opaque(pn.xo); opaque(pn.irho); opaque(pn.iS);
-                HY_FRESH_THETA(th); HY_FRESH_KC(kc);
-                double dinv[NS], ft[NS];
-                int piv[NS];
-                bool anyp;
-                double k1[NS], dk[NS];
-                hy_jac_ft2<NS, NR, GPB>(th, kc, pn, gam, ld, xEd, xLd, m1, ci, ow, As, ft);
+                HY_T(5);
+                hy_point2<NS, NR, BLOCK>(th, kc, hp.inv_R, un, T, P, m1, ln, pn, fr);
+                HY_T(6);
+                if (GRAD) {
 #pragma unroll
-                for (int i = 0; i < NS; ++i) k1[i] = fma(gam, ft[i], pn.f[i]);
+                    for (int i = 0; i < H; ++i) FR(20 + i) = pn.xo[i];
+                    FR(50) = pn.xE; FR(51) = pn.xL;
+                }
+                opaque(pn.Yo); opaque(pn.fo); opaque(pn.irho); opaque(pn.iS);
+                HY_FRESH_THETA(th); HY_FRESH_KC(kc);
+                double A[H][NS], dinv[NS], ft[H];
+                unsigned long long piv;
+                bool anyp;
+                double k1[H], dk[H];
+                hy_jac_ft2<NS, NR, BLOCK>(th, kc, pn, fr, gam, ld, xEd, xLd, m1, ln, A, ft);
+#pragma unroll
+                for (int i = 0; i < H; ++i) k1[i] = fma(gam, ft[i], pn.fo[i]);
                 opaque(k1);
+                if (GRAD) {
+#pragma unroll
+                    for (int i = 0; i < H; ++i) FR(25 + i) = pn.Yo[i];
+                    FR(52) = pn.irho; FR(53) = pn.iS;
+                }
                 CRNN_SCHED_FENCE();
-                (void)factor(dinv, piv, anyp);
+                HY_T(7);
+                (void)lu2_factor<NS>(A, m1, dinv, piv, anyp);
                 const bool wp = __builtin_amdgcn_ballot_w64(anyp) != 0;
-                lu_solve_lds<NS, GPB>(As, dinv, piv, wp, k1);
+                HY_T(8);
+                lu2_solve<NS>(A, dinv, piv, wp, m1, k1);
+                HY_T(9);
                 HY_FRESH_THETA(th); HY_FRESH_KC(kc);
                 {
-                    double u1[NS], T1, P1, a_, b_;
+                    double u1[H], T1, P1, a_, b_;
 #pragma unroll
-                    for (int i = 0; i < NS; ++i) u1[i] = fma(0.5 * h, k1[i], un[i]);
+                    for (int i = 0; i < H; ++i) u1[i] = fma(0.5 * h, k1[i], un[i]);
                     tab(tn + 0.5 * h, T1, P1, a_, b_);
-                    hy_point2<NS, NR>(th, kc, hp.inv_R, u1, T1, P1, m1, ci, ow, pm);
-                    opaque(pm.r); opaque(pm.Y); opaque(pm.f); opaque(pm.xo); opaque(pm.irho); opaque(pm.iS);
+                    hy_point2<NS, NR, BLOCK>(th, kc, hp.inv_R, u1, T1, P1, m1, ln, pm, fr + 10 * BLOCK);
+                    if (GRAD) {
+#pragma unroll
+                        for (int i = 0; i < H; ++i) { FR(30 + i) = pm.xo[i]; FR(35 + i) = pm.Yo[i]; }
+                        FR(54) = pm.xE; FR(55) = pm.xL; FR(56) = pm.irho; FR(57) = pm.iS;
+                    }
+                    opaque(pm.fo);
                 }
 #pragma unroll
-                for (int i = 0; i < NS; ++i) dk[i] = pm.f[i] - k1[i];
-                lu_solve_lds<NS, GPB>(As, dinv, piv, wp, dk);
+                for (int i = 0; i < H; ++i) dk[i] = pm.fo[i] - k1[i];
+                HY_T(6);
+                lu2_solve<NS>(A, dinv, piv, wp, m1, dk);
                 CRNN_SCHED_FENCE();
+                HY_T(9);
 
                 // ---- loss and seeds at the save points inside (tn, tnew]: each lane its own species
-                double k1o[H], dko[H], uno[H];
-                pair_own<NS, H>(k1, m1, k1o);
-                pair_own<NS, H>(dk, m1, dko);
-                pair_own<NS, H>(un, m1, uno);
-                double Ao[H], B1o[H], B2o[H];
+                double A_[H], B1[H], B2[H];
 #pragma unroll
-                for (int i = 0; i < H; ++i) { Ao[i] = 0.0; B1o[i] = 0.0; B2o[i] = 0.0; }
+                for (int i = 0; i < H; ++i) { A_[i] = 0.0; B1[i] = 0.0; B2[i] = 0.0; }
                 while (jsave > jlo && ts_lds[jsave - 1] > tn) {
                     const double ts = ts_lds[jsave - 1];
                     const bool at_end = (ts == tnew);
@@ -535,141 +766,117 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
 #pragma unroll
                     for (int i = 0; i < H; ++i) {
                         if (obs[i]) {
-                            const double k2i = k1o[i] + dko[i];
-                            double v = at_end ? fma(h, k2i, uno[i]) : fma(h, fma(c1, k1o[i], c2 * k2i), uno[i]);
+                            const double k2i = k1[i] + dk[i];
+                            double v = at_end ? fma(h, k2i, un[i]) : fma(h, fma(c1, k1[i], c2 * k2i), un[i]);
                             double mask = 1.0;
                             if (prm.clamp_pred) {
                                 mask = (v > kc->ub || v < -kc->ub) ? 0.0 : 1.0;
                                 v = clampv(v, -kc->ub, kc->ub);
                             }
-                            const double iy = kc->inv_yscale[ci[i]];
+                            const double iy = kc->inv_yscale[ln.ci[i]];
                             const double rr = (row[doff[i]] - v) * iy;
                             double w;
                             if (prm.loss_kind == 0) { loss_sum += fabs(rr); w = signbit(rr) ? 1.0 : -1.0; }
                             else { loss_sum = fma(rr, rr, loss_sum); w = -2.0 * rr; }
                             w *= mask * iy;
-                            Ao[i] += w;
-                            B1o[i] = fma(w, h * c1, B1o[i]);
-                            B2o[i] = fma(w, h * c2, B2o[i]);
+                            A_[i] += w;
+                            B1[i] = fma(w, h * c1, B1[i]);
+                            B2[i] = fma(w, h * c2, B2[i]);
                         }
                     }
                     --jsave;
                 }
+                if (GRAD) {
+#pragma unroll
+                    for (int i = 0; i < H; ++i) { FR(40 + i) = k1[i]; FR(45 + i) = dk[i]; }
+                }
                 load_rec(s - 1);     // next tape record, fetched and awaited before this step's accumulator atomics are issued
                 opaque(rt); opaque(rdt); opaque(ru);
+                HY_T(10);
                 if (GRAD) {
-                    double A_[NS], B1[NS], B2[NS];
-                    pair_gather<NS, H>(Ao, m1, A_);
-                    pair_gather<NS, H>(B1o, m1, B1);
-                    pair_gather<NS, H>(B2o, m1, B2);
-                    // park what the last phase of the step needs again (the pair shares the slot: each lane its species' x, lane 0 the rest)
+                    // the accumulator offsets are made opaque per step: hoisted out of the loop, the 130 accumulator ADDRESSES are
+                    // formed once and live in scratch (one reload per atomic)
+                    unsigned gl = goff_lane, go_[H], zf_ = 0;
+                    asm volatile("" : "+v"(gl));
+                    asm volatile("" : "+v"(zf_));          // the frame is re-read: the parked values are NOT kept in registers too
+                    const double *const fq = fr + zf_;
+#define FQ(k_) fq[(k_) * BLOCK]
+                    const unsigned mcY = pm.cY, mcC = pm.cC;
 #pragma unroll
-                    for (int i = 0; i < H; ++i)
-                        if (ow[i]) park[ci[i] * GPB] = pn.xo[i];
-                    if (!m1) {
-                        park[NS * GPB] = pn.xE; park[(NS + 1) * GPB] = pn.xL;
-#pragma unroll
-                        for (int j = 0; j < NR; ++j) { park[(NS + 2 + j) * GPB] = pn.r[j]; park[(PK_R1 + j) * GPB] = pm.r[j]; }
-#pragma unroll
-                        for (int i = 0; i < NS; ++i) {
-                            park[(NS + 2 + NR + i) * GPB] = pn.Y[i];
-                            park[(2 * NS + 4 + NR + i) * GPB] = k1[i];
-                            park[(3 * NS + 4 + NR + i) * GPB] = dk[i];
-                        }
-                        park[(2 * NS + 2 + NR) * GPB] = pn.irho;
-                        park[(2 * NS + 3 + NR) * GPB] = pn.iS;
-                    }
+                    for (int i = 0; i < H; ++i) { go_[i] = goff_own[i]; asm volatile("" : "+v"(go_[i])); }
                     const unsigned ncY = pn.cY, ncC = pn.cC;
                     CRNN_SCHED_FENCE();
-                    double kb1[NS], v[NS], ub[NS];
+                    double kb1[H], v[H], ub[H];
 #pragma unroll
-                    for (int i = 0; i < NS; ++i) { v[i] = fma(h, lam[i], B2[i]); ub[i] = lam[i] + A_[i]; kb1[i] = B1[i] + v[i]; }
-                    lu_solve_T_lds<NS, GPB>(As, dinv, piv, wp, v);
-#pragma unroll
-                    for (int i = 0; i < NS; ++i) kb1[i] -= v[i];
+                    for (int i = 0; i < H; ++i) { v[i] = fma(h, lam[i], B2[i]); ub[i] = lam[i] + A_[i]; kb1[i] = B1[i] + v[i]; }
+                    lu2_solve_T<NS>(A, dinv, piv, wp, m1, v);
+                    HY_T(11);
                     double vto[H];      // (gsc .* v) of this lane's species
-                    {
-                        double vo[H];
-                        pair_own<NS, H>(v, m1, vo);
 #pragma unroll
-                        for (int i = 0; i < H; ++i) vto[i] = ow[i] ? vo[i] * kc->gsc[ci[i]] : 0.0;
-                    }
+                    for (int i = 0; i < H; ++i) { kb1[i] -= v[i]; vto[i] = v[i] * kc->gsc[ln.ci[i]]; }
                     opaque(vto); opaque(kb1); opaque(ub);
                     CRNN_SCHED_FENCE();
                     HY_FRESH_THETA(th); HY_FRESH_KC(kc);
                     // -------- point u_mid: adjoint of v.f
-                    double irho_mid = pm.irho;
-                    opaque(irho_mid);
                     {
-                        double P2o[H], psi = 0.0;
+                        double P2o[H], mxo[H], psi = 0.0;
 #pragma unroll
-                        for (int i = 0; i < H; ++i) P2o[i] = 0.0;
-#pragma unroll 1
+                        for (int i = 0; i < H; ++i) { P2o[i] = 0.0; mxo[i] = FQ(30 + i); }
+                        const double m_irho = FQ(56), mxE = FQ(54), mxL = FQ(55);
+#pragma unroll
                         for (int j = 0; j < NR; ++j) {
+                            CRNN_SCHED_FENCE();
+                            HY_FRESH_THETA(th);      // per reaction: merged, the 10 x 12 theta reads would be issued up front
                             const double *wo_ = th + L_::wo(0, j), *wi_ = th + L_::wi(0, j);
                             double At = 0.0;
 #pragma unroll
-                            for (int i = 0; i < H; ++i) At = fma(vto[i], wo_[ci[i]], At);
+                            for (int i = 0; i < H; ++i) At = fma(vto[i], wo_[ln.ci[i]], At);
                             At = pair_sum(At);
-                            const double ir = pm.irho * pm.r[j];
+                            const double ir = m_irho * FQ(10 + j);
                             const double Psi = At * ir;
                             psi += Psi;
-                            double *gj = gacc + (size_t)L_::wi(0, j) * 64;
 #pragma unroll
                             for (int i = 0; i < H; ++i) {
-                                if (ow[i]) HY_ACC(gj + (size_t)ci[i] * 64, Psi * pm.xo[i]);
-                                P2o[i] = fma(Psi, ow[i] ? wi_[ci[i]] : 0.0, P2o[i]);
+                                if (ln.ow[i]) HY2_ACC(L_::wi(0, j), go_[i], Psi * mxo[i]);
+                                P2o[i] = fma(Psi, ln.ow[i] ? wi_[ln.ci[i]] : 0.0, P2o[i]);
                             }
-                            if (!m1) { HY_ACC(gj + (size_t)NS * 64, Psi * pm.xE); HY_ACC(gj + (size_t)(NS + 1) * 64, Psi * pm.xL); }
+                            if (!m1) { HY2_ACC(L_::wi(NS, j), gl, Psi * mxE); HY2_ACC(L_::wi(NS + 1, j), gl, Psi * mxL); }
                         }
                         double scp = 0.0;
 #pragma unroll
-                        for (int i = 0; i < H; ++i) scp += (ow[i] && ((pm.cC >> ci[i]) & 1u)) ? P2o[i] : 0.0;
+                        for (int i = 0; i < H; ++i) scp += (ln.ow[i] && ((mcC >> ln.ci[i]) & 1u)) ? P2o[i] : 0.0;
                         scp = pair_sum(scp);
-                        double mo[H], mf[NS];
+                        const double m_iS = FQ(57);
 #pragma unroll
                         for (int i = 0; i < H; ++i) {
-                            const bool iy = ow[i] && ((pm.cY >> ci[i]) & 1u), ic = (pm.cC >> ci[i]) & 1u;
-                            double m_ = iy ? kc->imw[ci[i]] * pm.iS * (psi - scp) : 0.0;
-                            if (iy && ic) m_ = fma(P2o[i], frcp(m1 ? pm.Y[H + i < NS ? H + i : 0] : pm.Y[i]), m_);
-                            mo[i] = m_;
+                            const bool iy = ln.ow[i] && ((mcY >> ln.ci[i]) & 1u), ic = (mcC >> ln.ci[i]) & 1u;
+                            double m_ = iy ? kc->imw[ln.ci[i]] * m_iS * (psi - scp) : 0.0;
+                            if (iy && ic) m_ = fma(P2o[i], frcp(FQ(35 + i)), m_);
+                            ub[i] += m_;
+                            kb1[i] = fma(0.5 * h, m_, kb1[i]);
                         }
-                        pair_gather<NS, H>(mo, m1, mf);
-#pragma unroll
-                        for (int c = 0; c < NS; ++c) { ub[c] += mf[c]; kb1[c] = fma(0.5 * h, mf[c], kb1[c]); }
                     }
                     CRNN_SCHED_FENCE();
-                    lu_solve_T_lds<NS, GPB>(As, dinv, piv, wp, kb1);     // kb1 = w
+                    HY_T(12);
+                    lu2_solve_T<NS>(A, dinv, piv, wp, m1, kb1);     // kb1 = w
+                    HY_T(11);
                     opaque(kb1); opaque(ub); opaque(vto);
                     CRNN_SCHED_FENCE();
                     HY_FRESH_THETA(th); HY_FRESH_KC(kc);
                     // -------- point u_n: adjoint of w.f + gam ( v.Df[(dk,0)] + w.Df[(k1,1)] )
                     {
-                        HY2_LDS_SYNC();        // the pair's parked values (each lane wrote a part)
-                        unsigned zp_ = 0;
-                        asm volatile("" : "+v"(zp_));
-                        const double *pk = park + zp_;
-                        double xno[H], Yo[H], k1p[H], dkp[H], wto[H];
+                        double wto[H], k1p[H], dkp[H], Yn[H], xno[H];
 #pragma unroll
                         for (int i = 0; i < H; ++i) {
-                            xno[i] = pk[ci[i] * GPB];
-                            Yo[i] = pk[(NS + 2 + NR + ci[i]) * GPB];
-                            k1p[i] = pk[(2 * NS + 4 + NR + ci[i]) * GPB];
-                            dkp[i] = pk[(3 * NS + 4 + NR + ci[i]) * GPB];
+                            wto[i] = kb1[i] * kc->gsc[ln.ci[i]];
+                            k1p[i] = FQ(40 + i); dkp[i] = FQ(45 + i); Yn[i] = FQ(25 + i); xno[i] = FQ(20 + i);
                         }
-                        const double xnE = pk[NS * GPB], xnL = pk[(NS + 1) * GPB];
-                        const double n_irho = pk[(2 * NS + 2 + NR) * GPB], n_iS = pk[(2 * NS + 3 + NR) * GPB];
-                        {
-                            double wo2[H];
-                            pair_own<NS, H>(kb1, m1, wo2);
-#pragma unroll
-                            for (int i = 0; i < H; ++i) wto[i] = ow[i] ? wo2[i] * kc->gsc[ci[i]] : 0.0;
-                        }
+                        const double n_irho = FQ(52), n_iS = FQ(53), m_irho = FQ(56), xnE = FQ(50), xnL = FQ(51);
                         // direction data (this lane's species)
                         double Spv = 0.0, Spw = 0.0, xpvo[H], xpwo[H];
 #pragma unroll
                         for (int i = 0; i < H; ++i) {
-                            const double sg = (ow[i] && ((ncY >> ci[i]) & 1u)) ? kc->imw[ci[i]] * n_iS : 0.0;
+                            const double sg = (ln.ow[i] && ((ncY >> ln.ci[i]) & 1u)) ? kc->imw[ln.ci[i]] * n_iS : 0.0;
                             Spv = fma(sg, dkp[i], Spv);
                             Spw = fma(sg, k1p[i], Spw);
                         }
@@ -678,81 +885,78 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                         const double lpv = -Spv, lpw = ld - Spw;
 #pragma unroll
                         for (int i = 0; i < H; ++i) {
-                            const bool iy = ow[i] && ((ncY >> ci[i]) & 1u), ic = ow[i] && ((ncC >> ci[i]) & 1u);
-                            const double gy = iy ? frcp(Yo[i]) : 0.0;
+                            const bool iy = ln.ow[i] && ((ncY >> ln.ci[i]) & 1u), ic = ln.ow[i] && ((ncC >> ln.ci[i]) & 1u);
+                            const double gy = iy ? frcp(Yn[i]) : 0.0;
                             xpvo[i] = ic ? fma(gy, dkp[i], lpv) : 0.0;
                             xpwo[i] = ic ? fma(gy, k1p[i], lpw) : 0.0;
                         }
                         double PEo[H], P2vo[H], P2wo[H], SE = 0.0, psiv = 0.0, psiw = 0.0;
 #pragma unroll
                         for (int i = 0; i < H; ++i) { PEo[i] = 0.0; P2vo[i] = 0.0; P2wo[i] = 0.0; }
-#pragma unroll 1
+#pragma unroll
                         for (int j = 0; j < NR; ++j) {
+                            CRNN_SCHED_FENCE();
+                            HY_FRESH_THETA(th);
                             const double *wo_ = th + L_::wo(0, j), *wi_ = th + L_::wi(0, j);
                             double Av = 0.0, Aw = 0.0, zv = 0.0, zw = 0.0;
 #pragma unroll
                             for (int i = 0; i < H; ++i) {
-                                const double wij = ow[i] ? wi_[ci[i]] : 0.0;
-                                Av = fma(vto[i], wo_[ci[i]], Av);
-                                Aw = fma(wto[i], wo_[ci[i]], Aw);
+                                const double wij = ln.ow[i] ? wi_[ln.ci[i]] : 0.0;
+                                Av = fma(vto[i], wo_[ln.ci[i]], Av);
+                                Aw = fma(wto[i], wo_[ln.ci[i]], Aw);
                                 zv = fma(wij, xpvo[i], zv);
                                 zw = fma(wij, xpwo[i], zw);
                             }
                             Av = pair_sum(Av); Aw = pair_sum(Aw); zv = pair_sum(zv);
                             zw = pair_sum(zw) + fma(wi_[NS], xEd, wi_[NS + 1] * xLd);
-                            const double ir = n_irho * pk[(NS + 2 + j) * GPB];
+                            const double ir = n_irho * FQ(j);
                             const double Pv = Av * ir, Pw = Aw * ir;
                             const double yv = zv - lpv, yw = zw - lpw;
                             const double cw = fma(gam, yw, 1.0), cv = gam * yv;
                             const double E = fma(Pw, cw, Pv * cv);
                             SE += E; psiv += Pv; psiw += Pw;
-                            const double irm = irho_mid * pk[(PK_R1 + j) * GPB];   // the u_mid point's irho r_j
-                            if (!m1) HY_ACC(gacc + (size_t)L_::wb(j) * 64, fma(Av, irm, E));
+                            const double irm = m_irho * FQ(10 + j);   // the u_mid point's irho r_j
+                            if (!m1) HY2_ACC(L_::wb(j), gl, fma(Av, irm, E));
                             const double gPv = gam * Pv, gPw = gam * Pw;
-                            double *gj = gacc + (size_t)L_::wi(0, j) * 64;
-                            double *go = gacc + (size_t)L_::wo(0, j) * 64;
 #pragma unroll
                             for (int i = 0; i < H; ++i) {
-                                if (ow[i]) {
-                                    HY_ACC(gj + (size_t)ci[i] * 64, fma(E, xno[i], fma(gPw, xpwo[i], gPv * xpvo[i])));
-                                    HY_ACC(go + (size_t)ci[i] * 64, fma(vto[i], fma(ir, cv, irm), wto[i] * (ir * cw)));
+                                if (ln.ow[i]) {
+                                    HY2_ACC(L_::wi(0, j), go_[i], fma(E, xno[i], fma(gPw, xpwo[i], gPv * xpvo[i])));
+                                    HY2_ACC(L_::wo(0, j), go_[i], fma(vto[i], fma(ir, cv, irm), wto[i] * (ir * cw)));
                                 }
-                                const double wij = ow[i] ? wi_[ci[i]] : 0.0;
+                                const double wij = ln.ow[i] ? wi_[ln.ci[i]] : 0.0;
                                 PEo[i] = fma(E, wij, PEo[i]);
                                 P2vo[i] = fma(Pv, wij, P2vo[i]);
                                 P2wo[i] = fma(Pw, wij, P2wo[i]);
                             }
                             if (!m1) {
-                                HY_ACC(gj + (size_t)NS * 64, fma(E, xnE, gPw * xEd));
-                                HY_ACC(gj + (size_t)(NS + 1) * 64, fma(E, xnL, gPw * xLd));
+                                HY2_ACC(L_::wi(NS, j), gl, fma(E, xnE, gPw * xEd));
+                                HY2_ACC(L_::wi(NS + 1, j), gl, fma(E, xnL, gPw * xLd));
                             }
                         }
                         double scE = 0.0, scv = 0.0, scw = 0.0;
 #pragma unroll
                         for (int i = 0; i < H; ++i) {
-                            const bool ic = ow[i] && ((ncC >> ci[i]) & 1u);
+                            const bool ic = ln.ow[i] && ((ncC >> ln.ci[i]) & 1u);
                             scE += ic ? PEo[i] : 0.0;
                             scv += ic ? P2vo[i] : 0.0;
                             scw += ic ? P2wo[i] : 0.0;
                         }
                         scE = pair_sum(scE); scv = pair_sum(scv); scw = pair_sum(scw);
                         const double brk = (SE - scE) + gam * fma(Spw, scw - psiw, Spv * (scv - psiv));
-                        double mo[H], mf[NS];
 #pragma unroll
                         for (int i = 0; i < H; ++i) {
-                            const bool iy = ow[i] && ((ncY >> ci[i]) & 1u), ic = (ncC >> ci[i]) & 1u;
-                            double m_ = iy ? kc->imw[ci[i]] * n_iS * brk : 0.0;
+                            const bool iy = ln.ow[i] && ((ncY >> ln.ci[i]) & 1u), ic = (ncC >> ln.ci[i]) & 1u;
+                            double m_ = iy ? kc->imw[ln.ci[i]] * n_iS * brk : 0.0;
                             if (iy && ic) {
-                                const double gy = frcp(Yo[i]);
+                                const double gy = frcp(Yn[i]);
                                 m_ = fma(gy, PEo[i] - gam * gy * fma(P2wo[i], k1p[i], P2vo[i] * dkp[i]), m_);
                             }
-                            mo[i] = m_;
+                            lam[i] = ub[i] + m_;
                         }
-                        pair_gather<NS, H>(mo, m1, mf);
-#pragma unroll
-                        for (int c = 0; c < NS; ++c) lam[c] = ub[c] + mf[c];
-                        HY2_LDS_SYNC();        // the parked values are consumed before the next step parks again
                     }
+                    HY_T(13);
+#undef FQ
                 }
                 tnew = tn;
                 --s;
@@ -764,9 +968,9 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
 #pragma unroll
                 for (int i = 0; i < H; ++i) {
                     if (obs[i]) {
-                        double v = prm.u0[(size_t)ci[i] * prm.B + b];
+                        double v = prm.u0[(size_t)ln.ci[i] * prm.B + b];
                         if (prm.clamp_pred) v = clampv(v, -kc->ub, kc->ub);
-                        const double rr = (drows[doff[i]] - v) * kc->inv_yscale[ci[i]];
+                        const double rr = (drows[doff[i]] - v) * kc->inv_yscale[ln.ci[i]];
                         loss_sum += (prm.loss_kind == 0) ? fabs(rr) : rr * rr;
                     }
                 }
@@ -782,7 +986,12 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
             }
         }
     }
-#undef HY2_LDS_SYNC
+#undef HY2_ACC
+#undef FR
+#ifdef HY_PROF
+    if (hp.prof && blockIdx.x == 0 && tid == 0)
+        for (int k = 0; k < 16; ++k) hp.prof[k] = prof_acc[k];
+#endif
 }
 
 }  // namespace crnn
