@@ -614,11 +614,15 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
     const int nth = c->n_theta;
     const int npart_th = nth + crnn::kExtra, npart = P + crnn::kTail;
     using KFn = void (*)(const crnn::SolveParams, const double *, const crnn::HyParams);
-    // W's factors + parked state in LDS: ~1.1 KB per TRAJECTORY, 128 trajectories per CU either way: one lane each in a 128-lane
-    // block (hychem_kernel) or a lane pair each in a 256-lane block (hychem2_kernel.hpp: the step's critical path split over the pair)
-    // AUTO = the pair at every size: both kernels hold 128 trajectories per CU, the pair works through each of them faster
-    // (32 768: 8.12 -> 6.71 ms, 65 536: 8.97 -> 7.95, all 262 144 of config 4 on one GPU: 35.3 -> 31.8 ms)
-    const int G = c->lanes_per_traj == 1 ? 1 : 2;
+    // 128 trajectories per CU either way: one lane each in a 128-lane block (hychem_kernel: W's factors + parked state in LDS,
+    // ~1.1 KB per trajectory) or a lane pair each in a 256-lane block (hychem2_kernel.hpp: every vector and W's rows distributed
+    // over the pair, 512 registers per lane).  AUTO = the pair at every size: it works through each trajectory faster
+    // (32 768: 8.12 -> 6.06 ms, all 262 144 of config 4 on one GPU: 35.3 -> 27.2 ms)
+    // (the pair kernel addresses its accumulators with 32-bit byte offsets: launches whose accumulator buffer reaches 4 GiB --
+    //  2.5 million trajectories -- take the one-lane kernel)
+    const size_t gacc_need = (size_t)((count + 63) / 64) * nth * 64;
+    const bool gacc_small = gacc_need * sizeof(double) < ((size_t)1 << 32);
+    const int G = (c->lanes_per_traj == 1 || !gacc_small) ? 1 : 2;
     c->last_lanes = G;
     const int kHyBlock = 128 * G;
     KFn fn = G == 2 ? (P > 0 ? (KFn)crnn::hychem2_kernel<9, 10, true, 256> : (KFn)crnn::hychem2_kernel<9, 10, false, 256>)
@@ -643,7 +647,6 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
     if (c->tape_doubles < lanes * (size_t)cap * recw && ensure(c, &c->d_tape, &c->tape_doubles, lanes * (size_t)cap * recw)) return -1;
     const int rblk = (int)((count + 255) / 256);
     if (ensure(c, &c->d_partials, &c->partials_cap, (size_t)rblk * std::max(npart_th, npart))) return -1;
-    const size_t gacc_need = (size_t)((count + 63) / 64) * nth * 64;
     if (P > 0 && ensure(c, &c->d_gacc, &c->gacc_cap, gacc_need)) return -1;
     if (c->npart_max < npart) {
         if (c->d_red) HIP_TRY(c, hipFree(c->d_red));

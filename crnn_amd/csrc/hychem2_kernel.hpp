@@ -32,10 +32,13 @@ __device__ __forceinline__ double pair_other(double a) {   // the other lane of 
 }
 __device__ __forceinline__ int pair_other_i(int a) { return __builtin_amdgcn_update_dpp(0, a, 0xB1, 0xF, 0xF, false); }
 
-// the value held by the pair's lane `owner_odd`, in both lanes
-__device__ __forceinline__ double pair_pick(const double mine, const bool owner_odd, const bool m1) {
-    const double oth = pair_other(mine);
-    return (m1 == owner_odd) ? mine : oth;
+// the value held by the pair's lane `owner_odd`, in both lanes: one DPP move per half, quad_perm [1,1,3,3] / [0,0,2,2]
+// (owner_odd is a constant wherever this is called from an unrolled loop; the other branch folds away)
+__device__ __forceinline__ double pair_pick(const double mine, const bool owner_odd, const bool) {
+    const int lo = __double2loint(mine), hi = __double2hiint(mine);
+    if (owner_odd)
+        return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0xF5, 0xF, 0xF, false), __builtin_amdgcn_update_dpp(0, lo, 0xF5, 0xF, 0xF, false));
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0xA0, 0xF, 0xF, false), __builtin_amdgcn_update_dpp(0, lo, 0xA0, 0xF, 0xF, false));
 }
 
 // species-distributed (lane m holds species 2 i + m in own[i]) -> full-length, replicated
@@ -401,9 +404,11 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
     __shared__ double ts_lds[kMaxSave];
     __shared__ double th_lds[NTH];
     // the lane's LDS frame (slot k at fr[k BLOCK]; nobody else touches the column): what a step needs again much later is
-    // parked here instead of being carried in registers -- the rates of the FSAL point / of u_n (0-9) and of the new point /
-    // u_mid (10-19); reverse sweep: x, Y of the two points (20-39), k1, k2 - k1 (40-49), their scalars (50-57)
-    constexpr int NFR = GRAD ? 58 : 20;
+    // parked here instead of being carried in registers (a value the allocator spills goes to scratch memory, and a wavefront
+    // that runs alone on its SIMD waits out every reload: 700 bytes of scratch cost this kernel 40 % of its time) -- the rates
+    // of the FSAL point / of u_n (0-9) and of the new point / u_mid (10-19); reverse sweep: x, Y of the two points (20-39),
+    // k1, k2 - k1 (40-49), their scalars (50-57)
+    constexpr int NFR = 66;      // 58-65: the FSAL point's Y, irho, iS, clamp masks (forward sweep)
     __shared__ double fr_lds[NFR * BLOCK];
     const int tid = threadIdx.x;
     double *const fr = fr_lds + tid;
@@ -469,7 +474,8 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
 
         // ================================================================== forward sweep
         double u[H];
-        HyPoint2<NS, NR> p0;     // FSAL point (u, t)
+        HyPoint2<NS, NR> p0;     // FSAL point (u, t): only f stays in registers (f0), the rest is parked in the frame
+        double f0[H];
         double t = t0, dt = 0.0, lqold = lqinit;
         int iter = 0, jsave = 0, nacc = 0, nrej = 0;
         int rc = valid ? -1 : 0;
@@ -480,6 +486,9 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
             double T, P, Td, Pd;
             tab(t0, T, P, Td, Pd);
             hy_point2<NS, NR, BLOCK>(th, kc, hp.inv_R, u, T, P, m1, ln, p0, fr);
+#pragma unroll
+            for (int i = 0; i < H; ++i) FR(58 + i) = p0.Yo[i];
+            FR(63) = p0.irho; FR(64) = p0.iS; FR(65) = __hiloint2double((int)p0.cC, (int)p0.cY);
             double d0 = 0.0, d1 = 0.0, sk[H];
 #pragma unroll
             for (int i = 0; i < H; ++i) {
@@ -505,6 +514,8 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
             const double dm = fmax(d1, d2);
             const double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : exp(-0.5 * (4.605170185988091368 + flog(dm)));
             dt = fmax(kc->dtmin, fmin(fmin(100.0 * dt0, dt1), dtmax));
+#pragma unroll
+            for (int i = 0; i < H; ++i) f0[i] = p0.fo[i];
         }
         if (start_saved) {
             if (valid && prm.pred) {
@@ -538,6 +549,16 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                     unsigned long long piv;
                     bool anyp;
                     HY_T(0);
+                    {
+                        unsigned zf_ = 0;
+                        asm volatile("" : "+v"(zf_));
+                        const double *const fq = fr + zf_;
+#pragma unroll
+                        for (int i = 0; i < H; ++i) { p0.Yo[i] = fq[(58 + i) * BLOCK]; p0.fo[i] = f0[i]; }
+                        p0.irho = fq[63 * BLOCK]; p0.iS = fq[64 * BLOCK];
+                        const double mk = fq[65 * BLOCK];
+                        p0.cY = (unsigned)__double2loint(mk); p0.cC = (unsigned)__double2hiint(mk);
+                    }
                     hy_jac_ft2<NS, NR, BLOCK>(th, kc, p0, fr + rsl * BLOCK, gam, Pd * frcp(P) - Td * frcp(T), -hp.inv_R * Td * frcp(T * T), Td * frcp(T), m1, ln, A, ft);
                     CRNN_SCHED_FENCE();
                     HY_T(1);
@@ -546,7 +567,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                     HY_T(2);
                     double k1[H], dk[H], unew[H], f1[H];
 #pragma unroll
-                    for (int i = 0; i < H; ++i) k1[i] = fma(gam, ft[i], p0.fo[i]);
+                    for (int i = 0; i < H; ++i) k1[i] = fma(gam, ft[i], f0[i]);
                     lu2_solve<NS>(A, dinv, piv, wp, m1, k1);
                     CRNN_SCHED_FENCE();
                     HY_T(3);
@@ -584,7 +605,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
 #pragma unroll
                     for (int i = 0; i < H; ++i) {
                         const double k2i = k1[i] + dk[i];
-                        k3[i] = fma(dt, ft[i], p2.fo[i] - c32 * (k2i - f1[i]) - 2.0 * (k1[i] - p0.fo[i]));
+                        k3[i] = fma(dt, ft[i], p2.fo[i] - c32 * (k2i - f1[i]) - 2.0 * (k1[i] - f0[i]));
                     }
                     lu2_solve<NS>(A, dinv, piv, wp, m1, k3);
                     HY_T(3);
@@ -641,7 +662,9 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                                 }
 #pragma unroll
                                 for (int i = 0; i < H; ++i) u[i] = unew[i];
-                                p0 = p2;
+#pragma unroll
+                                for (int i = 0; i < H; ++i) { f0[i] = p2.fo[i]; FR(58 + i) = p2.Yo[i]; }
+                                FR(63) = p2.irho; FR(64) = p2.iS; FR(65) = __hiloint2double((int)p2.cC, (int)p2.cY);
                                 rsl = 10 - rsl;
                                 t = tnew;
                                 if (q >= kc->qsteady_min && q <= kc->qsteady_max) q = 1.0;
@@ -819,10 +842,10 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                     HY_FRESH_THETA(th); HY_FRESH_KC(kc);
                     // -------- point u_mid: adjoint of v.f
                     {
-                        double P2o[H], mxo[H], psi = 0.0;
+                        double P2o[H], Psis[NR], psi = 0.0;
 #pragma unroll
-                        for (int i = 0; i < H; ++i) { P2o[i] = 0.0; mxo[i] = FQ(30 + i); }
-                        const double m_irho = FQ(56), mxE = FQ(54), mxL = FQ(55);
+                        for (int i = 0; i < H; ++i) P2o[i] = 0.0;
+                        const double m_irho = FQ(56);
 #pragma unroll
                         for (int j = 0; j < NR; ++j) {
                             CRNN_SCHED_FENCE();
@@ -835,12 +858,9 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                             const double ir = m_irho * FQ(10 + j);
                             const double Psi = At * ir;
                             psi += Psi;
+                            Psis[j] = Psi;       // its w_in terms Psi_j x_mid are added together with the u_n point's (70 atomics less per step)
 #pragma unroll
-                            for (int i = 0; i < H; ++i) {
-                                if (ln.ow[i]) HY2_ACC(L_::wi(0, j), go_[i], Psi * mxo[i]);
-                                P2o[i] = fma(Psi, ln.ow[i] ? wi_[ln.ci[i]] : 0.0, P2o[i]);
-                            }
-                            if (!m1) { HY2_ACC(L_::wi(NS, j), gl, Psi * mxE); HY2_ACC(L_::wi(NS + 1, j), gl, Psi * mxL); }
+                            for (int i = 0; i < H; ++i) P2o[i] = fma(Psi, ln.ow[i] ? wi_[ln.ci[i]] : 0.0, P2o[i]);
                         }
                         double scp = 0.0;
 #pragma unroll
@@ -855,6 +875,10 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                             ub[i] += m_;
                             kb1[i] = fma(0.5 * h, m_, kb1[i]);
                         }
+                        // Psi_j -> frame slots 58-65 (the forward sweep's, idle now) and 35-36 (Y_mid, consumed above)
+                        static_assert(NR == 10, "frame slots of Psi");
+#pragma unroll
+                        for (int j = 0; j < NR; ++j) FR(j < 8 ? 58 + j : 27 + j) = Psis[j];
                     }
                     CRNN_SCHED_FENCE();
                     HY_T(12);
@@ -865,13 +889,16 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                     HY_FRESH_THETA(th); HY_FRESH_KC(kc);
                     // -------- point u_n: adjoint of w.f + gam ( v.Df[(dk,0)] + w.Df[(k1,1)] )
                     {
-                        double wto[H], k1p[H], dkp[H], Yn[H], xno[H];
+                        double wto[H], k1p[H], dkp[H], Yn[H], xno[H], mxo[H];
 #pragma unroll
                         for (int i = 0; i < H; ++i) {
                             wto[i] = kb1[i] * kc->gsc[ln.ci[i]];
-                            k1p[i] = FQ(40 + i); dkp[i] = FQ(45 + i); Yn[i] = FQ(25 + i); xno[i] = FQ(20 + i);
+                            k1p[i] = FQ(40 + i); dkp[i] = FQ(45 + i); Yn[i] = FQ(25 + i); xno[i] = FQ(20 + i); mxo[i] = FQ(30 + i);
                         }
-                        const double n_irho = FQ(52), n_iS = FQ(53), m_irho = FQ(56), xnE = FQ(50), xnL = FQ(51);
+                        const double n_irho = FQ(52), n_iS = FQ(53), m_irho = FQ(56), xnE = FQ(50), xnL = FQ(51), mxE = FQ(54), mxL = FQ(55);
+                        unsigned zg_ = 0;
+                        asm volatile("" : "+v"(zg_));
+                        const double *const fp = fr + zg_;   // Psi_j, re-read
                         // direction data (this lane's species)
                         double Spv = 0.0, Spw = 0.0, xpvo[H], xpwo[H];
 #pragma unroll
@@ -918,10 +945,11 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                             const double irm = m_irho * FQ(10 + j);   // the u_mid point's irho r_j
                             if (!m1) HY2_ACC(L_::wb(j), gl, fma(Av, irm, E));
                             const double gPv = gam * Pv, gPw = gam * Pw;
+                            const double Psi = fp[(j < 8 ? 58 + j : 27 + j) * BLOCK];
 #pragma unroll
                             for (int i = 0; i < H; ++i) {
                                 if (ln.ow[i]) {
-                                    HY2_ACC(L_::wi(0, j), go_[i], fma(E, xno[i], fma(gPw, xpwo[i], gPv * xpvo[i])));
+                                    HY2_ACC(L_::wi(0, j), go_[i], fma(E, xno[i], fma(gPw, xpwo[i], fma(gPv, xpvo[i], Psi * mxo[i]))));
                                     HY2_ACC(L_::wo(0, j), go_[i], fma(vto[i], fma(ir, cv, irm), wto[i] * (ir * cw)));
                                 }
                                 const double wij = ln.ow[i] ? wi_[ln.ci[i]] : 0.0;
@@ -930,8 +958,8 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                                 P2wo[i] = fma(Pw, wij, P2wo[i]);
                             }
                             if (!m1) {
-                                HY2_ACC(L_::wi(NS, j), gl, fma(E, xnE, gPw * xEd));
-                                HY2_ACC(L_::wi(NS + 1, j), gl, fma(E, xnL, gPw * xLd));
+                                HY2_ACC(L_::wi(NS, j), gl, fma(E, xnE, fma(gPw, xEd, Psi * mxE)));
+                                HY2_ACC(L_::wi(NS + 1, j), gl, fma(E, xnL, fma(gPw, xLd, Psi * mxL)));
                             }
                         }
                         double scE = 0.0, scv = 0.0, scw = 0.0;
