@@ -435,6 +435,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
     const double tend = ts_lds[nsave - 1], ts0 = ts_lds[0], t0 = kc->t0;
     const double dtmax = tend - t0;
     const double lqinit = flog(kc->qoldinit);
+    const double inv_qmax = 1.0 / kc->qmax, inv_qmin = 1.0 / kc->qmin;   // (the same quotients the one-lane kernel forms each step)
     const bool start_saved = (ts0 == t0);
     double *const tape = hp.tape + (size_t)((size_t)blockIdx.x * GPB + gib) * hp.tape_cap * RECW;
 #ifdef HY_PROF
@@ -622,13 +623,14 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                     }
                     es = pair_sum(es) * (1.0 / NS);
                     const bool finite = pair_and(fin) != 0;
+                    HY_T(14);
                     if (!finite) rc = 3;
                     else {
                         const bool ee_zero = (es == 0.0);
                         const double lEE = 0.5 * flog(ee_zero ? 1.0 : es);
                         const double lq11 = kc->beta1 * lEE;
-                        double q = ee_zero ? 1.0 / kc->qmax
-                                           : fmax(1.0 / kc->qmax, fmin(1.0 / kc->qmin, exp(lq11 - kc->beta2 * lqold) / kc->gamma));
+                        double q = ee_zero ? inv_qmax
+                                           : fmax(inv_qmax, fmin(inv_qmin, exp(lq11 - kc->beta2 * lqold) / kc->gamma));
                         if (es <= 1.0) {
                             if (nacc >= hp.tape_cap) {
                                 rc = 5;
@@ -674,9 +676,10 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                             }
                         } else {
                             ++nrej;
-                            dt = dt / fmin(1.0 / kc->qmin, exp(lq11) / kc->gamma);
+                            dt = dt / fmin(inv_qmin, exp(lq11) / kc->gamma);
                         }
                     }
+                    HY_T(15);
                 }
             }
         }
@@ -860,7 +863,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                             psi += Psi;
                             Psis[j] = Psi;       // its w_in terms Psi_j x_mid are added together with the u_n point's (70 atomics less per step)
 #pragma unroll
-                            for (int i = 0; i < H; ++i) P2o[i] = fma(Psi, ln.ow[i] ? wi_[ln.ci[i]] : 0.0, P2o[i]);
+                            for (int i = 0; i < H; ++i) P2o[i] = fma(Psi, wi_[ln.ci[i]], P2o[i]);   // (padding slot: never read)
                         }
                         double scp = 0.0;
 #pragma unroll
@@ -928,7 +931,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                             double Av = 0.0, Aw = 0.0, zv = 0.0, zw = 0.0;
 #pragma unroll
                             for (int i = 0; i < H; ++i) {
-                                const double wij = ln.ow[i] ? wi_[ln.ci[i]] : 0.0;
+                                const double wij = wi_[ln.ci[i]];   // (padding slot: multiplies zeros / feeds sums read under the mask)
                                 Av = fma(vto[i], wo_[ln.ci[i]], Av);
                                 Aw = fma(wto[i], wo_[ln.ci[i]], Aw);
                                 zv = fma(wij, xpvo[i], zv);
@@ -952,7 +955,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                                     HY2_ACC(L_::wi(0, j), go_[i], fma(E, xno[i], fma(gPw, xpwo[i], fma(gPv, xpvo[i], Psi * mxo[i]))));
                                     HY2_ACC(L_::wo(0, j), go_[i], fma(vto[i], fma(ir, cv, irm), wto[i] * (ir * cw)));
                                 }
-                                const double wij = ln.ow[i] ? wi_[ln.ci[i]] : 0.0;
+                                const double wij = wi_[ln.ci[i]];   // (padding slot: multiplies zeros / feeds sums read under the mask)
                                 PEo[i] = fma(E, wij, PEo[i]);
                                 P2vo[i] = fma(Pv, wij, P2vo[i]);
                                 P2wo[i] = fma(Pw, wij, P2wo[i]);

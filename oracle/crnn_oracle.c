@@ -341,11 +341,14 @@ int orc_p2vec(int kind, int ns, int nr, const double *p, double *th, double *dth
 /* ------------------------------------------------------------------------ */
 /* Dense LU with partial pivoting (n <= ORC_MAXN).                          */
 /* ------------------------------------------------------------------------ */
+static long g_lu_swaps = 0;   /* row exchanges since the last orc_lu_swaps(1): lets a test show that a scenario pivots */
+long orc_lu_swaps(int reset) { long v = g_lu_swaps; if (reset) g_lu_swaps = 0; return v; }
 static int lu_factor(int n, double *A, int *piv) {
     for (int k = 0; k < n; ++k) {
         int p = k; double best = fabs(A[k + n * k]);
         for (int i = k + 1; i < n; ++i) { double v = fabs(A[i + n * k]); if (v > best) { best = v; p = i; } }
         piv[k] = p;
+        if (p != k) ++g_lu_swaps;
         if (p != k) for (int c = 0; c < n; ++c) { double t = A[k + n * c]; A[k + n * c] = A[p + n * c]; A[p + n * c] = t; }
         double d = A[k + n * k];
         if (d == 0.0) return -1;

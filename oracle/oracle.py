@@ -318,6 +318,12 @@ class Hychem(C.Structure):
                 ("beta2", C.c_double), ("qsteady_min", C.c_double), ("qsteady_max", C.c_double), ("qoldinit", C.c_double)]
 
 
+def lu_swaps(reset=True):
+    """Row exchanges the oracle's LU factorisations have made since the last reset (pivoting coverage of a scenario)."""
+    lib().orc_lu_swaps.restype = C.c_long
+    return int(lib().orc_lu_swaps(C.c_int(1 if reset else 0)))
+
+
 def make_hychem(dydt_scale=None, yscale=None, atol=None, rtol=None, maxiters=None):
     c = Hychem()
     lib().orc_hychem_defaults(C.byref(c))

@@ -428,6 +428,45 @@ def test_gpu_hychem_queue_by_step_count_beyond_the_resident_lanes(hfx):
 
 
 @pytest.mark.gpu
+def test_gpu_hychem_pivoting_steps_pair_kernel(orc, hfx):
+    """Loose tolerances (rtol 1, atol 0.1) make the steps long enough that W = I - gam J loses its diagonal dominance: the
+    oracle's LU exchanges rows in these solves (counted, asserted > 0), so the pair kernel's row-distributed pivot search, its
+    register row swap and the permuted solves run -- against the one-lane kernel (same step counts, losses 1e-10, gradient 1e-7)
+    and against the oracle at the usual bars."""
+    from crnn_amd import p2vec_jac
+    u0s, datas, Tts, Pts = _synthetic(hfx, 29, 11)
+    u0 = np.concatenate([hfx["u0"], u0s]); data = np.concatenate([hfx["data"], datas])
+    Tt = np.concatenate([hfx["Ttab"], Tts]); Pt = np.concatenate([hfx["Ptab"], Pts])
+    B = len(u0)
+    p = np.array(hfx["p"])
+    th, dth = orc.hychem_p2vec(p)
+    c = _oracle_cfg(orc, hfx, atol=0.1, rtol=1.0)
+    orc.lu_swaps()
+    gref = np.zeros(211); lref = np.zeros(B); nacc = np.zeros(B, int)
+    for b in range(B):
+        r = orc.hychem_solve_one(c, th, u0[b], hfx["ts"], Tt[b], Pt[b], data[b], dtheta=dth)
+        assert r["retcode"] == 0
+        gref += r["grad"]; lref[b] = r["loss"]; nacc[b] = r["naccept"]
+    swaps = orc.lu_swaps()
+    assert swaps >= 20, swaps           # (30 measured; the three fixture trajectories alone: 8 exchanges in 19 steps)
+    out = {}
+    for lanes in (1, 2):
+        node = _node(hfx, u0, data, Tt, Pt, atol=0.1, rtol=1.0)
+        node.set_lanes_per_traj(lanes)
+        th_d, dth_d = p2vec_jac(node.pmap, 9, 10, p)
+        _, loss, gsum, ret, nsv = node._solve(node._ctx, B, th_d, dth_d, 0, B, None, False)
+        na, _ = node.step_counts()
+        assert node.last_lanes_per_traj() == lanes and np.all(ret == 0)
+        assert np.array_equal(na, nacc)
+        assert np.max(np.abs(loss - lref) / lref) < 1e-9
+        assert np.max(np.abs(gsum - gref)) < 1e-6 * np.max(np.abs(gref))
+        out[lanes] = (loss.copy(), gsum.copy())
+        node.close()
+    assert np.max(np.abs(out[1][0] - out[2][0]) / out[1][0]) < 1e-10
+    assert np.max(np.abs(out[1][1] - out[2][1])) < 1e-7 * np.max(np.abs(out[1][1]))
+
+
+@pytest.mark.gpu
 def test_gpu_hychem_two_lanes_match_one_lane_and_oracle(orc, hfx):
     """hychem2_kernel (a lane pair per trajectory: logarithms, exponentials, Jacobian rows, species contractions and accumulators
     split over the pair) against hychem_kernel (one lane) and the oracle: identical return codes and step counts, losses 1e-10,
