@@ -26,29 +26,27 @@ namespace crnn {
 
 __device__ __forceinline__ double pair_other(double a) {   // the other lane of the pair's value
     const int lo = __double2loint(a), hi = __double2hiint(a);
-    const int plo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false);
-    const int phi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false);
+    const int plo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true);
+    const int phi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
     return __hiloint2double(phi, plo);
 }
-__device__ __forceinline__ int pair_other_i(int a) { return __builtin_amdgcn_update_dpp(0, a, 0xB1, 0xF, 0xF, false); }
+__device__ __forceinline__ int pair_other_i(int a) { return __builtin_amdgcn_update_dpp(0, a, 0xB1, 0xF, 0xF, true); }
 
 // the value held by the pair's lane `owner_odd`, in both lanes: one DPP move per half, quad_perm [1,1,3,3] / [0,0,2,2]
 // (owner_odd is a constant wherever this is called from an unrolled loop; the other branch folds away)
 __device__ __forceinline__ double pair_pick(const double mine, const bool owner_odd, const bool) {
     const int lo = __double2loint(mine), hi = __double2hiint(mine);
     if (owner_odd)
-        return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0xF5, 0xF, 0xF, false), __builtin_amdgcn_update_dpp(0, lo, 0xF5, 0xF, 0xF, false));
-    return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0xA0, 0xF, 0xF, false), __builtin_amdgcn_update_dpp(0, lo, 0xA0, 0xF, 0xF, false));
+        return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0xF5, 0xF, 0xF, false), __builtin_amdgcn_update_dpp(0, lo, 0xF5, 0xF, 0xF, true));
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0xA0, 0xF, 0xF, false), __builtin_amdgcn_update_dpp(0, lo, 0xA0, 0xF, 0xF, true));
 }
 
-// species-distributed (lane m holds species 2 i + m in own[i]) -> full-length, replicated
+
+// species-distributed (lane m holds species 2 i + m in own[i]) -> full-length, replicated: one broadcast per element
 template <int NS, int H>
 __device__ __forceinline__ void pair_gather(const double (&own)[H], const bool m1, double (&full)[NS]) {
-    double oth[H];
 #pragma unroll
-    for (int i = 0; i < H; ++i) oth[i] = pair_other(own[i]);
-#pragma unroll
-    for (int c = 0; c < NS; ++c) full[c] = (m1 == ((c & 1) != 0)) ? own[c >> 1] : oth[c >> 1];
+    for (int c = 0; c < NS; ++c) full[c] = pair_pick(own[c >> 1], (c & 1) != 0, m1);
 }
 // full-length, replicated -> this lane's species
 template <int NS, int H>
@@ -111,8 +109,7 @@ __device__ __forceinline__ void hy_point2(const double *th, const KConst *kc, co
         flog_vec<H>(a_, la_);
 #pragma unroll
         for (int i = 0; i < H; ++i) pt.xo[i] = la_[i];
-        const double lt_other = pair_other(la_[H - 1]);
-        pt.xL = m1 ? la_[H - 1] : lt_other;
+        pt.xL = pair_pick(la_[H - 1], true, m1);
     }
     {
         const unsigned sh = m1 ? 1u : 0u;
@@ -135,14 +132,12 @@ __device__ __forceinline__ void hy_point2(const double *th, const KConst *kc, co
     CRNN_SCHED_FENCE();
     double r[NR];
     {   // H exponentials per lane, exchanged
-        double a_[H], e_[H], o_[H];
+        double a_[H], e_[H];
 #pragma unroll
         for (int k = 0; k < H; ++k) a_[k] = m1 ? z[H + k] : z[k];
         fexp_vec<H>(a_, e_);
 #pragma unroll
-        for (int k = 0; k < H; ++k) o_[k] = pair_other(e_[k]);
-#pragma unroll
-        for (int k = 0; k < H; ++k) { r[k] = m1 ? o_[k] : e_[k]; r[H + k] = m1 ? e_[k] : o_[k]; }
+        for (int k = 0; k < H; ++k) { r[k] = pair_pick(e_[k], false, m1); r[H + k] = pair_pick(e_[k], true, m1); }
     }
     if (rf) {
 #pragma unroll
@@ -714,7 +709,9 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
         };
         load_rec(s);
 
+        int itw = 0;             // the wavefront's reverse iterations (uniform)
         while (__builtin_amdgcn_ballot_w64(s >= 0) != 0) {
+            ++itw;
             if (s >= 0) {
                 const double tn = rt, h = rdt;
                 double un[H];
@@ -923,10 +920,15 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                         double PEo[H], P2vo[H], P2wo[H], SE = 0.0, psiv = 0.0, psiw = 0.0;
 #pragma unroll
                         for (int i = 0; i < H; ++i) { PEo[i] = 0.0; P2vo[i] = 0.0; P2wo[i] = 0.0; }
-#pragma unroll
-                        for (int j = 0; j < NR; ++j) {
-                            CRNN_SCHED_FENCE();
-                            HY_FRESH_THETA(th);
+                        // The reactions in a ROLLED loop (one copy of the body in the instruction stream) whose direction alternates
+                        // from one reverse iteration of the wavefront to the next: the accumulator lines touched last are touched
+                        // first again, so the part of a wavefront's 54 KB of accumulators that its XCD's L2 still holds is reused
+                        // (an XCD's wavefronts own 6.9 MB of accumulators, its L2 holds 4 MB; walked in one direction every line
+                        // would be evicted before its next visit)
+                        const int rev = __builtin_amdgcn_readfirstlane(itw & 1);
+#pragma unroll 1
+                        for (int jj = 0; jj < NR; ++jj) {
+                            const int j = rev ? NR - 1 - jj : jj;
                             const double *wo_ = th + L_::wo(0, j), *wi_ = th + L_::wi(0, j);
                             double Av = 0.0, Aw = 0.0, zv = 0.0, zw = 0.0;
 #pragma unroll

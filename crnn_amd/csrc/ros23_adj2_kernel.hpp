@@ -30,11 +30,12 @@ namespace crnn {
 // a + (the other lane of the pair's a): one DPP step per 32-bit half; identical bits in both lanes (a+b == b+a)
 __device__ __forceinline__ double pair_sum(double a) {
     const int lo = __double2loint(a), hi = __double2hiint(a);
-    const int plo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
-    const int phi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false);
+    // quad_perm [1,0,3,2]; bound_ctrl (every source lane exists) so that no "old" value has to be moved into the destination first
+    const int plo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true);
+    const int phi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
     return a + __hiloint2double(phi, plo);
 }
-__device__ __forceinline__ int pair_and(int a) { return a & __builtin_amdgcn_update_dpp(0, a, 0xB1, 0xF, 0xF, false); }
+__device__ __forceinline__ int pair_and(int a) { return a & __builtin_amdgcn_update_dpp(0, a, 0xB1, 0xF, 0xF, true); }
 
 template <int NS, int NR, bool HAS_T, int BLOCK, int OCC>
 __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParams prm, const double *__restrict__ theta,
