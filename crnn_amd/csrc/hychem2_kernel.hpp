@@ -700,14 +700,19 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
         bool obs[H];
 #pragma unroll
         for (int i = 0; i < H; ++i) { const int dr = ln.ow[i] ? (int)kc->drow[ln.ci[i]] : -1; obs[i] = dr >= 0; doff[i] = obs[i] ? dr : 0; }
-        double rt = 0.0, rdt = 0.0, ru[H];
-        auto load_rec = [&](int idx) {
+        // tape records are fetched TWO steps ahead: record s - 2 is requested just before step s issues its accumulator atomics and
+        // is consumed one iteration later, at the same point -- by then the atomics that were queued behind it have long drained
+        // (vmcnt counts loads and atomics in issue order: a load requested after them, or awaited right behind them, stalls the lane
+        // for a full memory latency per step)
+        double rt = 0.0, rdt = 0.0, ru[H], qt = 0.0, qdt = 0.0, qu[H];
+        auto fetch_rec = [&](int idx, double &t_, double &dt_, double (&u_)[H]) {
             const double *rec = tape + (size_t)(idx > 0 ? idx : 0) * RECW;
-            rt = rec[0]; rdt = rec[1];
+            t_ = rec[0]; dt_ = rec[1];
 #pragma unroll
-            for (int i = 0; i < H; ++i) { const double v = rec[2 + ln.ci[i]]; ru[i] = ln.ow[i] ? v : 0.0; }
+            for (int i = 0; i < H; ++i) { const double v = rec[2 + ln.ci[i]]; u_[i] = ln.ow[i] ? v : 0.0; }
         };
-        load_rec(s);
+        fetch_rec(s, rt, rdt, ru);
+        fetch_rec(s - 1, qt, qdt, qu);
 
         int itw = 0;             // the wavefront's reverse iterations (uniform)
         while (__builtin_amdgcn_ballot_w64(s >= 0) != 0) {
@@ -813,8 +818,11 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
 #pragma unroll
                     for (int i = 0; i < H; ++i) { FR(40 + i) = k1[i]; FR(45 + i) = dk[i]; }
                 }
-                load_rec(s - 1);     // next tape record, fetched and awaited before this step's accumulator atomics are issued
-                opaque(rt); opaque(rdt); opaque(ru);
+                opaque(qt); opaque(qdt); opaque(qu);          // record s - 1 (requested one iteration ago) has arrived
+                rt = qt; rdt = qdt;
+#pragma unroll
+                for (int i = 0; i < H; ++i) ru[i] = qu[i];
+                fetch_rec(s - 2, qt, qdt, qu);                 // in flight across this step's atomics
                 HY_T(10);
                 if (GRAD) {
                     // the accumulator offsets are made opaque per step: hoisted out of the loop, the 130 accumulator ADDRESSES are
