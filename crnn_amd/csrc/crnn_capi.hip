@@ -618,11 +618,10 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
     // ~1.1 KB per trajectory) or a lane pair each in a 256-lane block (hychem2_kernel.hpp: every vector and W's rows distributed
     // over the pair, 512 registers per lane).  AUTO = the pair at every size: it works through each trajectory faster
     // (32 768: 8.12 -> 6.06 ms, all 262 144 of config 4 on one GPU: 35.3 -> 27.2 ms)
-    // (the pair kernel addresses its accumulators with 32-bit byte offsets: launches whose accumulator buffer reaches 4 GiB --
-    //  2.5 million trajectories -- take the one-lane kernel)
-    const size_t gacc_need = (size_t)((count + 63) / 64) * nth * 64;
-    const bool gacc_small = gacc_need * sizeof(double) < ((size_t)1 << 32);
-    const int G = (c->lanes_per_traj == 1 || !gacc_small) ? 1 : 2;
+    // Gradient accumulators: the one-lane kernel keeps 210 per trajectory in HBM (global atomics, reduce_gacc_kernel); the pair
+    // kernel sums over the 32 trajectories of a batch with FP64 MFMAs and writes one row per batch.
+    const int G = c->lanes_per_traj == 1 ? 1 : 2;
+    const size_t gacc_need = G == 1 ? (size_t)((count + 63) / 64) * nth * 64 : 0;
     c->last_lanes = G;
     const int kHyBlock = 128 * G;
     KFn fn = G == 2 ? (P > 0 ? (KFn)crnn::hychem2_kernel<9, 10, true, 256> : (KFn)crnn::hychem2_kernel<9, 10, false, 256>)
@@ -646,8 +645,9 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
     cap = std::min<int64_t>(cap, c->cfg.maxiters);
     if (c->tape_doubles < lanes * (size_t)cap * recw && ensure(c, &c->d_tape, &c->tape_doubles, lanes * (size_t)cap * recw)) return -1;
     const int rblk = (int)((count + 255) / 256);
-    if (ensure(c, &c->d_partials, &c->partials_cap, (size_t)rblk * std::max(npart_th, npart))) return -1;
-    if (P > 0 && ensure(c, &c->d_gacc, &c->gacc_cap, gacc_need)) return -1;
+    const int wrows = (G == 2 && P > 0) ? (int)((count + 31) / 32) : 0;   // the pair kernel's rows of the partial-sum table: one per batch of 32
+    if (ensure(c, &c->d_partials, &c->partials_cap, (size_t)(wrows + rblk) * std::max(npart_th, npart))) return -1;
+    if (P > 0 && G == 1 && ensure(c, &c->d_gacc, &c->gacc_cap, gacc_need)) return -1;
     if (c->npart_max < npart) {
         if (c->d_red) HIP_TRY(c, hipFree(c->d_red));
         c->d_red = nullptr;
@@ -658,7 +658,8 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
     crnn::SolveParams prm{};
     fill_params(c, prm, P, first, count, n_save_active, want_pred);
     crnn::HyParams hp{};
-    hp.tabs = c->d_tabs; hp.tape = c->d_tape; hp.tape_cap = (int32_t)cap; hp.overflow = c->d_overflow; hp.gacc = c->d_gacc;
+    hp.tabs = c->d_tabs; hp.tape = c->d_tape; hp.tape_cap = (int32_t)cap; hp.overflow = c->d_overflow;
+    hp.gacc = G == 2 ? c->d_partials : c->d_gacc;
     hp.n_save_total = c->cfg.n_save; hp.inv_R = c->cfg.inv_R;
     if (queue_by_steps(c, lanes, first, count, &hp.perm)) return -1;
 #ifdef HY_PROF
@@ -673,7 +674,7 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
         HIP_TRY(c, hipMemsetAsync(c->d_overflow, 0, sizeof(unsigned int), c->stream));
     }
     c->flags_zeroed = false;
-    if (P > 0) HIP_TRY(c, hipMemsetAsync(c->d_gacc, 0, sizeof(double) * gacc_need, c->stream));
+    if (P > 0 && G == 1) HIP_TRY(c, hipMemsetAsync(c->d_gacc, 0, sizeof(double) * gacc_need, c->stream));
     c->ev0 = c->ring0[c->n_launch % Ctx::kRing];
     c->ev1 = c->ring1[c->n_launch % Ctx::kRing];
     ++c->n_launch;
@@ -682,10 +683,14 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     if (P > 0) {
-        hipLaunchKernelGGL(crnn::reduce_gacc_kernel, dim3(rblk), dim3(256), 0, c->stream, c->d_gacc, nth, c->n_obs, c->d_loss,
-                           c->d_ret, c->d_nsaved, c->d_nacc, c->d_nrej, first, count, hp.perm, c->d_partials);
+        if (G == 2)
+            hipLaunchKernelGGL(crnn::hy2_extras_kernel, dim3(rblk), dim3(256), 0, c->stream, c->d_partials + (size_t)wrows * npart_th, nth,
+                               c->d_loss, c->d_ret, c->d_nacc, c->d_nrej, first, count);
+        else
+            hipLaunchKernelGGL(crnn::reduce_gacc_kernel, dim3(rblk), dim3(256), 0, c->stream, c->d_gacc, nth, c->n_obs, c->d_loss,
+                               c->d_ret, c->d_nsaved, c->d_nacc, c->d_nrej, first, count, hp.perm, c->d_partials);
         HIP_TRY(c, hipGetLastError());
-        hipLaunchKernelGGL(crnn::reduce_project_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_partials, rblk, d_dtheta, nth, P,
+        hipLaunchKernelGGL(crnn::reduce_project_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_partials, wrows + rblk, d_dtheta, nth, P,
                            c->d_red_theta, c->d_red, (const unsigned int *)nullptr);
         HIP_TRY(c, hipGetLastError());
     } else {

@@ -24,6 +24,8 @@
 
 namespace crnn {
 
+typedef double hy_v4d __attribute__((ext_vector_type(4)));   // one lane's share of a 16 x 16 FP64 MFMA tile
+
 __device__ __forceinline__ double pair_other(double a) {   // the other lane of the pair's value
     const int lo = __double2loint(a), hi = __double2hiint(a);
     const int plo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true);
@@ -403,17 +405,37 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
     // that runs alone on its SIMD waits out every reload: 700 bytes of scratch cost this kernel 40 % of its time) -- the rates
     // of the FSAL point / of u_n (0-9) and of the new point / u_mid (10-19); reverse sweep: x, Y of the two points (20-39),
     // k1, k2 - k1 (40-49), their scalars (50-57)
-    constexpr int NFR = 66;      // 58-65: the FSAL point's Y, irho, iS, clamp masks (forward sweep)
+    constexpr int NFR = 65;      // 58-64: the FSAL point's Y, irho, iS (forward sweep).  Lane-major, pitch 65 doubles: every slot is an
+                                 // immediate offset from ONE address register (slot-major, 2 KB apart, half the slots were out of the
+                                 // 64 KB offset range and each had its own address register -- spilled), and the odd pitch is conflict-free
     __shared__ double fr_lds[NFR * BLOCK];
+    // Gradient accumulation (GRAD): the sum over the wavefront's trajectories of the step's outer products  x (features) y^T
+    // (reactions) is a contraction over the LANE axis -- v_mfma_f64_16x16x4_f64 does it: the lanes stage x (12 rows: 9 species,
+    // -1/(R T), log T, 1 for w_b) and y (10 columns) of one term in this buffer, [row][trajectory] with a row pitch of 33 so
+    // that the 16 rows an operand load touches fall into different banks; eight MFMAs (four trajectories of K each) add the
+    // term to the wavefront's 16 x 16 tile.  The tiles (w_in | w_b and w_out: 2 x 4 doubles per lane) live in registers for the
+    // whole kernel and are written out once; no accumulator ever goes to HBM.
+    constexpr int ST_P = 33, ST_X = 12 * ST_P, ST_W = ST_X + NR * ST_P;
+    __shared__ double st_lds[GRAD ? (BLOCK / 64) * ST_W : 1];
     const int tid = threadIdx.x;
-    double *const fr = fr_lds + tid;
-#define FR(k_) fr[(k_) * BLOCK]
+    double *const fr = fr_lds + tid * NFR;
+#define FR(k_) fr[(k_)]
+    // wave-level ordering of LDS traffic between the lanes of the wavefront (one lane's stores, another lane's loads)
+#define HY2_LDS_SYNC()                                                   \
+    do {                                                                 \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");           \
+        __builtin_amdgcn_wave_barrier();                                 \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");           \
+    } while (0)
     const int lane = tid & 63;
     const bool m1 = (lane & 1) != 0;
     const int gib = tid >> 1, giw = lane >> 1;
     for (int idx = tid; idx < kNConst; idx += BLOCK) kc_lds[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
     for (int idx = tid; idx < hp.n_save_total; idx += BLOCK) ts_lds[idx] = prm.tsave[idx];
     for (int idx = tid; idx < NTH; idx += BLOCK) th_lds[idx] = theta[idx];
+    if (GRAD) {   // (the MFMA stage reads the frame of lanes that have not run a step yet: make what they find finite)
+        for (int k = 0; k < NFR; ++k) fr_lds[threadIdx.x * NFR + k] = 0.0;
+    }
     __syncthreads();
     const KConst *kc = reinterpret_cast<const KConst *>(kc_lds);
     const double *th = th_lds;
@@ -425,6 +447,9 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
         ln.ci[i] = ln.ow[i] ? c : 0;
     }
 
+    hy_v4d acc_wi = {0.0, 0.0, 0.0, 0.0}, acc_wo = {0.0, 0.0, 0.0, 0.0}, acc_wi2 = {0.0, 0.0, 0.0, 0.0}, acc_wo2 = {0.0, 0.0, 0.0, 0.0};
+    double *const st = st_lds + (GRAD ? (tid >> 6) * ST_W : 0);
+    const int st_row = lane & 15, st_k = lane >> 4;       // MFMA operand (row or column, k) of this lane
     const double d_ = 0.29289321881345248, c32 = 7.4142135623730950, inv12d = 2.4142135623730950;
     const int nsave = prm.n_save, Dfull = hp.n_save_total;
     const double tend = ts_lds[nsave - 1], ts0 = ts_lds[0], t0 = kc->t0;
@@ -472,6 +497,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
         double u[H];
         HyPoint2<NS, NR> p0;     // FSAL point (u, t): only f stays in registers (f0), the rest is parked in the frame
         double f0[H];
+        unsigned f0cY = 0, f0cC = 0;     // the FSAL point's clamp masks
         double t = t0, dt = 0.0, lqold = lqinit;
         int iter = 0, jsave = 0, nacc = 0, nrej = 0;
         int rc = valid ? -1 : 0;
@@ -481,10 +507,11 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
         {
             double T, P, Td, Pd;
             tab(t0, T, P, Td, Pd);
-            hy_point2<NS, NR, BLOCK>(th, kc, hp.inv_R, u, T, P, m1, ln, p0, fr);
+            hy_point2<NS, NR, 1>(th, kc, hp.inv_R, u, T, P, m1, ln, p0, fr);
 #pragma unroll
             for (int i = 0; i < H; ++i) FR(58 + i) = p0.Yo[i];
-            FR(63) = p0.irho; FR(64) = p0.iS; FR(65) = __hiloint2double((int)p0.cC, (int)p0.cY);
+            FR(63) = p0.irho; FR(64) = p0.iS;
+            f0cY = p0.cY; f0cC = p0.cC;
             double d0 = 0.0, d1 = 0.0, sk[H];
 #pragma unroll
             for (int i = 0; i < H; ++i) {
@@ -502,7 +529,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
             for (int i = 0; i < H; ++i) u1[i] = fma(dt0, p0.fo[i], u[i]);
             HyPoint2<NS, NR> p1;
             tab(t0 + dt0, T, P, Td, Pd);
-            hy_point2<NS, NR, BLOCK>(th, kc, hp.inv_R, u1, T, P, m1, ln, p1, nullptr);
+            hy_point2<NS, NR, 1>(th, kc, hp.inv_R, u1, T, P, m1, ln, p1, nullptr);
             double d2 = 0.0;
 #pragma unroll
             for (int i = 0; i < H; ++i) { const double e = (p1.fo[i] - p0.fo[i]) * sk[i]; d2 = fma(e, e, d2); }
@@ -550,12 +577,11 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                         asm volatile("" : "+v"(zf_));
                         const double *const fq = fr + zf_;
 #pragma unroll
-                        for (int i = 0; i < H; ++i) { p0.Yo[i] = fq[(58 + i) * BLOCK]; p0.fo[i] = f0[i]; }
-                        p0.irho = fq[63 * BLOCK]; p0.iS = fq[64 * BLOCK];
-                        const double mk = fq[65 * BLOCK];
-                        p0.cY = (unsigned)__double2loint(mk); p0.cC = (unsigned)__double2hiint(mk);
+                        for (int i = 0; i < H; ++i) { p0.Yo[i] = fq[58 + i]; p0.fo[i] = f0[i]; }
+                        p0.irho = fq[63]; p0.iS = fq[64];
+                        p0.cY = f0cY; p0.cC = f0cC;
                     }
-                    hy_jac_ft2<NS, NR, BLOCK>(th, kc, p0, fr + rsl * BLOCK, gam, Pd * frcp(P) - Td * frcp(T), -hp.inv_R * Td * frcp(T * T), Td * frcp(T), m1, ln, A, ft);
+                    hy_jac_ft2<NS, NR, 1>(th, kc, p0, fr + rsl, gam, Pd * frcp(P) - Td * frcp(T), -hp.inv_R * Td * frcp(T * T), Td * frcp(T), m1, ln, A, ft);
                     CRNN_SCHED_FENCE();
                     HY_T(1);
                     const bool okf = lu2_factor<NS>(A, m1, dinv, piv, anyp);
@@ -575,7 +601,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                         HyPoint2<NS, NR> p1;
                         double T1, P1, a_, b_;
                         tab(t + 0.5 * dt, T1, P1, a_, b_);
-                        hy_point2<NS, NR, BLOCK>(th, kc, hp.inv_R, u1, T1, P1, m1, ln, p1, nullptr);
+                        hy_point2<NS, NR, 1>(th, kc, hp.inv_R, u1, T1, P1, m1, ln, p1, nullptr);
 #pragma unroll
                         for (int i = 0; i < H; ++i) f1[i] = p1.fo[i];
                         opaque(f1);
@@ -593,7 +619,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                     {
                         double T2, P2, a_, b_;
                         tab(tnew, T2, P2, a_, b_);
-                        hy_point2<NS, NR, BLOCK>(th, kc, hp.inv_R, unew, T2, P2, m1, ln, p2, fr + (10 - rsl) * BLOCK);
+                        hy_point2<NS, NR, 1>(th, kc, hp.inv_R, unew, T2, P2, m1, ln, p2, fr + (10 - rsl));
                     }
                     CRNN_SCHED_FENCE();
                     HY_T(4);
@@ -661,7 +687,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                                 for (int i = 0; i < H; ++i) u[i] = unew[i];
 #pragma unroll
                                 for (int i = 0; i < H; ++i) { f0[i] = p2.fo[i]; FR(58 + i) = p2.Yo[i]; }
-                                FR(63) = p2.irho; FR(64) = p2.iS; FR(65) = __hiloint2double((int)p2.cC, (int)p2.cY);
+                                FR(63) = p2.irho; FR(64) = p2.iS; f0cY = p2.cY; f0cC = p2.cC;
                                 rsl = 10 - rsl;
                                 t = tnew;
                                 if (q >= kc->qsteady_min && q <= kc->qsteady_max) q = 1.0;
@@ -688,13 +714,9 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
         double loss_sum = 0.0;            // this lane's species only; the pair's sum is formed at the end
         double tnew = t;
         int s = valid ? nacc - 1 : -1;
-        // accumulator m of queue position r = wave_base + giw: gacc[(r >> 6) NTH 64 + m 64 + (r & 63)] (reduce_gacc_kernel's layout),
-        // addressed as uniform base (hp.gacc + m 64, SGPRs) + 32-bit byte offset of the lane (the host bounds the buffer to 4 GiB)
-        const unsigned goff_lane = (unsigned)((((wave_base + giw) >> 6) * NTH * 64 + ((wave_base + giw) & 63)) * 8);
-        unsigned goff_own[H];
-#pragma unroll
-        for (int i = 0; i < H; ++i) goff_own[i] = goff_lane + (unsigned)ln.ci[i] * 512u;
-#define HY2_ACC(m_, off_, val_) HY_ACC(reinterpret_cast<double *>(reinterpret_cast<char *>(hp.gacc) + (size_t)(m_) * 512 + (off_)), (val_))
+        // the trajectory's weight in the batch gradient, 1 / (n_obs n_saved) (reduce_gacc_kernel's scale): carried by the loss seeds,
+        // so every adjoint quantity -- linear in the seeds -- arrives at the wavefront's tiles already weighted
+        const double gscale = n_saved > 0 ? 1.0 / ((double)prm.n_obs * (double)n_saved) : 0.0;
         const double *const drows = prm.data + (size_t)b * prm.row_stride;
         int doff[H];
         bool obs[H];
@@ -714,9 +736,11 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
         fetch_rec(s, rt, rdt, ru);
         fetch_rec(s - 1, qt, qdt, qu);
 
-        int itw = 0;             // the wavefront's reverse iterations (uniform)
         while (__builtin_amdgcn_ballot_w64(s >= 0) != 0) {
-            ++itw;
+            const bool act = (s >= 0);
+            // what the step hands to the MFMA stage below (outside the divergent region: the matrix unit ignores EXEC)
+            // (most of it waits in the lane's frame; registers carry the direction data, v~, w~ and the lane's half of one factor)
+            double c2h[NR / 2], sxw[H], sxv[H], svt[H], swt[H], s_xEd = 0.0, s_xLd = 0.0;
             if (s >= 0) {
                 const double tn = rt, h = rdt;
                 double un[H];
@@ -730,7 +754,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                 const double ld = Pd * frcp(P) - Td * frcp(T), xEd = -hp.inv_R * Td * frcp(T * T), xLd = Td * frcp(T);
                 HyPoint2<NS, NR> pn, pm;
                 HY_T(5);
-                hy_point2<NS, NR, BLOCK>(th, kc, hp.inv_R, un, T, P, m1, ln, pn, fr);
+                hy_point2<NS, NR, 1>(th, kc, hp.inv_R, un, T, P, m1, ln, pn, fr);
                 HY_T(6);
                 if (GRAD) {
 #pragma unroll
@@ -743,7 +767,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                 unsigned long long piv;
                 bool anyp;
                 double k1[H], dk[H];
-                hy_jac_ft2<NS, NR, BLOCK>(th, kc, pn, fr, gam, ld, xEd, xLd, m1, ln, A, ft);
+                hy_jac_ft2<NS, NR, 1>(th, kc, pn, fr, gam, ld, xEd, xLd, m1, ln, A, ft);
 #pragma unroll
                 for (int i = 0; i < H; ++i) k1[i] = fma(gam, ft[i], pn.fo[i]);
                 opaque(k1);
@@ -765,7 +789,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
 #pragma unroll
                     for (int i = 0; i < H; ++i) u1[i] = fma(0.5 * h, k1[i], un[i]);
                     tab(tn + 0.5 * h, T1, P1, a_, b_);
-                    hy_point2<NS, NR, BLOCK>(th, kc, hp.inv_R, u1, T1, P1, m1, ln, pm, fr + 10 * BLOCK);
+                    hy_point2<NS, NR, 1>(th, kc, hp.inv_R, u1, T1, P1, m1, ln, pm, fr + 10);
                     if (GRAD) {
 #pragma unroll
                         for (int i = 0; i < H; ++i) { FR(30 + i) = pm.xo[i]; FR(35 + i) = pm.Yo[i]; }
@@ -806,7 +830,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                             double w;
                             if (prm.loss_kind == 0) { loss_sum += fabs(rr); w = signbit(rr) ? 1.0 : -1.0; }
                             else { loss_sum = fma(rr, rr, loss_sum); w = -2.0 * rr; }
-                            w *= mask * iy;
+                            w *= mask * iy * (GRAD ? gscale : 1.0);
                             A_[i] += w;
                             B1[i] = fma(w, h * c1, B1[i]);
                             B2[i] = fma(w, h * c2, B2[i]);
@@ -825,16 +849,11 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                 fetch_rec(s - 2, qt, qdt, qu);                 // in flight across this step's atomics
                 HY_T(10);
                 if (GRAD) {
-                    // the accumulator offsets are made opaque per step: hoisted out of the loop, the 130 accumulator ADDRESSES are
-                    // formed once and live in scratch (one reload per atomic)
-                    unsigned gl = goff_lane, go_[H], zf_ = 0;
-                    asm volatile("" : "+v"(gl));
+                    unsigned zf_ = 0;
                     asm volatile("" : "+v"(zf_));          // the frame is re-read: the parked values are NOT kept in registers too
                     const double *const fq = fr + zf_;
-#define FQ(k_) fq[(k_) * BLOCK]
+#define FQ(k_) fq[(k_)]
                     const unsigned mcY = pm.cY, mcC = pm.cC;
-#pragma unroll
-                    for (int i = 0; i < H; ++i) { go_[i] = goff_own[i]; asm volatile("" : "+v"(go_[i])); }
                     const unsigned ncY = pn.cY, ncC = pn.cC;
                     CRNN_SCHED_FENCE();
                     double kb1[H], v[H], ub[H];
@@ -883,10 +902,10 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                             ub[i] += m_;
                             kb1[i] = fma(0.5 * h, m_, kb1[i]);
                         }
-                        // Psi_j -> frame slots 58-65 (the forward sweep's, idle now) and 35-36 (Y_mid, consumed above)
+                        // Psi_j -> frame slots 58-64 (the forward sweep's, idle now), 57 (iS of u_mid, consumed above) and 35-36 (Y_mid, likewise)
                         static_assert(NR == 10, "frame slots of Psi");
 #pragma unroll
-                        for (int j = 0; j < NR; ++j) FR(j < 8 ? 58 + j : 27 + j) = Psis[j];
+                        for (int j = 0; j < NR; ++j) FR(j < 7 ? 58 + j : (j == 7 ? 57 : 27 + j)) = Psis[j];
                     }
                     CRNN_SCHED_FENCE();
                     HY_T(12);
@@ -928,15 +947,10 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                         double PEo[H], P2vo[H], P2wo[H], SE = 0.0, psiv = 0.0, psiw = 0.0;
 #pragma unroll
                         for (int i = 0; i < H; ++i) { PEo[i] = 0.0; P2vo[i] = 0.0; P2wo[i] = 0.0; }
-                        // The reactions in a ROLLED loop (one copy of the body in the instruction stream) whose direction alternates
-                        // from one reverse iteration of the wavefront to the next: the accumulator lines touched last are touched
-                        // first again, so the part of a wavefront's 54 KB of accumulators that its XCD's L2 still holds is reused
-                        // (an XCD's wavefronts own 6.9 MB of accumulators, its L2 holds 4 MB; walked in one direction every line
-                        // would be evicted before its next visit)
-                        const int rev = __builtin_amdgcn_readfirstlane(itw & 1);
-#pragma unroll 1
-                        for (int jj = 0; jj < NR; ++jj) {
-                            const int j = rev ? NR - 1 - jj : jj;
+#pragma unroll
+                        for (int j = 0; j < NR; ++j) {
+                            CRNN_SCHED_FENCE();
+                            HY_FRESH_THETA(th);      // per reaction: merged, the 10 x 12 theta reads would be issued up front
                             const double *wo_ = th + L_::wo(0, j), *wi_ = th + L_::wi(0, j);
                             double Av = 0.0, Aw = 0.0, zv = 0.0, zw = 0.0;
 #pragma unroll
@@ -956,25 +970,26 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                             const double E = fma(Pw, cw, Pv * cv);
                             SE += E; psiv += Pv; psiw += Pw;
                             const double irm = m_irho * FQ(10 + j);   // the u_mid point's irho r_j
-                            if (!m1) HY2_ACC(L_::wb(j), gl, fma(Av, irm, E));
-                            const double gPv = gam * Pv, gPw = gam * Pw;
-                            const double Psi = fp[(j < 8 ? 58 + j : 27 + j) * BLOCK];
+                            // the step's gradient terms, per reaction (they meet the species factors in the MFMA stage):
+                            //   w_in[m][j] += E x_n[m] + gam Pw x'_w[m] + gam Pv x'_v[m] + Psi x_mid[m]      (m: species, -1/(RT), log T)
+                            //   w_b[j]     += E + Psi                 (Av irm = Psi: the same v . w_out contraction, the u_mid point's irho r_j)
+                            //   w_out[i][j] += vt[i] (ir cv + irm) + wt[i] (ir cw)
+                            // parked per reaction in frame slots whose contents have been consumed (the rates: read above; Y_n, k1,
+                            // k2 - k1, the scalars: in registers since the top of the block); c2: the lane's half in registers
+                            FR(j) = E; FR(10 + j) = gam * Pw; FR(40 + j) = gam * Pv;
+                            FR(j < 5 ? 25 + j : (j < 8 ? 32 + j : 44 + j)) = fma(ir, cv, irm);
+                            c2h[j % (NR / 2)] = (m1 == (j >= NR / 2)) ? ir * cw : c2h[j % (NR / 2)];
 #pragma unroll
                             for (int i = 0; i < H; ++i) {
-                                if (ln.ow[i]) {
-                                    HY2_ACC(L_::wi(0, j), go_[i], fma(E, xno[i], fma(gPw, xpwo[i], fma(gPv, xpvo[i], Psi * mxo[i]))));
-                                    HY2_ACC(L_::wo(0, j), go_[i], fma(vto[i], fma(ir, cv, irm), wto[i] * (ir * cw)));
-                                }
-                                const double wij = wi_[ln.ci[i]];   // (padding slot: multiplies zeros / feeds sums read under the mask)
+                                const double wij = wi_[ln.ci[i]];
                                 PEo[i] = fma(E, wij, PEo[i]);
                                 P2vo[i] = fma(Pv, wij, P2vo[i]);
                                 P2wo[i] = fma(Pw, wij, P2wo[i]);
                             }
-                            if (!m1) {
-                                HY2_ACC(L_::wi(NS, j), gl, fma(E, xnE, fma(gPw, xEd, Psi * mxE)));
-                                HY2_ACC(L_::wi(NS + 1, j), gl, fma(E, xnL, fma(gPw, xLd, Psi * mxL)));
-                            }
                         }
+#pragma unroll
+                        for (int i = 0; i < H; ++i) { sxw[i] = xpwo[i]; sxv[i] = xpvo[i]; svt[i] = vto[i]; swt[i] = wto[i]; }
+                        s_xEd = xEd; s_xLd = xLd;
                         double scE = 0.0, scv = 0.0, scw = 0.0;
 #pragma unroll
                         for (int i = 0; i < H; ++i) {
@@ -1002,6 +1017,85 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                 tnew = tn;
                 --s;
             }
+            if (GRAD) {
+                // ---- the wavefront adds the step's six terms to its tiles (uniform control flow; inactive pairs stage zeros)
+                HY_T(13);
+                // this lane's half of the reactions' factors: reactions 5 m .. 5 m + 4
+                unsigned zs_ = 0;
+                asm volatile("" : "+v"(zs_));
+                const double *const fs = fr + zs_;
+                // staging addresses are formed here, per iteration, from opaque copies: as loop invariants they are computed once
+                // per trajectory, do not fit the register file and come back from scratch (one memory latency each)
+                int g_ = giw, sr_ = st_row, sk_ = st_k;
+                asm volatile("" : "+v"(g_));
+                asm volatile("" : "+v"(sr_));
+                asm volatile("" : "+v"(sk_));
+                double *const stw = st + g_;
+                auto stage_term = [&](const double (&xs)[H], const double xE_, const double xL_, const double x1_, const double (&yh)[NR / 2],
+                                      const int nrows, hy_v4d &acc_a, hy_v4d &acc_b) {
+                    HY2_LDS_SYNC();          // the previous term's operand loads are done
+#pragma unroll
+                    for (int i = 0; i < H; ++i)
+                        if (ln.ow[i]) stw[ln.ci[i] * ST_P] = xs[i];
+                    if (!m1 && nrows > NS) {
+                        stw[NS * ST_P] = xE_;
+                        stw[(NS + 1) * ST_P] = xL_;
+                        stw[(NS + 2) * ST_P] = x1_;
+                    }
+#pragma unroll
+                    for (int k = 0; k < NR / 2; ++k) stw[ST_X + ((m1 ? NR / 2 : 0) + k) * ST_P] = act ? yh[k] : 0.0;
+                    HY2_LDS_SYNC();
+                    const bool arow = sr_ < nrows, bcol = sr_ < NR;
+                    const double *pa = st + (arow ? sr_ : 0) * ST_P + sk_;
+                    const double *pb = st + ST_X + (bcol ? sr_ : 0) * ST_P + sk_;
+#pragma unroll
+                    for (int n = 0; n < 8; n += 2) {      // two independent accumulation chains
+                        const double a0 = arow ? pa[4 * n] : 0.0, b0 = bcol ? pb[4 * n] : 0.0;
+                        const double a1 = arow ? pa[4 * n + 4] : 0.0, b1 = bcol ? pb[4 * n + 4] : 0.0;
+                        acc_a = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc_a, 0, 0, 0);
+                        acc_b = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc_b, 0, 0, 0);
+                    }
+                };
+                // (inactive pairs: their reactions' factors are staged as zeros; the species factors are made finite -- stale frame
+                //  contents are, the frame is cleared at kernel start -- so that 0 x them adds nothing)
+                double xs_[H], yh_[NR / 2];
+                const int hoff = m1 ? NR / 2 : 0;
+#pragma unroll
+                for (int i = 0; i < H; ++i) xs_[i] = fs[20 + i];
+#pragma unroll
+                for (int k = 0; k < NR / 2; ++k) yh_[k] = fs[hoff + k];
+                stage_term(xs_, fs[50], fs[51], 1.0, yh_, NS + 3, acc_wi, acc_wi2);          // E x_n
+#pragma unroll
+                for (int i = 0; i < H; ++i) xs_[i] = act ? sxw[i] : 0.0;
+#pragma unroll
+                for (int k = 0; k < NR / 2; ++k) yh_[k] = fs[10 + hoff + k];
+                stage_term(xs_, act ? s_xEd : 0.0, act ? s_xLd : 0.0, 0.0, yh_, NS + 3, acc_wi, acc_wi2);     // gam Pw x'_w
+#pragma unroll
+                for (int i = 0; i < H; ++i) xs_[i] = act ? sxv[i] : 0.0;
+#pragma unroll
+                for (int k = 0; k < NR / 2; ++k) yh_[k] = fs[40 + hoff + k];
+                stage_term(xs_, 0.0, 0.0, 0.0, yh_, NS + 3, acc_wi, acc_wi2);                                  // gam Pv x'_v
+#pragma unroll
+                for (int i = 0; i < H; ++i) xs_[i] = fs[30 + i];
+#pragma unroll
+                for (int k = 0; k < NR / 2; ++k) {       // Psi_j: slots 58-64, 57, 35, 36
+                    const int j1 = NR / 2 + k;
+                    yh_[k] = fs[m1 ? (j1 < 7 ? 58 + j1 : (j1 == 7 ? 57 : 27 + j1)) : 58 + k];
+                }
+                stage_term(xs_, fs[54], fs[55], 1.0, yh_, NS + 3, acc_wi, acc_wi2);           // Psi x_mid
+#pragma unroll
+                for (int i = 0; i < H; ++i) xs_[i] = act ? svt[i] : 0.0;
+#pragma unroll
+                for (int k = 0; k < NR / 2; ++k) {       // c1_j: slots 25-29 | 37, 38, 39, 52, 53
+                    const int j1 = NR / 2 + k;
+                    yh_[k] = fs[m1 ? (j1 < 8 ? 32 + j1 : 44 + j1) : 25 + k];
+                }
+                stage_term(xs_, 0.0, 0.0, 0.0, yh_, NS, acc_wo, acc_wo2);                                      // v~ (ir cv + irm)
+#pragma unroll
+                for (int i = 0; i < H; ++i) xs_[i] = act ? swt[i] : 0.0;
+                stage_term(xs_, 0.0, 0.0, 0.0, c2h, NS, acc_wo, acc_wo2);                                      // w~ (ir cw)
+                HY_T(5);
+            }
         }
 
         {
@@ -1016,6 +1110,26 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                     }
                 }
             }
+            if (GRAD) {
+                // the batch's share of the gradient: row (queue position / 32) of the partial-sum table (theta layout, the five extras
+                // zero) -- rows belong to BATCHES, not to wavefronts, so the table does not depend on which wavefront took which
+                // batch and the reduction over it is run-to-run identical.  Tile element (i, j) is in lane j + 16 (i % 4),
+                // component i / 4 (tools/ubench/mfma_f64_layout.hip).
+                double *const row = hp.gacc + (size_t)(wave_base >> 5) * (NTH + kExtra);
+                const int j = lane & 15;
+                if (j < NR) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 4 * r + (lane >> 4);
+                        if (i < NS + 2) row[L_::wi(i, j)] = acc_wi[r] + acc_wi2[r];
+                        else if (i == NS + 2) row[L_::wb(j)] = acc_wi[r] + acc_wi2[r];
+                        if (i < NS) row[L_::wo(i, j)] = acc_wo[r] + acc_wo2[r];
+                    }
+                }
+                if (lane < kExtra) row[NTH + lane] = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { acc_wi[r] = 0.0; acc_wo[r] = 0.0; acc_wi2[r] = 0.0; acc_wo2[r] = 0.0; }
+            }
             const double loss_tot = pair_sum(loss_sum);
             if (valid && !m1) {
                 const double denom = (double)prm.n_obs * (double)n_saved;
@@ -1027,12 +1141,43 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
             }
         }
     }
-#undef HY2_ACC
+#undef HY2_LDS_SYNC
 #undef FR
 #ifdef HY_PROF
     if (hp.prof && blockIdx.x == 0 && tid == 0)
         for (int k = 0; k < 16; ++k) hp.prof[k] = prof_acc[k];
 #endif
+}
+
+// The pair kernel's partial-sum table has one row per wavefront (its MFMA tiles); this adds one row per 256 trajectories that
+// carries only the five extras (loss sum, converged count, accepted, rejected, count) -- reduce_project_kernel sums all rows.
+__global__ __launch_bounds__(256) void hy2_extras_kernel(double *__restrict__ rows, int nth, const double *__restrict__ loss,
+                                                         const int32_t *__restrict__ retcode, const int32_t *__restrict__ n_accept,
+                                                         const int32_t *__restrict__ n_reject, int64_t first, int64_t count) {
+    __shared__ double ex[256];
+    const int tid = threadIdx.x;
+    const int64_t r = (int64_t)blockIdx.x * 256 + tid;
+    double *out = rows + (size_t)blockIdx.x * (nth + kExtra);
+    for (int m = tid; m < nth; m += 256) out[m] = 0.0;
+    double e[kExtra] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (r < count) {
+        const int64_t b = first + r;
+        e[0] = loss[b];
+        e[1] = (retcode[b] == 0) ? 1.0 : 0.0;
+        e[2] = (double)n_accept[b];
+        e[3] = (double)n_reject[b];
+        e[4] = 1.0;
+    }
+    for (int k = 0; k < kExtra; ++k) {
+        __syncthreads();
+        ex[tid] = e[k];
+        __syncthreads();
+        for (int s_ = 128; s_ > 0; s_ >>= 1) {
+            if (tid < s_) ex[tid] += ex[tid + s_];
+            __syncthreads();
+        }
+        if (tid == 0) out[nth + k] = ex[0];
+    }
 }
 
 }  // namespace crnn
