@@ -1,7 +1,8 @@
 // crnn_amd/csrc/hychem2_kernel.hpp -- gfx950 (MI355X): the HyChem pyrolysis CRNN (HyChem/crnn_pyrolysis_mass.jl) with TWO LANES
-// PER TRAJECTORY (round 3, second form).  Same mathematics, tape, accumulators and outputs as hychem_kernel.hpp (read that
-// header first: the RHS with its density coupling, the non-autonomous Rosenbrock23 step, the adjoint formulas); what changes
-// is the mapping.
+// PER TRAJECTORY (round 3).  Same mathematics, tape and outputs as hychem_kernel.hpp (read that header first: the RHS with its
+// density coupling, the non-autonomous Rosenbrock23 step, the adjoint formulas); what changes is the mapping of a trajectory
+// onto lanes, where the step's long-lived values wait (an LDS frame per lane instead of registers that spill), and how the
+// gradient is accumulated (on chip, by the matrix unit, instead of 210 HBM accumulators per trajectory).
 //
 // hychem_kernel gives a trajectory one lane and parks W's 81 factors in LDS: 1.1 KB per trajectory, 128 trajectories per CU
 // on two of its four SIMDs, ~25 000 instructions per step pair on the critical path of every wavefront.  Here an adjacent
@@ -16,8 +17,18 @@
 //     W^T x = b in dot form (each lane's partial dot product over ITS rows, summed over the pair);
 //   * contractions over the species: partial sums + pair_sum; the ten rates are replicated (five exponentials per lane,
 //     exchanged), as are the step-size controller and the scalars.
-// What remains replicated is the controller arithmetic and the rates; a step pair costs each lane ~40 % of the one-lane
-// kernel's instructions.  The pair's 64-lane wavefront takes 32 trajectories from the queue.
+// What remains replicated is the controller arithmetic and the rates.  The pair's 64-lane wavefront takes 32 trajectories
+// (a "batch") from the queue.
+//   * The lane's LDS frame (65 doubles, lane-major): with 512 registers a lane cannot hold a reverse step's live set, and what
+//     the allocator spills goes to scratch MEMORY -- a wavefront alone on its SIMD waits out every reload (700 bytes of scratch
+//     cost this kernel 40 % of its time).  So the values a step needs again much later are parked explicitly: rates, x, Y, k1,
+//     k2 - k1 and scalars of the two points, the FSAL point in the forward sweep, the reactions' gradient factors.
+//   * Gradient: per step and trajectory, w_in / w_b / w_out receive six outer products (species-or-feature factor) x (reaction
+//     factor)^T.  Summed over the batch's trajectories that is a [12 x 32] . [32 x 10] contraction over the LANE axis per term --
+//     v_mfma_f64_16x16x4_f64 (the one FP64 matrix shape; operands staged through LDS, see the MFMA stage).  The two 16 x 16
+//     tiles live in AGPRs for the batch and are written once as ONE ROW of the partial-sum table per batch: run-to-run
+//     identical (rows belong to batches, not to wavefronts), no atomics, no accumulator traffic to HBM.  Each trajectory's
+//     weight 1 / (n_obs n_saved) rides on its loss seeds (the adjoint is linear in them).
 #pragma once
 #include "hychem_kernel.hpp"
 #include "ros23_adj2_kernel.hpp"   // pair_sum, pair_and
@@ -722,10 +733,8 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
         bool obs[H];
 #pragma unroll
         for (int i = 0; i < H; ++i) { const int dr = ln.ow[i] ? (int)kc->drow[ln.ci[i]] : -1; obs[i] = dr >= 0; doff[i] = obs[i] ? dr : 0; }
-        // tape records are fetched TWO steps ahead: record s - 2 is requested just before step s issues its accumulator atomics and
-        // is consumed one iteration later, at the same point -- by then the atomics that were queued behind it have long drained
-        // (vmcnt counts loads and atomics in issue order: a load requested after them, or awaited right behind them, stalls the lane
-        // for a full memory latency per step)
+        // tape records are fetched TWO steps ahead: record s - 2 is requested in step s and consumed one iteration later, at the
+        // same point -- a load awaited in the step that requests it stalls the lane for a full memory latency per step
         double rt = 0.0, rdt = 0.0, ru[H], qt = 0.0, qdt = 0.0, qu[H];
         auto fetch_rec = [&](int idx, double &t_, double &dt_, double (&u_)[H]) {
             const double *rec = tape + (size_t)(idx > 0 ? idx : 0) * RECW;
@@ -846,7 +855,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                 rt = qt; rdt = qdt;
 #pragma unroll
                 for (int i = 0; i < H; ++i) ru[i] = qu[i];
-                fetch_rec(s - 2, qt, qdt, qu);                 // in flight across this step's atomics
+                fetch_rec(s - 2, qt, qdt, qu);                 // in flight until the next iteration
                 HY_T(10);
                 if (GRAD) {
                     unsigned zf_ = 0;
@@ -885,7 +894,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                             const double ir = m_irho * FQ(10 + j);
                             const double Psi = At * ir;
                             psi += Psi;
-                            Psis[j] = Psi;       // its w_in terms Psi_j x_mid are added together with the u_n point's (70 atomics less per step)
+                            Psis[j] = Psi;       // its w_in terms Psi_j x_mid join the u_n point's in the MFMA stage
 #pragma unroll
                             for (int i = 0; i < H; ++i) P2o[i] = fma(Psi, wi_[ln.ci[i]], P2o[i]);   // (padding slot: never read)
                         }
@@ -1149,7 +1158,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
 #endif
 }
 
-// The pair kernel's partial-sum table has one row per wavefront (its MFMA tiles); this adds one row per 256 trajectories that
+// The pair kernel's partial-sum table has one row per batch of 32 trajectories (its MFMA tiles); this adds one row per 256 trajectories that
 // carries only the five extras (loss sum, converged count, accepted, rejected, count) -- reduce_project_kernel sums all rows.
 __global__ __launch_bounds__(256) void hy2_extras_kernel(double *__restrict__ rows, int nth, const double *__restrict__ loss,
                                                          const int32_t *__restrict__ retcode, const int32_t *__restrict__ n_accept,
