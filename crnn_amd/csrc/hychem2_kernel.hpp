@@ -932,9 +932,6 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                             k1p[i] = FQ(40 + i); dkp[i] = FQ(45 + i); Yn[i] = FQ(25 + i); xno[i] = FQ(20 + i); mxo[i] = FQ(30 + i);
                         }
                         const double n_irho = FQ(52), n_iS = FQ(53), m_irho = FQ(56), xnE = FQ(50), xnL = FQ(51), mxE = FQ(54), mxL = FQ(55);
-                        unsigned zg_ = 0;
-                        asm volatile("" : "+v"(zg_));
-                        const double *const fp = fr + zg_;   // Psi_j, re-read
                         // direction data (this lane's species)
                         double Spv = 0.0, Spw = 0.0, xpvo[H], xpwo[H];
 #pragma unroll
