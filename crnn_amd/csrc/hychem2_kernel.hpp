@@ -43,6 +43,11 @@ __device__ __forceinline__ double pair_other(double a) {   // the other lane of 
     const int phi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
     return __hiloint2double(phi, plo);
 }
+// a wave-uniform double that came out of LDS (so in VGPRs) -> SGPRs: kernel-invariant scalars held in VGPRs for the whole kernel
+// are what the allocator spills first
+__device__ __forceinline__ double to_sgpr(double a) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(a)), __builtin_amdgcn_readfirstlane(__double2loint(a)));
+}
 __device__ __forceinline__ int pair_other_i(int a) { return __builtin_amdgcn_update_dpp(0, a, 0xB1, 0xF, 0xF, true); }
 
 // the value held by the pair's lane `owner_odd`, in both lanes: one DPP move per half, quad_perm [1,1,3,3] / [0,0,2,2]
@@ -66,6 +71,35 @@ template <int NS, int H>
 __device__ __forceinline__ void pair_own(const double (&full)[NS], const bool m1, double (&own)[H]) {
 #pragma unroll
     for (int i = 0; i < H; ++i) own[i] = m1 ? (2 * i + 1 < NS ? full[2 * i + 1 < NS ? 2 * i + 1 : 0] : 0.0) : full[2 * i];
+}
+
+// ros23_kernel.hpp's flog, bit for bit, for the step-size controller.  The five constants that START a multiply-add chain are
+// addends of v_fmac, i.e. live in VGPRs; the compiler materialises them once per kernel, cannot keep ten registers for a function
+// that runs once per step, and reloads them from SCRATCH at each call (five memory latencies per step).  Passed through an
+// SGPR-constrained asm they are formed where they are used (two s_mov each).
+__device__ __forceinline__ double hy_sconst(double c) {
+    asm volatile("" : "+s"(c));
+    return c;
+}
+__device__ __forceinline__ double flog_ctl(double x) {
+    double m = __builtin_amdgcn_frexp_mant(x);      // [0.5, 1)
+    int k = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;                             // [sqrt(1/2), sqrt 2)
+    k = lo ? k - 1 : k;
+    const double f = m - 1.0;
+    const double r = frcp1(2.0 + f);
+    double s = f * r;
+    s = fma(fma(-(2.0 + f), s, f), r, s);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, hy_sconst(2.222219843214978396e-01)), hy_sconst(3.999999999940941908e-01));
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, hy_sconst(1.818357216161805012e-01)),
+                                     hy_sconst(2.857142874366239149e-01)), hy_sconst(6.666666666666735130e-01));
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    return fma(dk, 6.93147180369123816490e-01, -((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f));
 }
 
 template <int NS, int NR>
@@ -408,6 +442,8 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
     constexpr int H = (NS + 1) / 2;
     constexpr int GPB = BLOCK / 2;
     constexpr int RECW = NS + 2;
+    // (separate LDS objects on purpose: carved out of ONE array -- theta first, so that its address folds into ds_read's immediate
+    //  offset -- the kernel is 8 % slower: every frame store may then alias every theta load)
     __shared__ double kc_lds[kNConst];
     __shared__ double ts_lds[kMaxSave];
     __shared__ double th_lds[NTH];
@@ -463,10 +499,10 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
     const int st_row = lane & 15, st_k = lane >> 4;       // MFMA operand (row or column, k) of this lane
     const double d_ = 0.29289321881345248, c32 = 7.4142135623730950, inv12d = 2.4142135623730950;
     const int nsave = prm.n_save, Dfull = hp.n_save_total;
-    const double tend = ts_lds[nsave - 1], ts0 = ts_lds[0], t0 = kc->t0;
-    const double dtmax = tend - t0;
-    const double lqinit = flog(kc->qoldinit);
-    const double inv_qmax = 1.0 / kc->qmax, inv_qmin = 1.0 / kc->qmin;   // (the same quotients the one-lane kernel forms each step)
+    const double tend = to_sgpr(ts_lds[nsave - 1]), ts0 = to_sgpr(ts_lds[0]), t0 = to_sgpr(kc->t0);
+    const double dtmax = to_sgpr(tend - t0);
+    const double lqinit = to_sgpr(flog(kc->qoldinit));
+    const double inv_qmax = to_sgpr(1.0 / kc->qmax), inv_qmin = to_sgpr(1.0 / kc->qmin);   // (the quotients the one-lane kernel forms each step)
     const bool start_saved = (ts0 == t0);
     double *const tape = hp.tape + (size_t)((size_t)blockIdx.x * GPB + gib) * hp.tape_cap * RECW;
 #ifdef HY_PROF
@@ -512,7 +548,6 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
         double t = t0, dt = 0.0, lqold = lqinit;
         int iter = 0, jsave = 0, nacc = 0, nrej = 0;
         int rc = valid ? -1 : 0;
-        int rsl = 0;             // frame slot of the FSAL point's rates (0 or 10; the new point's go to the other one)
 #pragma unroll
         for (int i = 0; i < H; ++i) u[i] = ln.ow[i] ? prm.u0[(size_t)ln.ci[i] * prm.B + b] : 0.0;
         {
@@ -592,7 +627,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                         p0.irho = fq[63]; p0.iS = fq[64];
                         p0.cY = f0cY; p0.cC = f0cC;
                     }
-                    hy_jac_ft2<NS, NR, 1>(th, kc, p0, fr + rsl, gam, Pd * frcp(P) - Td * frcp(T), -hp.inv_R * Td * frcp(T * T), Td * frcp(T), m1, ln, A, ft);
+                    hy_jac_ft2<NS, NR, 1>(th, kc, p0, fr, gam, Pd * frcp(P) - Td * frcp(T), -hp.inv_R * Td * frcp(T * T), Td * frcp(T), m1, ln, A, ft);
                     CRNN_SCHED_FENCE();
                     HY_T(1);
                     const bool okf = lu2_factor<NS>(A, m1, dinv, piv, anyp);
@@ -630,7 +665,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                     {
                         double T2, P2, a_, b_;
                         tab(tnew, T2, P2, a_, b_);
-                        hy_point2<NS, NR, 1>(th, kc, hp.inv_R, unew, T2, P2, m1, ln, p2, fr + (10 - rsl));
+                        hy_point2<NS, NR, 1>(th, kc, hp.inv_R, unew, T2, P2, m1, ln, p2, fr + 10);
                     }
                     CRNN_SCHED_FENCE();
                     HY_T(4);
@@ -659,7 +694,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                     if (!finite) rc = 3;
                     else {
                         const bool ee_zero = (es == 0.0);
-                        const double lEE = 0.5 * flog(ee_zero ? 1.0 : es);
+                        const double lEE = 0.5 * flog_ctl(ee_zero ? 1.0 : es);
                         const double lq11 = kc->beta1 * lEE;
                         double q = ee_zero ? inv_qmax
                                            : fmax(inv_qmax, fmin(inv_qmin, exp(lq11 - kc->beta2 * lqold) / kc->gamma));
@@ -699,7 +734,13 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
 #pragma unroll
                                 for (int i = 0; i < H; ++i) { f0[i] = p2.fo[i]; FR(58 + i) = p2.Yo[i]; }
                                 FR(63) = p2.irho; FR(64) = p2.iS; f0cY = p2.cY; f0cC = p2.cC;
-                                rsl = 10 - rsl;
+                                {   // the new point's rates (slots 10-19) become the FSAL point's (0-9)
+                                    double rr_[NR];
+#pragma unroll
+                                    for (int j = 0; j < NR; ++j) rr_[j] = FR(10 + j);
+#pragma unroll
+                                    for (int j = 0; j < NR; ++j) FR(j) = rr_[j];
+                                }
                                 t = tnew;
                                 if (q >= kc->qsteady_min && q <= kc->qsteady_max) q = 1.0;
                                 lqold = ee_zero ? lqinit : fmax(lEE, lqinit);
@@ -925,13 +966,14 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                     HY_FRESH_THETA(th); HY_FRESH_KC(kc);
                     // -------- point u_n: adjoint of w.f + gam ( v.Df[(dk,0)] + w.Df[(k1,1)] )
                     {
-                        double wto[H], k1p[H], dkp[H], Yn[H], xno[H], mxo[H];
+                        double wto[H], k1p[H], dkp[H], Yn[H];
 #pragma unroll
                         for (int i = 0; i < H; ++i) {
                             wto[i] = kb1[i] * kc->gsc[ln.ci[i]];
-                            k1p[i] = FQ(40 + i); dkp[i] = FQ(45 + i); Yn[i] = FQ(25 + i); xno[i] = FQ(20 + i); mxo[i] = FQ(30 + i);
+                            k1p[i] = FQ(40 + i); dkp[i] = FQ(45 + i); Yn[i] = FQ(25 + i);
                         }
-                        const double n_irho = FQ(52), n_iS = FQ(53), m_irho = FQ(56), xnE = FQ(50), xnL = FQ(51), mxE = FQ(54), mxL = FQ(55);
+                        // (x of the two points and their -1/(RT), log T stay in the frame: slots 20-24, 30-34, 50, 51, 54, 55 feed the MFMA stage)
+                        const double n_irho = FQ(52), n_iS = FQ(53), m_irho = FQ(56);
                         // direction data (this lane's species)
                         double Spv = 0.0, Spw = 0.0, xpvo[H], xpwo[H];
 #pragma unroll
