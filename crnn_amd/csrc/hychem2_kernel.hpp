@@ -232,7 +232,7 @@ __device__ __forceinline__ void hy_jac_ft2(const double *th, const KConst *kc, c
     for (int i = 0; i < H; ++i) {
         // theta re-read row by row (90 broadcast ds_reads): merged across the rows it would pin 180 VGPRs
         unsigned z_ = 0;
-        asm volatile("" : "+v"(z_));
+        asm volatile("" : "+s"(z_));
         const double *const thr = th + z_;
         const double Gi = ln.ow[i] ? kc->gsc[ln.ci[i]] * pt.irho : 0.0;
         double a[NR], tB = 0.0, tz = 0.0;
@@ -474,6 +474,21 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
         __builtin_amdgcn_wave_barrier();                                 \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");           \
     } while (0)
+    // hychem_kernel.hpp's HY_FRESH_* with the opaque zero in an SGPR: the pointer stays uniform, so when registers run out it is
+    // re-formed by one v_mov from the SGPR instead of being reloaded from scratch (as a VGPR value it was the most-reloaded
+    // spill slot of the kernel: ~25 reloads per step pair)
+#define HY2_FRESH_THETA(ptr)                    \
+    do {                                        \
+        unsigned z_ = 0;                        \
+        asm volatile("" : "+s"(z_));            \
+        (ptr) = th_lds + z_;                    \
+    } while (0)
+#define HY2_FRESH_KC(ptr)                                            \
+    do {                                                             \
+        unsigned z_ = 0;                                             \
+        asm volatile("" : "+s"(z_));                                 \
+        (ptr) = reinterpret_cast<const KConst *>(kc_lds + z_);       \
+    } while (0)
     const int lane = tid & 63;
     const bool m1 = (lane & 1) != 0;
     const int gib = tid >> 1, giw = lane >> 1;
@@ -609,7 +624,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                 if (t + dt * (1.0 + 1e-13) >= tend) { dt = tend - t; last = true; }
                 if (rc < 0 && (!(dt > kc->dtmin) || t + dt == t)) rc = 2;
                 if (rc < 0) {
-                    HY_FRESH_THETA(th); HY_FRESH_KC(kc);
+                    HY2_FRESH_THETA(th); HY2_FRESH_KC(kc);
                     const double gam = d_ * dt;
                     const double tnew = last ? tend : t + dt;
                     double T, P, Td, Pd;
@@ -639,7 +654,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                     lu2_solve<NS>(A, dinv, piv, wp, m1, k1);
                     CRNN_SCHED_FENCE();
                     HY_T(3);
-                    HY_FRESH_THETA(th); HY_FRESH_KC(kc);
+                    HY2_FRESH_THETA(th); HY2_FRESH_KC(kc);
                     {
                         double u1[H];
 #pragma unroll
@@ -661,7 +676,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                     for (int i = 0; i < H; ++i) unew[i] = fma(dt, k1[i] + dk[i], u[i]);
                     CRNN_SCHED_FENCE();
                     HyPoint2<NS, NR> p2;
-                    HY_FRESH_THETA(th); HY_FRESH_KC(kc);
+                    HY2_FRESH_THETA(th); HY2_FRESH_KC(kc);
                     {
                         double T2, P2, a_, b_;
                         tab(tnew, T2, P2, a_, b_);
@@ -797,7 +812,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
 #pragma unroll
                 for (int i = 0; i < H; ++i) un[i] = ru[i];
                 // ---- re-form the step
-                HY_FRESH_THETA(th); HY_FRESH_KC(kc);
+                HY2_FRESH_THETA(th); HY2_FRESH_KC(kc);
                 const double gam = d_ * h;
                 double T, P, Td, Pd;
                 tab(tn, T, P, Td, Pd);
@@ -812,7 +827,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                     FR(50) = pn.xE; FR(51) = pn.xL;
                 }
                 opaque(pn.Yo); opaque(pn.fo); opaque(pn.irho); opaque(pn.iS);
-                HY_FRESH_THETA(th); HY_FRESH_KC(kc);
+                HY2_FRESH_THETA(th); HY2_FRESH_KC(kc);
                 double A[H][NS], dinv[NS], ft[H];
                 unsigned long long piv;
                 bool anyp;
@@ -833,7 +848,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                 HY_T(8);
                 lu2_solve<NS>(A, dinv, piv, wp, m1, k1);
                 HY_T(9);
-                HY_FRESH_THETA(th); HY_FRESH_KC(kc);
+                HY2_FRESH_THETA(th); HY2_FRESH_KC(kc);
                 {
                     double u1[H], T1, P1, a_, b_;
 #pragma unroll
@@ -916,7 +931,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                     for (int i = 0; i < H; ++i) { kb1[i] -= v[i]; vto[i] = v[i] * kc->gsc[ln.ci[i]]; }
                     opaque(vto); opaque(kb1); opaque(ub);
                     CRNN_SCHED_FENCE();
-                    HY_FRESH_THETA(th); HY_FRESH_KC(kc);
+                    HY2_FRESH_THETA(th); HY2_FRESH_KC(kc);
                     // -------- point u_mid: adjoint of v.f
                     {
                         double P2o[H], Psis[NR], psi = 0.0;
@@ -926,7 +941,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
 #pragma unroll
                         for (int j = 0; j < NR; ++j) {
                             CRNN_SCHED_FENCE();
-                            HY_FRESH_THETA(th);      // per reaction: merged, the 10 x 12 theta reads would be issued up front
+                            HY2_FRESH_THETA(th);      // per reaction: merged, the 10 x 12 theta reads would be issued up front
                             const double *wo_ = th + L_::wo(0, j), *wi_ = th + L_::wi(0, j);
                             double At = 0.0;
 #pragma unroll
@@ -963,7 +978,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                     HY_T(11);
                     opaque(kb1); opaque(ub); opaque(vto);
                     CRNN_SCHED_FENCE();
-                    HY_FRESH_THETA(th); HY_FRESH_KC(kc);
+                    HY2_FRESH_THETA(th); HY2_FRESH_KC(kc);
                     // -------- point u_n: adjoint of w.f + gam ( v.Df[(dk,0)] + w.Df[(k1,1)] )
                     {
                         double wto[H], k1p[H], dkp[H], Yn[H];
@@ -998,7 +1013,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
 #pragma unroll
                         for (int j = 0; j < NR; ++j) {
                             CRNN_SCHED_FENCE();
-                            HY_FRESH_THETA(th);      // per reaction: merged, the 10 x 12 theta reads would be issued up front
+                            HY2_FRESH_THETA(th);      // per reaction: merged, the 10 x 12 theta reads would be issued up front
                             const double *wo_ = th + L_::wo(0, j), *wi_ = th + L_::wi(0, j);
                             double Av = 0.0, Aw = 0.0, zv = 0.0, zw = 0.0;
 #pragma unroll
@@ -1190,6 +1205,8 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
         }
     }
 #undef HY2_LDS_SYNC
+#undef HY2_FRESH_THETA
+#undef HY2_FRESH_KC
 #undef FR
 #ifdef HY_PROF
     if (hp.prof && blockIdx.x == 0 && tid == 0)
