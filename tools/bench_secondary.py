@@ -119,7 +119,8 @@ def hychem(B=32768, reps=4, device=0):
     node.close()
     return _entry("hychem", B, kms, st, {"workload": "HyChem pyrolysis CRNN, 32 768 ICs (one GPU's share of 262 144), T(t)/P(t) tables, "
                                                      "Rosenbrock23 atol 1e-8 rtol 1e-3, adjoint gradient (P = 211)",
-                                         "kernel": "hychem2_kernel<9,10,GRAD,256> (a lane pair per trajectory)"}, wall,
+                                         "kernel": "hychem2_kernel<9,10,GRAD,256> (a lane pair per trajectory, W's rows in registers, LDS frame, "
+                                                   "gradient summed over each batch of 32 by v_mfma_f64_16x16x4: no accumulator in HBM)"}, wall,
                   traffic_key="hychem_B32768_lane_pair" if B == 32768 else None)
 
 
