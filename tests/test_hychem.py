@@ -368,7 +368,8 @@ def test_gpu_hychem_full_share_properties():
 
 
 @pytest.mark.gpu
-def test_gpu_hychem_config4_as_eight_logical_shards():
+@pytest.mark.parametrize("lanes", [0, 1])
+def test_gpu_hychem_config4_as_eight_logical_shards(lanes):
     """BASELINE config 4 at full size on one GPU: 262 144 experiments, solved once as a whole and once as the eight
     contiguous 32 768-experiment shards an 8-GPU node would own (crnn_amd.dist.shard_range).  The all-reduce sums
     [grad_sum | loss_sum | counts]; done here on the host, it must reproduce the single-launch mean loss and gradient to
@@ -389,9 +390,9 @@ def test_gpu_hychem_config4_as_eight_logical_shards():
     node.set_tables(Tt, Pt)
     p = hy.true_p() + 0.02 * np.random.Generator(np.random.PCG64(5)).standard_normal(hy.NP)
     p[-1] = 0.1
-    node.set_lanes_per_traj(1)     # one kernel for the whole ensemble and for its shards: the sums below agree to 1e-12 only
-    L, G = node.loss_and_grad(p)   # then (AUTO takes the lane-pair kernel for the shards and the one-lane kernel beyond 32 768)
-    assert node.last_stats["n_ok"] == B
+    node.set_lanes_per_traj(lanes)     # AUTO (the lane-pair kernel, batch sums by MFMA) and the one-lane kernel (HBM accumulators)
+    L, G = node.loss_and_grad(p)
+    assert node.last_stats["n_ok"] == B and node.last_lanes_per_traj() == (2 if lanes == 0 else 1)
     lsum, gsum, n = 0.0, np.zeros(hy.NP), 0
     for r in range(W):
         first, count = shard_range(B, r, W)
@@ -401,6 +402,7 @@ def test_gpu_hychem_config4_as_eight_logical_shards():
         assert st["n_traj"] == count and st["n_ok"] == count
         lsum += l * count; gsum += g * count; n += count
     assert n == B
+    print(f"lanes {lanes}: loss dev {abs(lsum / B - L) / L:.1e} grad dev {np.max(np.abs(gsum / B - G)) / np.max(np.abs(G)):.1e}")
     assert abs(lsum / B - L) < 1e-12 * L
     assert np.max(np.abs(gsum / B - G)) < 1e-11 * np.max(np.abs(G))
     node.close()
