@@ -215,8 +215,10 @@ int32_t crnn_ctx_set_queue_order(crnn_ctx *ctx, int32_t order);
  * pairs fit the resident lanes (32 768 trajectories on 256 CUs), else 1.  Beyond that size two lanes still pay where step
  * counts spread widely (case2 at trained parameters, 65 536 trajectories: -4 %) and cost where they do not (-13 % at the
  * reference's initialiser): the host's call.  HyChem contexts: 1 = hychem_kernel, 2 (and AUTO, at every ensemble size) =
- * hychem2_kernel, a lane pair per trajectory with the same 1.1 KB of LDS per trajectory.  Same derivative either way; results agree to rounding (the species
- * sums are formed in a different order), per-trajectory outputs do not depend on the launch geometry. */
+ * hychem2_kernel: a lane pair per trajectory, every vector and W's rows distributed over the pair, and the batch gradient
+ * summed on chip (FP64 MFMAs over each batch of 32 trajectories) instead of in 210 HBM accumulators per trajectory.  Same
+ * derivative either way; results agree to rounding (the species sums and the batch sums are formed in a different order),
+ * per-trajectory outputs do not depend on the launch geometry. */
 int32_t crnn_ctx_set_lanes_per_traj(crnn_ctx *ctx, int32_t lanes);
 /* Lanes per trajectory the most recent adjoint gradient launch used (1 or 2; 0 if no adjoint launch has run, -1 for a null ctx). */
 int32_t crnn_last_lanes_per_traj(const crnn_ctx *ctx);
