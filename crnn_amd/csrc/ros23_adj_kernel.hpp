@@ -489,7 +489,11 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
             for (int i = 0; i < NS; ++i) d[i] = (CRNN_ADJ_DBG & 2) ? 0.5 : row[doff[i]];
         };
         double ts_cur = (jsave - 1 >= jlo) ? ts_lds[jsave - 1] : -INFINITY;   // save point jsave-1 (none: -inf, never inside a step)
-        double ts_nxt = (jsave - 2 >= jlo) ? ts_lds[jsave - 2] : -INFINITY;
+        // (the one after it too where registers allow: with ns >= 5 the allocator spills that second value to scratch and reloads
+        //  it three times per step -- a memory latency each for a wavefront alone on its SIMD: case2 at 65 536 0.512 -> 0.493 ms
+        //  without it; robertson's shape keeps it, +1 %)
+        constexpr bool TS_PF = NS < 5;
+        double ts_nxt = (TS_PF && jsave - 2 >= jlo) ? ts_lds[jsave - 2] : -INFINITY;
         double rt = 0.0, rdt = 0.0, ru[NS];   // tape record s, prefetched
 #if CRNN_ADJ_TAPE_K
         double rk1[NS], rdk[NS];
@@ -599,16 +603,20 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                 double A_[NS], B1[NS], B2[NS];
 #pragma unroll
                 for (int i = 0; i < NS; ++i) { A_[i] = 0.0; B1[i] = 0.0; B2[i] = 0.0; }
-                // the times of the next two save points (backwards) sit in registers: the test "is it inside this step" and the
-                // seed itself do not wait for LDS, the read for the one after next has a whole seed to complete (case2 -2.5 %;
-                // the same in the forward sweep's save-point loop gains nothing: two more registers live across that loop)
+                // the time of the next save point (backwards) sits in a register -- and, TS_PF, the one after it: the test "is it
+                // inside this step" and the seed itself do not wait for LDS (the same in the forward sweep's save-point loop gains
+                // nothing: two more registers live across that loop)
                 const double inv_h = frcp(h);      // one reciprocal per step instead of an IEEE division per save point (1e-16)
                 auto in_step = [&]() -> bool { return ts_cur > tn; };
                 auto seed_point = [&](const double (&dobs)[NS]) {
                     const double ts = ts_cur;
                     CRNN_CHK(jsave - 1 >= jlo && jsave - 1 < nsave, 8);
-                    ts_cur = ts_nxt;
-                    ts_nxt = (jsave - 3 >= jlo) ? ts_lds[jsave - 3] : -INFINITY;
+                    if (TS_PF) {
+                        ts_cur = ts_nxt;
+                        ts_nxt = (jsave - 3 >= jlo) ? ts_lds[jsave - 3] : -INFINITY;
+                    } else {
+                        ts_cur = (jsave - 2 >= jlo) ? ts_lds[jsave - 2] : -INFINITY;
+                    }
                     const bool at_end = (ts == tnew);
                     const double Th = at_end ? 1.0 : (ts - tn) * inv_h;
                     const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
