@@ -91,9 +91,11 @@ struct AdjEntry {
     int solver, ns, nr, has_t, use_scale;
     AdjKernelFn fn;
     int max_gen = 1;   // two-lane entries: AUTO uses the kernel while count <= max_gen * (resident lane pairs)
+    AdjKernelFn fn_primal = nullptr;   // the forward sweep alone (ros23_adj_kernel<..., PRIMAL = true>): crnn_solve with no directions
 };
 #define KADJ(NS, NR, HT, SC) \
-    { CRNN_SOLVER_ROSENBROCK23, NS, NR, HT, SC, (AdjKernelFn)crnn::ros23_adj_kernel<NS, NR, (HT) != 0, (SC) != 0, kBlock> }
+    { CRNN_SOLVER_ROSENBROCK23, NS, NR, HT, SC, (AdjKernelFn)crnn::ros23_adj_kernel<NS, NR, (HT) != 0, (SC) != 0, kBlock>, 1, \
+      (AdjKernelFn)crnn::ros23_adj_kernel<NS, NR, (HT) != 0, (SC) != 0, kBlock, true> }
 #define KAUTO(SOLVER, NS, NR, HT, SC, COMPOSITE) \
     { SOLVER, NS, NR, HT, SC, (AdjKernelFn)crnn::auto_adj_kernel<NS, NR, (HT) != 0, (SC) != 0, kBlock, COMPOSITE> }
 // Rosenbrock23 discrete adjoint with TWO lanes per trajectory (ros23_adj2_kernel.hpp): shapes with nr < ns, no rate scaling.
@@ -487,7 +489,9 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
     // the chip then uses its idle lanes to shorten every step instead of leaving them empty (lanes_per_traj = AUTO), or
     // wherever the caller asks for it (crnn_ctx_set_lanes_per_traj).
     int G = 1;
-    if (const AdjEntry *k2 = (k->solver == CRNN_SOLVER_ROSENBROCK23 && c->lanes_per_traj != 1) ? find_adjoint2(c) : nullptr) {
+    const bool primal = (P == 0 && k->fn_primal != nullptr);   // forward sweep only: no tape, no reverse sweep, one lane per trajectory
+                                                               // (the Tsit5 / AutoTsit5 tape kernels run their primal calls themselves, P = 0)
+    if (const AdjEntry *k2 = (!primal && k->solver == CRNN_SOLVER_ROSENBROCK23 && c->lanes_per_traj != 1) ? find_adjoint2(c) : nullptr) {
         if (c->adj2_occ < 1) {
             HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->adj2_occ, (const void *)k2->fn, kBlock, 0));
             if (c->adj2_occ < 1) c->adj2_occ = 1;
@@ -514,7 +518,7 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
         cap = std::max<int64_t>(cap, 64);
     }
     cap = std::min<int64_t>(cap, c->cfg.maxiters);
-    if (c->tape_doubles < lanes * (size_t)cap * recw) {
+    if (!primal && c->tape_doubles < lanes * (size_t)cap * recw) {
         if (ensure(c, &c->d_tape, &c->tape_doubles, lanes * (size_t)cap * recw)) return -1;
     }
     const int nbatch = (int)((count + tpw - 1) / tpw);   // one partial row per batch of a wavefront (written by the solve kernel)
@@ -558,7 +562,7 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
     c->ev1 = c->ring1[c->n_launch % Ctx::kRing];
     ++c->n_launch;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    hipLaunchKernelGGL(k->fn, dim3(nblk), dim3(kBlock), 0, c->stream, prm, d_theta, adj);
+    hipLaunchKernelGGL(primal ? k->fn_primal : k->fn, dim3(nblk), dim3(kBlock), 0, c->stream, prm, d_theta, adj);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     // the next launch over this range will want the queue ordered by this launch's step counts (queue_by_steps): sort
@@ -851,6 +855,14 @@ int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int 
     if (P > 0 && c->cfg.grad_mode == CRNN_GRAD_AUTO && !c->force_forward && !two_lane_adjoint) {
         for (const auto &ke : kKernels)
             if (shape_match(c, ke) && ke.C == 1 && ke.L >= P && count <= (int64_t)c->num_cu * 4 * (64 / ke.L)) k_small = &ke;
+    }
+    if (P == 0 && c->cfg.errnorm_sens == 0) {   // primal solve: the adjoint kernel's forward sweep (wave-synchronous batches, sorted queue)
+        const AdjEntry *ka = find_adjoint(c);
+        if (ka && ka->fn_primal) {
+            c->last_deferred = false;
+            const int32_t r = launch_adjoint(c, ka, d_theta, d_dtheta, 0, first, count, n_save_active, want_pred, false);
+            return r < 0 ? r : 0;
+        }
     }
     if (P > 0 && c->cfg.grad_mode != CRNN_GRAD_FORWARD && !c->force_forward && !k_small) {
         const AdjEntry *ka = find_adjoint(c);

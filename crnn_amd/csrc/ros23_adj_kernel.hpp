@@ -171,7 +171,12 @@ __device__ __forceinline__ void solve_T(const Woodbury<NS, NR, HAS_T, USE_SCALE>
     }
 }
 
-template <int NS, int NR, bool HAS_T, bool USE_SCALE, int BLOCK>
+// PRIMAL = true: the forward sweep alone -- solution at the save points (prm.pred), loss accumulated there, no tape, no reverse
+// sweep.  This is the primal path of crnn_solve (predict_neuralode, the epoch-end loss loop, case2.jl:124-128 / 199-203): the
+// same wave-synchronous batches and longest-first queue as the gradient launch, where ros23_kernel's one-lane-group-per-trajectory
+// scheme (built for tangent columns) lets the 64 lanes of a wavefront drift apart -- 0.55 ms per 65 536 against 0.50 for the
+// whole gradient.
+template <int NS, int NR, bool HAS_T, bool USE_SCALE, int BLOCK, bool PRIMAL = false>
 __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm, const double *__restrict__ theta,
                                                           const AdjParams adj) {
     using L_ = Lay<NS, NR, HAS_T>;
@@ -309,6 +314,19 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
             jsave = 1;
         }
 
+        // PRIMAL: the loss is accumulated at the save points of the forward sweep (ascending, as ros23_kernel does); the observed row
+        // of the next save point is requested one save point ahead
+        double pf_loss = 0.0, pf_row[NS];
+        int pf_off[NS];
+        bool pf_obs[NS];
+        const double *const pf_rows = prm.data + (size_t)b * prm.row_stride;
+        if (PRIMAL) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) { const int dr = (int)kc->drow[i]; pf_obs[i] = dr >= 0; pf_off[i] = dr >= 0 ? dr : 0; }
+            const double *row = pf_rows + (size_t)(jsave < nsave ? jsave : 0) * prm.n_obs;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) pf_row[i] = row[pf_off[i]];
+        }
         while (__builtin_amdgcn_ballot_w64(rc < 0) != 0) {
             if (rc < 0) {
                 ++iter;
@@ -384,39 +402,53 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                                            : fmax(1.0 / kc->qmax, fmin(1.0 / kc->qmin, exp(lq11 - kc->beta2 * lqold) / kc->gamma));
                         ADJ_T(7);   // controller (log, exp, divisions)
                         if (es <= 1.0) {
-                            if (nacc >= adj.tape_cap) {
+                            if (!PRIMAL && nacc >= adj.tape_cap) {
                                 rc = 5;  // out of tape: the host re-runs the call with forward tangents
                                 atomicAdd(adj.overflow, 1u);
                             } else {
-                                CRNN_CHK(nacc >= 0 && nacc < adj.tape_cap, 5);
-                                double *rec = tape + (size_t)((CRNN_ADJ_DBG & 4) ? 0 : nacc) * RECW;
-                                rec[0] = t;
-                                rec[1] = dt;
+                                if (!PRIMAL) {
+                                    CRNN_CHK(nacc >= 0 && nacc < adj.tape_cap, 5);
+                                    double *rec = tape + (size_t)((CRNN_ADJ_DBG & 4) ? 0 : nacc) * RECW;
+                                    rec[0] = t;
+                                    rec[1] = dt;
 #pragma unroll
-                                for (int i = 0; i < NS; ++i) rec[2 + i] = u[i];
+                                    for (int i = 0; i < NS; ++i) rec[2 + i] = u[i];
 #if CRNN_ADJ_TAPE_K
 #pragma unroll
-                                for (int i = 0; i < NS; ++i) { rec[2 + NS + i] = k1[i]; rec[2 + 2 * NS + i] = dk[i]; }
+                                    for (int i = 0; i < NS; ++i) { rec[2 + NS + i] = k1[i]; rec[2 + 2 * NS + i] = dk[i]; }
 #endif
+                                }
                                 ++nacc;
                                 const double tnew = last ? tend : t + dt;
                                 while (jsave < nsave) {
                                     CRNN_CHK(jsave >= 0 && jsave < nsave, 6);
                                     const double ts = ts_lds[jsave];
                                     if (!(ts <= tnew)) break;
-                                    if (prm.pred) {
+                                    if (prm.pred || PRIMAL) {
                                         const bool at_end = (ts == tnew);
                                         const double Th = at_end ? 1.0 : (ts - t) / dt;
                                         const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
                                         const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d_) * inv12d;
+                                        double drow_[NS];
+                                        if (PRIMAL) {   // this save point's observations; the next one's are requested below
+#pragma unroll
+                                            for (int i = 0; i < NS; ++i) drow_[i] = pf_row[i];
+                                            const double *nrow = pf_rows + (size_t)(jsave + 1 < nsave ? jsave + 1 : jsave) * prm.n_obs;
+#pragma unroll
+                                            for (int i = 0; i < NS; ++i) pf_row[i] = nrow[pf_off[i]];
+                                        }
 #pragma unroll
                                         for (int i = 0; i < NS; ++i) {
                                             double k2i = k1[i] + dk[i];
                                             double v = at_end ? unew[i] : fma(dt, fma(c1, k1[i], c2 * k2i), u[i]);
                                             if (prm.clamp_pred) v = clampv(v, -kc->ub, kc->ub);
-                                            prm.pred[((size_t)jsave * N + i) * prm.B + b] = v;
+                                            if (prm.pred) prm.pred[((size_t)jsave * N + i) * prm.B + b] = v;
+                                            if (PRIMAL && pf_obs[i]) {
+                                                const double rr = (drow_[i] - v) * kc->inv_yscale[i];
+                                                pf_loss = (prm.loss_kind == 0) ? pf_loss + fabs(rr) : fma(rr, rr, pf_loss);
+                                            }
                                         }
-                                        if (HAS_T) {
+                                        if (HAS_T && prm.pred) {
                                             double v = Tconst;
                                             if (prm.clamp_pred) v = clampv(v, -kc->ub, kc->ub);
                                             prm.pred[((size_t)jsave * N + NS) * prm.B + b] = v;
@@ -472,9 +504,9 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
         double wbb[NR];
 #pragma unroll
         for (int j = 0; j < NR; ++j) wbb[j] = 0.0;
-        double loss_sum = 0.0;
+        double loss_sum = PRIMAL ? pf_loss : 0.0;
         double tnew = t;             // end time of the step being reversed
-        int s = (valid && !(CRNN_ADJ_DBG & 1)) ? nacc - 1 : -1;
+        int s = (!PRIMAL && valid && !(CRNN_ADJ_DBG & 1)) ? nacc - 1 : -1;
 
         // Observed rows are fetched at the top of a reverse step, a whole step re-formation (~2 us of arithmetic) ahead
         // of their use: rows jsave-1, jsave-2, jsave-3 cover the save points one step usually spans.
