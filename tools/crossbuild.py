@@ -110,6 +110,7 @@ def _problems():
         ("case1_ros23_adjoint_2lanes", PRESET_CASE1, c1, dict(solver=L.SOLVER_ROSENBROCK23, grad_mode=2, lanes=2)),
         ("rober_ros23_adjoint", PRESET_ROBER, rb, dict(rate_scale=sc, grad_mode=2)),
         ("case2_ros23_forward", PRESET_CASE2, c2, dict(grad_mode=1)),
+        ("case2_ros23_primal", PRESET_CASE2, c2, dict(primal=True)),       # ros23_adj_kernel<..., PRIMAL>: predictions + losses, no directions
     ]
     # HyChem (its own kernels: one lane and a lane pair per trajectory), 300 trajectories, 211 parameters
     from crnn_amd import PRESET_HYCHEM, hychem as hy
@@ -127,7 +128,9 @@ def _problems():
         out.append((f"hychem_adjoint_{lanes}lane", node, hp))
     for name, preset, (ts, u0, data, ys, p), kw in specs:
         lanes = kw.pop("lanes", None)
+        primal = kw.pop("primal", False)
         node = NeuralODE(ODEProblem(preset, ts, **kw))
+        node._xb_primal = primal
         if lanes is not None:
             node.set_lanes_per_traj(lanes)
         node.set_queue_order(L.QUEUE_INDEX)
@@ -145,14 +148,17 @@ def worker():
     res = {}
     for name, node, p in _problems():
         th, dth = p2vec_jac(node.pmap, node.ns, node.nr, p)
-        _, loss, grad, ret, nsv = node._solve(node._ctx, node.B, th, dth, 0, node.B, None, False)
+        if getattr(node, "_xb_primal", False):
+            grad, loss, _, ret, nsv = node._solve(node._ctx, node.B, th, None, 0, node.B, None, True)    # "grad" := the predictions
+        else:
+            _, loss, grad, ret, nsv = node._solve(node._ctx, node.B, th, dth, 0, node.B, None, False)
         na, nr = node.step_counts()
         h = hashlib.sha256()
         for a in (loss, grad, ret, nsv, na, nr):
             h.update(np.ascontiguousarray(a).tobytes())
         viol, site = C.c_uint32(0), C.c_uint32(0)
         chk = L.lib.crnn_debug_bounds(C.byref(viol), C.byref(site))     # -1: no checks compiled into this build
-        res[name] = dict(digest=h.hexdigest()[:24], bounds_checked=(chk == 0), bounds_violations=int(viol.value), bounds_site=int(site.value), loss_sum=float(loss.sum()).hex(), grad0=float(grad[0]).hex(),
+        res[name] = dict(digest=h.hexdigest()[:24], bounds_checked=(chk == 0), bounds_violations=int(viol.value), bounds_site=int(site.value), loss_sum=float(loss.sum()).hex(), grad0=float(np.ravel(grad)[0]).hex(),
                          gnorm=float(np.linalg.norm(grad)).hex(), n_accept=int(na.sum()), n_reject=int(nr.sum()),
                          n_fail=int((ret != 0).sum()), loss=[float(x).hex() for x in loss[:8]])
         node.close()
