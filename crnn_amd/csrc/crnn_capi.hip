@@ -499,7 +499,7 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
         const int64_t resident_pairs = (int64_t)c->num_cu * c->adj2_occ * (kBlock / 2);
         if (c->lanes_per_traj == 2 || count <= (int64_t)k2->max_gen * resident_pairs) { G = 2; k = k2; }
     }
-    c->last_lanes = G;
+    if (!primal) c->last_lanes = G;      // (crnn_last_lanes_per_traj reports gradient launches)
     const int occ = G == 2 ? c->adj2_occ : c->adj_occ;
     const int tpb = kBlock / G;                                  // trajectories per block
     const int tpw = 64 / G;                                      // trajectories per wavefront = per batch row
