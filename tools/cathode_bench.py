@@ -41,3 +41,10 @@ n = args.particles * args.rates
 print(f"cathode-UQ {args.particles} particles x {args.rates} rates = {n} trajectories+17-gradients: kernel_ms median "
       f"{np.median(ms):.2f} -> {n / np.median(ms) * 1e3:.3e} traj+grads/s; steps/traj {st['n_accept'] / st['n_traj']:.1f} "
       f"rej/traj {st['n_reject'] / st['n_traj']:.2f} ok {st['n_ok']}/{st['n_traj']} mean loss {loss.mean():.4e}")
+# the primal launches (loss only; loss + HRR at the measured temperatures) next to the gradient launch
+for name, kw in (("primal (loss)", dict(want_grad=False)), ("primal + HRR", dict(want_grad=False, want_hrr=True))):
+    ms = []
+    for _ in range(max(2, args.reps)):
+        uq.solve(p, **kw)
+        ms.append(uq.last_stats["kernel_ms"])
+    print(f"  {name}: kernel_ms median {np.median(ms):.2f}")
