@@ -413,8 +413,12 @@ struct CathAdjParams {
 // then reverses them.  Same arithmetic as the forward sweep, so the re-formed states are the recorded ones; the tape
 // shrinks from 40 to 8 + 32 / KCP bytes per step (KCP = 4: 16 B, 2.5x less HBM traffic) for KCP - 1 extra re-formations
 // per KCP steps.
-template <int BLOCK, int KCP>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CRNN_CATH_ADJ_WAVES, CRNN_CATH_ADJ_WAVES))) void cathode_adj_kernel(const CathodeParams prm, const CathAdjParams adj) {
+// PRIMAL = true: the forward sweep alone -- loss (and HRR at the measured temperatures) accumulated at the save points as they are
+// passed, no tape, no reverse sweep: the primal calls of the UQ wrappers (loss_neuralode, pred_n_ode / HRR_getter, network.jl:167-275).
+// cathode_kernel, which served them, maps consecutive LANES to consecutive heating rates of one particle (different grids and step
+// counts side by side in a wavefront): 24.8 ms per 4 096 x 256 against 35.6 for the whole gradient here.
+template <int BLOCK, int KCP, bool PRIMAL = false>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CRNN_CATH_ADJ_WAVES, PRIMAL ? 2 : CRNN_CATH_ADJ_WAVES))) void cathode_adj_kernel(const CathodeParams prm, const CathAdjParams adj) {
     __shared__ double ts_s[kCathMaxSets * kCathMaxD];
     __shared__ double db_s[kCathMaxSets * kCathMaxD];
     __shared__ double d2_s[kCathMaxSets * kCathMaxD];
@@ -521,6 +525,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CRNN_CATH
         };
         if (valid && prm.hrr) prm.hrr[(size_t)traj * prm.Dmax + 0] = hrr_of(u, t0);
         jsave = 1;    // saveat contains tspan[1]
+        double pf_loss = 0.0;   // PRIMAL: the loss, accumulated at the save points of the forward sweep
 
         while (__builtin_amdgcn_ballot_w64(rc < 0) != 0) {
             if (rc < 0) {
@@ -584,11 +589,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CRNN_CATH
                         double q = ee_zero ? 1.0 / prm.qmax
                                            : fmax(1.0 / prm.qmax, fmin(1.0 / prm.qmin, exp(lq11 - prm.beta2 * lqold) / prm.gamma));
                         if (es <= 1.0) {
-                            if (nacc >= adj.tape_cap) {
+                            if (!PRIMAL && nacc >= adj.tape_cap) {
                                 rc = 5;
                                 atomicAdd(adj.overflow, 1u);
                             } else {
-                                if constexpr (KCP > 1) {
+                                if constexpr (PRIMAL) {
+                                } else if constexpr (KCP > 1) {
                                     CATH_DT(nacc) = dt;
                                     if (nacc % KCP == 0) {
                                         const int kk = nacc / KCP;
@@ -602,7 +608,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CRNN_CATH
                                 while (jsave < D) {
                                     const double tsj = tsv[jsave];
                                     if (!(tsj <= tnew)) break;
-                                    if (prm.hrr) {
+                                    if (prm.hrr || PRIMAL) {
                                         const bool at_end = (tsj == tnew);
                                         const double Th = at_end ? 1.0 : (tsj - t) / dt;
                                         const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
@@ -610,7 +616,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CRNN_CATH
                                         double ui[3];
 #pragma unroll
                                         for (int i = 0; i < 3; ++i) ui[i] = at_end ? unew[i] : fma(dt, fma(c1, k1[i], c2 * (k1[i] + dk[i])), u[i]);
-                                        prm.hrr[(size_t)traj * prm.Dmax + jsave] = hrr_of(ui, tsj);
+                                        const double hv = hrr_of(ui, tsj);
+                                        if (prm.hrr) prm.hrr[(size_t)traj * prm.Dmax + jsave] = hv;
+                                        if (PRIMAL) {
+                                            const double db = dbv[jsave], e = hv - db;
+                                            pf_loss += fma(e, e, d2v[jsave] - db * db);
+                                        }
                                     }
                                     ++jsave;
                                 }
@@ -637,8 +648,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CRNN_CATH
         double thb[kCathNP], lam[3] = {0.0, 0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < kCathNP; ++k) thb[k] = 0.0;
-        double loss_sum = 0.0, tnew = t;
-        int s = valid ? nacc - 1 : -1;
+        double loss_sum = PRIMAL ? pf_loss : 0.0, tnew = t;
+        int s = (valid && !PRIMAL) ? nacc - 1 : -1;
         // observation at a save point: loss term, direct theta gradients (into thb), state seed w
         auto observe = [&](const double (&uu)[3], double tt, int j, double (&w)[3]) {
             CathPoint q;

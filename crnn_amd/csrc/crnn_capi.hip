@@ -993,7 +993,7 @@ struct CathCtx {
     int rank = 0, world = 1;
     double *d_ag_send = nullptr, *d_ag_recv = nullptr;
     size_t ag_send_cap = 0, ag_recv_cap = 0;
-    int adj_occ = 0, fwd_occ = 0;
+    int adj_occ = 0, fwd_occ = 0, prim_occ = 0;
     int tape_every = CRNN_CATH_TAPE_EVERY;   // adjoint tape: 1 = every step in full, 4 / 8 = checkpoint every 4th / 8th step
     // device-resident SVGD loop (crnn_cathode_set_particles / crnn_cathode_svgd_step)
     double *d_pn = nullptr, *d_pn2 = nullptr, *d_lnp = nullptr, *d_pscales = nullptr;   // particles (current / moved), lnpgrad, [p_scales(17) | mean loss, n_failed]
@@ -1943,19 +1943,22 @@ int32_t cath_run(CathCtx *c, int64_t n_part, int set_first, int set_count, bool 
     prm.qsteady_min = c->cfg.qsteady_min; prm.qsteady_max = c->cfg.qsteady_max; prm.qoldinit = c->cfg.qoldinit;
     constexpr int kB = 256;
     bool done = false;
-    if (want_grad && c->cfg.grad_mode != CRNN_GRAD_FORWARD) {
+    const bool primal = !want_grad;      // primal calls: the adjoint kernel's forward sweep alone (cathode_adj_kernel<..., PRIMAL>)
+    if (primal || c->cfg.grad_mode != CRNN_GRAD_FORWARD) {
         // discrete adjoint (cathode_adj_kernel): a wavefront takes 64 particles of one heating rate
         // tape layout: every step in full (40 B) or checkpointed every kcp-th step (8 + 32 / kcp B per step; cathode_kernel.hpp)
-        const int kcp = c->tape_every;
+        const int kcp = primal ? 1 : c->tape_every;
         using AdjFn = void (*)(const crnn::CathodeParams, const crnn::CathAdjParams);
-        const AdjFn adj_fn = kcp == 4 ? (AdjFn)crnn::cathode_adj_kernel<kB, 4> : kcp == 8 ? (AdjFn)crnn::cathode_adj_kernel<kB, 8>
+        const AdjFn adj_fn = primal ? (AdjFn)crnn::cathode_adj_kernel<kB, 1, true>
+                           : kcp == 4 ? (AdjFn)crnn::cathode_adj_kernel<kB, 4> : kcp == 8 ? (AdjFn)crnn::cathode_adj_kernel<kB, 8>
                                                                                           : (AdjFn)crnn::cathode_adj_kernel<kB, 1>;
-        if (c->adj_occ < 1) {
-            CHIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->adj_occ, (const void *)adj_fn, kB, 0));
-            if (c->adj_occ < 1) c->adj_occ = 1;
+        int &occ_ = primal ? c->prim_occ : c->adj_occ;      // (the primal instantiation fits two wavefronts per SIMD)
+        if (occ_ < 1) {
+            CHIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_, (const void *)adj_fn, kB, 0));
+            if (occ_ < 1) occ_ = 1;
         }
         const int64_t n_batches = ((n_part + 63) / 64) * set_count;
-        const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((n_batches + 3) / 4, (int64_t)c->num_cu * c->adj_occ));
+        const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((n_batches + 3) / 4, (int64_t)c->num_cu * occ_));
         const size_t lanes = (size_t)nblk * kB;
         if (c->tape_budget == 0) {
             size_t fr = 0, tot = 0;
@@ -1966,7 +1969,7 @@ int32_t cath_run(CathCtx *c, int64_t n_part, int set_first, int set_count, bool 
         int64_t cap = std::max<int64_t>((int64_t)((double)c->tape_budget / ((double)lanes * per_step * sizeof(double))) - kcp, 64);
         cap = std::min<int64_t>(cap, c->cfg.maxiters);
         const size_t lane_doubles = kcp > 1 ? (size_t)cap + 4 * (((size_t)cap + kcp - 1) / kcp) : (size_t)cap * 5;
-        if (c->tape_doubles < lanes * lane_doubles) {
+        if (!primal && c->tape_doubles < lanes * lane_doubles) {
             if (cgrow(c, &c->d_tape, lanes * lane_doubles)) return -1;
             c->tape_doubles = lanes * lane_doubles;
         }
