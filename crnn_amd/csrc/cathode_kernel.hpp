@@ -413,15 +413,37 @@ struct CathAdjParams {
 // then reverses them.  Same arithmetic as the forward sweep, so the re-formed states are the recorded ones; the tape
 // shrinks from 40 to 8 + 32 / KCP bytes per step (KCP = 4: 16 B, 2.5x less HBM traffic) for KCP - 1 extra re-formations
 // per KCP steps.
+// The lane's 17 gradient accumulators: registers, or -- full-tape kernel -- a column of LDS (pitch 17, odd: conflict-free).  In LDS
+// they cost a read-modify-write per update (same arithmetic, same bits) and free 34 registers: with them the full-tape kernel is
+// built for two wavefronts per SIMD (256 registers; 61 spilled values left, none of them touched more than twice per step) and a
+// CU holds two blocks: 4 096 x 256 trajectories 35.8 -> 32.1 ms.  With one wavefront per SIMD the LDS version is slower (37.8), and
+// the checkpointed-tape kernels have no LDS to spare (their block states), so they keep registers.
+template <bool IN_LDS, int N>
+struct CathAcc;
+template <int N>
+struct CathAcc<false, N> {
+    double v[N];
+    __device__ __forceinline__ void bind(double *, int) {}
+    __device__ __forceinline__ double &operator[](int k) { return v[k]; }
+};
+template <int N>
+struct CathAcc<true, N> {
+    double *p;
+    __device__ __forceinline__ void bind(double *base, int tid) { p = base + tid * N; }
+    __device__ __forceinline__ double &operator[](int k) { return p[k]; }
+};
+
 // PRIMAL = true: the forward sweep alone -- loss (and HRR at the measured temperatures) accumulated at the save points as they are
 // passed, no tape, no reverse sweep: the primal calls of the UQ wrappers (loss_neuralode, pred_n_ode / HRR_getter, network.jl:167-275).
 // cathode_kernel, which served them, maps consecutive LANES to consecutive heating rates of one particle (different grids and step
 // counts side by side in a wavefront): 24.8 ms per 4 096 x 256 against 35.6 for the whole gradient here.
 template <int BLOCK, int KCP, bool PRIMAL = false>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CRNN_CATH_ADJ_WAVES, PRIMAL ? 2 : CRNN_CATH_ADJ_WAVES))) void cathode_adj_kernel(const CathodeParams prm, const CathAdjParams adj) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((KCP == 1 && !PRIMAL) ? 2 : CRNN_CATH_ADJ_WAVES, (KCP == 1 || PRIMAL) ? 2 : CRNN_CATH_ADJ_WAVES))) void cathode_adj_kernel(const CathodeParams prm, const CathAdjParams adj) {
     __shared__ double ts_s[kCathMaxSets * kCathMaxD];
     __shared__ double db_s[kCathMaxSets * kCathMaxD];
     __shared__ double d2_s[kCathMaxSets * kCathMaxD];
+    constexpr bool THB_LDS = (KCP == 1 && !PRIMAL);
+    __shared__ double thb_lds[THB_LDS ? BLOCK * kCathNP : 1];
     __shared__ double blk_s[KCP > 1 ? KCP * 4 * BLOCK : 1];      // states (t, u) of the steps of the block being reversed, per lane
     const int tid = threadIdx.x;
     const bool staged = prm.n_sets <= kCathMaxSets;
@@ -645,7 +667,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CRNN_CATH
 
         // ================================================================== reverse sweep
         const int n_saved = jsave;
-        double thb[kCathNP], lam[3] = {0.0, 0.0, 0.0};
+        CathAcc<THB_LDS, kCathNP> thb;
+        thb.bind(thb_lds, (int)threadIdx.x);
+        double lam[3] = {0.0, 0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < kCathNP; ++k) thb[k] = 0.0;
         double loss_sum = PRIMAL ? pf_loss : 0.0, tnew = t;
