@@ -155,7 +155,7 @@ def cathode(n_part=4096, n_rates=256, reps=3, device=0):
     uq.close()
     return _entry("cathode", n_part * n_rates, kms[1:], st,
                   {"workload": "Cathode-UQ: 4 096 particles x 256 heating rates, non-autonomous Rosenbrock23 atol 1e-12 rtol 1e-3, "
-                               "per-particle adjoint gradients (17 parameters each)", "kernel": "cathode_adj_kernel<256>",
+                               "per-particle adjoint gradients (17 parameters each)", "kernel": "cathode_adj_kernel<256,1> (full tape, two wavefronts per SIMD, accumulators in LDS)",
                    "svgd_move_ms": float(np.median(sv[2:])), "svgd_iteration_solve_ms": float(np.median(so[2:])),
                    "svgd_note": "device-resident SVGD iteration (crnn_cathode_svgd_step): svgd_iteration_solve_ms = the solve kernel "
                                 "over the 4 096 particles of ONE heating rate, svgd_move_ms = median select + kernel sums + move "
