@@ -97,7 +97,8 @@ struct AdjEntry {
     { CRNN_SOLVER_ROSENBROCK23, NS, NR, HT, SC, (AdjKernelFn)crnn::ros23_adj_kernel<NS, NR, (HT) != 0, (SC) != 0, kBlock>, 1, \
       (AdjKernelFn)crnn::ros23_adj_kernel<NS, NR, (HT) != 0, (SC) != 0, kBlock, true> }
 #define KAUTO(SOLVER, NS, NR, HT, SC, COMPOSITE) \
-    { SOLVER, NS, NR, HT, SC, (AdjKernelFn)crnn::auto_adj_kernel<NS, NR, (HT) != 0, (SC) != 0, kBlock, COMPOSITE> }
+    { SOLVER, NS, NR, HT, SC, (AdjKernelFn)crnn::auto_adj_kernel<NS, NR, (HT) != 0, (SC) != 0, kBlock, COMPOSITE>, 1, \
+      (AdjKernelFn)crnn::auto_adj_kernel<NS, NR, (HT) != 0, (SC) != 0, kBlock, COMPOSITE, true> }
 // Rosenbrock23 discrete adjoint with TWO lanes per trajectory (ros23_adj2_kernel.hpp): shapes with nr < ns, no rate scaling.
 // Two instantiations per shape: at most 512 registers per lane (one wavefront per SIMD) and at most 256 (two per SIMD).
 #ifndef CRNN_ADJ2_OCC

@@ -17,7 +17,9 @@ rng = np.random.Generator(np.random.PCG64([1234, 0]))
 ts = cases.case2_tsteps()
 u0 = cases.case2_u0(B, rng)
 p = np.array(fx["case2_ckpt"]["p"])
-node = NeuralODE(ODEProblem(PRESET_CASE2, ts))
+from crnn_amd import _lib as L  # noqa: E402
+SOLVER = {"ros23": L.SOLVER_ROSENBROCK23, "tsit5": L.SOLVER_TSIT5, "autotsit5": L.SOLVER_AUTOTSIT5}[os.environ.get("SOLVER", "ros23")]
+node = NeuralODE(ODEProblem(PRESET_CASE2, ts, solver=SOLVER))
 node.set_ensemble(u0, np.zeros((B, 6, len(ts))), np.ones(6))
 for name, fn in (("loss_and_grad", lambda: node.loss_and_grad(p)), ("losses", lambda: node.losses(p)),
                  ("predict_n_ode", lambda: node.predict_n_ode(p))):
@@ -28,7 +30,7 @@ for name, fn in (("loss_and_grad", lambda: node.loss_and_grad(p)), ("losses", la
     print(f"{name:16s} kernel_ms {np.median(k):.4f}  (first {k[0]:.4f})")
 node.close()
 import time
-node = NeuralODE(ODEProblem(PRESET_CASE2, ts))
+node = NeuralODE(ODEProblem(PRESET_CASE2, ts, solver=SOLVER))
 node.set_ensemble(u0, np.zeros((B, 6, len(ts))), np.ones(6))
 for name, fn in (("loss_and_grad", lambda: node.loss_and_grad(p)), ("losses", lambda: node.losses(p))):
     fn(); fn()
