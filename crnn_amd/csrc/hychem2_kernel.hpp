@@ -615,6 +615,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
             jsave = 1;
         }
 
+        double pf_loss = 0.0;    // primal launch (GRAD = false): the loss, accumulated at the save points of the forward sweep
         while (__builtin_amdgcn_ballot_w64(rc < 0) != 0) {
             if (rc < 0) {
                 ++iter;
@@ -714,31 +715,41 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                         double q = ee_zero ? inv_qmax
                                            : fmax(inv_qmax, fmin(inv_qmin, exp(lq11 - kc->beta2 * lqold) / kc->gamma));
                         if (es <= 1.0) {
-                            if (nacc >= hp.tape_cap) {
+                            if (GRAD && nacc >= hp.tape_cap) {
                                 rc = 5;
                                 if (!m1) atomicAdd(hp.overflow, 1u);
                             } else {
-                                double *rec = tape + (size_t)nacc * RECW;
-                                if (!m1) { rec[0] = t; rec[1] = dt; }
+                                if (GRAD) {
+                                    double *rec = tape + (size_t)nacc * RECW;
+                                    if (!m1) { rec[0] = t; rec[1] = dt; }
 #pragma unroll
-                                for (int i = 0; i < H; ++i)
-                                    if (ln.ow[i]) rec[2 + ln.ci[i]] = u[i];
+                                    for (int i = 0; i < H; ++i)
+                                        if (ln.ow[i]) rec[2 + ln.ci[i]] = u[i];
+                                }
                                 ++nacc;
                                 while (jsave < nsave) {
                                     const double ts = ts_lds[jsave];
                                     if (!(ts <= tnew)) break;
-                                    if (prm.pred) {
+                                    if (prm.pred || !GRAD) {
                                         const bool at_end = (ts == tnew);
                                         const double Th = at_end ? 1.0 : (ts - t) / dt;
                                         const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
                                         const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d_) * inv12d;
+                                        const double *prow = prm.data + (size_t)b * prm.row_stride + (size_t)jsave * prm.n_obs;
 #pragma unroll
                                         for (int i = 0; i < H; ++i) {
                                             if (ln.ow[i]) {
                                                 const double k2i = k1[i] + dk[i];
                                                 double v = at_end ? unew[i] : fma(dt, fma(c1, k1[i], c2 * k2i), u[i]);
                                                 if (prm.clamp_pred) v = clampv(v, -kc->ub, kc->ub);
-                                                prm.pred[((size_t)jsave * NS + ln.ci[i]) * prm.B + b] = v;
+                                                if (prm.pred) prm.pred[((size_t)jsave * NS + ln.ci[i]) * prm.B + b] = v;
+                                                if (!GRAD) {     // primal launch: the loss term of this save point, here (no tape, no reverse sweep)
+                                                    const int dr = (int)kc->drow[ln.ci[i]];
+                                                    if (dr >= 0) {
+                                                        const double rr = (prow[dr] - v) * kc->inv_yscale[ln.ci[i]];
+                                                        pf_loss = (prm.loss_kind == 0) ? pf_loss + fabs(rr) : fma(rr, rr, pf_loss);
+                                                    }
+                                                }
                                             }
                                         }
                                     }
@@ -778,9 +789,9 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
         double lam[H];
 #pragma unroll
         for (int i = 0; i < H; ++i) lam[i] = 0.0;
-        double loss_sum = 0.0;            // this lane's species only; the pair's sum is formed at the end
+        double loss_sum = GRAD ? 0.0 : pf_loss;   // this lane's species only; the pair's sum is formed at the end
         double tnew = t;
-        int s = valid ? nacc - 1 : -1;
+        int s = (valid && GRAD) ? nacc - 1 : -1;     // (primal launch: no reverse sweep)
         // the trajectory's weight in the batch gradient, 1 / (n_obs n_saved) (reduce_gacc_kernel's scale): carried by the loss seeds,
         // so every adjoint quantity -- linear in the seeds -- arrives at the wavefront's tiles already weighted
         const double gscale = n_saved > 0 ? 1.0 / ((double)prm.n_obs * (double)n_saved) : 0.0;
