@@ -2,7 +2,8 @@
 other BASELINE configurations and regimes.  Every entry: kernel time = median HIP-event duration of the solve kernel over
 `reps` loss+gradient calls (crnn_stats.kernel_ms), value = trajectories+gradients per second of that kernel, `roofline` =
 algorithmic HBM bytes per trajectory x trajectories / kernel time against 8 TB/s, plus the step statistics
-the kernel reports.  Ensembles are synthetic and seeded; nothing here reads /root/reference.
+the kernel reports; `primal_kernel_ms` = the same median for the primal launch (losses only: the epoch-end evaluation loop) at the
+same p.  Ensembles are synthetic and seeded; nothing here reads /root/reference.
 """
 import json
 import os
@@ -50,6 +51,15 @@ def _time_calls(node, p, reps):
     return kms[1:], float(np.median(walls[1:])), node.last_stats
 
 
+def _primal_ms(node, p, reps=4):
+    """Median kernel time of the primal launch (crnn_solve with no directions: the epoch-end loss loop, case2.jl:199-203)."""
+    kms = []
+    for _ in range(reps):
+        node.losses(p)
+        kms.append(node.last_stats["kernel_ms"])
+    return float(np.median(kms[1:]))
+
+
 def case2_fixed(u0, data, yscale, p, label_extra=None, reps=6, device=0, lanes=None, **probkw):
     """case2 at a fixed p (no optimiser update) on a caller-supplied ensemble.  lanes: crnn_ctx_set_lanes_per_traj (None = AUTO)."""
     from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE2, cases
@@ -60,6 +70,8 @@ def case2_fixed(u0, data, yscale, p, label_extra=None, reps=6, device=0, lanes=N
     kms, wall, st = _time_calls(node, p, reps)
     e = _entry("case2", u0.shape[0], kms, st, label_extra, wall)
     e["lanes_per_traj"] = node.last_lanes_per_traj()
+    if not probkw.get("errnorm_sens"):
+        e["primal_kernel_ms"] = _primal_ms(node, p)
     if e["lanes_per_traj"] == 2 and u0.shape[0] in (8192, 32768):
         e["roofline"]["traffic"] = _traffic(f"case2_B{u0.shape[0]}_lane_pair")
     node.close()
@@ -95,8 +107,9 @@ def robertson(B=65536, reps=6, device=0):
     node = NeuralODE(ODEProblem(PRESET_ROBER, ts, rate_scale=sc, device=device))
     node.set_ensemble(u0, data, ys)
     kms, wall, st = _time_calls(node, p, reps)
+    prim = _primal_ms(node, p)
     node.close()
-    return _entry("robertson", B, kms, st, {"workload": "robertson CRNN, 65 536 ICs, Rosenbrock23 atol [1e-6,1e-8,1e-6] rtol 1e-3, adjoint gradient (P = 43)",
+    return _entry("robertson", B, kms, st, {"primal_kernel_ms": prim, "workload": "robertson CRNN, 65 536 ICs, Rosenbrock23 atol [1e-6,1e-8,1e-6] rtol 1e-3, adjoint gradient (P = 43)",
                                             "kernel": "ros23_adj_kernel<3,6,scaled>"}, wall, traffic_key="robertson_B65536" if B == 65536 else None)
 
 
@@ -116,8 +129,9 @@ def hychem(B=32768, reps=4, device=0):
     p = hy.true_p() + 0.02 * np.random.Generator(np.random.PCG64(5)).standard_normal(hy.NP)
     p[-1] = 0.1
     kms, wall, st = _time_calls(node, p, reps)
+    prim = _primal_ms(node, p, 3)
     node.close()
-    return _entry("hychem", B, kms, st, {"workload": "HyChem pyrolysis CRNN, 32 768 ICs (one GPU's share of 262 144), T(t)/P(t) tables, "
+    return _entry("hychem", B, kms, st, {"primal_kernel_ms": prim, "workload": "HyChem pyrolysis CRNN, 32 768 ICs (one GPU's share of 262 144), T(t)/P(t) tables, "
                                                      "Rosenbrock23 atol 1e-8 rtol 1e-3, adjoint gradient (P = 211)",
                                          "kernel": "hychem2_kernel<9,10,GRAD,256> (a lane pair per trajectory, W's rows in registers, LDS frame, "
                                                    "gradient summed over each batch of 32 by v_mfma_f64_16x16x4: no accumulator in HBM)"}, wall,
@@ -145,6 +159,10 @@ def cathode(n_part=4096, n_rates=256, reps=3, device=0):
         uq.solve(p)
         kms.append(uq.last_stats["kernel_ms"])
     st = uq.last_stats
+    pk = []
+    for _ in range(3):
+        uq.solve(p, want_grad=False)
+        pk.append(uq.last_stats["kernel_ms"])
     # the reference's own iteration (crnn_cathode.jl:36-50): ONE heating rate per SVGD move, particles resident on the device --
     # solve of n_part trajectories + chain rule + exact-median select + kernel sums + update, enqueued back to back
     uq.set_particles(p)
@@ -156,6 +174,7 @@ def cathode(n_part=4096, n_rates=256, reps=3, device=0):
     return _entry("cathode", n_part * n_rates, kms[1:], st,
                   {"workload": "Cathode-UQ: 4 096 particles x 256 heating rates, non-autonomous Rosenbrock23 atol 1e-12 rtol 1e-3, "
                                "per-particle adjoint gradients (17 parameters each)", "kernel": "cathode_adj_kernel<256,1> (full tape, two wavefronts per SIMD, accumulators in LDS)",
+                   "primal_kernel_ms": float(np.median(pk[1:])),
                    "svgd_move_ms": float(np.median(sv[2:])), "svgd_iteration_solve_ms": float(np.median(so[2:])),
                    "svgd_note": "device-resident SVGD iteration (crnn_cathode_svgd_step): svgd_iteration_solve_ms = the solve kernel "
                                 "over the 4 096 particles of ONE heating rate, svgd_move_ms = median select + kernel sums + move "
