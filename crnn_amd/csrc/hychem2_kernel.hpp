@@ -102,6 +102,30 @@ __device__ __forceinline__ double flog_ctl(double x) {
     return fma(dk, 6.93147180369123816490e-01, -((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f));
 }
 
+// exp for the step-size controller: __ocml_exp_f64's arithmetic, operation for operation (the same bits as the exp() call it
+// replaces -- the constants are the device library's, read off the ISA), with the same cure as flog_ctl: the ten coefficients that
+// are ADDENDS of the multiply-add chain were materialised once per kernel in fourteen AGPRs and two scratch slots (two memory
+// latencies per step, in the controller's dependent chain); formed in SGPRs where they are used they cost two s_mov each.
+__device__ __forceinline__ double fexp_ctl(double x) {
+    const double dn = __builtin_rint(x * 0x1.71547652b82fep+0);
+    double t = fma(-dn, 0x1.62e42fefa39efp-1, x);
+    t = fma(-dn, 0x1.abc9e3b39803fp-56, t);
+    double p = fma(t, 0x1.ade156a5dcb37p-26, hy_sconst(0x1.28af3fca7ab0cp-22));
+    p = fma(t, p, hy_sconst(0x1.71dee623fde64p-19));
+    p = fma(t, p, hy_sconst(0x1.a01997c89e6b0p-16));
+    p = fma(t, p, hy_sconst(0x1.a01a014761f6ep-13));
+    p = fma(t, p, hy_sconst(0x1.6c16c1852b7b0p-10));
+    p = fma(t, p, hy_sconst(0x1.1111111122322p-7));
+    p = fma(t, p, hy_sconst(0x1.55555555502a1p-5));
+    p = fma(t, p, hy_sconst(0x1.5555555555511p-3));
+    p = fma(t, p, hy_sconst(0x1.000000000000bp-1));
+    p = fma(t, p, 1.0);
+    p = fma(t, p, 1.0);
+    double z = __builtin_amdgcn_ldexp(p, (int)dn);
+    z = x > 1024.0 ? __builtin_inf() : z;
+    return x < -1075.0 ? 0.0 : z;
+}
+
 template <int NS, int NR>
 struct HyPoint2 {
     static constexpr int H = (NS + 1) / 2;
@@ -713,7 +737,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                         const double lEE = 0.5 * flog_ctl(ee_zero ? 1.0 : es);
                         const double lq11 = kc->beta1 * lEE;
                         double q = ee_zero ? inv_qmax
-                                           : fmax(inv_qmax, fmin(inv_qmin, exp(lq11 - kc->beta2 * lqold) / kc->gamma));
+                                           : fmax(inv_qmax, fmin(inv_qmin, fexp_ctl(lq11 - kc->beta2 * lqold) / kc->gamma));
                         if (es <= 1.0) {
                             if (GRAD && nacc >= hp.tape_cap) {
                                 rc = 5;
@@ -775,7 +799,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                             }
                         } else {
                             ++nrej;
-                            dt = dt / fmin(inv_qmin, exp(lq11) / kc->gamma);
+                            dt = dt / fmin(inv_qmin, fexp_ctl(lq11) / kc->gamma);
                         }
                     }
                     HY_T(15);
