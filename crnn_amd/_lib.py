@@ -129,7 +129,6 @@ SYMBOLS = {
     "crnn_cathode_comm_destroy": (C.c_int32, [_CTX]),
     "crnn_cathode_allgather": (C.c_int32, [_CTX, _DP, C.c_int64, C.c_int32, C.c_int64, _DP]),
     "crnn_cathode_set_tape_every": (C.c_int32, [_CTX, C.c_int32]),
-    "crnn_cathode_set_solver": (C.c_int32, [_CTX, C.c_int32]),
     "crnn_cathode_set_particles": (C.c_int32, [_CTX, _DP, _DP, C.c_int64]),
     "crnn_cathode_svgd_step": (C.c_int32, [_CTX, C.c_int32, _DP, C.c_double, C.c_double, _DP, _DP, _DP]),
     "crnn_cathode_get_particles": (C.c_int32, [_CTX, _DP]),

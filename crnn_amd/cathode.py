@@ -79,7 +79,7 @@ class CathodeUQ:
     """exp_data: list of arrays [D_s, 1 + n_replicas] (col 0 = time in s, dataset.jl:19-23), heating_rates in K/min."""
 
     def __init__(self, exp_data, heating_rates, p_scales, *, atol=None, rtol=None, maxiters=None, lb_clamp=None, device=0,
-                 normalizer=None, grad_mode=None, tape_every=None, solver=None):
+                 normalizer=None, grad_mode=None, tape_every=None):
         self.cfg = CathodeConfig()
         check(lib.crnn_cathode_config_default(C.byref(self.cfg)))
         self.cfg.device = device
@@ -90,8 +90,6 @@ class CathodeUQ:
         check(lib.crnn_cathode_create(C.byref(self.cfg), C.byref(self.h)))
         if tape_every is not None:     # adjoint tape: 1 = every step in full (default), 4 / 8 = checkpointed (include/crnn_hip.h)
             self._check(lib.crnn_cathode_set_tape_every(self.h, int(tape_every)))
-        if solver is not None:         # _lib.SOLVER_ROSENBROCK23 (default) / SOLVER_AUTOTSIT5: the composite of network.jl:195 (include/crnn_hip.h)
-            self._check(lib.crnn_cathode_set_solver(self.h, int(solver)))
         self.p_scales = np.asarray(p_scales, float)[:17].copy()
         self.beta = np.ascontiguousarray(heating_rates, np.float64)
         self.exp_data = [np.asarray(e, float) for e in exp_data]

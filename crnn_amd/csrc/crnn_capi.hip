@@ -24,7 +24,6 @@
 #include "auto_adj_kernel.hpp"
 #include "ros23_adj2_kernel.hpp"
 #include "cathode_kernel.hpp"
-#include "cathode_auto_kernel.hpp"
 #include "svgd_kernel.hpp"
 
 namespace {
@@ -996,7 +995,6 @@ struct CathCtx {
     double *d_ag_send = nullptr, *d_ag_recv = nullptr;
     size_t ag_send_cap = 0, ag_recv_cap = 0;
     int adj_occ = 0, fwd_occ = 0, prim_occ = 0;
-    int solver = CRNN_SOLVER_ROSENBROCK23;   // crnn_cathode_set_solver: ROSENBROCK23 or the AUTOTSIT5 composite (cathode_auto_kernel.hpp)
     int tape_every = CRNN_CATH_TAPE_EVERY;   // adjoint tape: 1 = every step in full, 4 / 8 = checkpoint every 4th / 8th step
     // device-resident SVGD loop (crnn_cathode_set_particles / crnn_cathode_svgd_step)
     double *d_pn = nullptr, *d_pn2 = nullptr, *d_lnp = nullptr, *d_pscales = nullptr;   // particles (current / moved), lnpgrad, [p_scales(17) | mean loss, n_failed]
@@ -1947,17 +1945,12 @@ int32_t cath_run(CathCtx *c, int64_t n_part, int set_first, int set_count, bool 
     constexpr int kB = 256;
     bool done = false;
     const bool primal = !want_grad;      // primal calls: the adjoint kernel's forward sweep alone (cathode_adj_kernel<..., PRIMAL>)
-    if (c->solver == CRNN_SOLVER_AUTOTSIT5 && !primal)
-        return cfail(c, "cathode: CRNN_SOLVER_AUTOTSIT5 serves primal calls only -- the linearisation of its explicit steps is unstable "
-                        "(cathode_auto_kernel.hpp); gradients run on CRNN_SOLVER_ROSENBROCK23");
     if (primal || c->cfg.grad_mode != CRNN_GRAD_FORWARD) {
         // discrete adjoint (cathode_adj_kernel): a wavefront takes 64 particles of one heating rate
         // tape layout: every step in full (40 B) or checkpointed every kcp-th step (8 + 32 / kcp B per step; cathode_kernel.hpp)
-        const bool composite = c->solver == CRNN_SOLVER_AUTOTSIT5;   // (primal launches only, see above)
         const int kcp = primal ? 1 : c->tape_every;
         using AdjFn = void (*)(const crnn::CathodeParams, const crnn::CathAdjParams);
-        const AdjFn adj_fn = composite ? (AdjFn)crnn::cathode_auto_kernel<kB>
-                           : primal ? (AdjFn)crnn::cathode_adj_kernel<kB, 1, true>
+        const AdjFn adj_fn = primal ? (AdjFn)crnn::cathode_adj_kernel<kB, 1, true>
                            : kcp == 4 ? (AdjFn)crnn::cathode_adj_kernel<kB, 4> : kcp == 8 ? (AdjFn)crnn::cathode_adj_kernel<kB, 8>
                                                                                           : (AdjFn)crnn::cathode_adj_kernel<kB, 1>;
         int &occ_ = primal ? c->prim_occ : c->adj_occ;      // (the primal instantiation fits two wavefronts per SIMD)
@@ -2074,18 +2067,6 @@ int32_t crnn_cathode_solve(crnn_cathode_ctx *ctx, const double *theta, int64_t n
 // ---- device-resident SVGD loop of the Bayesian ensemble (crnn_cathode.jl:36-50): particles, gradients and the move stay on
 // the device; per iteration one solve launch over the particles of ONE heating rate (the reference draws i_exp at random)
 // and the SVGD move, enqueued back to back.
-int32_t crnn_cathode_set_solver(crnn_cathode_ctx *ctx, int32_t solver) {
-    CathCtx *c = reinterpret_cast<CathCtx *>(ctx);
-    if (!c) return cfail(nullptr, "null ctx");
-    if (solver != CRNN_SOLVER_ROSENBROCK23 && solver != CRNN_SOLVER_AUTOTSIT5)
-        return cfail(c, "crnn_cathode_set_solver: CRNN_SOLVER_ROSENBROCK23 or CRNN_SOLVER_AUTOTSIT5");
-    if (solver != c->solver) { c->solver = solver; c->adj_occ = 0; c->prim_occ = 0; }
-    // the steady band of the algorithm type, as crnn_config_set_solver: a composite is not an implicit algorithm (qsteady_max_default = 1);
-    // the PI exponents are those of the running algorithm inside the kernel
-    c->cfg.qsteady_max = solver == CRNN_SOLVER_AUTOTSIT5 ? 1.0 : 1.2;
-    return 0;
-}
-
 int32_t crnn_cathode_set_tape_every(crnn_cathode_ctx *ctx, int32_t every) {
     CathCtx *c = reinterpret_cast<CathCtx *>(ctx);
     if (!c) return cfail(nullptr, "null ctx");

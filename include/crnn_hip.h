@@ -378,16 +378,6 @@ int32_t crnn_cathode_set_particles(crnn_cathode_ctx *ctx, const double *p, const
  * (4 096 x 256 trajectories, 338 steps each): HBM traffic 31 -> 9.4 GB per launch, tape capacity per trajectory 3.3x, kernel
  * time 35.7 -> 40.3 ms (the kernel is issue-bound, not bandwidth-bound: profiles/r03e_*). */
 int32_t crnn_cathode_set_tape_every(crnn_cathode_ctx *ctx, int32_t every);
-/* Stepper of the cathode's PRIMAL calls (loss / heat-release rates; grad == NULL in crnn_cathode_solve).
- * CRNN_SOLVER_ROSENBROCK23 (default): non-autonomous Rosenbrock23 for every step.
- * CRNN_SOLVER_AUTOTSIT5: the composite of the reference's call site -- Cathode_NCM333_UQ/src_333/network.jl:195
- * `alg = AutoTsit5(TRBDF2(autodiff = true))` -- with Tsit5 as its explicit algorithm, the AutoSwitch rule of crnn_config_set_solver's
- * composite, and Rosenbrock23 (not TRBDF2) as its stiff algorithm: on BASELINE config 5's ensemble 97 % of the trajectories never
- * leave Tsit5 (tools/cathode_autoswitch_census.py) and take a third of the steps.  Gradient calls (crnn_cathode_solve with grad,
- * crnn_cathode_svgd_step) are an ERROR under this solver: the linearisation of the explicit steps is unstable for this model
- * (measured, crnn_amd/csrc/cathode_auto_kernel.hpp); they need ROSENBROCK23.  Also sets the config's qsteady_max (1 for the
- * composite, 1.2 for Rosenbrock23: the defaults of the algorithm types). */
-int32_t crnn_cathode_set_solver(crnn_cathode_ctx *ctx, int32_t solver);
 int32_t crnn_cathode_svgd_step(crnn_cathode_ctx *ctx, int32_t i_set, const double *normalizer2 /* [17] */, double stepsize, double h,
                                double *loss_mean, double *h_out, double *ms);
 int32_t crnn_cathode_get_particles(crnn_cathode_ctx *ctx, double *p);
