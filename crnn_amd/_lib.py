@@ -138,14 +138,16 @@ SYMBOLS = {
 
 
 def source_hash() -> str:
-    """sha256 prefix over the sorted csrc/*.hip, *.hpp and include/crnn_hip.h -- the same digest the Makefile bakes into
-    the binary (crnn_build_info) and writes to libcrnn_hip.so.srchash."""
+    """sha256 prefix over the sorted csrc/*.hip, *.hpp, include/crnn_hip.h and csrc/Makefile (the default flags are part of
+    what the binary is) -- the same digest the Makefile bakes into the binary (crnn_build_info) and writes to
+    libcrnn_hip.so.srchash."""
     import hashlib
     files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp")))
     h = hashlib.sha256()
     for f in files:
         h.update(open(os.path.join(CSRC, f), "rb").read())
     h.update(open(os.path.join(CSRC, "..", "..", "include", "crnn_hip.h"), "rb").read())
+    h.update(open(os.path.join(CSRC, "Makefile"), "rb").read())
     return h.hexdigest()[:16]
 
 

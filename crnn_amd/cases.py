@@ -17,6 +17,11 @@ R_KCAL = 1.98720425864083e-3           # case2/case2.jl:56
 # `inv_R = - 1 / 1.98720425864083f-3` (case2/case2.jl:113): R is a Float32 literal, so the quotient is formed in Float32.
 # Its double value differs from -1/R_KCAL by 2e-8 relative -- 4e-7 in a rate at Ea = 14.5 kcal/mol, T = 333 K.
 INV_R = float(np.float32(-1.0) / np.float32(R_KCAL))
+# `lb = 1.f-5` (case1/case1.jl:34) and `lb = 1.f-6` (case2/case2.jl:34) are Float32 literals; `clamp(u, lb, ub)` and
+# `max_min(...) .+ lb` promote them to the Float64 values 9.999999747378752e-06 / 9.999999974752427e-07 (robertson's
+# `lb = 1e-8` and HyChem's `lb = atol = 1.e-8` are Float64 literals and stay decimal).
+LB_CASE1 = float(np.float32(1e-5))
+LB_CASE2 = float(np.float32(1e-6))
 
 
 def pack_theta(w_in, w_b, w_out):

@@ -547,12 +547,15 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
         double ts_cur = (jsave - 1 >= jlo) ? ts_lds[jsave - 1] : -INFINITY;   // none left: -inf, never inside a step
         double ts_nxt = (jsave - 2 >= jlo) ? ts_lds[jsave - 2] : -INFINITY;
         double rt = 0.0, rdt = 0.0, ru[NS];   // tape record s, prefetched
-        {
+        if constexpr (!PRIMAL) {   // a context that has only made primal calls has no tape at all: nothing may touch it
             CRNN_CHK(s < adj.tape_cap, 3);
             const double *rec = tape + (size_t)(s > 0 ? s : 0) * RECW;
             rt = rec[0]; rdt = rec[1];
 #pragma unroll
             for (int i = 0; i < NS; ++i) ru[i] = rec[2 + i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) ru[i] = 0.0;
         }
 
         while (__builtin_amdgcn_ballot_w64(s >= 0) != 0) {

@@ -695,7 +695,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((KCP == 1
             }
         };
         double rt = 0.0, rdt = 0.0, ru[3] = {0.0, 0.0, 0.0};
-        if constexpr (KCP == 1) {
+        if constexpr (KCP == 1 && !PRIMAL) {   // (a context that has only made primal calls has no tape at all)
             const double *rec = tape + (size_t)(s > 0 ? s : 0) * RECW;
             rt = rec[0]; rdt = rec[1]; ru[0] = rec[2]; ru[1] = rec[3]; ru[2] = rec[4];
         }

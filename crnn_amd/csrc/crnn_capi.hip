@@ -1081,14 +1081,14 @@ int32_t crnn_config_preset(crnn_config *cfg, int32_t preset) {
     case CRNN_PRESET_CASE1:  // case1/case1.jl:19-35
         cfg->ns = 5; cfg->nr = 4; cfg->has_temp = 0; cfg->param_map = CRNN_PMAP_CASE1;
         cfg->n_save = 100; cfg->clamp_pred = 1; cfg->maxiters = 10000;
-        cfg->lb = 1e-5; cfg->ub = 10.0;
+        cfg->lb = (double)1e-5f; cfg->ub = 10.0;   // `lb = 1.f-5`: a Float32 literal, promoted by clamp (case1.jl:34,81)
         for (int i = 0; i < CRNN_MAX_N; ++i) { cfg->atol[i] = 1e-5; cfg->rtol[i] = 1e-2; }
         crnn_config_set_solver(cfg, CRNN_SOLVER_TSIT5);  // alg = Tsit5(), case1/case1.jl:28
         break;
     case CRNN_PRESET_CASE2:  // case2/case2.jl:18-35,113
         cfg->ns = 6; cfg->nr = 3; cfg->has_temp = 1; cfg->param_map = CRNN_PMAP_CASE2;
         cfg->n_save = 50; cfg->clamp_pred = 1;
-        cfg->lb = 1e-6; cfg->ub = 10.0;
+        cfg->lb = (double)1e-6f; cfg->ub = 10.0;   // `lb = 1.f-6`: a Float32 literal, promoted by clamp (case2.jl:34,115)
         cfg->inv_R = (double)(-1.0f / 1.98720425864083e-3f);   // `- 1 / 1.98720425864083f-3`: a Float32 literal, the quotient is Float32 (case2.jl:113)
         break;
     case CRNN_PRESET_ROBER:  // robertson/rober_crnn.jl:20-37
@@ -2093,6 +2093,7 @@ int32_t crnn_cathode_set_particles(crnn_cathode_ctx *ctx, const double *p, const
     }
     if (!c->d_pscales) CHIP(c, hipMalloc((void **)&c->d_pscales, sizeof(double) * (2 * CRNN_CATHODE_NP + 2)));   // [p_scales | mean loss, n_failed | normalizer2]
     CHIP(c, svgd_ws_reserve(c->svgd, n_part, CRNN_CATHODE_NP, false));
+    CHIP(c, hipMemsetAsync(c->svgd.d_sel, 0, sizeof(crnn::SvgdSel), c->stream));   // new particles: the sticky `bad` flag is cleared
     CHIP(c, hipMemcpyAsync(c->d_pn, p, sizeof(double) * (size_t)n_part * CRNN_CATHODE_NP, hipMemcpyHostToDevice, c->stream));
     CHIP(c, hipMemcpyAsync(c->d_pscales, p_scales, sizeof(double) * CRNN_CATHODE_NP, hipMemcpyHostToDevice, c->stream));
     CHIP(c, hipStreamSynchronize(c->stream));
@@ -2105,8 +2106,12 @@ int32_t crnn_cathode_get_particles(crnn_cathode_ctx *ctx, double *p) {
     if (!c) return cfail(nullptr, "null ctx");
     if (!p || c->n_particles < 2) return cfail(c, "crnn_cathode_get_particles: no particles on the device (crnn_cathode_set_particles)");
     CHIP(c, hipSetDevice(c->cfg.device));
+    crnn::SvgdSel sel{};
     CHIP(c, hipMemcpyAsync(p, c->d_pn, sizeof(double) * (size_t)c->n_particles * CRNN_CATHODE_NP, hipMemcpyDeviceToHost, c->stream));
+    CHIP(c, hipMemcpyAsync(&sel, c->svgd.d_sel, sizeof(sel), hipMemcpyDeviceToHost, c->stream));
     CHIP(c, hipStreamSynchronize(c->stream));
+    if (sel.bad) return cfail(c, "crnn_cathode_get_particles: an earlier crnn_cathode_svgd_step found a bandwidth that was not finite and "
+                                 "positive and left the particles unmoved from there on (coincident particles, or NaN gradients of failed solves)");
     return 0;
 }
 
@@ -2141,7 +2146,9 @@ int32_t crnn_cathode_svgd_step(crnn_cathode_ctx *ctx, int32_t i_set, const doubl
         CHIP(c, hipMemcpyAsync(&sel, c->svgd.d_sel, sizeof(sel), hipMemcpyDeviceToHost, c->stream));
         CHIP(c, hipStreamSynchronize(c->stream));
         if (out2[1] != 0.0) printf("ode solver failed\n");     // network.jl:214
-        if (!(sel.h > 0)) return cfail(c, "crnn_cathode_svgd_step: bandwidth h is not positive (all particles coincide?)");
+        if (sel.bad || !(sel.h > 0) || !(sel.h < INFINITY))
+            return cfail(c, "crnn_cathode_svgd_step: bandwidth h is not finite and positive (all particles coincide, or a failed solve "
+                            "gave NaN gradients); the particles were left where they were");
         if (loss_mean) *loss_mean = out2[0];
         if (h_out) *h_out = sel.h;
         if (ms) {
@@ -2227,8 +2234,12 @@ hipError_t svgd_ws_reserve(SvgdWs &w, int64_t N, int dim, bool io_buffers) {
     get((void **)&w.d_sel, sizeof(crnn::SvgdSel));
     get((void **)&w.d_cnt, 3 * sizeof(unsigned long long));
     const size_t npairs = (size_t)N * (size_t)(N - 1) / 2;
-    if (npairs * sizeof(double) <= ((size_t)8 << 30)) get((void **)&w.d_dist, npairs * sizeof(double));   // 4 096 particles: 67 MB
+    // the stored pair distances are an optimisation (4 096 particles: 67 MB): if they do not fit, or the allocation fails, the
+    // select recomputes them per pass
+    if (e == hipSuccess && npairs * sizeof(double) <= ((size_t)8 << 30) &&
+        hipMalloc((void **)&w.d_dist, npairs * sizeof(double)) != hipSuccess) { w.d_dist = nullptr; (void)hipGetLastError(); }
     if (e == hipSuccess) e = hipMemset(w.d_hist, 0, crnn::kSvgdBins * sizeof(unsigned int));   // the pick kernel keeps it zeroed from here on
+    if (e == hipSuccess) e = hipMemset(w.d_sel, 0, sizeof(crnn::SvgdSel));                      // (the sticky `bad` flag starts clear)
     if (e != hipSuccess) { w.release(); return e; }
     w.N = N; w.dim = dim; w.nchunk = nchunk;
     return hipSuccess;

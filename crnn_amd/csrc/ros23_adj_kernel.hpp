@@ -530,7 +530,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
 #if CRNN_ADJ_TAPE_K
         double rk1[NS], rdk[NS];
 #endif
-        {
+        if constexpr (!PRIMAL) {   // a context that has only made primal calls has no tape at all: nothing may touch it
             CRNN_CHK(s < adj.tape_cap, 3);
             const double *rec = tape + (size_t)(s > 0 ? s : 0) * RECW;
             rt = rec[0]; rdt = rec[1];
@@ -539,6 +539,13 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
 #if CRNN_ADJ_TAPE_K
 #pragma unroll
             for (int i = 0; i < NS; ++i) { rk1[i] = rec[2 + NS + i]; rdk[i] = rec[2 + 2 * NS + i]; }
+#endif
+        } else {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) ru[i] = 0.0;
+#if CRNN_ADJ_TAPE_K
+#pragma unroll
+            for (int i = 0; i < NS; ++i) { rk1[i] = 0.0; rdk[i] = 0.0; }
 #endif
         }
 

@@ -56,7 +56,7 @@ struct SvgdSel {
     unsigned long long prefix;   // bits of the order statistic found so far
     long long rank;              // its rank among the pairs that share the prefix
     int prefix_shift;            // 64: no prefix yet
-    int pad_;
+    int bad;                     // sticky: a move found h not finite and positive and left the particles where they were
     double median[2];            // the two middle order statistics (as values)
     double h;                    // bandwidth
     double inv2h2, inv_h2;       // 1/(2 h^2), 1/h^2
@@ -394,7 +394,12 @@ __global__ __launch_bounds__(256) void svgd_update_dev_kernel(const double *__re
     const double rep = (pv * sk - sp) * inv_h2;
     if (data_term) data_term[idx] = sg;
     if (repulsion) repulsion[idx] = rep;
-    p_new[idx] = pv + step_over_n * (sg + rep);
+    // a bandwidth that is not finite and positive (coincident particles, NaN positions) would turn every particle into NaN/Inf:
+    // the particles stay where they are and the state says so (the host checks `bad` where it looks at the loop)
+    const double hh = st->h;
+    const bool ok = hh > 0.0 && hh < INFINITY;
+    if (!ok && idx == 0) const_cast<SvgdSel *>(st)->bad = 1;
+    p_new[idx] = ok ? pv + step_over_n * (sg + rep) : pv;
 }
 
 }  // namespace crnn

@@ -14,6 +14,8 @@ import sys
 
 import numpy as np
 
+LB_CASE1, LB_CASE2 = float(np.float32(1e-5)), float(np.float32(1e-6))   # `lb = 1.f-5` / `lb = 1.f-6`: Float32 literals (case1/case1.jl:34, case2/case2.jl:34)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -41,7 +43,7 @@ def main():
     clean = gen.predict_theta(u0, cases.case2_true_theta())[:, :6, :]
     gen.close()
     data = cases.add_noise(clean, 0.05, rng)
-    yscale = cases.max_min(data, lb=1e-6)
+    yscale = cases.max_min(data, lb=LB_CASE2)
 
     node = NeuralODE(ODEProblem(PRESET_CASE2, ts))
     node.set_ensemble(u0, data, yscale)

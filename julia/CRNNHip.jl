@@ -343,12 +343,13 @@ function svgd_update(p::Matrix{Float64}, lnpgrad::Matrix{Float64}, stepsize::Flo
     return permutedims(pn), hout[]
 end
 
-"""Device-resident SVGD loop (crnn_cathode.jl:36-50): `set_particles!(c, p)` uploads the normalised particles p [N, 17];
-`svgd_step!(c, i_exp, normalizer2, stepsize)` runs dlnprob for heating rate i_exp and the SVGD move on the device
-(returns the mean loss and the bandwidth); `particles(c)` copies them out."""
 """Adjoint tape layout: 1 = every step in full (default, fastest), 4 / 8 = checkpointed (2.5x / 3.3x less tape traffic and memory)."""
 set_tape_every!(c::Cathode, every::Integer) = ccall((:crnn_cathode_set_tape_every, LIB), Int32, (Ptr{Cvoid}, Int32), c.ctx, Int32(every)) == 0 ||
     error(unsafe_string(ccall((:crnn_cathode_last_error, LIB), Cstring, (Ptr{Cvoid},), c.ctx)))
+
+"""Device-resident SVGD loop (crnn_cathode.jl:36-50): `set_particles!(c, p)` uploads the normalised particles p [N, 17];
+`svgd_step!(c, i_exp, normalizer2, stepsize)` runs dlnprob for heating rate i_exp and the SVGD move on the device
+(returns the mean loss and the bandwidth); `particles(c, N)` copies them out."""
 function set_particles!(c::Cathode, p::Matrix{Float64})
     pr = permutedims(p)                                   # row-major [N][17] for the ABI
     rc = ccall((:crnn_cathode_set_particles, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64), c.ctx, pr, c.p_scales, size(p, 1))

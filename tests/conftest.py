@@ -3,6 +3,8 @@ import os
 import sys
 
 import numpy as np
+
+LB_CASE1, LB_CASE2 = float(np.float32(1e-5)), float(np.float32(1e-6))   # `lb = 1.f-5` / `lb = 1.f-6`: Float32 literals (case1/case1.jl:34, case2/case2.jl:34)
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -81,7 +83,7 @@ def rober_setup(fx):
 
 def oracle_problem(orc, case, setup, atol=None, rtol=None, maxiters=None, **kw):
     if case == "case2":
-        return orc.make_problem(ns=6, nr=3, has_temp=1, lb=1e-6, ub=10.0, inv_R=INV_R,
+        return orc.make_problem(ns=6, nr=3, has_temp=1, lb=LB_CASE2, ub=10.0, inv_R=INV_R,
                                 atol=1e-6 if atol is None else atol, rtol=1e-3 if rtol is None else rtol,
                                 yscale=setup["yscale"], clamp_pred=1, maxiters=maxiters or 100000, **kw)
     if case == "rober":

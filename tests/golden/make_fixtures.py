@@ -108,7 +108,10 @@ def p2vec_case1(p, ns=5, nr=4):
 INV_R = float(np.float32(-1.0) / np.float32(1.98720425864083e-3))   # case2.jl:113: R is a Float32 literal
 
 
-def crnn_case2(u, w_in, w_b, w_out, lb=1e-6, ub=10.0):
+LB_CASE2 = float(np.float32(1e-6))   # `lb = 1.f-6` (case2/case2.jl:34): a Float32 literal, promoted where it meets Float64s
+
+
+def crnn_case2(u, w_in, w_b, w_out, lb=LB_CASE2, ub=10.0):
     logX = np.log(cclamp(u[:-1], lb, ub))
     w_in_x = w_in.T @ np.concatenate([logX, [INV_R / u[-1]]])
     return np.concatenate([w_out @ np.exp(w_in_x + w_b), [0.0]])
@@ -240,7 +243,7 @@ def main():
         y = radau(lambda y: true_case2(y, k), u0[i], tsteps)[:ns]
         clean[i] = y
         data[i] = y + rng.standard_normal(y.shape) * y * 0.05
-    yscale = np.max(np.max(data, axis=2) - np.min(data, axis=2) + 1e-6, axis=0)
+    yscale = np.max(np.max(data, axis=2) - np.min(data, axis=2) + LB_CASE2, axis=0)
     pred = np.zeros((nic, ns + 1, 50))
     for i in range(nic):
         pred[i] = radau(lambda y: crnn_case2(y, w_in, w_b, w_out), u0[i], tsteps)

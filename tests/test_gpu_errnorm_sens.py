@@ -5,6 +5,8 @@ HIP kernel (ros23_sens_kernel.hpp) vs the oracle's errnorm_sens = 1 on the same 
 rejected step counts, gradients to 1e-7 of max |grad|.  [UNVERIFIED-DEP]: the norm itself is a restatement of
 DiffEqBase.ODE_DEFAULT_NORM on Dual arrays (oracle header)."""
 import numpy as np
+
+LB_CASE1, LB_CASE2 = float(np.float32(1e-5)), float(np.float32(1e-6))   # `lb = 1.f-5` / `lb = 1.f-6`: Float32 literals (case1/case1.jl:34, case2/case2.jl:34)
 import pytest
 
 from conftest import oracle_problem
@@ -32,11 +34,11 @@ def _setup(case, case2_setup, rober_setup, fx):
     gen = NeuralODE(ODEProblem(PRESET_CASE1, ts, atol=1e-12, rtol=1e-10))
     data = cases.add_noise(gen.predict_theta(u0, cases.case1_true_theta()), 0.05, rng)
     gen.close()
-    ys = cases.max_min(data, lb=1e-5)
+    ys = cases.max_min(data, lb=LB_CASE1)
     s = dict(u0=u0, tsteps=ts, data=data, yscale=ys, p_ckpt=np.array(fx["case1"]["p"]))
     sv = 1 if case == "case1-tsit5" else 0           # case1's own algorithm is Tsit5 (case1.jl:28)
     mk = lambda **kw: NeuralODE(ODEProblem(PRESET_CASE1, ts, solver=SOLVER_TSIT5 if sv else SOLVER_ROSENBROCK23, **kw))
-    mkpb = lambda orc, **kw: orc.make_problem(ns=5, nr=4, lb=1e-5, ub=10.0, atol=1e-5, rtol=1e-2, yscale=ys, clamp_pred=1,
+    mkpb = lambda orc, **kw: orc.make_problem(ns=5, nr=4, lb=LB_CASE1, ub=10.0, atol=1e-5, rtol=1e-2, yscale=ys, clamp_pred=1,
                                               maxiters=10000, solver=sv, **kw)
     return s, mk, (1, 5, 4), mkpb
 

@@ -6,6 +6,8 @@ invariance."""
 import ctypes as C
 
 import numpy as np
+
+LB_CASE1, LB_CASE2 = float(np.float32(1e-5)), float(np.float32(1e-6))   # `lb = 1.f-5` / `lb = 1.f-6`: Float32 literals (case1/case1.jl:34, case2/case2.jl:34)
 import pytest
 
 from conftest import INV_R, oracle_problem
@@ -24,7 +26,7 @@ def _case2_ensemble(B, seed=1234):
     assert np.all(gen.last_retcode == 0)
     gen.close()
     data = cases.add_noise(clean, 0.05, rng)
-    return ts, u0, data, cases.max_min(data, lb=1e-6)
+    return ts, u0, data, cases.max_min(data, lb=LB_CASE2)
 
 
 @pytest.fixture(scope="module")
@@ -228,7 +230,7 @@ def test_observation_mask_and_mse(orc, case2_setup):
     node.set_ensemble(s["u0"], data, ys, i_obs=i_obs)
     loss, grad = node.loss_and_grad(p)
     th, dth = orc.p2vec(2, 6, 3, p)
-    pb = orc.make_problem(ns=6, nr=3, has_temp=1, lb=1e-6, ub=10.0, inv_R=INV_R, atol=1e-6, rtol=1e-3, yscale=ys,
+    pb = orc.make_problem(ns=6, nr=3, has_temp=1, lb=LB_CASE2, ub=10.0, inv_R=INV_R, atol=1e-6, rtol=1e-3, yscale=ys,
                           i_obs=i_obs, clamp_pred=1)
     rs = [orc.solve_one(pb, th, s["u0"][i], s["tsteps"], data[i], dtheta=dth) for i in range(8)]
     assert abs(loss - np.mean([r["loss"] for r in rs])) < 1e-9 * loss
@@ -240,7 +242,7 @@ def test_observation_mask_and_mse(orc, case2_setup):
     node = NeuralODE(ODEProblem(PRESET_CASE2, s["tsteps"], loss_kind=LOSS_MSE))
     node.set_ensemble(s["u0"], s["data"], s["yscale"])
     loss, grad = node.loss_and_grad(p)
-    pb = orc.make_problem(ns=6, nr=3, has_temp=1, lb=1e-6, ub=10.0, inv_R=INV_R, atol=1e-6, rtol=1e-3,
+    pb = orc.make_problem(ns=6, nr=3, has_temp=1, lb=LB_CASE2, ub=10.0, inv_R=INV_R, atol=1e-6, rtol=1e-3,
                           yscale=s["yscale"], clamp_pred=1, loss_kind=1)
     rs = [orc.solve_one(pb, th, s["u0"][i], s["tsteps"], s["data"][i], dtheta=dth) for i in range(8)]
     assert abs(loss - np.mean([r["loss"] for r in rs])) < 1e-9 * loss

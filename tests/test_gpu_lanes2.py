@@ -5,6 +5,8 @@ Tolerances (floating point, written at each assert): against the oracle the bars
 relative, gradients 1e-7 of max |grad|, identical return codes and step counts; against the one-lane kernel 1e-10 / 1e-9
 (both sum the same terms, in different orders)."""
 import numpy as np
+
+LB_CASE1, LB_CASE2 = float(np.float32(1e-5)), float(np.float32(1e-6))   # `lb = 1.f-5` / `lb = 1.f-6`: Float32 literals (case1/case1.jl:34, case2/case2.jl:34)
 import pytest
 
 from conftest import oracle_problem
@@ -68,8 +70,8 @@ def test_case1_shape_odd_species_count(orc, fx):
     gen = NeuralODE(ODEProblem(PRESET_CASE1, ts, atol=1e-12, rtol=1e-10, solver=0))
     data = cases.add_noise(gen.predict_theta(u0, cases.case1_true_theta()), 0.05, rng)
     gen.close()
-    ys = cases.max_min(data, lb=1e-5)
-    pb = orc.make_problem(ns=5, nr=4, lb=1e-5, ub=10.0, atol=1e-5, rtol=1e-2, yscale=ys, clamp_pred=1, maxiters=10000, solver=0)
+    ys = cases.max_min(data, lb=LB_CASE1)
+    pb = orc.make_problem(ns=5, nr=4, lb=LB_CASE1, ub=10.0, atol=1e-5, rtol=1e-2, yscale=ys, clamp_pred=1, maxiters=10000, solver=0)
     th, dth = orc.p2vec(1, 5, 4, p)
     ref = orc.solve_batch(pb, th, np.ascontiguousarray(u0.T), ts, np.ascontiguousarray(data.transpose(2, 1, 0)), dtheta=dth)
     out = {}
@@ -95,7 +97,7 @@ def test_ragged_ensemble_queue_orders_and_subranges(case2_setup):
     B = 1061
     u0 = cases.case2_u0(B, rng)
     data = np.abs(rng.standard_normal((B, 6, len(ts)))) * 0.5
-    s = dict(tsteps=ts, u0=u0, data=data, yscale=cases.max_min(data, lb=1e-6))
+    s = dict(tsteps=ts, u0=u0, data=data, yscale=cases.max_min(data, lb=LB_CASE2))
     p = case2_setup["p_ckpt"]
     n1, n2 = _node(s, 1), _node(s, 2)
     l1, g1, r1, _, a1, _ = _per_traj(n1, p)

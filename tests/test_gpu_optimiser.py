@@ -9,6 +9,8 @@ against the ORACLE's optimiser (oracle/crnn_oracle.c: orc_opt_update) and agains
   * the optimiser state (crnn_get_opt_state / crnn_set_opt_state) against the oracle's state vector
 """
 import numpy as np
+
+LB_CASE1, LB_CASE2 = float(np.float32(1e-5)), float(np.float32(1e-6))   # `lb = 1.f-5` / `lb = 1.f-6`: Float32 literals (case1/case1.jl:34, case2/case2.jl:34)
 import pytest
 
 from conftest import WD6, WD8, oracle_problem
@@ -107,11 +109,11 @@ def test_training_loop_case1_tsit5_matches_oracle_chain(orc, fx):
     gen = NeuralODE(ODEProblem(PRESET_CASE1, ts, atol=1e-12, rtol=1e-10))
     data = cases.add_noise(gen.predict_theta(u0, cases.case1_true_theta()), 0.05, rng)
     gen.close()
-    ys = cases.max_min(data, lb=1e-5)
+    ys = cases.max_min(data, lb=LB_CASE1)
     node = NeuralODE(ODEProblem(PRESET_CASE1, ts))
     node.set_ensemble(u0, data, ys)
     node.train_init(Optimiser(24, PRESET_CASE1), p0)
-    pb = orc.make_problem(ns=5, nr=4, lb=1e-5, ub=10.0, atol=1e-5, rtol=1e-2, yscale=ys, clamp_pred=1, maxiters=10000, solver=1)
+    pb = orc.make_problem(ns=5, nr=4, lb=LB_CASE1, ub=10.0, atol=1e-5, rtol=1e-2, yscale=ys, clamp_pred=1, maxiters=10000, solver=1)
     oopt = orc.Optimiser(24, eta=0.001, wd=WD8)
     po = p0.copy()
     for it in range(10):

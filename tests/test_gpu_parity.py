@@ -2,6 +2,8 @@
 against the CPU oracle on identical inputs, and against the committed golden
 vectors.  Floating point: tolerances are written at each assert."""
 import numpy as np
+
+LB_CASE1, LB_CASE2 = float(np.float32(1e-5)), float(np.float32(1e-6))   # `lb = 1.f-5` / `lb = 1.f-6`: Float32 literals (case1/case1.jl:34, case2/case2.jl:34)
 import pytest
 
 from conftest import oracle_problem
@@ -256,7 +258,7 @@ def test_case1_rosenbrock23_adjoint_woodbury_4x4(orc, fx):
     gen = NeuralODE(ODEProblem(PRESET_CASE1, ts, atol=1e-12, rtol=1e-10))
     data = cases.add_noise(gen.predict_theta(u0, cases.case1_true_theta()), 0.05, rng)
     gen.close()
-    ys = cases.max_min(data, lb=1e-5)
+    ys = cases.max_min(data, lb=LB_CASE1)
     res = {}
     for mode in (1, 2):
         node = NeuralODE(ODEProblem(PRESET_CASE1, ts, solver=SOLVER_ROSENBROCK23, grad_mode=mode, atol=1e-7, rtol=1e-5))
@@ -264,7 +266,7 @@ def test_case1_rosenbrock23_adjoint_woodbury_4x4(orc, fx):
         res[mode] = node.loss_and_grad(p) + (node.last_stats["n_accept"],)
         node.close()
     th, dth = orc.p2vec(1, 5, 4, p)
-    pb = orc.make_problem(ns=5, nr=4, lb=1e-5, ub=10.0, atol=1e-7, rtol=1e-5, yscale=ys, clamp_pred=1, maxiters=10000, solver=0)
+    pb = orc.make_problem(ns=5, nr=4, lb=LB_CASE1, ub=10.0, atol=1e-7, rtol=1e-5, yscale=ys, clamp_pred=1, maxiters=10000, solver=0)
     B = u0.shape[0]
     ref = orc.solve_batch(pb, th, np.ascontiguousarray(u0.T), ts, np.ascontiguousarray(data.transpose(2, 1, 0)), dtheta=dth)
     gref = ref["grad"] / B
@@ -382,11 +384,11 @@ def test_tsit5_case1_reference_configuration(orc, fx):
     clean = gen.predict_theta(u0, cases.case1_true_theta())
     gen.close()
     data = cases.add_noise(clean, 0.05, rng)
-    ys = cases.max_min(data, lb=1e-5)
+    ys = cases.max_min(data, lb=LB_CASE1)
     node = NeuralODE(ODEProblem(PRESET_CASE1, ts))          # preset = the reference's Tsit5 configuration
     node.set_ensemble(u0, data, ys)
     th, dth = orc.p2vec(1, 5, 4, p)
-    pb = orc.make_problem(ns=5, nr=4, lb=1e-5, ub=10.0, atol=1e-5, rtol=1e-2, yscale=ys, clamp_pred=1, maxiters=10000, solver=1)
+    pb = orc.make_problem(ns=5, nr=4, lb=LB_CASE1, ub=10.0, atol=1e-5, rtol=1e-2, yscale=ys, clamp_pred=1, maxiters=10000, solver=1)
     B = u0.shape[0]
     ref = orc.solve_batch(pb, th, np.ascontiguousarray(u0.T), ts, np.ascontiguousarray(data.transpose(2, 1, 0)), dtheta=dth,
                           want_pred=True)
@@ -516,11 +518,11 @@ def test_autotsit5_case1_matches_oracle(orc, fx):
     clean = gen.predict_theta(u0, cases.case1_true_theta())
     gen.close()
     data = cases.add_noise(clean, 0.05, rng)
-    ys = cases.max_min(data, lb=1e-5)
+    ys = cases.max_min(data, lb=LB_CASE1)
     node = NeuralODE(ODEProblem(PRESET_CASE1, ts, solver=SOLVER_AUTOTSIT5))
     node.set_ensemble(u0, data, ys)
     th, dth = orc.p2vec(1, 5, 4, p)
-    pb = orc.make_problem(ns=5, nr=4, lb=1e-5, ub=10.0, atol=1e-5, rtol=1e-2, yscale=ys, clamp_pred=1, maxiters=10000, solver=2)
+    pb = orc.make_problem(ns=5, nr=4, lb=LB_CASE1, ub=10.0, atol=1e-5, rtol=1e-2, yscale=ys, clamp_pred=1, maxiters=10000, solver=2)
     B = u0.shape[0]
     ref = orc.solve_batch(pb, th, np.ascontiguousarray(u0.T), ts, np.ascontiguousarray(data.transpose(2, 1, 0)), dtheta=dth,
                           want_pred=True)

@@ -10,6 +10,8 @@ Checked here, on top of the oracle comparisons of the other test files (which ca
   * ragged ensembles, sub-ranges and a truncated horizon.
 Floating point throughout; tolerances at each assert."""
 import numpy as np
+
+LB_CASE1, LB_CASE2 = float(np.float32(1e-5)), float(np.float32(1e-6))   # `lb = 1.f-5` / `lb = 1.f-6`: Float32 literals (case1/case1.jl:34, case2/case2.jl:34)
 import pytest
 
 from conftest import oracle_problem
@@ -73,13 +75,13 @@ def test_ragged_large_ensemble_primal_launch(case2_setup):
     u0 = cases.case2_u0(B, rng)
     data = np.abs(rng.standard_normal((B, 6, len(s["tsteps"])))) * 0.5
     node = NeuralODE(ODEProblem(PRESET_CASE2, s["tsteps"], grad_mode=2))
-    node.set_ensemble(u0, data, cases.max_min(data, lb=1e-6))
+    node.set_ensemble(u0, data, cases.max_min(data, lb=LB_CASE2))
     lg, lp = _both(node, s["p_ckpt"])
     assert np.max(np.abs(lg - lp) / lg) < 1e-13
     l2 = node.losses(s["p_ckpt"])                   # second primal launch: sorted queue, same per-trajectory results
     assert np.array_equal(l2, lp)
     pred = node.predict_n_ode(s["p_ckpt"])
     fwd = NeuralODE(ODEProblem(PRESET_CASE2, s["tsteps"], grad_mode=1, errnorm_sens=2))   # (a context whose primal calls stay on ros23_kernel)
-    fwd.set_ensemble(u0[:2048], data[:2048], cases.max_min(data, lb=1e-6))
+    fwd.set_ensemble(u0[:2048], data[:2048], cases.max_min(data, lb=LB_CASE2))
     assert np.array_equal(fwd.predict_n_ode(s["p_ckpt"]), pred[:2048])
     node.close(); fwd.close()

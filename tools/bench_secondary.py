@@ -11,6 +11,8 @@ import time
 
 import numpy as np
 
+LB_CASE1, LB_CASE2 = float(np.float32(1e-5)), float(np.float32(1e-6))   # `lb = 1.f-5` / `lb = 1.f-6`: Float32 literals (case1/case1.jl:34, case2/case2.jl:34)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HBM_PEAK_GBS = 8000.0
 # 8 * [n (u0) + n_obs * D (data) + loss + (retcode, n_saved)] bytes per trajectory (+ 8 P for per-trajectory gradients)
@@ -87,7 +89,7 @@ def case2_ensemble(B, seed, device=0):
     clean = gen.predict_theta(u0, cases.case2_true_theta())[:, :6, :]
     gen.close()
     data = cases.add_noise(clean, 0.05, rng)
-    return u0, data, cases.max_min(data, lb=1e-6)
+    return u0, data, cases.max_min(data, lb=LB_CASE2)
 
 
 def robertson(B=65536, reps=6, device=0):

@@ -82,7 +82,7 @@ def _problems():
         ts = cases.case2_tsteps()
         u0 = cases.case2_u0(B, rng)
         data = np.abs(rng.standard_normal((B, 6, len(ts)))) * 0.5
-        return ts, u0, data, cases.max_min(data, lb=1e-6), np.array(fx["case2_ckpt"]["p"])
+        return ts, u0, data, cases.max_min(data, lb=cases.LB_CASE2), np.array(fx["case2_ckpt"]["p"])
 
     def rober(B):
         ts = cases.rober_tsteps()
@@ -95,7 +95,7 @@ def _problems():
         ts = cases.case1_tsteps()
         u0 = cases.case1_u0(B, rng)
         data = np.abs(rng.standard_normal((B, 5, len(ts)))) * 0.5
-        return ts, u0, data, cases.max_min(data, lb=1e-5), np.array(fx["case1"]["p"])
+        return ts, u0, data, cases.max_min(data, lb=cases.LB_CASE1), np.array(fx["case1"]["p"])
 
     B = 1024 + 37    # ragged: the last wavefront is partly empty
     c2, rb, c1 = case2(B), rober(B), case1(B)

@@ -42,11 +42,11 @@ for it in range(args.start, args.n):
         kind = rng.random()
         p = (cases.case2_init_p(rng) if kind < 0.4 else np.array(fx["case2_ckpt"]["p"]) * (1 + 0.1 * rng.standard_normal(25)))
         data = np.abs(rng.standard_normal((B, 6, len(ts)))) * rng.uniform(0.1, 2.0)
-        ys = cases.max_min(data, lb=1e-6)
+        ys = cases.max_min(data, lb=cases.LB_CASE2)
         atol = rtol * 1e-3
         maxiters = int(rng.choice([100000, 100000, 60]))
         node = NeuralODE(ODEProblem(PRESET_CASE2, ts, atol=atol, rtol=rtol, maxiters=maxiters, solver=solver))
-        pb = orc.make_problem(ns=6, nr=3, has_temp=1, lb=1e-6, ub=10.0, inv_R=INV_R, atol=atol, rtol=rtol, yscale=ys,
+        pb = orc.make_problem(ns=6, nr=3, has_temp=1, lb=cases.LB_CASE2, ub=10.0, inv_R=INV_R, atol=atol, rtol=rtol, yscale=ys,
                               clamp_pred=1, maxiters=maxiters, solver=solver)
         pk, ns, nr = 2, 6, 3
     else:

@@ -36,7 +36,7 @@ if args.case == "case2":
     gen.close()
     data = cases.add_noise(clean, 0.05, rng)
     node = NeuralODE(ODEProblem(PRESET_CASE2, ts, grad_mode=gm, solver=sv, errnorm_sens=args.errnorm_sens))
-    node.set_ensemble(u0, data, cases.max_min(data, lb=1e-6))
+    node.set_ensemble(u0, data, cases.max_min(data, lb=cases.LB_CASE2))
     p = np.array(fx["case2_ckpt"]["p"])
 elif args.case == "case1":
     ts = cases.case1_tsteps()
@@ -46,7 +46,7 @@ elif args.case == "case1":
     gen.close()
     data = cases.add_noise(clean, 0.05, rng)
     node = NeuralODE(ODEProblem(PRESET_CASE1, ts, grad_mode=gm, solver=sv, errnorm_sens=args.errnorm_sens))
-    node.set_ensemble(u0, data, cases.max_min(data, lb=1e-5))
+    node.set_ensemble(u0, data, cases.max_min(data, lb=cases.LB_CASE1))
     p = np.array(fx["case1"]["p"])
 elif args.case == "hychem":
     from crnn_amd import PRESET_HYCHEM, hychem as hy

@@ -12,7 +12,7 @@ B=16384
 u0=cases.case2_u0(B,rng); ts=cases.case2_tsteps()
 fx=json.load(open('tests/golden/fixtures.json')); p=np.array(fx['case2_ckpt']['p'])
 th,dth=orc.p2vec(2,6,3,p)
-pb=orc.make_problem(ns=6,nr=3,has_temp=1,lb=1e-6,ub=10.0,inv_R=cases.INV_R,atol=1e-6,rtol=1e-3,clamp_pred=1)
+pb=orc.make_problem(ns=6,nr=3,has_temp=1,lb=cases.LB_CASE2,ub=10.0,inv_R=cases.INV_R,atol=1e-6,rtol=1e-3,clamp_pred=1)
 data=np.zeros((50,6,B))
 for nt in (1,8,16,32,64,128,256):
     t0=time.time(); r=orc.solve_batch(pb,th,np.ascontiguousarray(u0.T),ts,data,dtheta=dth,nthreads=nt); dt=time.time()-t0

@@ -28,7 +28,7 @@ gen = NeuralODE(ODEProblem(PRESET_CASE2, ts, atol=1e-10, rtol=1e-8))
 clean = gen.predict_theta(u0, cases.case2_true_theta())[:, :6, :]
 gen.close()
 data = cases.add_noise(clean, 0.05, rng)
-ys = cases.max_min(data, lb=1e-6)
+ys = cases.max_min(data, lb=cases.LB_CASE2)
 p0 = np.array(fx["case2_ckpt"]["p"]) if args.theta0 == "ckpt" else cases.case2_init_p(np.random.Generator(np.random.PCG64(7)))
 
 
