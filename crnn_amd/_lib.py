@@ -22,6 +22,7 @@ PRESET_CASE1, PRESET_CASE2, PRESET_ROBER, PRESET_HYCHEM = 1, 2, 3, 4
 SOLVER_ROSENBROCK23, SOLVER_TSIT5, SOLVER_AUTOTSIT5 = 0, 1, 2
 GRAD_AUTO, GRAD_FORWARD, GRAD_ADJOINT = 0, 1, 2
 QUEUE_AUTO, QUEUE_INDEX = 0, 1
+CATH_SOLVER_ROSENBROCK23, CATH_SOLVER_AUTOTSIT5_TRBDF2, CATH_SOLVER_AUTOTSIT5_ROS23 = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CRNN_HIP_LIB: load another build of the same ABI (kernel experiments, tools/); the default is the in-tree library
@@ -129,6 +130,7 @@ SYMBOLS = {
     "crnn_cathode_comm_destroy": (C.c_int32, [_CTX]),
     "crnn_cathode_allgather": (C.c_int32, [_CTX, _DP, C.c_int64, C.c_int32, C.c_int64, _DP]),
     "crnn_cathode_set_tape_every": (C.c_int32, [_CTX, C.c_int32]),
+    "crnn_cathode_set_solver": (C.c_int32, [_CTX, C.c_int32]),
     "crnn_cathode_set_particles": (C.c_int32, [_CTX, _DP, _DP, C.c_int64]),
     "crnn_cathode_svgd_step": (C.c_int32, [_CTX, C.c_int32, _DP, C.c_double, C.c_double, _DP, _DP, _DP]),
     "crnn_cathode_get_particles": (C.c_int32, [_CTX, _DP]),

@@ -79,7 +79,7 @@ class CathodeUQ:
     """exp_data: list of arrays [D_s, 1 + n_replicas] (col 0 = time in s, dataset.jl:19-23), heating_rates in K/min."""
 
     def __init__(self, exp_data, heating_rates, p_scales, *, atol=None, rtol=None, maxiters=None, lb_clamp=None, device=0,
-                 normalizer=None, grad_mode=None, tape_every=None):
+                 normalizer=None, grad_mode=None, tape_every=None, solver=None):
         self.cfg = CathodeConfig()
         check(lib.crnn_cathode_config_default(C.byref(self.cfg)))
         self.cfg.device = device
@@ -90,6 +90,8 @@ class CathodeUQ:
         check(lib.crnn_cathode_create(C.byref(self.cfg), C.byref(self.h)))
         if tape_every is not None:     # adjoint tape: 1 = every step in full (default), 4 / 8 = checkpointed (include/crnn_hip.h)
             self._check(lib.crnn_cathode_set_tape_every(self.h, int(tape_every)))
+        if solver is not None:         # stepper of the primal calls: "autotsit5_trbdf2" = the reference's `alg` (network.jl:195)
+            self.set_solver(solver)
         self.p_scales = np.asarray(p_scales, float)[:17].copy()
         self.beta = np.ascontiguousarray(heating_rates, np.float64)
         self.exp_data = [np.asarray(e, float) for e in exp_data]
@@ -113,6 +115,15 @@ class CathodeUQ:
     def _check(self, rc):
         if rc != 0:
             raise L.CrnnError(lib.crnn_cathode_last_error(self.h).decode())
+
+    SOLVERS = {"rosenbrock23": L.CATH_SOLVER_ROSENBROCK23, "autotsit5_trbdf2": L.CATH_SOLVER_AUTOTSIT5_TRBDF2,
+               "autotsit5_rosenbrock23": L.CATH_SOLVER_AUTOTSIT5_ROS23}
+
+    def set_solver(self, solver):
+        """Stepper of the PRIMAL calls (pred_n_ode, loss_neuralode, solve(want_grad=False)): "rosenbrock23" (default),
+        "autotsit5_trbdf2" -- `alg = AutoTsit5(TRBDF2(autodiff = true))`, network.jl:195 -- or "autotsit5_rosenbrock23".
+        Gradient calls (dlnprob) always run the Rosenbrock23 adjoint (include/crnn_hip.h: crnn_cathode_set_solver)."""
+        self._check(lib.crnn_cathode_set_solver(self.h, self.SOLVERS[solver] if isinstance(solver, str) else int(solver)))
 
     def solve(self, p, want_grad=True, want_hrr=False):
         """All particles x all heating rates in one launch.  p [N, 17] normalised particles.

@@ -1,0 +1,499 @@
+// crnn_amd/csrc/cathode_auto_kernel.hpp -- the Bayesian cathode CRNN through the reference's COMPOSITE stepper (gfx950).
+//
+// Reference: Cathode_NCM333_UQ/src_333/network.jl:195  alg = AutoTsit5(TRBDF2(autodiff = true)), used by pred_n_ode (:205-212).
+// crnn_cathode_set_solver(ctx, CRNN_CATH_SOLVER_AUTOTSIT5_TRBDF2 | _AUTOTSIT5_ROS23) selects this kernel for PRIMAL launches
+// (pred_n_ode / HRR_getter / loss_neuralode, the loss-only half of dlnprob: loss and heat-release rates, no gradient):
+//   * Tsit5 with the stage times t + c_s dt (the system is non-autonomous: T = T0 + beta/60 t), free 4th-order interpolant;
+//   * OrdinaryDiffEq's AutoSwitch rule as auto_adj_kernel.hpp restates it (eigen estimate of every attempt, more than 10 stiff /
+//     3 non-stiff verdicts in a row, dt * 2 and dt / 2 at the switches, PI exponents of the running algorithm, steady band [1, 1]);
+//   * the stiff algorithm: STIFF_TRBDF2 = true -> TRBDF2 with OrdinaryDiffEq's Newton machinery (the reference's choice; restated
+//     in oracle/crnn_oracle.c: cath_trbdf2_nlsolve, where every branch is described and marked [UNVERIFIED-DEP]); false ->
+//     Rosenbrock23 (the stepper the gradient path uses), the composite round 3 measured.
+// On BASELINE config 5's ensemble 97 % of the trajectories never leave Tsit5 and 0.2-0.4 % of all accepted steps are stiff ones
+// (tools/cathode_autoswitch_census.py): 114 accepted steps per trajectory against Rosenbrock23's 338.
+//
+// Why primal only.  A discrete adjoint of these steps was built and measured (round 3, commit 157d3a6) and is not shipped:
+// through the explicit steps the linearisation is unstable -- late in a run the depleted species sit near the absolute tolerance
+// with Tsit5 at its stability limit for their (invisible) modes; the error controller holds the primal there, nothing holds the
+// tangents or adjoints (10 % of the gradients off by 0.03 .. 1.5 of their largest entry at the reference tolerances).  The
+// reference escapes it because ForwardDiff's partials sit inside its error norm.  Gradient calls stay on the L-stable
+// Rosenbrock23 adjoint whatever the solver setting.  And even the primal is only reproducible to solver tolerance across
+// implementations: round-off in the invisible modes is amplified until the controller sees it, so two correct implementations of
+// this composite (this kernel and the oracle) take a slightly different number of steps on some trajectories; their losses agree
+// to ~1e-8 and their heat-release curves to a small fraction of rtol -- the bar the parity tests state (tests/test_cathode.py).
+//
+// The J of TRBDF2's Newton iteration is lower bidiagonal (J = S diag(a), a_j = r_j n_j g_j): W = J - I/(gamma dt) is solved by
+// forward substitution; the iteration's cache (J, the dt W was built for, the last status) lives in registers across steps and
+// across algorithm switches, as the package's cache does.
+// Work is handed out as in cathode_adj_kernel: 64 particles of one heating rate per wavefront.
+#pragma once
+#include "auto_adj_kernel.hpp"
+#include "cathode_kernel.hpp"
+
+namespace crnn {
+
+template <int BLOCK, bool STIFF_TRBDF2>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void cathode_auto_kernel(const CathodeParams prm, const CathAdjParams adj) {
+    __shared__ double ts_s[kCathMaxSets * kCathMaxD];
+    __shared__ double db_s[kCathMaxSets * kCathMaxD];
+    __shared__ double d2_s[kCathMaxSets * kCathMaxD];
+    const int tid = threadIdx.x;
+    const bool staged = prm.n_sets <= kCathMaxSets;
+    if (staged) {
+        for (int idx = tid; idx < prm.n_sets * prm.Dmax; idx += BLOCK) {
+            const int s = idx / prm.Dmax, i = idx - s * prm.Dmax;
+            ts_s[s * kCathMaxD + i] = prm.ts[idx];
+            db_s[s * kCathMaxD + i] = prm.dbar[idx];
+            d2_s[s * kCathMaxD + i] = prm.d2bar[idx];
+        }
+    }
+    __syncthreads();
+    constexpr double d_ = 0.29289321881345248, c32 = 7.4142135623730950, inv12d = 2.4142135623730950;
+    constexpr double Rg = -1.0 / 8.314;
+    constexpr double b1_ts = 7.0 / 50.0, b2_ts = 2.0 / 25.0, b1_rb = 7.0 / 20.0, b2_rb = 2.0 / 10.0;   // TRBDF2: order 2, the same exponents
+    // TRBDF2Tableau
+    constexpr double s2_ = 1.4142135623730951;
+    constexpr double tb_g = 2.0 - s2_, tb_d = 1.0 - s2_ / 2.0, tb_w = s2_ / 4.0;
+    constexpr double tb_bt1 = (1.0 - s2_) / 3.0, tb_bt2 = 1.0 / 3.0, tb_bt3 = (s2_ - 2.0) / 3.0, tb_a1 = -s2_ / 2.0, tb_a2 = 1.0 + s2_ / 2.0;
+    constexpr int NL_CONV = 1, NL_DIV = -2, NL_TRYAGAIN = -4;
+    const double lqinit = flog(prm.qoldinit);
+    const int lane = tid & 63;
+    const int64_t per_set = (adj.n_part + 63) / 64;              // wave batches per heating rate
+    const int64_t n_batches = per_set * prm.n_sets;
+
+    while (true) {
+        unsigned long long bq = 0;
+        if (lane == 0) bq = atomicAdd(prm.queue, 1ULL);
+        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)bq);
+        const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(bq >> 32));
+        const int64_t batch = (int64_t)(((unsigned long long)bhi << 32) | blo);
+        if (batch >= n_batches) break;
+        const int set = (int)(batch / per_set);
+        const int64_t part = (batch - (int64_t)set * per_set) * 64 + lane;
+        const bool valid = part < adj.n_part;
+        const int64_t traj = (valid ? part : 0) * prm.n_sets + set;
+
+        double th[kCathNP];
+#pragma unroll
+        for (int k = 0; k < kCathNP; ++k) th[k] = prm.theta[(size_t)(valid ? part : 0) * kCathNP + k];
+        const int D = prm.D[set];
+        const double *tsv, *dbv, *d2v;
+        if (staged) { tsv = ts_s + set * kCathMaxD; dbv = db_s + set * kCathMaxD; d2v = d2_s + set * kCathMaxD; }
+        else { tsv = prm.ts + (size_t)set * prm.Dmax; dbv = prm.dbar + (size_t)set * prm.Dmax; d2v = prm.d2bar + (size_t)set * prm.Dmax; }
+        const double Tdot = prm.beta[set] * (1.0 / 60.0);
+        const double t0 = tsv[0], tend = tsv[D - 1];
+
+        auto point_at = [&](const double (&uu)[3], double tt, CathPoint &P) { cath_point(uu, fma(Tdot, tt, prm.T0), th, prm.lb, P); };
+        auto wfac = [&](const CathPoint &P, double gam, double (&a)[3], double (&iw)[3]) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { a[j] = P.r[j] * th[12 + j] * P.g[j]; iw[j] = frcp(fma(gam, a[j], 1.0)); }
+        };
+        auto ftime = [&](const CathPoint &P, double (&sig)[3], double (&ft)[3]) {
+            double rho[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { sig[j] = (th[6 + j] * P.it - th[3 + j] * 1e5 * Rg * P.it * P.it) * Tdot; rho[j] = P.r[j] * sig[j]; }
+            ft[0] = -rho[0]; ft[1] = fma(th[15], rho[0], -rho[1]); ft[2] = fma(th[16], rho[1], -rho[2]);
+        };
+        auto hrr_at = [&](const CathPoint &q) -> double { return fma(q.r[0], th[9], fma(q.r[1], th[10], q.r[2] * th[11])); };
+        // stage s (1..6) of a Tsit5 step from (un, tn, h): point and slope; the seventh stage sits at the step's end time t_end
+        auto ts5_stage_point = [&](int s, const double (&un)[3], double h, const double (&k)[7][3], double (&g)[3]) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                double a = 0.0;
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+                    if (j < s) a = fma(Ts5::a(s - 1, j), k[j][i], a);
+                g[i] = fma(h, a, un[i]);
+            }
+        };
+        auto ts5_stage_time = [&](int s, double tn, double h, double t_end) -> double {
+            return s == 6 ? t_end : s == 5 ? tn + h : fma(s == 1 ? Ts5::c2 : s == 2 ? Ts5::c3 : s == 3 ? Ts5::c4 : Ts5::c5, h, tn);
+        };
+
+        // ================================================================== forward sweep
+        double u[3] = {1.0, 0.0, 0.0}, f0[3];
+        CathPoint P0;
+        double t = t0, dt = 0.0, lqold = lqinit;
+        int iter = 0, jsave = 0, nacc = 0, nrej = 0;
+        int rc = valid ? -1 : 0;
+        int alg = 0, cnt = 0;          // 0 Tsit5, 1 the stiff algorithm; signed run length of the stiffness test
+        double eig = 0.0;
+        bool have_eig = false;
+        // TRBDF2's nonlinear-solver cache (NLNewtonCache): J = S diag(nl_a) formed at time nl_Jt, W = J - I / nl_Wgdt, last status
+        double nl_a[3] = {0.0, 0.0, 0.0}, nl_Jt = -INFINITY, nl_Wgdt = 0.0, ee_prev = 1.0;
+        int nl_status = NL_DIV;
+        bool nl_first = true;
+        point_at(u, t0, P0);
+        cath_f(P0, th, f0);
+        {   // Hairer initial step with the order of the starting algorithm (5)
+            double sk[3], d0 = 0.0, d1 = 0.0, d2 = 0.0, u1[3], f1[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                sk[i] = frcp(fma(fabs(u[i]), prm.rtol, prm.atol));
+                d0 = fma(u[i] * sk[i], u[i] * sk[i], d0);
+                d1 = fma(f0[i] * sk[i], f0[i] * sk[i], d1);
+            }
+            d0 = sqrt(d0 * (1.0 / 3.0)); d1 = sqrt(d1 * (1.0 / 3.0));
+            const double dtmax = tend - t0;
+            double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 / d1);
+            dt0 = fmin(dt0, dtmax);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) u1[i] = fma(dt0, f0[i], u[i]);
+            CathPoint q;
+            point_at(u1, t + dt0, q);
+            cath_f(q, th, f1);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { const double e = (f1[i] - f0[i]) * sk[i]; d2 = fma(e, e, d2); }
+            d2 = sqrt(d2 * (1.0 / 3.0)) / dt0;
+            const double dm = fmax(d1, d2);
+            const double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : exp(-0.2 * (4.605170185988091368 + flog(dm)));
+            dt = fmin(fmin(100.0 * dt0, dt1), dtmax);
+        }
+        if (valid && prm.hrr) prm.hrr[(size_t)traj * prm.Dmax + 0] = hrr_at(P0);
+        jsave = 1;    // saveat contains tspan[1]
+        double pf_loss = 0.0;   // the loss, accumulated at the save points as they are passed
+        auto save_fwd = [&](const double (&ui)[3], double tsj, int j) {
+            CathPoint q;
+            point_at(ui, tsj, q);
+            const double hv = hrr_at(q);
+            if (prm.hrr) prm.hrr[(size_t)traj * prm.Dmax + j] = hv;
+            const double db = dbv[j], e = hv - db;
+            pf_loss += fma(e, e, d2v[j] - db * db);
+        };
+
+        while (__builtin_amdgcn_ballot_w64(rc < 0) != 0) {
+            if (rc < 0) {
+                ++iter;
+                bool last = false;
+                if (jsave >= D) rc = 0;
+                else if (iter > prm.maxiters) rc = 1;
+                if (rc < 0 && have_eig) {   // choose_algorithm! at the loop header
+                    const bool stiff = fabs(eig * dt * (1.0 / AutoSw::stability_size)) > AutoSw::tol;
+                    cnt = stiff ? (cnt < 0 ? 1 : cnt + 1) : (cnt > 0 ? -1 : cnt - 1);
+                    if (alg == 0 && cnt > AutoSw::maxstiffstep) { dt *= AutoSw::dtfac; alg = 1; }
+                    else if (alg == 1 && cnt < -AutoSw::maxnonstiffstep) {
+                        dt *= 1.0 / AutoSw::dtfac; alg = 0;
+                        if constexpr (STIFF_TRBDF2) {   // initialize!(Tsit5 cache): fsalfirst = f(uprev, t) afresh (TRBDF2 left z / dt there)
+                            point_at(u, t, P0);
+                            cath_f(P0, th, f0);
+                        }
+                    }
+                }
+                if (t + dt * (1.0 + 1e-13) >= tend) { dt = tend - t; last = true; }
+                if (rc < 0 && (!(dt > 0.0) || t + dt == t)) rc = 2;
+                if (rc < 0) {
+                    const double tnew = last ? tend : t + dt;
+                    double unew[3], f2[3], es = 0.0;
+                    CathPoint P2;
+                    bool finite = true, accepted = false, ee_zero = false, stepfail = false;
+                    double q = 1.0, lEE = 0.0, lq11 = 0.0;
+                    auto controller = [&](double b1, double b2) -> bool {
+                        ee_zero = (es == 0.0);
+                        lEE = 0.5 * flog(ee_zero ? 1.0 : es);
+                        lq11 = b1 * lEE;
+                        q = ee_zero ? 1.0 / prm.qmax : fmax(1.0 / prm.qmax, fmin(1.0 / prm.qmin, exp(lq11 - b2 * lqold) / prm.gamma));
+                        return es <= 1.0;
+                    };
+                    if (alg == 0) {
+                        // ---------------------------------------------------------------- Tsit5 attempt
+                        double k[7][3], g6[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) k[0][i] = f0[i];
+#pragma unroll
+                        for (int s = 1; s < 7; ++s) {
+                            double g[3];
+                            ts5_stage_point(s, u, dt, k, g);
+                            if (s == 5) {
+#pragma unroll
+                                for (int i = 0; i < 3; ++i) g6[i] = g[i];
+                            }
+                            if (s == 6) {
+#pragma unroll
+                                for (int i = 0; i < 3; ++i) unew[i] = g[i];
+                                point_at(g, tnew, P2);
+                                cath_f(P2, th, k[6]);
+                            } else {
+                                CathPoint Ps;
+                                point_at(g, ts5_stage_time(s, t, dt, tnew), Ps);
+                                cath_f(Ps, th, k[s]);
+                            }
+                        }
+                        double est = 0.0;
+                        bool isnan_ = false;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            f2[i] = k[6][i];
+                            double a = 0.0;
+#pragma unroll
+                            for (int j = 0; j < 7; ++j) a = fma(Ts5::bt(j), k[j][i], a);
+                            const double ev = dt * a;
+                            const double m = fmax(fabs(u[i]), fabs(unew[i]));
+                            const double e = ev * frcp(fma(prm.rtol, m, prm.atol));
+                            es = fma(e, e, es);
+                            finite = finite && isfinite(unew[i]) && isfinite(ev);
+                            const double qq = fabs((k[6][i] - k[5][i]) / (unew[i] - g6[i]));   // Hairer II p.22, Inf norm; NaN propagates
+                            isnan_ = isnan_ || (qq != qq);
+                            est = fmax(est, qq);
+                        }
+                        es *= (1.0 / 3.0);
+                        eig = isnan_ ? __longlong_as_double(0x7ff8000000000000LL) : est;
+                        have_eig = true;
+                        if (!finite) rc = 3;
+                        else if (controller(b1_ts, b2_ts)) {
+                            accepted = true;
+                            ++nacc;
+                            while (jsave < D) {
+                                const double tsj = tsv[jsave];
+                                if (!(tsj <= tnew)) break;
+                                const bool at_end = (tsj == tnew);
+                                double bth[7], ui[3];
+                                Ts5::dense(at_end ? 1.0 : (tsj - t) / dt, bth);
+#pragma unroll
+                                for (int i = 0; i < 3; ++i) {
+                                    double a = 0.0;
+#pragma unroll
+                                    for (int j = 0; j < 7; ++j) a = fma(bth[j], k[j][i], a);
+                                    ui[i] = at_end ? unew[i] : fma(dt, a, u[i]);
+                                }
+                                save_fwd(ui, tsj, jsave);
+                                ++jsave;
+                            }
+                        } else {
+                            ++nrej;
+                            dt = dt / fmin(1.0 / prm.qmin, exp(lq11) / prm.gamma);
+                        }
+                    } else if constexpr (STIFF_TRBDF2) {
+                        // ---------------------------------------------------------------- TRBDF2 attempt (oracle: cath_trbdf2_nlsolve)
+                        have_eig = true;
+                        const double gW = tb_d * dt;
+                        // one nlsolve! call: z = dt f(tmp + d z, t + cst dt); false = the step fails
+                        auto nlsolve = [&](bool isfs, double cst, const double (&tmp)[3], double (&z)[3]) -> bool {
+                            const double inv_gdt = 1.0 / gW, tstep = last && cst == 1.0 ? tnew : fma(cst, dt, t);
+                            for (int redo = 0; redo < 3; ++redo) {
+                                bool new_jac, new_W;
+                                if (iter <= 1 || nl_first) { new_jac = true; new_W = true; }
+                                else {
+                                    const bool errorfail = ee_prev > 1.0;
+                                    const bool freshJ = (t == nl_Jt) && !errorfail;
+                                    bool jbad = false, small = true;
+                                    if (!freshJ) {
+                                        small = fabs(inv_gdt / (1.0 / nl_Wgdt) - 1.0) <= 0.2;
+                                        jbad = (nl_status == NL_TRYAGAIN) && small;
+                                    }
+                                    const bool wbad = (!small) || (isfs && errorfail) || nl_status == NL_DIV;
+                                    new_jac = jbad; new_W = jbad || wbad;
+                                }
+                                if (new_jac) {   // J = df/du at (uprev, t); calc_J! of a composite: eigen_est = opnorm(J, Inf)
+                                    CathPoint Pj;
+                                    point_at(u, t, Pj);
+#pragma unroll
+                                    for (int j = 0; j < 3; ++j) nl_a[j] = Pj.r[j] * th[12 + j] * Pj.g[j];
+                                    nl_Jt = t;
+                                    eig = fmax(fabs(nl_a[0]), fmax(fabs(th[15] * nl_a[0]) + fabs(nl_a[1]), fabs(th[16] * nl_a[1]) + fabs(nl_a[2])));
+                                }
+                                if (new_W) nl_Wgdt = gW;
+                                const double wi = 1.0 / nl_Wgdt;
+                                const double iw0 = 1.0 / (-nl_a[0] - wi), iw1 = 1.0 / (-nl_a[1] - wi), iw2 = 1.0 / (-nl_a[2] - wi);
+                                const double l21 = th[15] * nl_a[0], l32 = th[16] * nl_a[1];
+                                nl_status = NL_DIV;   // check_div: what a loop that runs out of iterations leaves behind
+                                double ndz = 0.0, ndzprev = 0.0;
+                                for (int it = 1; it <= 10; ++it) {
+                                    double us[3], fs[3], dz[3];
+#pragma unroll
+                                    for (int i = 0; i < 3; ++i) us[i] = fma(tb_d, z[i], tmp[i]);
+                                    CathPoint Ps;
+                                    point_at(us, tstep, Ps);
+                                    cath_f(Ps, th, fs);
+#pragma unroll
+                                    for (int i = 0; i < 3; ++i) dz[i] = (dt * fs[i] - z[i]) * inv_gdt;
+                                    dz[0] *= iw0;
+                                    dz[1] = (dz[1] - l21 * dz[0]) * iw1;
+                                    dz[2] = (dz[2] - l32 * dz[1]) * iw2;
+                                    double ss = 0.0;
+#pragma unroll
+                                    for (int i = 0; i < 3; ++i) {
+                                        const double e = dz[i] / fma(prm.rtol, fmax(fabs(u[i]), fabs(us[i])), prm.atol);
+                                        ss = fma(e, e, ss);
+                                    }
+                                    ndzprev = ndz;
+                                    ndz = sqrt(ss * (1.0 / 3.0));
+                                    if (!isfinite(ndz)) { nl_status = NL_DIV; break; }
+                                    double theta = 0.0;
+                                    if (it > 1) {
+                                        theta = ndz / ndzprev;
+                                        if (fabs(theta - 1.0) <= 10.0 * 2.220446049250313e-16) { nl_status = ndz <= 1.0 ? NL_CONV : NL_DIV; break; }
+                                        if (theta > 2.0) { nl_status = NL_DIV; break; }
+                                    }
+#pragma unroll
+                                    for (int i = 0; i < 3; ++i) z[i] -= dz[i];   // apply_step!
+                                    const double eta = theta / (1.0 - theta);
+                                    if ((it == 1 && ndz < 1e-5) || (it > 1 && eta >= 0.0 && eta * ndz < 1.0 / 100.0)) { nl_status = NL_CONV; break; }
+                                }
+                                if (nl_status == NL_DIV && !(t == nl_Jt)) { nl_status = NL_TRYAGAIN; continue; }   // @goto REDO
+                                break;
+                            }
+                            nl_first = false;   // postamble!
+                            return nl_status >= 0;
+                        };
+                        double zp[3], zg[3], z[3], tmp[3];
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) { zp[i] = dt * f0[i]; zg[i] = zp[i]; tmp[i] = fma(tb_d, zp[i], u[i]); }
+                        stepfail = !nlsolve(true, tb_g, tmp, zg);
+                        if (!stepfail) {
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) { z[i] = tb_a1 * zp[i] + tb_a2 * zg[i]; tmp[i] = u[i] + tb_w * zp[i] + tb_w * zg[i]; }
+                            stepfail = !nlsolve(false, 1.0, tmp, z);
+                        }
+                        if (stepfail) {   // force_stepfail: dt / failfactor, no controller call, EEst as it was
+                            ++nrej;
+                            dt *= 0.5;
+                        } else {
+                            double est[3];
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) {
+                                unew[i] = fma(tb_d, z[i], tmp[i]);
+                                f2[i] = z[i] / dt;                                   // fsallast = z ./ dt
+                                est[i] = tb_bt1 * zp[i] + tb_bt2 * zg[i] + tb_bt3 * z[i];
+                            }
+                            {   // smooth_est: get_W(nlsolver) \ tmp, with the W the iteration holds
+                                const double wi = 1.0 / nl_Wgdt;
+                                est[0] = est[0] / (-nl_a[0] - wi);
+                                est[1] = (est[1] - th[15] * nl_a[0] * est[0]) / (-nl_a[1] - wi);
+                                est[2] = (est[2] - th[16] * nl_a[1] * est[1]) / (-nl_a[2] - wi);
+                            }
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) {
+                                const double m = fmax(fabs(u[i]), fabs(unew[i]));
+                                const double e = est[i] * frcp(fma(prm.rtol, m, prm.atol));
+                                es = fma(e, e, es);
+                                finite = finite && isfinite(unew[i]) && isfinite(est[i]);
+                            }
+                            es *= (1.0 / 3.0);
+                            if (!finite) rc = 3;
+                            else if (controller(b1_rb, b2_rb)) {
+                                accepted = true;
+                                ++nacc;
+                                while (jsave < D) {
+                                    const double tsj = tsv[jsave];
+                                    if (!(tsj <= tnew)) break;
+                                    const bool at_end = (tsj == tnew);
+                                    const double Th = at_end ? 1.0 : (tsj - t) / dt;
+                                    double ui[3];
+#pragma unroll
+                                    for (int i = 0; i < 3; ++i) {   // Hermite on (uprev, u, fsalfirst, fsallast)
+                                        const double dy = unew[i] - u[i];
+                                        const double hm = (1.0 - Th) * u[i] + Th * unew[i]
+                                                          + Th * (Th - 1.0) * ((1.0 - 2.0 * Th) * dy + (Th - 1.0) * dt * f0[i] + Th * dt * f2[i]);
+                                        ui[i] = at_end ? unew[i] : hm;
+                                    }
+                                    save_fwd(ui, tsj, jsave);
+                                    ++jsave;
+                                }
+                            } else {
+                                ++nrej;
+                                dt = dt / fmin(1.0 / prm.qmin, exp(lq11) / prm.gamma);
+                            }
+                        }
+                    } else {
+                        // ---------------------------------------------------------------- Rosenbrock23 attempt (cathode_adj_kernel)
+                        const double gam = d_ * dt;
+                        double a[3], iw[3], sig[3], ft[3];
+                        wfac(P0, gam, a, iw);
+                        ftime(P0, sig, ft);
+                        // eigen_est = opnorm(J, Inf), J = S diag(a)
+                        eig = fmax(fabs(a[0]), fmax(fabs(th[15] * a[0]) + fabs(a[1]), fabs(th[16] * a[1]) + fabs(a[2])));
+                        have_eig = true;
+                        const double l21 = gam * th[15] * a[0], l32 = gam * th[16] * a[1];
+                        auto wsolve = [&](double (&b)[3]) {
+                            b[0] *= iw[0];
+                            b[1] = fma(l21, b[0], b[1]) * iw[1];
+                            b[2] = fma(l32, b[1], b[2]) * iw[2];
+                        };
+                        double k1[3], dk[3], k3[3], u1[3], f1[3];
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) k1[i] = fma(gam, ft[i], f0[i]);
+                        wsolve(k1);
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) u1[i] = fma(0.5 * dt, k1[i], u[i]);
+                        CathPoint P1;
+                        point_at(u1, t + 0.5 * dt, P1);
+                        cath_f(P1, th, f1);
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) dk[i] = f1[i] - k1[i];
+                        wsolve(dk);
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) unew[i] = fma(dt, k1[i] + dk[i], u[i]);
+                        point_at(unew, tnew, P2);
+                        cath_f(P2, th, f2);
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            const double k2i = k1[i] + dk[i];
+                            k3[i] = f2[i] - c32 * (k2i - f1[i]) - 2.0 * (k1[i] - f0[i]) + dt * ft[i];
+                        }
+                        wsolve(k3);
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            const double k2i = k1[i] + dk[i];
+                            const double ev = dt * (1.0 / 6.0) * (k1[i] - 2.0 * k2i + k3[i]);
+                            const double m = fmax(fabs(u[i]), fabs(unew[i]));
+                            const double e = ev * frcp(fma(prm.rtol, m, prm.atol));
+                            es = fma(e, e, es);
+                            finite = finite && isfinite(unew[i]) && isfinite(ev);
+                        }
+                        es *= (1.0 / 3.0);
+                        if (!finite) rc = 3;
+                        else if (controller(b1_rb, b2_rb)) {
+                            accepted = true;
+                            ++nacc;
+                            while (jsave < D) {
+                                const double tsj = tsv[jsave];
+                                if (!(tsj <= tnew)) break;
+                                const bool at_end = (tsj == tnew);
+                                const double Th = at_end ? 1.0 : (tsj - t) / dt;
+                                const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
+                                const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d_) * inv12d;
+                                double ui[3];
+#pragma unroll
+                                for (int i = 0; i < 3; ++i) ui[i] = at_end ? unew[i] : fma(dt, fma(c1, k1[i], c2 * (k1[i] + dk[i])), u[i]);
+                                save_fwd(ui, tsj, jsave);
+                                ++jsave;
+                            }
+                        } else {
+                            ++nrej;
+                            dt = dt / fmin(1.0 / prm.qmin, exp(lq11) / prm.gamma);
+                        }
+                    }
+                    if (rc < 0 && !stepfail) ee_prev = sqrt(es);   // integrator.EEst of this attempt (do_newJW's errorfail)
+                    if (accepted) {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) { u[i] = unew[i]; f0[i] = f2[i]; }
+                        if (!(STIFF_TRBDF2 && alg == 1)) P0 = P2;
+                        t = tnew;
+                        if (q >= prm.qsteady_min && q <= prm.qsteady_max) q = 1.0;
+                        lqold = ee_zero ? lqinit : fmax(lEE, lqinit);
+                        dt = fmin(dt / q, tend - t0);
+                        if (jsave >= D) rc = 0;
+                    }
+                }
+            }
+        }
+
+        if (valid) {
+            {   // the saved initial point's loss term
+                const double u00[3] = {1.0, 0.0, 0.0};
+                CathPoint q;
+                point_at(u00, t0, q);
+                const double db = dbv[0], e = hrr_at(q) - db;
+                pf_loss += fma(e, e, d2v[0] - db * db);
+            }
+            const double invD = 1.0 / (double)D;   // the FULL row count, also for a truncated solution (network.jl:266)
+            prm.loss[traj] = pf_loss * invD;
+            prm.retcode[traj] = rc;
+            prm.n_saved[traj] = jsave;
+            prm.n_accept[traj] = nacc;
+            prm.n_reject[traj] = nrej;
+        }
+    }
+}
+
+}  // namespace crnn

@@ -24,6 +24,7 @@
 #include "auto_adj_kernel.hpp"
 #include "ros23_adj2_kernel.hpp"
 #include "cathode_kernel.hpp"
+#include "cathode_auto_kernel.hpp"
 #include "svgd_kernel.hpp"
 
 namespace {
@@ -995,6 +996,7 @@ struct CathCtx {
     double *d_ag_send = nullptr, *d_ag_recv = nullptr;
     size_t ag_send_cap = 0, ag_recv_cap = 0;
     int adj_occ = 0, fwd_occ = 0, prim_occ = 0;
+    int solver = CRNN_CATH_SOLVER_ROSENBROCK23, auto_occ[2] = {0, 0};   // stepper of primal launches (crnn_cathode_set_solver)
     int tape_every = CRNN_CATH_TAPE_EVERY;   // adjoint tape: 1 = every step in full, 4 / 8 = checkpoint every 4th / 8th step
     // device-resident SVGD loop (crnn_cathode_set_particles / crnn_cathode_svgd_step)
     double *d_pn = nullptr, *d_pn2 = nullptr, *d_lnp = nullptr, *d_pscales = nullptr;   // particles (current / moved), lnpgrad, [p_scales(17) | mean loss, n_failed]
@@ -1945,6 +1947,27 @@ int32_t cath_run(CathCtx *c, int64_t n_part, int set_first, int set_count, bool 
     constexpr int kB = 256;
     bool done = false;
     const bool primal = !want_grad;      // primal calls: the adjoint kernel's forward sweep alone (cathode_adj_kernel<..., PRIMAL>)
+    if (primal && c->solver != CRNN_CATH_SOLVER_ROSENBROCK23) {
+        // the reference's composite (network.jl:195): cathode_auto_kernel, a wavefront takes 64 particles of one heating rate
+        const bool tr = c->solver == CRNN_CATH_SOLVER_AUTOTSIT5_TRBDF2;
+        using AutoFn = void (*)(const crnn::CathodeParams, const crnn::CathAdjParams);
+        const AutoFn fn = tr ? (AutoFn)crnn::cathode_auto_kernel<kB, true> : (AutoFn)crnn::cathode_auto_kernel<kB, false>;
+        int &occ_ = c->auto_occ[tr ? 0 : 1];
+        if (occ_ < 1) {
+            CHIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_, (const void *)fn, kB, 0));
+            if (occ_ < 1) occ_ = 1;
+        }
+        prm.qsteady_min = 1.0; prm.qsteady_max = 1.0;   // qsteady_max_default of a composite (not an implicit algorithm type)
+        const int64_t n_batches = ((n_part + 63) / 64) * set_count;
+        const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((n_batches + 3) / 4, (int64_t)c->num_cu * occ_));
+        crnn::CathAdjParams adj{};
+        adj.n_part = n_part;
+        CHIP(c, hipEventRecord(c->ev0, c->stream));
+        hipLaunchKernelGGL(fn, dim3(nblk), dim3(kB), 0, c->stream, prm, adj);
+        CHIP(c, hipGetLastError());
+        CHIP(c, hipEventRecord(c->ev1, c->stream));
+        return 0;
+    }
     if (primal || c->cfg.grad_mode != CRNN_GRAD_FORWARD) {
         // discrete adjoint (cathode_adj_kernel): a wavefront takes 64 particles of one heating rate
         // tape layout: every step in full (40 B) or checkpointed every kcp-th step (8 + 32 / kcp B per step; cathode_kernel.hpp)
@@ -2072,6 +2095,15 @@ int32_t crnn_cathode_set_tape_every(crnn_cathode_ctx *ctx, int32_t every) {
     if (!c) return cfail(nullptr, "null ctx");
     if (every != 1 && every != 4 && every != 8) return cfail(c, "crnn_cathode_set_tape_every: every must be 1, 4 or 8");
     if (every != c->tape_every) { c->tape_every = every; c->adj_occ = 0; }
+    return 0;
+}
+
+int32_t crnn_cathode_set_solver(crnn_cathode_ctx *ctx, int32_t solver) {
+    CathCtx *c = reinterpret_cast<CathCtx *>(ctx);
+    if (!c) return cfail(nullptr, "null ctx");
+    if (solver != CRNN_CATH_SOLVER_ROSENBROCK23 && solver != CRNN_CATH_SOLVER_AUTOTSIT5_TRBDF2 && solver != CRNN_CATH_SOLVER_AUTOTSIT5_ROS23)
+        return cfail(c, "crnn_cathode_set_solver: solver must be CRNN_CATH_SOLVER_ROSENBROCK23, _AUTOTSIT5_TRBDF2 or _AUTOTSIT5_ROS23");
+    c->solver = solver;
     return 0;
 }
 

@@ -314,8 +314,8 @@ int32_t crnn_allreduce_grad(crnn_ctx *ctx, double *buf, int32_t n);
  *   [lnA(3) | Ea(3) (exponent uses Ea*1e5) | b(3) | dH(3) | reaction order n(3) | nu2, nu3].
  * An observation set = one heating rate: its time grid ts (from the temperatures, dataset.jl:19-23), the replica
  * statistics dbar_i = mean_k data_ik and d2bar_i = mean_k data_ik^2 (all the MSE needs), beta in K/min.
- * Trajectory index = particle * n_sets + set.  Stepper: non-autonomous Rosenbrock23 (the reference runs
- * AutoTsit5(TRBDF2)): agreement to solver tolerance only.
+ * Trajectory index = particle * n_sets + set.  Stepper: non-autonomous Rosenbrock23 for gradient launches; primal launches run
+ * Rosenbrock23 or the reference's AutoTsit5(TRBDF2) composite (crnn_cathode_set_solver below).
  * ======================================================================== */
 #define CRNN_CATHODE_NP 17
 #define CRNN_CATHODE_MAX_D 128
@@ -378,6 +378,22 @@ int32_t crnn_cathode_set_particles(crnn_cathode_ctx *ctx, const double *p, const
  * (4 096 x 256 trajectories, 338 steps each): HBM traffic 31 -> 9.4 GB per launch, tape capacity per trajectory 3.3x, kernel
  * time 35.7 -> 40.3 ms (the kernel is issue-bound, not bandwidth-bound: profiles/r03e_*). */
 int32_t crnn_cathode_set_tape_every(crnn_cathode_ctx *ctx, int32_t every);
+/* The stepper of PRIMAL launches (crnn_cathode_solve with grad == NULL: pred_n_ode / HRR_getter / loss_neuralode, the epoch-end
+ * loss loop).  The reference integrates this model with `alg = AutoTsit5(TRBDF2(autodiff = true))` (network.jl:195, used by
+ * pred_n_ode :205-212):
+ *   CRNN_CATH_SOLVER_ROSENBROCK23      (default) Rosenbrock23 throughout: 338 accepted steps per config-5 trajectory
+ *   CRNN_CATH_SOLVER_AUTOTSIT5_TRBDF2  the reference's composite: Tsit5 + OrdinaryDiffEq's AutoSwitch + TRBDF2 (Newton iteration,
+ *                                      Jacobian / W reuse, smoothed error estimate) -- 114 accepted steps per trajectory
+ *   CRNN_CATH_SOLVER_AUTOTSIT5_ROS23   the same composite with Rosenbrock23 as its stiff algorithm
+ * All restated from the published algorithms ([UNVERIFIED-DEP]: the packages are not in the reference tree; oracle/crnn_oracle.c
+ * states every branch).  GRADIENT launches are not affected: they run the L-stable Rosenbrock23 discrete adjoint whatever this
+ * setting (the adjoint through Tsit5's steps is unstable for this model: cathode_auto_kernel.hpp).  Results of the three agree to
+ * solver tolerance (at tight tolerance to 1e-8); two implementations of the composite agree to ~1e-8 in the loss and a fraction
+ * of rtol in the heat-release curve, not step for step (explicit steps at their stability limit amplify round-off). */
+#define CRNN_CATH_SOLVER_ROSENBROCK23 0
+#define CRNN_CATH_SOLVER_AUTOTSIT5_TRBDF2 1
+#define CRNN_CATH_SOLVER_AUTOTSIT5_ROS23 2
+int32_t crnn_cathode_set_solver(crnn_cathode_ctx *ctx, int32_t solver);
 int32_t crnn_cathode_svgd_step(crnn_cathode_ctx *ctx, int32_t i_set, const double *normalizer2 /* [17] */, double stepsize, double h,
                                double *loss_mean, double *h_out, double *ms);
 int32_t crnn_cathode_get_particles(crnn_cathode_ctx *ctx, double *p);

@@ -347,6 +347,12 @@ end
 set_tape_every!(c::Cathode, every::Integer) = ccall((:crnn_cathode_set_tape_every, LIB), Int32, (Ptr{Cvoid}, Int32), c.ctx, Int32(every)) == 0 ||
     error(unsafe_string(ccall((:crnn_cathode_last_error, LIB), Cstring, (Ptr{Cvoid},), c.ctx)))
 
+"""Stepper of the primal calls (`solve(c, p)` without gradients is not exposed here; `pred_n_ode` / `loss_neuralode` go through it):
+0 = Rosenbrock23 (default), 1 = `AutoTsit5(TRBDF2(autodiff = true))` -- the reference's `alg` (network.jl:195) --, 2 = AutoTsit5 with
+Rosenbrock23 as the stiff algorithm.  Gradient launches always run the Rosenbrock23 adjoint."""
+set_solver!(c::Cathode, solver::Integer) = ccall((:crnn_cathode_set_solver, LIB), Int32, (Ptr{Cvoid}, Int32), c.ctx, Int32(solver)) == 0 ||
+    error(unsafe_string(ccall((:crnn_cathode_last_error, LIB), Cstring, (Ptr{Cvoid},), c.ctx)))
+
 """Device-resident SVGD loop (crnn_cathode.jl:36-50): `set_particles!(c, p)` uploads the normalised particles p [N, 17];
 `svgd_step!(c, i_exp, normalizer2, stepsize)` runs dlnprob for heating rate i_exp and the SVGD move on the device
 (returns the mean loss and the bandwidth); `particles(c, N)` copies them out."""

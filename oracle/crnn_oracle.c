@@ -1412,10 +1412,16 @@ typedef struct orc_cathode {
     double lb_clamp, T0, beta;      /* beta in K/min: T = T0 + beta/60 t */
     double atol, rtol;
     int32_t maxiters;
-    int32_t solver;   /* 0 Rosenbrock23; 2 AutoTsit5 composite with Rosenbrock23 as its stiff algorithm (the reference:
-                         AutoTsit5(TRBDF2(autodiff=true)), network.jl:195 -- the explicit branch and the switching rule
-                         are restated, the stiff branch is NOT TRBDF2; see solve_one_auto above for the rule) */
+    int32_t solver;   /* 0 Rosenbrock23; 2 AutoTsit5 composite with Rosenbrock23 as its stiff algorithm;
+                         3 AutoTsit5(TRBDF2(autodiff = true)) -- THE REFERENCE'S ALGORITHM (network.jl:195, used :205-212): the
+                           explicit branch, the switching rule (see solve_one_auto above) and TRBDF2 with OrdinaryDiffEq's Newton
+                           machinery restated (cath_trbdf2_* below; primal only);
+                         4 TRBDF2 alone (to test the stepper by itself) */
     double gamma, qmin, qmax, beta1, beta2, qsteady_min, qsteady_max, qoldinit;
+    int32_t trbdf2_est;   /* TRBDF2's smoothed error estimate (smooth_est = true, the default): 0 = `W \ tmp` with the W the Newton
+                             iteration holds, W = J - I/(gamma dt) -- what the package's perform_step! reads like; 1 = Shampine's
+                             (I - gamma dt J)^-1 tmp (differs by the factor gamma dt).  [UNVERIFIED-DEP] */
+    int32_t pad_;
 } orc_cathode;
 
 void orc_cathode_defaults(orc_cathode *c) {
@@ -1481,6 +1487,134 @@ static void csolve3(const double *W, const int *piv, cplx *b) {   /* real LU app
     for (int k = 2; k >= 0; --k) { b[k] /= W[k + 3 * k]; cplx a = b[k]; for (int i = 0; i < k; ++i) b[i] -= W[i + 3 * k] * a; }
 }
 
+/* ------------------------------------------------------------------------------------------------------------------ *
+ * TRBDF2 (Bank et al. / Hosea & Shampine) as OrdinaryDiffEqSDIRK's `TRBDF2(autodiff = true)` runs it -- the stiff algorithm of
+ * the reference's composite (network.jl:195; Cathode_NCM333_UQ/Manifest.toml pins OrdinaryDiffEqSDIRK 1.7.0,
+ * OrdinaryDiffEqNonlinearSolve, OrdinaryDiffEqDifferentiation 1.16.0 -- none of them vendored).  EVERYTHING BELOW IS
+ * [UNVERIFIED-DEP]: restated from the packages' published source as remembered, not executable here (no Julia).  Branch by
+ * branch:
+ *   tableau      gamma = 2 - sqrt 2, d = 1 - sqrt2/2 (= gamma/2), omega = sqrt2/4, btilde = ((1 - sqrt2)/3, 1/3, (sqrt2 - 2)/3),
+ *                alpha1 = -sqrt2/2, alpha2 = 1 + sqrt2/2 (TRBDF2Tableau)
+ *   stages       in z = dt f form.  zprev = dt fsalfirst;  stage 1: tmp = uprev + d zprev, guess z = zprev,
+ *                solve z = dt f(tmp + d z, t + gamma dt) -> z_g;  stage 2: tmp = uprev + omega zprev + omega z_g, guess
+ *                z = alpha1 zprev + alpha2 z_g (Shampine), solve z = dt f(tmp + d z, t + dt);  u = tmp + d z;
+ *                fsallast = z / dt (NOT a fresh f(u): the next TRBDF2 step starts from it; an algorithm switch re-evaluates f)
+ *   Newton       NLNewton defaults: kappa = 1/100, max_iter = 10, fast_convergence_cutoff = 1/5, new_W_dt_cutoff = 1/5, no
+ *                relaxation.  W = J - I/(gamma dt) (gamma = d; LU with partial pivoting); iteration
+ *                dz = W \ ((dt f(tmp + d z) - z)/(gamma dt)), z <- z - dz, ndz = RMS(dz / (atol + rtol max(|uprev|, |ustep|)));
+ *                first iteration converged if ndz < 1e-5; from the second theta = ndz/ndz_prev, divergence if theta > 2,
+ *                eta = theta/(1 - theta), converged if eta >= 0 and eta ndz < kappa; round-off guard |theta - 1| <= 10 eps;
+ *                ten iterations without convergence = divergence; a divergence with a Jacobian that is not the current step's
+ *                -> status TryAgain, new J, once more from the current iterate; otherwise the step fails:
+ *                dt <- dt / failfactor (2), no controller call, EEst untouched.
+ *   J / W reuse  do_newJW: new J and W at integrator.iter <= 1 and at the cache's first call; else errorfail = (EEst of the
+ *                previous attempt > 1), freshJ = (J was formed at this t) && !errorfail; if !freshJ:
+ *                smallstepchange = |W_gammadt/(gamma dt) - 1| <= 1/5, jbad = (status == TryAgain && smallstepchange);
+ *                wbad = !smallstepchange || (first stage && errorfail) || status == Divergence; (new_jac, new_W) = (jbad,
+ *                jbad || wbad).  J = df/du at (uprev, t) by ForwardDiff (exact derivative arithmetic: the analytic J here),
+ *                held for both stages and, stale, for later steps; calc_J! of a composite also sets eigen_est = opnorm(J, Inf),
+ *                so the switch-back test of AutoSwitch sees the norm of the LAST FORMED Jacobian.
+ *   error        tmp = btilde1 zprev + btilde2 z_g + btilde3 z; smooth_est: est = W \ tmp (trbdf2_est above); EEst = RMS(est /
+ *                (atol + rtol max(|uprev|, |u|))); order 2 -> PI exponents 7/20, 2/10.
+ *   saveat       TRBDF2 has no interpolant of its own: third-order Hermite on (uprev, u, k1 = fsalfirst, k2 = fsallast).
+ * ------------------------------------------------------------------------------------------------------------------ */
+enum { NL_FASTCONV = 2, NL_CONV = 1, NL_DIV = -2, NL_TRYAGAIN = -4 };
+typedef struct cath_nl {
+    double J[9], W[9];
+    int piv[3];
+    double J_t, W_gdt, eta_old;
+    int status, firstcall, new_W;
+    int64_t n_newton, n_jac, n_w, n_fail;   /* statistics */
+} cath_nl;
+static void cath_nl_init(cath_nl *nl) {
+    memset(nl, 0, sizeof(*nl));
+    nl->J_t = NAN; nl->W_gdt = 0.0; nl->eta_old = 1.0; nl->status = NL_DIV; nl->firstcall = 1;
+}
+static void cath_jac_real(const orc_cathode *c, const double *th, const double *u, double t, double *J) {
+    cplx thc[17], uc[3], Jc[9], ftc[3];
+    for (int k = 0; k < 17; ++k) thc[k] = th[k];
+    for (int i = 0; i < 3; ++i) uc[i] = u[i];
+    cath_jac_ft(c, thc, uc, t, Jc, ftc);
+    for (int k = 0; k < 9; ++k) J[k] = creal(Jc[k]);
+}
+/* one nlsolve! call: stage equation z = dt f(tmp + gam z, t + cst dt), z in/out.  Returns 0 (converged) or -1 (step fails). */
+static int cath_trbdf2_nlsolve(const orc_cathode *c, const double *th, cath_nl *nl, const double *uprev, double t, double dt,
+                               int integ_iter, double EEst_prev, int isfs, double gam, double cst, const double *tmp, double *z,
+                               double *eigen_est) {
+    const double kappa = 1.0 / 100.0, gW = gam * dt;
+    double eta = nl->eta_old;
+    for (int redo = 0; redo < 3; ++redo) {
+        /* ---- update_W! -> calc_W! -> do_newJW */
+        int new_jac, new_W;
+        if (integ_iter <= 1 || nl->firstcall) { new_jac = 1; new_W = 1; }
+        else {
+            const int errorfail = EEst_prev > 1.0;
+            const int freshJ = (t == nl->J_t) && !errorfail;
+            int jbad, small;
+            if (freshJ) { jbad = 0; small = 1; }
+            else {
+                const double W_igdt = 1.0 / nl->W_gdt, igdt = 1.0 / gW;
+                small = fabs(igdt / W_igdt - 1.0) <= 0.2;
+                jbad = (nl->status == NL_TRYAGAIN) && small;
+            }
+            const int wbad = (!small) || (isfs && errorfail) || nl->status == NL_DIV;
+            new_jac = jbad; new_W = jbad || wbad;
+        }
+        if (new_jac) {
+            cath_jac_real(c, th, uprev, t, nl->J);
+            nl->J_t = t; nl->n_jac++;
+            double est = 0.0;   /* calc_J! of a composite: eigen_est = opnorm(J, Inf) */
+            for (int i = 0; i < 3; ++i) { double a = 0.0; for (int cc = 0; cc < 3; ++cc) a += fabs(nl->J[i + 3 * cc]); if (a > est) est = a; }
+            *eigen_est = est;
+        }
+        if (new_W) {
+            const double inv = 1.0 / gW;
+            for (int cc = 0; cc < 3; ++cc) for (int i = 0; i < 3; ++i) nl->W[i + 3 * cc] = nl->J[i + 3 * cc] - (i == cc ? inv : 0.0);
+            if (lu_factor(3, nl->W, nl->piv) != 0) { nl->status = NL_DIV; return -1; }
+            nl->W_gdt = gW; nl->n_w++;
+        }
+        nl->new_W = new_W;
+        /* ---- initialize!, the iteration */
+        const double inv_gdt = 1.0 / (dt * gam), tstep = t + cst * dt;
+        nl->status = NL_DIV;   /* check_div: what a loop that runs out of iterations leaves behind */
+        eta = new_W ? pow(fmax(nl->eta_old, 2.220446049250313e-16), 0.8) : nl->eta_old;
+        double ndz = 0.0, ndzprev = 0.0;
+        for (int it = 1; it <= 10; ++it) {
+            double ustep[3], f[3], dz[3], zt[3];
+            for (int i = 0; i < 3; ++i) ustep[i] = tmp[i] + gam * z[i];
+            cath_rhs_real(c, th, ustep, tstep, f);
+            for (int i = 0; i < 3; ++i) dz[i] = (dt * f[i] - z[i]) * inv_gdt;
+            lu_solve(3, nl->W, nl->piv, dz);
+            nl->n_newton++;
+            double s_ = 0.0;
+            for (int i = 0; i < 3; ++i) { const double e = dz[i] / (c->atol + c->rtol * fmax(fabs(uprev[i]), fabs(ustep[i]))); s_ += e * e; }
+            ndzprev = ndz; ndz = sqrt(s_ / 3.0);
+            for (int i = 0; i < 3; ++i) zt[i] = z[i] - dz[i];
+            if (!isfinite(ndz)) { nl->status = NL_DIV; break; }
+            double theta = 0.0;
+            if (it > 1) {
+                theta = ndz / ndzprev;
+                if (fabs(theta - 1.0) <= 10.0 * 2.220446049250313e-16) {
+                    if (ndz <= 1.0) { nl->status = NL_CONV; break; }
+                    nl->status = NL_DIV; break;
+                }
+                if (theta > 2.0) { nl->status = NL_DIV; break; }
+            }
+            for (int i = 0; i < 3; ++i) z[i] = zt[i];   /* apply_step! */
+            if (it > 1) eta = theta / (1.0 - theta);
+            if ((it == 1 && ndz < 1e-5) || (it > 1 && eta >= 0.0 && eta * ndz < kappa)) { nl->status = NL_CONV; break; }
+        }
+        if (nl->status == NL_DIV && !(t == nl->J_t)) { nl->status = NL_TRYAGAIN; continue; }   /* @goto REDO */
+        break;
+    }
+    nl->eta_old = eta;
+    nl->firstcall = 0;   /* postamble! */
+    if (nl->status < 0) { nl->n_fail++; return -1; }
+    return 0;
+}
+_Thread_local int64_t orc_cathode_last_nl[4] = {0, 0, 0, 0};   /* Newton iterations, Jacobians, W factorisations, failed solves */
+void orc_cathode_nl_stats(int64_t *out) { for (int i = 0; i < 4; ++i) out[i] = orc_cathode_last_nl[i]; }
+
 /* One (particle, heating-rate) trajectory: HRR prediction, MSE loss against the replica statistics
    dbar[i] = mean_k data[i,k], d2bar[i] = mean_k data[i,k]^2, gradient wrt theta (17).
    Complex-step: for direction e_k the whole step is evaluated at theta + i*h*e_k, u + i*h*s_k with the REAL
@@ -1492,6 +1626,8 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
                           double *loss_out, double *grad /*[17] or NULL*/, int32_t *n_saved_out, orc_stats *st) {
     const double d = 1.0 / (2.0 + sqrt(2.0)), c32 = 6.0 + sqrt(2.0), h = 1e-30;
     const int P = grad ? 17 : 0;
+    const int composite = (c->solver == 2 || c->solver == 3), trbdf2 = (c->solver == 3 || c->solver == 4);
+    if (trbdf2 && grad) return -1;   /* TRBDF2 is restated for primal solves only */
     const double t0 = ts[0], tend = ts[D - 1];
     double t = t0;
     cplx u[18][3];   /* u[P] = primal (imag 0); u[k] = primal + i h s_k */
@@ -1518,7 +1654,7 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
         for (int i = 0; i < 3; ++i) { double e = (f1[i] - fr[i]) / sk[i]; d2 += e * e; }
         d2 = sqrt(d2 / 3) / dt0;
         double dm = fmax(d1, d2);
-        double dt1 = dm <= 1e-15 ? fmax(1e-6, dt0 * 1e-3) : pow(10.0, -(2.0 + log10(dm)) / (c->solver == 2 ? 5.0 : 2.0));   /* order + 1 of the starting algorithm */
+        double dt1 = dm <= 1e-15 ? fmax(1e-6, dt0 * 1e-3) : pow(10.0, -(2.0 + log10(dm)) / (composite ? 5.0 : 2.0));   /* the order of the starting algorithm */
         dt = fmin(fmin(100 * dt0, dt1), dtmax);
     }
     double qold = c->qoldinit, loss_sum = 0.0, g[17];
@@ -1541,16 +1677,24 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
     } while (0)
     CATH_SAVE(u[k][i], t0);   /* saveat contains tspan[1] */
     static _Thread_local cplx KT[7][18][3];   /* Tsit5 stage slopes of all copies */
-    int alg = c->solver == 2 ? 0 : 1, cnt = 0, have_est = 0;
+    int alg = composite ? 0 : 1, cnt = 0, have_est = 0;
     int64_t n_ts5 = 0;
     double eigen_est = 0.0;
+    cath_nl nl;                 /* TRBDF2's nonlinear-solver cache: lives across steps and across algorithm switches */
+    cath_nl_init(&nl);
+    double EEst_prev = 1.0;     /* integrator.EEst: the last attempt's estimate, whichever algorithm made it (do_newJW's errorfail) */
+    double zg_[3] = {0, 0, 0}, z_[3] = {0, 0, 0};
     while (jsave < D) {
         if (++iter > c->maxiters) { retcode = 1; break; }
-        if (c->solver == 2 && have_est) {   /* choose_algorithm!, as in solve_one_auto */
+        if (composite && have_est) {   /* choose_algorithm!, as in solve_one_auto */
             const int stiff = fabs(eigen_est * dt / AS_STAB) > AS_TOL;
             cnt = stiff ? (cnt < 0 ? 1 : cnt + 1) : (cnt > 0 ? -1 : cnt - 1);
             if (alg == 0 && cnt > AS_MAXSTIFF) { dt *= AS_DTFAC; alg = 1; }
-            else if (alg == 1 && cnt < -AS_MAXNONSTIFF) { dt /= AS_DTFAC; alg = 0; }
+            else if (alg == 1 && cnt < -AS_MAXNONSTIFF) {
+                dt /= AS_DTFAC; alg = 0;
+                /* initialize!(Tsit5 cache): fsalfirst = f(uprev, t) afresh -- TRBDF2 left z/dt there, not a function value */
+                if (trbdf2) cath_rhs(c, thk[PR], u[PR], t, f0[PR]);
+            }
         }
         int last = 0;
         if (t + dt * (1.0 + 1e-13) >= tend) { dt = tend - t; last = 1; }
@@ -1561,7 +1705,8 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
         cplx k1[18][3], k2[18][3], k3[18][3], un[18][3], f2[18][3];
         int finite = 1;
         double ev[3], EEst = 0.0;
-        if (alg == 0 && c->solver == 2) {
+        int stepfail = 0;
+        if (alg == 0 && composite) {
             /* ---- Tsit5 attempt (non-autonomous: stage s at t + c_s dt) ---- */
             for (int pass = 0; pass < 2; ++pass) {
                 for (int k = 0; k <= 17; ++k) {
@@ -1599,6 +1744,36 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
                     EEst = sqrt(s_ / 3.0);
                     if (!(EEst <= 1.0) || P == 0) break;
                 }
+            }
+        } else if (trbdf2) {
+            /* ---- TRBDF2 attempt (primal only; see the block comment above cath_trbdf2_nlsolve) ---- */
+            const double s2 = sqrt(2.0), tg = 2.0 - s2, dd = 1.0 - s2 / 2.0, om = s2 / 4.0;
+            const double bt1 = (1.0 - s2) / 3.0, bt2 = 1.0 / 3.0, bt3 = (s2 - 2.0) / 3.0, al1 = -s2 / 2.0, al2 = 1.0 + s2 / 2.0;
+            double up[3], zp[3], tmp[3];
+            for (int i = 0; i < 3; ++i) { up[i] = creal(u[PR][i]); zp[i] = dt * creal(f0[PR][i]); }
+            for (int i = 0; i < 3; ++i) { zg_[i] = zp[i]; tmp[i] = up[i] + dd * zp[i]; }
+            stepfail = cath_trbdf2_nlsolve(c, th, &nl, up, t, dt, iter, EEst_prev, 1, dd, tg, tmp, zg_, &eigen_est) != 0;
+            if (!stepfail) {
+                for (int i = 0; i < 3; ++i) { z_[i] = al1 * zp[i] + al2 * zg_[i]; tmp[i] = up[i] + om * zp[i] + om * zg_[i]; }
+                stepfail = cath_trbdf2_nlsolve(c, th, &nl, up, t, dt, iter, EEst_prev, 0, dd, 1.0, tmp, z_, &eigen_est) != 0;
+            }
+            if (!stepfail) {
+                double est[3], s_ = 0.0;
+                for (int i = 0; i < 3; ++i) {
+                    un[PR][i] = tmp[i] + dd * z_[i];
+                    f2[PR][i] = z_[i] / dt;                      /* fsallast = z ./ dt */
+                    est[i] = bt1 * zp[i] + bt2 * zg_[i] + bt3 * z_[i];
+                }
+                lu_solve(3, nl.W, nl.piv, est);                   /* smooth_est: get_W(nlsolver) \ tmp */
+                for (int i = 0; i < 3; ++i) {
+                    if (c->trbdf2_est == 1) est[i] /= nl.W_gdt;   /* Shampine's (I - gamma dt J)^-1 tmp, up to sign */
+                    ev[i] = est[i];
+                    if (!isfinite(creal(un[PR][i])) || !isfinite(ev[i])) finite = 0;
+                    const double m = fmax(fabs(up[i]), fabs(creal(un[PR][i])));
+                    const double e = ev[i] / (c->atol + c->rtol * m);
+                    s_ += e * e;
+                }
+                EEst = sqrt(s_ / 3.0);
             }
         } else {
         cath_jac_ft(c, thk[PR], u[PR], t, Jc, ftc);
@@ -1643,23 +1818,34 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
         }
         }
         have_est = 1;
+        if (stepfail) {   /* the Newton iteration failed: force_stepfail -> dt / failfactor, no controller, EEst as it was */
+            if (st) st->nreject++;
+            dt = dt / 2.0;
+            continue;
+        }
         if (!finite) { retcode = 3; break; }
+        EEst_prev = EEst;
         int accept = (EEst <= 1.0);
-        const double b1_ = c->solver == 2 ? (alg == 0 ? 7.0 / 50.0 : 7.0 / 20.0) : c->beta1;
-        const double b2_ = c->solver == 2 ? (alg == 0 ? 2.0 / 25.0 : 2.0 / 10.0) : c->beta2;
+        const double b1_ = composite ? (alg == 0 ? 7.0 / 50.0 : 7.0 / 20.0) : c->beta1;
+        const double b2_ = composite ? (alg == 0 ? 2.0 / 25.0 : 2.0 / 10.0) : c->beta2;
         double q, q11 = 0.0;
         if (EEst == 0.0) q = 1.0 / c->qmax;
         else { q11 = pow(EEst, b1_); q = q11 / pow(qold, b2_); q = fmax(1.0 / c->qmax, fmin(1.0 / c->qmin, q / c->gamma)); }
         if (accept) {
             if (st) st->naccept++;
-            if (alg == 0 && c->solver == 2) n_ts5++;
+            if (alg == 0 && composite) n_ts5++;
             if (q >= c->qsteady_min && q <= c->qsteady_max) q = 1.0;
             qold = fmax(EEst, c->qoldinit);
             double tnew = last ? tend : t + dt;
             while (jsave < D && ts[jsave] <= tnew) {
                 double tsv = ts[jsave];
                 if (tsv == tnew) { CATH_SAVE(un[k][i], tsv); }
-                else if (alg == 0 && c->solver == 2) {
+                else if (trbdf2 && alg == 1) {   /* Hermite on (uprev, u, fsalfirst, fsallast) */
+                    const double Th = (tsv - t) / dt;
+                    CATH_SAVE((1.0 - Th) * u[k][i] + Th * un[k][i] + Th * (Th - 1.0) * ((1.0 - 2.0 * Th) * (un[k][i] - u[k][i])
+                              + (Th - 1.0) * dt * f0[k][i] + Th * dt * f2[k][i]), tsv);
+                }
+                else if (alg == 0 && composite) {
                     double bth[7];
                     orc_tsit5_dense((tsv - t) / dt, bth);
                     CATH_SAVE(u[k][i] + dt * (bth[0] * KT[0][k][i] + bth[1] * KT[1][k][i] + bth[2] * KT[2][k][i] + bth[3] * KT[3][k][i]
@@ -1685,6 +1871,7 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
     if (grad) for (int k = 0; k < 17; ++k) grad[k] = g[k] / (double)D;
     if (n_saved_out) *n_saved_out = jsave;
     orc_cathode_last_tsit5_steps = n_ts5;
+    orc_cathode_last_nl[0] = nl.n_newton; orc_cathode_last_nl[1] = nl.n_jac; orc_cathode_last_nl[2] = nl.n_w; orc_cathode_last_nl[3] = nl.n_fail;
     return retcode;
 }
 

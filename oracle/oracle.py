@@ -258,17 +258,21 @@ class Cathode(C.Structure):
     _fields_ = [("lb_clamp", C.c_double), ("T0", C.c_double), ("beta", C.c_double), ("atol", C.c_double),
                 ("rtol", C.c_double), ("maxiters", C.c_int32), ("solver", C.c_int32),
                 ("gamma", C.c_double), ("qmin", C.c_double), ("qmax", C.c_double), ("beta1", C.c_double),
-                ("beta2", C.c_double), ("qsteady_min", C.c_double), ("qsteady_max", C.c_double), ("qoldinit", C.c_double)]
+                ("beta2", C.c_double), ("qsteady_min", C.c_double), ("qsteady_max", C.c_double), ("qoldinit", C.c_double),
+                ("trbdf2_est", C.c_int32), ("pad_", C.c_int32)]
 
 
-def make_cathode(beta, atol=1e-12, rtol=1e-3, maxiters=2500000, lb_clamp=1e-16, solver=0):
-    """solver 0: Rosenbrock23; 2: AutoTsit5 composite (Tsit5 + stiffness switch, Rosenbrock23 as the stiff algorithm)."""
+def make_cathode(beta, atol=1e-12, rtol=1e-3, maxiters=2500000, lb_clamp=1e-16, solver=0, trbdf2_est=0):
+    """solver 0: Rosenbrock23; 2: AutoTsit5 composite (Tsit5 + stiffness switch) with Rosenbrock23 as the stiff algorithm;
+    3: AutoTsit5(TRBDF2(autodiff=true)) -- the reference's algorithm (network.jl:195), primal only; 4: TRBDF2 alone.
+    trbdf2_est: 0 = smoothed estimate `W \\ tmp` with the Newton iteration's W (default), 1 = Shampine's (I - gamma dt J)^-1 tmp."""
     c = Cathode()
     lib().orc_cathode_defaults(C.byref(c))
     assert lib().orc_sizeof_cathode() == C.sizeof(Cathode)
     c.beta, c.atol, c.rtol, c.maxiters, c.lb_clamp = float(beta), atol, rtol, int(maxiters), lb_clamp
     c.solver = int(solver)
-    if solver == 2:
+    c.trbdf2_est = int(trbdf2_est)
+    if solver in (2, 3):
         c.qsteady_max = 1.0          # a composite is not an implicit algorithm type (see solve_one_auto)
     return c
 
@@ -293,8 +297,11 @@ def cathode_solve_one(c, theta, ts, dbar, d2bar, want_grad=True):
                                      _dp(np.ascontiguousarray(dbar, float)), _dp(np.ascontiguousarray(d2bar, float)),
                                      _dp(hrr), C.byref(loss), _dp(grad), C.byref(ns), C.cast(st, C.c_void_p))
     lib().orc_cathode_tsit5_steps.restype = C.c_int64
+    nl = np.zeros(4, np.int64)
+    lib().orc_cathode_nl_stats(nl.ctypes.data_as(C.POINTER(C.c_int64)))
     return dict(hrr=hrr, loss=loss.value, grad=grad, retcode=rc, n_saved=ns.value, naccept=st[0], nreject=st[1],
-                n_tsit5=int(lib().orc_cathode_tsit5_steps()))
+                n_tsit5=int(lib().orc_cathode_tsit5_steps()),
+                n_newton=int(nl[0]), n_jac=int(nl[1]), n_w=int(nl[2]), n_nlfail=int(nl[3]))
 
 
 def cathode_census(c, theta, beta, ts, D, nthreads=0):

@@ -359,6 +359,152 @@ def test_oracle_cathode_autotsit5_restatement_stays_on_tsit5(orc, cfx):
     assert worst > 1.0      # the instability described above is there (if this ever fails, revisit the choice of stepper)
 
 
+# ------------------------------------------------------------------ the reference's stepper: AutoTsit5(TRBDF2(autodiff = true))
+def _perturbed(spread, N, seed=5):
+    rng = np.random.default_rng(seed)
+    p = 1 + spread * rng.standard_normal((N, 17))
+    p[:, 6:9] = 0.0
+    return p
+
+
+def test_oracle_trbdf2_alone_converges_to_the_golden_vectors(orc, cfx):
+    """TRBDF2 by itself (oracle solver 4: the restated stepper + Newton machinery, network.jl:195's stiff algorithm) against
+    Radau: second-order convergence towards the golden heat-release curves, with both readings of the smoothed error
+    estimate; the Newton iteration reuses its Jacobian (a handful of J evaluations per run, as do_newJW intends)."""
+    th = np.array(cfx["theta"])
+    for est in (0, 1):
+        for s in cfx["sets"][::2]:
+            hg = np.array(s["hrr"])
+            errs = []
+            for atol, rtol in ((1e-12, 1e-3), (1e-13, 1e-6), (1e-14, 1e-9)):
+                c = orc.make_cathode(s["beta"], atol=atol, rtol=rtol, solver=4, trbdf2_est=est)
+                c.qsteady_max = 1.2            # TRBDF2 alone is an implicit algorithm type
+                r = orc.cathode_solve_one(c, th, s["ts"], s["dbar"], s["d2bar"], want_grad=False)
+                assert r["retcode"] == 0 and r["n_saved"] == len(s["ts"])
+                assert r["n_newton"] >= 4 * r["naccept"] and r["n_jac"] <= 0.1 * r["naccept"] + 5 and r["n_w"] >= r["n_jac"]
+                errs.append(np.max(np.abs(r["hrr"] - hg)) / np.max(np.abs(hg)))
+            assert errs[0] < 3e-3 and errs[1] < 5e-5 and errs[2] < 2e-6, errs      # measured 1.2e-3 / 2.3e-5 / 7e-7 at worst
+            assert errs[2] < 0.1 * errs[1] < 0.01 * errs[0] * 10
+
+
+def test_oracle_autotsit5_trbdf2_composite(orc, cfx):
+    """The reference's `alg` (oracle solver 3).  At the reference's own parameter vector the detector never fires, so the run is
+    the Tsit5 run of the Rosenbrock23 composite (solver 2), bit for bit; in a perturbed cloud some trajectories do reach
+    TRBDF2, take a few Newton-solved steps and return; results agree with the Rosenbrock23 path to solver tolerance and, at
+    tight tolerance, to 1e-7."""
+    th = np.array(cfx["theta"])
+    for s in cfx["sets"]:
+        a = orc.cathode_solve_one(orc.make_cathode(s["beta"], solver=3), th, s["ts"], s["dbar"], s["d2bar"], want_grad=False)
+        b = orc.cathode_solve_one(orc.make_cathode(s["beta"], solver=2), th, s["ts"], s["dbar"], s["d2bar"], want_grad=False)
+        assert a["retcode"] == 0 and a["n_tsit5"] == a["naccept"] == b["naccept"] and a["n_newton"] == 0
+        assert a["loss"] == b["loss"] and np.array_equal(a["hrr"], b["hrr"])
+    s0 = cfx["sets"][0]     # TRBDF2 is restated for primal solves only: a gradient request is refused
+    assert orc.cathode_solve_one(orc.make_cathode(s0["beta"], solver=3), th, s0["ts"], s0["dbar"], s0["d2bar"], want_grad=True)["retcode"] == -1
+    p = _perturbed(0.05, 24)
+    n_switch = n_newton = 0
+    acc = [0, 0]
+    for n in range(p.shape[0]):
+        for s in cfx["sets"][1::2]:
+            r = orc.cathode_solve_one(orc.make_cathode(s["beta"], solver=3), p[n] * th, s["ts"], s["dbar"], s["d2bar"], want_grad=False)
+            r0 = orc.cathode_solve_one(orc.make_cathode(s["beta"], solver=0), p[n] * th, s["ts"], s["dbar"], s["d2bar"], want_grad=False)
+            assert r["retcode"] == 0
+            assert abs(r["loss"] - r0["loss"]) < 3e-2 * r0["loss"]
+            n_switch += r["n_tsit5"] != r["naccept"]; n_newton += r["n_newton"]
+            acc[0] += r["naccept"]; acc[1] += r0["naccept"]
+            t = orc.cathode_solve_one(orc.make_cathode(s["beta"], solver=3, atol=1e-14, rtol=1e-9), p[n] * th, s["ts"], s["dbar"], s["d2bar"], want_grad=False)
+            t0 = orc.cathode_solve_one(orc.make_cathode(s["beta"], solver=0, atol=1e-14, rtol=1e-9), p[n] * th, s["ts"], s["dbar"], s["d2bar"], want_grad=False)
+            assert abs(t["loss"] - t0["loss"]) < 1e-7 * t0["loss"]
+            assert np.max(np.abs(t["hrr"] - t0["hrr"])) < 1e-7 * np.max(np.abs(t0["hrr"]))
+    assert n_switch >= 3 and n_newton > 0      # the stiff branch did run
+    assert acc[0] < 0.5 * acc[1]               # and the composite takes well under half of Rosenbrock23's steps overall
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver,osolver", [("autotsit5_trbdf2", 3), ("autotsit5_rosenbrock23", 2)])
+def test_gpu_cathode_composite_primal_matches_oracle_composite(orc, cfx, solver, osolver):
+    """crnn_cathode_set_solver: primal launches through the reference's composite (network.jl:195,205-212) against the oracle's
+    statement of the same composite, perturbed particles x the reference's five heating rates.  Explicit steps at their
+    stability limit amplify round-off, so two implementations agree to a fraction of the solver tolerance, not step for step
+    (cathode_auto_kernel.hpp): the bars are the tolerances themselves -- measured (tools/cath_composite_probe.py): loss 8e-7 /
+    1e-4, curve 8e-5 / 1e-3 of its peak at rtol 1e-3 (cloud 1e-3 / 5e-2); 1.4e-7 / 8e-7 at rtol 1e-6; 4e-10 / 3e-9 at 1e-9 -- and
+    the accepted step counts agree to 4 % (rtol 1e-9: 12 %)."""
+    from crnn_amd.cathode import CathodeUQ
+    th = np.array(cfx["theta"])
+    mk = lambda **kw: CathodeUQ([_two_replicas(s) for s in cfx["sets"]], [s["beta"] for s in cfx["sets"]], cfx["theta"], **kw)
+    for spread, N in ((1e-3, 16), (0.05, 24)):
+        p = _perturbed(spread, N)
+        for (atol, rtol), bar_l, bar_h in (((1e-12, 1e-3), 1e-3, 4e-3), ((1e-13, 1e-6), 2e-6, 1e-5), ((1e-14, 1e-9), 1e-8, 1e-7)):
+            uq = mk(atol=atol, rtol=rtol, solver=solver)
+            loss, grad, hrr = uq.solve(p, want_grad=False, want_hrr=True)
+            assert grad is None and np.all(uq.last_retcode == 0)
+            nacc = 0
+            for n in range(N):
+                for i, s in enumerate(cfx["sets"]):
+                    r = orc.cathode_solve_one(orc.make_cathode(s["beta"], atol=atol, rtol=rtol, solver=osolver), p[n] * th, s["ts"], s["dbar"],
+                                              s["d2bar"], want_grad=False)
+                    D = len(s["ts"])
+                    assert r["retcode"] == 0 and uq.last_n_saved[n, i] == D
+                    assert abs(loss[n, i] - r["loss"]) < bar_l * abs(r["loss"]), (spread, rtol, n, i)
+                    assert np.max(np.abs(hrr[n, i, :D] - r["hrr"])) < bar_h * np.max(np.abs(r["hrr"])), (spread, rtol, n, i)
+                    nacc += r["naccept"]
+            # (at rtol 1e-9 the wide cloud switches back and forth on 100-150 of its trajectories, and where a switch falls is
+            #  round-off: the totals then differ by up to 12 %, the results by 3e-9)
+            assert abs(uq.last_stats["n_accept"] - nacc) < (0.04 if rtol > 1e-8 else 0.2) * nacc
+            # the gradient launch of the same context is the Rosenbrock23 adjoint, untouched by the solver setting
+            if rtol == 1e-3 and spread == 0.05:
+                ref = mk(atol=atol, rtol=rtol)
+                l0, g0, _ = ref.solve(p[:4])
+                l1, g1, _ = uq.solve(p[:4])
+                assert np.array_equal(l0, l1) and np.array_equal(g0, g1)
+                # and the primal of the two steppers agrees to solver tolerance (Tsit5 of order 5 against Rosenbrock23 of order 2 at rtol 1e-3)
+                lr, _, _ = ref.solve(p, want_grad=False)
+                assert np.max(np.abs(loss - lr) / lr) < 5e-2
+
+
+@pytest.mark.gpu
+def test_gpu_cathode_composite_primal_matches_golden_at_tight_tolerance(cfx):
+    """north_star's bar: trajectories within 1e-6 of the converged solution -- the composite at tight tolerance against the Radau
+    vectors of the reference's own data (measured 1e-9)."""
+    from crnn_amd.cathode import CathodeUQ
+    for solver in ("autotsit5_trbdf2", "autotsit5_rosenbrock23"):
+        uq = CathodeUQ([_two_replicas(s) for s in cfx["sets"]], [s["beta"] for s in cfx["sets"]], cfx["theta"], atol=1e-14, rtol=1e-9, solver=solver)
+        loss, _, hrr = uq.solve(np.ones((1, 17)), want_grad=False, want_hrr=True)
+        for i, s in enumerate(cfx["sets"]):
+            D = len(s["ts"])
+            assert np.max(np.abs(hrr[0, i, :D] - np.array(s["hrr"]))) < 1e-6 * np.max(np.abs(s["hrr"]))
+            assert abs(loss[0, i] - s["loss"]) < 1e-6 * s["loss"]
+        heat, tt = uq.pred_n_ode(np.ones(17), 2)          # the reference surface goes through the same launch
+        assert np.max(np.abs(heat - np.array(cfx["sets"][2]["hrr"]))) < 1e-6 * np.max(np.abs(cfx["sets"][2]["hrr"]))
+    with pytest.raises(Exception):
+        uq.set_solver(7)
+
+
+@pytest.mark.gpu
+def test_gpu_cathode_composite_config5_full_size(orc, cfx):
+    """BASELINE config 5 at full size through the reference's composite, primal: every solve succeeds, a third of Rosenbrock23's
+    accepted steps, tiles bit-identical wherever they sat in the queue, 48 random rows within solver tolerance of the oracle."""
+    from crnn_amd.cathode import CathodeUQ
+    betas, exp_data = _many_rates(cfx, 256)
+    uq = CathodeUQ(exp_data, betas, cfx["theta"], normalizer=np.ones((256, 3)), solver="autotsit5_trbdf2")
+    rng = np.random.default_rng(55)
+    base = 1 + 1e-3 * rng.standard_normal((16, 17))
+    base[:, 6:9] = 0.0
+    p = np.tile(base, (256, 1))
+    loss, _, _ = uq.solve(p, want_grad=False)
+    st = uq.last_stats
+    assert st["n_traj"] == 4096 * 256 == st["n_ok"] and 100 < st["n_accept"] / st["n_traj"] < 130
+    L4 = loss.reshape(256, 16, 256)
+    assert np.array_equal(L4, np.broadcast_to(L4[0], L4.shape))
+    ps = np.array(cfx["theta"])
+    for _ in range(48):
+        n, i = int(rng.integers(0, 4096)), int(rng.integers(0, 256))
+        e = exp_data[i]
+        r = orc.cathode_solve_one(orc.make_cathode(betas[i], solver=3), p[n] * ps, e[:, 0], e[:, 1:].mean(axis=1), (e[:, 1:] ** 2).mean(axis=1),
+                                  want_grad=False)
+        assert r["retcode"] == 0 and abs(loss[n, i] - r["loss"]) < 1e-3 * abs(r["loss"])
+    print(f"config 5 through AutoTsit5(TRBDF2), primal: kernel {st['kernel_ms']:.1f} ms, {st['n_accept'] / st['n_traj']:.0f} steps/trajectory")
+
+
 @pytest.mark.gpu
 def test_gpu_device_resident_svgd_loop_matches_host_driven_loop(orc, cfx):
     """crnn_cathode_set_particles / crnn_cathode_svgd_step (particles, per-particle gradients, median select and move all on the

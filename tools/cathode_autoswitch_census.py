@@ -46,8 +46,11 @@ p = 1 + a.spread * rng.standard_normal((a.particles, 17))
 p[:, 6:9] = 0.0
 theta = p * np.array(fx["theta"])[:17]
 out = {}
-for name, solver in (("AutoTsit5 composite (restated AutoSwitch, stiff branch = Rosenbrock23 standing in)", 2), ("Rosenbrock23 (what the device runs)", 0)):
-    c = orc.make_cathode(1.0, solver=solver)
+ap_solvers = (("AutoTsit5(TRBDF2) -- the reference's algorithm (restated AutoSwitch + restated TRBDF2 / Newton machinery, smooth_est as the package reads)", 3, 0),
+              ("AutoTsit5(TRBDF2), Shampine's scaling of the smoothed estimate", 3, 1),
+              ("AutoTsit5 composite (restated AutoSwitch, stiff branch = Rosenbrock23)", 2, 0), ("Rosenbrock23 (the device's gradient path)", 0, 0))
+for name, solver, est in ap_solvers:
+    c = orc.make_cathode(1.0, solver=solver, trbdf2_est=est)
     t0 = time.time()
     r = orc.cathode_census(c, theta, betas, ts, D, nthreads=a.threads)
     r["seconds"] = time.time() - t0

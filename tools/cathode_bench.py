@@ -48,3 +48,17 @@ for name, kw in (("primal (loss)", dict(want_grad=False)), ("primal + HRR", dict
         uq.solve(p, **kw)
         ms.append(uq.last_stats["kernel_ms"])
     print(f"  {name}: kernel_ms median {np.median(ms):.2f}")
+# the same primal launches through the reference's composite (network.jl:195) -- crnn_cathode_set_solver
+l_ros, _, _ = uq.solve(p, want_grad=False)
+for solver in ("autotsit5_trbdf2", "autotsit5_rosenbrock23"):
+    uq.set_solver(solver)
+    for name, kw in (("primal (loss)", dict(want_grad=False)), ("primal + HRR", dict(want_grad=False, want_hrr=True))):
+        ms = []
+        for _ in range(max(2, args.reps)):
+            l_c, _, _ = uq.solve(p, **kw)
+            ms.append(uq.last_stats["kernel_ms"])
+        st = uq.last_stats
+        print(f"  {solver} {name}: kernel_ms median {np.median(ms):.2f}; steps/traj {st['n_accept'] / st['n_traj']:.1f} rej/traj "
+              f"{st['n_reject'] / st['n_traj']:.2f} ok {st['n_ok']}/{st['n_traj']}; max |loss - loss_rosenbrock23| / loss "
+              f"{np.max(np.abs(l_c - l_ros) / l_ros):.2e}")
+uq.set_solver("rosenbrock23")
