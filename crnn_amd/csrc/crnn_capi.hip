@@ -20,6 +20,7 @@
 #include "tsit5_sens_kernel.hpp"
 #include "hychem_kernel.hpp"
 #include "hychem2_kernel.hpp"
+#include "hychem_auto_kernel.hpp"
 #include "tsit5_kernel.hpp"
 #include "auto_adj_kernel.hpp"
 #include "ros23_adj2_kernel.hpp"
@@ -626,12 +627,24 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
     // (32 768: 8.12 -> 6.06 ms, all 262 144 of config 4 on one GPU: 35.3 -> 27.2 ms)
     // Gradient accumulators: the one-lane kernel keeps 210 per trajectory in HBM (global atomics, reduce_gacc_kernel); the pair
     // kernel sums over the 32 trajectories of a batch with FP64 MFMAs and writes one row per batch.
-    const int G = c->lanes_per_traj == 1 ? 1 : 2;
+    // AutoTsit5(Rosenbrock23) (crnn_pyrolysis_mass.jl:29): primal launches run the composite (hychem_auto_kernel, a lane pair per
+    // trajectory); gradient launches run the Rosenbrock23 adjoint with Rosenbrock23's controller constants (hychem_auto_kernel.hpp)
+    const bool composite = c->cfg.solver == CRNN_SOLVER_AUTOTSIT5;
+    const bool auto_primal = composite && P == 0;
+    const int G = (c->lanes_per_traj == 1 && !auto_primal) ? 1 : 2;
     const size_t gacc_need = G == 1 ? (size_t)((count + 63) / 64) * nth * 64 : 0;
     c->last_lanes = G;
     const int kHyBlock = 128 * G;
-    KFn fn = G == 2 ? (P > 0 ? (KFn)crnn::hychem2_kernel<9, 10, true, 256> : (KFn)crnn::hychem2_kernel<9, 10, false, 256>)
-                    : (P > 0 ? (KFn)crnn::hychem_kernel<9, 10, true, 128> : (KFn)crnn::hychem_kernel<9, 10, false, 128>);
+    KFn fn = auto_primal ? (KFn)crnn::hychem_auto_kernel<9, 10, 256>
+             : G == 2 ? (P > 0 ? (KFn)crnn::hychem2_kernel<9, 10, true, 256> : (KFn)crnn::hychem2_kernel<9, 10, false, 256>)
+                      : (P > 0 ? (KFn)crnn::hychem_kernel<9, 10, true, 128> : (KFn)crnn::hychem_kernel<9, 10, false, 128>);
+    struct CtlGuard {   // a gradient launch of a composite context: Rosenbrock23's PI exponents and steady band for this launch
+        Ctx *c; bool on; double b1, b2, qs;
+        CtlGuard(Ctx *c_, bool on_) : c(c_), on(on_), b1(c_->cfg.beta1), b2(c_->cfg.beta2), qs(c_->cfg.qsteady_max) {
+            if (on) { c->cfg.beta1 = 7.0 / 20.0; c->cfg.beta2 = 2.0 / 10.0; c->cfg.qsteady_max = 1.2; c->kc_dirty = true; }
+        }
+        ~CtlGuard() { if (on) { c->cfg.beta1 = b1; c->cfg.beta2 = b2; c->cfg.qsteady_max = qs; c->kc_dirty = true; } }
+    } ctl_guard(c, composite && P > 0);
     int occ = 0;
     HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, kHyBlock, 0));
     if (occ < 1) occ = 1;
@@ -1189,9 +1202,9 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
     c->nfx = c->hychem ? 2 : cfg->has_temp;
     c->n_theta = crnn::n_theta_of(cfg->ns, cfg->nr, c->nfx);
     c->n_params = crnn::n_params_of(cfg->param_map, cfg->ns, cfg->nr, c->nfx);
-    if (c->hychem && (cfg->has_temp != 0 || cfg->solver != CRNN_SOLVER_ROSENBROCK23 || !(cfg->gas_const > 0))) {
+    if (c->hychem && (cfg->has_temp != 0 || (cfg->solver != CRNN_SOLVER_ROSENBROCK23 && cfg->solver != CRNN_SOLVER_AUTOTSIT5) || !(cfg->gas_const > 0))) {
         delete c;
-        return fail(nullptr, "crnn_ctx_create: HyChem needs has_temp = 0, Rosenbrock23 and gas_const > 0");
+        return fail(nullptr, "crnn_ctx_create: HyChem needs has_temp = 0, Rosenbrock23 or AutoTsit5(Rosenbrock23), and gas_const > 0");
     }
     if (c->n_params < 0) { delete c; return fail(nullptr, "crnn_ctx_create: unknown param_map"); }
     c->use_scale = false;

@@ -1913,8 +1913,8 @@ int orc_cathode_census(const orc_cathode *c0, const double *theta /*[n_part][17]
  *   Y2density, Y2C, crnn!       :107-131     (T = itpT(t), P = itpP(t): LinearInterpolation on tsteps, :103-104)
  *   predict_n_ode / loss_n_ode  :135-147     (saveat = tsteps[1:sample], mae(pred ./ yscale, data ./ yscale))
  *   ForwardDiff.gradient        :201
- * Stepper: non-autonomous Rosenbrock23 (the reference's AutoTsit5(Rosenbrock23(autodiff=false)) in its stiff branch),
- * dT = df/dt analytic on the current table segment (the reference takes a finite difference).  Tangents: complex step
+ * Stepper: non-autonomous Rosenbrock23 (solver 0: the reference's AutoTsit5(Rosenbrock23(autodiff=false)) in its stiff branch)
+ * or that composite itself (solver 2), dT = df/dt analytic on the current table segment (the reference takes a finite difference).  Tangents: complex step
  * per direction (theta + i h dtheta_k, u + i h s_k) through the same step arithmetic with the real W factorisation,
  * dt held real -- ForwardDiff's arithmetic, and deliberately a different mechanism from the device's analytic adjoint.
  * PARITY UNPINNED for solver internals (no Manifest, no reference tests); pinned against Radau + sensitivities of
@@ -1922,7 +1922,11 @@ int orc_cathode_census(const orc_cathode *c0, const double *theta /*[n_part][17]
  * theta = [ w_in ((ns+2) x nr col-major; row ns: x (-1/(R T)), row ns+1: x log T) | w_b | w_out (ns x nr) ].
  * ======================================================================================================== */
 typedef struct orc_hychem {
-    int32_t ns, nr, maxiters, pad_;
+    int32_t ns, nr, maxiters;
+    int32_t solver;   /* 0 Rosenbrock23; 2 AutoTsit5(Rosenbrock23(autodiff=false)) -- the reference's `ode_solver`
+                         (crnn_pyrolysis_mass.jl:29, used :138-139): Tsit5 with stage times t + c_s dt on the T/P tables, the
+                         AutoSwitch rule of solve_one_auto, Rosenbrock23 (analytic J: the reference's autodiff=false takes finite
+                         differences) as the stiff algorithm; set qsteady_max = 1 with it (a composite is not an implicit type) */
     double lb, ub, inv_R, Ru, atol, rtol;
     double mw[12], scale[12], inv_yscale[12];
     double gamma, qmin, qmax, beta1, beta2, qsteady_min, qsteady_max, qoldinit;
@@ -2064,6 +2068,8 @@ static void hy_csolve(int n, const double *W, const int *piv, cplx *b) {   /* re
     for (int k = n - 1; k >= 0; --k) { b[k] /= W[k + n * k]; cplx a = b[k]; for (int i = 0; i < k; ++i) b[i] -= W[i + n * k] * a; }
 }
 
+_Thread_local int64_t orc_hychem_last_tsit5_steps = 0;   /* accepted Tsit5 steps of the calling thread's last solve (composite) */
+int64_t orc_hychem_tsit5_steps(void) { return orc_hychem_last_tsit5_steps; }
 /* u0 [ns]; ts, Ttab, Ptab [D]; data [ns][D] (species-major rows of length Dfull); pred [ns][Dfull] or NULL;
  * dth [ndir][nth] or NULL; grad [ndir].  Returns the retcode. */
 int orc_hychem_solve_one(const orc_hychem *c, const double *th, const double *dth, int ndir, const double *u0,
@@ -2099,11 +2105,16 @@ int orc_hychem_solve_one(const orc_hychem *c, const double *th, const double *dt
         for (int i = 0; i < ns; ++i) { f1r[i] = creal(f1[i]); double e = (f1r[i] - fr[i]) / sk[i]; d2 += e * e; }
         d2 = sqrt(d2 / ns) / dt0;
         double dm = fmax(d1, d2);
-        double dt1 = dm <= 1e-15 ? fmax(1e-6, dt0 * 1e-3) : pow(10.0, -(2.0 + log10(dm)) / 2.0);
+        double dt1 = dm <= 1e-15 ? fmax(1e-6, dt0 * 1e-3) : pow(10.0, -(2.0 + log10(dm)) / (c->solver == 2 ? 5.0 : 2.0));   /* order of the starting algorithm */
         dt = fmin(fmin(100 * dt0, dt1), dtmax);
     }
     double qold = c->qoldinit, loss_sum = 0.0;
     int jsave = 0, retcode = 0, iter = 0;
+    const int composite = c->solver == 2;
+    int alg = composite ? 0 : 1, cnt = 0, have_est = 0;
+    int64_t n_ts5 = 0;
+    double eigen_est = 0.0;
+    cplx *KT = composite ? (cplx *)malloc(sizeof(cplx) * 7 * (size_t)K * ns) : NULL;   /* Tsit5 stage slopes of all copies: KT[(s * K + k) * ns + i] */
 #define HY_SAVE(UEXPR)                                                                                           \
     do {                                                                                                         \
         for (int i = 0; i < ns; ++i) {                                                                           \
@@ -2122,20 +2133,75 @@ int orc_hychem_solve_one(const orc_hychem *c, const double *th, const double *dt
     int piv[12];
     while (jsave < D) {
         if (++iter > c->maxiters) { retcode = 1; break; }
+        if (composite && have_est) {   /* choose_algorithm!, as in solve_one_auto */
+            const int stiff = fabs(eigen_est * dt / AS_STAB) > AS_TOL;      /* false for NaN */
+            cnt = stiff ? (cnt < 0 ? 1 : cnt + 1) : (cnt > 0 ? -1 : cnt - 1);
+            if (alg == 0 && cnt > AS_MAXSTIFF) { dt *= AS_DTFAC; alg = 1; }
+            else if (alg == 1 && cnt < -AS_MAXNONSTIFF) { dt /= AS_DTFAC; alg = 0; }
+        }
         int last = 0;
         if (t + dt * (1.0 + 1e-13) >= tend) { dt = tend - t; last = 1; }
         if (!(dt > 0.0) || t + dt == t) { retcode = 2; break; }
         const double gam = d * dt, tm = t + 0.5 * dt, tnew = last ? tend : t + dt;
         double Tm, Pm, T2, P2;
+        int finite = 1;
+        double ev[12], EEst = 0.0;
+        cplx ftk[12], fdum[12];
+        if (alg == 0 && composite) {
+            /* ---- Tsit5 attempt: stage s at t + c_s dt on the tables (the seventh at the step's end time) ---- */
+            for (int pass = 0; pass < 2; ++pass) {
+                for (int k = 0; k < K; ++k) {
+                    if (pass == 0 ? (k != PR) : !(k < ndir)) continue;
+                    cplx gk[12], g6[12];
+                    const cplx *thc = thk + (size_t)k * nth;
+                    for (int i = 0; i < ns; ++i) { KT[((size_t)0 * K + k) * ns + i] = f0[k * ns + i]; g6[i] = 0.0; }
+                    for (int s_ = 1; s_ < 7; ++s_) {
+                        for (int i = 0; i < ns; ++i) {
+                            cplx a = 0.0;
+                            for (int j = 0; j < s_; ++j) a += TS_A[s_][j] * KT[((size_t)j * K + k) * ns + i];
+                            gk[i] = u[k * ns + i] + dt * a;
+                        }
+                        if (s_ == 5) for (int i = 0; i < ns; ++i) g6[i] = gk[i];
+                        if (s_ == 6) for (int i = 0; i < ns; ++i) un[k * ns + i] = gk[i];
+                        const double tq = s_ == 6 ? tnew : t + TS_C[s_] * dt;
+                        double Tq, Pq;
+                        hy_tab(ts, Dfull, Ttab, tq, &Tq, NULL); hy_tab(ts, Dfull, Ptab, tq, &Pq, NULL);
+                        hy_eval(c, thc, gk, Tq, Pq, 0, 0, KT + ((size_t)s_ * K + k) * ns, NULL, NULL);
+                    }
+                    for (int i = 0; i < ns; ++i) f2[k * ns + i] = KT[((size_t)6 * K + k) * ns + i];
+                    if (k == PR) {
+                        double est = 0.0; int isnan_ = 0;
+                        for (int i = 0; i < ns; ++i) {
+                            cplx a = 0.0;
+                            for (int j = 0; j < 7; ++j) a += TS_BT[j] * KT[((size_t)j * K + k) * ns + i];
+                            ev[i] = dt * creal(a);
+                            if (!isfinite(creal(un[k * ns + i])) || !isfinite(ev[i])) finite = 0;
+                            const double q_ = fabs(creal(KT[((size_t)6 * K + k) * ns + i] - KT[((size_t)5 * K + k) * ns + i]) / creal(un[k * ns + i] - g6[i]));
+                            if (q_ != q_) isnan_ = 1; else if (q_ > est) est = q_;
+                        }
+                        eigen_est = isnan_ ? NAN : est;
+                    }
+                }
+                if (pass == 0) {
+                    if (!finite) break;
+                    double s_ = 0.0;
+                    for (int i = 0; i < ns; ++i) { double m = fmax(fabs(creal(u[PR * ns + i])), fabs(creal(un[PR * ns + i]))); double e = ev[i] / (c->atol + c->rtol * m); s_ += e * e; }
+                    EEst = sqrt(s_ / ns);
+                    if (!(EEst <= 1.0) || ndir == 0) break;
+                }
+            }
+        } else {
         hy_tab(ts, Dfull, Ttab, t, &Tn, &Tdn); hy_tab(ts, Dfull, Ptab, t, &Pn, &Pdn);
         hy_tab(ts, Dfull, Ttab, tm, &Tm, NULL); hy_tab(ts, Dfull, Ptab, tm, &Pm, NULL);
         hy_tab(ts, Dfull, Ttab, tnew, &T2, NULL); hy_tab(ts, Dfull, Ptab, tnew, &P2, NULL);
-        cplx ftk[12], fdum[12];
         hy_eval(c, thk + (size_t)PR * nth, u + PR * ns, Tn, Pn, Tdn, Pdn, fdum, Jk, ftk);
+        {   /* eigen_est of the stiff algorithm: opnorm(J, Inf) */
+            double est = 0.0;
+            for (int i = 0; i < ns; ++i) { double a = 0.0; for (int cc = 0; cc < ns; ++cc) a += fabs(creal(Jk[i + ns * cc])); if (a > est) est = a; }
+            eigen_est = est;
+        }
         for (int i = 0; i < ns * ns; ++i) W[i] = ((i % ns) == (i / ns) ? 1.0 : 0.0) - gam * creal(Jk[i]);
         if (lu_factor(ns, W, piv) != 0) { retcode = 3; break; }
-        int finite = 1;
-        double ev[12], EEst = 0.0;
         for (int pass = 0; pass < 2; ++pass) {
             for (int k = 0; k < K; ++k) {
                 if (pass == 0 ? (k != PR) : !(k < ndir)) continue;
@@ -2169,18 +2235,30 @@ int orc_hychem_solve_one(const orc_hychem *c, const double *th, const double *dt
                 if (!(EEst <= 1.0) || ndir == 0) break;
             }
         }
+        }
+        have_est = 1;
         if (!finite) { retcode = 3; break; }
         const int accept = (EEst <= 1.0);
+        const double b1_ = composite ? (alg == 0 ? 7.0 / 50.0 : 7.0 / 20.0) : c->beta1;
+        const double b2_ = composite ? (alg == 0 ? 2.0 / 25.0 : 2.0 / 10.0) : c->beta2;
         double q, q11 = 0.0;
         if (EEst == 0.0) q = 1.0 / c->qmax;
-        else { q11 = pow(EEst, c->beta1); q = q11 / pow(qold, c->beta2); q = fmax(1.0 / c->qmax, fmin(1.0 / c->qmin, q / c->gamma)); }
+        else { q11 = pow(EEst, b1_); q = q11 / pow(qold, b2_); q = fmax(1.0 / c->qmax, fmin(1.0 / c->qmin, q / c->gamma)); }
         if (accept) {
             if (st) st->naccept++;
+            if (alg == 0 && composite) n_ts5++;
             if (q >= c->qsteady_min && q <= c->qsteady_max) q = 1.0;
             qold = fmax(EEst, c->qoldinit);
             while (jsave < D && ts[jsave] <= tnew) {
                 const double tsv = ts[jsave];
                 if (tsv == tnew) { HY_SAVE(un[k * ns + i]); }
+                else if (alg == 0 && composite) {
+                    double bth[7];
+                    orc_tsit5_dense((tsv - t) / dt, bth);
+#define KTI(s_) KT[((size_t)(s_) * K + k) * ns + i]
+                    HY_SAVE(u[k * ns + i] + dt * (bth[0] * KTI(0) + bth[1] * KTI(1) + bth[2] * KTI(2) + bth[3] * KTI(3) + bth[4] * KTI(4) + bth[5] * KTI(5) + bth[6] * KTI(6)));
+#undef KTI
+                }
                 else {
                     const double Th = (tsv - t) / dt;
                     const double c1 = Th * (1.0 - Th) / (1.0 - 2.0 * d), c2 = Th * (Th - 2.0 * d) / (1.0 - 2.0 * d);
@@ -2200,7 +2278,8 @@ int orc_hychem_solve_one(const orc_hychem *c, const double *th, const double *dt
     if (loss_out) *loss_out = jsave > 0 ? loss_sum / den : 0.0;
     if (grad) for (int k = 0; k < ndir; ++k) grad[k] = jsave > 0 ? g[k] / den : 0.0;
     if (n_saved_out) *n_saved_out = jsave;
-    free(W); free(Jk); free(thk); free(ws); free(g);
+    orc_hychem_last_tsit5_steps = n_ts5;
+    free(W); free(Jk); free(thk); free(ws); free(g); free(KT);
     return retcode;
 }
 

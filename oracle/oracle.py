@@ -317,7 +317,7 @@ def cathode_census(c, theta, beta, ts, D, nthreads=0):
 
 # ---------------------------------------------------------------------------- HyChem restatement
 class Hychem(C.Structure):
-    _fields_ = [("ns", C.c_int32), ("nr", C.c_int32), ("maxiters", C.c_int32), ("pad_", C.c_int32),
+    _fields_ = [("ns", C.c_int32), ("nr", C.c_int32), ("maxiters", C.c_int32), ("solver", C.c_int32),
                 ("lb", C.c_double), ("ub", C.c_double), ("inv_R", C.c_double), ("Ru", C.c_double),
                 ("atol", C.c_double), ("rtol", C.c_double),
                 ("mw", C.c_double * 12), ("scale", C.c_double * 12), ("inv_yscale", C.c_double * 12),
@@ -331,7 +331,8 @@ def lu_swaps(reset=True):
     return int(lib().orc_lu_swaps(C.c_int(1 if reset else 0)))
 
 
-def make_hychem(dydt_scale=None, yscale=None, atol=None, rtol=None, maxiters=None):
+def make_hychem(dydt_scale=None, yscale=None, atol=None, rtol=None, maxiters=None, solver=0):
+    """solver 0: Rosenbrock23; 2: AutoTsit5(Rosenbrock23(autodiff=false)) -- the reference's `ode_solver` (crnn_pyrolysis_mass.jl:29)."""
     c = Hychem()
     lib().orc_hychem_defaults(C.byref(c))
     assert lib().orc_sizeof_hychem() == C.sizeof(Hychem)
@@ -346,6 +347,9 @@ def make_hychem(dydt_scale=None, yscale=None, atol=None, rtol=None, maxiters=Non
         c.rtol = rtol
     if maxiters is not None:
         c.maxiters = int(maxiters)
+    c.solver = int(solver)
+    if solver == 2:
+        c.qsteady_max = 1.0          # a composite is not an implicit algorithm type (see solve_one_auto)
     return c
 
 
@@ -382,7 +386,9 @@ def hychem_solve_one(c, theta, u0, ts, Ttab, Ptab, data, dtheta=None, sample=Non
                                     _dp(np.ascontiguousarray(Ttab, float)), _dp(np.ascontiguousarray(Ptab, float)),
                                     _dp(np.ascontiguousarray(data, float)), _dp(pred), C.byref(loss), _dp(grad),
                                     C.byref(nsv), C.cast(st, C.c_void_p))
-    return dict(loss=loss.value, grad=grad[:ndir], pred=pred, retcode=rc, n_saved=nsv.value, naccept=st[0], nreject=st[1])
+    lib().orc_hychem_tsit5_steps.restype = C.c_int64
+    return dict(loss=loss.value, grad=grad[:ndir], pred=pred, retcode=rc, n_saved=nsv.value, naccept=st[0], nreject=st[1],
+                n_tsit5=int(lib().orc_hychem_tsit5_steps()))
 
 
 def svgd_update(p, lnpgrad, stepsize, h=-1.0):
