@@ -131,6 +131,8 @@ SYMBOLS = {
     "crnn_cathode_allgather": (C.c_int32, [_CTX, _DP, C.c_int64, C.c_int32, C.c_int64, _DP]),
     "crnn_cathode_set_tape_every": (C.c_int32, [_CTX, C.c_int32]),
     "crnn_cathode_set_solver": (C.c_int32, [_CTX, C.c_int32]),
+    "crnn_cathode_set_errnorm_sens": (C.c_int32, [_CTX, C.c_int32, _DP]),
+    "crnn_cathode_last_chunk_stats": (C.c_int32, [_CTX, C.POINTER(C.c_int64)]),
     "crnn_cathode_set_particles": (C.c_int32, [_CTX, _DP, _DP, C.c_int64]),
     "crnn_cathode_svgd_step": (C.c_int32, [_CTX, C.c_int32, _DP, C.c_double, C.c_double, _DP, _DP, _DP]),
     "crnn_cathode_get_particles": (C.c_int32, [_CTX, _DP]),

@@ -79,7 +79,7 @@ class CathodeUQ:
     """exp_data: list of arrays [D_s, 1 + n_replicas] (col 0 = time in s, dataset.jl:19-23), heating_rates in K/min."""
 
     def __init__(self, exp_data, heating_rates, p_scales, *, atol=None, rtol=None, maxiters=None, lb_clamp=None, device=0,
-                 normalizer=None, grad_mode=None, tape_every=None, solver=None):
+                 normalizer=None, grad_mode=None, tape_every=None, solver=None, errnorm_sens=0):
         self.cfg = CathodeConfig()
         check(lib.crnn_cathode_config_default(C.byref(self.cfg)))
         self.cfg.device = device
@@ -93,6 +93,8 @@ class CathodeUQ:
         if solver is not None:         # stepper of the primal calls: "autotsit5_trbdf2" = the reference's `alg` (network.jl:195)
             self.set_solver(solver)
         self.p_scales = np.asarray(p_scales, float)[:17].copy()
+        if errnorm_sens:               # gradient calls as ForwardDiff evaluates them (network.jl:232): chunks of 9 + 8, partials in the error norm
+            self._check(lib.crnn_cathode_set_errnorm_sens(self.h, int(errnorm_sens), dptr(np.ascontiguousarray(self.p_scales))))
         self.beta = np.ascontiguousarray(heating_rates, np.float64)
         self.exp_data = [np.asarray(e, float) for e in exp_data]
         self.n_sets = len(self.exp_data)
@@ -118,6 +120,12 @@ class CathodeUQ:
 
     SOLVERS = {"rosenbrock23": L.CATH_SOLVER_ROSENBROCK23, "autotsit5_trbdf2": L.CATH_SOLVER_AUTOTSIT5_TRBDF2,
                "autotsit5_rosenbrock23": L.CATH_SOLVER_AUTOTSIT5_ROS23}
+
+    def last_chunk_stats(self):
+        """[(accepted, rejected)] summed over the trajectories for the two ForwardDiff chunks of the last errnorm_sens gradient call."""
+        out = (C.c_int64 * 4)()
+        self._check(lib.crnn_cathode_last_chunk_stats(self.h, out))
+        return [(int(out[0]), int(out[1])), (int(out[2]), int(out[3]))]
 
     def set_solver(self, solver):
         """Stepper of the PRIMAL calls (pred_n_ode, loss_neuralode, solve(want_grad=False)): "rosenbrock23" (default),

@@ -26,6 +26,7 @@
 #include "ros23_adj2_kernel.hpp"
 #include "cathode_kernel.hpp"
 #include "cathode_auto_kernel.hpp"
+#include "cathode_sens_kernel.hpp"
 #include "svgd_kernel.hpp"
 
 namespace {
@@ -139,6 +140,11 @@ struct Ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     static constexpr int kRing = 64;
+    static constexpr int kSpreadRing = 4;
+    int32_t *d_spread = nullptr, *h_spread = nullptr;        // step-count spread of a launch {longest, median, count}: device slot, pinned host ring
+    hipEvent_t ev_spread[kSpreadRing] = {};
+    int64_t spread_first[kSpreadRing] = {}, spread_count[kSpreadRing] = {};
+    uint64_t spread_n = 0;                                   // spreads recorded in a row (0: no history)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;           // events of the most recent solve kernel
     hipEvent_t ring0[kRing] = {}, ring1[kRing] = {};   // ring of (start, stop) pairs, one per launch
     int64_t n_launch = 0;
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(1024) void reduce_opt_sort_kernel(const double *__r
                                                                double *__restrict__ red_theta, double *red,   // no restrict
                                                                const unsigned int *overflow_in,
                                                                const int32_t *__restrict__ n_accept, const int32_t *__restrict__ n_reject,
-                                                               int64_t first, int count, int32_t *__restrict__ perm,
+                                                               int64_t first, int count, int32_t *__restrict__ perm, int32_t *__restrict__ spread,
                                                                crnn::OptCfg o, int npart, double *p, double *state, int pmap, int ns,
                                                                int nr, int has_temp, double *th, double *dth,
                                                                unsigned long long *queue, unsigned int *overflow, double *poison) {
@@ -378,8 +384,10 @@ __global__ __launch_bounds__(1024) void reduce_opt_sort_kernel(const double *__r
         __threadfence_block();
         __syncthreads();          // red[] is complete and visible to the whole block; dtheta_in is not read any more
         opt_body<1024>(o, P, npart, p, red, state, pmap, ns, nr, has_temp, th, dth, nth, queue, overflow, poison, sh);
+    } else if (spread && blockIdx.x == gridDim.x - 1) {
+        crnn::step_spread_block(n_accept, n_reject, first, count, spread, key);
     } else if (perm) {
-        crnn::sort_steps_run(n_accept, n_reject, first, count, perm, (int)blockIdx.x - 1, (int)gridDim.x - 1, key);
+        crnn::sort_steps_run(n_accept, n_reject, first, count, perm, (int)blockIdx.x - 1, (int)gridDim.x - 1 - (spread ? 1 : 0), key);
     }
 }
 
@@ -492,6 +500,7 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
     // the chip then uses its idle lanes to shorten every step instead of leaving them empty (lanes_per_traj = AUTO), or
     // wherever the caller asks for it (crnn_ctx_set_lanes_per_traj).
     int G = 1;
+    bool want_spread = false;
     const bool primal = (P == 0 && k->fn_primal != nullptr);   // forward sweep only: no tape, no reverse sweep, one lane per trajectory
                                                                // (the Tsit5 / AutoTsit5 tape kernels run their primal calls themselves, P = 0)
     if (const AdjEntry *k2 = (!primal && k->solver == CRNN_SOLVER_ROSENBROCK23 && c->lanes_per_traj != 1) ? find_adjoint2(c) : nullptr) {
@@ -501,6 +510,24 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
         }
         const int64_t resident_pairs = (int64_t)c->num_cu * c->adj2_occ * (kBlock / 2);
         if (c->lanes_per_traj == 2 || count <= (int64_t)k2->max_gen * resident_pairs) { G = 2; k = k2; }
+        else if (c->lanes_per_traj == 0 && count <= 2 * (int64_t)k2->max_gen * resident_pairs) {
+            // AUTO beyond one generation of pairs (round 4): two generations of pairs, longest first, last about
+            // 0.6 (longest + median) step times of the one-lane kernel, one lane per trajectory lasts `longest` of them (one
+            // wavefront per SIMD either way; ros23_adj2_kernel.hpp has the measurements) -- pairs win where the step counts
+            // spread (a trained p: longest 48, median 29), single lanes where they do not (the initialiser: 25 / 23).  The
+            // spread is that of the launch BEFORE the previous one over the same range (step_spread_block; its 12 bytes were
+            // copied out behind that launch, so waiting for them never waits for the launch in flight): the choice is a
+            // deterministic function of the run's own history, like the queue order.
+            want_spread = true;
+            if (c->spread_n >= 2) {
+                const int slot = (int)((c->spread_n - 2) % Ctx::kSpreadRing);
+                if (c->spread_first[slot] == first && c->spread_count[slot] == count) {
+                    HIP_TRY(c, hipEventSynchronize(c->ev_spread[slot]));
+                    const int32_t *h = c->h_spread + 4 * slot;
+                    if (h[2] == (int32_t)count && 8 * (int64_t)h[1] <= 5 * (int64_t)h[0]) { G = 2; k = k2; }   // median <= 0.625 longest
+                }
+            }
+        }
     }
     if (!primal) c->last_lanes = G;      // (crnn_last_lanes_per_traj reports gradient launches)
     const int occ = G == 2 ? c->adj2_occ : c->adj_occ;
@@ -572,17 +599,27 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
     // them in the same launch as the reduction
     const bool sort_next = c->queue_order == CRNN_QUEUE_AUTO && ((size_t)count > lanes || count >= 2048) && count < ((int64_t)1 << 31);
     if (sort_next && ensure(c, &c->d_perm, &c->perm_cap, (size_t)count)) return -1;
+    want_spread = want_spread && sort_next && !primal;
+    if (want_spread && !c->h_spread) {
+        // pinned, host-coherent, mapped: the sort launch's extra block writes the three numbers straight into the host ring (no copy
+        // operation in the stream -- a 12-byte hipMemcpyAsync cost 30 us of every step); the event behind the launch orders the read
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_spread, 4 * Ctx::kSpreadRing * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_spread, c->h_spread, 0));
+        for (int i = 0; i < Ctx::kSpreadRing; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_spread[i], hipEventDisableTiming));
+    }
+    int32_t *const spread = want_spread ? c->d_spread + 4 * (c->spread_n % Ctx::kSpreadRing) : nullptr;
+    const unsigned sort_blocks = sort_next ? (unsigned)((count + 1023) / 1024) + (spread ? 1u : 0u) : 0u;
     if (c->fuse_opt && defer) {   // crnn_train_step without a communicator: reduction, optimiser update and the next launch's sort in one
-        hipLaunchKernelGGL(reduce_opt_sort_kernel, dim3(1 + (sort_next ? (unsigned)((count + 1023) / 1024) : 0u)), dim3(1024), 0, c->stream,
+        hipLaunchKernelGGL(reduce_opt_sort_kernel, dim3(1 + sort_blocks), dim3(1024), 0, c->stream,
                            c->d_partials, nbatch, d_dtheta, nth, P, c->d_red_theta, c->d_red, c->d_overflow, c->d_nacc, c->d_nrej,
-                           first, (int)count, sort_next ? c->d_perm : nullptr, c->opt, npart, c->d_p, c->d_opt, c->cfg.param_map,
+                           first, (int)count, sort_next ? c->d_perm : nullptr, spread, c->opt, npart, c->d_p, c->d_opt, c->cfg.param_map,
                            c->cfg.ns, c->cfg.nr, c->nfx, c->d_theta, c->d_dtheta, c->d_queue, c->d_overflow, c->d_poison);
         c->opt_fused = true;
         c->perm_ready = sort_next; c->perm_first = first; c->perm_count = count;
     } else if (sort_next) {
-        hipLaunchKernelGGL(crnn::reduce_project_sort_kernel, dim3(1 + (unsigned)((count + 1023) / 1024)), dim3(1024), 0, c->stream,
+        hipLaunchKernelGGL(crnn::reduce_project_sort_kernel, dim3(1 + sort_blocks), dim3(1024), 0, c->stream,
                            c->d_partials, nbatch, d_dtheta, nth, P, c->d_red_theta, c->d_red, c->d_overflow, c->d_nacc, c->d_nrej,
-                           first, (int)count, c->d_perm);
+                           first, (int)count, c->d_perm, spread);
         c->perm_ready = true; c->perm_first = first; c->perm_count = count;
     } else {
         hipLaunchKernelGGL(crnn::reduce_project_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_partials, nbatch, d_dtheta, nth, P,
@@ -590,6 +627,12 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
         c->perm_ready = false;
     }
     HIP_TRY(c, hipGetLastError());
+    if (spread) {   // the spread travels to the host behind the launch; launch n + 2 over the same range reads it
+        const int slot = (int)(c->spread_n % Ctx::kSpreadRing);
+        HIP_TRY(c, hipEventRecord(c->ev_spread[slot], c->stream));
+        c->spread_first[slot] = first; c->spread_count[slot] = count;
+        ++c->spread_n;
+    } else if (!primal) c->spread_n = 0;    // another launch shape in between: the history starts over
     c->last_npart = npart;
     c->last_P = P;
     c->steps_first = first; c->steps_count = count;     // d_nacc / d_nrej of this range are current once the launch has run
@@ -1010,6 +1053,9 @@ struct CathCtx {
     size_t ag_send_cap = 0, ag_recv_cap = 0;
     int adj_occ = 0, fwd_occ = 0, prim_occ = 0;
     int solver = CRNN_CATH_SOLVER_ROSENBROCK23, auto_occ[2] = {0, 0};   // stepper of primal launches (crnn_cathode_set_solver)
+    int errnorm_sens = 0, sens_occ[2] = {0, 0};   // gradient launches as ForwardDiff evaluates them (crnn_cathode_set_errnorm_sens)
+    double *d_dirscale = nullptr;                 // [17] d theta / d p of the chunked dual-norm gradient
+    int64_t chunk_stats[4] = {0, 0, 0, 0};        // accepted / rejected steps of the two chunk launches of the last gradient call
     int tape_every = CRNN_CATH_TAPE_EVERY;   // adjoint tape: 1 = every step in full, 4 / 8 = checkpoint every 4th / 8th step
     // device-resident SVGD loop (crnn_cathode_set_particles / crnn_cathode_svgd_step)
     double *d_pn = nullptr, *d_pn2 = nullptr, *d_lnp = nullptr, *d_pscales = nullptr;   // particles (current / moved), lnpgrad, [p_scales(17) | mean loss, n_failed]
@@ -1269,6 +1315,8 @@ void crnn_ctx_destroy(crnn_ctx *ctx) {
     void *ptrs[] = {c->d_perm, c->d_red_asm, c->d_poison, c->d_tabs, c->d_gacc, c->d_tape, c->d_overflow, c->d_red_theta, c->d_queue, c->d_nacc, c->d_nrej, c->d_gtraj, c->d_kc, c->d_tsave, c->d_pred, c->d_loss, c->d_ret, c->d_nsaved, c->d_theta, c->d_dtheta,
                     c->d_partials, c->d_red, c->d_p, c->d_p_eval, c->d_opt, c->d_comm_buf};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (c->h_spread) (void)hipHostFree(c->h_spread);     // (d_spread is its device alias)
+    for (int i = 0; i < Ctx::kSpreadRing; ++i) if (c->ev_spread[i]) (void)hipEventDestroy(c->ev_spread[i]);
     for (int i = 0; i < Ctx::kRing; ++i) {
         if (c->ring0[i]) (void)hipEventDestroy(c->ring0[i]);
         if (c->ring1[i]) (void)hipEventDestroy(c->ring1[i]);
@@ -1878,7 +1926,7 @@ void crnn_cathode_destroy(crnn_cathode_ctx *ctx) {
     if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
     void *ptrs[] = {c->d_ts, c->d_dbar, c->d_d2bar, c->d_beta, c->d_D, c->d_queue, c->d_theta, c->d_loss, c->d_grad,
                     c->d_hrr, c->d_ret, c->d_nsv, c->d_nacc, c->d_nrej, c->d_tape, c->d_overflow, c->d_ag_send, c->d_ag_recv,
-                    c->d_pn, c->d_pn2, c->d_lnp, c->d_pscales};
+                    c->d_pn, c->d_pn2, c->d_lnp, c->d_pscales, c->d_dirscale};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     c->svgd.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -1931,6 +1979,8 @@ namespace {
 // retcode / n_saved / step counts in the ctx's device buffers.  Adjoint first (unless grad_mode says forward); a trajectory
 // that outruns the tape makes the call repeat with forward tangents (one 4-byte read-back decides).
 int32_t cath_run(CathCtx *c, int64_t n_part, int set_first, int set_count, bool want_grad, bool want_hrr) {
+    const bool grad_requested = want_grad;
+    (void)grad_requested;
     const int64_t ntraj = n_part * set_count;
     if ((size_t)ntraj > c->cap_traj) {
         if (cgrow(c, &c->d_loss, (size_t)ntraj) || cgrow(c, &c->d_grad, (size_t)ntraj * CRNN_CATHODE_NP) ||
@@ -1959,6 +2009,37 @@ int32_t cath_run(CathCtx *c, int64_t n_part, int set_first, int set_count, bool 
     prm.qsteady_min = c->cfg.qsteady_min; prm.qsteady_max = c->cfg.qsteady_max; prm.qoldinit = c->cfg.qoldinit;
     constexpr int kB = 256;
     bool done = false;
+    if (want_grad && c->errnorm_sens != 0) {
+        // The gradient as the reference evaluates it (network.jl:232): ForwardDiff's two chunks of p, each its own adaptive solve whose
+        // error norm weighs the chunk's partials (cathode_sens_kernel.hpp); loss, heat-release curves, return codes and step statistics
+        // are those of the plain solve that follows.
+        crnn::CathSensParams sp{};
+        sp.dir_scale = c->d_dirscale; sp.mode = c->errnorm_sens; sp.dual_partials = 9;
+        crnn::CathodeParams prs = prm;
+        prs.hrr = nullptr; prs.want_grad = 1;
+        std::vector<int32_t> h_a((size_t)ntraj), h_r((size_t)ntraj);
+        for (int ch = 0; ch < 2; ++ch) {
+            using SensFn = void (*)(const crnn::CathodeParams, const crnn::CathSensParams);
+            const SensFn fn = ch == 0 ? (SensFn)crnn::cathode_sens_kernel<kB, 0> : (SensFn)crnn::cathode_sens_kernel<kB, 1>;
+            if (c->sens_occ[ch] < 1) {
+                CHIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->sens_occ[ch], (const void *)fn, kB, 0));
+                if (c->sens_occ[ch] < 1) c->sens_occ[ch] = 1;
+            }
+            const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((ntraj + kB - 1) / kB, (int64_t)c->num_cu * c->sens_occ[ch]));
+            CHIP(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), c->stream));
+            hipLaunchKernelGGL(fn, dim3(nblk), dim3(kB), 0, c->stream, prs, sp);
+            CHIP(c, hipGetLastError());
+            CHIP(c, hipMemcpyAsync(h_a.data(), c->d_nacc, sizeof(int32_t) * ntraj, hipMemcpyDeviceToHost, c->stream));
+            CHIP(c, hipMemcpyAsync(h_r.data(), c->d_nrej, sizeof(int32_t) * ntraj, hipMemcpyDeviceToHost, c->stream));
+            CHIP(c, hipStreamSynchronize(c->stream));
+            int64_t sa = 0, sr = 0;
+            for (int64_t i = 0; i < ntraj; ++i) { sa += h_a[i]; sr += h_r[i]; }
+            c->chunk_stats[2 * ch] = sa; c->chunk_stats[2 * ch + 1] = sr;
+        }
+        CHIP(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), c->stream));
+        prm.grad = nullptr; prm.want_grad = 0;      // the gradient rows are complete; what follows is the plain solve
+        want_grad = false;
+    }
     const bool primal = !want_grad;      // primal calls: the adjoint kernel's forward sweep alone (cathode_adj_kernel<..., PRIMAL>)
     if (primal && c->solver != CRNN_CATH_SOLVER_ROSENBROCK23) {
         // the reference's composite (network.jl:195): cathode_auto_kernel, a wavefront takes 64 particles of one heating rate
@@ -2117,6 +2198,30 @@ int32_t crnn_cathode_set_solver(crnn_cathode_ctx *ctx, int32_t solver) {
     if (solver != CRNN_CATH_SOLVER_ROSENBROCK23 && solver != CRNN_CATH_SOLVER_AUTOTSIT5_TRBDF2 && solver != CRNN_CATH_SOLVER_AUTOTSIT5_ROS23)
         return cfail(c, "crnn_cathode_set_solver: solver must be CRNN_CATH_SOLVER_ROSENBROCK23, _AUTOTSIT5_TRBDF2 or _AUTOTSIT5_ROS23");
     c->solver = solver;
+    return 0;
+}
+
+int32_t crnn_cathode_set_errnorm_sens(crnn_cathode_ctx *ctx, int32_t mode, const double *p_scales) {
+    CathCtx *c = reinterpret_cast<CathCtx *>(ctx);
+    if (!c) return cfail(nullptr, "null ctx");
+    if (mode < 0 || mode > 2) return cfail(c, "crnn_cathode_set_errnorm_sens: mode must be 0 (off), 1 or 2");
+    if (mode != 0 && !p_scales) return cfail(c, "crnn_cathode_set_errnorm_sens: p_scales (d theta / d p, 17 entries) is required");
+    CHIP(c, hipSetDevice(c->cfg.device));
+    if (mode != 0) {
+        for (int k = 0; k < CRNN_CATHODE_NP; ++k)
+            if (!std::isfinite(p_scales[k])) return cfail(c, "crnn_cathode_set_errnorm_sens: p_scales must be finite");
+        if (!c->d_dirscale) CHIP(c, hipMalloc((void **)&c->d_dirscale, sizeof(double) * CRNN_CATHODE_NP));
+        CHIP(c, hipStreamSynchronize(c->stream));
+        CHIP(c, hipMemcpy(c->d_dirscale, p_scales, sizeof(double) * CRNN_CATHODE_NP, hipMemcpyHostToDevice));
+    }
+    c->errnorm_sens = mode;
+    return 0;
+}
+
+int32_t crnn_cathode_last_chunk_stats(crnn_cathode_ctx *ctx, int64_t *out /* [4] */) {
+    CathCtx *c = reinterpret_cast<CathCtx *>(ctx);
+    if (!c || !out) return cfail(c, "crnn_cathode_last_chunk_stats: null");
+    for (int i = 0; i < 4; ++i) out[i] = c->chunk_stats[i];
     return 0;
 }
 

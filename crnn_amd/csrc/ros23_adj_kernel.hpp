@@ -902,6 +902,31 @@ __device__ __forceinline__ void sort_steps_run(const int32_t *__restrict__ n_acc
         perm[pos] = base + (int)(key[tid] & 1023u);
     }
 }
+// Spread of a launch's step counts (accepted + rejected, clipped like the sort key): { longest, lower median, count }.  What
+// lanes_per_traj = AUTO needs to choose between one lane and a lane pair per trajectory when the pairs need a second generation
+// (crnn_capi.hip: launch_adjoint) -- a deterministic function of the launch, formed by one extra block of the sort launch.
+__device__ __forceinline__ void step_spread_block(const int32_t *__restrict__ n_accept, const int32_t *__restrict__ n_reject,
+                                                  int64_t first, int count, int32_t *__restrict__ spread, unsigned *hist /* 1024 words */) {
+    const int tid = threadIdx.x;
+    __shared__ int mx_s;
+    hist[tid] = 0u;
+    if (tid == 0) mx_s = 0;
+    __syncthreads();
+    for (int e = tid; e < count; e += 1024) atomicAdd(&hist[min(max(n_accept[first + e] + n_reject[first + e], 0), 1023)], 1u);
+    __syncthreads();
+    const unsigned own = hist[tid];
+    if (own) atomicMax(&mx_s, tid);
+    // inclusive prefix sums over the 1 024 bins (Hillis-Steele in place: ten rounds; a serial scan by one thread cost 40 us)
+    for (int off = 1; off < 1024; off <<= 1) {
+        const unsigned v = hist[tid] + (tid >= off ? hist[tid - off] : 0u);
+        __syncthreads();
+        hist[tid] = v;
+        __syncthreads();
+    }
+    const unsigned incl = hist[tid], rank = (unsigned)((count - 1) / 2);
+    if (own && incl - own <= rank && rank < incl) spread[1] = tid;     // the bin that holds the lower median
+    if (tid == 0) { spread[0] = mx_s; spread[2] = count; }
+}
 __global__ __launch_bounds__(1024) void sort_steps_kernel(const int32_t *__restrict__ n_accept, const int32_t *__restrict__ n_reject,
                                                           int64_t first, int count, int32_t *__restrict__ perm) {
     __shared__ unsigned key[1024];
@@ -924,14 +949,16 @@ __device__ __forceinline__ void reduce_project_body(const double *__restrict__ p
         const int k = c0 + col;
         double a0 = 0.0, a1 = 0.0;
         if (k < npart) {
-            // rows rl, rl + 16, rl + 32, ... ; eight loads in flight per step of the loop (the sum order stays fixed: even
-            // positions of the row sequence into a0, odd ones into a1)
-            for (int bI = rl; bI < nblk; bI += 128) {
-                double v[8];
+            // rows rl, rl + 16, rl + 32, ... ; sixteen loads in flight per step of the loop (thirty-two spill: a 1 024-thread block has 128 registers per lane) (the sum order stays fixed: even
+            // positions of the row sequence into a0, odd ones into a1).  This block is alone on the critical path between two solve
+            // launches and every step of this loop is one exposed memory latency: with eight loads in flight the 2 048 batch rows of a
+            // lane-pair launch took 50 us (1 024 rows: 18 us).
+            for (int bI = rl; bI < nblk; bI += 256) {
+                double v[16];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = (bI + 16 * q < nblk) ? partials[(size_t)(bI + 16 * q) * npart + k] : 0.0;
+                for (int q = 0; q < 16; ++q) v[q] = (bI + 16 * q < nblk) ? partials[(size_t)(bI + 16 * q) * npart + k] : 0.0;
 #pragma unroll
-                for (int q = 0; q < 8; q += 2) { a0 += v[q]; a1 += v[q + 1]; }
+                for (int q = 0; q < 16; q += 2) { a0 += v[q]; a1 += v[q + 1]; }
             }
         }
         part[rl][col] = a0 + a1;
@@ -975,12 +1002,14 @@ __global__ __launch_bounds__(1024) void reduce_project_sort_kernel(const double 
                                                                    const unsigned int *__restrict__ overflow,
                                                                    const int32_t *__restrict__ n_accept,
                                                                    const int32_t *__restrict__ n_reject, int64_t first, int count,
-                                                                   int32_t *__restrict__ perm) {
+                                                                   int32_t *__restrict__ perm, int32_t *__restrict__ spread) {
     __shared__ double sh[256];
     __shared__ double part[16][64];
     __shared__ unsigned key[1024];
+    const int extra = spread ? 1 : 0;        // one more block at the end of the grid: the spread of the step counts
     if (blockIdx.x == 0) reduce_project_body(partials, nblk, dtheta, nth, P, red_theta, out, overflow, sh, part);
-    else sort_steps_run(n_accept, n_reject, first, count, perm, (int)blockIdx.x - 1, (int)gridDim.x - 1, key);
+    else if (extra && blockIdx.x == gridDim.x - 1) step_spread_block(n_accept, n_reject, first, count, spread, key);
+    else sort_steps_run(n_accept, n_reject, first, count, perm, (int)blockIdx.x - 1, (int)gridDim.x - 1 - extra, key);
 }
 
 }  // namespace crnn

@@ -394,6 +394,17 @@ int32_t crnn_cathode_set_tape_every(crnn_cathode_ctx *ctx, int32_t every);
 #define CRNN_CATH_SOLVER_AUTOTSIT5_TRBDF2 1
 #define CRNN_CATH_SOLVER_AUTOTSIT5_ROS23 2
 int32_t crnn_cathode_set_solver(crnn_cathode_ctx *ctx, int32_t solver);
+/* The gradient as the reference evaluates it: `ForwardDiff.gradient(x -> loss_neuralode(x, i_exp), p_temp)` (network.jl:232) pushes
+ * Duals through the adaptive solve, in ForwardDiff's chunks of the 17 normalised parameters (9, then 8 and a zero partial), every
+ * chunk its own adaptive solve, the error norm weighing the chunk's partials (crnn_config.errnorm_sens has the norm; mode 1:
+ * / length(u); mode 2: / totallength(u), the form of the DiffEqBase 6.189 this project's Manifest pins).  p_scales[17] = d theta / d p
+ * (network.jl:152-157): the partials in the norm are those with respect to p.  mode != 0: a gradient call = two chunk launches
+ * (forward tangents through every attempt, Rosenbrock23: cathode_sens_kernel.hpp) + the plain solve whose loss / curves / return
+ * codes it reports; the gradient is still returned with respect to theta.  mode 0 (default): primal-only norm, discrete adjoint
+ * (about three times faster; the two gradients differ by up to a few 1e-3 of their largest entry at reltol 1e-3).
+ * crnn_cathode_last_chunk_stats: {accepted, rejected} steps summed over the trajectories, for chunk 1 and chunk 2 of the last call. */
+int32_t crnn_cathode_set_errnorm_sens(crnn_cathode_ctx *ctx, int32_t mode, const double *p_scales /* [17] */);
+int32_t crnn_cathode_last_chunk_stats(crnn_cathode_ctx *ctx, int64_t *out /* [4] */);
 int32_t crnn_cathode_svgd_step(crnn_cathode_ctx *ctx, int32_t i_set, const double *normalizer2 /* [17] */, double stepsize, double h,
                                double *loss_mean, double *h_out, double *ms);
 int32_t crnn_cathode_get_particles(crnn_cathode_ctx *ctx, double *p);

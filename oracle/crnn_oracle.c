@@ -1418,6 +1418,14 @@ typedef struct orc_cathode {
                            machinery restated (cath_trbdf2_* below; primal only);
                          4 TRBDF2 alone (to test the stepper by itself) */
     double gamma, qmin, qmax, beta1, beta2, qsteady_min, qsteady_max, qoldinit;
+    /* errnorm_sens != 0 (Rosenbrock23, gradient solves): ForwardDiff.gradient(x -> loss_neuralode(x, i_exp), p_temp) (network.jl:232)
+       pushes Duals through the adaptive solve in chunks of 9 (+ 8 and one zero partial) of the 17 normalised parameters, and the
+       error norm weighs the partials (solve_one_ws has the formula; 1: / length(u), 2: / totallength(u) -- the cathode Manifest pins
+       DiffEqBase 6.189, the totallength era).  One call = ONE chunk: the directions [dir_lo, dir_lo + dir_n) of theta, each scaled by
+       dir_scale[k] = d theta_k / d p_k = p_scales[k] (network.jl:152-157) in the norm, dual_partials partials per Dual (9).  The
+       gradient is still returned with respect to theta; entries outside the chunk are zero. */
+    int32_t errnorm_sens, dir_lo, dir_n, dual_partials;
+    double dir_scale[17];
     int32_t trbdf2_est;   /* TRBDF2's smoothed error estimate (smooth_est = true, the default): 0 = `W \ tmp` with the W the Newton
                              iteration holds, W = J - I/(gamma dt) -- what the package's perform_step! reads like; 1 = Shampine's
                              (I - gamma dt J)^-1 tmp (differs by the factor gamma dt).  [UNVERIFIED-DEP] */
@@ -1628,6 +1636,10 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
     const int P = grad ? 17 : 0;
     const int composite = (c->solver == 2 || c->solver == 3), trbdf2 = (c->solver == 3 || c->solver == 4);
     if (trbdf2 && grad) return -1;   /* TRBDF2 is restated for primal solves only */
+    const int sens = (c->errnorm_sens != 0 && grad != NULL);
+    if (sens && (c->solver != 0 || c->dir_n < 1 || c->dir_lo < 0 || c->dir_lo + c->dir_n > 17)) return -1;   /* Rosenbrock23 only */
+#define ACT(k) ((k) < P && (!sens || ((k) >= c->dir_lo && (k) < c->dir_lo + c->dir_n)))
+    const double sens_div = c->errnorm_sens == 2 ? 3.0 * (1.0 + (double)c->dual_partials) : 3.0;
     const double t0 = ts[0], tend = ts[D - 1];
     double t = t0;
     cplx u[18][3];   /* u[P] = primal (imag 0); u[k] = primal + i h s_k */
@@ -1638,21 +1650,29 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
     }
     const int PR = 17;  /* index of the primal copy */
     cplx f0[18][3];
-    for (int k = 0; k <= 17; ++k) if (k == PR || k < P) cath_rhs(c, thk[k], u[k], t, f0[k]);
-    /* initial step (Hairer, order 2) on the primal */
+    for (int k = 0; k <= 17; ++k) if (k == PR || ACT(k)) cath_rhs(c, thk[k], u[k], t, f0[k]);
+    /* initial step (Hairer, order 2) on the primal; with errnorm_sens every norm of it is the dual-inclusive one (init_dt_sens) */
     double dt;
     {
         double sk[3], d0 = 0, d1 = 0, d2 = 0, ur[3], fr[3], u1[3], f1[3];
         for (int i = 0; i < 3; ++i) { ur[i] = creal(u[PR][i]); fr[i] = creal(f0[PR][i]); sk[i] = c->atol + fabs(ur[i]) * c->rtol;
             d0 += (ur[i] / sk[i]) * (ur[i] / sk[i]); d1 += (fr[i] / sk[i]) * (fr[i] / sk[i]); }
-        d0 = sqrt(d0 / 3); d1 = sqrt(d1 / 3);
+        if (sens) for (int k = 0; k < 17; ++k) if (ACT(k)) for (int i = 0; i < 3; ++i) { double e = c->dir_scale[k] * cimag(f0[k][i]) / h / sk[i]; d1 += e * e; }
+        const double dv = sens ? sens_div : 3.0;
+        d0 = sqrt(d0 / dv); d1 = sqrt(d1 / dv);
         double dtmax = tend - t0;
         double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
         dt0 = fmin(dt0, dtmax);
         for (int i = 0; i < 3; ++i) u1[i] = ur[i] + dt0 * fr[i];
         cath_rhs_real(c, th, u1, t + dt0, f1);
         for (int i = 0; i < 3; ++i) { double e = (f1[i] - fr[i]) / sk[i]; d2 += e * e; }
-        d2 = sqrt(d2 / 3) / dt0;
+        if (sens) for (int k = 0; k < 17; ++k) if (ACT(k)) {
+            cplx u1k[3], f1k[3];
+            for (int i = 0; i < 3; ++i) u1k[i] = u[k][i] + dt0 * f0[k][i];
+            cath_rhs(c, thk[k], u1k, t + dt0, f1k);
+            for (int i = 0; i < 3; ++i) { double e = c->dir_scale[k] * cimag(f1k[i] - f0[k][i]) / h / sk[i]; d2 += e * e; }
+        }
+        d2 = sqrt(d2 / dv) / dt0;
         double dm = fmax(d1, d2);
         double dt1 = dm <= 1e-15 ? fmax(1e-6, dt0 * 1e-3) : pow(10.0, -(2.0 + log10(dm)) / (composite ? 5.0 : 2.0));   /* the order of the starting algorithm */
         dt = fmin(fmin(100 * dt0, dt1), dtmax);
@@ -1663,7 +1683,7 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
 #define CATH_SAVE(UARR_EXPR, tsv)                                                                                \
     do {                                                                                                        \
         cplx hv[18];                                                                                            \
-        for (int k = 0; k <= 17; ++k) if (k == PR || k < P) {                                                   \
+        for (int k = 0; k <= 17; ++k) if (k == PR || ACT(k)) {                                                  \
             cplx uu[3], r[3];                                                                                   \
             for (int i = 0; i < 3; ++i) uu[i] = (UARR_EXPR);                                                    \
             cath_rates(c, thk[k], uu, (tsv), r);                                                                \
@@ -1672,7 +1692,7 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
         double hp = creal(hv[PR]), e = hp - dbar[jsave];                                                        \
         if (hrr) hrr[jsave] = hp;                                                                               \
         loss_sum += e * e + (d2bar[jsave] - dbar[jsave] * dbar[jsave]);                                         \
-        for (int k = 0; k < P; ++k) g[k] += 2.0 * e * cimag(hv[k]) / h;                                         \
+        for (int k = 0; k < P; ++k) if (ACT(k)) g[k] += 2.0 * e * cimag(hv[k]) / h;                             \
         ++jsave;                                                                                                \
     } while (0)
     CATH_SAVE(u[k][i], t0);   /* saveat contains tspan[1] */
@@ -1710,7 +1730,7 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
             /* ---- Tsit5 attempt (non-autonomous: stage s at t + c_s dt) ---- */
             for (int pass = 0; pass < 2; ++pass) {
                 for (int k = 0; k <= 17; ++k) {
-                    if (pass == 0 ? (k != PR) : !(k < P)) continue;
+                    if (pass == 0 ? (k != PR) : !ACT(k)) continue;
                     cplx g[3], g6[3] = {0, 0, 0};
                     for (int i = 0; i < 3; ++i) KT[0][k][i] = f0[k][i];
                     for (int s_ = 1; s_ < 7; ++s_) {
@@ -1786,7 +1806,7 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
         if (lu_factor(3, W, piv) != 0) { retcode = 3; break; }
         for (int pass = 0; pass < 2; ++pass) {       /* pass 0: primal (and accept test), pass 1: tangents if accepted */
             for (int k = 0; k <= 17; ++k) {
-                if (pass == 0 ? (k != PR) : !(k < P)) continue;
+                if (pass == 0 ? (k != PR) : !ACT(k)) continue;
                 cplx Jk[9], ftk[3], b[3], u1[3], f1[3], tmp[3];
                 cath_jac_ft(c, thk[k], u[k], t, Jk, ftk);
                 /* W_k k1 = f0 + gam ft, with W_k = W + i h W': solve with the real W and move i h W' k1 to the rhs:
@@ -1801,10 +1821,12 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
                 csolve3(W, piv, tmp);
                 for (int i = 0; i < 3; ++i) { k2[k][i] = tmp[i] + k1[k][i]; un[k][i] = u[k][i] + dt * k2[k][i]; }
                 cath_rhs(c, thk[k], un[k], t + dt, f2[k]);
-                if (k == PR) {
+                if (k == PR || sens) {   /* the third stage: the primal's for the error estimate, with errnorm_sens the tangents' too */
                     for (int i = 0; i < 3; ++i) b[i] = f2[k][i] - c32 * (k2[k][i] - f1[i]) - 2.0 * (k1[k][i] - f0[k][i]) + dt * ftk[i];
+                    if (k != PR) for (int i = 0; i < 3; ++i) for (int cc = 0; cc < 3; ++cc) b[i] += gam * (Jk[i + 3 * cc] - creal(Jk[i + 3 * cc])) * creal(k3[PR][cc]);
                     csolve3(W, piv, b);
-                    for (int i = 0; i < 3; ++i) { k3[k][i] = b[i]; ev[i] = dt / 6.0 * creal(k1[k][i] - 2.0 * k2[k][i] + k3[k][i]);
+                    for (int i = 0; i < 3; ++i) k3[k][i] = b[i];
+                    if (k == PR) for (int i = 0; i < 3; ++i) { ev[i] = dt / 6.0 * creal(k1[k][i] - 2.0 * k2[k][i] + k3[k][i]);
                         if (!isfinite(creal(un[k][i])) || !isfinite(ev[i])) finite = 0; }
                 }
             }
@@ -1813,7 +1835,24 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
                 double s_ = 0.0;
                 for (int i = 0; i < 3; ++i) { double m = fmax(fabs(creal(u[PR][i])), fabs(creal(un[PR][i]))); double e = ev[i] / (c->atol + c->rtol * m); s_ += e * e; }
                 EEst = sqrt(s_ / 3.0);
-                if (!(EEst <= 1.0) || P == 0) break;
+                if (!sens && (!(EEst <= 1.0) || P == 0)) break;
+            } else if (sens) {
+                /* the dual-inclusive norm (solve_one_ws): value and the chunk's partials, each partial taken with respect to the
+                   normalised parameter p_k = theta_k / dir_scale[k] */
+                double ssum = 0.0;
+                for (int i = 0; i < 3; ++i) {
+                    double na = creal(u[PR][i]) * creal(u[PR][i]), nb = creal(un[PR][i]) * creal(un[PR][i]), ee = ev[i] * ev[i];
+                    for (int k = 0; k < 17; ++k) if (ACT(k)) {
+                        const double sc = c->dir_scale[k] / h;
+                        const double s_ = sc * cimag(u[k][i]), sn_ = sc * cimag(un[k][i]);
+                        const double de = sc * dt / 6.0 * cimag(k1[k][i] - 2.0 * k2[k][i] + k3[k][i]);
+                        na += s_ * s_; nb += sn_ * sn_; ee += de * de;
+                    }
+                    const double scl = c->atol + c->rtol * sqrt(fmax(na, nb));
+                    ssum += ee / (scl * scl);
+                }
+                EEst = sqrt(ssum / sens_div);
+                if (!isfinite(EEst)) finite = 0;
             }
         }
         }
@@ -1857,7 +1896,7 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
                     CATH_SAVE(u[k][i] + dt * (c1 * k1[k][i] + c2 * k2[k][i]), tsv);
                 }
             }
-            for (int k = 0; k <= 17; ++k) if (k == PR || k < P) for (int i = 0; i < 3; ++i) { u[k][i] = un[k][i]; f0[k][i] = f2[k][i]; }
+            for (int k = 0; k <= 17; ++k) if (k == PR || ACT(k)) for (int i = 0; i < 3; ++i) { u[k][i] = un[k][i]; f0[k][i] = f2[k][i]; }
             t = tnew;
             dt = fmin(dt / q, tend - t0);
         } else {
@@ -1866,6 +1905,7 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
         }
     }
 #undef CATH_SAVE
+#undef ACT
     /* loss = sum(...)/n_replicas/size(exp_data)[1]: divided by the FULL number of rows (network.jl:266) */
     if (loss_out) *loss_out = loss_sum / (double)D;
     if (grad) for (int k = 0; k < 17; ++k) grad[k] = g[k] / (double)D;

@@ -259,6 +259,8 @@ class Cathode(C.Structure):
                 ("rtol", C.c_double), ("maxiters", C.c_int32), ("solver", C.c_int32),
                 ("gamma", C.c_double), ("qmin", C.c_double), ("qmax", C.c_double), ("beta1", C.c_double),
                 ("beta2", C.c_double), ("qsteady_min", C.c_double), ("qsteady_max", C.c_double), ("qoldinit", C.c_double),
+                ("errnorm_sens", C.c_int32), ("dir_lo", C.c_int32), ("dir_n", C.c_int32), ("dual_partials", C.c_int32),
+                ("dir_scale", C.c_double * 17),
                 ("trbdf2_est", C.c_int32), ("pad_", C.c_int32)]
 
 
@@ -275,6 +277,21 @@ def make_cathode(beta, atol=1e-12, rtol=1e-3, maxiters=2500000, lb_clamp=1e-16, 
     if solver in (2, 3):
         c.qsteady_max = 1.0          # a composite is not an implicit algorithm type (see solve_one_auto)
     return c
+
+
+def cathode_sens_chunks(c, p_scales, mode=2):
+    """ForwardDiff's chunks of the 17 normalised parameters (pickchunksize(17) = 9: p[0:9], then p[9:17] + one zero partial) as
+    configurations of `c` for cathode_solve_one(..., want_grad=True): each chunk is its own adaptive solve whose error norm weighs
+    that chunk's partials (errnorm_sens = mode; dir_scale = p_scales = d theta / d p)."""
+    import copy
+    out = []
+    for lo, n in ((0, 9), (9, 8)):
+        cc = copy.copy(c)
+        cc.errnorm_sens, cc.dir_lo, cc.dir_n, cc.dual_partials = int(mode), lo, n, 9
+        for k in range(17):
+            cc.dir_scale[k] = float(p_scales[k])
+        out.append(cc)
+    return out
 
 
 def cathode_rhs(c, theta, u, t):

@@ -505,6 +505,77 @@ def test_gpu_cathode_composite_config5_full_size(orc, cfx):
     print(f"config 5 through AutoTsit5(TRBDF2), primal: kernel {st['kernel_ms']:.1f} ms, {st['n_accept'] / st['n_traj']:.0f} steps/trajectory")
 
 
+# ------------------------------------------------------------------ the gradient as ForwardDiff evaluates it (network.jl:232)
+def test_oracle_cathode_errnorm_sens_chunks(orc, cfx):
+    """errnorm_sens in the oracle's cathode solve: ForwardDiff's two chunks (9, then 8 + a zero partial) are two different adaptive
+    solves -- their step counts differ from each other and from the plain solve's --, the gradient pieces stay within solver
+    tolerance of the primal-norm gradient, both norms (1: / length(u), 2: / totallength(u)) are distinguishable, and with all
+    direction scales zero the chunks reproduce the plain solve's step sequence."""
+    th = np.array(cfx["theta"])
+    p = _perturbed(0.02, 1)[0]
+    for s in cfx["sets"][::2]:
+        c = orc.make_cathode(s["beta"])
+        r0 = orc.cathode_solve_one(c, p * th, s["ts"], s["dbar"], s["d2bar"])
+        counts = {}
+        for mode in (1, 2):
+            g = np.zeros(17)
+            for cc in orc.cathode_sens_chunks(c, th, mode):
+                r = orc.cathode_solve_one(cc, p * th, s["ts"], s["dbar"], s["d2bar"])
+                assert r["retcode"] == 0 and abs(r["loss"] - r0["loss"]) < 1e-2 * r0["loss"]
+                sl = slice(cc.dir_lo, cc.dir_lo + cc.dir_n)
+                g[sl] = r["grad"][sl]
+                assert np.all(r["grad"][:cc.dir_lo] == 0) and np.all(r["grad"][cc.dir_lo + cc.dir_n:] == 0)
+                counts[(mode, cc.dir_lo)] = (r["naccept"], r["nreject"])
+            assert np.max(np.abs((g - r0["grad"]) * th)) < 2e-2 * np.max(np.abs(r0["grad"] * th))
+        assert len(set(counts.values()) | {(r0["naccept"], r0["nreject"])}) >= 4
+        for cc in orc.cathode_sens_chunks(c, np.zeros(17), 1):
+            r = orc.cathode_solve_one(cc, p * th, s["ts"], s["dbar"], s["d2bar"])
+            assert (r["naccept"], r["nreject"]) == (r0["naccept"], r0["nreject"]) and abs(r["loss"] - r0["loss"]) < 1e-12 * r0["loss"]   # (the norm is formed in another order: last bits)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 2])
+def test_gpu_cathode_errnorm_sens_matches_oracle_chunk_for_chunk(orc, cfx, mode):
+    """crnn_cathode_set_errnorm_sens: the two chunk launches (cathode_sens_kernel) against the oracle's chunked solves on perturbed
+    particles x the reference's heating rates -- the same step sequences (accepted / rejected counts per chunk, summed over the
+    trajectories, identical), gradient pieces to 1e-7 of the largest entry (with respect to p), loss and curves of the call those of
+    the plain solve."""
+    from crnn_amd.cathode import CathodeUQ
+    th = np.array(cfx["theta"])
+    N = 6
+    p = _perturbed(0.03, N, seed=17)
+    uq = CathodeUQ([_two_replicas(s) for s in cfx["sets"]], [s["beta"] for s in cfx["sets"]], cfx["theta"], errnorm_sens=mode)
+    ref = CathodeUQ([_two_replicas(s) for s in cfx["sets"]], [s["beta"] for s in cfx["sets"]], cfx["theta"])
+    loss, grad, hrr = uq.solve(p, want_hrr=True)
+    l0, g0, h0 = ref.solve(p, want_hrr=True)
+    n_acc_plain = ref.last_stats["n_accept"]
+    lp, _, hp = ref.solve(p, want_grad=False, want_hrr=True)
+    assert np.array_equal(loss, lp) and np.array_equal(hrr, hp)            # the plain (primal) solve's, bit for bit
+    assert np.max(np.abs(loss - l0) / l0) < 1e-12                           # (the adjoint launch sums the same loss terms backwards)
+    assert uq.last_stats["n_accept"] == n_acc_plain
+    tot = np.zeros((2, 2), np.int64)
+    for n in range(N):
+        for i, s in enumerate(cfx["sets"]):
+            c = orc.make_cathode(s["beta"])
+            g = np.zeros(17)
+            for ch, cc in enumerate(orc.cathode_sens_chunks(c, th, mode)):
+                r = orc.cathode_solve_one(cc, p[n] * th, s["ts"], s["dbar"], s["d2bar"])
+                assert r["retcode"] == 0
+                g[cc.dir_lo:cc.dir_lo + cc.dir_n] = r["grad"][cc.dir_lo:cc.dir_lo + cc.dir_n]
+                tot[ch] += (r["naccept"], r["nreject"])
+            assert np.max(np.abs(grad[n, i] - g * th)) < 1e-7 * np.max(np.abs(g * th)), (n, i)
+    # the same step sequences: the per-chunk totals agree (to one or two attempts in 11 000: a decision that sits on the threshold of
+    # `EEst <= 1` can fall the other way in the last bit -- the gradients above agree to 1e-7 nonetheless)
+    assert np.max(np.abs(tot - np.array(uq.last_chunk_stats()))) <= 2, (tot, uq.last_chunk_stats())
+    # the two gradients are different numbers (a few 1e-3 at reltol 1e-3), and the dual-norm chunks take their own step counts
+    assert 1e-5 < np.max(np.abs(grad - g0)) / np.max(np.abs(g0)) < 5e-2
+    assert uq.last_chunk_stats()[0][0] != n_acc_plain
+    # dlnprob goes through the same call
+    l, lnp = uq.dlnprob(p, 2)
+    from crnn_amd.cathode import NORMALIZER, NORM_COL
+    assert np.allclose(lnp, -grad[:, 2] / NORMALIZER[2, NORM_COL] ** 2, rtol=0, atol=0)
+
+
 @pytest.mark.gpu
 def test_gpu_device_resident_svgd_loop_matches_host_driven_loop(orc, cfx):
     """crnn_cathode_set_particles / crnn_cathode_svgd_step (particles, per-particle gradients, median select and move all on the

@@ -157,3 +157,47 @@ def test_training_steps_agree_and_auto_picks_two_lanes_for_small_shards(case2_se
             nr.set_lanes_per_traj(2)                   # robertson (ns < nr, scaled): no two-lane instantiation
         finally:
             nr.close()
+
+
+def test_auto_beyond_one_generation_follows_the_step_count_spread():
+    """65 536 trajectories = two generations of lane pairs: lanes_per_traj = AUTO decides from the spread of the step counts of the
+    launch before the previous one over the same range (crnn_capi.hip: launch_adjoint / step_spread_block) -- pairs where the
+    counts spread (the reference's trained p: longest 48 against a median of 29), single lanes where they do not (its initialiser:
+    nearly uniform counts).  The choice is a function of the run's own history: two runs are bit-identical; whichever kernel
+    runs, the results are the forced kernels' (per-trajectory losses 1e-10 against the other kernel, bit-identical to its own)."""
+    import json
+    import os
+    from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE2, cases
+    B = 65536
+    rng = np.random.Generator(np.random.PCG64(1234))
+    ts = cases.case2_tsteps()
+    u0 = cases.case2_u0(B, rng)
+    gen = NeuralODE(ODEProblem(PRESET_CASE2, ts, atol=1e-10, rtol=1e-8))
+    clean = gen.predict_theta(u0, cases.case2_true_theta())[:, :6, :]
+    gen.close()
+    data = cases.add_noise(clean, 0.05, rng)
+    s = dict(tsteps=ts, u0=u0, data=data, yscale=cases.max_min(data, lb=LB_CASE2))
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fixtures.json")))
+    p_ckpt = np.array(fx["case2_ckpt"]["p"])
+    p_init = cases.case2_init_p(np.random.Generator(np.random.PCG64(7)))
+    for p, want in ((p_ckpt, 2), (p_init, 1)):
+        runs = []
+        for _ in range(2):
+            node = _node(s, 0)
+            seq = []
+            for _ in range(4):
+                l, g = node.loss_and_grad(p)
+                seq.append((node.last_lanes_per_traj(), l, g.copy()))
+            na, nr = node.step_counts()
+            runs.append(seq)
+            node.close()
+        steps = na + nr
+        print(f"longest {steps.max()} median {int(np.median(steps))} -> lanes {[q[0] for q in runs[0]]}")
+        assert [q[0] for q in runs[0]] == [1, 1, want, want]            # no history for the first two launches
+        for a, b in zip(runs[0], runs[1]):                              # deterministic: a function of the run's own history
+            assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2])
+        forced = _node(s, want)
+        forced.loss_and_grad(p); forced.loss_and_grad(p)
+        lf, gf = forced.loss_and_grad(p)                                 # third launch of the forced kernel: the same queue history
+        assert runs[0][2][1] == pytest.approx(lf, rel=1e-12) and np.max(np.abs(runs[0][2][2] - gf)) < 1e-10 * np.max(np.abs(gf))
+        forced.close()
