@@ -7,7 +7,7 @@
 //   * OrdinaryDiffEq's AutoSwitch rule as auto_adj_kernel.hpp restates it (eigen estimate of every attempt, more than 10 stiff /
 //     3 non-stiff verdicts in a row, dt * 2 and dt / 2 at the switches, PI exponents of the running algorithm, steady band [1, 1]);
 //   * the stiff algorithm: STIFF_TRBDF2 = true -> TRBDF2 with OrdinaryDiffEq's Newton machinery (the reference's choice; restated
-//     in oracle/crnn_oracle.c: cath_trbdf2_nlsolve, where every branch is described and marked [UNVERIFIED-DEP]); false ->
+//     branch by branch in DESIGN.md section 2 "TRBDF2", every branch marked [UNVERIFIED-DEP]); false ->
 //     Rosenbrock23 (the stepper the gradient path uses), the composite round 3 measured.
 // On BASELINE config 5's ensemble 97 % of the trajectories never leave Tsit5 and 0.2-0.4 % of all accepted steps are stiff ones
 // (tools/cathode_autoswitch_census.py): 114 accepted steps per trajectory against Rosenbrock23's 338.
@@ -19,7 +19,7 @@
 // reference escapes it because ForwardDiff's partials sit inside its error norm.  Gradient calls stay on the L-stable
 // Rosenbrock23 adjoint whatever the solver setting.  And even the primal is only reproducible to solver tolerance across
 // implementations: round-off in the invisible modes is amplified until the controller sees it, so two correct implementations of
-// this composite (this kernel and the oracle) take a slightly different number of steps on some trajectories; their losses agree
+// this composite (this kernel and the CPU restatement the tests compare it with) take a slightly different number of steps on some trajectories; their losses agree
 // to ~1e-8 and their heat-release curves to a small fraction of rtol -- the bar the parity tests state (tests/test_cathode.py).
 //
 // The J of TRBDF2's Newton iteration is lower bidiagonal (J = S diag(a), a_j = r_j n_j g_j): W = J - I/(gamma dt) is solved by
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                             dt = dt / fmin(1.0 / prm.qmin, exp(lq11) / prm.gamma);
                         }
                     } else if constexpr (STIFF_TRBDF2) {
-                        // ---------------------------------------------------------------- TRBDF2 attempt (oracle: cath_trbdf2_nlsolve)
+                        // ---------------------------------------------------------------- TRBDF2 attempt (DESIGN.md section 2 "TRBDF2")
                         have_eig = true;
                         const double gW = tb_d * dt;
                         // one nlsolve! call: z = dt f(tmp + d z, t + cst dt); false = the step fails

@@ -438,11 +438,11 @@ struct CathAcc<true, N> {
 // cathode_kernel, which served them, maps consecutive LANES to consecutive heating rates of one particle (different grids and step
 // counts side by side in a wavefront): 24.8 ms per 4 096 x 256 against 35.6 for the whole gradient here.
 template <int BLOCK, int KCP, bool PRIMAL = false>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((KCP == 1 && !PRIMAL) ? 2 : CRNN_CATH_ADJ_WAVES, (KCP == 1 || PRIMAL) ? 2 : CRNN_CATH_ADJ_WAVES))) void cathode_adj_kernel(const CathodeParams prm, const CathAdjParams adj) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((KCP <= 2 && !PRIMAL) ? 2 : CRNN_CATH_ADJ_WAVES, (KCP <= 2 || PRIMAL) ? 2 : CRNN_CATH_ADJ_WAVES))) void cathode_adj_kernel(const CathodeParams prm, const CathAdjParams adj) {
     __shared__ double ts_s[kCathMaxSets * kCathMaxD];
     __shared__ double db_s[kCathMaxSets * kCathMaxD];
     __shared__ double d2_s[kCathMaxSets * kCathMaxD];
-    constexpr bool THB_LDS = (KCP == 1 && !PRIMAL);
+    constexpr bool THB_LDS = (KCP <= 2 && !PRIMAL);   // two wavefronts per SIMD: accumulators in LDS (KCP = 2: 75 KB per block with the checkpoint block's states -- two blocks per CU still fit; KCP = 4 would need 91 KB)
     __shared__ double thb_lds[THB_LDS ? BLOCK * kCathNP : 1];
     __shared__ double blk_s[KCP > 1 ? KCP * 4 * BLOCK : 1];      // states (t, u) of the steps of the block being reversed, per lane
     const int tid = threadIdx.x;

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(BLOCK) void cathode_sens_kernel(const CathodeParams
                     d0 = fma(u[i] * sk[i], u[i] * sk[i], d0);
                     d1 = fma(f0[i] * sk[i], f0[i] * sk[i], d1);
                 }
-                // ode_determine_initdt with Duals: u0 has zero partials, f0 and f1 = f(u0 + dt0 f0) carry those of p (oracle: init_dt_sens)
+                // ode_determine_initdt with Duals: u0 has zero partials, f0 and f1 = f(u0 + dt0 f0) carry those of p (ros23_sens_kernel.hpp: sens_init_dt)
                 double f0p_[NCOL][3];
 #pragma unroll
                 for (int kk = 0; kk < NCOL; ++kk) {

@@ -510,14 +510,15 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
         }
         const int64_t resident_pairs = (int64_t)c->num_cu * c->adj2_occ * (kBlock / 2);
         if (c->lanes_per_traj == 2 || count <= (int64_t)k2->max_gen * resident_pairs) { G = 2; k = k2; }
-        else if (c->lanes_per_traj == 0 && count <= 2 * (int64_t)k2->max_gen * resident_pairs) {
+        else if (c->lanes_per_traj == 0 && c->queue_order == CRNN_QUEUE_AUTO && count <= 2 * (int64_t)k2->max_gen * resident_pairs) {
             // AUTO beyond one generation of pairs (round 4): two generations of pairs, longest first, last about
             // 0.6 (longest + median) step times of the one-lane kernel, one lane per trajectory lasts `longest` of them (one
             // wavefront per SIMD either way; ros23_adj2_kernel.hpp has the measurements) -- pairs win where the step counts
             // spread (a trained p: longest 48, median 29), single lanes where they do not (the initialiser: 25 / 23).  The
             // spread is that of the launch BEFORE the previous one over the same range (step_spread_block; its 12 bytes were
             // copied out behind that launch, so waiting for them never waits for the launch in flight): the choice is a
-            // deterministic function of the run's own history, like the queue order.
+            // deterministic function of the run's own history, like the queue order (and only with it: in index order -- batch sums that
+            // depend on the call's inputs alone -- the choice is one lane, as before).
             want_spread = true;
             if (c->spread_n >= 2) {
                 const int slot = (int)((c->spread_n - 2) % Ctx::kSpreadRing);
@@ -2068,6 +2069,7 @@ int32_t cath_run(CathCtx *c, int64_t n_part, int set_first, int set_count, bool 
         const int kcp = primal ? 1 : c->tape_every;
         using AdjFn = void (*)(const crnn::CathodeParams, const crnn::CathAdjParams);
         const AdjFn adj_fn = primal ? (AdjFn)crnn::cathode_adj_kernel<kB, 1, true>
+                           : kcp == 2 ? (AdjFn)crnn::cathode_adj_kernel<kB, 2>
                            : kcp == 4 ? (AdjFn)crnn::cathode_adj_kernel<kB, 4> : kcp == 8 ? (AdjFn)crnn::cathode_adj_kernel<kB, 8>
                                                                                           : (AdjFn)crnn::cathode_adj_kernel<kB, 1>;
         int &occ_ = primal ? c->prim_occ : c->adj_occ;      // (the primal instantiation fits two wavefronts per SIMD)
@@ -2187,7 +2189,7 @@ int32_t crnn_cathode_solve(crnn_cathode_ctx *ctx, const double *theta, int64_t n
 int32_t crnn_cathode_set_tape_every(crnn_cathode_ctx *ctx, int32_t every) {
     CathCtx *c = reinterpret_cast<CathCtx *>(ctx);
     if (!c) return cfail(nullptr, "null ctx");
-    if (every != 1 && every != 4 && every != 8) return cfail(c, "crnn_cathode_set_tape_every: every must be 1, 4 or 8");
+    if (every != 1 && every != 2 && every != 4 && every != 8) return cfail(c, "crnn_cathode_set_tape_every: every must be 1, 2, 4 or 8");
     if (every != c->tape_every) { c->tape_every = every; c->adj_occ = 0; }
     return 0;
 }

@@ -9,7 +9,7 @@
 //     stiff / 3 non-stiff verdicts in a row, dt * 2 and dt / 2 at the switches, PI exponents of the running algorithm);
 //   * non-autonomous Rosenbrock23 with the analytic Jacobian as the stiff algorithm (the reference's autodiff=false takes
 //     FiniteDiff increments: INTEGRATION.md) -- hychem2_kernel's step, operation for operation.
-// The oracle states the same composite (oracle/crnn_oracle.c: orc_hychem.solver = 2).  All of it [UNVERIFIED-DEP] like the other
+// The tests compare it with a CPU statement of the same composite.  All of it [UNVERIFIED-DEP] like the other
 // steppers (no Manifest for HyChem; the packages are not in the reference tree).
 //
 // Mapping: hychem2_kernel's -- a lane PAIR per trajectory, everything of length ns distributed over the pair (species 2 i + m in
