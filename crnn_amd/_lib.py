@@ -11,7 +11,7 @@ import os
 
 MAX_N = 12
 MAX_NR = 16
-ABI_VERSION = 3
+ABI_VERSION = 4
 UNIQUE_ID_BYTES = 128
 
 PMAP_IDENTITY, PMAP_CASE1, PMAP_CASE2, PMAP_ROBER, PMAP_HYCHEM = 0, 1, 2, 3, 4

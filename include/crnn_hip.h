@@ -41,7 +41,10 @@
 extern "C" {
 #endif
 
-#define CRNN_ABI_VERSION 3
+/* v4 (round 4): + crnn_cathode_set_solver, crnn_cathode_set_errnorm_sens, crnn_cathode_last_chunk_stats; crnn_cathode_set_tape_every
+ * takes 2; CRNN_SOLVER_AUTOTSIT5 is accepted on the HyChem preset; the lb of the case1 / case2 presets is the Float32 value.  No
+ * struct layout changed. */
+#define CRNN_ABI_VERSION 4
 #define CRNN_MAX_N 12   /* max ODE states  */
 #define CRNN_MAX_NR 16  /* max reactions   */
 
@@ -372,11 +375,12 @@ int32_t crnn_svgd_update(int32_t device, const double *p, const double *lnpgrad,
  *                                read back beyond the 4-byte tape-overflow flag of the adjoint launch.
  *   crnn_cathode_get_particles   copies the current particles out */
 int32_t crnn_cathode_set_particles(crnn_cathode_ctx *ctx, const double *p, const double *p_scales, int64_t n_part);
-/* Layout of the adjoint's step tape.  1 (default): (t, dt, u) of every accepted step, 40 B per step -- the fastest.  4 / 8:
- * CHECKPOINTED: dt of every step and (t, u) of every 4th / 8th (16 / 12 B per step); the reverse sweep re-forms the states
+/* Layout of the adjoint's step tape.  1 (default): (t, dt, u) of every accepted step, 40 B per step -- the fastest.  2 / 4 / 8:
+ * CHECKPOINTED: dt of every step and (t, u) of every 2nd / 4th / 8th (24 / 16 / 12 B per step); the reverse sweep re-forms the states
  * in between (same arithmetic as the forward sweep, gradients agree to rounding).  BASELINE config 5 on one MI355X
  * (4 096 x 256 trajectories, 338 steps each): HBM traffic 31 -> 9.4 GB per launch, tape capacity per trajectory 3.3x, kernel
- * time 35.7 -> 40.3 ms (the kernel is issue-bound, not bandwidth-bound: profiles/r03e_*). */
+ * time 35.7 -> 40.3 ms (the kernel is issue-bound, not bandwidth-bound: profiles/r03e_*).  Round 4: every 2nd step at two
+ * wavefronts per SIMD like the full tape -- 40.3 ms too (full tape: 31.9): the re-formations cost what the traffic saves. */
 int32_t crnn_cathode_set_tape_every(crnn_cathode_ctx *ctx, int32_t every);
 /* The stepper of PRIMAL launches (crnn_cathode_solve with grad == NULL: pred_n_ode / HRR_getter / loss_neuralode, the epoch-end
  * loss loop).  The reference integrates this model with `alg = AutoTsit5(TRBDF2(autodiff = true))` (network.jl:195, used by

@@ -353,6 +353,12 @@ Rosenbrock23 as the stiff algorithm.  Gradient launches always run the Rosenbroc
 set_solver!(c::Cathode, solver::Integer) = ccall((:crnn_cathode_set_solver, LIB), Int32, (Ptr{Cvoid}, Int32), c.ctx, Int32(solver)) == 0 ||
     error(unsafe_string(ccall((:crnn_cathode_last_error, LIB), Cstring, (Ptr{Cvoid},), c.ctx)))
 
+"""The gradient as the reference evaluates it (network.jl:232: `ForwardDiff.gradient` through the adaptive solve): `mode` 1 / 2 puts the
+partials of ForwardDiff's chunks (9, then 8 + a zero partial) into the error norm of gradient launches (2 = the `totallength(u)` divisor of
+the DiffEqBase this project pins); `mode` 0 (default): primal-only norm, discrete adjoint."""
+set_errnorm_sens!(c::Cathode, mode::Integer) = ccall((:crnn_cathode_set_errnorm_sens, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}), c.ctx, Int32(mode), c.p_scales) == 0 ||
+    error(unsafe_string(ccall((:crnn_cathode_last_error, LIB), Cstring, (Ptr{Cvoid},), c.ctx)))
+
 """Device-resident SVGD loop (crnn_cathode.jl:36-50): `set_particles!(c, p)` uploads the normalised particles p [N, 17];
 `svgd_step!(c, i_exp, normalizer2, stepsize)` runs dlnprob for heating rate i_exp and the SVGD move on the device
 (returns the mean loss and the bandwidth); `particles(c, N)` copies them out."""
