@@ -157,6 +157,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             point_at(ui, tsj, q);
             const double hv = hrr_at(q);
             if (prm.hrr) prm.hrr[(size_t)traj * prm.Dmax + j] = hv;
+            CRNN_CHK(j >= 0 && j < D && D <= prm.Dmax && traj < prm.n_traj, 45);
             const double db = dbv[j], e = hv - db;
             pf_loss += fma(e, e, d2v[j] - db * db);
         };

@@ -115,6 +115,7 @@ __global__ __launch_bounds__(BLOCK) void cathode_kernel(const CathodeParams prm)
         CathPoint q;
         cath_point(uu, fma(Tdot, tt - 0.0, prm.T0), th, prm.lb, q);
         const double hv = fma(q.r[0], th[9], fma(q.r[1], th[10], q.r[2] * th[11]));
+        CRNN_CHK(jsave >= 0 && jsave < D && D <= prm.Dmax && traj < prm.n_traj, 60);
         const double db = dbv[jsave];
         const double e = hv - db;
         loss_sum += fma(e, e, d2v[jsave] - db * db);
@@ -617,12 +618,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((KCP <= 2
                             } else {
                                 if constexpr (PRIMAL) {
                                 } else if constexpr (KCP > 1) {
+                                    CRNN_CHK(nacc >= 0 && nacc < adj.tape_cap, 46);
                                     CATH_DT(nacc) = dt;
                                     if (nacc % KCP == 0) {
                                         const int kk = nacc / KCP;
                                         CATH_CK(kk, 0) = t; CATH_CK(kk, 1) = u[0]; CATH_CK(kk, 2) = u[1]; CATH_CK(kk, 3) = u[2];
                                     }
                                 } else {
+                                    CRNN_CHK(nacc >= 0 && nacc < adj.tape_cap, 40);
                                     double *rec = tape + (size_t)nacc * RECW;
                                     rec[0] = t; rec[1] = dt; rec[2] = u[0]; rec[3] = u[1]; rec[4] = u[2];
                                 }
@@ -641,6 +644,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((KCP <= 2
                                         const double hv = hrr_of(ui, tsj);
                                         if (prm.hrr) prm.hrr[(size_t)traj * prm.Dmax + jsave] = hv;
                                         if (PRIMAL) {
+                                            CRNN_CHK(jsave < D && D <= prm.Dmax && traj < prm.n_traj, 41);
                                             const double db = dbv[jsave], e = hv - db;
                                             pf_loss += fma(e, e, d2v[jsave] - db * db);
                                         }
@@ -679,6 +683,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((KCP <= 2
             CathPoint q;
             cath_point(uu, fma(Tdot, tt, prm.T0), th, prm.lb, q);
             const double hv = fma(q.r[0], th[9], fma(q.r[1], th[10], q.r[2] * th[11]));
+            CRNN_CHK(j >= 0 && j < D && D <= prm.Dmax, 42);
             const double db = dbv[j];
             const double e = hv - db;
             loss_sum += fma(e, e, d2v[j] - db * db);
@@ -696,6 +701,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((KCP <= 2
         };
         double rt = 0.0, rdt = 0.0, ru[3] = {0.0, 0.0, 0.0};
         if constexpr (KCP == 1 && !PRIMAL) {   // (a context that has only made primal calls has no tape at all)
+            CRNN_CHK(s < adj.tape_cap, 43);
             const double *rec = tape + (size_t)(s > 0 ? s : 0) * RECW;
             rt = rec[0]; rdt = rec[1]; ru[0] = rec[2]; ru[1] = rec[3]; ru[2] = rec[4];
         }
@@ -754,6 +760,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((KCP <= 2
                     h_ = CATH_DT(s);
                 } else {
                     tn_ = rt; h_ = rdt; un_[0] = ru[0]; un_[1] = ru[1]; un_[2] = ru[2];
+                    CRNN_CHK(s - 1 < adj.tape_cap, 44);
                     const double *rec = tape + (size_t)(s > 0 ? s - 1 : 0) * RECW;
                     rt = rec[0]; rdt = rec[1]; ru[0] = rec[2]; ru[1] = rec[3]; ru[2] = rec[4];
                 }

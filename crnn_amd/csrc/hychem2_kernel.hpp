@@ -558,6 +558,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
         const int64_t traj = wave_base + giw;
         const bool valid = traj < prm.count;
         const int64_t b = prm.first + (valid ? (hp.perm ? (int64_t)hp.perm[traj] : traj) : 0);
+        CRNN_CHK(b >= prm.first && b < prm.first + prm.count && b < prm.B, 21);
         const double *const tabT = hp.tabs + (size_t)b * 2 * Dfull;
         const double *const tabP = tabT + Dfull;
 
@@ -569,6 +570,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
             while (sg > 0 && ts_lds[sg] > tq) --sg;
             if (sg != seg) {
                 seg = sg;
+                CRNN_CHK(sg >= 0 && sg + 1 < Dfull, 20);
                 Ta = tabT[sg]; Tb = tabT[sg + 1]; Pa = tabP[sg]; Pb = tabP[sg + 1];
                 tsa = ts_lds[sg];
                 idts = frcp(ts_lds[sg + 1] - tsa);
@@ -744,6 +746,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                                 if (!m1) atomicAdd(hp.overflow, 1u);
                             } else {
                                 if (GRAD) {
+                                    CRNN_CHK(nacc >= 0 && nacc < hp.tape_cap, 22);
                                     double *rec = tape + (size_t)nacc * RECW;
                                     if (!m1) { rec[0] = t; rec[1] = dt; }
 #pragma unroll
@@ -759,6 +762,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
                                         const double Th = at_end ? 1.0 : (ts - t) / dt;
                                         const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
                                         const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d_) * inv12d;
+                                        CRNN_CHK((int64_t)(jsave + 1) * prm.n_obs <= prm.row_stride && jsave < Dfull, 23);
                                         const double *prow = prm.data + (size_t)b * prm.row_stride + (size_t)jsave * prm.n_obs;
 #pragma unroll
                                         for (int i = 0; i < H; ++i) {
@@ -828,6 +832,7 @@ __global__ __launch_bounds__(BLOCK) void hychem2_kernel(const SolveParams prm, c
         // same point -- a load awaited in the step that requests it stalls the lane for a full memory latency per step
         double rt = 0.0, rdt = 0.0, ru[H], qt = 0.0, qdt = 0.0, qu[H];
         auto fetch_rec = [&](int idx, double &t_, double &dt_, double (&u_)[H]) {
+            CRNN_CHK(idx < hp.tape_cap, 25);
             const double *rec = tape + (size_t)(idx > 0 ? idx : 0) * RECW;
             t_ = rec[0]; dt_ = rec[1];
 #pragma unroll

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_auto_kernel(const SolveParams pr
         const int64_t traj = wave_base + giw;
         const bool valid = traj < prm.count;
         const int64_t b = prm.first + (valid ? (hp.perm ? (int64_t)hp.perm[traj] : traj) : 0);
+        CRNN_CHK(b >= prm.first && b < prm.first + prm.count && b < prm.B, 21);
         const double *const tabT = hp.tabs + (size_t)b * 2 * Dfull;
         const double *const tabP = tabT + Dfull;
 
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_auto_kernel(const SolveParams pr
             while (sg > 0 && ts_lds[sg] > tq) --sg;
             if (sg != seg) {
                 seg = sg;
+                CRNN_CHK(sg >= 0 && sg + 1 < Dfull, 20);
                 Ta = tabT[sg]; Tb = tabT[sg + 1]; Pa = tabP[sg]; Pb = tabP[sg + 1];
                 tsa = ts_lds[sg];
                 idts = frcp(ts_lds[sg + 1] - tsa);
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_auto_kernel(const SolveParams pr
         double pf_loss = 0.0;
         // a save point: prediction out, its loss term in (this lane's species)
         auto save_point = [&](const double (&v_)[H], const int j) {
+            CRNN_CHK(j >= 0 && (int64_t)(j + 1) * prm.n_obs <= prm.row_stride && j < Dfull, 24);
             const double *prow = prm.data + (size_t)b * prm.row_stride + (size_t)j * prm.n_obs;
 #pragma unroll
             for (int i = 0; i < H; ++i) {

@@ -76,12 +76,8 @@ namespace crnn {
 #ifndef CRNN_ADJ_THETA
 #define CRNN_ADJ_THETA 0     // 0: theta staged in LDS (broadcast reads, parked in AGPRs); 3: scalar loads re-issued per step
 #endif
-#ifdef CRNN_BOUNDS_CHECK
-__device__ unsigned int g_bounds[2];
-#define CRNN_CHK(cond, code) do { if (!(cond)) { if (atomicAdd(&g_bounds[0], 1u) == 0u) g_bounds[1] = (unsigned)(code); } } while (0)
-#else
-#define CRNN_CHK(cond, code) ((void)0)
-#endif
+// (g_bounds / CRNN_CHK live in ros23_kernel.hpp since round 4: the HyChem, cathode and forward-tangent kernels carry checks too --
+//  site codes 1-19 adjoint kernels, 20-39 HyChem, 40-59 cathode, 60-69 forward tangents)
 
 struct AdjParams {
     double *tape;                // [lanes][tape_cap][NS + 2]

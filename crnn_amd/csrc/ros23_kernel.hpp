@@ -43,6 +43,19 @@
 #endif
 
 namespace crnn {
+// Bounds-checked build (-DCRNN_BOUNDS_CHECK; tools/crossbuild.py variant "O3chk"): indexed global-memory accesses -- tape records,
+// observed rows, tables, u0 / pred / per-trajectory outputs, queue permutations, partial rows -- are checked against their extents
+// on the lanes that perform them; violations are counted in g_bounds[0], the site code of the first one is kept in g_bounds[1]
+// (crnn_debug_bounds reads the pair).  Release builds compile the checks away.
+#ifdef CRNN_BOUNDS_CHECK
+__device__ unsigned int g_bounds[2];
+#define CRNN_CHK(cond, code) do { if (!(cond)) { if (atomicAdd(&g_bounds[0], 1u) == 0u) g_bounds[1] = (unsigned)(code); } } while (0)
+#else
+#define CRNN_CHK(cond, code) ((void)0)
+#endif
+}  // namespace crnn
+
+namespace crnn {
 
 constexpr int kMaxN = 12;
 constexpr int kMaxSave = 256;  // max saveat points (LDS-staged)

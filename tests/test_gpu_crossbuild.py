@@ -4,7 +4,9 @@ allocation and schedule).  With -ffp-contract=on the floating-point sequence is 
 between the builds is undefined behaviour or a miscompile -- the failure mode round 2 recorded for auto_adj_kernel
 ("a printf changed its losses", a memory fault after a logically equivalent edit).  Problems: the AutoTsit5 composite on
 robertson and case1, Tsit5 adjoint on case1 / case2, Rosenbrock23 adjoint on case2 / robertson, forward tangents on
-case2, the primal launch (predictions + losses) on case2; 1 061 trajectories each (ragged last wavefront); per-trajectory losses, return codes, saved counts, accepted /
+case2, the primal launch (predictions + losses) on case2, HyChem (adjoint on one lane and on a lane pair, the primal launch, the AutoTsit5
+composite), the cathode kernels (adjoint with full / checkpointed tapes, forward tangents, primal, both composites, the chunked
+dual-norm gradient); 1 061 trajectories each (ragged last wavefront); per-trajectory losses, return codes, saved counts, accepted /
 rejected steps and the index-order batch gradient compared through a digest of their bytes (tools/crossbuild.py).
 Integer comparison of bit patterns: no tolerance."""
 import os
@@ -27,7 +29,7 @@ def test_gradient_kernels_are_bit_identical_across_builds():
     assert set(results) == set(crossbuild.VARIANTS)
     for name, r in results.items():
         assert "error" not in r, (name, r)
-        assert len(r) == 12 and all(v["n_accept"] > 0 for v in r.values()), (name, r)
+        assert len(r) == 22 and all(v["n_accept"] > 0 for v in r.values()), (name, r)     # 12 + round 4's HyChem primal / composite and 8 cathode launches
         # the composite really switches on robertson (Tsit5 start, Rosenbrock23 after the detector fires): it takes a small
         # multiple of Rosenbrock23's step count, not Tsit5's ~19 000 per trajectory
         assert r["rober_autotsit5_adjoint"]["n_accept"] < 4 * r["rober_ros23_adjoint"]["n_accept"]

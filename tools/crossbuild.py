@@ -18,7 +18,9 @@ against its extent -- the stand-in for a device address sanitizer, whose instrum
 must also report ZERO violations).  Problems: the AutoTsit5(Rosenbrock23) composite on robertson (switches
 algorithm mid-run), Tsit5 adjoint on case1 and on case2, Rosenbrock23 adjoint on case2 (one lane and two lanes per trajectory),
 case1's shape (two lanes, odd species count), robertson, HyChem (one lane and a lane pair),
-forward tangents on case2 -- per-trajectory losses, return codes, saved counts, accepted / rejected steps and the batch
+forward tangents on case2; round 4: the HyChem primal launches (pair kernel, AutoTsit5 composite) and the cathode kernels (adjoint with
+the full and the checkpointed tapes, forward tangents, primal, both composites, the chunked dual-norm gradient) -- the bounds checks
+cover those kernel families too -- per-trajectory losses, return codes, saved counts, accepted / rejected steps and the batch
 gradient in index order (crnn_ctx_set_queue_order(INDEX): the batch sum is then a function of the inputs alone).
 tests/test_gpu_crossbuild.py runs `run` on every GPU session.
 """
@@ -46,6 +48,7 @@ def source_hash():
     for f in sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))):
         h.update(open(os.path.join(CSRC, f), "rb").read())
     h.update(open(os.path.join(ROOT, "include", "crnn_hip.h"), "rb").read())
+    h.update(open(os.path.join(CSRC, "Makefile"), "rb").read())      # as crnn_amd/_lib.py source_hash()
     return h.hexdigest()[:16]
 
 
@@ -162,6 +165,55 @@ def worker():
                          gnorm=float(np.linalg.norm(grad)).hex(), n_accept=int(na.sum()), n_reject=int(nr.sum()),
                          n_fail=int((ret != 0).sum()), loss=[float(x).hex() for x in loss[:8]])
         node.close()
+    # ---- round 4: the HyChem primal launches (pair kernel, and the AutoTsit5 composite), the cathode kernels
+    from crnn_amd import PRESET_HYCHEM, hychem as hy
+
+    def record(name, arrays, na, nr, nfail):
+        h = hashlib.sha256()
+        for a in arrays:
+            h.update(np.ascontiguousarray(a).tobytes())
+        viol, site = C.c_uint32(0), C.c_uint32(0)
+        chk = L.lib.crnn_debug_bounds(C.byref(viol), C.byref(site))
+        res[name] = dict(digest=h.hexdigest()[:24], bounds_checked=(chk == 0), bounds_violations=int(viol.value), bounds_site=int(site.value),
+                         loss_sum=float(np.sum(arrays[0])).hex(), n_accept=int(na), n_reject=int(nr), n_fail=int(nfail))
+
+    hrng = np.random.Generator(np.random.PCG64([77, 4]))
+    hts, hu0, hT, hP = hy.sample_conditions(300, hrng)
+    hdata = np.abs(hrng.standard_normal((300, 9, len(hts)))) * 0.05
+    hp = hy.true_p() + 0.02 * hrng.standard_normal(hy.NP)
+    hp[-1] = 0.1
+    for name, kw in (("hychem_primal_pair", dict()), ("hychem_autotsit5_primal", dict(solver=L.SOLVER_AUTOTSIT5))):
+        from crnn_amd import NeuralODE, ODEProblem
+        node = NeuralODE(ODEProblem(PRESET_HYCHEM, hts, rate_scale=hy.DYDT_SCALE, **kw))
+        node.set_queue_order(L.QUEUE_INDEX)
+        node.set_ensemble(hu0, hdata, np.ones(9))
+        node.set_tables(hT, hP)
+        th, _ = p2vec_jac(node.pmap, node.ns, node.nr, hp)
+        pred, loss, _, ret, nsv = node._solve(node._ctx, node.B, th, None, 0, node.B, None, True)
+        na, nr = node.step_counts()
+        record(name, (loss, pred, ret, nsv, na, nr), na.sum(), nr.sum(), (ret != 0).sum())
+        node.close()
+    from crnn_amd.cathode import CathodeUQ
+    cfx = json.load(open(os.path.join(ROOT, "tests", "golden", "fixtures_cathode.json")))
+
+    def two(s_):
+        dbar, d2bar = np.array(s_["dbar"]), np.array(s_["d2bar"])
+        sd = np.sqrt(np.maximum(d2bar - dbar ** 2, 0.0))
+        return np.stack([np.array(s_["ts"]), dbar + sd, dbar - sd], axis=1)
+
+    crng = np.random.default_rng(21)
+    cp = 1 + 0.05 * crng.standard_normal((70, 17))
+    cp[:, 6:9] = 0.0
+    for name, kw, grad in (("cathode_adjoint", dict(grad_mode=2), True), ("cathode_adjoint_tape4", dict(grad_mode=2, tape_every=4), True),
+                           ("cathode_adjoint_tape2", dict(grad_mode=2, tape_every=2), True), ("cathode_forward", dict(grad_mode=1), True),
+                           ("cathode_primal", dict(), False), ("cathode_autotsit5_trbdf2_primal", dict(solver="autotsit5_trbdf2"), False),
+                           ("cathode_autotsit5_ros23_primal", dict(solver="autotsit5_rosenbrock23"), False),
+                           ("cathode_errnorm_sens2", dict(errnorm_sens=2), True)):
+        uq = CathodeUQ([two(s_) for s_ in cfx["sets"]], [s_["beta"] for s_ in cfx["sets"]], cfx["theta"], **kw)
+        loss, grad_, hrr = uq.solve(cp, want_grad=grad, want_hrr=True)
+        st = uq.last_stats
+        record(name, (loss, hrr, uq.last_retcode, uq.last_n_saved) + ((grad_,) if grad else ()), st["n_accept"], st["n_reject"], (uq.last_retcode != 0).sum())
+        uq.close()
     print("XBRESULT " + json.dumps(res))
 
 
