@@ -186,6 +186,7 @@ struct Ctx {
     int adj_occ = 0;                // cached occupancy of the adjoint kernel
     int adj2_occ = 0;               // ... of the two-lanes-per-trajectory variant
     int lanes_per_traj = 0;         // crnn_ctx_set_lanes_per_traj: 0 = AUTO, 1, 2
+    int64_t hy_tape_retries = 0;    // HyChem launches repeated with fewer resident trajectories after a tape overflow
     int last_lanes = 0;             // lanes per trajectory of the most recent adjoint launch (0: another kernel family ran)
     // deferred outcome of adjoint training steps (crnn_train_step): see check_pending
     bool defer_next = false, last_deferred = false, force_forward = false;
@@ -657,9 +658,12 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
 }
 
 // HyChem: one kernel family (hychem_kernel.hpp).  P > 0: discrete-adjoint gradient in theta space (HBM accumulators)
-// + chain rule; P == 0: primal + loss.  A tape overflow is an error here (no forward-tangent fallback for 211 parameters).
+// + chain rule; P == 0: primal + loss.  A trajectory that outruns the tape (there is no forward-tangent kernel for 211 parameters to
+// fall back on): with the tape sized automatically the call is repeated with a quarter of the resident trajectories -- four
+// times the records per lane from the same budget, the queue works through the ensemble in more generations -- until the
+// records fit or a lane holds maxiters of them (no trajectory accepts more); with an explicit crnn_config.tape_steps it is an error.
 int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int P, int64_t first, int64_t count,
-                      int n_save_active, bool want_pred) {
+                      int n_save_active, bool want_pred, int max_blocks = 0) {
     if (c->cfg.ns != 9 || c->cfg.nr != 10) return fail(c, "crnn_solve: the HyChem kernel is instantiated for ns = 9, nr = 10");
     if (!c->d_tabs || c->tabs_B != c->B) return fail(c, "crnn_solve: HyChem needs T/P tables (crnn_ctx_set_tables after crnn_ctx_set_data)");
     const int nth = c->n_theta;
@@ -693,7 +697,8 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
     HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, kHyBlock, 0));
     if (occ < 1) occ = 1;
     const int64_t need_blocks = (count + 127) / 128;
-    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(need_blocks, (int64_t)c->num_cu * occ));
+    int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(need_blocks, (int64_t)c->num_cu * occ));
+    if (max_blocks > 0) nblk = std::min(nblk, max_blocks);
     const size_t lanes = (size_t)nblk * 128;      // resident trajectories = tape slots
     const size_t recw = (size_t)c->cfg.ns + 2;
     int64_t cap = c->cfg.tape_steps;
@@ -702,6 +707,10 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
             size_t fr = 0, tot = 0;
             HIP_TRY(c, hipMemGetInfo(&fr, &tot));
             c->tape_budget = std::min<size_t>(fr / 4, (size_t)16 << 30);
+            if (const char *e = getenv("CRNN_TAPE_BUDGET_BYTES")) {   // test override: a budget small enough to exercise the overflow path
+                const long long v = atoll(e);
+                if (v > 0) c->tape_budget = (size_t)v;
+            }
         }
         cap = std::max<int64_t>((int64_t)(c->tape_budget / (lanes * recw * sizeof(double))), 64);
     }
@@ -780,7 +789,12 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
         fprintf(stderr, " total %.3f ms\n", (double)tot / 1e5);
     }
 #endif
-    if (ovf) return fail(c, "crnn_solve: a trajectory accepted more steps than the adjoint tape holds; raise crnn_config.tape_steps");
+    if (ovf) {
+        if (c->cfg.tape_steps > 0 || cap >= c->cfg.maxiters || nblk <= 1)
+            return fail(c, "crnn_solve: a trajectory accepted more steps than the adjoint tape holds; raise crnn_config.tape_steps");
+        c->hy_tape_retries++;
+        return launch_hychem(c, d_theta, d_dtheta, P, first, count, n_save_active, want_pred, std::max(1, nblk / 4));
+    }
     return 0;
 }
 

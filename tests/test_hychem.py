@@ -327,6 +327,32 @@ def test_gpu_hychem_autotsit5_composite_primal(orc, hfx):
 
 
 @pytest.mark.gpu
+def test_gpu_hychem_tape_overflow_degrades_instead_of_failing(hfx, monkeypatch):
+    """a HyChem trajectory that outran the adjoint tape aborted the call.  With the tape sized automatically the launch is
+    now repeated with a quarter of the resident trajectories (four times the records per lane from the same budget) until the records
+    fit: same loss and gradient (to rounding) as a launch whose tape was large enough.  An explicit crnn_config.tape_steps stays a hard limit."""
+    from crnn_amd._lib import CrnnError
+    B = 2048
+    u0, data, Tt, Pt = _synthetic(hfx, B, 31)
+    p = hfx["p"]
+    ref = _node(hfx, u0, data, Tt, Pt)
+    l0, g0 = ref.loss_and_grad(p)
+    na, nr = ref.step_counts()
+    assert na.max() > 64                                   # some trajectory needs more than 64 records
+    ref.close()
+    monkeypatch.setenv("CRNN_TAPE_BUDGET_BYTES", str(B * 11 * 8 * 64))      # 64 records per lane when all 2 048 trajectories are resident
+    small = _node(hfx, u0, data, Tt, Pt)
+    l1, g1 = small.loss_and_grad(p)
+    assert small.last_stats["n_ok"] == B
+    assert l1 == l0 and np.max(np.abs(g1 - g0)) < 1e-12 * np.max(np.abs(g0))     # (per-trajectory results identical; the MFMA batch sums see
+    small.close()                                                                  #  other finished pairs next to a batch's stragglers)
+    hard = _node(hfx, u0, data, Tt, Pt, tape_steps=64)
+    with pytest.raises(CrnnError, match="tape"):
+        hard.loss_and_grad(p)
+    hard.close()
+
+
+@pytest.mark.gpu
 def test_gpu_hychem_converged_golden(hfx):
     node = _node(hfx, hfx["u0"], hfx["data"], hfx["Ttab"], hfx["Ptab"], atol=1e-13, rtol=1e-9, maxiters=10**7, tape_steps=40000)
     p = hfx["p"]
