@@ -21,6 +21,7 @@
 #include "hychem_kernel.hpp"
 #include "hychem2_kernel.hpp"
 #include "hychem_auto_kernel.hpp"
+#include "hychem_sens_kernel.hpp"
 #include "tsit5_kernel.hpp"
 #include "auto_adj_kernel.hpp"
 #include "ros23_adj2_kernel.hpp"
@@ -186,6 +187,7 @@ struct Ctx {
     int adj_occ = 0;                // cached occupancy of the adjoint kernel
     int adj2_occ = 0;               // ... of the two-lanes-per-trajectory variant
     int lanes_per_traj = 0;         // crnn_ctx_set_lanes_per_traj: 0 = AUTO, 1, 2
+    int hysens_occ = 0;
     int64_t hy_tape_retries = 0;    // HyChem launches repeated with fewer resident trajectories after a tape overflow
     int last_lanes = 0;             // lanes per trajectory of the most recent adjoint launch (0: another kernel family ran)
     // deferred outcome of adjoint training steps (crnn_train_step): see check_pending
@@ -845,18 +847,73 @@ int32_t launch_sens_chunk(Ctx *c, const KernelEntry *k, const double *d_theta, c
     return 0;
 }
 
+// HyChem: one ForwardDiff chunk of <= 12 directions, a group of twelve lanes per trajectory (hychem_sens_kernel.hpp); the same
+// per-trajectory gradient rows and fixed-order reduction as launch_sens_chunk.
+int32_t launch_hychem_sens_chunk(Ctx *c, const double *d_theta, const double *d_dtheta, int P, int64_t first, int64_t count,
+                                 int n_save_active, bool want_pred, int dual_partials) {
+    if (c->cfg.ns != 9 || c->cfg.nr != 10) return fail(c, "crnn_solve: the HyChem kernel is instantiated for ns = 9, nr = 10");
+    if (!c->d_tabs || c->tabs_B != c->B) return fail(c, "crnn_solve: HyChem needs T/P tables (crnn_ctx_set_tables after crnn_ctx_set_data)");
+    constexpr int kC = 12, kBlk = 128, kGroups = (kBlk / 64) * (64 / kC);
+    const int npart_pad = kC + crnn::kExtra, npart = P + crnn::kTail;
+    using SFn = void (*)(const crnn::SolveParams, const double *, const crnn::HyParams, const crnn::HySensParams);
+    const SFn fn = (SFn)crnn::hychem_sens_kernel<9, 10, kBlk>;
+    if (c->hysens_occ < 1) {
+        HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->hysens_occ, (const void *)fn, kBlk, 0));
+        if (c->hysens_occ < 1) c->hysens_occ = 1;
+    }
+    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((count + kGroups - 1) / kGroups, (int64_t)c->num_cu * c->hysens_occ));
+    const int rblk = (int)((count + 255) / 256);
+    if (ensure(c, &c->d_partials, &c->partials_cap, (size_t)rblk * npart_pad)) return -1;
+    if (ensure(c, &c->d_gtraj, &c->gtraj_cap, (size_t)count * kC)) return -1;
+    if (c->npart_max < npart) {
+        if (c->d_red) HIP_TRY(c, hipFree(c->d_red));
+        c->d_red = nullptr;
+        HIP_TRY(c, hipMalloc((void **)&c->d_red, sizeof(double) * npart));
+        c->npart_max = npart;
+    }
+    if (want_pred && ensure_pred(c)) return -1;
+    crnn::SolveParams prm{};
+    fill_params(c, prm, P, first, count, n_save_active, want_pred);
+    crnn::HyParams hp{};
+    hp.tabs = c->d_tabs; hp.n_save_total = c->cfg.n_save; hp.inv_R = c->cfg.inv_R;
+    crnn::HySensParams sp{};
+    sp.dth = d_dtheta; sp.n_dir = P; sp.mode = c->cfg.errnorm_sens; sp.dual_partials = dual_partials;
+    if (upload_consts(c)) return -1;
+    c->flags_zeroed = false;
+    c->ev0 = c->ring0[c->n_launch % Ctx::kRing];
+    c->ev1 = c->ring1[c->n_launch % Ctx::kRing];
+    ++c->n_launch;
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    hipLaunchKernelGGL(fn, dim3(nblk), dim3(kBlk), 0, c->stream, prm, d_theta, hp, sp);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    hipLaunchKernelGGL(crnn::reduce_traj_kernel, dim3(rblk), dim3(256), 0, c->stream, c->d_gtraj, kC, c->d_loss, c->d_ret,
+                       c->d_nacc, c->d_nrej, first, count, 256, c->d_partials);
+    HIP_TRY(c, hipGetLastError());
+    hipLaunchKernelGGL(crnn::reduce_partials_kernel, dim3(npart_pad), dim3(256), 0, c->stream, c->d_partials, rblk, kC, P, c->d_red);
+    HIP_TRY(c, hipGetLastError());
+    c->last_npart = npart;
+    c->last_P = P;
+    c->steps_first = first; c->steps_count = count;
+    return 0;
+}
+
 // errnorm_sens = 1.  P <= C*L (crnn_solve: the caller's directions are ONE chunk): a single launch.  Otherwise
 // (crnn_loss_grad, crnn_train_step: the P parameters) ForwardDiff's chunking: consecutive chunks of fd_chunk_size(P)
 // partials, each its own adaptive solve, the gradient pieces concatenated; per-trajectory losses, return codes and the
 // step statistics are those of a final plain solve -- what loss_neuralode(p) evaluates (case2/case2.jl:199-201).
 int32_t launch_sens(Ctx *c, const double *d_theta, const double *d_dtheta, int P, int64_t first, int64_t count,
                     int n_save_active, bool want_pred, bool single_chunk) {
-    const KernelEntry *k = find_sens(c);
-    if (!k) return fail(c, "crnn_solve: errnorm_sens = 1 has no kernel for this (solver, ns, nr, has_temp)");
-    const int cap = k->C * k->L;
+    const KernelEntry *k = c->hychem ? nullptr : find_sens(c);
+    if (!k && !c->hychem) return fail(c, "crnn_solve: errnorm_sens = 1 has no kernel for this (solver, ns, nr, has_temp)");
+    const int cap = c->hychem ? 12 : k->C * k->L;
+    auto chunk_launch = [&](const double *dth, int Pc, bool pred, int partials) -> int32_t {
+        return c->hychem ? launch_hychem_sens_chunk(c, d_theta, dth, Pc, first, count, n_save_active, pred, partials)
+                         : launch_sens_chunk(c, k, d_theta, dth, Pc, first, count, n_save_active, pred, partials);
+    };
     if (single_chunk) {
         if (P > cap) return fail(c, "crnn_solve: with errnorm_sens = 1 the directions of one call are one ForwardDiff chunk: n_dir <= " + std::to_string(cap));
-        return launch_sens_chunk(c, k, d_theta, d_dtheta, P, first, count, n_save_active, want_pred, P);
+        return chunk_launch(d_dtheta, P, want_pred, P);
     }
     const int chunk = fd_chunk_size(P);
     if (chunk > cap) return fail(c, "crnn_loss_grad: errnorm_sens = 1 chunk size exceeds the instantiated kernel");
@@ -870,7 +927,7 @@ int32_t launch_sens(Ctx *c, const double *d_theta, const double *d_dtheta, int P
     for (int k0 = 0; k0 < P; k0 += chunk) {
         const int Pc = std::min(chunk, P - k0);
         // every Dual of a chunked ForwardDiff.gradient carries `chunk` partials, the last chunk's surplus ones are zero
-        if (launch_sens_chunk(c, k, d_theta, d_dtheta + (size_t)k0 * c->n_theta, Pc, first, count, n_save_active, false, chunk)) return -1;
+        if (chunk_launch(d_dtheta + (size_t)k0 * c->n_theta, Pc, false, chunk)) return -1;
         HIP_TRY(c, hipMemcpyAsync(c->d_red_asm + k0, c->d_red, sizeof(double) * Pc, hipMemcpyDeviceToDevice, c->stream));
     }
     const int es = c->cfg.errnorm_sens;
@@ -900,8 +957,9 @@ int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int 
     if (first < 0 || count <= 0 || first + count > c->B) return fail(c, "crnn_solve: [first, first+count) outside the ensemble");
     if (n_save_active <= 0 || n_save_active > c->cfg.n_save) return fail(c, "crnn_solve: n_save_active out of range");
     if (c->hychem) {
+        if (c->cfg.errnorm_sens && P > 0) return launch_sens(c, d_theta, d_dtheta, P, first, count, n_save_active, want_pred, want_percase);
         if (P > 0 && c->cfg.grad_mode == CRNN_GRAD_FORWARD)
-            return fail(c, "crnn_solve: HyChem gradients exist as discrete adjoint only (grad_mode AUTO or ADJOINT)");
+            return fail(c, "crnn_solve: HyChem's forward tangents exist with the dual-inclusive error norm only (errnorm_sens = 1 / 2); the primal-norm gradient is the discrete adjoint (grad_mode AUTO or ADJOINT)");
         return launch_hychem(c, d_theta, d_dtheta, P, first, count, n_save_active, want_pred);
     }
     c->last_deferred = false;
@@ -1248,8 +1306,9 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
     if (cfg->ns < 1 || cfg->nr < 1 || cfg->ns + cfg->has_temp > CRNN_MAX_N || cfg->nr > CRNN_MAX_NR)
         return fail(nullptr, "crnn_ctx_create: ns/nr out of range");
     if (cfg->errnorm_sens < 0 || cfg->errnorm_sens > 2) return fail(nullptr, "crnn_ctx_create: errnorm_sens must be 0, 1 or 2");
-    if (cfg->errnorm_sens != 0 && (cfg->solver == CRNN_SOLVER_AUTOTSIT5 || cfg->rhs_kind != CRNN_RHS_CRNN || cfg->grad_mode == CRNN_GRAD_ADJOINT))
-        return fail(nullptr, "crnn_ctx_create: errnorm_sens = 1 / 2 exists for Rosenbrock23 and Tsit5 with forward tangents (grad_mode AUTO or FORWARD) on the CRNN right-hand side");
+    if (cfg->errnorm_sens != 0 && (cfg->solver == CRNN_SOLVER_AUTOTSIT5 || cfg->grad_mode == CRNN_GRAD_ADJOINT ||
+                                   (cfg->rhs_kind == CRNN_RHS_HYCHEM && cfg->solver != CRNN_SOLVER_ROSENBROCK23)))
+        return fail(nullptr, "crnn_ctx_create: errnorm_sens = 1 / 2 exists for Rosenbrock23 and Tsit5 (HyChem: Rosenbrock23) with forward tangents (grad_mode AUTO or FORWARD)");
     if (cfg->solver != CRNN_SOLVER_ROSENBROCK23 && cfg->solver != CRNN_SOLVER_TSIT5 && cfg->solver != CRNN_SOLVER_AUTOTSIT5)
         return fail(nullptr, "crnn_ctx_create: unknown solver");
     if (cfg->rhs_kind != CRNN_RHS_CRNN && cfg->rhs_kind != CRNN_RHS_HYCHEM) return fail(nullptr, "crnn_ctx_create: unknown rhs_kind");
@@ -1277,7 +1336,7 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
         delete c;
         return fail(nullptr, "crnn_ctx_create: no gfx950 kernel instantiated for this (solver, ns, nr, has_temp)");
     }
-    if (cfg->errnorm_sens != 0 && !find_sens(c)) {
+    if (cfg->errnorm_sens != 0 && !c->hychem && !find_sens(c)) {
         delete c;
         return fail(nullptr, "crnn_ctx_create: errnorm_sens = 1 has no kernel for this (ns, nr, has_temp)");
     }

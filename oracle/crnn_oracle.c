@@ -1967,6 +1967,10 @@ typedef struct orc_hychem {
                          (crnn_pyrolysis_mass.jl:29, used :138-139): Tsit5 with stage times t + c_s dt on the T/P tables, the
                          AutoSwitch rule of solve_one_auto, Rosenbrock23 (analytic J: the reference's autodiff=false takes finite
                          differences) as the stiff algorithm; set qsteady_max = 1 with it (a composite is not an implicit type) */
+    int32_t errnorm_sens, dual_partials;   /* errnorm_sens != 0 (Rosenbrock23): the `ndir` directions of a call are ONE ForwardDiff chunk
+                         (ForwardDiff.gradient(x -> loss_n_ode(x, sample), p), crnn_pyrolysis_mass.jl:201: 211 parameters in chunks of 12)
+                         whose partials weigh in the error norm (solve_one_ws has the formula; 1: / length(u), 2: / totallength(u) with
+                         dual_partials partials per Dual -- the zero-padded ones of the last chunk count) */
     double lb, ub, inv_R, Ru, atol, rtol;
     double mw[12], scale[12], inv_yscale[12];
     double gamma, qmin, qmax, beta1, beta2, qsteady_min, qsteady_max, qoldinit;
@@ -2118,9 +2122,12 @@ int orc_hychem_solve_one(const orc_hychem *c, const double *th, const double *dt
     const int ns = c->ns, nth = c->nr * (2 * ns + 3), K = ndir + 1, PR = ndir;
     const double d = 1.0 / (2.0 + sqrt(2.0)), c32 = 6.0 + sqrt(2.0), h = 1e-30;
     const double t0 = 0.0, tend = ts[D - 1];                          /* tspan = [0, tsteps[sample]], :137 */
+    const int sens = (c->errnorm_sens != 0 && ndir > 0);
+    if (sens && c->solver != 0) return -1;                            /* the dual-inclusive norm is restated for Rosenbrock23 */
+    const double sens_div = c->errnorm_sens == 2 ? (double)ns * (1.0 + (double)c->dual_partials) : (double)ns;
     cplx *thk = (cplx *)malloc(sizeof(cplx) * (size_t)K * nth);
-    cplx *ws = (cplx *)malloc(sizeof(cplx) * (size_t)K * ns * 6);
-    cplx *u = ws, *f0 = ws + K * ns, *k1 = ws + 2 * K * ns, *k2 = ws + 3 * K * ns, *un = ws + 4 * K * ns, *f2 = ws + 5 * K * ns;
+    cplx *ws = (cplx *)malloc(sizeof(cplx) * (size_t)K * ns * 7);
+    cplx *u = ws, *f0 = ws + K * ns, *k1 = ws + 2 * K * ns, *k2 = ws + 3 * K * ns, *un = ws + 4 * K * ns, *f2 = ws + 5 * K * ns, *k3 = ws + 6 * K * ns;
     double *g = (double *)calloc((size_t)(ndir > 0 ? ndir : 1), sizeof(double));
     for (int k = 0; k < K; ++k) {
         for (int m = 0; m < nth; ++m) thk[(size_t)k * nth + m] = th[m] + (k < ndir ? I * h * dth[(size_t)k * nth + m] : 0.0);
@@ -2135,7 +2142,9 @@ int orc_hychem_solve_one(const orc_hychem *c, const double *th, const double *dt
         cplx u1[12] = {0}, f1[12] = {0};
         for (int i = 0; i < ns; ++i) { ur[i] = creal(u[PR * ns + i]); fr[i] = creal(f0[PR * ns + i]); sk[i] = c->atol + fabs(ur[i]) * c->rtol;
             d0 += (ur[i] / sk[i]) * (ur[i] / sk[i]); d1 += (fr[i] / sk[i]) * (fr[i] / sk[i]); }
-        d0 = sqrt(d0 / ns); d1 = sqrt(d1 / ns);
+        if (sens) for (int k = 0; k < ndir; ++k) for (int i = 0; i < ns; ++i) { double e = cimag(f0[k * ns + i]) / h / sk[i]; d1 += e * e; }
+        const double dv = sens ? sens_div : (double)ns;
+        d0 = sqrt(d0 / dv); d1 = sqrt(d1 / dv);
         const double dtmax = tend - t0;
         double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
         dt0 = fmin(dt0, dtmax);
@@ -2143,7 +2152,13 @@ int orc_hychem_solve_one(const orc_hychem *c, const double *th, const double *dt
         double T1, P1; hy_tab(ts, Dfull, Ttab, t + dt0, &T1, NULL); hy_tab(ts, Dfull, Ptab, t + dt0, &P1, NULL);
         hy_eval(c, thk + (size_t)PR * nth, u1, T1, P1, 0, 0, f1, NULL, NULL);
         for (int i = 0; i < ns; ++i) { f1r[i] = creal(f1[i]); double e = (f1r[i] - fr[i]) / sk[i]; d2 += e * e; }
-        d2 = sqrt(d2 / ns) / dt0;
+        if (sens) for (int k = 0; k < ndir; ++k) {   /* f1 = f(u0 + dt0 f0) with Duals: the tangent of u1 is dt0 f0' */
+            cplx u1k[12], f1k[12];
+            for (int i = 0; i < ns; ++i) u1k[i] = u[k * ns + i] + dt0 * f0[k * ns + i];
+            hy_eval(c, thk + (size_t)k * nth, u1k, T1, P1, 0, 0, f1k, NULL, NULL);
+            for (int i = 0; i < ns; ++i) { double e = cimag(f1k[i] - f0[k * ns + i]) / h / sk[i]; d2 += e * e; }
+        }
+        d2 = sqrt(d2 / dv) / dt0;
         double dm = fmax(d1, d2);
         double dt1 = dm <= 1e-15 ? fmax(1e-6, dt0 * 1e-3) : pow(10.0, -(2.0 + log10(dm)) / (c->solver == 2 ? 5.0 : 2.0));   /* order of the starting algorithm */
         dt = fmin(fmin(100 * dt0, dt1), dtmax);
@@ -2260,10 +2275,13 @@ int orc_hychem_solve_one(const orc_hychem *c, const double *th, const double *dt
                 hy_csolve(ns, W, piv, tmp);
                 for (int i = 0; i < ns; ++i) { k2[k * ns + i] = tmp[i] + k1[k * ns + i]; un[k * ns + i] = u[k * ns + i] + dt * k2[k * ns + i]; }
                 hy_eval(c, thc, un + k * ns, T2, P2, 0, 0, f2 + k * ns, NULL, NULL);
-                if (k == PR) {
+                if (k == PR || sens) {   /* the third stage: the primal's for the error estimate, with errnorm_sens the tangents' too */
                     for (int i = 0; i < ns; ++i) b[i] = f2[k * ns + i] - c32 * (k2[k * ns + i] - f1[i]) - 2.0 * (k1[k * ns + i] - f0[k * ns + i]) + dt * ftk[i];
+                    if (k != PR) for (int i = 0; i < ns; ++i) for (int cc = 0; cc < ns; ++cc)
+                        b[i] += gam * (Jk[i + ns * cc] - creal(Jk[i + ns * cc])) * creal(k3[PR * ns + cc]);
                     hy_csolve(ns, W, piv, b);
-                    for (int i = 0; i < ns; ++i) { ev[i] = dt / 6.0 * creal(k1[k * ns + i] - 2.0 * k2[k * ns + i] + b[i]);
+                    for (int i = 0; i < ns; ++i) k3[k * ns + i] = b[i];
+                    if (k == PR) for (int i = 0; i < ns; ++i) { ev[i] = dt / 6.0 * creal(k1[k * ns + i] - 2.0 * k2[k * ns + i] + b[i]);
                         if (!isfinite(creal(un[k * ns + i])) || !isfinite(ev[i])) finite = 0; }
                 }
             }
@@ -2272,7 +2290,21 @@ int orc_hychem_solve_one(const orc_hychem *c, const double *th, const double *dt
                 double s_ = 0.0;
                 for (int i = 0; i < ns; ++i) { double m = fmax(fabs(creal(u[PR * ns + i])), fabs(creal(un[PR * ns + i]))); double e = ev[i] / (c->atol + c->rtol * m); s_ += e * e; }
                 EEst = sqrt(s_ / ns);
-                if (!(EEst <= 1.0) || ndir == 0) break;
+                if (!sens && (!(EEst <= 1.0) || ndir == 0)) break;
+            } else if (sens) {   /* the dual-inclusive norm (solve_one_ws): value and the chunk's partials */
+                double ssum = 0.0;
+                for (int i = 0; i < ns; ++i) {
+                    double na = creal(u[PR * ns + i]) * creal(u[PR * ns + i]), nb = creal(un[PR * ns + i]) * creal(un[PR * ns + i]), ee = ev[i] * ev[i];
+                    for (int k = 0; k < ndir; ++k) {
+                        const double s_ = cimag(u[k * ns + i]) / h, sn_ = cimag(un[k * ns + i]) / h;
+                        const double de = dt / 6.0 * cimag(k1[k * ns + i] - 2.0 * k2[k * ns + i] + k3[k * ns + i]) / h;
+                        na += s_ * s_; nb += sn_ * sn_; ee += de * de;
+                    }
+                    const double scl = c->atol + c->rtol * sqrt(fmax(na, nb));
+                    ssum += ee / (scl * scl);
+                }
+                EEst = sqrt(ssum / sens_div);
+                if (!isfinite(EEst)) finite = 0;
             }
         }
         }

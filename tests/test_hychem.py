@@ -326,6 +326,97 @@ def test_gpu_hychem_autotsit5_composite_primal(orc, hfx):
     assert n_switch >= 3
 
 
+def test_hychem_oracle_errnorm_sens_chunks(orc, hfx):
+    """errnorm_sens in the oracle's HyChem solve (crnn_pyrolysis_mass.jl:201 as ForwardDiff evaluates it: 211 parameters in chunks of
+    12, each its own adaptive solve with the chunk's partials in the error norm): the chunks take their own step counts, the gradient
+    stays within solver tolerance of the primal-norm one, zero directions reproduce the plain step sequence."""
+    th, dth = orc.hychem_p2vec(hfx["p"])
+    b = 1
+    args = (th, hfx["u0"][b], hfx["ts"], hfx["Ttab"][b], hfx["Ptab"][b], hfx["data"][b])
+    r0 = orc.hychem_solve_one(_oracle_cfg(orc, hfx), *args, dtheta=dth)
+    counts = set()
+    g = np.zeros(211)
+    for k0 in range(0, 211, 12):
+        k1 = min(211, k0 + 12)
+        c = orc.make_hychem(dydt_scale=hfx["dydt_scale"], yscale=hfx["yscale"], errnorm_sens=2, dual_partials=12)
+        r = orc.hychem_solve_one(c, *args, dtheta=dth[k0:k1])
+        assert r["retcode"] == 0 and abs(r["loss"] - r0["loss"]) < 2e-2 * r0["loss"]
+        g[k0:k1] = r["grad"]
+        counts.add((r["naccept"], r["nreject"]))
+    assert len(counts) > 6 and np.max(np.abs(g - r0["grad"])) < 0.1 * np.max(np.abs(r0["grad"]))
+    c = orc.make_hychem(dydt_scale=hfx["dydt_scale"], yscale=hfx["yscale"], errnorm_sens=1, dual_partials=12)
+    rz = orc.hychem_solve_one(c, *args, dtheta=np.zeros((12, th.size)))
+    assert (rz["naccept"], rz["nreject"]) == (r0["naccept"], r0["nreject"]) and abs(rz["loss"] - r0["loss"]) < 1e-12 * r0["loss"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 2])
+def test_gpu_hychem_errnorm_sens_matches_oracle_chunk_for_chunk(orc, hfx, mode):
+    """crnn_config.errnorm_sens on the HyChem preset (hychem_sens_kernel: a group of twelve lanes per trajectory, the tangents through
+    every attempt by nested dual numbers) against the oracle's chunked complex-step solves: the same step sequence (accepted / rejected
+    counts) and gradient pieces to 1e-6 of the largest entry in every chunk that is well-conditioned by the oracle's own measure; the batched call (crnn_loss_grad) assembles
+    the same pieces; loss and step statistics of a gradient call are the plain solve's."""
+    from crnn_amd import p2vec_jac
+    # the fixture's three conditions (two hot, one cold) + the cold one twice more with other observations and a leaner mixture
+    u0c = hfx["u0"][2].copy(); u0c[0] *= 0.8; u0c[5] += 0.2 * hfx["u0"][2][0]
+    u0 = np.concatenate([hfx["u0"], hfx["u0"][2:3], u0c[None]]); data = np.concatenate([hfx["data"], 0.9 * hfx["data"][0:1], 1.1 * hfx["data"][1:2]])
+    Tt = np.concatenate([hfx["Ttab"], hfx["Ttab"][2:3], hfx["Ttab"][2:3]]); Pt = np.concatenate([hfx["Ptab"], hfx["Ptab"][2:3], hfx["Ptab"][2:3]])
+    B = u0.shape[0]
+    node = _node(hfx, u0, data, Tt, Pt, errnorm_sens=mode)
+    plain = _node(hfx, u0, data, Tt, Pt)
+    p = hfx["p"]
+    th, dth = orc.hychem_p2vec(p)
+    gsum = np.zeros(211)
+    # The fixture's two hot trajectories are ill-conditioned in this mode: a species crosses its clamp at lb from below, the tangent
+    # jumps there, and with the tangents inside the error norm the STEP SEQUENCE inherits the sensitivity -- the oracle's own chunk
+    # counts move ((169, 105) -> (165, 96)) and its gradient by 3e-4 when p is perturbed by 1e-13 (tools/hy_sens_probe.py).  So every
+    # trajectory is classified by the oracle itself: where a 1e-13 perturbation of p leaves the step counts of all 18 chunks alone the device must reproduce
+    # counts exactly and the gradient piece to 1e-6; elsewhere to what such perturbations move (the accepted counts by up to 15 %, the rejected
+    # ones -- there are more rejected than accepted attempts on these trajectories: every step across the kink fails its test -- by up to
+    # half, the gradient by 1e-2).
+    p_pert = p * (1 + 1e-13 * np.random.default_rng(0).standard_normal(211))
+    th2, dth2 = orc.hychem_p2vec(p_pert)
+    n_exact = n_loose = 0
+    tol_sum = 0.0
+    for b in range(B):
+        g = node.gradient(p, b)
+        stats = list(node.last_chunk_stats)
+        assert len(stats) == 18
+        gref = np.zeros(211)
+        gmax = None
+        pieces = []
+        for ci, k0 in enumerate(range(0, 211, 12)):
+            k1 = min(211, k0 + 12)
+            c = orc.make_hychem(dydt_scale=hfx["dydt_scale"], yscale=hfx["yscale"], errnorm_sens=mode, dual_partials=12)
+            r = orc.hychem_solve_one(c, th, u0[b], hfx["ts"], Tt[b], Pt[b], data[b], dtheta=dth[k0:k1])
+            r2 = orc.hychem_solve_one(c, th2, u0[b], hfx["ts"], Tt[b], Pt[b], data[b], dtheta=dth2[k0:k1])
+            assert r["retcode"] == 0
+            gref[k0:k1] = r["grad"]
+            pieces.append((ci, k0, k1, (r["naccept"], r["nreject"]), (r2["naccept"], r2["nreject"])))
+        gmax = np.max(np.abs(gref))
+        stable = all(cnt == cnt2 for _, _, _, cnt, cnt2 in pieces)      # the TRAJECTORY is well-conditioned: no chunk's counts moved
+        for ci, k0, k1, cnt, cnt2 in pieces:
+            if stable:
+                assert stats[ci] == cnt, (b, ci, stats[ci], cnt)
+                assert np.max(np.abs(g[k0:k1] - gref[k0:k1])) < 1e-6 * gmax, (b, ci)
+                n_exact += 1
+            else:
+                assert abs(stats[ci][0] - cnt[0]) <= 0.15 * cnt[0] and abs(stats[ci][1] - cnt[1]) <= 0.5 * cnt[1] + 5, (b, ci, stats[ci], cnt)
+                assert np.max(np.abs(g[k0:k1] - gref[k0:k1])) < 1e-2 * gmax, (b, ci)
+                n_loose += 1
+        gsum += gref
+        tol_sum += (1e-6 if stable else 1e-2) * gmax
+    assert n_exact >= 36           # the well-conditioned trajectories (at least two of the five): all 18 chunks step for step
+    print(f"errnorm_sens {mode}: {n_exact} chunks step for step, {n_loose} ill-conditioned ones within the oracle's own sensitivity")
+    L, G = node.loss_and_grad(p)
+    L0 = plain.losses(p).mean()
+    assert abs(L - L0) < 1e-12 * L0 and node.last_stats["n_accept"] == plain.last_stats["n_accept"]
+    assert np.max(np.abs(G - gsum / B)) < tol_sum / B + 1e-9 * np.max(np.abs(gsum / B))      # the same pieces, each to its trajectory's bar
+    G0 = plain.loss_and_grad(p)[1]
+    assert np.max(np.abs(G - G0)) / np.max(np.abs(G0)) > 1e-4            # a different number than the primal-norm gradient
+    node.close(); plain.close()
+
+
 @pytest.mark.gpu
 def test_gpu_hychem_tape_overflow_degrades_instead_of_failing(hfx, monkeypatch):
     """a HyChem trajectory that outran the adjoint tape aborted the call.  With the tape sized automatically the launch is
