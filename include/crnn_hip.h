@@ -102,8 +102,9 @@ typedef struct crnn_config {
                                      call takes the step sequence of a plain solve; every gradient algorithm).  1: ForwardDiff's
                                      dual-inclusive norm, chunked like ForwardDiff.pickchunksize -- what the reference's
                                      ForwardDiff.gradient through the adaptive solver does (case2/case2.jl:195); Rosenbrock23 and
-                                     Tsit5, forward tangents (grad_mode AUTO or FORWARD), CRNN right-hand side.  crnn_solve then
-                                     treats its n_dir directions as ONE chunk (n_dir <= 9 case2, 12 case1 / robertson);
+                                     Tsit5, forward tangents (grad_mode AUTO or FORWARD); round 4: also the HyChem right-hand side
+                                     (Rosenbrock23; crnn_pyrolysis_mass.jl:201: 211 parameters in 18 chunks of 12).  crnn_solve then
+                                     treats its n_dir directions as ONE chunk (n_dir <= 9 case2, 12 case1 / robertson / HyChem);
                                      crnn_loss_grad / crnn_train_step run ForwardDiff's chunks, loss and statistics from a
                                      final plain solve.  The squared norm is divided by length(u) -- DiffEqBase of the Julia-1.6
                                      era the reference's README names for case1 / case2 / robertson.  2: the same with

@@ -133,7 +133,26 @@ def hychem(B=32768, reps=4, device=0):
     kms, wall, st = _time_calls(node, p, reps)
     prim = _primal_ms(node, p, 3)
     node.close()
-    return _entry("hychem", B, kms, st, {"primal_kernel_ms": prim, "workload": "HyChem pyrolysis CRNN, 32 768 ICs (one GPU's share of 262 144), T(t)/P(t) tables, "
+    extra4 = {}
+    if B == 32768:      # round 4: the reference's composite for primal launches; the gradient as ForwardDiff evaluates it (1 024 of the ICs)
+        from crnn_amd import SOLVER_AUTOTSIT5
+        comp = NeuralODE(ODEProblem(PRESET_HYCHEM, ts, rate_scale=hy.DYDT_SCALE, device=device, solver=SOLVER_AUTOTSIT5))
+        comp.set_ensemble(u0, data, ys); comp.set_tables(Tt, Pt)
+        extra4["primal_autotsit5_kernel_ms"] = _primal_ms(comp, p, 3)
+        extra4["primal_autotsit5_steps_per_traj"] = comp.last_stats["n_accept"] / B
+        comp.close()
+        n = 1024
+        sens = NeuralODE(ODEProblem(PRESET_HYCHEM, ts, rate_scale=hy.DYDT_SCALE, device=device, errnorm_sens=2))
+        sens.set_ensemble(u0[:n], data[:n], ys); sens.set_tables(Tt[:n], Pt[:n])
+        sens.loss_and_grad(p)
+        t0 = time.perf_counter(); sens.loss_and_grad(p); w = (time.perf_counter() - t0) * 1e3
+        sens.close()
+        extra4["errnorm_sens2_B1024_call_ms"] = w
+        extra4["errnorm_sens2_value"] = n / (w * 1e-3)
+        extra4["errnorm_sens_note"] = ("crnn_config.errnorm_sens = 2 on the HyChem preset: ForwardDiff's 18 chunks of 12 partials, each its own "
+                                       "adaptive solve with the partials in the error norm (hychem_sens_kernel) + the plain solve; wall time of one "
+                                       "loss+gradient call over 1 024 ICs")
+    return _entry("hychem", B, kms, st, {**extra4, "primal_kernel_ms": prim, "workload": "HyChem pyrolysis CRNN, 32 768 ICs (one GPU's share of 262 144), T(t)/P(t) tables, "
                                                      "Rosenbrock23 atol 1e-8 rtol 1e-3, adjoint gradient (P = 211)",
                                          "kernel": "hychem2_kernel<9,10,GRAD,256> (a lane pair per trajectory, W's rows in registers, LDS frame, "
                                                    "gradient summed over each batch of 32 by v_mfma_f64_16x16x4: no accumulator in HBM)"}, wall,
@@ -165,6 +184,22 @@ def cathode(n_part=4096, n_rates=256, reps=3, device=0):
     for _ in range(3):
         uq.solve(p, want_grad=False)
         pk.append(uq.last_stats["kernel_ms"])
+    # round 4: primal launches through the reference's composite (network.jl:195); the gradient as ForwardDiff evaluates it
+    comp_ms = {}
+    for name in ("autotsit5_trbdf2", "autotsit5_rosenbrock23"):
+        uq.set_solver(name)
+        ck = []
+        for _ in range(3):
+            uq.solve(p, want_grad=False)
+            ck.append(uq.last_stats["kernel_ms"])
+        comp_ms[name] = (float(np.median(ck[1:])), uq.last_stats["n_accept"] / uq.last_stats["n_traj"])
+    uq.set_solver("rosenbrock23")
+    sens = CathodeUQ(exp_data, betas, fx["theta"], normalizer=np.ones((n_rates, 3)), device=device, errnorm_sens=2)
+    sens.solve(p)
+    t0 = time.perf_counter(); sens.solve(p); sens_wall = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter(); uq.solve(p); adj_wall = (time.perf_counter() - t0) * 1e3
+    sens_chunks = sens.last_chunk_stats()
+    sens.close()
     # the reference's own iteration (crnn_cathode.jl:36-50): ONE heating rate per SVGD move, particles resident on the device --
     # solve of n_part trajectories + chain rule + exact-median select + kernel sums + update, enqueued back to back
     uq.set_particles(p)
@@ -177,6 +212,15 @@ def cathode(n_part=4096, n_rates=256, reps=3, device=0):
                   {"workload": "Cathode-UQ: 4 096 particles x 256 heating rates, non-autonomous Rosenbrock23 atol 1e-12 rtol 1e-3, "
                                "per-particle adjoint gradients (17 parameters each)", "kernel": "cathode_adj_kernel<256,1> (full tape, two wavefronts per SIMD, accumulators in LDS)",
                    "primal_kernel_ms": float(np.median(pk[1:])),
+                   "primal_autotsit5_trbdf2_kernel_ms": comp_ms["autotsit5_trbdf2"][0], "primal_autotsit5_trbdf2_steps_per_traj": comp_ms["autotsit5_trbdf2"][1],
+                   "primal_autotsit5_rosenbrock23_kernel_ms": comp_ms["autotsit5_rosenbrock23"][0],
+                   "composite_note": "crnn_cathode_set_solver: primal launches through AutoTsit5(TRBDF2) (the reference's alg, network.jl:195) / "
+                                     "AutoTsit5(Rosenbrock23): a third of Rosenbrock23's accepted steps, six right-hand sides per step instead of two",
+                   "errnorm_sens2_call_ms": sens_wall, "adjoint_call_ms": adj_wall,
+                   "errnorm_sens2_steps_per_traj_chunks": [sens_chunks[0][0] / (n_part * n_rates), sens_chunks[1][0] / (n_part * n_rates)],
+                   "errnorm_sens_note": "crnn_cathode_set_errnorm_sens(2): ForwardDiff's chunks 9 + 8, each its own adaptive solve with the partials in "
+                                        "the error norm (cathode_sens_kernel) + the plain solve; wall time of one gradient call incl. the read-back, next "
+                                        "to the adjoint call's",
                    "svgd_move_ms": float(np.median(sv[2:])), "svgd_iteration_solve_ms": float(np.median(so[2:])),
                    "svgd_note": "device-resident SVGD iteration (crnn_cathode_svgd_step): svgd_iteration_solve_ms = the solve kernel "
                                 "over the 4 096 particles of ONE heating rate, svgd_move_ms = median select + kernel sums + move "
