@@ -37,6 +37,13 @@ __device__ __forceinline__ double pair_sum(double a) {
 }
 __device__ __forceinline__ int pair_and(int a) { return a & __builtin_amdgcn_update_dpp(0, a, 0xB1, 0xF, 0xF, true); }
 
+// CRNN_ADJ2_LEAN (round 4 experiment): the lane's weight rows and tolerances are re-read from LDS where they are used (the
+// two lanes of a pair need different rows, but there are only two variants per wavefront: a broadcast read) and its gradient accumulators
+// live in the staging area's cells (lane-private: ds_add_f64, fire and forget) -- 51 doubles less in registers, for a build at two
+// wavefronts per SIMD (CRNN_ADJ2_OCC = 2).  NS even only (no padding slot whose weights would have to read as zero).
+#ifndef CRNN_ADJ2_LEAN
+#define CRNN_ADJ2_LEAN 0
+#endif
 template <int NS, int NR, bool HAS_T, int BLOCK, int OCC>
 __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParams prm, const double *__restrict__ theta,
                                                                 const AdjParams adj) {
@@ -52,7 +59,10 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
     __shared__ double kc_lds[kNConst];
     __shared__ double ts_lds[kMaxSave];
     __shared__ double stage_lds[(NTH + kExtra) * GPB];    // batch sums: [column][pair of this block]
+    constexpr bool LEAN = (CRNN_ADJ2_LEAN != 0) && (NS % 2 == 0);
+    __shared__ double th2_lds[LEAN ? NTH : 1];
     const int tid = threadIdx.x;
+    if (LEAN) for (int idx = tid; idx < NTH; idx += BLOCK) th2_lds[idx] = theta[idx];
     for (int idx = tid; idx < kNConst; idx += BLOCK) kc_lds[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
     for (int idx = tid; idx < prm.n_save; idx += BLOCK) ts_lds[idx] = prm.tsave[idx];
     __syncthreads();
@@ -64,8 +74,8 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
     const int giw = lane >> 1;              // pair index within the wavefront (0..31)
 
     // ---- this lane's weights and per-species constants, in registers for the whole kernel
-    double wi[H][NR], wo[H][NR], wT[NR], wb_[NR];
-    double atl[H], rtl[H], iys[H];
+    double wi_[LEAN ? 1 : H][NR], wo_[LEAN ? 1 : H][NR], wT[LEAN ? 1 : NR], wb_[LEAN ? 1 : NR];
+    double atl_[LEAN ? 1 : H], rtl_[LEAN ? 1 : H], iys_[LEAN ? 1 : H];
     int dro[H];                             // data column of the species, -1 if unobserved (or padding)
     bool own[H];
 #pragma unroll
@@ -73,21 +83,35 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
         const int c = m * H + i;
         own[i] = c < NS;
         const int cc = own[i] ? c : 0;
+        if constexpr (!LEAN) {
 #pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            wi[i][j] = own[i] ? theta[L_::wi(cc, j)] : 0.0;
-            wo[i][j] = own[i] ? theta[L_::wo(cc, j)] : 0.0;
+            for (int j = 0; j < NR; ++j) {
+                wi_[i][j] = own[i] ? theta[L_::wi(cc, j)] : 0.0;
+                wo_[i][j] = own[i] ? theta[L_::wo(cc, j)] : 0.0;
+            }
+            atl_[i] = own[i] ? kc->atol[cc] : 1.0;
+            rtl_[i] = own[i] ? kc->rtol[cc] : 0.0;
+            iys_[i] = own[i] ? kc->inv_yscale[cc] : 0.0;
         }
-        atl[i] = own[i] ? kc->atol[cc] : 1.0;
-        rtl[i] = own[i] ? kc->rtol[cc] : 0.0;
-        iys[i] = own[i] ? kc->inv_yscale[cc] : 0.0;
         dro[i] = own[i] ? (int)kc->drow[cc] : -1;
     }
+    if constexpr (!LEAN) {
 #pragma unroll
-    for (int j = 0; j < NR; ++j) {
-        wT[j] = HAS_T ? theta[L_::wi(NS, j)] : 0.0;
-        wb_[j] = theta[L_::wb(j)];
+        for (int j = 0; j < NR; ++j) {
+            wT[j] = HAS_T ? theta[L_::wi(NS, j)] : 0.0;
+            wb_[j] = theta[L_::wb(j)];
+        }
     }
+    // LEAN: this lane's rows through a pointer that is re-derived (opaque zero) in every phase, so that the reads are neither hoisted
+    // out of the step loops nor kept alive across phases
+    const double *const thl0 = th2_lds + (LEAN ? m * H : 0);
+    const double *const kcl0 = kc_lds;
+#define ADJ2_THP() (thl0 + opaque_zero())
+#define WI(i, j) (LEAN ? thp[L_::wi((i), (j))] : wi_[LEAN ? 0 : (i)][(j)])
+#define WO(i, j) (LEAN ? thp[L_::wo((i), (j))] : wo_[LEAN ? 0 : (i)][(j)])
+#define ATL(i) (LEAN ? reinterpret_cast<const KConst *>(kcl0 + opaque_zero())->atol[m * H + (i)] : atl_[LEAN ? 0 : (i)])
+#define RTL(i) (LEAN ? reinterpret_cast<const KConst *>(kcl0 + opaque_zero())->rtol[m * H + (i)] : rtl_[LEAN ? 0 : (i)])
+#define IYS(i) (LEAN ? reinterpret_cast<const KConst *>(kcl0 + opaque_zero())->inv_yscale[m * H + (i)] : iys_[LEAN ? 0 : (i)])
 
     const double d_ = 0.29289321881345248;    // 1/(2+sqrt 2)
     const double c32 = 7.4142135623730950;    // 6+sqrt 2
@@ -119,13 +143,15 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
         double xT = 0.0, Tconst = 0.0;
         // point evaluation: x = log clamp(u), g = dx/du (this lane's species); r (replicated); f (this lane's species)
         auto eval_point = [&](const double (&uu)[H], double (&x)[H], double (&g)[H], double (&r)[NR], double (&f)[H]) {
+            const double *const thp = ADJ2_THP();
+            (void)thp;
             features<H>(uu, kc->lb, kc->ub, x, g);
             double z[NR];
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
                 double a = 0.0;
 #pragma unroll
-                for (int i = 0; i < H; ++i) a = fma(wi[i][j], x[i], a);
+                for (int i = 0; i < H; ++i) a = fma(WI(i, j), x[i], a);
                 z[j] = pair_sum(a) + bT[j];
             }
             fexp_vec<NR>(z, r);
@@ -133,7 +159,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
             for (int i = 0; i < H; ++i) {
                 double a = 0.0;
 #pragma unroll
-                for (int j = 0; j < NR; ++j) a = fma(wo[i][j], r[j], a);
+                for (int j = 0; j < NR; ++j) a = fma(WO(i, j), r[j], a);
                 f[i] = a;
             }
         };
@@ -142,16 +168,18 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
         int piv[NR];
         bool wave_pivots = false;
         auto factor = [&](const double (&g)[H], const double (&r)[NR], const double gam) -> bool {
+            const double *const thp = ADJ2_THP();
+            (void)thp;
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
                 double tj[H];
 #pragma unroll
-                for (int i = 0; i < H; ++i) tj[i] = wi[i][j] * g[i];
+                for (int i = 0; i < H; ++i) tj[i] = WI(i, j) * g[i];
 #pragma unroll
                 for (int l = 0; l < NR; ++l) {
                     double a = 0.0;
 #pragma unroll
-                    for (int i = 0; i < H; ++i) a = fma(tj[i], wo[i][l], a);
+                    for (int i = 0; i < H; ++i) a = fma(tj[i], WO(i, l), a);
                     M[j][l] = ((j == l) ? 1.0 : 0.0) - (gam * r[l]) * pair_sum(a);
                 }
             }
@@ -162,12 +190,14 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
         };
         // b <- W^-1 b = b + w_out (gr .* M^-1 (w_in^T (g .* b)))
         auto solve = [&](const double (&g)[H], const double (&gr)[NR], double (&bb)[H]) {
+            const double *const thp = ADJ2_THP();
+            (void)thp;
             double y[NR];
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
                 double a = 0.0;
 #pragma unroll
-                for (int i = 0; i < H; ++i) a = fma(wi[i][j], g[i] * bb[i], a);
+                for (int i = 0; i < H; ++i) a = fma(WI(i, j), g[i] * bb[i], a);
                 y[j] = pair_sum(a);
             }
             lu_solve<NR>(M, dinv, piv, wave_pivots, y);
@@ -177,18 +207,20 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
             for (int i = 0; i < H; ++i) {
                 double a = 0.0;
 #pragma unroll
-                for (int j = 0; j < NR; ++j) a = fma(wo[i][j], y[j], a);
+                for (int j = 0; j < NR; ++j) a = fma(WO(i, j), y[j], a);
                 bb[i] += a;
             }
         };
         // b <- W^-T b = b + g .* (w_in (M^-T (gr .* (w_out^T b))))
         auto solve_Tr = [&](const double (&g)[H], const double (&gr)[NR], double (&bb)[H]) {
+            const double *const thp = ADJ2_THP();
+            (void)thp;
             double y[NR];
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
                 double a = 0.0;
 #pragma unroll
-                for (int i = 0; i < H; ++i) a = fma(wo[i][j], bb[i], a);
+                for (int i = 0; i < H; ++i) a = fma(WO(i, j), bb[i], a);
                 y[j] = pair_sum(a) * gr[j];
             }
             lu_solve_T<NR>(M, dinv, piv, wave_pivots, y);
@@ -196,7 +228,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
             for (int i = 0; i < H; ++i) {
                 double a = 0.0;
 #pragma unroll
-                for (int j = 0; j < NR; ++j) a = fma(wi[i][j], y[j], a);
+                for (int j = 0; j < NR; ++j) a = fma(WI(i, j), y[j], a);
                 bb[i] = fma(a, g[i], bb[i]);
             }
         };
@@ -213,7 +245,10 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
             xT = kc->inv_R * frcp(Tconst);
         }
 #pragma unroll
-        for (int j = 0; j < NR; ++j) bT[j] = HAS_T ? fma(wT[j], xT, wb_[j]) : wb_[j];
+        for (int j = 0; j < NR; ++j) {
+            const double wTj = LEAN ? (HAS_T ? th2_lds[L_::wi(NS, j)] : 0.0) : wT[LEAN ? 0 : j], wbj = LEAN ? th2_lds[L_::wb(j)] : wb_[LEAN ? 0 : j];
+            bT[j] = HAS_T ? fma(wTj, xT, wbj) : wbj;
+        }
         {
             double x0[H];
             eval_point(u, x0, g0, r0, f0);
@@ -221,7 +256,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
             double d0 = 0.0, d1 = 0.0, sk[H];
 #pragma unroll
             for (int i = 0; i < H; ++i) {
-                sk[i] = own[i] ? frcp(fma(fabs(u[i]), rtl[i], atl[i])) : 0.0;
+                sk[i] = own[i] ? frcp(fma(fabs(u[i]), RTL(i), ATL(i))) : 0.0;
                 const double a = u[i] * sk[i], c = f0[i] * sk[i];
                 d0 = fma(a, a, d0);
                 d1 = fma(c, c, d1);
@@ -313,7 +348,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
                         const double k2i = k1[i] + dk[i];
                         const double ev = dt * (1.0 / 6.0) * (k1[i] - 2.0 * k2i + k3[i]);
                         const double mx = fmax(fabs(u[i]), fabs(unew[i]));
-                        const double e = ev * frcp1(fma(rtl[i], mx, atl[i]));
+                        const double e = ev * frcp1(fma(RTL(i), mx, ATL(i)));
                         es = fma(e, e, es);
                         finite = finite && isfinite(unew[i]) && isfinite(ev);
                     }
@@ -382,11 +417,17 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
         // ================================================================== reverse sweep
         const int n_saved = jsave;
         const int jlo = start_saved ? 1 : 0;
-        double awi[H][NR], awo[H][NR];     // d loss / d (this lane's rows of w_in, w_out): registers, no atomics
+        double awi[LEAN ? 1 : H][NR], awo[LEAN ? 1 : H][NR];     // d loss / d (this lane's rows of w_in, w_out): registers, no atomics
+        double *const stc = stage_lds + gib;               // LEAN: the accumulators live in the pair's staging cells (this lane's rows)
 #pragma unroll
         for (int i = 0; i < H; ++i)
 #pragma unroll
-            for (int j = 0; j < NR; ++j) { awi[i][j] = 0.0; awo[i][j] = 0.0; }
+            for (int j = 0; j < NR; ++j) {
+                if constexpr (LEAN) { stc[L_::wi(m * H + i, j) * GPB] = 0.0; stc[L_::wo(m * H + i, j) * GPB] = 0.0; }
+                else { awi[LEAN ? 0 : i][j] = 0.0; awo[LEAN ? 0 : i][j] = 0.0; }
+            }
+#define AWI_ADD(i, j, val) do { if constexpr (LEAN) unsafeAtomicAdd(&stc[L_::wi(m * H + (i), (j)) * GPB], (val)); else awi[LEAN ? 0 : (i)][(j)] += (val); } while (0)
+#define AWO_ADD(i, j, val) do { if constexpr (LEAN) unsafeAtomicAdd(&stc[L_::wo(m * H + (i), (j)) * GPB], (val)); else awo[LEAN ? 0 : (i)][(j)] += (val); } while (0)
         double lam[H];
 #pragma unroll
         for (int i = 0; i < H; ++i) lam[i] = 0.0;
@@ -477,11 +518,12 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
                                 mask = (v > kc->ub || v < -kc->ub) ? 0.0 : 1.0;
                                 v = clampv(v, -kc->ub, kc->ub);
                             }
-                            const double rr = (dobs[i] - v) * iys[i];
+                            const double iy = IYS(i);
+                            const double rr = (dobs[i] - v) * iy;
                             double w;
                             if (prm.loss_kind == 0) { loss_sum += fabs(rr); w = signbit(rr) ? 1.0 : -1.0; }
                             else { loss_sum = fma(rr, rr, loss_sum); w = -2.0 * rr; }
-                            w *= mask * iys[i];
+                            w *= mask * iy;
                             A_[i] += w;
                             B1[i] = fma(w, h * c1, B1[i]);
                             B2[i] = fma(w, h * c2, B2[i]);
@@ -513,12 +555,14 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
                 solve_Tr(gg0, gr0, v);                 // v = W^-T kb2
 #pragma unroll
                 for (int i = 0; i < H; ++i) kb1[i] -= v[i];
+                const double *const thp = ADJ2_THP();
+                (void)thp;
                 double av[NR];
 #pragma unroll
                 for (int j = 0; j < NR; ++j) {
                     double a = 0.0;
 #pragma unroll
-                    for (int i = 0; i < H; ++i) a = fma(v[i], wo[i][j], a);
+                    for (int i = 0; i < H; ++i) a = fma(v[i], WO(i, j), a);
                     av[j] = pair_sum(a);
                 }
                 double rho1[NR];   // av_j r_j(u_mid)
@@ -531,7 +575,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
                         const double rho = av[j] * r1[j];
                         rho1[j] = rho;
 #pragma unroll
-                        for (int i = 0; i < H; ++i) um[i] = fma(rho, wi[i][j], um[i]);
+                        for (int i = 0; i < H; ++i) um[i] = fma(rho, WI(i, j), um[i]);
                     }
 #pragma unroll
                     for (int i = 0; i < H; ++i) {
@@ -550,8 +594,8 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
                         double aw = 0.0, q1 = 0.0, qd = 0.0;
 #pragma unroll
                         for (int i = 0; i < H; ++i) {
-                            aw = fma(kb1[i], wo[i][j], aw);
-                            const double wg = wi[i][j] * gg0[i];
+                            aw = fma(kb1[i], WO(i, j), aw);
+                            const double wg = WI(i, j) * gg0[i];
                             q1 = fma(wg, k1[i], q1);
                             qd = fma(wg, dk[i], qd);
                         }
@@ -568,10 +612,11 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
 #pragma unroll
                         for (int i = 0; i < H; ++i) {
                             const double mm = fma(pv, dk[i], gpw * k1[i]);
-                            awi[i][j] += fma(rho1[j], x1[i], fma(beta, x0[i], gg0[i] * mm));
-                            s1[i] = fma(beta, wi[i][j], s1[i]);
-                            s2[i] = fma(wi[i][j], mm, s2[i]);
-                            awo[i][j] += fma(v[i], ca, kb1[i] * cb);
+                            AWI_ADD(i, j, fma(rho1[j], x1[i], fma(beta, x0[i], gg0[i] * mm)));
+                            const double wij = WI(i, j);
+                            s1[i] = fma(beta, wij, s1[i]);
+                            s2[i] = fma(wij, mm, s2[i]);
+                            AWO_ADD(i, j, fma(v[i], ca, kb1[i] * cb));
                         }
                     }
 #pragma unroll
@@ -592,7 +637,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
                 if (dro[i] >= 0) {
                     double v = prm.u0[(size_t)(m * H + i) * prm.B + b];
                     if (prm.clamp_pred) v = clampv(v, -kc->ub, kc->ub);
-                    const double rr = (drows[doff[i]] - v) * iys[i];
+                    const double rr = (drows[doff[i]] - v) * IYS(i);
                     loss_sum += (prm.loss_kind == 0) ? fabs(rr) : rr * rr;
                 }
             }
@@ -617,8 +662,11 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
                 if (own[i]) {
 #pragma unroll
                     for (int j = 0; j < NR; ++j) {
-                        st[L_::wi(m * H + i, j) * GPB] = awi[i][j] * scale_;
-                        st[L_::wo(m * H + i, j) * GPB] = awo[i][j] * scale_;
+                        if constexpr (LEAN) { st[L_::wi(m * H + i, j) * GPB] *= scale_; st[L_::wo(m * H + i, j) * GPB] *= scale_; }
+                        else {
+                            st[L_::wi(m * H + i, j) * GPB] = awi[LEAN ? 0 : i][j] * scale_;
+                            st[L_::wo(m * H + i, j) * GPB] = awo[LEAN ? 0 : i][j] * scale_;
+                        }
                     }
                 }
             }
@@ -651,4 +699,12 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
     }
 }
 
+#undef ADJ2_THP
+#undef WI
+#undef WO
+#undef ATL
+#undef RTL
+#undef IYS
+#undef AWI_ADD
+#undef AWO_ADD
 }  // namespace crnn
