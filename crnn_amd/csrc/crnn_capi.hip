@@ -807,10 +807,11 @@ int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int 
 // (ros23_sens_kernel.hpp), fixed-order reduction into c->d_red in the common layout.
 int32_t launch_sens_chunk(Ctx *c, const KernelEntry *k, const double *d_theta, const double *d_dtheta, int P, int64_t first,
                           int64_t count, int n_save_active, bool want_pred, int dual_partials) {
-    const int C = k->C, L = k->L, gpw = 64 / L, waves = kSensBlock / 64;
+    const int blk = kSensBlock;
+    const int C = k->C, L = k->L, gpw = 64 / L, waves = blk / 64;
     const int ppad = L * C, npart_pad = ppad + crnn::kExtra, npart = P + crnn::kTail;
     int occ = 0;
-    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k->fn, kSensBlock, 0));
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k->fn, blk, 0));
     if (occ < 1) occ = 1;
     const int64_t gpb = (int64_t)waves * gpw;
     const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((count + gpb - 1) / gpb, (int64_t)c->num_cu * occ));
@@ -827,13 +828,17 @@ int32_t launch_sens_chunk(Ctx *c, const KernelEntry *k, const double *d_theta, c
     crnn::SolveParams prm{};
     fill_params(c, prm, P, first, count, n_save_active, want_pred);
     prm.norm_cols = c->cfg.errnorm_sens == 2 ? dual_partials : 0;
+    // batches in the order of the last plain solve's step counts (the chunk's own counts differ little from them); the order
+    // stays with the context for the plain solve that ends this gradient call (queue_by_steps)
+    prm.perm = (c->queue_order == CRNN_QUEUE_AUTO && c->perm_ready && c->perm_first == first && c->perm_count == count) ? c->d_perm : nullptr;
     if (upload_consts(c)) return -1;
+    if (!c->flags_zeroed) HIP_TRY(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), c->stream));
     c->flags_zeroed = false;
     c->ev0 = c->ring0[c->n_launch % Ctx::kRing];
     c->ev1 = c->ring1[c->n_launch % Ctx::kRing];
     ++c->n_launch;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    hipLaunchKernelGGL(k->fn, dim3(nblk), dim3(kSensBlock), 0, c->stream, prm, d_theta, d_dtheta);
+    hipLaunchKernelGGL(k->fn, dim3(nblk), dim3(blk), 0, c->stream, prm, d_theta, d_dtheta);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     hipLaunchKernelGGL(crnn::reduce_traj_kernel, dim3(rblk), dim3(256), 0, c->stream, c->d_gtraj, ppad, c->d_loss, c->d_ret,

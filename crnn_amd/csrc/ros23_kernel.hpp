@@ -97,6 +97,7 @@ struct SolveParams {
     int32_t P;             // tangent directions
     int32_t maxiters, clamp_pred, loss_kind, n_obs;
     int32_t norm_cols;     // dual-norm kernels: 0 = divide the squared norm by n; N > 0 = by n (1 + N), N partials per Dual
+    const int32_t *perm;   // ros23_sens1_kernel: position in the queue -> trajectory (relative to first); null = index order
 };
 
 // ---------------------------------------------------------------------------

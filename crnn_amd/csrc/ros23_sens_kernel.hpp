@@ -21,8 +21,8 @@
 // step computed redundantly, a per-group LDS step record that lane 0 of the group publishes) with three differences:
 // the seeds of the save points inside the attempted step, the new tangent columns (second LDS slot) and the gradient
 // increments are PROVISIONAL until the group has summed its lanes' norm contributions (three ds_bpermute rounds per
-// species) and taken the decision; the record also carries the u+ point and k3; trajectories are assigned by a plain
-// grid-stride loop.  This mode costs about (1 + 1.6 C L) primal attempts per attempt and three or four launches per
+// species) and taken the decision; the record also carries the u+ point and k3; trajectories come in wave-synchronous
+// batches from a queue.  This mode costs about (1 + 1.6 C L) primal attempts per attempt and three or four launches per
 // gradient: it exists for parity with the reference's step sequence, not for speed (bench.py reports its cost).
 #pragma once
 #include "ros23_kernel.hpp"
@@ -193,8 +193,12 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
     const double dtmax = tend - t0;
     const double lqinit = flog(kc->qoldinit);
 
-    const int64_t ngroups = (int64_t)gridDim.x * WAVES * GPW;
-    int64_t traj = lane_active ? ((int64_t)blockIdx.x * WAVES + wave) * GPW + grp : prm.count;
+    // wave-synchronous batches of GPW trajectories from a queue (one atomic per batch, fetched a batch ahead); positions map to
+    // trajectories through SolveParams::perm when the context has an order by step counts (its last plain solve): a batch
+    // lasts as long as its longest trajectory, so it should be homogeneous, and the queue longest-first
+    const unsigned nwaves = gridDim.x * WAVES;
+    const int64_t nbatch = (prm.count + GPW - 1) / GPW;
+    int64_t bi = (int64_t)blockIdx.x * WAVES + wave;
 
     // sum of v over the L lanes of this lane's group, in lane order (identical on every lane of the group)
     auto group_sum = [&](double v) -> double {
@@ -204,7 +208,13 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
         return a;
     };
 
-    for (; traj < prm.count; traj += ngroups) {
+    for (; bi < nbatch;) {
+        unsigned nx = 0;
+        if (lane == 0) nx = (unsigned)atomicAdd(prm.queue, 1ULL);
+        const int64_t pos = bi * GPW + grp;
+        if (lane_active && pos < prm.count) {
+        CRNN_CHK(!prm.perm || ((int64_t)prm.perm[pos] >= 0 && (int64_t)prm.perm[pos] < prm.count), 0x5001);
+        const int64_t traj = prm.perm ? (int64_t)prm.perm[pos] : pos;
         const int64_t b = prm.first + traj;
         const double *const drows = prm.data + (size_t)b * prm.row_stride;
         double u[NS], f0[NS], g0[NS], x0[NS], r0[NR], bT[NR], gtr[C];
@@ -594,6 +604,8 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
         double *grow = prm.gtraj + (size_t)traj * PPAD + chunk * C;
 #pragma unroll
         for (int q_ = 0; q_ < C; ++q_) grow[q_] = gtr[q_] * inv_den;
+        }
+        bi = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)nx) + nwaves;
     }
 }
 
