@@ -56,6 +56,7 @@ using KernelFn = void (*)(const crnn::SolveParams, const double *, const double 
 struct KernelEntry {
     int solver, ns, nr, has_t, use_scale, C, L;
     KernelFn fn;
+    int drows = 0;   // dual-norm kernels: rows of d theta / d p the kernel stages (> P: all chunks of a gradient in one launch)
 };
 
 constexpr int kBlock = 256;
@@ -81,12 +82,14 @@ const KernelEntry kKernels[] = {
 // errnorm_sens = 1 (ForwardDiff's dual-inclusive error norm): one launch = one ForwardDiff chunk of at most C*L partials.
 // (C, L) are sized for ForwardDiff.pickchunksize: case2 P = 25 -> 9 + 9 + 7, robertson 43 -> 11 x 3 + 10, case1 24 -> 12 + 12.
 constexpr int kSensBlock = 128;
-#define KSENS(NS, NR, HT, SC, C, L) \
-    { CRNN_SOLVER_ROSENBROCK23, NS, NR, HT, SC, C, L, (KernelFn)crnn::ros23_sens_kernel<NS, NR, (HT) != 0, (SC) != 0, C, L, kSensBlock> }
+#define KSENS(NS, NR, HT, SC, C, L, DROWS) \
+    { CRNN_SOLVER_ROSENBROCK23, NS, NR, HT, SC, C, L, \
+      (KernelFn)crnn::ros23_sens_kernel<NS, NR, (HT) != 0, (SC) != 0, C, L, kSensBlock, DROWS>, DROWS }
 #define KSENS5(NS, NR, HT, SC, C, L) \
     { CRNN_SOLVER_TSIT5, NS, NR, HT, SC, C, L, (KernelFn)crnn::tsit5_sens_kernel<NS, NR, (HT) != 0, (SC) != 0, C, L, kSensBlock> }
 const KernelEntry kSensKernels[] = {
-    KSENS(6, 3, 1, 0, 3, 3), KSENS(3, 6, 0, 1, 4, 3), KSENS(5, 4, 0, 0, 4, 3),
+    // DROWS = P + 1 where two blocks per CU still fit (case2: 25 parameters, robertson: 43): the chunks of a gradient in one launch
+    KSENS(6, 3, 1, 0, 3, 3, 26), KSENS(3, 6, 0, 1, 4, 3, 44), KSENS(5, 4, 0, 0, 4, 3, 13),
     KSENS5(5, 4, 0, 0, 4, 3), KSENS5(6, 3, 1, 0, 3, 3),      // case1's Tsit5 (case1.jl:28); the non-stiff branch of case2's AutoTsit5
 };
 
@@ -208,6 +211,8 @@ struct Ctx {
     double *d_p = nullptr, *d_opt = nullptr;
     double *d_p_eval = nullptr;     // scratch copy of a caller's p (crnn_loss_grad) -- never the training parameters
     bool theta_current = false;     // d_theta/d_dtheta already hold p2vec(d_p) (written by the fused optimiser kernel)
+    bool sens_one_launch = true;    // errnorm_sens gradients: the chunks of a gradient in one launch where the kernel stages all of d theta / d p
+                                    // (CRNN_SENS_ONE_LAUNCH=0 at context creation: one launch per chunk, for measurements)
     bool flags_zeroed = false;      // queue head / overflow counter already zeroed on the stream by the optimiser kernel
     crnn::OptCfg opt{};
     bool train_ready = false;
@@ -805,16 +810,19 @@ int32_t launch_solve(Ctx *c, const double *d_theta, const double *d_dtheta, int 
 
 // One ForwardDiff chunk with the dual-inclusive error norm: primal + P <= C*L tangent columns through every attempt
 // (ros23_sens_kernel.hpp), fixed-order reduction into c->d_red in the common layout.
+// n_chunks > 1 (ros23_sens_kernel with drows > P): d_dtheta holds all P directions, the launch runs the n_chunks chunks of
+// chunk_size partials each (the last one short), per-trajectory gradient rows come out compact [count][P]; the per-trajectory
+// losses and statistics are not written (launch_sens follows with the plain solve).
 int32_t launch_sens_chunk(Ctx *c, const KernelEntry *k, const double *d_theta, const double *d_dtheta, int P, int64_t first,
-                          int64_t count, int n_save_active, bool want_pred, int dual_partials) {
+                          int64_t count, int n_save_active, bool want_pred, int dual_partials, int n_chunks = 1, int chunk_size = 0) {
     const int blk = kSensBlock;
     const int C = k->C, L = k->L, gpw = 64 / L, waves = blk / 64;
-    const int ppad = L * C, npart_pad = ppad + crnn::kExtra, npart = P + crnn::kTail;
+    const int ppad = n_chunks > 1 ? P : L * C, npart_pad = ppad + crnn::kExtra, npart = P + crnn::kTail;
     int occ = 0;
     HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k->fn, blk, 0));
     if (occ < 1) occ = 1;
-    const int64_t gpb = (int64_t)waves * gpw;
-    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((count + gpb - 1) / gpb, (int64_t)c->num_cu * occ));
+    const int64_t nbatch = ((count + gpw - 1) / gpw) * std::max(1, n_chunks);
+    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((nbatch + waves - 1) / waves, (int64_t)c->num_cu * occ));
     const int rblk = (int)((count + 255) / 256);
     if (ensure(c, &c->d_partials, &c->partials_cap, (size_t)rblk * npart_pad)) return -1;
     if (ensure(c, &c->d_gtraj, &c->gtraj_cap, (size_t)count * ppad)) return -1;
@@ -831,6 +839,7 @@ int32_t launch_sens_chunk(Ctx *c, const KernelEntry *k, const double *d_theta, c
     // batches in the order of the last plain solve's step counts (the chunk's own counts differ little from them); the order
     // stays with the context for the plain solve that ends this gradient call (queue_by_steps)
     prm.perm = (c->queue_order == CRNN_QUEUE_AUTO && c->perm_ready && c->perm_first == first && c->perm_count == count) ? c->d_perm : nullptr;
+    prm.n_chunks = n_chunks; prm.chunk_size = chunk_size;
     if (upload_consts(c)) return -1;
     if (!c->flags_zeroed) HIP_TRY(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), c->stream));
     c->flags_zeroed = false;
@@ -929,11 +938,17 @@ int32_t launch_sens(Ctx *c, const double *d_theta, const double *d_dtheta, int P
         HIP_TRY(c, hipMalloc((void **)&c->d_red_asm, sizeof(double) * npart));
         c->red_asm_len = npart;
     }
-    for (int k0 = 0; k0 < P; k0 += chunk) {
-        const int Pc = std::min(chunk, P - k0);
-        // every Dual of a chunked ForwardDiff.gradient carries `chunk` partials, the last chunk's surplus ones are zero
-        if (chunk_launch(d_dtheta + (size_t)k0 * c->n_theta, Pc, false, chunk)) return -1;
-        HIP_TRY(c, hipMemcpyAsync(c->d_red_asm + k0, c->d_red, sizeof(double) * Pc, hipMemcpyDeviceToDevice, c->stream));
+    if (k && k->drows > P && c->sens_one_launch) {
+        // all chunks in one launch (ros23_sens_kernel, n_chunks > 1): the same independent adaptive solves, one tail
+        if (launch_sens_chunk(c, k, d_theta, d_dtheta, P, first, count, n_save_active, false, chunk, (P + chunk - 1) / chunk, chunk)) return -1;
+        HIP_TRY(c, hipMemcpyAsync(c->d_red_asm, c->d_red, sizeof(double) * P, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        for (int k0 = 0; k0 < P; k0 += chunk) {
+            const int Pc = std::min(chunk, P - k0);
+            // every Dual of a chunked ForwardDiff.gradient carries `chunk` partials, the last chunk's surplus ones are zero
+            if (chunk_launch(d_dtheta + (size_t)k0 * c->n_theta, Pc, false, chunk)) return -1;
+            HIP_TRY(c, hipMemcpyAsync(c->d_red_asm + k0, c->d_red, sizeof(double) * Pc, hipMemcpyDeviceToDevice, c->stream));
+        }
     }
     const int es = c->cfg.errnorm_sens;
     c->cfg.errnorm_sens = 0;      // the plain solve
@@ -1334,6 +1349,7 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
     if (c->n_params < 0) { delete c; return fail(nullptr, "crnn_ctx_create: unknown param_map"); }
     c->use_scale = false;
     for (int i = 0; i < cfg->ns; ++i) if (cfg->rate_scale[i] != 1.0) c->use_scale = true;
+    if (const char *e = getenv("CRNN_SENS_ONE_LAUNCH")) { if (*e) c->sens_one_launch = atoi(e) != 0; }   // measurement override
     // robertson-shaped problems always take the scaled kernel (one instantiation per shape)
     auto has_kernel = [&]() { return c->cfg.solver == CRNN_SOLVER_AUTOTSIT5 ? find_adjoint(c) != nullptr : find_primal(c) != nullptr; };
     if (!c->hychem && !has_kernel()) { c->use_scale = !c->use_scale; if (!has_kernel()) c->use_scale = !c->use_scale; }

@@ -97,7 +97,9 @@ struct SolveParams {
     int32_t P;             // tangent directions
     int32_t maxiters, clamp_pred, loss_kind, n_obs;
     int32_t norm_cols;     // dual-norm kernels: 0 = divide the squared norm by n; N > 0 = by n (1 + N), N partials per Dual
-    const int32_t *perm;   // ros23_sens1_kernel: position in the queue -> trajectory (relative to first); null = index order
+    const int32_t *perm;   // dual-norm kernels: position in the queue -> trajectory (relative to first); null = index order
+    int32_t n_chunks;      // ros23_sens_kernel: > 1 = all ForwardDiff chunks of the P directions in this launch, chunk_size partials each
+    int32_t chunk_size;
 };
 
 // ---------------------------------------------------------------------------

@@ -27,6 +27,23 @@
 #pragma once
 #include "ros23_kernel.hpp"
 
+// scheduling fences of the tangent column (CRNN_SCHED_FENCE), individually switchable for measurements
+#ifndef SENS_FENCE_1
+#define SENS_FENCE_1() CRNN_SCHED_FENCE()
+#endif
+#ifndef SENS_FENCE_2
+#define SENS_FENCE_2() CRNN_SCHED_FENCE()
+#endif
+#ifndef SENS_FENCE_3
+#define SENS_FENCE_3() CRNN_SCHED_FENCE()
+#endif
+#ifndef SENS_FENCE_4
+#define SENS_FENCE_4() CRNN_SCHED_FENCE()
+#endif
+#ifndef SENS_FENCE_5
+#define SENS_FENCE_5() CRNN_SCHED_FENCE()
+#endif
+
 namespace crnn {
 
 template <int NS, int NR>
@@ -58,11 +75,13 @@ struct RecS {
 // inclusive one -- d1 and d2 grow by the partials, d0 only shares the divisor ([UNVERIFIED-DEP] like the norm itself).
 // Every lane of the group calls this with the same primal point (x0, r0, f0) and its own C columns; the partial sums are
 // combined over the group's L lanes in lane order.  Stmp: the lane's LDS slot (C * NS doubles, stride 64) parks f0'.
+// The lane's columns qc < nvalid are the rows dcols + qc * pitch of d theta / d p, the others read the all-zero row zcol.
 template <int NS, int NR, bool HAS_T, bool USE_SCALE, int C, int L, int ORDER>
 __device__ __forceinline__ double sens_init_dt(const double *__restrict__ th, const KConst *kc, const double *dcols, const int pitch,
                                                double *Stmp, const double (&u)[NS], const double (&f0)[NS], const double (&x0)[NS],
                                                const double (&r0)[NR], const double (&bT)[NR], const double xT, const double Tconst,
-                                               const double dtmax, const int norm_cols, const int gbase) {
+                                               const double dtmax, const int norm_cols, const int gbase, const int nvalid = C,
+                                               const double *zcol = nullptr) {
     using L_ = Lay<NS, NR, HAS_T>;
     constexpr int N = L_::N;
     auto group_sum = [&](double v) -> double {
@@ -84,7 +103,7 @@ __device__ __forceinline__ double sens_init_dt(const double *__restrict__ th, co
     double d1p = 0.0;
 #pragma unroll 1
     for (int qc = 0; qc < C; ++qc) {
-        const double *dcol = dcols + qc * pitch;
+        const double *dcol = qc < nvalid ? dcols + qc * pitch : zcol;
         double f0p[NS];
 #pragma unroll
         for (int i = 0; i < NS; ++i) f0p[i] = 0.0;
@@ -121,7 +140,7 @@ __device__ __forceinline__ double sens_init_dt(const double *__restrict__ th, co
     for (int i = 0; i < NS; ++i) { const double e = (f1[i] - f0[i]) * sk[i]; d2 = fma(e, e, d2); }
 #pragma unroll 1
     for (int qc = 0; qc < C; ++qc) {
-        const double *dcol = dcols + qc * pitch;
+        const double *dcol = qc < nvalid ? dcols + qc * pitch : zcol;
         double gs1[NS], f1p[NS];
 #pragma unroll
         for (int c = 0; c < NS; ++c) { gs1[c] = g1[c] * (dt0 * Stmp[(qc * NS + c) * 64]); f1p[c] = 0.0; }
@@ -148,7 +167,13 @@ __device__ __forceinline__ double sens_init_dt(const double *__restrict__ th, co
     return fmax(kc->dtmin, fmin(fmin(100.0 * dt0, dt1), dtmax));
 }
 
-template <int NS, int NR, bool HAS_T, bool USE_SCALE, int C, int L, int BLOCK>
+// DROWS: rows of d theta / d p staged in LDS (the last one all zero).  L * C + 1: one chunk per launch.  P + 1 or more: ALL
+// chunks of a P-parameter gradient in ONE launch (SolveParams::n_chunks > 1) -- a batch is (chunk, GPW trajectories), batches
+// of the chunks alternate in the queue, a lane's columns are rows cid * chunk_size + chunk * C + qc while those lie inside the
+// chunk and inside P (the surplus partials of ForwardDiff's last chunk are zero: the zero row), gradient rows come out
+// compact [count][P].  The chunks are independent adaptive solves either way; one launch has one tail instead of one per
+// chunk, and no batch of a later chunk waits for the stragglers of an earlier one.
+template <int NS, int NR, bool HAS_T, bool USE_SCALE, int C, int L, int BLOCK, int DROWS = L * C + 1>
 __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm, const double *__restrict__ theta,
                                                            const double *__restrict__ dtheta) {
     using L_ = Lay<NS, NR, HAS_T>;
@@ -160,12 +185,12 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
     constexpr int WAVES = BLOCK / 64;
     constexpr int GPW = 64 / L;
     constexpr int PPAD = L * C;
-    static_assert(C > 0 && L >= 1 && L <= 64, "lane-group shape");
+    static_assert(C > 0 && L >= 1 && L <= 64 && DROWS > PPAD, "lane-group shape");
     using Solver = typename SolverSel<(NR < NS), NS, NR, HAS_T, USE_SCALE>::type;
 
     __shared__ double kc_lds[kNConst];
     __shared__ double ts_lds[kMaxSave];
-    __shared__ double dth_lds[PPAD * NTHP];
+    __shared__ double dth_lds[DROWS * NTHP];
     __shared__ double S_lds[2 * WAVES * C * NS * 64];   // two slots per lane: committed columns / columns of the attempt
     __shared__ double rec_lds[WAVES * NREC * GPW];
 
@@ -179,10 +204,14 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
 
     for (int idx = tid; idx < kNConst; idx += BLOCK) kc_lds[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
     for (int idx = tid; idx < prm.n_save; idx += BLOCK) ts_lds[idx] = prm.tsave[idx];
-    for (int idx = tid; idx < PPAD * NTHP; idx += BLOCK) {
+    for (int idx = tid; idx < DROWS * NTHP; idx += BLOCK) {
         const int k = idx / NTHP, m = idx - k * NTHP;
-        dth_lds[idx] = (k < prm.P && m < NTH) ? dtheta[(size_t)k * NTH + m] : 0.0;
+        dth_lds[idx] = (k < prm.P && k < DROWS - 1 && m < NTH) ? dtheta[(size_t)k * NTH + m] : 0.0;
     }
+    const double *const zcol = dth_lds + (DROWS - 1) * NTHP;
+    const int nch = prm.n_chunks > 1 ? prm.n_chunks : 1;     // chunks in this launch
+    const int cs_eff = nch > 1 ? prm.chunk_size : PPAD;      // partials of a (full) chunk
+    const int ncols = nch > 1 ? prm.P : PPAD;                // columns in a gradient row
     __syncthreads();
     const KConst *kc = reinterpret_cast<const KConst *>(kc_lds);
     const double *__restrict__ th = theta;
@@ -197,7 +226,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
     // trajectories through SolveParams::perm when the context has an order by step counts (its last plain solve): a batch
     // lasts as long as its longest trajectory, so it should be homogeneous, and the queue longest-first
     const unsigned nwaves = gridDim.x * WAVES;
-    const int64_t nbatch = (prm.count + GPW - 1) / GPW;
+    const int64_t nbatch = ((prm.count + GPW - 1) / GPW) * nch;
     int64_t bi = (int64_t)blockIdx.x * WAVES + wave;
 
     // sum of v over the L lanes of this lane's group, in lane order (identical on every lane of the group)
@@ -211,7 +240,11 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
     for (; bi < nbatch;) {
         unsigned nx = 0;
         if (lane == 0) nx = (unsigned)atomicAdd(prm.queue, 1ULL);
-        const int64_t pos = bi * GPW + grp;
+        const int cid = nch > 1 ? (int)(bi % nch) : 0;
+        const int64_t pos = (nch > 1 ? bi / nch : bi) * GPW + grp;
+        const int col0 = cid * cs_eff + chunk * C;        // this lane's first column; the valid ones are a prefix
+        const int nvalid = max(0, min(C, min(cs_eff - chunk * C, ncols - col0)));
+        const double *const dcols = dth_lds + (nvalid > 0 ? col0 : 0) * NTHP;
         if (lane_active && pos < prm.count) {
         CRNN_CHK(!prm.perm || ((int64_t)prm.perm[pos] >= 0 && (int64_t)prm.perm[pos] < prm.count), 0x5001);
         const int64_t traj = prm.perm ? (int64_t)prm.perm[pos] : pos;
@@ -231,9 +264,9 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
         rates<NS, NR, HAS_T>(th, x0, bT, r0);
         rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r0, kc->scale, f0);
         // Hairer initial step with the dual-inclusive norms (the Sn slot parks f0' meanwhile; it is zeroed below)
-        const double dt0_ = sens_init_dt<NS, NR, HAS_T, USE_SCALE, C, L, 2>(th, kc, dth_lds + (chunk * C) * NTHP, NTHP,
+        const double dt0_ = sens_init_dt<NS, NR, HAS_T, USE_SCALE, C, L, 2>(th, kc, dcols, NTHP,
                                                                               S_base + (size_t)C * NS * 64, u, f0, x0, r0, bT, xT,
-                                                                              Tconst, dtmax, prm.norm_cols, gbase);
+                                                                              Tconst, dtmax, prm.norm_cols, gbase, nvalid, zcol);
         double dt = dt0_;
         double t = t0, lqold = lqinit, loss_sum = 0.0;
         int iter = 0, jsave = 0, nacc = 0, nrej = 0, cur = 0, rc = -1;
@@ -269,6 +302,20 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
             if (t + dt * (1.0 + 1e-13) >= tend) { dt = tend - t; last = true; }
             if (!(dt > kc->dtmin) || t + dt == t) { rc = 2; break; }
 
+            // the observed rows of the next two save points, requested before the stage arithmetic (an attempt covers 1.5 save
+            // points on case2; read where they are used, every one of them was an exposed HBM / L2 round trip)
+            double dA[NS], dB[NS];
+            {
+                const int ja = jsave < nsave ? jsave : nsave - 1, jb = jsave + 1 < nsave ? jsave + 1 : nsave - 1;
+                const double *const ra = drows + (size_t)ja * prm.n_obs, *const rb = drows + (size_t)jb * prm.n_obs;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    const int dr = (int)kc->drow[i];
+                    CRNN_CHK((size_t)b * prm.row_stride + (size_t)jb * prm.n_obs + (dr >= 0 ? dr : 0) < (size_t)prm.B * prm.row_stride, 0x5002);
+                    dA[i] = ra[dr >= 0 ? dr : 0];
+                    dB[i] = rb[dr >= 0 ? dr : 0];
+                }
+            }
             // ============================================================ PRIMAL: one Rosenbrock23 attempt
             Solver W;
             const double gam = d_ * dt;
@@ -332,6 +379,14 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
                 const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
                 const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d_) * inv12d;
                 const double *row = drows + (size_t)jnew * prm.n_obs;
+                double ob[NS];
+                if (jnew - jsave < 2) {
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) ob[i] = (jnew == jsave) ? dA[i] : dB[i];
+                } else {   // a third save point inside one attempt
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) { const int dr = (int)kc->drow[i]; ob[i] = row[dr >= 0 ? dr : 0]; }
+                }
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
                     const double k2i = k1[i] + dk[i];
@@ -346,7 +401,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
                     const int dr = (int)kc->drow[i];
                     if (dr >= 0) {
                         const double iy = kc->inv_yscale[i];
-                        const double rr = (row[dr] - v) * iy;
+                        const double rr = (ob[i] - v) * iy;
                         double w;
                         if (prm.loss_kind == 0) { loss_new += fabs(rr); w = signbit(rr) ? 1.0 : -1.0; }
                         else { loss_new = fma(rr, rr, loss_new); w = -2.0 * rr; }
@@ -409,31 +464,66 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
             const double hdt = 0.5 * dt;
 #pragma unroll 1
             for (int qc = 0; qc < C; ++qc) {
-                const double *dcol = dth_lds + (chunk * C + qc) * NTHP;
+                const double *dcol = qc < nvalid ? dcols + qc * NTHP : zcol;
                 const double *Sq = Sc + qc * NS * 64;
                 double *Sqn = Sn + qc * NS * 64;
+                // The LDS operands of a loop step are requested one step ahead of their use (double-buffered by hand, the fences keep
+                // the requests above the arithmetic of the current step): the lane's wavefront has its SIMD to itself, so nothing
+                // else hides an LDS round trip -- left to the scheduler, ~100 of them per column were waited for one at a time
+                // (36 % of the wave cycles waiting).  The arithmetic and its order are unchanged.
+                struct P1 { double sc, g, x0, x1, x2, k1, dk, k3, dwi[NR]; };
+                struct P2 { double r0, r1, r2, gr, c1, cz, c3, dwo[NS]; };
+                auto load1 = [&](const int c, P1 &v) {
+                    v.sc = Sq[c * 64];
+                    v.g = rec[(R_::G0 + c) * GPW];
+                    v.x0 = rec[(R_::X0 + c) * GPW]; v.x1 = rec[(R_::X1 + c) * GPW]; v.x2 = rec[(R_::X2 + c) * GPW];
+                    v.k1 = rec[(R_::K1 + c) * GPW]; v.dk = rec[(R_::DK + c) * GPW]; v.k3 = rec[(R_::K3 + c) * GPW];
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) v.dwi[j] = dcol[L_::wi(c, j)];
+                };
+                auto load2 = [&](const int j, P2 &v) {
+                    v.r0 = rec[(R_::R0 + j) * GPW]; v.r1 = rec[(R_::R1 + j) * GPW]; v.r2 = rec[(R_::R2 + j) * GPW];
+                    v.gr = rec[(R_::GR0 + j) * GPW];
+                    v.c1 = rec[(R_::C1J + j) * GPW]; v.cz = rec[(R_::CZD + j) * GPW]; v.c3 = rec[(R_::CZ3 + j) * GPW];
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) v.dwo[i] = dcol[L_::wo(i, j)];
+                };
                 // ---- pass 1 (species-major)
                 double e0[NR], e1d[NR], e2d[NR], zp1[NR], zpd[NR], zp3[NR];
-                double gq[NS], grq[NR];
+                double gq[NS], grq[NR], sv[NS];
+                P1 p1a, p1b;
+                P2 p2a, p2b;
+                {
+                    double dwb[NR], dwT[NR];
 #pragma unroll
-                for (int j = 0; j < NR; ++j) {
-                    double e = dcol[L_::wb(j)];
-                    if (HAS_T) e = fma(dcol[L_::wi(NS, j)], xT, e);
-                    e0[j] = e; e1d[j] = e; e2d[j] = e; zp1[j] = 0.0; zpd[j] = 0.0; zp3[j] = 0.0;
+                    for (int j = 0; j < NR; ++j) { dwb[j] = dcol[L_::wb(j)]; dwT[j] = HAS_T ? dcol[L_::wi(NS, j)] : 0.0; }
+                    load1(0, p1a);
+                    SENS_FENCE_1();
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        double e = dwb[j];
+                        if (HAS_T) e = fma(dwT[j], xT, e);
+                        e0[j] = e; e1d[j] = e; e2d[j] = e; zp1[j] = 0.0; zpd[j] = 0.0; zp3[j] = 0.0;
+                    }
                 }
 #pragma unroll
                 for (int c = 0; c < NS; ++c) {
-                    const double sc_ = Sq[c * 64];
-                    const double g = rec[(R_::G0 + c) * GPW];
+                    P1 &cur1 = (c & 1) ? p1b : p1a;
+                    P1 &nxt1 = (c & 1) ? p1a : p1b;
+                    if (c + 1 < NS) load1(c + 1, nxt1); else load2(0, p2a);
+                    SENS_FENCE_1();
+                    const double sc_ = cur1.sc;
+                    const double g = cur1.g;
                     gq[c] = g;
-                    const double x0c = rec[(R_::X0 + c) * GPW], x1c = rec[(R_::X1 + c) * GPW], x2c = rec[(R_::X2 + c) * GPW];
-                    const double k1c = rec[(R_::K1 + c) * GPW], dkc = rec[(R_::DK + c) * GPW], k3c = rec[(R_::K3 + c) * GPW];
+                    sv[c] = sc_;
+                    const double x0c = cur1.x0, x1c = cur1.x1, x2c = cur1.x2;
+                    const double k1c = cur1.k1, dkc = cur1.dk, k3c = cur1.k3;
                     const double gsv = g * sc_;
                     const double hsv = -g * gsv;   // g' = -g^2 s inside the window (g = 1/u), 0 outside
                     na[c] = fma(sc_, sc_, na[c]);
 #pragma unroll
                     for (int j = 0; j < NR; ++j) {
-                        const double dwi = dcol[L_::wi(c, j)];
+                        const double dwi = cur1.dwi[j];
                         const double wi = th[L_::wi(c, j)];
                         e0[j] = fma(dwi, x0c, e0[j]);
                         e0[j] = fma(wi, gsv, e0[j]);
@@ -444,23 +534,34 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
                         zpd[j] = fma(m, dkc, zpd[j]);
                         zp3[j] = fma(m, k3c, zp3[j]);
                     }
+                    SENS_FENCE_1();
                 }
-                CRNN_SCHED_FENCE();
                 // ---- pass 2 (reaction-major)
                 double rhs1[NS], w2[NS], w3[NS], f0p[NS], f1d[NS], f2d[NS];
+                double g1v[NS], r1v[NR];      // requested during the last step of pass 2, used behind the first solve
 #pragma unroll
                 for (int i = 0; i < NS; ++i) { rhs1[i] = 0.0; w2[i] = 0.0; w3[i] = 0.0; f0p[i] = 0.0; f1d[i] = 0.0; f2d[i] = 0.0; }
 #pragma unroll
                 for (int j = 0; j < NR; ++j) {
-                    const double r0j = rec[(R_::R0 + j) * GPW], r1j = rec[(R_::R1 + j) * GPW], r2j = rec[(R_::R2 + j) * GPW];
-                    const double gr = rec[(R_::GR0 + j) * GPW];
+                    P2 &cur2 = (j & 1) ? p2b : p2a;
+                    P2 &nxt2 = (j & 1) ? p2a : p2b;
+                    if (j + 1 < NR) load2(j + 1, nxt2);
+                    else {
+#pragma unroll
+                        for (int c = 0; c < NS; ++c) g1v[c] = rec[(R_::G1 + c) * GPW];
+#pragma unroll
+                        for (int jj = 0; jj < NR; ++jj) r1v[jj] = rec[(R_::R1 + jj) * GPW];
+                    }
+                    SENS_FENCE_2();
+                    const double r0j = cur2.r0, r1j = cur2.r1, r2j = cur2.r2;
+                    const double gr = cur2.gr;
                     grq[j] = gr;
-                    const double c1 = rec[(R_::C1J + j) * GPW], cz = rec[(R_::CZD + j) * GPW], c3 = rec[(R_::CZ3 + j) * GPW];
+                    const double c1 = cur2.c1, cz = cur2.cz, c3 = cur2.c3;
                     const double y1 = gr * zp1[j], yd = gr * zpd[j], y3 = gr * zp3[j];
 #pragma unroll
                     for (int i = 0; i < NS; ++i) {
                         const double wo = th[L_::wo(i, j)];
-                        const double dwo = dcol[L_::wo(i, j)];
+                        const double dwo = cur2.dwo[i];
                         const double H = fma(wo, e0[j], dwo) * r0j;
                         rhs1[i] = fma(H, c1, rhs1[i]);
                         rhs1[i] = fma(wo, y1, rhs1[i]);
@@ -472,20 +573,26 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
                         f1d[i] = fma(dwo, r1j, f1d[i]);
                         f2d[i] = fma(dwo, r2j, f2d[i]);
                     }
+                    SENS_FENCE_2();
                 }
                 if (USE_SCALE) {
 #pragma unroll
                     for (int i = 0; i < NS; ++i) { const double sc = kc->scale[i]; rhs1[i] *= sc; w2[i] *= sc; w3[i] *= sc; f0p[i] *= sc; }
                 }
-                CRNN_SCHED_FENCE();
                 W.solve(th, gq, grq, kc->scale, rhs1);   // k1'
-                CRNN_SCHED_FENCE();
+                SENS_FENCE_3();
                 // f1' at u1 with s1 = s + dt/2 k1'
                 double f1p[NS];
+                double av[NS], b1v[NS], b2v[NS];   // the save-point seeds: requested here, used behind the second solve
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    av[i] = rec[(R_::AA + i) * GPW]; b1v[i] = rec[(R_::B1 + i) * GPW]; b2v[i] = rec[(R_::B2 + i) * GPW];
+                }
+                SENS_FENCE_3();
                 {
                     double gs1[NS];
 #pragma unroll
-                    for (int c = 0; c < NS; ++c) gs1[c] = rec[(R_::G1 + c) * GPW] * fma(hdt, rhs1[c], Sq[c * 64]);
+                    for (int c = 0; c < NS; ++c) gs1[c] = g1v[c] * fma(hdt, rhs1[c], sv[c]);
 #pragma unroll
                     for (int i = 0; i < NS; ++i) f1p[i] = f1d[i];
 #pragma unroll
@@ -493,7 +600,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
                         double e = e1d[j];
 #pragma unroll
                         for (int c = 0; c < NS; ++c) e = fma(th[L_::wi(c, j)], gs1[c], e);
-                        const double er = e * rec[(R_::R1 + j) * GPW];
+                        const double er = e * r1v[j];
 #pragma unroll
                         for (int i = 0; i < NS; ++i) f1p[i] = fma(th[L_::wo(i, j)], er, f1p[i]);
                     }
@@ -502,31 +609,38 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
                         for (int i = 0; i < NS; ++i) f1p[i] *= kc->scale[i];
                     }
                 }
-                CRNN_SCHED_FENCE();
+                SENS_FENCE_4();
                 double rhs2[NS];
+                double g2v[NS], r2v[NR];      // requested before the second solve, used behind it
+#pragma unroll
+                for (int c = 0; c < NS; ++c) g2v[c] = rec[(R_::G2 + c) * GPW];
+#pragma unroll
+                for (int j = 0; j < NR; ++j) r2v[j] = rec[(R_::R2 + j) * GPW];
+                SENS_FENCE_4();
 #pragma unroll
                 for (int i = 0; i < NS; ++i) rhs2[i] = f1p[i] - rhs1[i] + w2[i];
                 W.solve(th, gq, grq, kc->scale, rhs2);   // (k2 - k1)'
-                double k2p[NS], acc = 0.0;
+                double k2p[NS], snv[NS], acc = 0.0;
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
-                    const double si = Sq[i * 64];
+                    const double si = sv[i];
                     k2p[i] = rhs1[i] + rhs2[i];
-                    acc = fma(rec[(R_::AA + i) * GPW], si, acc);
-                    acc = fma(rec[(R_::B1 + i) * GPW], rhs1[i], acc);
-                    acc = fma(rec[(R_::B2 + i) * GPW], k2p[i], acc);
+                    acc = fma(av[i], si, acc);
+                    acc = fma(b1v[i], rhs1[i], acc);
+                    acc = fma(b2v[i], k2p[i], acc);
                     const double sn = fma(dt, k2p[i], si);
                     Sqn[i * 64] = sn;
+                    snv[i] = sn;
                     nb[i] = fma(sn, sn, nb[i]);
                 }
                 gnew[qc] = acc;
-                CRNN_SCHED_FENCE();
+                SENS_FENCE_5();
                 // f2' at u+ with s+ ; then W k3' = f2' - c32 (k2' - f1') - 2 (k1' - f0') + gam J' k3
                 double rhs3[NS];
                 {
                     double gs2[NS];
 #pragma unroll
-                    for (int c = 0; c < NS; ++c) gs2[c] = rec[(R_::G2 + c) * GPW] * Sqn[c * 64];
+                    for (int c = 0; c < NS; ++c) gs2[c] = g2v[c] * snv[c];
 #pragma unroll
                     for (int i = 0; i < NS; ++i) rhs3[i] = f2d[i];
 #pragma unroll
@@ -534,7 +648,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
                         double e = e2d[j];
 #pragma unroll
                         for (int c = 0; c < NS; ++c) e = fma(th[L_::wi(c, j)], gs2[c], e);
-                        const double er = e * rec[(R_::R2 + j) * GPW];
+                        const double er = e * r2v[j];
 #pragma unroll
                         for (int i = 0; i < NS; ++i) rhs3[i] = fma(th[L_::wo(i, j)], er, rhs3[i]);
                     }
@@ -594,16 +708,17 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
 
         const double denom = (double)prm.n_obs * (double)jsave;
         const double inv_den = jsave > 0 ? 1.0 / denom : 0.0;
-        if (chunk == 0) {
+        if (chunk == 0 && nch == 1) {   // a launch of all chunks: loss and statistics are those of the plain solve that follows
             prm.loss[b] = loss_sum * inv_den;
             prm.retcode[b] = rc;
             prm.n_saved[b] = jsave;
             prm.n_accept[b] = nacc;
             prm.n_reject[b] = nrej;
         }
-        double *grow = prm.gtraj + (size_t)traj * PPAD + chunk * C;
+        double *grow = prm.gtraj + (size_t)traj * ncols + col0;
 #pragma unroll
-        for (int q_ = 0; q_ < C; ++q_) grow[q_] = gtr[q_] * inv_den;
+        for (int q_ = 0; q_ < C; ++q_)
+            if (q_ < nvalid) grow[q_] = gtr[q_] * inv_den;
         }
         bi = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)nx) + nwaves;
     }

@@ -117,6 +117,31 @@ def test_loss_grad_and_training_step_assemble_the_chunks(orc, case2_setup):
     node.close(); node0.close()
 
 
+@pytest.mark.parametrize("case", ["case2", "rober"])
+def test_all_chunks_in_one_launch_equal_one_launch_per_chunk(monkeypatch, fx, case2_setup, rober_setup, case):
+    """crnn_loss_grad with errnorm_sens = 1 runs ForwardDiff's chunks (case2 9 + 9 + 7, robertson 11 + 11 + 11 + 10) as the batches
+    of ONE launch where the kernel stages all of d theta / d p; CRNN_SENS_ONE_LAUNCH=0 (read at context creation) keeps one launch
+    per chunk.  The chunks are the same independent adaptive solves either way: per-trajectory gradient rows are the same bits,
+    the batch sums differ only by the order of the fixed-order reduction (row pitch 25 / 43 against 9 / 12)."""
+    s, mk, _, _ = _setup(case, case2_setup, rober_setup, fx)
+    p = s["p_ckpt"]
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CRNN_SENS_ONE_LAUNCH", mode)
+        node = mk(errnorm_sens=1)
+        node.set_ensemble(s["u0"], s["data"], s["yscale"])
+        out[mode] = (node.loss_and_grad(p), dict(node.last_stats))
+        out[mode + "again"] = node.loss_and_grad(p)           # second call: the queue is ordered by the first call's plain solve
+        node.close()
+    (l1, g1), st1 = out["1"]
+    (l0, g0), st0 = out["0"]
+    assert l1 == l0 and st1["n_accept"] == st0["n_accept"] and st1["n_reject"] == st0["n_reject"]
+    assert np.max(np.abs(g1 - g0)) <= 1e-13 * np.max(np.abs(g0))
+    for mode in ("1", "0"):
+        la, ga = out[mode + "again"]
+        assert la == out[mode][0][0] and np.max(np.abs(ga - out[mode][0][1])) <= 1e-13 * np.max(np.abs(ga))
+
+
 def test_errnorm_sens_rejects_unsupported_combinations():
     from crnn_amd import CrnnError, NeuralODE, ODEProblem, PRESET_CASE2, SOLVER_AUTOTSIT5, cases
     with pytest.raises(CrnnError, match="errnorm_sens"):

@@ -19,6 +19,7 @@ ap.add_argument("--case", default="case2")
 ap.add_argument("--solver", default=None, choices=[None, "rosenbrock23", "tsit5", "autotsit5"])
 ap.add_argument("--errnorm-sens", type=int, default=0)
 ap.add_argument("--lanes", type=int, default=0, help="lanes per trajectory in the Rosenbrock23 adjoint kernel: 0 auto, 1, 2")
+ap.add_argument("--wall", action="store_true", help="also print the wall time per loss+gradient call (several launches per call: errnorm_sens)")
 args = ap.parse_args()
 
 from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE1, PRESET_CASE2, PRESET_ROBER, cases  # noqa: E402
@@ -72,11 +73,15 @@ else:
     p = np.array(fx["rober_ckpt"]["p"])
 if args.lanes:
     node.set_lanes_per_traj(args.lanes)
-ms = []
+import time  # noqa: E402
+ms, wall = [], []
 for _ in range(args.reps):
+    t0 = time.perf_counter()
     loss, grad = node.loss_and_grad(p)
+    wall.append((time.perf_counter() - t0) * 1e3)
     ms.append(node.last_stats["kernel_ms"])
 st = node.last_stats
 print(f"lib={os.path.basename(os.environ.get('CRNN_HIP_LIB', 'libcrnn_hip.so'))} case={args.case} solver={args.solver} grad={args.grad} lanes={args.lanes} B={B} "
       f"kernel_ms median {np.median(ms[2:]):.4f} min {min(ms[2:]):.4f}  steps/traj {st['n_accept'] / st['n_traj']:.2f} "
-      f"rej/traj {st['n_reject'] / st['n_traj']:.2f} loss {loss:.6e} |g| {np.linalg.norm(grad):.6e}")
+      f"rej/traj {st['n_reject'] / st['n_traj']:.2f} loss {loss:.6e} |g| {np.linalg.norm(grad):.6e}"
+      + (f"  wall_ms/call median {np.median(wall[2:]):.3f} min {min(wall[2:]):.3f} ({B / np.median(wall[2:]) / 1e3:.2f} M traj+grads/s)" if args.wall else ""))
