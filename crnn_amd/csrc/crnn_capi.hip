@@ -850,6 +850,18 @@ int32_t launch_sens_chunk(Ctx *c, const KernelEntry *k, const double *d_theta, c
     hipLaunchKernelGGL(k->fn, dim3(nblk), dim3(blk), 0, c->stream, prm, d_theta, d_dtheta);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+#ifdef CRNN_SENS_PROF
+    if (k->solver == CRNN_SOLVER_ROSENBROCK23) {
+        unsigned long long hp_[16];
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipMemcpyFromSymbol(hp_, HIP_SYMBOL(crnn::g_sens_prof), sizeof(hp_)));
+        double tot = 0;
+        for (int q = 0; q < 16; ++q) tot += (double)hp_[q];
+        fprintf(stderr, "[sens_prof] wave 0 ticks %.0f:", tot);
+        for (int q = 0; q < 12; ++q) fprintf(stderr, " %d:%.1f%%", q, 100.0 * (double)hp_[q] / (tot > 0 ? tot : 1));
+        fprintf(stderr, "\n");
+    }
+#endif
     hipLaunchKernelGGL(crnn::reduce_traj_kernel, dim3(rblk), dim3(256), 0, c->stream, c->d_gtraj, ppad, c->d_loss, c->d_ret,
                        c->d_nacc, c->d_nrej, first, count, 256, c->d_partials);
     HIP_TRY(c, hipGetLastError());

@@ -27,6 +27,16 @@
 #pragma once
 #include "ros23_kernel.hpp"
 
+// phase timing (tools/kvariants.sh build prof="-DCRNN_SENS_PROF=1"; the library then prints the shares of wave 0 of block 0 to
+// stderr after every chunk launch): s_memtime deltas per phase summed in scalar registers (32-bit: launches of a few ms), no
+// fences at the phase boundaries -- the shares are a guide, not the measurement
+#ifdef CRNN_SENS_PROF
+namespace crnn { __device__ unsigned long long g_sens_prof[16]; }
+#define SENS_T(k) do { const unsigned now_ = (unsigned)__builtin_readcyclecounter(); prof_acc[(k)] += now_ - prof_last; prof_last = now_; } while (0)
+#else
+#define SENS_T(k) do { } while (0)
+#endif
+
 // scheduling fences of the tangent column (CRNN_SCHED_FENCE), individually switchable for measurements
 #ifndef SENS_FENCE_1
 #define SENS_FENCE_1() CRNN_SCHED_FENCE()
@@ -193,6 +203,10 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
     __shared__ double dth_lds[DROWS * NTHP];
     __shared__ double S_lds[2 * WAVES * C * NS * 64];   // two slots per lane: committed columns / columns of the attempt
     __shared__ double rec_lds[WAVES * NREC * GPW];
+#ifdef CRNN_SENS_PROF
+    unsigned prof_acc[12] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // wave-uniform: scalar registers
+    unsigned prof_last = (unsigned)__builtin_readcyclecounter();
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = lane / L, chunk = lane - grp * L;
@@ -270,6 +284,10 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
         double dt = dt0_;
         double t = t0, lqold = lqinit, loss_sum = 0.0;
         int iter = 0, jsave = 0, nacc = 0, nrej = 0, cur = 0, rc = -1;
+        // sum_k s_ik^2 over the group's committed columns: the accepted attempt's sum_k s+_ik^2 (the same sums of the same numbers), kept
+        double nas[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) nas[i] = 0.0;
 #pragma unroll
         for (int q = 0; q < C; ++q) gtr[q] = 0.0;
 #pragma unroll
@@ -294,6 +312,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
             jsave = 1;
         }
 
+        SENS_T(0);
         while (rc < 0) {
             ++iter;
             bool last = false;
@@ -316,6 +335,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
                     dB[i] = rb[dr >= 0 ? dr : 0];
                 }
             }
+            double tsc = ts_lds[jsave < nsave ? jsave : nsave - 1];   // the next save time, requested ahead like the rows
             // ============================================================ PRIMAL: one Rosenbrock23 attempt
             Solver W;
             const double gam = d_ * dt;
@@ -364,60 +384,65 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
             }
             if (!finite) { rc = 3; break; }
 
-            // ---- PROVISIONAL save points of (t, tnew]: loss terms and seeds as if the attempt were accepted
+            SENS_T(1);
+            // ---- PROVISIONAL save points of (t, tnew]: loss terms and seeds as if the attempt were accepted.  Straight-line per
+            //      save point: an unobserved species is a zero weight, an unclamped prediction an infinite clamp, the loss kind a
+            //      select -- per-species branches (forty small blocks per save point) cost a quarter of the kernel's time; the
+            //      save time and the observed row of the NEXT save points are requested while this one is worked on.
             const double tnew = last ? tend : t + dt;
-            double A_[NS], B1[NS], B2[NS];
+            double A_[NS], B1[NS], B2[NS], iym[NS];
 #pragma unroll
-            for (int i = 0; i < NS; ++i) { A_[i] = 0.0; B1[i] = 0.0; B2[i] = 0.0; }
+            for (int i = 0; i < NS; ++i) {
+                A_[i] = 0.0; B1[i] = 0.0; B2[i] = 0.0;
+                iym[i] = kc->drow[i] >= 0.0 ? kc->inv_yscale[i] : 0.0;
+            }
+            const double ubc = prm.clamp_pred ? kc->ub : __builtin_inf();
+            const bool lk0 = prm.loss_kind == 0;
             double loss_new = loss_sum;
             int jnew = jsave;
             while (jnew < nsave) {
-                const double ts = ts_lds[jnew];
+                const double ts = tsc;
                 if (!(ts <= tnew)) break;
+                tsc = ts_lds[jnew + 1 < nsave ? jnew + 1 : nsave - 1];
+                double ob[NS];
+                {   // rotate the row queue: this point's row, the next one's, and a request for the one after
+                    const int jc = jnew + 2 < nsave ? jnew + 2 : nsave - 1;
+                    const double *const rc_ = drows + (size_t)jc * prm.n_obs;
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        const int dr = (int)kc->drow[i];
+                        ob[i] = dA[i]; dA[i] = dB[i]; dB[i] = rc_[dr >= 0 ? dr : 0];
+                    }
+                }
                 const bool at_end = (ts == tnew);
                 const double Th = at_end ? 1.0 : (ts - t) / dt;
                 const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
                 const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d_) * inv12d;
-                const double *row = drows + (size_t)jnew * prm.n_obs;
-                double ob[NS];
-                if (jnew - jsave < 2) {
-#pragma unroll
-                    for (int i = 0; i < NS; ++i) ob[i] = (jnew == jsave) ? dA[i] : dB[i];
-                } else {   // a third save point inside one attempt
-#pragma unroll
-                    for (int i = 0; i < NS; ++i) { const int dr = (int)kc->drow[i]; ob[i] = row[dr >= 0 ? dr : 0]; }
-                }
+                double vv[NS];
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
                     const double k2i = k1[i] + dk[i];
                     double v = at_end ? unew[i] : fma(dt, fma(c1, k1[i], c2 * k2i), u[i]);
-                    double mask = 1.0;
-                    if (prm.clamp_pred) {
-                        mask = (v > kc->ub || v < -kc->ub) ? 0.0 : 1.0;
-                        v = clampv(v, -kc->ub, kc->ub);
-                    }
-                    // a rejected attempt's values are overwritten by the accepted step that covers this save point
-                    if (prm.pred && chunk == 0) prm.pred[((size_t)jnew * N + i) * prm.B + b] = v;
-                    const int dr = (int)kc->drow[i];
-                    if (dr >= 0) {
-                        const double iy = kc->inv_yscale[i];
-                        const double rr = (ob[i] - v) * iy;
-                        double w;
-                        if (prm.loss_kind == 0) { loss_new += fabs(rr); w = signbit(rr) ? 1.0 : -1.0; }
-                        else { loss_new = fma(rr, rr, loss_new); w = -2.0 * rr; }
-                        w *= mask * iy;
-                        A_[i] += w;
-                        B1[i] = fma(w, dt * c1, B1[i]);
-                        B2[i] = fma(w, dt * c2, B2[i]);
-                    }
+                    const double mask = (v > ubc || v < -ubc) ? 0.0 : 1.0;
+                    v = clampv(v, -ubc, ubc);
+                    vv[i] = v;
+                    const double iy = iym[i];
+                    const double rr = (ob[i] - v) * iy;
+                    loss_new = lk0 ? loss_new + fabs(rr) : fma(rr, rr, loss_new);
+                    double w = lk0 ? (signbit(rr) ? 1.0 : -1.0) : -2.0 * rr;
+                    w *= mask * iy;
+                    A_[i] += w;
+                    B1[i] = fma(w, dt * c1, B1[i]);
+                    B2[i] = fma(w, dt * c2, B2[i]);
                 }
-                if (HAS_T && prm.pred && chunk == 0) {
-                    double v = Tconst;
-                    if (prm.clamp_pred) v = clampv(v, -kc->ub, kc->ub);
-                    prm.pred[((size_t)jnew * N + NS) * prm.B + b] = v;
+                if (prm.pred && chunk == 0) {   // a rejected attempt's values are overwritten by the accepted step that covers this save point
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) prm.pred[((size_t)jnew * N + i) * prm.B + b] = vv[i];
+                    if (HAS_T) prm.pred[((size_t)jnew * N + NS) * prm.B + b] = clampv(Tconst, -ubc, ubc);
                 }
                 ++jnew;
             }
+            SENS_T(2);
             // ---- publish the step record
             {
                 double c1j[NR], czd[NR], cz3[NR];
@@ -455,12 +480,13 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+            SENS_T(3);
             // ============================================================ TANGENTS of the attempt, C columns per lane
             double *const Sc = S_base + (size_t)cur * C * NS * 64;         // committed columns
             double *const Sn = S_base + (size_t)(cur ^ 1) * C * NS * 64;   // columns after this attempt
-            double ee[NS], na[NS], nb[NS], gnew[C];
+            double ee[NS], nb[NS], gnew[C];
 #pragma unroll
-            for (int i = 0; i < NS; ++i) { ee[i] = 0.0; na[i] = 0.0; nb[i] = 0.0; }
+            for (int i = 0; i < NS; ++i) { ee[i] = 0.0; nb[i] = 0.0; }
             const double hdt = 0.5 * dt;
 #pragma unroll 1
             for (int qc = 0; qc < C; ++qc) {
@@ -520,7 +546,6 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
                     const double k1c = cur1.k1, dkc = cur1.dk, k3c = cur1.k3;
                     const double gsv = g * sc_;
                     const double hsv = -g * gsv;   // g' = -g^2 s inside the window (g = 1/u), 0 outside
-                    na[c] = fma(sc_, sc_, na[c]);
 #pragma unroll
                     for (int j = 0; j < NR; ++j) {
                         const double dwi = cur1.dwi[j];
@@ -536,6 +561,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
                     }
                     SENS_FENCE_1();
                 }
+                SENS_T(4);
                 // ---- pass 2 (reaction-major)
                 double rhs1[NS], w2[NS], w3[NS], f0p[NS], f1d[NS], f2d[NS];
                 double g1v[NS], r1v[NR];      // requested during the last step of pass 2, used behind the first solve
@@ -579,8 +605,10 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
 #pragma unroll
                     for (int i = 0; i < NS; ++i) { const double sc = kc->scale[i]; rhs1[i] *= sc; w2[i] *= sc; w3[i] *= sc; f0p[i] *= sc; }
                 }
+                SENS_T(5);
                 W.solve(th, gq, grq, kc->scale, rhs1);   // k1'
                 SENS_FENCE_3();
+                SENS_T(6);
                 // f1' at u1 with s1 = s + dt/2 k1'
                 double f1p[NS];
                 double av[NS], b1v[NS], b2v[NS];   // the save-point seeds: requested here, used behind the second solve
@@ -610,6 +638,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
                     }
                 }
                 SENS_FENCE_4();
+                SENS_T(7);
                 double rhs2[NS];
                 double g2v[NS], r2v[NR];      // requested before the second solve, used behind it
 #pragma unroll
@@ -635,6 +664,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
                 }
                 gnew[qc] = acc;
                 SENS_FENCE_5();
+                SENS_T(8);
                 // f2' at u+ with s+ ; then W k3' = f2' - c32 (k2' - f1') - 2 (k1' - f0') + gam J' k3
                 double rhs3[NS];
                 {
@@ -658,6 +688,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
                     const double f2p = USE_SCALE ? rhs3[i] * kc->scale[i] : rhs3[i];
                     rhs3[i] = f2p - c32 * (k2p[i] - f1p[i]) - 2.0 * (rhs1[i] - f0p[i]) + w3[i];
                 }
+                SENS_T(9);
                 W.solve(th, gq, grq, kc->scale, rhs3);   // k3'
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
@@ -665,12 +696,14 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
                     ee[i] = fma(de, de, ee[i]);
                 }
             }
+            SENS_T(10);
             // ---- the group's dual-inclusive error norm and the decision (identical on the L lanes of the group)
             double es = 0.0;
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
-                const double nai = fma(u[i], u[i], group_sum(na[i]));
-                const double nbi = fma(unew[i], unew[i], group_sum(nb[i]));
+                nb[i] = group_sum(nb[i]);
+                const double nai = fma(u[i], u[i], nas[i]);
+                const double nbi = fma(unew[i], unew[i], nb[i]);
                 const double eei = fma(ev[i], ev[i], group_sum(ee[i]));
                 const double sc = fma(kc->rtol[i], sqrt(fmax(nai, nbi)), kc->atol[i]);
                 es += eei / (sc * sc);
@@ -681,28 +714,42 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
             const bool ee_zero = (es == 0.0);
             const double lEE = 0.5 * flog(ee_zero ? 1.0 : es);
             const double lq11 = kc->beta1 * lEE;
-            double q = ee_zero ? 1.0 / kc->qmax
-                               : fmax(1.0 / kc->qmax, fmin(1.0 / kc->qmin, exp(lq11 - kc->beta2 * lqold) / kc->gamma));
-            if (es <= 1.0) {   // commit
+            // one exponential and one division for both outcomes (with 21 trajectories in a wavefront some lane rejects in most
+            // iterations, so both branches used to run): accepted: q = clamp(exp(lq11 - beta2 lqold) / gamma), rejected: exp(lq11) / gamma
+            const bool accept = es <= 1.0;
+            // x, g, r of the point the trajectory stands on after this attempt come back from the step record (u+ if accepted, u_n
+            // if not: the three areas lie 2 (2 NS + NR) fields apart) -- held in registers across the tangent columns they were
+            // thirty doubles of a register file that is full; requested here, used by the next attempt
+            {
+                const int po = accept ? (R_::X2 - R_::X0) : 0;
+                static_assert(R_::X2 - R_::X0 == R_::G2 - R_::G0 && R_::X2 - R_::X0 == R_::R2 - R_::R0, "record layout");
+#pragma unroll
+                for (int i = 0; i < NS; ++i) { x0[i] = rec[(R_::X0 + po + i) * GPW]; g0[i] = rec[(R_::G0 + po + i) * GPW]; }
+#pragma unroll
+                for (int j = 0; j < NR; ++j) r0[j] = rec[(R_::R0 + po + j) * GPW];
+            }
+            const double qe = exp(accept ? lq11 - kc->beta2 * lqold : lq11) / kc->gamma;
+            double q = ee_zero ? 1.0 / kc->qmax : fmax(1.0 / kc->qmax, fmin(1.0 / kc->qmin, qe));
+            if (q >= kc->qsteady_min && q <= kc->qsteady_max) q = 1.0;
+            const double dtq = dt / (accept ? q : fmin(1.0 / kc->qmin, qe));
+            if (accept) {   // commit
                 ++nacc;
 #pragma unroll
-                for (int i = 0; i < NS; ++i) { u[i] = unew[i]; f0[i] = f2[i]; g0[i] = g2[i]; x0[i] = x2[i]; }
-#pragma unroll
-                for (int j = 0; j < NR; ++j) r0[j] = r2[j];
+                for (int i = 0; i < NS; ++i) { u[i] = unew[i]; f0[i] = f2[i]; nas[i] = nb[i]; }
 #pragma unroll
                 for (int qc = 0; qc < C; ++qc) gtr[qc] += gnew[qc];
                 cur ^= 1;
                 loss_sum = loss_new;
                 jsave = jnew;
                 t = tnew;
-                if (q >= kc->qsteady_min && q <= kc->qsteady_max) q = 1.0;
                 lqold = ee_zero ? lqinit : fmax(lEE, lqinit);
-                dt = fmin(dt / q, dtmax);
+                dt = fmin(dtq, dtmax);
                 if (jsave >= nsave) rc = 0;
             } else {
                 ++nrej;
-                dt = dt / fmin(1.0 / kc->qmin, exp(lq11) / kc->gamma);
+                dt = dtq;
             }
+            SENS_T(11);
             __builtin_amdgcn_wave_barrier();   // the record is rewritten by the next attempt
         }
 
@@ -722,6 +769,10 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
         }
         bi = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)nx) + nwaves;
     }
+#ifdef CRNN_SENS_PROF
+    if (blockIdx.x == 0 && tid == 0)
+        for (int k = 0; k < 12; ++k) g_sens_prof[k] = prof_acc[k];
+#endif
 }
 
 }  // namespace crnn
