@@ -85,12 +85,13 @@ constexpr int kSensBlock = 128;
 #define KSENS(NS, NR, HT, SC, C, L, DROWS) \
     { CRNN_SOLVER_ROSENBROCK23, NS, NR, HT, SC, C, L, \
       (KernelFn)crnn::ros23_sens_kernel<NS, NR, (HT) != 0, (SC) != 0, C, L, kSensBlock, DROWS>, DROWS }
-#define KSENS5(NS, NR, HT, SC, C, L) \
-    { CRNN_SOLVER_TSIT5, NS, NR, HT, SC, C, L, (KernelFn)crnn::tsit5_sens_kernel<NS, NR, (HT) != 0, (SC) != 0, C, L, kSensBlock> }
+#define KSENS5(NS, NR, HT, SC, C, L, DROWS) \
+    { CRNN_SOLVER_TSIT5, NS, NR, HT, SC, C, L, \
+      (KernelFn)crnn::tsit5_sens_kernel<NS, NR, (HT) != 0, (SC) != 0, C, L, kSensBlock, DROWS>, DROWS }
 const KernelEntry kSensKernels[] = {
     // DROWS = P + 1 where two blocks per CU still fit (case2: 25 parameters, robertson: 43): the chunks of a gradient in one launch
     KSENS(6, 3, 1, 0, 3, 3, 26), KSENS(3, 6, 0, 1, 4, 3, 44), KSENS(5, 4, 0, 0, 4, 3, 13),
-    KSENS5(5, 4, 0, 0, 4, 3), KSENS5(6, 3, 1, 0, 3, 3),      // case1's Tsit5 (case1.jl:28); the non-stiff branch of case2's AutoTsit5
+    KSENS5(5, 4, 0, 0, 4, 3, 13), KSENS5(6, 3, 1, 0, 3, 3, 26),      // case1's Tsit5 (case1.jl:28); the non-stiff branch of case2's AutoTsit5
 };
 
 using AdjKernelFn = void (*)(const crnn::SolveParams, const double *, const crnn::AdjParams);

@@ -28,7 +28,8 @@ struct RecTS {
     static constexpr int NREC = BB + 7 * NS;
 };
 
-template <int NS, int NR, bool HAS_T, bool USE_SCALE, int C, int L, int BLOCK>
+// DROWS, batches, queue order: as ros23_sens_kernel (DROWS > P: all chunks of a gradient in one launch, SolveParams::n_chunks > 1)
+template <int NS, int NR, bool HAS_T, bool USE_SCALE, int C, int L, int BLOCK, int DROWS = L * C + 1>
 __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm, const double *__restrict__ theta,
                                                            const double *__restrict__ dtheta) {
     using L_ = Lay<NS, NR, HAS_T>;
@@ -40,11 +41,11 @@ __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm
     constexpr int WAVES = BLOCK / 64;
     constexpr int GPW = 64 / L;
     constexpr int PPAD = L * C;
-    static_assert(C > 0 && L >= 1 && L <= 64, "lane-group shape");
+    static_assert(C > 0 && L >= 1 && L <= 64 && DROWS > PPAD, "lane-group shape");
 
     __shared__ double kc_lds[kNConst];
     __shared__ double ts_lds[kMaxSave];
-    __shared__ double dth_lds[PPAD * NTHP];
+    __shared__ double dth_lds[DROWS * NTHP];
     __shared__ double S_lds[2 * WAVES * C * NS * 64];   // two slots per lane: committed columns / columns of the attempt
     __shared__ double rec_lds[WAVES * NREC * GPW];
 
@@ -58,10 +59,14 @@ __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm
 
     for (int idx = tid; idx < kNConst; idx += BLOCK) kc_lds[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
     for (int idx = tid; idx < prm.n_save; idx += BLOCK) ts_lds[idx] = prm.tsave[idx];
-    for (int idx = tid; idx < PPAD * NTHP; idx += BLOCK) {
+    for (int idx = tid; idx < DROWS * NTHP; idx += BLOCK) {
         const int k = idx / NTHP, m = idx - k * NTHP;
-        dth_lds[idx] = (k < prm.P && m < NTH) ? dtheta[(size_t)k * NTH + m] : 0.0;
+        dth_lds[idx] = (k < prm.P && k < DROWS - 1 && m < NTH) ? dtheta[(size_t)k * NTH + m] : 0.0;
     }
+    const double *const zcol = dth_lds + (DROWS - 1) * NTHP;
+    const int nch = prm.n_chunks > 1 ? prm.n_chunks : 1;     // chunks in this launch
+    const int cs_eff = nch > 1 ? prm.chunk_size : PPAD;      // partials of a (full) chunk
+    const int ncols = nch > 1 ? prm.P : PPAD;                // columns in a gradient row
     __syncthreads();
     const KConst *kc = reinterpret_cast<const KConst *>(kc_lds);
     const double *__restrict__ th = theta;
@@ -70,8 +75,9 @@ __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm
     const double tend = ts_lds[nsave - 1], ts0 = ts_lds[0], t0 = kc->t0;
     const double dtmax = tend - t0;
     const double lqinit = flog(kc->qoldinit);
-    const int64_t ngroups = (int64_t)gridDim.x * WAVES * GPW;
-    int64_t traj = lane_active ? ((int64_t)blockIdx.x * WAVES + wave) * GPW + grp : prm.count;
+    const unsigned nwaves = gridDim.x * WAVES;
+    const int64_t nbatch = ((prm.count + GPW - 1) / GPW) * nch;
+    int64_t bi = (int64_t)blockIdx.x * WAVES + wave;
 
     auto group_sum = [&](double v) -> double {
         double a = 0.0;
@@ -80,7 +86,17 @@ __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm
         return a;
     };
 
-    for (; traj < prm.count; traj += ngroups) {
+    for (; bi < nbatch;) {
+        unsigned nx = 0;
+        if (lane == 0) nx = (unsigned)atomicAdd(prm.queue, 1ULL);
+        const int cid = nch > 1 ? (int)(bi % nch) : 0;
+        const int64_t pos = (nch > 1 ? bi / nch : bi) * GPW + grp;
+        const int col0 = cid * cs_eff + chunk * C;        // this lane's first column; the valid ones are a prefix
+        const int nvalid = max(0, min(C, min(cs_eff - chunk * C, ncols - col0)));
+        const double *const dcols = dth_lds + (nvalid > 0 ? col0 : 0) * NTHP;
+        if (lane_active && pos < prm.count) {
+        CRNN_CHK(!prm.perm || ((int64_t)prm.perm[pos] >= 0 && (int64_t)prm.perm[pos] < prm.count), 0x5201);
+        const int64_t traj = prm.perm ? (int64_t)prm.perm[pos] : pos;
         const int64_t b = prm.first + traj;
         const double *const drows = prm.data + (size_t)b * prm.row_stride;
         double u[NS], k1[NS], x1[NS], g1[NS], r1[NR], bT[NR], gtr[C];
@@ -97,9 +113,9 @@ __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm
         rates<NS, NR, HAS_T>(th, x1, bT, r1);
         rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r1, kc->scale, k1);
         // Hairer initial step (order 5) with the dual-inclusive norms: ros23_sens_kernel.hpp sens_init_dt
-        double dt = sens_init_dt<NS, NR, HAS_T, USE_SCALE, C, L, 5>(th, kc, dth_lds + (chunk * C) * NTHP, NTHP,
+        double dt = sens_init_dt<NS, NR, HAS_T, USE_SCALE, C, L, 5>(th, kc, dcols, NTHP,
                                                                       S_base + (size_t)C * NS * 64, u, k1, x1, r1, bT, xT, Tconst,
-                                                                      dtmax, prm.norm_cols, gbase);
+                                                                      dtmax, prm.norm_cols, gbase, nvalid, zcol);
         double t = t0, lqold = lqinit, loss_sum = 0.0;
         int iter = 0, jsave = 0, nacc = 0, nrej = 0, cur = 0, rc = -1;
 #pragma unroll
@@ -252,7 +268,7 @@ __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm
             for (int i = 0; i < NS; ++i) { ee[i] = 0.0; na[i] = 0.0; nb[i] = 0.0; }
 #pragma unroll 1
             for (int qc = 0; qc < C; ++qc) {
-                const double *dcol = dth_lds + (chunk * C + qc) * NTHP;
+                const double *dcol = qc < nvalid ? dcols + qc * NTHP : zcol;
                 const double *Sq = Sc + qc * NS * 64;
                 double *Sqn = Sn + qc * NS * 64;
                 double dth_r[NTH];
@@ -360,16 +376,19 @@ __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm
 
         const double denom = (double)prm.n_obs * (double)jsave;
         const double inv_den = jsave > 0 ? 1.0 / denom : 0.0;
-        if (chunk == 0) {
+        if (chunk == 0 && nch == 1) {   // a launch of all chunks: loss and statistics are those of the plain solve that follows
             prm.loss[b] = loss_sum * inv_den;
             prm.retcode[b] = rc;
             prm.n_saved[b] = jsave;
             prm.n_accept[b] = nacc;
             prm.n_reject[b] = nrej;
         }
-        double *grow = prm.gtraj + (size_t)traj * PPAD + chunk * C;
+        double *grow = prm.gtraj + (size_t)traj * ncols + col0;
 #pragma unroll
-        for (int q_ = 0; q_ < C; ++q_) grow[q_] = gtr[q_] * inv_den;
+        for (int q_ = 0; q_ < C; ++q_)
+            if (q_ < nvalid) grow[q_] = gtr[q_] * inv_den;
+        }
+        bi = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)nx) + nwaves;
     }
 }
 

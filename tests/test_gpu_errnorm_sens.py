@@ -117,7 +117,7 @@ def test_loss_grad_and_training_step_assemble_the_chunks(orc, case2_setup):
     node.close(); node0.close()
 
 
-@pytest.mark.parametrize("case", ["case2", "rober"])
+@pytest.mark.parametrize("case", ["case2", "rober", "case2-tsit5"])
 def test_all_chunks_in_one_launch_equal_one_launch_per_chunk(monkeypatch, fx, case2_setup, rober_setup, case):
     """crnn_loss_grad with errnorm_sens = 1 runs ForwardDiff's chunks (case2 9 + 9 + 7, robertson 11 + 11 + 11 + 10) as the batches
     of ONE launch where the kernel stages all of d theta / d p; CRNN_SENS_ONE_LAUNCH=0 (read at context creation) keeps one launch
