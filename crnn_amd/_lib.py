@@ -22,6 +22,7 @@ PRESET_CASE1, PRESET_CASE2, PRESET_ROBER, PRESET_HYCHEM = 1, 2, 3, 4
 SOLVER_ROSENBROCK23, SOLVER_TSIT5, SOLVER_AUTOTSIT5 = 0, 1, 2
 GRAD_AUTO, GRAD_FORWARD, GRAD_ADJOINT = 0, 1, 2
 QUEUE_AUTO, QUEUE_INDEX = 0, 1
+JAC_ANALYTIC, JAC_FINITE_DIFF = 0, 1
 CATH_SOLVER_ROSENBROCK23, CATH_SOLVER_AUTOTSIT5_TRBDF2, CATH_SOLVER_AUTOTSIT5_ROS23 = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -111,6 +112,7 @@ SYMBOLS = {
     "crnn_ctx_set_queue_order": (C.c_int32, [_CTX, C.c_int32]),
     "crnn_ctx_set_lanes_per_traj": (C.c_int32, [_CTX, C.c_int32]),
     "crnn_last_lanes_per_traj": (C.c_int32, [_CTX]),
+    "crnn_ctx_set_jacobian": (C.c_int32, [_CTX, C.c_int32]),
     "crnn_last_step_counts": (C.c_int32, [_CTX, C.c_int64, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "crnn_kernel_times": (C.c_int32, [_CTX, _DP, C.c_int32]),
     "crnn_synchronize": (C.c_int32, [_CTX]),

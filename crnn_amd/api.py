@@ -318,6 +318,8 @@ class NeuralODE:
         B = u0b.shape[0]
         if self._adhoc is None:
             self._adhoc = _Ctx(self.cfg)
+            if getattr(self, "_jac_mode", 0):
+                check(lib.crnn_ctx_set_jacobian(self._adhoc.h, self._jac_mode), self._adhoc.h)
         zeros = np.zeros((B, self.ns, self.D), order="F")
         check(lib.crnn_ctx_set_data(self._adhoc.h, dptr(u0b), dptr(zeros), dptr(self.tsteps), None, None, self.ns, B),
               self._adhoc.h)
@@ -435,6 +437,15 @@ class NeuralODE:
         """0 (AUTO, default) / 1 / 2 lanes per trajectory in the Rosenbrock23 adjoint kernel -- include/crnn_hip.h:
         crnn_ctx_set_lanes_per_traj.  2 = an adjacent lane pair per trajectory (shards smaller than the chip)."""
         check(lib.crnn_ctx_set_lanes_per_traj(self._ctx.h, int(lanes)), self._ctx.h)
+
+    def set_jacobian(self, mode):
+        """JAC_ANALYTIC (default) / JAC_FINITE_DIFF: the Jacobian behind W in the Rosenbrock23 primal launches (predict, loss) --
+        `Rosenbrock23(autodiff=true)` (robertson/rober_crnn.jl:33) / `Rosenbrock23(autodiff=false)` (case2/case2.jl:26):
+        include/crnn_hip.h: crnn_ctx_set_jacobian."""
+        check(lib.crnn_ctx_set_jacobian(self._ctx.h, int(mode)), self._ctx.h)
+        self._jac_mode = int(mode)
+        if self._adhoc is not None:     # predict_theta / predict_neuralode integrate on their own context
+            check(lib.crnn_ctx_set_jacobian(self._adhoc.h, int(mode)), self._adhoc.h)
 
     def last_lanes_per_traj(self):
         """Lanes per trajectory of the most recent adjoint gradient launch (1 or 2; 0: none yet)."""

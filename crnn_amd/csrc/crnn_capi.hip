@@ -100,10 +100,12 @@ struct AdjEntry {
     AdjKernelFn fn;
     int max_gen = 1;   // two-lane entries: AUTO uses the kernel while count <= max_gen * (resident lane pairs)
     AdjKernelFn fn_primal = nullptr;   // the forward sweep alone (ros23_adj_kernel<..., PRIMAL = true>): crnn_solve with no directions
+    AdjKernelFn fn_primal_fd = nullptr;   // the same with W from forward differences (Rosenbrock23(autodiff = false): crnn_ctx_set_jacobian)
 };
 #define KADJ(NS, NR, HT, SC) \
     { CRNN_SOLVER_ROSENBROCK23, NS, NR, HT, SC, (AdjKernelFn)crnn::ros23_adj_kernel<NS, NR, (HT) != 0, (SC) != 0, kBlock>, 1, \
-      (AdjKernelFn)crnn::ros23_adj_kernel<NS, NR, (HT) != 0, (SC) != 0, kBlock, true> }
+      (AdjKernelFn)crnn::ros23_adj_kernel<NS, NR, (HT) != 0, (SC) != 0, kBlock, true>, \
+      (AdjKernelFn)crnn::ros23_adj_kernel<NS, NR, (HT) != 0, (SC) != 0, kBlock, true, true> }
 #define KAUTO(SOLVER, NS, NR, HT, SC, COMPOSITE) \
     { SOLVER, NS, NR, HT, SC, (AdjKernelFn)crnn::auto_adj_kernel<NS, NR, (HT) != 0, (SC) != 0, kBlock, COMPOSITE>, 1, \
       (AdjKernelFn)crnn::auto_adj_kernel<NS, NR, (HT) != 0, (SC) != 0, kBlock, COMPOSITE, true> }
@@ -191,6 +193,7 @@ struct Ctx {
     int adj_occ = 0;                // cached occupancy of the adjoint kernel
     int adj2_occ = 0;               // ... of the two-lanes-per-trajectory variant
     int lanes_per_traj = 0;         // crnn_ctx_set_lanes_per_traj: 0 = AUTO, 1, 2
+    int jac_mode = CRNN_JAC_ANALYTIC;   // crnn_ctx_set_jacobian: W of the Rosenbrock23 primal launches
     int hysens_occ = 0;
     int64_t hy_tape_retries = 0;    // HyChem launches repeated with fewer resident trajectories after a tape overflow
     int last_lanes = 0;             // lanes per trajectory of the most recent adjoint launch (0: another kernel family ran)
@@ -602,7 +605,8 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
     c->ev1 = c->ring1[c->n_launch % Ctx::kRing];
     ++c->n_launch;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    hipLaunchKernelGGL(primal ? k->fn_primal : k->fn, dim3(nblk), dim3(kBlock), 0, c->stream, prm, d_theta, adj);
+    const AdjKernelFn fn = !primal ? k->fn : (c->jac_mode == CRNN_JAC_FINITE_DIFF && k->fn_primal_fd) ? k->fn_primal_fd : k->fn_primal;
+    hipLaunchKernelGGL(fn, dim3(nblk), dim3(kBlock), 0, c->stream, prm, d_theta, adj);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     // the next launch over this range will want the queue ordered by this launch's step counts (queue_by_steps): sort
@@ -1883,6 +1887,19 @@ int32_t crnn_ctx_set_lanes_per_traj(crnn_ctx *ctx, int32_t lanes) {
     if (lanes == 2 && !c->hychem && (c->cfg.solver != CRNN_SOLVER_ROSENBROCK23 || !find_adjoint2(c)))
         return fail(c, "crnn_ctx_set_lanes_per_traj: no two-lane kernel for this problem (Rosenbrock23, nr < ns, no rate scaling)");
     c->lanes_per_traj = lanes;
+    return 0;
+}
+
+int32_t crnn_ctx_set_jacobian(crnn_ctx *ctx, int32_t mode) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctx);
+    if (!c) return fail(c, "crnn_ctx_set_jacobian: null");
+    if (mode != CRNN_JAC_ANALYTIC && mode != CRNN_JAC_FINITE_DIFF) return fail(c, "crnn_ctx_set_jacobian: mode must be CRNN_JAC_ANALYTIC or CRNN_JAC_FINITE_DIFF");
+    if (mode == CRNN_JAC_FINITE_DIFF) {
+        const AdjEntry *ka = (c->hychem || c->cfg.solver != CRNN_SOLVER_ROSENBROCK23) ? nullptr : find_adjoint(c);
+        if (!ka || !ka->fn_primal_fd)
+            return fail(c, "crnn_ctx_set_jacobian: the finite-difference W exists for the Rosenbrock23 primal launches of the CRNN right-hand side (case1, case2, robertson shapes)");
+    }
+    c->jac_mode = mode;
     return 0;
 }
 

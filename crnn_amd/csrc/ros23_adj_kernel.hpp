@@ -172,7 +172,9 @@ __device__ __forceinline__ void solve_T(const Woodbury<NS, NR, HAS_T, USE_SCALE>
 // same wave-synchronous batches and longest-first queue as the gradient launch, where ros23_kernel's one-lane-group-per-trajectory
 // scheme (built for tangent columns) lets the 64 lanes of a wavefront drift apart -- 0.55 ms per 65 536 against 0.50 for the
 // whole gradient.
-template <int NS, int NR, bool HAS_T, bool USE_SCALE, int BLOCK, bool PRIMAL = false>
+// JFD = true (PRIMAL only): Rosenbrock23(autodiff = false) -- W from forward differences of the right-hand side
+// (DenseLU::factor_fd, ros23_kernel.hpp; crnn_ctx_set_jacobian): NS more right-hand sides per attempt, a dense NS x NS factorisation.
+template <int NS, int NR, bool HAS_T, bool USE_SCALE, int BLOCK, bool PRIMAL = false, bool JFD = false>
 __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm, const double *__restrict__ theta,
                                                           const AdjParams adj) {
     using L_ = Lay<NS, NR, HAS_T>;
@@ -180,7 +182,8 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
     constexpr int NTH = L_::NTH;
     constexpr int RECW = CRNN_ADJ_TAPE_K ? 3 * NS + 2 : NS + 2;
     static_assert(NTH + kExtra <= 64, "the per-batch sums use one lane per column");
-    using Solver = typename SolverSel<(NR < NS), NS, NR, HAS_T, USE_SCALE>::type;
+    static_assert(!JFD || PRIMAL, "the finite-difference W exists for primal launches");
+    using Solver = typename SolverSel<(NR < NS) && !JFD, NS, NR, HAS_T, USE_SCALE>::type;
 
     __shared__ double kc_lds[kNConst];
     __shared__ double ts_lds[kMaxSave];
@@ -340,7 +343,15 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
 #pragma unroll
                     for (int j = 0; j < NR; ++j) gr0[j] = gam * r0[j];
                     double k1[NS], dk[NS], unew[NS], f1[NS], f2[NS], g2[NS], r2[NR];
-                    const bool okf = W.factor(th, g0, r0, gam, kc->scale);
+                    bool okf;
+                    if constexpr (JFD) {
+                        okf = W.factor_fd(u, f0, gam, [&](const double (&up)[NS], double (&fp)[NS]) {
+                            double xp[NS], gp[NS], rp[NR];
+                            features<NS>(up, kc->lb, kc->ub, xp, gp);
+                            rates<NS, NR, HAS_T>(th, xp, bT, rp);
+                            rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, rp, kc->scale, fp);
+                        });
+                    } else okf = W.factor(th, g0, r0, gam, kc->scale);
 #pragma unroll
                     for (int i = 0; i < NS; ++i) k1[i] = f0[i];
                     W.solve(th, g0, gr0, kc->scale, k1);

@@ -427,6 +427,30 @@ struct DenseLU {
         wave_pivots = __builtin_amdgcn_ballot_w64(anyp) != 0;
         return ok;
     }
+    // Rosenbrock23(autodiff = false) (case2/case2.jl:26, robertson/rober_crnn_lm.jl:34): W = I - gam J with J filled by
+    // FiniteDiff.finite_difference_jacobian!(J, f, u, Val(:forward)): column c = (f(u + eps_c e_c) - f(u)) / eps_c,
+    // eps_c = max(sqrt(eps) |u_c|, sqrt(eps)) [UNVERIFIED-DEP: FiniteDiff.jl's default step, restated].
+    // rhs(up, fp) evaluates the right-hand side; f0 = f(u) is the value the stepper holds.  A temperature state needs no column:
+    // its row of J is zero and every right-hand side W meets has a zero temperature component, so that block never acts.
+    template <class F>
+    __device__ __forceinline__ bool factor_fd(const double (&u)[NS], const double (&f0)[NS], const double gam, F &&rhs) {
+        const double rel = 1.4901161193847656e-08;   // sqrt(2^-52)
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {
+            double up[NS], fp[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) up[i] = u[i];
+            const double eps = fmax(rel * fabs(u[c]), rel);
+            up[c] = u[c] + eps;
+            rhs(up, fp);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) A[i][c] = ((i == c) ? 1.0 : 0.0) - gam * ((fp[i] - f0[i]) / eps);
+        }
+        bool anyp;
+        const bool ok = lu_factor<NS>(A, dinv, piv, anyp);
+        wave_pivots = __builtin_amdgcn_ballot_w64(anyp) != 0;
+        return ok;
+    }
     // g, gr (= gam * r) are unused here; the signature is shared with Woodbury
     __device__ __forceinline__ void solve(const double *__restrict__, const double (&)[NS], const double (&)[NR],
                                           const double *, double (&b)[NS]) const {

@@ -226,6 +226,18 @@ int32_t crnn_ctx_set_queue_order(crnn_ctx *ctx, int32_t order);
 int32_t crnn_ctx_set_lanes_per_traj(crnn_ctx *ctx, int32_t lanes);
 /* Lanes per trajectory the most recent adjoint gradient launch used (1 or 2; 0 if no adjoint launch has run, -1 for a null ctx). */
 int32_t crnn_last_lanes_per_traj(const crnn_ctx *ctx);
+/* Jacobian behind W = I - gam J of the Rosenbrock23 stepper in PRIMAL launches (crnn_solve with n_dir = 0: predict_neuralode,
+ * loss_neuralode, the epoch-end loop).  ANALYTIC (default): the exact J -- what Rosenbrock23(autodiff = true) forms
+ * (robertson/rober_crnn.jl:33).  FINITE_DIFF: what Rosenbrock23(autodiff = false) forms (case2/case2.jl:26,
+ * robertson/rober_crnn_lm.jl:34): forward differences of the right-hand side, column c = (f(u + eps_c e_c) - f(u)) / eps_c with
+ * eps_c = max(sqrt(eps) |u_c|, sqrt(eps)) (FiniteDiff.jl's default step for forward differences, restated -- FiniteDiff is
+ * not vendored with the reference), ns more right-hand sides per attempt and a dense ns x ns factorisation.  Rosenbrock23 is a
+ * W-method, so both are Rosenbrock23 solves of the same problem: results differ by ~1e-8 relative in J, ~1e-9 in a loss at
+ * the reference's tolerances.  Gradient launches are not affected: they differentiate the analytic-W step (the reference
+ * pushes Duals through FiniteDiff's increments).  CRNN right-hand side with Rosenbrock23 only (not HyChem,
+ * whose reference Jacobian also carries a finite-difference time derivative). */
+enum { CRNN_JAC_ANALYTIC = 0, CRNN_JAC_FINITE_DIFF = 1 };
+int32_t crnn_ctx_set_jacobian(crnn_ctx *ctx, int32_t mode);
 
 /* ---- the hot path at theta level ---------------------------------------- *
  * Integrates trajectories [first, first+count) of the uploaded ensemble with

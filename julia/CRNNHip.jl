@@ -113,6 +113,13 @@ last_lanes_per_traj(prob::Problem) = ccall((:crnn_last_lanes_per_traj, LIB), Int
 set_lanes_per_traj!(prob::Problem, lanes::Integer) =
     check(ccall((:crnn_ctx_set_lanes_per_traj, LIB), Int32, (Ptr{Cvoid}, Int32), prob.ctx, Int32(lanes)), prob.ctx)
 
+"""`set_jacobian!(prob, JAC_FINITE_DIFF)`: the primal launches build `W` from forward differences of the right-hand side, as
+`Rosenbrock23(autodiff=false)` does (`case2/case2.jl:26`); `JAC_ANALYTIC` (default): the exact Jacobian (`autodiff=true`)."""
+set_jacobian!(prob::Problem, mode::Integer) =
+    check(ccall((:crnn_ctx_set_jacobian, LIB), Int32, (Ptr{Cvoid}, Int32), prob.ctx, Int32(mode)), prob.ctx)
+const JAC_ANALYTIC = Int32(0)
+const JAC_FINITE_DIFF = Int32(1)
+
 """`sol.destats.naccept / nreject` of every `solve` of the most recent ensemble launch over `first .+ (0:count-1)` (0-based)."""
 function last_step_counts(prob::Problem, first::Integer = 0, count::Integer = prob.B - first)
     na = zeros(Int32, count); nr = zeros(Int32, count)

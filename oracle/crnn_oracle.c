@@ -80,6 +80,8 @@ typedef struct orc_problem {
     int32_t grad_adjoint;       /* 1: Rosenbrock23 gradients by the discrete adjoint of the accepted steps (solve_one_adj) instead
                                    of forward tangents -- the SAME derivative, the algorithm the GPU runs; CPU-baseline timing
                                    and an independent check of the adjoint formulas (bench.py, tests/test_oracle_golden.py) */
+    int32_t jac_fd;             /* 1: Rosenbrock23(autodiff = false) (case2/case2.jl:26): W = I - gam J with J by forward differences of the
+                                   right-hand side (orc_jac_fd); primal solves only (P = 0) */
     double lb, ub;              /* log-clamp window; ub may be +inf */
     double inv_R;               /* -1/R for the Arrhenius row (has_temp) */
     double rate_scale[ORC_MAXN];/* dydt_scale (robertson), else 1 */
@@ -184,6 +186,27 @@ void orc_jac(const orc_problem *pb, const double *th, const double *u, double *J
                 for (int j = 0; j < nr; ++j) a += w_out[i + ns * j] * r[j] * w_in[c + n * j];
             J[i + n * c] = (i < ns) ? a * g[c] * pb->rate_scale[i] : 0.0;
         }
+}
+
+/* Rosenbrock23(autodiff = false) (case2/case2.jl:26, robertson/rober_crnn_lm.jl:34): OrdinaryDiffEq fills J with
+   FiniteDiff.finite_difference_jacobian!(J, f, u, Val(:forward)) -- column c = (f(u + eps_c e_c) - f(u)) / eps_c with
+   eps_c = max(relstep |u_c|, absstep), relstep = absstep = sqrt(eps(Float64)) (FiniteDiff's default_relstep / compute_epsilon for
+   forward differences) [UNVERIFIED-DEP: FiniteDiff.jl is not vendored with the reference; restated from its published algorithm].
+   f0 = f(u) is the value the stepper already holds.  The temperature state gets its column too (its row is zero: du_T = 0), as
+   FiniteDiff differences every state.  The companion time derivative dT = (f(t + eps_t) - f(t)) / eps_t is exactly zero for these
+   right-hand sides (they do not read t) and is not formed. */
+void orc_jac_fd(const orc_problem *pb, const double *th, const double *u, const double *f0, double *J) {
+    const int n = N_(pb);
+    const double rel = 1.4901161193847656e-08;   /* sqrt(2^-52) */
+    double up[ORC_MAXN], fp[ORC_MAXN];
+    memcpy(up, u, sizeof(double) * n);
+    for (int c = 0; c < n; ++c) {
+        const double eps = fmax(rel * fabs(u[c]), rel);
+        up[c] = u[c] + eps;
+        orc_rhs(pb, th, up, fp);
+        for (int i = 0; i < n; ++i) J[i + n * c] = (fp[i] - f0[i]) / eps;
+        up[c] = u[c];
+    }
 }
 
 /* Directional derivative of f along (su, dth): out = f_u su + f_theta dth. */
@@ -532,7 +555,7 @@ static int solve_one_ws(const orc_problem *pb, const double *th, const double *d
         if (t + dt * (1.0 + 1e-13) >= tend) { dt = tend - t; last = 1; }
         if (!(dt > pb->dtmin) || t + dt == t) { retcode = 2; break; }
         const double gam = d * dt;
-        orc_jac(pb, th, u, J);
+        if (pb->jac_fd) orc_jac_fd(pb, th, u, f0, J); else orc_jac(pb, th, u, J);
         for (int c = 0; c < n; ++c) for (int i = 0; i < n; ++i) W[i + n * c] = (i == c ? 1.0 : 0.0) - gam * J[i + n * c];
         if (lu_factor(n, W, piv) != 0) { retcode = 3; break; }
         double k1[ORC_MAXN], k2[ORC_MAXN], k3[ORC_MAXN], u1[ORC_MAXN], f1[ORC_MAXN], unew[ORC_MAXN], f2[ORC_MAXN], tmp[ORC_MAXN];
@@ -1262,6 +1285,7 @@ static int solve_dispatch(const orc_problem *pb, const double *th, const double 
                           const double *u0, const double *tsave, int nsave,
                           const double *data, double *pred, double *dpred,
                           double *loss_out, double *grad, int32_t *n_saved_out, orc_stats *st, double *ws) {
+    if (pb->jac_fd && (P > 0 || pb->solver != 0)) return -7;   /* the finite-difference W exists for plain Rosenbrock23 primal solves */
     if (pb->solver == 2) return solve_one_auto(pb, th, dth, P, u0, tsave, nsave, data, pred, dpred, loss_out, grad, n_saved_out, st, ws, NULL);
     if (pb->solver == 1) return solve_one_tsit5(pb, th, dth, P, u0, tsave, nsave, data, pred, dpred, loss_out, grad, n_saved_out, st, ws);
     if (pb->grad_adjoint && P > 0 && !pb->errnorm_sens && !dpred)

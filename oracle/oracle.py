@@ -29,6 +29,7 @@ class Problem(C.Structure):
         ("n_obs", C.c_int32), ("i_obs", C.c_int32 * MAXN),
         ("clamp_pred", C.c_int32), ("loss_kind", C.c_int32),
         ("maxiters", C.c_int32), ("errnorm_sens", C.c_int32), ("solver", C.c_int32), ("grad_adjoint", C.c_int32),
+        ("jac_fd", C.c_int32),
         ("lb", C.c_double), ("ub", C.c_double), ("inv_R", C.c_double),
         ("rate_scale", C.c_double * MAXN),
         ("atol", C.c_double * MAXN), ("rtol", C.c_double * MAXN),
@@ -73,7 +74,7 @@ def _ip(a):
 
 def make_problem(*, ns, nr, has_temp=0, lb=1e-6, ub=np.inf, inv_R=0.0, rate_scale=None,
                  atol=1e-6, rtol=1e-3, yscale=None, i_obs=None, clamp_pred=0, loss_kind=0,
-                 maxiters=100000, errnorm_sens=0, t0=0.0, solver=0, grad_adjoint=0) -> Problem:
+                 maxiters=100000, errnorm_sens=0, t0=0.0, solver=0, grad_adjoint=0, jac_fd=0) -> Problem:
     pb = Problem()
     lib().orc_problem_defaults(C.byref(pb))
     n = ns + has_temp
@@ -82,6 +83,7 @@ def make_problem(*, ns, nr, has_temp=0, lb=1e-6, ub=np.inf, inv_R=0.0, rate_scal
     pb.clamp_pred, pb.loss_kind, pb.maxiters, pb.errnorm_sens = clamp_pred, loss_kind, maxiters, errnorm_sens
     pb.t0 = t0
     pb.grad_adjoint = int(grad_adjoint)      # Rosenbrock23 gradients by the discrete adjoint (same derivative, other algorithm)
+    pb.jac_fd = int(jac_fd)                  # Rosenbrock23(autodiff=false): W from forward differences of the right-hand side (primal solves)
     lib().orc_set_solver(C.byref(pb), int(solver))
     at = np.broadcast_to(np.asarray(atol, float), (n,))
     rt = np.broadcast_to(np.asarray(rtol, float), (n,))

@@ -85,3 +85,59 @@ def test_ragged_large_ensemble_primal_launch(case2_setup):
     fwd.set_ensemble(u0[:2048], data[:2048], cases.max_min(data, lb=LB_CASE2))
     assert np.array_equal(fwd.predict_n_ode(s["p_ckpt"]), pred[:2048])
     node.close(); fwd.close()
+
+
+@pytest.mark.parametrize("case", ["case2", "rober"])
+def test_finite_difference_jacobian_mode_matches_the_oracle(orc, case2_setup, rober_setup, case):
+    """crnn_ctx_set_jacobian(CRNN_JAC_FINITE_DIFF): primal launches build W = I - gam J from forward differences of the right-hand
+    side, as Rosenbrock23(autodiff=false) does (case2/case2.jl:26, robertson/rober_crnn_lm.jl:34; FiniteDiff's default step
+    restated, [UNVERIFIED-DEP]).  HIP against the oracle's jac_fd = 1: same accepted / rejected counts; losses and predictions to
+    1e-8 on case2 and 1e-5 on robertson -- the two sides' right-hand sides differ in their last bits (other log / exp), the
+    1.5e-8 increments magnify that to ~1e-8 of |f| in a column of J, and robertson's W = I - gam J (gam |J| >> 1, a species at
+    1e-5 below the absolute increment) passes it on: measured 4e-9 ... 8e-7 per trajectory, against the 3e-4 ... 1.3e-3 by which
+    the finite-difference W moves robertson's losses away from the analytic-W ones (case2: 2e-9).  Distinguishable from the
+    analytic-W solve, which gradient launches keep using."""
+    from conftest import oracle_problem
+    from crnn_amd import JAC_ANALYTIC, JAC_FINITE_DIFF, NeuralODE, ODEProblem, PRESET_CASE2, PRESET_ROBER
+    if case == "case2":
+        s = case2_setup
+        node = NeuralODE(ODEProblem(PRESET_CASE2, s["tsteps"]))
+        kind, ns, nr = 2, 6, 3
+    else:
+        s = rober_setup
+        node = NeuralODE(ODEProblem(PRESET_ROBER, s["tsteps"], rate_scale=s["dydt_scale"]))
+        kind, ns, nr = 3, 3, 6
+    node.set_ensemble(s["u0"], s["data"], s["yscale"])
+    p = s["p_ckpt"]
+    th, _ = orc.p2vec(kind, ns, nr, p)
+    B = s["u0"].shape[0]
+    u0T = np.ascontiguousarray(s["u0"].T); dT = np.ascontiguousarray(s["data"].transpose(2, 1, 0))
+    pred_an = node.predict_n_ode(p); loss_an = node.losses(p).mean()
+    _, grad_an = node.loss_and_grad(p)
+    node.set_jacobian(JAC_FINITE_DIFF)
+    pred_fd = node.predict_n_ode(p); loss_fd = node.losses(p).mean()
+    st = dict(node.last_stats)
+    ref = orc.solve_batch(oracle_problem(orc, case, s, jac_fd=1), th, u0T, s["tsteps"], dT, want_pred=True)
+    assert st["n_accept"] == ref["naccept"] and st["n_reject"] == ref["nreject"]
+    tol = 1e-8 if case == "case2" else 1e-5
+    assert abs(loss_fd - ref["loss"].mean()) < tol * abs(loss_fd)
+    pr = ref["pred"].transpose(2, 1, 0)                                   # [B, n, D]
+    assert pr.shape == pred_fd.shape and np.max(np.abs(pred_fd - pr)) < tol * np.max(np.abs(pr))
+    d_an = abs(loss_fd - loss_an) / abs(loss_an)
+    assert 1e-12 < d_an < 1e-2                                            # another W, the same method: close, not equal
+    if case == "rober":
+        assert d_an > 10 * tol                                            # ... and further apart than the two implementations of it
+    assert np.max(np.abs(pred_fd - pred_an)) > 0
+    _, grad_fd = node.loss_and_grad(p)                                    # gradient launches: the analytic-W step, unchanged
+    assert np.array_equal(grad_fd, grad_an)
+    node.set_jacobian(JAC_ANALYTIC)
+    assert node.losses(p).mean() == loss_an
+    node.close()
+
+
+def test_finite_difference_jacobian_mode_is_refused_where_it_does_not_exist():
+    from crnn_amd import CrnnError, JAC_FINITE_DIFF, NeuralODE, ODEProblem, PRESET_CASE2, SOLVER_TSIT5, cases
+    node = NeuralODE(ODEProblem(PRESET_CASE2, cases.case2_tsteps(), solver=SOLVER_TSIT5))
+    with pytest.raises(CrnnError, match="crnn_ctx_set_jacobian"):
+        node.set_jacobian(JAC_FINITE_DIFF)
+    node.close()
