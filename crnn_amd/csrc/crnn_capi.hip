@@ -347,6 +347,7 @@ __device__ __forceinline__ void opt_body(const crnn::OptCfg &o, int P, int npart
         if (tid == 0) { *ncalls = nc; *ed_eta = e; }
     }
     const double b1t = bp[0], b2t = bp[1];
+    __syncthreads();   // sh (the clip norm's tree) is re-used for the new p below
     for (int k = tid; k < P; k += NT) {
         double g = red[k] * gscale;
         if (clip) g = g / gn * o.grad_clip_norm;
@@ -356,15 +357,19 @@ __device__ __forceinline__ void opt_body(const crnn::OptCfg &o, int P, int npart
         m[k] = mk;
         v[k] = vk;
         double delta = mk / (1.0 - b1t) / (sqrt(vk / (1.0 - b2t)) + 1e-8) * o.eta;
-        delta += o.wd * p[k];
-        p[k] -= delta;
+        const double pk = p[k];
+        delta += o.wd * pk;
+        const double pn = pk - delta;
+        p[k] = pn;
+        if (k < NT) sh[k] = pn;     // the new p for the one thread that forms theta: read back from global memory it was two dozen
+                                    // dependent round trips (the loads cannot pass the stores to th / dth), 17 us of a 27 us launch
     }
     for (int i = tid; i < nth * P; i += NT) dth[i] = 0.0;
     __syncthreads();
     if (tid == 0) {
         bp[0] = b1t * o.beta1;
         bp[1] = b2t * o.beta2;
-        crnn::p2vec_eval(pmap, ns, nr, has_temp, p, th, dth);
+        crnn::p2vec_eval(pmap, ns, nr, has_temp, P <= NT ? sh : p, th, dth);
         *queue = 0ULL;
         *overflow = 0u;
     }
@@ -881,21 +886,23 @@ int32_t launch_sens_chunk(Ctx *c, const KernelEntry *k, const double *d_theta, c
 // HyChem: one ForwardDiff chunk of <= 12 directions, a group of twelve lanes per trajectory (hychem_sens_kernel.hpp); the same
 // per-trajectory gradient rows and fixed-order reduction as launch_sens_chunk.
 int32_t launch_hychem_sens_chunk(Ctx *c, const double *d_theta, const double *d_dtheta, int P, int64_t first, int64_t count,
-                                 int n_save_active, bool want_pred, int dual_partials) {
+                                 int n_save_active, bool want_pred, int dual_partials, int n_chunks = 1) {
     if (c->cfg.ns != 9 || c->cfg.nr != 10) return fail(c, "crnn_solve: the HyChem kernel is instantiated for ns = 9, nr = 10");
     if (!c->d_tabs || c->tabs_B != c->B) return fail(c, "crnn_solve: HyChem needs T/P tables (crnn_ctx_set_tables after crnn_ctx_set_data)");
     constexpr int kC = 12, kBlk = 128, kGroups = (kBlk / 64) * (64 / kC);
-    const int npart_pad = kC + crnn::kExtra, npart = P + crnn::kTail;
+    const int ppad = n_chunks > 1 ? P : kC;      // gradient row: the chunk's 12 columns | all chunks in one launch: compact [P]
+    const int npart_pad = ppad + crnn::kExtra, npart = P + crnn::kTail;
     using SFn = void (*)(const crnn::SolveParams, const double *, const crnn::HyParams, const crnn::HySensParams);
     const SFn fn = (SFn)crnn::hychem_sens_kernel<9, 10, kBlk>;
     if (c->hysens_occ < 1) {
         HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->hysens_occ, (const void *)fn, kBlk, 0));
         if (c->hysens_occ < 1) c->hysens_occ = 1;
     }
-    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((count + kGroups - 1) / kGroups, (int64_t)c->num_cu * c->hysens_occ));
+    const int nch = std::max(1, n_chunks);
+    const int nblk = nch * (int)std::max<int64_t>(1, std::min<int64_t>((count + kGroups - 1) / kGroups, std::max<int64_t>(1, (int64_t)c->num_cu * c->hysens_occ / nch)));
     const int rblk = (int)((count + 255) / 256);
     if (ensure(c, &c->d_partials, &c->partials_cap, (size_t)rblk * npart_pad)) return -1;
-    if (ensure(c, &c->d_gtraj, &c->gtraj_cap, (size_t)count * kC)) return -1;
+    if (ensure(c, &c->d_gtraj, &c->gtraj_cap, (size_t)count * ppad)) return -1;
     if (c->npart_max < npart) {
         if (c->d_red) HIP_TRY(c, hipFree(c->d_red));
         c->d_red = nullptr;
@@ -909,6 +916,7 @@ int32_t launch_hychem_sens_chunk(Ctx *c, const double *d_theta, const double *d_
     hp.tabs = c->d_tabs; hp.n_save_total = c->cfg.n_save; hp.inv_R = c->cfg.inv_R;
     crnn::HySensParams sp{};
     sp.dth = d_dtheta; sp.n_dir = P; sp.mode = c->cfg.errnorm_sens; sp.dual_partials = dual_partials;
+    sp.n_chunks = n_chunks; sp.n_total = P;
     if (upload_consts(c)) return -1;
     c->flags_zeroed = false;
     c->ev0 = c->ring0[c->n_launch % Ctx::kRing];
@@ -918,10 +926,10 @@ int32_t launch_hychem_sens_chunk(Ctx *c, const double *d_theta, const double *d_
     hipLaunchKernelGGL(fn, dim3(nblk), dim3(kBlk), 0, c->stream, prm, d_theta, hp, sp);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    hipLaunchKernelGGL(crnn::reduce_traj_kernel, dim3(rblk), dim3(256), 0, c->stream, c->d_gtraj, kC, c->d_loss, c->d_ret,
+    hipLaunchKernelGGL(crnn::reduce_traj_kernel, dim3(rblk), dim3(256), 0, c->stream, c->d_gtraj, ppad, c->d_loss, c->d_ret,
                        c->d_nacc, c->d_nrej, first, count, 256, c->d_partials);
     HIP_TRY(c, hipGetLastError());
-    hipLaunchKernelGGL(crnn::reduce_partials_kernel, dim3(npart_pad), dim3(256), 0, c->stream, c->d_partials, rblk, kC, P, c->d_red);
+    hipLaunchKernelGGL(crnn::reduce_partials_kernel, dim3(npart_pad), dim3(256), 0, c->stream, c->d_partials, rblk, ppad, P, c->d_red);
     HIP_TRY(c, hipGetLastError());
     c->last_npart = npart;
     c->last_P = P;
@@ -955,7 +963,11 @@ int32_t launch_sens(Ctx *c, const double *d_theta, const double *d_dtheta, int P
         HIP_TRY(c, hipMalloc((void **)&c->d_red_asm, sizeof(double) * npart));
         c->red_asm_len = npart;
     }
-    if (k && k->drows > P && c->sens_one_launch) {
+    if (c->hychem && c->sens_one_launch && P <= 255 && chunk == 12) {
+        // HyChem: the 18 chunks of 12 as the blocks of one launch (hychem_sens_kernel, n_chunks > 1)
+        if (launch_hychem_sens_chunk(c, d_theta, d_dtheta, P, first, count, n_save_active, false, chunk, (P + chunk - 1) / chunk)) return -1;
+        HIP_TRY(c, hipMemcpyAsync(c->d_red_asm, c->d_red, sizeof(double) * P, hipMemcpyDeviceToDevice, c->stream));
+    } else if (k && k->drows > P && c->sens_one_launch) {
         // all chunks in one launch (ros23_sens_kernel, n_chunks > 1): the same independent adaptive solves, one tail
         if (launch_sens_chunk(c, k, d_theta, d_dtheta, P, first, count, n_save_active, false, chunk, (P + chunk - 1) / chunk, chunk)) return -1;
         HIP_TRY(c, hipMemcpyAsync(c->d_red_asm, c->d_red, sizeof(double) * P, hipMemcpyDeviceToDevice, c->stream));

@@ -103,6 +103,10 @@ struct HySensParams {
     int32_t n_dir;         // real directions of this chunk (the others are zero partials)
     int32_t mode;          // 1: squared norm / length(u); 2: / totallength(u) = ns (1 + dual_partials)
     int32_t dual_partials; // partials per Dual (12)
+    int32_t n_chunks;      // > 1: dth holds all n_total directions; block b works on chunk b % n_chunks (its 12 rows of dth), the
+    int32_t n_total;       //      blocks of a chunk share its trajectories; gradient rows compact [count][n_total]; no per-trajectory
+                           //      losses / statistics (the plain solve behind the chunks writes them).  One launch instead of 18: a
+                           //      chunk launch of 1 024 trajectories is 192 wavefronts, a fifth of the chip, for one generation
 };
 
 template <int NS, int NR, int BLOCK>
@@ -121,7 +125,11 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens_kernel(const SolveParams pr
     for (int idx = tid; idx < kNConst; idx += BLOCK) kc_lds[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
     for (int idx = tid; idx < hp.n_save_total; idx += BLOCK) ts_lds[idx] = prm.tsave[idx];
     for (int idx = tid; idx < NTH; idx += BLOCK) th_lds[idx] = theta[idx];
-    for (int idx = tid; idx < C * NTH; idx += BLOCK) dth_lds[idx] = (idx / NTH) < sp.n_dir ? sp.dth[idx] : 0.0;
+    const int nch = sp.n_chunks > 1 ? sp.n_chunks : 1;
+    const int cid = nch > 1 ? (int)(blockIdx.x % nch) : 0;
+    const int ndir = nch > 1 ? min(C, sp.n_total - cid * C) : sp.n_dir;       // real directions of this block's chunk
+    const double *const dth_g = sp.dth + (size_t)cid * C * NTH;
+    for (int idx = tid; idx < C * NTH; idx += BLOCK) dth_lds[idx] = (idx / NTH) < ndir ? dth_g[idx] : 0.0;
     __syncthreads();
     const KConst *kc = reinterpret_cast<const KConst *>(kc_lds);
     const double *th = th_lds;
@@ -131,8 +139,8 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens_kernel(const SolveParams pr
     const int gbase = grp * C;                  // first lane of the group within the wavefront
     const double *const dthc = dth_lds + (lane_on ? col : 0) * NTH;
     double *const As = lu_lds + tid;
-    const int64_t groups_total = (int64_t)gridDim.x * (BLOCK / 64) * GPW;
-    int64_t traj = ((int64_t)blockIdx.x * (BLOCK / 64) + (tid >> 6)) * GPW + grp;
+    const int64_t groups_total = (int64_t)(gridDim.x / nch) * (BLOCK / 64) * GPW;      // groups working on this block's chunk
+    int64_t traj = ((int64_t)(blockIdx.x / nch) * (BLOCK / 64) + (tid >> 6)) * GPW + grp;
     if (!lane_on) traj = prm.count;             // the idle lanes never start a trajectory
 
     const double d_ = 0.29289321881345248, c32 = 7.4142135623730950, inv12d = 2.4142135623730950;
@@ -370,8 +378,9 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens_kernel(const SolveParams pr
         {
             const double denom = (double)prm.n_obs * (double)jsave;
             const double inv = jsave > 0 ? 1.0 / denom : 0.0;
-            prm.gtraj[(size_t)traj * C + col] = gsum * inv;          // d loss_b / d p_k of this chunk's k = column
-            if (col == 0) {
+            if (nch == 1) prm.gtraj[(size_t)traj * C + col] = gsum * inv;          // d loss_b / d p_k of this chunk's k = column
+            else if (col < ndir) prm.gtraj[(size_t)traj * sp.n_total + cid * C + col] = gsum * inv;
+            if (col == 0 && nch == 1) {
                 prm.loss[b] = loss_sum * inv;
                 prm.retcode[b] = rc;
                 prm.n_saved[b] = jsave;
