@@ -80,6 +80,66 @@ struct RecS {
     static constexpr int NREC = B2 + NS;
 };
 
+// features() / rates() of a point that the L lanes of a group all evaluate (the primal attempt is redundant across the group): the
+// logarithms and exponentials -- half of a primal attempt's arithmetic -- are divided among the lanes, lane q takes species
+// q, q + L, ... and reactions q, q + L, ..., and gathered with ds_bpermute (the same bits on every lane: one lane formed them).
+// flog_vec / fexp_vec work element by element, so the values are those of features() / rates().
+template <int NS, int L>
+__device__ __forceinline__ void features_grp(const double (&u)[NS], const double lb, const double ub, double (&x)[NS], double (&g)[NS],
+                                             const int q, const int gbase) {
+    constexpr int PER = (NS + L - 1) / L;
+    double c[NS], cm[PER], xm[PER];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        c[i] = fmin(fmax(u[i], lb), ub);
+        g[i] = (c[i] == u[i]) ? frcp1(c[i]) : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        cm[k] = c[k * L < NS ? k * L : 0];
+#pragma unroll
+        for (int m = 1; m < L; ++m)
+            if (k * L + m < NS) cm[k] = (q == m) ? c[k * L + m] : cm[k];
+    }
+    flog_vec<PER>(cm, xm);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) x[i] = __shfl(xm[i / L], gbase + i % L);
+}
+template <int NS, int NR, bool HAS_T, int L>
+__device__ __forceinline__ void rates_grp(const double *__restrict__ th, const double (&x)[NS], const double (&bT)[NR], double (&r)[NR],
+                                          const int q, const int gbase) {
+    using L_ = Lay<NS, NR, HAS_T>;
+    constexpr int PER = (NR + L - 1) / L;
+    double z[NR], zm[PER], em[PER];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        double zz = bT[j];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) zz = fma(th[L_::wi(i, j)], x[i], zz);
+        z[j] = zz;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        zm[k] = z[k * L < NR ? k * L : 0];
+#pragma unroll
+        for (int m = 1; m < L; ++m)
+            if (k * L + m < NR) zm[k] = (q == m) ? z[k * L + m] : zm[k];
+    }
+    fexp_vec<PER>(zm, em);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) r[j] = __shfl(em[j / L], gbase + j % L);
+}
+
+// sqrt(m) for finite m >= 0: v_rsq_f64 seed (~4e-8 like v_rcp_f64), two coupled Newton steps s += r/2 (m - s^2): 1.5 delta^2 after the
+// first, rounding after the second (1-2 ulp); m = 0 gives 0
+__device__ __forceinline__ double fsqrt_pos(const double m) {
+    const double r = __builtin_amdgcn_rsq(m), hr = 0.5 * r;
+    double s_ = m * r;
+    s_ = fma(hr, fma(-s_, s_, m), s_);
+    s_ = fma(hr, fma(-s_, s_, m), s_);
+    return m > 0.0 ? s_ : 0.0;
+}
+
 // Hairer's initial step (OrdinaryDiffEq ode_determine_initdt) when the state carries partials: u0 is promoted to Duals with
 // zero partials, f0 = f(u0, p) and f1 = f(u0 + dt0 f0, p) carry the partials of p, and every internalnorm is the dual-
 // inclusive one -- d1 and d2 grow by the partials, d0 only shares the divisor ([UNVERIFIED-DEP] like the norm itself).
@@ -274,8 +334,8 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
         }
 #pragma unroll
         for (int j = 0; j < NR; ++j) bT[j] = HAS_T ? fma(th[L_::wi(NS, j)], xT, th[L_::wb(j)]) : th[L_::wb(j)];
-        features<NS>(u, kc->lb, kc->ub, x0, g0);
-        rates<NS, NR, HAS_T>(th, x0, bT, r0);
+        features_grp<NS, L>(u, kc->lb, kc->ub, x0, g0, chunk, gbase);
+        rates_grp<NS, NR, HAS_T, L>(th, x0, bT, r0, chunk, gbase);
         rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r0, kc->scale, f0);
         // Hairer initial step with the dual-inclusive norms (the Sn slot parks f0' meanwhile; it is zeroed below)
         const double dt0_ = sens_init_dt<NS, NR, HAS_T, USE_SCALE, C, L, 2>(th, kc, dcols, NTHP,
@@ -351,8 +411,8 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
                 double u1[NS], x1[NS], g1[NS], r1[NR];
 #pragma unroll
                 for (int i = 0; i < NS; ++i) u1[i] = fma(0.5 * dt, k1[i], u[i]);
-                features<NS>(u1, kc->lb, kc->ub, x1, g1);
-                rates<NS, NR, HAS_T>(th, x1, bT, r1);
+                features_grp<NS, L>(u1, kc->lb, kc->ub, x1, g1, chunk, gbase);
+                rates_grp<NS, NR, HAS_T, L>(th, x1, bT, r1, chunk, gbase);
                 rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r1, kc->scale, f1);
                 if (lead) {
 #pragma unroll
@@ -366,8 +426,8 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
             W.solve(th, g0, gr0, kc->scale, dk);
 #pragma unroll
             for (int i = 0; i < NS; ++i) unew[i] = fma(dt, k1[i] + dk[i], u[i]);
-            features<NS>(unew, kc->lb, kc->ub, x2, g2);
-            rates<NS, NR, HAS_T>(th, x2, bT, r2);
+            features_grp<NS, L>(unew, kc->lb, kc->ub, x2, g2, chunk, gbase);
+            rates_grp<NS, NR, HAS_T, L>(th, x2, bT, r2, chunk, gbase);
             rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r2, kc->scale, f2);
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
@@ -705,8 +765,11 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
                 const double nai = fma(u[i], u[i], nas[i]);
                 const double nbi = fma(unew[i], unew[i], nb[i]);
                 const double eei = fma(ev[i], ev[i], group_sum(ee[i]));
-                const double sc = fma(kc->rtol[i], sqrt(fmax(nai, nbi)), kc->atol[i]);
-                es += eei / (sc * sc);
+                // sqrt and 1 / sc to 1-2 ulp (hardware seeds + one / two Newton steps: a third of the instructions of the IEEE
+                // routines, six of each per attempt); EEst^2 moves in its last digits, the decisions only if it sits within them of 1
+                const double sc = fma(kc->rtol[i], fsqrt_pos(fmax(nai, nbi)), kc->atol[i]);
+                const double isc = frcp(sc);
+                es = fma(eei * isc, isc, es);
             }
             // / length(u) (errnorm_sens = 1) or / totallength(u) = n (1 + partials per Dual) (errnorm_sens = 2)
             es = es / ((double)N * (1.0 + (double)prm.norm_cols));
