@@ -295,7 +295,8 @@ __global__ void p2vec_kernel(int pmap, int ns, int nr, int has_temp, const doubl
                              int nth, int P) {
     for (int i = threadIdx.x; i < nth * P; i += blockDim.x) dth[i] = 0.0;
     __syncthreads();
-    if (threadIdx.x == 0) crnn::p2vec_eval(pmap, ns, nr, has_temp, p, th, dth);
+    const int t = threadIdx.x;
+    if (t < nr * ns) crnn::p2vec_eval(pmap, ns, nr, has_temp, p, th, dth, t / ns, nr, t % ns, ns);   // one (species, reaction) pair per thread
 }
 
 // red = [grad_sum(P) | n_overflow | loss_sum, n_ok, n_accept, n_reject, n_traj]   (npart = P + kTail)
@@ -304,22 +305,36 @@ __global__ void p2vec_kernel(int pmap, int ns, int nr, int has_temp, const doubl
 // counter, so that a training step is [this kernel] -> solve -> reductions.
 // (device function: called by opt_kernel and, when no collective sits between the reduction and the update, by block 0 of
 // reduce_opt_sort_kernel; NT = threads of the block, sh = NT doubles of LDS)
+// What opt_body reads that does not depend on the reduced gradient: requested before the reduction (block 0 of
+// reduce_opt_sort_kernel) so that the values arrive while the partial rows are summed -- read where they are used, behind the block's
+// barriers, they were five dependent memory round trips of a launch that sits alone between two solve launches.
+struct OptPre { double poison0, ncalls, ed_eta, b1t, b2t, mk, vk, pk; };
+template <int NT>
+__device__ __forceinline__ void opt_prefetch(int P, const double *p, const double *state, const double *poison, OptPre &q) {
+    const int tid = threadIdx.x;
+    q.poison0 = poison[0];
+    q.b1t = state[2 * P]; q.b2t = state[2 * P + 1];
+    q.ed_eta = state[2 * P + 2]; q.ncalls = state[2 * P + 3];
+    const int k = tid < P ? tid : 0;
+    q.mk = state[k]; q.vk = state[P + k]; q.pk = p[k];
+}
 template <int NT>
 __device__ __forceinline__ void opt_body(const crnn::OptCfg &o, int P, int npart, double *p, const double *red,
                                          double *state, int pmap, int ns, int nr, int has_temp, double *th, double *dth,
-                                         int nth, unsigned long long *queue, unsigned int *overflow, double *poison, double *sh) {
+                                         int nth, unsigned long long *queue, unsigned int *overflow, double *poison, double *sh,
+                                         const OptPre &q) {
     const int tid = threadIdx.x;
     // A gradient formed while some rank's adjoint tape overflowed (summed overflow count != 0) is not applied, and neither
     // is any later step until the host has repeated the skipped ones in order (sticky flag): p, the optimiser state and
     // theta stay as they are.  Only the overflow count gates this: a NaN gradient from any other cause is applied and
     // shows up in p, as it would in the reference.
-    const bool skip = poison[0] != 0.0 || red[npart - crnn::kTail] != 0.0;
+    const double n_over = red[npart - crnn::kTail], ntraj = red[npart - 1], red_k = red[tid < P ? tid : 0];   // one round trip
+    const bool skip = q.poison0 != 0.0 || n_over != 0.0;
     __syncthreads();
     if (skip) {
         if (tid == 0) { poison[0] = 1.0; poison[1] += 1.0; *queue = 0ULL; *overflow = 0u; }
         return;
     }
-    const double ntraj = red[npart - 1];
     const double gscale = ntraj > 0 ? 1.0 / ntraj : 0.0;
     double *m = state, *v = state + P, *bp = state + 2 * P;
     double *ed_eta = state + 2 * P + 2, *ncalls = state + 2 * P + 3;
@@ -327,7 +342,7 @@ __device__ __forceinline__ void opt_body(const crnn::OptCfg &o, int P, int npart
     bool clip = false;
     if (o.grad_clip_norm > 0) {
         double a = 0.0;
-        for (int k = tid; k < P; k += NT) { const double g = red[k] * gscale; a = fma(g, g, a); }
+        for (int k = tid; k < P; k += NT) { const double g = (k == tid ? red_k : red[k]) * gscale; a = fma(g, g, a); }
         sh[tid] = a;
         __syncthreads();
         for (int s_ = NT / 2; s_ > 0; s_ >>= 1) {
@@ -339,37 +354,36 @@ __device__ __forceinline__ void opt_body(const crnn::OptCfg &o, int P, int npart
     }
     double eta_ed = 1.0;
     if (o.use_expdecay) {
-        const double nc = *ncalls + 1.0;
-        double e = *ed_eta;
+        const double nc = q.ncalls + 1.0;
+        double e = q.ed_eta;
         if (fmod(nc, (double)o.decay_step) == 0.0) { e = e * o.ed_decay; e = e > o.ed_clip ? e : o.ed_clip; }
         eta_ed = e;
-        __syncthreads();   // every thread has read the old values
         if (tid == 0) { *ncalls = nc; *ed_eta = e; }
     }
-    const double b1t = bp[0], b2t = bp[1];
+    const double b1t = q.b1t, b2t = q.b2t;
     __syncthreads();   // sh (the clip norm's tree) is re-used for the new p below
     for (int k = tid; k < P; k += NT) {
-        double g = red[k] * gscale;
+        const bool mine = (k == tid);
+        double g = (mine ? red_k : red[k]) * gscale;
         if (clip) g = g / gn * o.grad_clip_norm;
         g *= eta_ed;
-        const double mk = o.beta1 * m[k] + (1.0 - o.beta1) * g;
-        const double vk = o.beta2 * v[k] + (1.0 - o.beta2) * g * g;
+        const double mk = o.beta1 * (mine ? q.mk : m[k]) + (1.0 - o.beta1) * g;
+        const double vk = o.beta2 * (mine ? q.vk : v[k]) + (1.0 - o.beta2) * g * g;
         m[k] = mk;
         v[k] = vk;
         double delta = mk / (1.0 - b1t) / (sqrt(vk / (1.0 - b2t)) + 1e-8) * o.eta;
-        const double pk = p[k];
+        const double pk = mine ? q.pk : p[k];
         delta += o.wd * pk;
         const double pn = pk - delta;
         p[k] = pn;
-        if (k < NT) sh[k] = pn;     // the new p for the one thread that forms theta: read back from global memory it was two dozen
-                                    // dependent round trips (the loads cannot pass the stores to th / dth), 17 us of a 27 us launch
+        if (k < NT) sh[k] = pn;     // the new p for the one thread that forms theta (not read back from global memory)
     }
     for (int i = tid; i < nth * P; i += NT) dth[i] = 0.0;
     __syncthreads();
+    if (tid < nr * ns) crnn::p2vec_eval(pmap, ns, nr, has_temp, P <= NT ? sh : p, th, dth, tid / ns, nr, tid % ns, ns);   // one (species, reaction) pair per thread
     if (tid == 0) {
         bp[0] = b1t * o.beta1;
         bp[1] = b2t * o.beta2;
-        crnn::p2vec_eval(pmap, ns, nr, has_temp, P <= NT ? sh : p, th, dth);
         *queue = 0ULL;
         *overflow = 0u;
     }
@@ -379,7 +393,9 @@ __global__ __launch_bounds__(256) void opt_kernel(crnn::OptCfg o, int P, int npa
                                                   double *state, int pmap, int ns, int nr, int has_temp, double *th, double *dth,
                                                   int nth, unsigned long long *queue, unsigned int *overflow, double *poison) {
     __shared__ double sh[256];
-    opt_body<256>(o, P, npart, p, red, state, pmap, ns, nr, has_temp, th, dth, nth, queue, overflow, poison, sh);
+    OptPre q;
+    opt_prefetch<256>(P, p, state, poison, q);
+    opt_body<256>(o, P, npart, p, red, state, pmap, ns, nr, has_temp, th, dth, nth, queue, overflow, poison, sh, q);
 }
 
 // One launch for the tail of a training step that needs no collective: block 0 = reduction + chain rule, then the
@@ -397,10 +413,12 @@ __global__ __launch_bounds__(1024) void reduce_opt_sort_kernel(const double *__r
     __shared__ double part[16][64];
     __shared__ unsigned key[1024];
     if (blockIdx.x == 0) {
+        OptPre q;
+        opt_prefetch<1024>(P, p, state, poison, q);       // in flight during the reduction
         crnn::reduce_project_body(partials, nblk, dtheta_in, nth, P, red_theta, red, overflow_in, sh, part);
         __threadfence_block();
         __syncthreads();          // red[] is complete and visible to the whole block; dtheta_in is not read any more
-        opt_body<1024>(o, P, npart, p, red, state, pmap, ns, nr, has_temp, th, dth, nth, queue, overflow, poison, sh);
+        opt_body<1024>(o, P, npart, p, red, state, pmap, ns, nr, has_temp, th, dth, nth, queue, overflow, poison, sh, q);
     } else if (spread && blockIdx.x == gridDim.x - 1) {
         crnn::step_spread_block(n_accept, n_reject, first, count, spread, key);
     } else if (perm) {

@@ -46,7 +46,12 @@ CRNN_HD inline double dabsd(double v) { return signbit(v) ? -1.0 : 1.0; }
 
 // Writes only the structurally non-zero entries of dth (column-major nth x P);
 // the caller zero-fills dth first.  dth may be null.
-CRNN_HD inline int p2vec_eval(int pmap, int ns, int nr, int has_temp, const double *p, double *th, double *dth) {
+// (j0, jstep, i0, istep): the reactions j0, j0 + jstep, ... and, of each, the species i0, i0 + istep, ... (the entries that belong to
+// a reaction alone go with i0 = 0).  Defaults: everything, serially (host).  On the device nr * ns threads call it with
+// (t / ns, nr, t % ns, ns): one (species, reaction) pair each -- one thread writing all of theta and d theta / d p was 8 us of the
+// launch between two solve launches.
+CRNN_HD inline int p2vec_eval(int pmap, int ns, int nr, int has_temp, const double *p, double *th, double *dth,
+                              int j0 = 0, int jstep = 1, int i0 = 0, int istep = 1) {
     const int n = ns + has_temp;
     const int nth = n_theta_of(ns, nr, has_temp);
     const int P = n_params_of(pmap, ns, nr, has_temp);
@@ -54,13 +59,15 @@ CRNN_HD inline int p2vec_eval(int pmap, int ns, int nr, int has_temp, const doub
     if (P < 0) return -1;
 #define DTH(row, col) dth[(row) + (int64_t)nth * (col)]
     if (pmap == PMAP_IDENTITY) {
-        for (int k = 0; k < nth; ++k) { th[k] = p[k]; if (dth) DTH(k, k) = 1.0; }
+        for (int k = j0 * ns + i0; k < nth; k += (jstep > 1 ? jstep * ns : 1)) { th[k] = p[k]; if (dth) DTH(k, k) = 1.0; }
     } else if (pmap == PMAP_CASE1) {
         if (has_temp) return -1;
-        for (int j = 0; j < nr; ++j) {
-            th[o_b + j] = p[j] + (-10.0);
-            if (dth) DTH(o_b + j, j) = 1.0;
-            for (int i = 0; i < ns; ++i) {
+        for (int j = j0; j < nr; j += jstep) {
+            if (i0 == 0) {
+                th[o_b + j] = p[j] + (-10.0);
+                if (dth) DTH(o_b + j, j) = 1.0;
+            }
+            for (int i = i0; i < ns; i += istep) {
                 const int k = nr + i + ns * j;
                 const double wo = p[k];
                 th[o_out + i + ns * j] = wo;
@@ -71,30 +78,36 @@ CRNN_HD inline int p2vec_eval(int pmap, int ns, int nr, int has_temp, const doub
     } else if (pmap == PMAP_CASE2) {
         if (!has_temp) return -1;
         const double slope = p[P - 1] * 100.0;
-        for (int j = 0; j < nr; ++j) {
-            th[o_b + j] = p[j] * slope;
-            if (dth) { DTH(o_b + j, j) = slope; DTH(o_b + j, P - 1) = p[j] * 100.0; }
-            for (int i = 0; i < ns; ++i) {
+        for (int j = j0; j < nr; j += jstep) {
+            if (i0 == 0) {
+                th[o_b + j] = p[j] * slope;
+                if (dth) { DTH(o_b + j, j) = slope; DTH(o_b + j, P - 1) = p[j] * 100.0; }
+            }
+            for (int i = i0; i < ns; i += istep) {
                 const int k = nr + i + ns * j;
                 const double wo = p[k];
                 th[o_out + i + ns * j] = wo;
                 th[o_in + i + n * j] = clampd(-wo, 0.0, 4.0);
                 if (dth) { DTH(o_out + i + ns * j, k) = 1.0; DTH(o_in + i + n * j, k) = -dclampd(-wo, 0.0, 4.0); }
             }
-            const int ke = nr * (ns + 1) + j;
-            const double v = p[ke] * slope;
-            th[o_in + ns + n * j] = fabs(v);
-            if (dth) { DTH(o_in + ns + n * j, ke) = dabsd(v) * slope; DTH(o_in + ns + n * j, P - 1) = dabsd(v) * p[ke] * 100.0; }
+            if (i0 == 0) {
+                const int ke = nr * (ns + 1) + j;
+                const double v = p[ke] * slope;
+                th[o_in + ns + n * j] = fabs(v);
+                if (dth) { DTH(o_in + ns + n * j, ke) = dabsd(v) * slope; DTH(o_in + ns + n * j, P - 1) = dabsd(v) * p[ke] * 100.0; }
+            }
         }
     } else if (pmap == PMAP_ROBER) {
         if (has_temp) return -1;
         const double ps = p[P - 1];
         const double slope = fabs(ps);
         const double ln10 = 2.302585092994045684;
-        for (int j = 0; j < nr; ++j) {
-            th[o_b + j] = p[j] * (10.0 * slope);
-            if (dth) { DTH(o_b + j, j) = 10.0 * slope; DTH(o_b + j, P - 1) = p[j] * 10.0 * dabsd(ps); }
-            for (int i = 0; i < ns; ++i) {
+        for (int j = j0; j < nr; j += jstep) {
+            if (i0 == 0) {
+                th[o_b + j] = p[j] * (10.0 * slope);
+                if (dth) { DTH(o_b + j, j) = 10.0 * slope; DTH(o_b + j, P - 1) = p[j] * 10.0 * dabsd(ps); }
+            }
+            for (int i = i0; i < ns; i += istep) {
                 const int ko = nr + i + ns * j;
                 const int ki = nr * (ns + 1) + i + ns * j;
                 const double wi_raw = p[ki], wo_raw = p[ko];
@@ -114,16 +127,18 @@ CRNN_HD inline int p2vec_eval(int pmap, int ns, int nr, int has_temp, const doub
         if (has_temp != 2) return -1;
         const double slope = p[P - 1] * 10.0;
         const double ln10 = 2.302585092994045684;
-        for (int j = 0; j < nr; ++j) {
-            th[o_b + j] = p[j] * slope;
-            th[o_in + (ns + 1) + n * j] = p[nr + j];
-            th[o_in + ns + n * j] = p[2 * nr + j] * slope;
-            if (dth) {
-                DTH(o_b + j, j) = slope; DTH(o_b + j, P - 1) = p[j] * 10.0;
-                DTH(o_in + (ns + 1) + n * j, nr + j) = 1.0;
-                DTH(o_in + ns + n * j, 2 * nr + j) = slope; DTH(o_in + ns + n * j, P - 1) = p[2 * nr + j] * 10.0;
+        for (int j = j0; j < nr; j += jstep) {
+            if (i0 == 0) {
+                th[o_b + j] = p[j] * slope;
+                th[o_in + (ns + 1) + n * j] = p[nr + j];
+                th[o_in + ns + n * j] = p[2 * nr + j] * slope;
+                if (dth) {
+                    DTH(o_b + j, j) = slope; DTH(o_b + j, P - 1) = p[j] * 10.0;
+                    DTH(o_in + (ns + 1) + n * j, nr + j) = 1.0;
+                    DTH(o_in + ns + n * j, 2 * nr + j) = slope; DTH(o_in + ns + n * j, P - 1) = p[2 * nr + j] * 10.0;
+                }
             }
-            for (int i = 0; i < ns; ++i) {
+            for (int i = i0; i < ns; i += istep) {
                 const int ko = 3 * nr + i + ns * j, ki = nr * (ns + 3) + i + ns * j;
                 const double wo_raw = p[ko], wi_raw = p[ki];
                 const double pw = pow(10.0, wo_raw);
