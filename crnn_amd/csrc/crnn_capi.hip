@@ -673,6 +673,18 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
     c->last_npart = npart;
     c->last_P = P;
     c->steps_first = first; c->steps_count = count;     // d_nacc / d_nrej of this range are current once the launch has run
+#ifdef CRNN_ADJ2_PROF
+    if (G == 2) {
+        unsigned long long hp_[16];
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipMemcpyFromSymbol(hp_, HIP_SYMBOL(crnn::g_adj2_prof), sizeof(hp_)));
+        double tot = 0;
+        for (int q = 0; q < 14; ++q) tot += (double)hp_[q];
+        fprintf(stderr, "[adj2_prof] wave 0 ticks %.0f:", tot);
+        for (int q = 0; q < 14; ++q) fprintf(stderr, " %d:%.1f%%", q, 100.0 * (double)hp_[q] / (tot > 0 ? tot : 1));
+        fprintf(stderr, "\n");
+    }
+#endif
 #ifdef CRNN_ADJ_PROF
     {
         unsigned long long hp_[16];

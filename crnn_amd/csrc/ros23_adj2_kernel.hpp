@@ -25,6 +25,19 @@
 #pragma once
 #include "ros23_adj_kernel.hpp"
 
+// phase timing (tools/kvariants.sh build prof2="-DCRNN_ADJ2_PROF=1"; the library prints the shares of wave 0 of block 0 to stderr after
+// every lane-pair launch): s_memtime deltas per phase summed in scalar registers, no fences -- a guide, not the measurement
+#ifdef CRNN_ADJ2_PROF
+namespace crnn { __device__ unsigned long long g_adj2_prof[16]; }
+#if CRNN_ADJ2_PROF == 2   /* with scheduling fences at the phase boundaries: true attribution, slower kernel */
+#define ADJ2_T(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned now_ = (unsigned)__builtin_readcyclecounter(); prof_acc[(k)] += now_ - prof_last; prof_last = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define ADJ2_T(k) do { const unsigned now_ = (unsigned)__builtin_readcyclecounter(); prof_acc[(k)] += now_ - prof_last; prof_last = now_; } while (0)
+#endif
+#else
+#define ADJ2_T(k) do { } while (0)
+#endif
+
 namespace crnn {
 
 // a + (the other lane of the pair's a): one DPP step per 32-bit half; identical bits in both lanes (a+b == b+a)
@@ -43,6 +56,9 @@ __device__ __forceinline__ int pair_and(int a) { return a & __builtin_amdgcn_upd
 // wavefronts per SIMD (CRNN_ADJ2_OCC = 2).  NS even only (no padding slot whose weights would have to read as zero).
 #ifndef CRNN_ADJ2_LEAN
 #define CRNN_ADJ2_LEAN 0
+#endif
+#ifndef CRNN_ADJ2_SEEDS_FLAT
+#define CRNN_ADJ2_SEEDS_FLAT 0   // experiment: branch-free save-point seeds in the reverse sweep (see seed_point)
 #endif
 template <int NS, int NR, bool HAS_T, int BLOCK, int OCC>
 __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParams prm, const double *__restrict__ theta,
@@ -123,8 +139,16 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
     const double dtmax = tend - t0;
     const double lqinit = flog(kc->qoldinit);
     const bool start_saved = (ts0 == t0);
+#if CRNN_ADJ2_SEEDS_FLAT
+    const double ubc = prm.clamp_pred ? kc->ub : __builtin_inf();
+    const bool lk0 = prm.loss_kind == 0;
+#endif
 
     double *const tape = adj.tape + (size_t)((size_t)blockIdx.x * GPB + gib) * adj.tape_cap * RECW;
+#ifdef CRNN_ADJ2_PROF
+    unsigned prof_acc[14] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    unsigned prof_last = (unsigned)__builtin_readcyclecounter();
+#endif
 
     while (true) {
         // ---- next 32 trajectories for this wavefront
@@ -310,6 +334,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
                 if (t + dt * (1.0 + 1e-13) >= tend) { dt = tend - t; last = true; }
                 if (rc < 0 && (!(dt > kc->dtmin) || t + dt == t)) rc = 2;
                 if (rc < 0) {
+                    ADJ2_T(0);   // loop control
                     const double gam = d_ * dt;
                     double gr0[NR];
 #pragma unroll
@@ -319,21 +344,25 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
 #pragma unroll
                     for (int i = 0; i < H; ++i) k1[i] = f0[i];
                     solve(g0, gr0, k1);
+                    ADJ2_T(1);   // factor + solve
                     {
                         double u1[H], x1[H], g1[H], r1[NR];
 #pragma unroll
                         for (int i = 0; i < H; ++i) u1[i] = fma(0.5 * dt, k1[i], u[i]);
                         eval_point(u1, x1, g1, r1, f1);
                     }
+                    ADJ2_T(2);   // evaluation at u_mid
 #pragma unroll
                     for (int i = 0; i < H; ++i) dk[i] = f1[i] - k1[i];
                     solve(g0, gr0, dk);
 #pragma unroll
                     for (int i = 0; i < H; ++i) unew[i] = fma(dt, k1[i] + dk[i], u[i]);
+                    ADJ2_T(3);   // solve
                     {
                         double x2[H];
                         eval_point(unew, x2, g2, r2, f2);
                     }
+                    ADJ2_T(4);   // evaluation at u_new
                     double k3[H];
 #pragma unroll
                     for (int i = 0; i < H; ++i) {
@@ -354,6 +383,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
                     }
                     es = pair_sum(es) * (1.0 / N);
                     finite = pair_and(finite ? 1 : 0) != 0;
+                    ADJ2_T(5);   // solve + error norm
                     if (!finite) rc = 3;
                     else {
                         // PI controller (OrdinaryDiffEq PIController), in log space
@@ -362,6 +392,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
                         const double lq11 = kc->beta1 * lEE;
                         double q = ee_zero ? 1.0 / kc->qmax
                                            : fmax(1.0 / kc->qmax, fmin(1.0 / kc->qmin, exp(lq11 - kc->beta2 * lqold) / kc->gamma));
+                        ADJ2_T(6);   // controller
                         if (es <= 1.0) {
                             if (nacc >= adj.tape_cap) {
                                 rc = 5;  // out of tape: the host re-runs the call with forward tangents
@@ -404,6 +435,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
                                 lqold = ee_zero ? lqinit : fmax(lEE, lqinit);
                                 dt = fmin(dt / q, dtmax);
                                 if (jsave >= nsave) rc = 0;
+                                ADJ2_T(7);   // tape record, save-point loop, FSAL copy
                             }
                         } else {
                             ++nrej;
@@ -471,6 +503,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
                 load_row(jsave - 2, dB);
                 load_row(jsave - 3, dC);
                 load_rec(s - 1);   // prefetch the next record
+                ADJ2_T(8);   // reverse: loop control + prefetches
                 // ---- re-form the step
                 double x0[H], gg0[H], rr0[NR], ff0[H];
                 const double gam = d_ * h;
@@ -492,6 +525,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
                     for (int i = 0; i < H; ++i) dk[i] = f1[i] - k1[i];
                 }
                 solve(gg0, gr0, dk);
+                ADJ2_T(9);   // reverse: re-formation of the step
 
                 // ---- loss and its seeds at the save points inside (tn, tnew]
                 double A_[H], B1[H], B2[H];
@@ -508,6 +542,26 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
                     const double Th = at_end ? 1.0 : (ts - tn) * inv_h;
                     const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
                     const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d_) * inv12d;
+#if CRNN_ADJ2_SEEDS_FLAT
+                    // straight-line: an unobserved (or padding) species is a zero weight, no clamp an infinite clamp, the loss kind a
+                    // select -- this phase is a fifth of the kernel by -DCRNN_ADJ2_PROF=2 (20.3 %, as much as re-forming the step).
+                    // UNMEASURED: written when GPU access closed; same values by construction; default off until timed (kvariants flat="-DCRNN_ADJ2_SEEDS_FLAT=1")
+#pragma unroll
+                    for (int i = 0; i < H; ++i) {
+                        const double k2i = k1[i] + dk[i];
+                        double v = at_end ? fma(h, k2i, un[i]) : fma(h, fma(c1, k1[i], c2 * k2i), un[i]);
+                        const double mask = (v > ubc || v < -ubc) ? 0.0 : 1.0;
+                        v = clampv(v, -ubc, ubc);
+                        const double iy = dro[i] >= 0 ? IYS(i) : 0.0;
+                        const double rr = (dobs[i] - v) * iy;
+                        loss_sum = lk0 ? loss_sum + fabs(rr) : fma(rr, rr, loss_sum);
+                        double w = lk0 ? (signbit(rr) ? 1.0 : -1.0) : -2.0 * rr;
+                        w *= mask * iy;
+                        A_[i] += w;
+                        B1[i] = fma(w, h * c1, B1[i]);
+                        B2[i] = fma(w, h * c2, B2[i]);
+                    }
+#else
 #pragma unroll
                     for (int i = 0; i < H; ++i) {
                         if (dro[i] >= 0) {
@@ -529,6 +583,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
                             B2[i] = fma(w, h * c2, B2[i]);
                         }
                     }
+#endif
                     --jsave;
                 };
                 if (in_step()) {
@@ -546,6 +601,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
                     }
                 }
 
+                ADJ2_T(10);   // reverse: loss + seeds
                 // ---- adjoint of the step (ros23_adj_kernel.hpp, same formulas; sums over species cross the pair once)
                 double kb1[H], v[H], ub[H];
 #pragma unroll
@@ -585,6 +641,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
                     }
                 }
                 solve_Tr(gg0, gr0, kb1);               // kb1 = w = W^-T kb1
+                ADJ2_T(11);   // reverse: two transposed solves + u_mid terms
                 {
                     double s1[H], s2[H];
 #pragma unroll
@@ -627,6 +684,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
                 }
                 tnew = tn;
                 --s;
+                ADJ2_T(12);   // reverse: contraction into the gradient accumulators + lambda
             }
         }
 
@@ -696,7 +754,12 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
             }
             __builtin_amdgcn_wave_barrier();
         }
+        ADJ2_T(13);   // outputs + batch sums (and the next batch's start)
     }
+#ifdef CRNN_ADJ2_PROF
+    if (blockIdx.x == 0 && tid == 0)
+        for (int k = 0; k < 14; ++k) g_adj2_prof[k] = prof_acc[k];
+#endif
 }
 
 #undef ADJ2_THP
