@@ -81,7 +81,7 @@ typedef struct orc_problem {
                                    of forward tangents -- the SAME derivative, the algorithm the GPU runs; CPU-baseline timing
                                    and an independent check of the adjoint formulas (bench.py, tests/test_oracle_golden.py) */
     int32_t jac_fd;             /* 1: Rosenbrock23(autodiff = false) (case2/case2.jl:26): W = I - gam J with J by forward differences of the
-                                   right-hand side (orc_jac_fd); primal solves only (P = 0) */
+                                   right-hand side (orc_jac_fd); forward tangents differentiate through the quotient (orc_jac_fd_dir) */
     double lb, ub;              /* log-clamp window; ub may be +inf */
     double inv_R;               /* -1/R for the Arrhenius row (has_temp) */
     double rate_scale[ORC_MAXN];/* dydt_scale (robertson), else 1 */
@@ -232,6 +232,32 @@ void orc_rhs_jvp(const orc_problem *pb, const double *th, const double *dth,
         out[i] = a * pb->rate_scale[i];
     }
     if (pb->has_temp) out[ns] = 0.0;
+}
+
+/* Directional derivative of the finite-difference Jacobian along (su, dth) -- what ForwardDiff.gradient does to
+   Rosenbrock23(autodiff = false) (case2/case2.jl:26 with :195): the Duals go THROUGH FiniteDiff's quotient.  With x = u + su eps_D,
+   column c = (f(x + e e_c) - f(x)) / e, e = max(rel |x_c|, rel):
+     d column c = [ f'(u + e e_c; su + e' e_c, dth) - f'(u; su, dth) ] / e  -  J_fd[:, c] e' / e,
+   e' = rel sign(u_c) su_c where rel |u_c| > rel (the first argument of max wins: |u_c| > 1), else 0 (the absolute increment is a
+   constant); abs'(0) = +1 as everywhere here.  df0 = f'(u; su, dth) is the tangent the stepper holds.  [UNVERIFIED-DEP] as orc_jac_fd. */
+void orc_jac_fd_dir(const orc_problem *pb, const double *th, const double *dth, const double *u, const double *su,
+                    const double *df0, const double *Jfd, double *dJ) {
+    const int n = N_(pb);
+    const double rel = 1.4901161193847656e-08;
+    double up[ORC_MAXN], sp[ORC_MAXN], dfp[ORC_MAXN];
+    memcpy(up, u, sizeof(double) * n);
+    memcpy(sp, su, sizeof(double) * n);
+    for (int c = 0; c < n; ++c) {
+        const double a = rel * fabs(u[c]);
+        const double eps = fmax(a, rel);
+        const double deps = (a > rel) ? rel * (signbit(u[c]) ? -1.0 : 1.0) * su[c] : 0.0;
+        up[c] = u[c] + eps;
+        sp[c] = su[c] + deps;
+        orc_rhs_jvp(pb, th, dth, up, sp, dfp);
+        for (int i = 0; i < n; ++i) dJ[i + n * c] = (dfp[i] - df0[i]) / eps - Jfd[i + n * c] * (deps / eps);
+        up[c] = u[c];
+        sp[c] = su[c];
+    }
 }
 
 /* Directional derivative of the Jacobian along (su, dth): dJ (n x n). */
@@ -583,7 +609,7 @@ static int solve_one_ws(const orc_problem *pb, const double *th, const double *d
                 const double *dthk = dth + (size_t)nth * k;
                 double *s = S + (size_t)n * k, *a1 = dk1 + (size_t)n * k, *a2 = dk2 + (size_t)n * k, *a3 = dk3 + (size_t)n * k;
                 double *sn = Snew + (size_t)n * k, *b0 = df0 + (size_t)n * k, *b2 = df2 + (size_t)n * k;
-                orc_jac_dir(pb, th, dthk, u, s, dJ);
+                if (pb->jac_fd) orc_jac_fd_dir(pb, th, dthk, u, s, b0, J, dJ); else orc_jac_dir(pb, th, dthk, u, s, dJ);
                 /* W k1' = f0' + gam * dJ k1 */
                 matvec(n, dJ, k1, tmp);
                 for (int i = 0; i < n; ++i) a1[i] = b0[i] + gam * tmp[i];
@@ -1285,7 +1311,8 @@ static int solve_dispatch(const orc_problem *pb, const double *th, const double 
                           const double *u0, const double *tsave, int nsave,
                           const double *data, double *pred, double *dpred,
                           double *loss_out, double *grad, int32_t *n_saved_out, orc_stats *st, double *ws) {
-    if (pb->jac_fd && (P > 0 || pb->solver != 0)) return -7;   /* the finite-difference W exists for plain Rosenbrock23 primal solves */
+    if (pb->jac_fd && pb->solver != 0) return -7;   /* the finite-difference W is restated for plain Rosenbrock23 (primal solves and forward tangents) */
+    if (pb->jac_fd) return solve_one_ws(pb, th, dth, P, u0, tsave, nsave, data, pred, dpred, loss_out, grad, n_saved_out, st, ws);   /* never the analytic-J adjoint */
     if (pb->solver == 2) return solve_one_auto(pb, th, dth, P, u0, tsave, nsave, data, pred, dpred, loss_out, grad, n_saved_out, st, ws, NULL);
     if (pb->solver == 1) return solve_one_tsit5(pb, th, dth, P, u0, tsave, nsave, data, pred, dpred, loss_out, grad, n_saved_out, st, ws);
     if (pb->grad_adjoint && P > 0 && !pb->errnorm_sens && !dpred)
@@ -1301,6 +1328,7 @@ int orc_solve_one_auto(const orc_problem *pb, const double *th, const double *dt
     const int n = N_(pb);
     double *ws = P > 0 ? (double *)malloc(sizeof(double) * ((size_t)n * P * 9 + P)) : NULL;
     if (st_alg) st_alg[0] = st_alg[1] = st_alg[2] = 0;
+    if (pb->jac_fd) { free(ws); return -7; }   /* the composite's stiff branch is restated with the analytic J only */
     int rc = solve_one_auto(pb, th, dth, P, u0, tsave, nsave, data, pred, dpred, loss_out, grad, n_saved_out, st, ws, st_alg);
     free(ws);
     return rc;
