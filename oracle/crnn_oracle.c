@@ -2019,7 +2019,7 @@ typedef struct orc_hychem {
                          (crnn_pyrolysis_mass.jl:29, used :138-139): Tsit5 with stage times t + c_s dt on the T/P tables, the
                          AutoSwitch rule of solve_one_auto, Rosenbrock23 (analytic J: the reference's autodiff=false takes finite
                          differences) as the stiff algorithm; set qsteady_max = 1 with it (a composite is not an implicit type) */
-    int32_t errnorm_sens, dual_partials;   /* errnorm_sens != 0 (Rosenbrock23): the `ndir` directions of a call are ONE ForwardDiff chunk
+    int32_t errnorm_sens, dual_partials;   /* errnorm_sens != 0 (Rosenbrock23, and the AutoTsit5(Rosenbrock23) composite): the `ndir` directions of a call are ONE ForwardDiff chunk
                          (ForwardDiff.gradient(x -> loss_n_ode(x, sample), p), crnn_pyrolysis_mass.jl:201: 211 parameters in chunks of 12)
                          whose partials weigh in the error norm (solve_one_ws has the formula; 1: / length(u), 2: / totallength(u) with
                          dual_partials partials per Dual -- the zero-padded ones of the last chunk count) */
@@ -2175,7 +2175,7 @@ int orc_hychem_solve_one(const orc_hychem *c, const double *th, const double *dt
     const double d = 1.0 / (2.0 + sqrt(2.0)), c32 = 6.0 + sqrt(2.0), h = 1e-30;
     const double t0 = 0.0, tend = ts[D - 1];                          /* tspan = [0, tsteps[sample]], :137 */
     const int sens = (c->errnorm_sens != 0 && ndir > 0);
-    if (sens && c->solver != 0) return -1;                            /* the dual-inclusive norm is restated for Rosenbrock23 */
+    if (sens && c->solver != 0 && c->solver != 2) return -1;          /* the dual-inclusive norm is restated for Rosenbrock23 and for the AutoTsit5(Rosenbrock23) composite */
     const double sens_div = c->errnorm_sens == 2 ? (double)ns * (1.0 + (double)c->dual_partials) : (double)ns;
     cplx *thk = (cplx *)malloc(sizeof(cplx) * (size_t)K * nth);
     cplx *ws = (cplx *)malloc(sizeof(cplx) * (size_t)K * ns * 7);
@@ -2294,7 +2294,23 @@ int orc_hychem_solve_one(const orc_hychem *c, const double *th, const double *dt
                     double s_ = 0.0;
                     for (int i = 0; i < ns; ++i) { double m = fmax(fabs(creal(u[PR * ns + i])), fabs(creal(un[PR * ns + i]))); double e = ev[i] / (c->atol + c->rtol * m); s_ += e * e; }
                     EEst = sqrt(s_ / ns);
-                    if (!(EEst <= 1.0) || ndir == 0) break;
+                    if (!sens && (!(EEst <= 1.0) || ndir == 0)) break;
+                } else if (sens) {   /* the dual-inclusive norm of the Tsit5 attempt: the embedded error estimate's partials are dt sum_j bt_j k_j' */
+                    double ssum = 0.0;
+                    for (int i = 0; i < ns; ++i) {
+                        double na = creal(u[PR * ns + i]) * creal(u[PR * ns + i]), nb = creal(un[PR * ns + i]) * creal(un[PR * ns + i]), ee = ev[i] * ev[i];
+                        for (int k = 0; k < ndir; ++k) {
+                            const double s_ = cimag(u[k * ns + i]) / h, sn_ = cimag(un[k * ns + i]) / h;
+                            cplx a = 0.0;
+                            for (int j = 0; j < 7; ++j) a += TS_BT[j] * KT[((size_t)j * K + k) * ns + i];
+                            const double de = dt * cimag(a) / h;
+                            na += s_ * s_; nb += sn_ * sn_; ee += de * de;
+                        }
+                        const double scl = c->atol + c->rtol * sqrt(fmax(na, nb));
+                        ssum += ee / (scl * scl);
+                    }
+                    EEst = sqrt(ssum / sens_div);
+                    if (!isfinite(EEst)) finite = 0;
                 }
             }
         } else {
