@@ -210,3 +210,48 @@ def test_julia_shim_docstrings_each_have_a_target():
             assert not nxt.startswith('"'), (name, "docstring followed by a string literal", src[m.start():m.start() + 60])
             assert re.match(r"(function|struct|mutable struct|const|module|macro|abstract|@|[A-Za-z_!][\w!.]*\s*(\(|=|::))", nxt), \
                 (name, "docstring without a documentable target", nxt[:60])
+
+
+def test_p2vec_by_species_reaction_pairs_equals_the_serial_map(tmp_path):
+    """crnn_amd/csrc/p2vec.hpp p2vec_eval(..., j0, jstep, i0, istep): on the device nr * ns threads of the fused optimiser launch form
+    theta and d theta / d p of the new p, one (species, reaction) pair each (t / ns, nr, t % ns, ns).  Compiled here for the host:
+    the union of those calls writes exactly what the serial call writes -- every parameter map, bit for bit, nothing twice."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    src = tmp_path / "p2vec_pairs.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "p2vec.hpp"
+using namespace crnn;
+int main() {
+    struct { int pmap, ns, nr, ht; } cases[] = {{PMAP_IDENTITY, 6, 3, 1}, {PMAP_CASE1, 5, 4, 0}, {PMAP_CASE2, 6, 3, 1}, {PMAP_ROBER, 3, 6, 0}, {PMAP_HYCHEM, 9, 10, 2}};
+    for (auto &c : cases) {
+        const int nth = n_theta_of(c.ns, c.nr, c.ht), P = n_params_of(c.pmap, c.ns, c.nr, c.ht);
+        std::vector<double> p(P), th0(nth, -7.0), th1(nth, -7.0), d0((size_t)nth * P, 0.0), d1((size_t)nth * P, 0.0);
+        std::vector<int> writes((size_t)nth * P + nth, 0);
+        unsigned s = 12345u;
+        for (int k = 0; k < P; ++k) { s = s * 1664525u + 1013904223u; p[k] = ((int)(s >> 8) % 2001 - 1000) / 400.0; }
+        if (p2vec_eval(c.pmap, c.ns, c.nr, c.ht, p.data(), th0.data(), d0.data()) != 0) return 2;
+        for (int t = 0; t < c.nr * c.ns; ++t) {
+            std::vector<double> tht(nth, -7.0), dt((size_t)nth * P, -7.0);     // -7: untouched (the device zero-fills before the writers run)
+            if (p2vec_eval(c.pmap, c.ns, c.nr, c.ht, p.data(), tht.data(), dt.data(), t / c.ns, c.nr, t % c.ns, c.ns) != 0) return 3;
+            for (int m = 0; m < nth; ++m) if (tht[m] != -7.0) { th1[m] = tht[m]; ++writes[(size_t)nth * P + m]; }
+            for (size_t m = 0; m < dt.size(); ++m) if (dt[m] != -7.0) { d1[m] = dt[m]; ++writes[m]; }
+        }
+        if (std::memcmp(th0.data(), th1.data(), sizeof(double) * nth) != 0) { std::printf("theta differs, pmap %d\n", c.pmap); return 1; }
+        if (std::memcmp(d0.data(), d1.data(), sizeof(double) * d0.size()) != 0) { std::printf("dtheta differs, pmap %d\n", c.pmap); return 1; }
+        for (size_t m = 0; m < writes.size(); ++m) if (writes[m] > 1) {
+            std::printf("entry %zu written %d times, pmap %d\n", m, writes[m], c.pmap); return 1; }
+    }
+    std::printf("ok\n");
+    return 0;
+}
+''')
+    exe = tmp_path / "p2vec_pairs"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "crnn_amd", "csrc"), str(src), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
