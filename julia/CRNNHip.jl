@@ -389,4 +389,107 @@ function particles(c::Cathode, N::Integer)
     return permutedims(pr)
 end
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# The rest of include/crnn_hip.h: load-time checks of this file's struct mirrors, queries, the two-phase training step for hosts
+# that own their collective (MPI.jl), RCCL teardown, the cathode's particle exchange.  Same status as everything above: not executed.
+
+"""`check_abi()`: refuses a library whose ABI version or struct sizes differ from this file's mirrors (`crnn_abi_version`, `crnn_sizeof`
+for `crnn_config` / `crnn_stats` / `crnn_opt_config` / `crnn_cathode_config`).  Call once after loading; `build_info()` names the sources
+the binary was compiled from (`"src=<16 hex digits> arch=gfx950"`)."""
+function check_abi()
+    v = ccall((:crnn_abi_version, LIB), Int32, ())
+    v == 4 || error("libcrnn_hip.so has ABI version $v, CRNNHip.jl is written against 4")
+    for (which, T) in ((0, Config), (1, Stats), (2, OptConfig), (3, CathodeConfig))
+        n = ccall((:crnn_sizeof, LIB), Int32, (Int32,), Int32(which))
+        n == sizeof(T) || error("sizeof mismatch for $T: library $n, Julia mirror $(sizeof(T))")
+    end
+    return true
+end
+build_info() = unsafe_string(ccall((:crnn_build_info, LIB), Cstring, ()))
+
+"""Lengths of `p` and of the effective weights `theta` for a parameter map (`p2vec`'s input and output, case2/case2.jl:91-99)."""
+n_params(param_map::Integer, ns::Integer, nr::Integer) = Int(ccall((:crnn_n_params, LIB), Int32, (Int32, Int32, Int32), param_map, ns, nr))
+n_theta(ns::Integer, nr::Integer, extra_rows::Integer) = Int(ccall((:crnn_n_theta, LIB), Int32, (Int32, Int32, Int32), ns, nr, extra_rows))
+
+"""`sol.destats` of the most recent ensemble launch, summed over its trajectories (synchronises)."""
+function last_stats(prob::Problem)
+    st = Stats()
+    check(ccall((:crnn_last_stats, LIB), Int32, (Ptr{Cvoid}, Ref{Stats}), prob.ctx, st), prob.ctx)
+    return st
+end
+"""HIP-event durations (ms) of the solve kernel of the last `n <= 64` launches, oldest first (synchronises)."""
+function kernel_times(prob::Problem, n::Integer)
+    ms = zeros(n)
+    check(ccall((:crnn_kernel_times, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int32), prob.ctx, ms, Int32(n)), prob.ctx)
+    return ms
+end
+synchronize(prob::Problem) = check(ccall((:crnn_synchronize, LIB), Int32, (Ptr{Cvoid},), prob.ctx), prob.ctx)
+"""Run all of the context's work on a caller-owned `hipStream_t` (e.g. AMDGPU.jl's stream handle as a `Ptr{Cvoid}`)."""
+set_stream!(prob::Problem, hip_stream::Ptr{Cvoid}) = check(ccall((:crnn_ctx_set_stream, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), prob.ctx, hip_stream), prob.ctx)
+
+"""`set_ensemble_device!(prob, d_u0, d_data, yscale, B)`: as `set_ensemble!`, from buffers already resident on the context's device
+(`d_u0` [n][B], `d_data` [D][n_obs][B], both IC-fastest `Float64`; e.g. `pointer(::ROCArray)`): no PCIe copy."""
+function set_ensemble_device!(prob::Problem, d_u0::Ptr{Cvoid}, d_data::Ptr{Cvoid}, yscale::Vector{Float64}, B::Integer;
+                              i_obs::Union{Nothing,Vector{Int32}}=nothing)
+    nobs = i_obs === nothing ? Int32(prob.cfg.ns) : Int32(length(i_obs))
+    check(ccall((:crnn_ctx_set_data_device, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Int32, Int64),
+                prob.ctx, d_u0, d_data, prob.tsteps, yscale, i_obs === nothing ? C_NULL : i_obs, nobs, Int64(B)), prob.ctx)
+    prob.B = B
+    return prob
+end
+
+"""Overwrite the device-resident parameters of the training loop (`p .= p_new` between `train_step!`s; the optimiser state stays)."""
+set_params!(prob::Problem, p::Vector{Float64}) = check(ccall((:crnn_set_params, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), prob.ctx, p), prob.ctx)
+
+"""The two halves of `train_step!` for a host that runs its own collective between them (MPI.jl: `Allreduce!` on the device vector
+`grad_buffer(prob)` = `[grad_sum(P) | n_overflow | loss_sum, n_ok, n_accept, n_reject, n_traj]`, P + 6 doubles):
+`train_step_begin!(prob, first, count)` launches solve + gradient + reduction, `train_step_end!(prob)` applies `update!` and returns
+the mean loss over all ranks' trajectories."""
+train_step_begin!(prob::Problem, first::Integer=0, count::Integer=prob.B; n_save_active::Integer=length(prob.tsteps)) =
+    check(ccall((:crnn_train_step_begin, LIB), Int32, (Ptr{Cvoid}, Int64, Int64, Int32), prob.ctx, Int64(first), Int64(count), Int32(n_save_active)), prob.ctx)
+function train_step_end!(prob::Problem)
+    loss = Ref(0.0)
+    check(ccall((:crnn_train_step_end, LIB), Int32, (Ptr{Cvoid}, Ref{Float64}), prob.ctx, loss), prob.ctx)
+    return loss[]
+end
+function grad_buffer(prob::Problem)
+    dptr = Ref{Ptr{Cvoid}}(C_NULL); n = Ref{Int32}(0)
+    check(ccall((:crnn_grad_buffer, LIB), Int32, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ref{Int32}), prob.ctx, dptr, n), prob.ctx)
+    return dptr[], Int(n[])
+end
+
+"""RCCL side of a multi-GPU run (one process per GPU): `comm_destroy!` tears the communicator of `comm_init!` down; `comm_collectives`
+is the number of all-reduces the training loop has issued (every rank must report the same number); `allreduce_grad!(prob, buf)` sums
+a host vector in place over the ranks."""
+comm_destroy!(prob::Problem) = check(ccall((:crnn_comm_destroy, LIB), Int32, (Ptr{Cvoid},), prob.ctx), prob.ctx)
+comm_collectives(prob::Problem) = ccall((:crnn_comm_collectives, LIB), Int64, (Ptr{Cvoid},), prob.ctx)
+allreduce_grad!(prob::Problem, buf::Vector{Float64}) =
+    (check(ccall((:crnn_allreduce_grad, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int32), prob.ctx, buf, Int32(length(buf))), prob.ctx); buf)
+
+"""Cathode ensemble over several GPUs (crnn_cathode.jl:31: every rank needs all particles' `lnpgrad` for the SVGD move): the N particles are
+partitioned contiguously over the ranks; `allgather(c, local, n_total)` passes this rank's rows `local` [n_local, width] and returns all
+`n_total` rows (one `ncclAllGather`; without a communicator `n_local == n_total` and the rows are copied)."""
+function cathode_check(c::Cathode, rc)
+    rc == 0 || error(unsafe_string(ccall((:crnn_cathode_last_error, LIB), Cstring, (Ptr{Cvoid},), c.ctx)))
+    return nothing
+end
+comm_init!(c::Cathode, id::Vector{UInt8}, rank::Integer, world::Integer) =
+    cathode_check(c, ccall((:crnn_cathode_comm_init, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Int32, Int32), c.ctx, id, Int32(rank), Int32(world)))
+comm_destroy!(c::Cathode) = cathode_check(c, ccall((:crnn_cathode_comm_destroy, LIB), Int32, (Ptr{Cvoid},), c.ctx))
+function allgather(c::Cathode, local_rows::Matrix{Float64}, n_total::Integer)
+    n_local, width = size(local_rows)
+    lr = permutedims(local_rows)                          # row-major [n_local][width] for the ABI
+    full = zeros(width, n_total)
+    cathode_check(c, ccall((:crnn_cathode_allgather, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int32, Int64, Ptr{Float64}),
+                           c.ctx, lr, Int64(n_local), Int32(width), Int64(n_total), full))
+    return permutedims(full)
+end
+"""`(accepted_1, rejected_1, accepted_2, rejected_2)` of the last `errnorm_sens` gradient call: ForwardDiff's two chunks (9 + 8) are
+separate adaptive solves with their own step counts."""
+function last_chunk_stats(c::Cathode)
+    out = zeros(Int64, 4)
+    cathode_check(c, ccall((:crnn_cathode_last_chunk_stats, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), c.ctx, out))
+    return Tuple(out)
+end
+
 end # module

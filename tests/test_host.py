@@ -255,3 +255,17 @@ int main() {
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "crnn_amd", "csrc"), str(src), "-o", str(exe)])
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
+
+
+def test_julia_shim_binds_every_entry_point():
+    """julia/CRNNHip.jl (written, not executed: no Julia in the image) has a `ccall` for every function include/crnn_hip.h declares, and
+    its ABI check names the version the header defines."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "crnn_hip.h")).read()
+    jl = open(os.path.join(ROOT, "julia", "CRNNHip.jl")).read()
+    syms = sorted(set(re.findall(r"\b(crnn_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(syms) >= 64
+    missing = [s for s in syms if f"(:{s}, LIB)" not in jl]
+    assert not missing, missing
+    abi = int(re.search(r"#define CRNN_ABI_VERSION (\d+)", hdr).group(1))
+    assert f"v == {abi} ||" in jl
