@@ -2023,6 +2023,10 @@ typedef struct orc_hychem {
                          (ForwardDiff.gradient(x -> loss_n_ode(x, sample), p), crnn_pyrolysis_mass.jl:201: 211 parameters in chunks of 12)
                          whose partials weigh in the error norm (solve_one_ws has the formula; 1: / length(u), 2: / totallength(u) with
                          dual_partials partials per Dual -- the zero-padded ones of the last chunk count) */
+    int32_t jac_fd;   /* 1: the stiff algorithm as the reference configures it, Rosenbrock23(autodiff = false) (crnn_pyrolysis_mass.jl:29): J by
+                         FiniteDiff's forward differences of the right-hand side (orc_jac_fd has the increment) AND the time derivative
+                         dT = (f(u, t + e_t) - f(u, t)) / e_t, e_t = max(sqrt(eps) |t|, sqrt(eps)), on the T(t), P(t) tables; primal solves
+                         (ndir = 0) with solver 0 or 2 [UNVERIFIED-DEP] */
     double lb, ub, inv_R, Ru, atol, rtol;
     double mw[12], scale[12], inv_yscale[12];
     double gamma, qmin, qmax, beta1, beta2, qsteady_min, qsteady_max, qoldinit;
@@ -2175,6 +2179,7 @@ int orc_hychem_solve_one(const orc_hychem *c, const double *th, const double *dt
     const double d = 1.0 / (2.0 + sqrt(2.0)), c32 = 6.0 + sqrt(2.0), h = 1e-30;
     const double t0 = 0.0, tend = ts[D - 1];                          /* tspan = [0, tsteps[sample]], :137 */
     const int sens = (c->errnorm_sens != 0 && ndir > 0);
+    if (c->jac_fd && ndir > 0) return -7;                             /* tangents through the finite-difference quotients are not restated here */
     if (sens && c->solver != 0 && c->solver != 2) return -1;          /* the dual-inclusive norm is restated for Rosenbrock23 and for the AutoTsit5(Rosenbrock23) composite */
     const double sens_div = c->errnorm_sens == 2 ? (double)ns * (1.0 + (double)c->dual_partials) : (double)ns;
     cplx *thk = (cplx *)malloc(sizeof(cplx) * (size_t)K * nth);
@@ -2318,6 +2323,24 @@ int orc_hychem_solve_one(const orc_hychem *c, const double *th, const double *dt
         hy_tab(ts, Dfull, Ttab, tm, &Tm, NULL); hy_tab(ts, Dfull, Ptab, tm, &Pm, NULL);
         hy_tab(ts, Dfull, Ttab, tnew, &T2, NULL); hy_tab(ts, Dfull, Ptab, tnew, &P2, NULL);
         hy_eval(c, thk + (size_t)PR * nth, u + PR * ns, Tn, Pn, Tdn, Pdn, fdum, Jk, ftk);
+        double ftfd[12];
+        if (c->jac_fd) {   /* Rosenbrock23(autodiff = false): J and dT by forward differences (FiniteDiff's default increments) */
+            const double rel = 1.4901161193847656e-08;
+            cplx up[12], fp[12];
+            for (int i = 0; i < ns; ++i) up[i] = creal(u[PR * ns + i]);
+            for (int cc = 0; cc < ns; ++cc) {
+                const double uc = creal(u[PR * ns + cc]), eps = fmax(rel * fabs(uc), rel);
+                up[cc] = uc + eps;
+                hy_eval(c, thk + (size_t)PR * nth, up, Tn, Pn, 0, 0, fp, NULL, NULL);
+                for (int i = 0; i < ns; ++i) Jk[i + ns * cc] = (creal(fp[i]) - creal(f0[PR * ns + i])) / eps;
+                up[cc] = uc;
+            }
+            const double et = fmax(rel * fabs(t), rel);
+            double Te, Pe;
+            hy_tab(ts, Dfull, Ttab, t + et, &Te, NULL); hy_tab(ts, Dfull, Ptab, t + et, &Pe, NULL);
+            hy_eval(c, thk + (size_t)PR * nth, up, Te, Pe, 0, 0, fp, NULL, NULL);
+            for (int i = 0; i < ns; ++i) ftfd[i] = (creal(fp[i]) - creal(f0[PR * ns + i])) / et;
+        }
         {   /* eigen_est of the stiff algorithm: opnorm(J, Inf) */
             double est = 0.0;
             for (int i = 0; i < ns; ++i) { double a = 0.0; for (int cc = 0; cc < ns; ++cc) a += fabs(creal(Jk[i + ns * cc])); if (a > est) est = a; }
@@ -2330,7 +2353,8 @@ int orc_hychem_solve_one(const orc_hychem *c, const double *th, const double *dt
                 if (pass == 0 ? (k != PR) : !(k < ndir)) continue;
                 cplx b[12], u1[12], f1[12], tmp[12];
                 const cplx *thc = thk + (size_t)k * nth;
-                hy_eval(c, thc, u + k * ns, Tn, Pn, Tdn, Pdn, fdum, Jk, ftk);
+                if (!c->jac_fd) hy_eval(c, thc, u + k * ns, Tn, Pn, Tdn, Pdn, fdum, Jk, ftk);
+                else for (int i = 0; i < ns; ++i) ftk[i] = ftfd[i];     /* primal only: Jk already holds the difference quotients */
                 for (int i = 0; i < ns; ++i) b[i] = f0[k * ns + i] + gam * ftk[i];
                 if (k != PR) for (int i = 0; i < ns; ++i) for (int cc = 0; cc < ns; ++cc)
                     b[i] += gam * (Jk[i + ns * cc] - creal(Jk[i + ns * cc])) * creal(k1[PR * ns + cc]);

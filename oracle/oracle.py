@@ -337,7 +337,7 @@ def cathode_census(c, theta, beta, ts, D, nthreads=0):
 # ---------------------------------------------------------------------------- HyChem restatement
 class Hychem(C.Structure):
     _fields_ = [("ns", C.c_int32), ("nr", C.c_int32), ("maxiters", C.c_int32), ("solver", C.c_int32),
-                ("errnorm_sens", C.c_int32), ("dual_partials", C.c_int32),
+                ("errnorm_sens", C.c_int32), ("dual_partials", C.c_int32), ("jac_fd", C.c_int32),
                 ("lb", C.c_double), ("ub", C.c_double), ("inv_R", C.c_double), ("Ru", C.c_double),
                 ("atol", C.c_double), ("rtol", C.c_double),
                 ("mw", C.c_double * 12), ("scale", C.c_double * 12), ("inv_yscale", C.c_double * 12),
@@ -351,7 +351,7 @@ def lu_swaps(reset=True):
     return int(lib().orc_lu_swaps(C.c_int(1 if reset else 0)))
 
 
-def make_hychem(dydt_scale=None, yscale=None, atol=None, rtol=None, maxiters=None, solver=0, errnorm_sens=0, dual_partials=12):
+def make_hychem(dydt_scale=None, yscale=None, atol=None, rtol=None, maxiters=None, solver=0, errnorm_sens=0, dual_partials=12, jac_fd=0):
     """solver 0: Rosenbrock23; 2: AutoTsit5(Rosenbrock23(autodiff=false)) -- the reference's `ode_solver` (crnn_pyrolysis_mass.jl:29)."""
     c = Hychem()
     lib().orc_hychem_defaults(C.byref(c))
@@ -369,6 +369,7 @@ def make_hychem(dydt_scale=None, yscale=None, atol=None, rtol=None, maxiters=Non
         c.maxiters = int(maxiters)
     c.solver = int(solver)
     c.errnorm_sens, c.dual_partials = int(errnorm_sens), int(dual_partials)   # the directions of a call = one ForwardDiff chunk
+    c.jac_fd = int(jac_fd)           # Rosenbrock23(autodiff=false): finite-difference J and time derivative (primal solves)
     if solver == 2:
         c.qsteady_max = 1.0          # a composite is not an implicit algorithm type (see solve_one_auto)
     return c
