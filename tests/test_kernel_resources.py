@@ -1,0 +1,61 @@
+"""Register / scratch / LDS budget of the kernels whose speed depends on them, checked at compile time (no GPU: hipcc cross-compiles gfx950
+and reports every kernel's resources with -Rpass-analysis=kernel-resource-usage).  These kernels run one wavefront per SIMD with a full
+register file; a few more live values turn into scratch memory traffic that nothing hides (+40 ... +90 % kernel time), and
+a few more KB of LDS halve the blocks per CU.  Each budget below is what the shipped source compiles to, with the measurement it protects.
+One small translation unit per kernel header (seconds each), the library's flags."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "crnn_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="hipcc not available")
+
+
+def _resources(tmp_path, header, instantiation):
+    src = tmp_path / "tu.hip"
+    src.write_text(f'#include "{header}"\ntemplate __global__ void {instantiation};\n')
+    cmd = [HIPCC if os.path.exists(HIPCC) else "hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=on", "-I", CSRC,
+           "-Rpass-analysis=kernel-resource-usage", "-c", str(src), "-o", str(tmp_path / "tu.o")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    name = instantiation.split("(")[0].split("::")[-1].split("<")[0]
+    blocks = re.split(r"remark: Function Name: ", out.stderr)
+    for b in blocks:
+        if b.startswith("_ZN4crnn") and name in b.split("\n")[0]:
+            g = lambda key: int(re.search(key + r": (\d+)", b).group(1))
+            return dict(vgpr=g(r"VGPRs"), agpr=g(r"AGPRs"), scratch=g(r"ScratchSize \[bytes/lane\]"), lds=g(r"LDS Size \[bytes/block\]"),
+                        occ=g(r"Occupancy \[waves/SIMD\]"))
+    raise AssertionError("kernel not found in the resource report: " + name)
+
+
+ADJ = "const crnn::SolveParams, const double*, const crnn::AdjParams"
+SENS = "const crnn::SolveParams, const double*, const double*"
+
+
+def test_headline_lane_pair_kernel_has_no_scratch_and_fits_two_blocks_of_lds(tmp_path):
+    r = _resources(tmp_path, "ros23_adj2_kernel.hpp", f"crnn::ros23_adj2_kernel<6,3,true,256,1>({ADJ})")
+    assert r["scratch"] == 0 and r["vgpr"] + r["agpr"] <= 512 and r["lds"] <= 81920, r      # 404 registers, 51 KB (profiles/r04g)
+
+
+def test_one_lane_primal_kernels_have_no_scratch(tmp_path):
+    r = _resources(tmp_path, "ros23_adj_kernel.hpp", f"crnn::ros23_adj_kernel<6,3,true,false,256,true,false>({ADJ})")
+    assert r["scratch"] == 0, r
+    r = _resources(tmp_path, "ros23_adj_kernel.hpp", f"crnn::ros23_adj_kernel<6,3,true,false,256,true,true>({ADJ})")     # finite-difference W
+    assert r["scratch"] == 0, r
+
+
+def test_one_lane_gradient_kernel_keeps_its_small_scratch(tmp_path):
+    r = _resources(tmp_path, "ros23_adj_kernel.hpp", f"crnn::ros23_adj_kernel<6,3,true,false,256,false,false>({ADJ})")
+    assert r["scratch"] <= 76 and r["lds"] <= 163840, r       # 76 B per lane since round 2, one block per CU
+
+
+def test_dual_norm_kernel_has_no_scratch_and_two_blocks_per_cu(tmp_path):
+    r = _resources(tmp_path, "ros23_sens_kernel.hpp", f"crnn::ros23_sens_kernel<6,3,true,false,3,3,128,26>({SENS})")
+    # all of d theta / d p staged (26 rows) and still two blocks of 128 per CU: 2 x 79 984 B <= 160 KB; no scratch at 256 + 230 registers
+    assert r["scratch"] == 0 and 2 * r["lds"] <= 163840, r
