@@ -1581,6 +1581,7 @@ static void csolve3(const double *W, const int *piv, cplx *b) {   /* real LU app
 enum { NL_FASTCONV = 2, NL_CONV = 1, NL_DIV = -2, NL_TRYAGAIN = -4 };
 typedef struct cath_nl {
     double J[9], W[9];
+    cplx Jk[17][9];   /* the Jacobian of the tangent copies (theta + i h e_k, u + i h s_k), formed with J and reused with it */
     int piv[3];
     double J_t, W_gdt, eta_old;
     int status, firstcall, new_W;
@@ -1590,6 +1591,21 @@ static void cath_nl_init(cath_nl *nl) {
     memset(nl, 0, sizeof(*nl));
     nl->J_t = NAN; nl->W_gdt = 0.0; nl->eta_old = 1.0; nl->status = NL_DIV; nl->firstcall = 1;
 }
+/* The tangent copies that ride through a nonlinear solve (gradient of the TRBDF2 branch, primal error norm): copy k carries theta + i h e_k
+   and the state's tangent in its imaginary part.  They follow the primal's iteration step for step -- the same W (real: dt, the pivots and every
+   decision are the primal's), the same number of iterations -- with the partial of W moved to the right-hand side as in the Rosenbrock23 branch:
+   (W + i h W') (dz + i h dz') = rhs + i h rhs'  ->  W dz' = rhs' - W' dz,  W' = J' (the imaginary part of the copy's J at (uprev, t_J)).
+   That is ForwardDiff's arithmetic through NLNewton with a Dual-valued W, to first order in h -- EXCEPT that ForwardDiff's convergence
+   tests see the norm of Dual arrays (partials included) and these copies do not enter any test: the primal-norm mode of the other
+   branches (errnorm_sens = 0).  [UNVERIFIED-DEP] like the solver itself. */
+typedef struct cath_cp {
+    const int *act;        /* [17]: copy carried? */
+    cplx (*thk)[17];       /* [18][17] */
+    cplx (*uprev)[3];      /* [18][3] */
+    cplx (*tmp)[3];        /* [18][3] */
+    cplx (*z)[3];          /* [18][3], in/out */
+} cath_cp;
+static void csolve3(const double *W, const int *piv, cplx *b);
 static void cath_jac_real(const orc_cathode *c, const double *th, const double *u, double t, double *J) {
     cplx thc[17], uc[3], Jc[9], ftc[3];
     for (int k = 0; k < 17; ++k) thc[k] = th[k];
@@ -1600,7 +1616,7 @@ static void cath_jac_real(const orc_cathode *c, const double *th, const double *
 /* one nlsolve! call: stage equation z = dt f(tmp + gam z, t + cst dt), z in/out.  Returns 0 (converged) or -1 (step fails). */
 static int cath_trbdf2_nlsolve(const orc_cathode *c, const double *th, cath_nl *nl, const double *uprev, double t, double dt,
                                int integ_iter, double EEst_prev, int isfs, double gam, double cst, const double *tmp, double *z,
-                               double *eigen_est) {
+                               double *eigen_est, const cath_cp *cp) {
     const double kappa = 1.0 / 100.0, gW = gam * dt;
     double eta = nl->eta_old;
     for (int redo = 0; redo < 3; ++redo) {
@@ -1622,6 +1638,7 @@ static int cath_trbdf2_nlsolve(const orc_cathode *c, const double *th, cath_nl *
         }
         if (new_jac) {
             cath_jac_real(c, th, uprev, t, nl->J);
+            if (cp) for (int k = 0; k < 17; ++k) if (cp->act[k]) { cplx ftd[3]; cath_jac_ft(c, cp->thk[k], cp->uprev[k], t, nl->Jk[k], ftd); }
             nl->J_t = t; nl->n_jac++;
             double est = 0.0;   /* calc_J! of a composite: eigen_est = opnorm(J, Inf) */
             for (int i = 0; i < 3; ++i) { double a = 0.0; for (int cc = 0; cc < 3; ++cc) a += fabs(nl->J[i + 3 * cc]); if (a > est) est = a; }
@@ -1646,6 +1663,17 @@ static int cath_trbdf2_nlsolve(const orc_cathode *c, const double *th, cath_nl *
             for (int i = 0; i < 3; ++i) dz[i] = (dt * f[i] - z[i]) * inv_gdt;
             lu_solve(3, nl->W, nl->piv, dz);
             nl->n_newton++;
+            cplx dzk[17][3];
+            if (cp) for (int k = 0; k < 17; ++k) if (cp->act[k]) {
+                cplx us[3], fk[3];
+                for (int i = 0; i < 3; ++i) us[i] = cp->tmp[k][i] + gam * cp->z[k][i];
+                cath_rhs(c, cp->thk[k], us, tstep, fk);
+                for (int i = 0; i < 3; ++i) {
+                    dzk[k][i] = (dt * fk[i] - cp->z[k][i]) * inv_gdt;
+                    for (int cc = 0; cc < 3; ++cc) dzk[k][i] -= (nl->Jk[k][i + 3 * cc] - creal(nl->Jk[k][i + 3 * cc])) * dz[cc];
+                }
+                csolve3(nl->W, nl->piv, dzk[k]);
+            }
             double s_ = 0.0;
             for (int i = 0; i < 3; ++i) { const double e = dz[i] / (c->atol + c->rtol * fmax(fabs(uprev[i]), fabs(ustep[i]))); s_ += e * e; }
             ndzprev = ndz; ndz = sqrt(s_ / 3.0);
@@ -1661,6 +1689,7 @@ static int cath_trbdf2_nlsolve(const orc_cathode *c, const double *th, cath_nl *
                 if (theta > 2.0) { nl->status = NL_DIV; break; }
             }
             for (int i = 0; i < 3; ++i) z[i] = zt[i];   /* apply_step! */
+            if (cp) for (int k = 0; k < 17; ++k) if (cp->act[k]) for (int i = 0; i < 3; ++i) cp->z[k][i] -= dzk[k][i];
             if (it > 1) eta = theta / (1.0 - theta);
             if ((it == 1 && ndz < 1e-5) || (it > 1 && eta >= 0.0 && eta * ndz < kappa)) { nl->status = NL_CONV; break; }
         }
@@ -1687,9 +1716,10 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
     const double d = 1.0 / (2.0 + sqrt(2.0)), c32 = 6.0 + sqrt(2.0), h = 1e-30;
     const int P = grad ? 17 : 0;
     const int composite = (c->solver == 2 || c->solver == 3), trbdf2 = (c->solver == 3 || c->solver == 4);
-    if (trbdf2 && grad) return -1;   /* TRBDF2 is restated for primal solves only */
     const int sens = (c->errnorm_sens != 0 && grad != NULL);
-    if (sens && (c->solver != 0 || c->dir_n < 1 || c->dir_lo < 0 || c->dir_lo + c->dir_n > 17)) return -1;   /* Rosenbrock23 only */
+    /* errnorm_sens: every algorithm's error estimate carries the chunk's partials (Tsit5: dt sum_j bt_j k_j'; TRBDF2: the smoothed estimate's
+       partial W^-1 (tmp' - J' est)); TRBDF2's Newton convergence tests stay on the primal (cath_cp) */
+    if (sens && (c->dir_n < 1 || c->dir_lo < 0 || c->dir_lo + c->dir_n > 17)) return -1;
 #define ACT(k) ((k) < P && (!sens || ((k) >= c->dir_lo && (k) < c->dir_lo + c->dir_n)))
     const double sens_div = c->errnorm_sens == 2 ? 3.0 * (1.0 + (double)c->dual_partials) : 3.0;
     const double t0 = ts[0], tend = ts[D - 1];
@@ -1765,7 +1795,7 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
             else if (alg == 1 && cnt < -AS_MAXNONSTIFF) {
                 dt /= AS_DTFAC; alg = 0;
                 /* initialize!(Tsit5 cache): fsalfirst = f(uprev, t) afresh -- TRBDF2 left z/dt there, not a function value */
-                if (trbdf2) cath_rhs(c, thk[PR], u[PR], t, f0[PR]);
+                if (trbdf2) for (int k = 0; k <= 17; ++k) if (k == PR || ACT(k)) cath_rhs(c, thk[k], u[k], t, f0[k]);
             }
         }
         int last = 0;
@@ -1814,7 +1844,23 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
                     double s_ = 0.0;
                     for (int i = 0; i < 3; ++i) { double m = fmax(fabs(creal(u[PR][i])), fabs(creal(un[PR][i]))); double e = ev[i] / (c->atol + c->rtol * m); s_ += e * e; }
                     EEst = sqrt(s_ / 3.0);
-                    if (!(EEst <= 1.0) || P == 0) break;
+                    if (!sens && (!(EEst <= 1.0) || P == 0)) break;
+                } else if (sens) {   /* the dual-inclusive norm of the Tsit5 attempt (partials with respect to p_k = theta_k / dir_scale[k]) */
+                    double ssum = 0.0;
+                    for (int i = 0; i < 3; ++i) {
+                        double na = creal(u[PR][i]) * creal(u[PR][i]), nb = creal(un[PR][i]) * creal(un[PR][i]), ee = ev[i] * ev[i];
+                        for (int k = 0; k < 17; ++k) if (ACT(k)) {
+                            const double sc = c->dir_scale[k] / h;
+                            cplx a = 0.0;
+                            for (int j = 0; j < 7; ++j) a += TS_BT[j] * KT[j][k][i];
+                            const double s_ = sc * cimag(u[k][i]), sn_ = sc * cimag(un[k][i]), de = sc * dt * cimag(a);
+                            na += s_ * s_; nb += sn_ * sn_; ee += de * de;
+                        }
+                        const double scl = c->atol + c->rtol * sqrt(fmax(na, nb));
+                        ssum += ee / (scl * scl);
+                    }
+                    EEst = sqrt(ssum / sens_div);
+                    if (!isfinite(EEst)) finite = 0;
                 }
             }
         } else if (trbdf2) {
@@ -1822,15 +1868,24 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
             const double s2 = sqrt(2.0), tg = 2.0 - s2, dd = 1.0 - s2 / 2.0, om = s2 / 4.0;
             const double bt1 = (1.0 - s2) / 3.0, bt2 = 1.0 / 3.0, bt3 = (s2 - 2.0) / 3.0, al1 = -s2 / 2.0, al2 = 1.0 + s2 / 2.0;
             double up[3], zp[3], tmp[3];
+            cplx zpk[18][3], zgk[18][3], zk[18][3], tmpk[18][3];
+            int actv[17];
+            for (int k = 0; k < 17; ++k) actv[k] = ACT(k) ? 1 : 0;
+            cath_cp cpy = { actv, thk, u, tmpk, zgk };
+            const cath_cp *cp = P > 0 ? &cpy : NULL;
             for (int i = 0; i < 3; ++i) { up[i] = creal(u[PR][i]); zp[i] = dt * creal(f0[PR][i]); }
             for (int i = 0; i < 3; ++i) { zg_[i] = zp[i]; tmp[i] = up[i] + dd * zp[i]; }
-            stepfail = cath_trbdf2_nlsolve(c, th, &nl, up, t, dt, iter, EEst_prev, 1, dd, tg, tmp, zg_, &eigen_est) != 0;
+            if (cp) for (int k = 0; k < 17; ++k) if (actv[k]) for (int i = 0; i < 3; ++i) { zpk[k][i] = dt * f0[k][i]; zgk[k][i] = zpk[k][i]; tmpk[k][i] = u[k][i] + dd * zpk[k][i]; }
+            stepfail = cath_trbdf2_nlsolve(c, th, &nl, up, t, dt, iter, EEst_prev, 1, dd, tg, tmp, zg_, &eigen_est, cp) != 0;
             if (!stepfail) {
                 for (int i = 0; i < 3; ++i) { z_[i] = al1 * zp[i] + al2 * zg_[i]; tmp[i] = up[i] + om * zp[i] + om * zg_[i]; }
-                stepfail = cath_trbdf2_nlsolve(c, th, &nl, up, t, dt, iter, EEst_prev, 0, dd, 1.0, tmp, z_, &eigen_est) != 0;
+                if (cp) for (int k = 0; k < 17; ++k) if (actv[k]) for (int i = 0; i < 3; ++i) { zk[k][i] = al1 * zpk[k][i] + al2 * zgk[k][i]; tmpk[k][i] = u[k][i] + om * zpk[k][i] + om * zgk[k][i]; }
+                cpy.z = zk;
+                stepfail = cath_trbdf2_nlsolve(c, th, &nl, up, t, dt, iter, EEst_prev, 0, dd, 1.0, tmp, z_, &eigen_est, cp) != 0;
             }
             if (!stepfail) {
                 double est[3], s_ = 0.0;
+                if (cp) for (int k = 0; k < 17; ++k) if (actv[k]) for (int i = 0; i < 3; ++i) { un[k][i] = tmpk[k][i] + dd * zk[k][i]; f2[k][i] = zk[k][i] / dt; }
                 for (int i = 0; i < 3; ++i) {
                     un[PR][i] = tmp[i] + dd * z_[i];
                     f2[PR][i] = z_[i] / dt;                      /* fsallast = z ./ dt */
@@ -1846,6 +1901,28 @@ int orc_cathode_solve_one(const orc_cathode *c, const double *th, const double *
                     s_ += e * e;
                 }
                 EEst = sqrt(s_ / 3.0);
+                if (sens) {   /* the smoothed estimate's partials: est_k = W^-1 (tmp_k - J_k' est), then the dual-inclusive norm */
+                    double ssum = 0.0, na[3], nb[3], ee[3];
+                    for (int i = 0; i < 3; ++i) { na[i] = up[i] * up[i]; nb[i] = creal(un[PR][i]) * creal(un[PR][i]); ee[i] = ev[i] * ev[i]; }
+                    for (int k = 0; k < 17; ++k) if (actv[k]) {
+                        cplx ek[3];
+                        /* ev = W \ tmp, or that divided by W_gdt (trbdf2_est = 1): J' multiplies the unscaled solution */
+                        for (int i = 0; i < 3; ++i) {
+                            ek[i] = bt1 * zpk[k][i] + bt2 * zgk[k][i] + bt3 * zk[k][i];
+                            for (int cc = 0; cc < 3; ++cc) ek[i] -= (nl.Jk[k][i + 3 * cc] - creal(nl.Jk[k][i + 3 * cc])) * (c->trbdf2_est == 1 ? ev[cc] * nl.W_gdt : ev[cc]);
+                        }
+                        csolve3(nl.W, nl.piv, ek);
+                        const double sc = c->dir_scale[k] / h;
+                        for (int i = 0; i < 3; ++i) {
+                            const double de = sc * cimag(ek[i]) / (c->trbdf2_est == 1 ? nl.W_gdt : 1.0);
+                            const double s_ = sc * cimag(u[k][i]), sn_ = sc * cimag(un[k][i]);
+                            na[i] += s_ * s_; nb[i] += sn_ * sn_; ee[i] += de * de;
+                        }
+                    }
+                    for (int i = 0; i < 3; ++i) { const double scl = c->atol + c->rtol * sqrt(fmax(na[i], nb[i])); ssum += ee[i] / (scl * scl); }
+                    EEst = sqrt(ssum / sens_div);
+                    if (!isfinite(EEst)) finite = 0;
+                }
             }
         } else {
         cath_jac_ft(c, thk[PR], u[PR], t, Jc, ftc);

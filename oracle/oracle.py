@@ -268,7 +268,9 @@ class Cathode(C.Structure):
 
 def make_cathode(beta, atol=1e-12, rtol=1e-3, maxiters=2500000, lb_clamp=1e-16, solver=0, trbdf2_est=0):
     """solver 0: Rosenbrock23; 2: AutoTsit5 composite (Tsit5 + stiffness switch) with Rosenbrock23 as the stiff algorithm;
-    3: AutoTsit5(TRBDF2(autodiff=true)) -- the reference's algorithm (network.jl:195), primal only; 4: TRBDF2 alone.
+    3: AutoTsit5(TRBDF2(autodiff=true)) -- the reference's algorithm (network.jl:195); 4: TRBDF2 alone.  Gradients: tangent copies through
+    the Newton iteration (cath_cp); through a composite only with errnorm_sens (cathode_sens_chunks) -- with the primal norm the Tsit5
+    branch's tangents grow without bound.
     trbdf2_est: 0 = smoothed estimate `W \\ tmp` with the Newton iteration's W (default), 1 = Shampine's (I - gamma dt J)^-1 tmp."""
     c = Cathode()
     lib().orc_cathode_defaults(C.byref(c))
