@@ -50,6 +50,15 @@
  * kernels run -- with dense matrices; the two agree to 1e-15 of max |grad|
  * (tests/test_oracle_golden.py) and bench.py times both as the CPU baseline.
  *
+ * Restated here and NOT on the device (end of round 4; "oracle first": the checkers of kernels that do not exist yet, and the
+ * measurement of what the device's choices leave out -- INTEGRATION.md quotes the numbers):
+ *   - Rosenbrock23(autodiff = false): J by FiniteDiff's forward differences (orc_jac_fd; the device offers it for primal launches)
+ *     and ForwardDiff's derivative THROUGH the difference quotients (orc_jac_fd_dir); HyChem's finite-difference J and time
+ *     derivative on the T(t), P(t) tables (orc_hychem.jac_fd, primal solves);
+ *   - the gradient of configs 4 and 5 as the reference really evaluates it -- ForwardDiff's chunks through the AutoTsit5 composite with
+ *     the chunk's partials in the error estimate of every algorithm: HyChem solver 2 with errnorm_sens; cathode solver 2 / 3 with
+ *     errnorm_sens, including tangent copies through TRBDF2's Newton iteration (cath_cp).
+ *
  * Layout conventions (identical to the C ABI in include/crnn_hip.h):
  *   theta = [ w_in (n x nr, column-major) | w_b (nr) | w_out (ns x nr, col-major) ]
  *   n = ns + has_temp; state u = [species..., T]
