@@ -2237,6 +2237,92 @@ static void hy_eval(const orc_hychem *c, const cplx *th, const cplx *u, double T
     (void)om;
 }
 
+/* Closed-form tangents of the HyChem right-hand side in REAL arithmetic -- the formulas a hand-written dual-norm kernel would carry instead of
+   nested dual numbers (hychem_sens_kernel.hpp evaluates the right-hand side over Du<Du<double>>: 5.2 KB of scratch per lane), checked against
+   the complex-step evaluation above (tests/test_hychem.py).  For a direction (su, dth) at the point (u, T, P, Td, Pd):
+     fp    = f'(u; su, dth)                                     (first-order tangent)
+     mixed = d/d(su, dth) [ J(u) v + tau ft(u) ]                (the stage equations' W' = -gam J' and d_t f' terms; v, tau held fixed)
+   With Y = clamp(u), S = sum Y_i / M_i, L = log rho = log P - log(Ru T S), x_m = log clamp(1e3 rho Y_m / M_m), a_m / cY_m the clamp
+   indicators, sY = cY su:   L' = -S'/S;  x_m' = a_m (L' + sY_m / Y_m);  z_j' = dwb_j + sum_m dwi_mj x_m + wi_mj x_m';  r_j' = r_j z_j';
+     f_i = K_i om_i / rho,  om_i = sum_j wo_ij r_j:      f_i' = K_i / rho (sum_j dwo_ij r_j + wo_ij r_j') - f_i L'
+     (J v)_i = K_i / rho A_i - f_i Lv,  Lv = -sum_c cY_c v_c / (M_c S),  A_i = sum_j wo_ij r_j zv_j,  zv_j = sum_m wi_mj xv_m,
+               xv_m = a_m (Lv + cY_m v_m / Y_m):         Lv' = Lv L';  xv_m' = a_m (Lv L' - v_m sY_m / Y_m^2);
+               (J v)_i' = K_i / rho (A_i' - A_i L') - f_i' Lv - f_i Lv'
+     ft_i = K_i / rho B_i - f_i ld,  ld = Pd/P - Td/T,  B_i = sum_j wo_ij r_j zt_j,  zt_j = wi_Ej e1 + wi_Lj e2 + ld sum_m wi_mj a_m:
+               ft_i' = K_i / rho (B_i' - B_i L') - f_i' ld   (e1 = -inv_R Td / T^2, e2 = Td / T; the indicators are piecewise constant) */
+void orc_hychem_tangents(const orc_hychem *c, const double *th, const double *dth, const double *u, const double *su, const double *v,
+                         double tau, double T, double P, double Td, double Pd, double *fp, double *mixed) {
+    const int ns = c->ns, nr = c->nr, n = ns + 2;
+    const double *wi = th, *wb = th + n * nr, *wo = th + (n + 1) * nr;
+    const double *dwi = dth, *dwb = dth + n * nr, *dwo = dth + (n + 1) * nr;
+    double Y[12], cY[12], a[12], x[14], xp[12], xv[12], xvp[12], sY[12];
+    double S = 0.0, Sp = 0.0, Sv = 0.0;
+    for (int i = 0; i < ns; ++i) {
+        cY[i] = (u[i] >= c->lb && u[i] <= c->ub) ? 1.0 : 0.0;
+        Y[i] = u[i] < c->lb ? c->lb : (u[i] > c->ub ? c->ub : u[i]);
+        sY[i] = cY[i] * su[i];
+        S += Y[i] / c->mw[i]; Sp += sY[i] / c->mw[i]; Sv += cY[i] * v[i] / c->mw[i];
+    }
+    const double rho = P / (c->Ru * T * S), Lp = -Sp / S, Lv = -Sv / S, Lvp = Lv * Lp;
+    for (int m = 0; m < ns; ++m) {
+        const double C = rho * (Y[m] / c->mw[m]) * 1e3;
+        a[m] = (C >= c->lb && C <= c->ub) ? 1.0 : 0.0;
+        x[m] = log(C < c->lb ? c->lb : (C > c->ub ? c->ub : C));
+        xp[m] = a[m] * (Lp + sY[m] / Y[m]);
+        xv[m] = a[m] * (Lv + cY[m] * v[m] / Y[m]);
+        xvp[m] = a[m] * (Lvp - v[m] * sY[m] / (Y[m] * Y[m]));
+    }
+    x[ns] = c->inv_R / T; x[ns + 1] = log(T);
+    const double ld = Pd / P - Td / T, e1 = -c->inv_R * Td / (T * T), e2 = Td / T;
+    double r[16], rp[16], zv[16], zvp[16], zt[16], ztp[16];
+    for (int j = 0; j < nr; ++j) {
+        double z = wb[j], zp = dwb[j], sa = 0.0, dsa = 0.0;
+        zv[j] = 0.0; zvp[j] = 0.0;
+        for (int m = 0; m < n; ++m) { z += wi[m + n * j] * x[m]; zp += dwi[m + n * j] * x[m]; }
+        for (int m = 0; m < ns; ++m) {
+            zp += wi[m + n * j] * xp[m];
+            zv[j] += wi[m + n * j] * xv[m];
+            zvp[j] += dwi[m + n * j] * xv[m] + wi[m + n * j] * xvp[m];
+            sa += wi[m + n * j] * a[m]; dsa += dwi[m + n * j] * a[m];
+        }
+        r[j] = exp(z); rp[j] = r[j] * zp;
+        zt[j] = wi[ns + n * j] * e1 + wi[ns + 1 + n * j] * e2 + ld * sa;
+        ztp[j] = dwi[ns + n * j] * e1 + dwi[ns + 1 + n * j] * e2 + ld * dsa;
+    }
+    for (int i = 0; i < ns; ++i) {
+        double om = 0.0, omp = 0.0, A = 0.0, Ap = 0.0, B = 0.0, Bp = 0.0;
+        for (int j = 0; j < nr; ++j) {
+            const double w = wo[i + ns * j], dw = dwo[i + ns * j];
+            om += w * r[j]; omp += dw * r[j] + w * rp[j];
+            A += w * r[j] * zv[j]; Ap += dw * r[j] * zv[j] + w * (rp[j] * zv[j] + r[j] * zvp[j]);
+            B += w * r[j] * zt[j]; Bp += dw * r[j] * zt[j] + w * (rp[j] * zt[j] + r[j] * ztp[j]);
+        }
+        const double K = c->mw[i] * c->scale[i] / rho;
+        const double f = K * om, fpi = K * omp - f * Lp;
+        fp[i] = fpi;
+        const double Jvp = K * (Ap - A * Lp) - fpi * Lv - f * Lvp;
+        const double ftp = K * (Bp - B * Lp) - fpi * ld;
+        mixed[i] = Jvp + tau * ftp;
+    }
+}
+
+/* the same two quantities by the complex step through hy_eval (the arithmetic the solver's tangents use) */
+void orc_hychem_tangents_cs(const orc_hychem *c, const double *th, const double *dth, const double *u, const double *su, const double *v,
+                            double tau, double T, double P, double Td, double Pd, double *fp, double *mixed) {
+    const int ns = c->ns, nth = c->nr * (2 * ns + 3);
+    const double h = 1e-30;
+    cplx thc[256], uc[12] = {0}, fc[12], Jc[144], ftc[12];
+    for (int m = 0; m < nth; ++m) thc[m] = th[m] + I * h * dth[m];
+    for (int i = 0; i < ns; ++i) uc[i] = u[i] + I * h * su[i];
+    hy_eval(c, thc, uc, T, P, Td, Pd, fc, Jc, ftc);
+    for (int i = 0; i < ns; ++i) {
+        cplx jv = 0.0;
+        for (int cc = 0; cc < ns; ++cc) jv += Jc[i + ns * cc] * v[cc];
+        fp[i] = cimag(fc[i]) / h;
+        mixed[i] = cimag(jv) / h + tau * cimag(ftc[i]) / h;
+    }
+}
+
 void orc_hychem_rhs(const orc_hychem *c, const double *th, const double *u, double T, double P, double Td, double Pd,
                     double *f, double *J, double *ft) {
     const int ns = c->ns, nth = c->nr * (2 * ns + 3);
