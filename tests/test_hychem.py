@@ -400,6 +400,71 @@ def test_hychem_closed_form_tangents_equal_the_complex_step(orc, hfx):
         assert np.max(np.abs(out[1] - out[3])) <= 1e-12 * np.max(np.abs(out[3]))
 
 
+def test_column_loop_tangent_header_equals_the_complex_step(orc, hfx, tmp_path):
+    """crnn_amd/csrc/hychem_tan.hpp: the closed forms split by what they depend on (point / primal direction / column / both), one
+    source for host and device; here the host build, ns = 9, nr = 10, against the oracle's complex step (f', (J v + tau f_t)') and its
+    right-hand side (f, J v, f_t) on the inputs of the test above, three directions v sharing one point and one column."""
+    import ctypes as C
+    import os
+    import subprocess
+    src = tmp_path / "hy_tan_host.cpp"
+    src.write_text(r'''
+#include "hychem_tan.hpp"
+using namespace crnn;
+extern "C" void hy_tan_host(const double *th, const double *dth, const double *cst, const double *imw, const double *gsc, const double *u,
+                            const double *s, const double *v3, const double *tau3, const double *tp, double *f, double *ft, double *fp,
+                            double *Jv3, double *mixed3) {
+    HyTanConst k{cst[0], cst[1], cst[2], cst[3], imw, gsc};
+    HyTanPt<9, 10> pt;
+    HyTanCol<9, 10> c;
+    hy_tan_point<9, 10>(th, k, u, tp[0], tp[1], tp[2], tp[3], pt);
+    hy_tan_col<9, 10>(th, dth, pt, k, s, c);
+    for (int i = 0; i < 9; ++i) { f[i] = pt.f[i]; ft[i] = pt.ft[i]; fp[i] = c.fp[i]; }
+    for (int q = 0; q < 3; ++q) {
+        HyTanV<9, 10> pv;
+        hy_tan_v<9, 10>(th, pt, k, v3 + 9 * q, pv);
+        hy_tan_mixed<9, 10>(th, dth, pt, pv, c, v3 + 9 * q, mixed3 + 9 * q);
+        for (int i = 0; i < 9; ++i) { Jv3[9 * q + i] = pv.Jv[i]; mixed3[9 * q + i] += tau3[q] * c.ftp[i]; }
+    }
+}
+''')
+    so = tmp_path / "hy_tan_host.so"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "crnn_amd", "csrc")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-I", inc, str(src), "-o", str(so)], check=True)
+    H = C.CDLL(str(so))
+    th, dth = orc.hychem_p2vec(hfx["p"])
+    c = _oracle_cfg(orc, hfx)
+    L = orc.lib()
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    mw, sc = np.array(c.mw[:9]), np.array(c.scale[:9])
+    cst, imw, gsc = np.array([c.lb, c.ub, c.inv_R, c.Ru]), 1.0 / mw, mw * sc
+    rng = np.random.default_rng(2)
+    taus = np.array([1.0, 0.0, 1.0 / 0.29289321881345248])
+    for trial in range(40):
+        b = trial % 3
+        u = np.abs(hfx["u0"][b] * (1 + 0.3 * rng.standard_normal(9))) + 1e-6 * rng.random(9)
+        if trial % 4 == 0:
+            u[rng.integers(9)] = 1e-9
+        s, v3 = rng.standard_normal(9), rng.standard_normal((3, 9))
+        d = np.ascontiguousarray(dth[rng.integers(211)]) if trial % 2 else np.ascontiguousarray(rng.standard_normal(th.size))
+        T, P, Td, Pd = float(hfx["Ttab"][b][3]), float(hfx["Ptab"][b][3]), 50.0, -3.0e3
+        f, ft, fp, Jv3, mx3 = np.zeros(9), np.zeros(9), np.zeros(9), np.zeros((3, 9)), np.zeros((3, 9))
+        H.hy_tan_host(dp(th), dp(d), dp(cst), dp(imw), dp(gsc), dp(u), dp(s), dp(v3), dp(taus), dp(np.array([T, P, Td, Pd])),
+                      dp(f), dp(ft), dp(fp), dp(Jv3), dp(mx3))
+        fo, Jo, fto = np.zeros(9), np.zeros(81), np.zeros(9)
+        L.orc_hychem_rhs(C.byref(c), dp(th), dp(u), C.c_double(T), C.c_double(P), C.c_double(Td), C.c_double(Pd), dp(fo), dp(Jo), dp(fto))
+        Jm = Jo.reshape(9, 9).T                                   # column-major J[i + ns c]
+        rel = lambda x, y: np.max(np.abs(x - y)) / np.max(np.abs(y))
+        assert rel(f, fo) < 1e-13 and rel(ft, fto) < 1e-12
+        for q in range(3):
+            assert rel(Jv3[q], Jm @ v3[q]) < 1e-12
+            o1, o2 = np.zeros(9), np.zeros(9)
+            L.orc_hychem_tangents_cs(C.byref(c), dp(th), dp(d), dp(u), dp(s), dp(np.ascontiguousarray(v3[q])), C.c_double(taus[q]),
+                                     C.c_double(T), C.c_double(P), C.c_double(Td), C.c_double(Pd), dp(o1), dp(o2))
+            assert rel(fp, o1) < 1e-12
+            assert rel(mx3[q], o2) < 1e-12
+
+
 def test_hychem_oracle_gradient_through_the_reference_composite(orc, hfx):
     """The reference's config-4 gradient as it is really evaluated (crnn_pyrolysis_mass.jl:201 through :29): ForwardDiff's chunks of 12
     through AutoTsit5(Rosenbrock23) with the chunk's partials in the error norm of BOTH algorithms (oracle: solver = 2 with
