@@ -23,6 +23,15 @@
 // parity with the reference's step sequences, not for speed (bench.py reports it).
 #pragma once
 #include "hychem_kernel.hpp"
+#include "hychem_tan.hpp"
+
+// 1: the column's tangents by hychem_tan.hpp's closed forms (one point shared by the three mixed derivatives of a step) instead of hy_f
+// over nested duals.  Written at the end of round 4 WITHOUT device access: the arithmetic is pinned on the host (tests/test_hychem.py),
+// the kernel with the switch on has only been compiled (register report below) -- off until the errnorm tests and tools/hy_sens_time.py
+// have run on it.
+#ifndef CRNN_HY_SENS_CLOSED
+#define CRNN_HY_SENS_CLOSED 0
+#endif
 
 namespace crnn {
 
@@ -303,21 +312,72 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens_kernel(const SolveParams pr
             double k1p[NS], k2p[NS], snew[NS], f2p[NS];
             {
                 double mx[NS], s1[NS], f1p[NS], dkp[NS], k3p[NS];
+#if CRNN_HY_SENS_CLOSED
+                const HyTanConst tk{kc->lb, kc->ub, hp.inv_R, kc->Ru, kc->imw, kc->gsc};
+                HyTanPt<NS, NR> pt;
+                HyTanCol<NS, NR> cl;
+                // a HyTanPt from the primal evaluation the attempt already holds (no logarithm or exponential is taken twice)
+                auto from_point = [&](const HyPoint<NS, NR> &pp, HyTanPt<NS, NR> &pq) {
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        pq.q[i] = ((pp.cY >> i) & 1u) ? frcp(pp.Y[i]) : 0.0;
+                        pq.a[i] = ((pp.cC >> i) & 1u) ? 1.0 : 0.0;
+                        pq.f[i] = pp.f[i];
+                        pq.K[i] = kc->gsc[i] * pp.irho;
+                    }
+#pragma unroll
+                    for (int m = 0; m < NS + 2; ++m) pq.x[m] = pp.x[m];
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) { pq.r[j] = pp.r[j]; pq.zt[j] = 0.0; }
+                    pq.iS = pp.iS;
+                    pq.ld = pq.e1 = pq.e2 = 0.0;
+                };
+                from_point(p0, pt);
+                hy_tan_time<NS, NR>(th, tk, T, P, Td, Pd, pt);
+                hy_tan_col<NS, NR>(th, dthc, pt, tk, s, cl);
+                auto jvp_c = [&](const HyPoint<NS, NR> &pp, const double (&ss)[NS], double (&fp)[NS]) {
+                    HyTanPt<NS, NR> pq;
+                    HyTanCol<NS, NR> cq;
+                    from_point(pp, pq);
+                    hy_tan_col<NS, NR>(th, dthc, pq, tk, ss, cq);       // its time part is dead code here
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) fp[i] = cq.fp[i];
+                };
+                auto mixed_c = [&](const double (&v)[NS], const double tau, double (&out)[NS]) {
+                    HyTanV<NS, NR> pv;
+                    hy_tan_v<NS, NR>(th, pt, tk, v, pv);
+                    hy_tan_mixed<NS, NR>(th, dthc, pt, pv, cl, v, out);
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) out[i] = fma(tau, cl.ftp[i], out[i]);
+                };
+                mixed_c(k1, 1.0, mx);                                           // J' k1 + ft'
+#else
                 mixed(u, s, k1, 1.0, T, P, Td, Pd, mx);                         // J' k1 + ft'
+#endif
 #pragma unroll
                 for (int i = 0; i < NS; ++i) k1p[i] = fma(gam, mx[i], f0p[i]);
                 lu_solve_lds<NS, BLOCK>(As, dinv, piv, wp, k1p);
 #pragma unroll
                 for (int i = 0; i < NS; ++i) s1[i] = fma(0.5 * dt, k1p[i], s[i]);
+#if CRNN_HY_SENS_CLOSED
+                jvp_c(p1, s1, f1p);
+                mixed_c(dk, 0.0, mx);                                           // J' (k2 - k1)
+#else
                 jvp(u1, s1, T1, P1, f1p);
                 mixed(u, s, dk, 0.0, T, P, Td, Pd, mx);                         // J' (k2 - k1)
+#endif
 #pragma unroll
                 for (int i = 0; i < NS; ++i) dkp[i] = fma(gam, mx[i], f1p[i] - k1p[i]);
                 lu_solve_lds<NS, BLOCK>(As, dinv, piv, wp, dkp);
 #pragma unroll
                 for (int i = 0; i < NS; ++i) { k2p[i] = k1p[i] + dkp[i]; snew[i] = fma(dt, k2p[i], s[i]); }
+#if CRNN_HY_SENS_CLOSED
+                jvp_c(p2, snew, f2p);
+                mixed_c(k3, 1.0 / d_, mx);                                      // J' k3 + (dt / gam) ft'
+#else
                 jvp(unew, snew, T2, P2, f2p);
                 mixed(u, s, k3, 1.0 / d_, T, P, Td, Pd, mx);                    // J' k3 + (dt / gam) ft'
+#endif
 #pragma unroll
                 for (int i = 0; i < NS; ++i) k3p[i] = fma(gam, mx[i], f2p[i] - c32 * (k2p[i] - f1p[i]) - 2.0 * (k1p[i] - f0p[i]));
                 lu_solve_lds<NS, BLOCK>(As, dinv, piv, wp, k3p);

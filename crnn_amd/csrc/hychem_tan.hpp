@@ -10,7 +10,7 @@
 //   f'  = d/dε f(u + ε s; θ + ε dθ)                         at three points of a step
 //   (J v + τ ∂ₜf)' = d/dε [J(u + ε s; θ + ε dθ) v + τ ∂ₜ f(…)]   at the step's first point, for v = k1, k2 - k1, k3
 // Three levels, by what they depend on:
-//   HyTanPt   point (u, T, P, Ṫ, Ṗ) and θ            once per trajectory and point   hy_tan_point
+//   HyTanPt   point (u, T, P, Ṫ, Ṗ) and θ            once per trajectory and point   hy_tan_point (= primal part + hy_tan_time)
 //   HyTanV    + a primal direction v                   once per trajectory and v       hy_tan_v
 //   HyTanCol  + a column (s, dθ): f', ∂ₜf'             once per column and point       hy_tan_col
 //   mixed     + both                                   once per column and v           hy_tan_mixed
@@ -26,10 +26,12 @@
 
 // On the device every weight is an LDS read; fully unrolled, the scheduler hoists the reads of all reactions to the top of a phase and
 // the live set explodes (tools/ubench/hy_tan_probe.hip).  HYT_STEP closes one reaction's / one species' reads before the next one's.
+#if !defined(HYT_STEP)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define HYT_STEP asm volatile("" ::: "memory")
 #else
 #define HYT_STEP (void)0
+#endif
 #endif
 
 namespace crnn {
@@ -81,6 +83,28 @@ struct HyTanCol {
     double ftp[NS];      // (∂ₜ f)'
 };
 
+// the time part of a point whose q, a, x, r, f, K, iS are filled (by hy_tan_point, or from a primal evaluation the caller holds)
+template <int NS, int NR>
+CRNN_HD inline void hy_tan_time(const double *th, const HyTanConst &k, const double T, const double P, const double Td, const double Pd,
+                                HyTanPt<NS, NR> &pt) {
+    using L_ = HyTanLay<NS, NR>;
+    pt.ld = Pd / P - Td / T;
+    pt.e1 = -k.inv_R * Td / (T * T);
+    pt.e2 = Td / T;
+    for (int j = 0; j < NR; ++j) {
+        HYT_STEP;
+        double sa = 0.0;
+        for (int m = 0; m < NS; ++m) sa += th[L_::wi(m, j)] * pt.a[m];
+        pt.zt[j] = th[L_::wi(NS, j)] * pt.e1 + th[L_::wi(NS + 1, j)] * pt.e2 + pt.ld * sa;
+    }
+    for (int i = 0; i < NS; ++i) {
+        HYT_STEP;
+        double B = 0.0;
+        for (int j = 0; j < NR; ++j) B += th[L_::wo(i, j)] * pt.r[j] * pt.zt[j];
+        pt.ft[i] = pt.K[i] * B - pt.f[i] * pt.ld;
+    }
+}
+
 template <int NS, int NR>
 CRNN_HD inline void hy_tan_point(const double *th, const HyTanConst &k, const double *u, const double T, const double P, const double Td,
                                  const double Pd, HyTanPt<NS, NR> &pt) {
@@ -101,29 +125,20 @@ CRNN_HD inline void hy_tan_point(const double *th, const HyTanConst &k, const do
     }
     pt.x[NS] = k.inv_R / T;
     pt.x[NS + 1] = log(T);
-    pt.ld = Pd / P - Td / T;
-    pt.e1 = -k.inv_R * Td / (T * T);
-    pt.e2 = Td / T;
     for (int j = 0; j < NR; ++j) {
         HYT_STEP;
-        double z = th[L_::wb(j)], sa = 0.0;
+        double z = th[L_::wb(j)];
         for (int m = 0; m < NS + 2; ++m) z += th[L_::wi(m, j)] * pt.x[m];
-        for (int m = 0; m < NS; ++m) sa += th[L_::wi(m, j)] * pt.a[m];
         pt.r[j] = exp(z);
-        pt.zt[j] = th[L_::wi(NS, j)] * pt.e1 + th[L_::wi(NS + 1, j)] * pt.e2 + pt.ld * sa;
     }
     for (int i = 0; i < NS; ++i) {
         HYT_STEP;
-        double om = 0.0, B = 0.0;
-        for (int j = 0; j < NR; ++j) {
-            const double wr = th[L_::wo(i, j)] * pt.r[j];
-            om += wr;
-            B += wr * pt.zt[j];
-        }
+        double om = 0.0;
+        for (int j = 0; j < NR; ++j) om += th[L_::wo(i, j)] * pt.r[j];
         pt.K[i] = k.gsc[i] * irho;
         pt.f[i] = pt.K[i] * om;
-        pt.ft[i] = pt.K[i] * B - pt.f[i] * pt.ld;
     }
+    hy_tan_time<NS, NR>(th, k, T, P, Td, Pd, pt);
 }
 
 // J v at the point (the primal Rosenbrock stages need it anyway) and what the mixed derivative reuses of it

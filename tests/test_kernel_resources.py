@@ -17,11 +17,11 @@ HIPCC = "/opt/rocm/bin/hipcc"
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="hipcc not available")
 
 
-def _resources(tmp_path, header, instantiation):
+def _resources(tmp_path, header, instantiation, flags=()):
     src = tmp_path / "tu.hip"
     src.write_text(f'#include "{header}"\ntemplate __global__ void {instantiation};\n')
     cmd = [HIPCC if os.path.exists(HIPCC) else "hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=on", "-I", CSRC,
-           "-Rpass-analysis=kernel-resource-usage", "-c", str(src), "-o", str(tmp_path / "tu.o")]
+           *flags, "-Rpass-analysis=kernel-resource-usage", "-c", str(src), "-o", str(tmp_path / "tu.o")]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     name = instantiation.split("(")[0].split("::")[-1].split("<")[0]
@@ -59,3 +59,14 @@ def test_dual_norm_kernel_has_no_scratch_and_two_blocks_per_cu(tmp_path):
     r = _resources(tmp_path, "ros23_sens_kernel.hpp", f"crnn::ros23_sens_kernel<6,3,true,false,3,3,128,26>({SENS})")
     # all of d theta / d p staged (26 rows) and still two blocks of 128 per CU: 2 x 79 984 B <= 160 KB; no scratch at 256 + 230 registers
     assert r["scratch"] == 0 and 2 * r["lds"] <= 163840, r
+
+
+def test_hychem_dual_norm_kernel_scratch_and_its_closed_form_variant(tmp_path):
+    """hychem_sens_kernel spills 5.2 KB per lane (the kernel next in line).  The variant behind
+    -DCRNN_HY_SENS_CLOSED=1 (hychem_tan.hpp's closed forms on the primal evaluations the attempt already holds) must keep compiling and
+    keep its smaller footprint until a round with a device measures it."""
+    HY = "const crnn::SolveParams, const double*, const crnn::HyParams, const crnn::HySensParams"
+    base = _resources(tmp_path, "hychem_sens_kernel.hpp", f"crnn::hychem_sens_kernel<9,10,128>({HY})")
+    closed = _resources(tmp_path, "hychem_sens_kernel.hpp", f"crnn::hychem_sens_kernel<9,10,128>({HY})", flags=("-DCRNN_HY_SENS_CLOSED=1",))
+    assert base["scratch"] <= 5400 and base["lds"] <= 163840, base
+    assert closed["scratch"] <= 3700 and closed["scratch"] < base["scratch"], (base, closed)
