@@ -32,6 +32,14 @@
 #ifndef CRNN_HY_SENS_CLOSED
 #define CRNN_HY_SENS_CLOSED 0
 #endif
+// 1: ONE copy of W's factors per trajectory instead of one per lane.  The twelve lanes of a group factor the same W (same primal
+// state, same instructions, same bits) and park 81 doubles each: 83 KB of the block's 108 KB of LDS, which is why a CU holds one block
+// of 128 -- two wavefronts, two of its four SIMDs.  With the copy shared (the lanes store identical values to one address; reads are
+// broadcasts within a group and consecutive doubles across the five groups of a wavefront) a block needs 31 KB and two blocks fit
+// (registers: one wavefront per SIMD either way).  Same status as the switch above: compiled, not run.
+#ifndef CRNN_HY_SENS_SHARED_LU
+#define CRNN_HY_SENS_SHARED_LU 0
+#endif
 
 namespace crnn {
 
@@ -129,7 +137,12 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens_kernel(const SolveParams pr
     __shared__ double ts_lds[kMaxSave];
     __shared__ double th_lds[NTH];
     __shared__ double dth_lds[C * NTH];
-    __shared__ double lu_lds[NS * NS * BLOCK];  // W's factors of every lane (hychem_kernel.hpp's layout)
+#if CRNN_HY_SENS_SHARED_LU
+    constexpr int LUS = (BLOCK / 64) * GPW;     // W's factors of every trajectory: element e of group g at lu_lds[e * LUS + g]
+#else
+    constexpr int LUS = BLOCK;                  // W's factors of every lane (hychem_kernel.hpp's layout)
+#endif
+    __shared__ double lu_lds[NS * NS * LUS];
     const int tid = threadIdx.x;
     for (int idx = tid; idx < kNConst; idx += BLOCK) kc_lds[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
     for (int idx = tid; idx < hp.n_save_total; idx += BLOCK) ts_lds[idx] = prm.tsave[idx];
@@ -147,7 +160,11 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens_kernel(const SolveParams pr
     const bool lane_on = grp < GPW;
     const int gbase = grp * C;                  // first lane of the group within the wavefront
     const double *const dthc = dth_lds + (lane_on ? col : 0) * NTH;
+#if CRNN_HY_SENS_SHARED_LU
+    double *const As = lu_lds + (tid >> 6) * GPW + (lane_on ? grp : 0);
+#else
     double *const As = lu_lds + tid;
+#endif
     const int64_t groups_total = (int64_t)(gridDim.x / nch) * (BLOCK / 64) * GPW;      // groups working on this block's chunk
     int64_t traj = ((int64_t)(blockIdx.x / nch) * (BLOCK / 64) + (tid >> 6)) * GPW + grp;
     if (!lane_on) traj = prm.count;             // the idle lanes never start a trajectory
@@ -283,12 +300,12 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens_kernel(const SolveParams pr
             int piv[NS];
             bool anyp;
             hy_jac_ft<NS, NR, BLOCK>(th, kc, p0, gam, Pd * frcp(P) - Td * frcp(T), -hp.inv_R * Td * frcp(T * T), Td * frcp(T), A, ft);
-            const bool okf = lu_factor_to_lds<NS, BLOCK>(A, As, dinv, piv, anyp);
+            const bool okf = lu_factor_to_lds<NS, LUS>(A, As, dinv, piv, anyp);
             const bool wp = __builtin_amdgcn_ballot_w64(anyp) != 0;
             double k1[NS], dk[NS], k3[NS], u1[NS], unew[NS], f1[NS];
 #pragma unroll
             for (int i = 0; i < NS; ++i) k1[i] = fma(gam, ft[i], f0[i]);
-            lu_solve_lds<NS, BLOCK>(As, dinv, piv, wp, k1);
+            lu_solve_lds<NS, LUS>(As, dinv, piv, wp, k1);
 #pragma unroll
             for (int i = 0; i < NS; ++i) u1[i] = fma(0.5 * dt, k1[i], u[i]);
             HyPoint<NS, NR> p1, p2;
@@ -297,7 +314,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens_kernel(const SolveParams pr
             hy_point<NS, NR>(th, kc, hp.inv_R, u1, T1, P1, p1);
 #pragma unroll
             for (int i = 0; i < NS; ++i) { f1[i] = p1.f[i]; dk[i] = f1[i] - k1[i]; }
-            lu_solve_lds<NS, BLOCK>(As, dinv, piv, wp, dk);
+            lu_solve_lds<NS, LUS>(As, dinv, piv, wp, dk);
 #pragma unroll
             for (int i = 0; i < NS; ++i) unew[i] = fma(dt, k1[i] + dk[i], u[i]);
             tab(tnew, T2, P2, a_, b_);
@@ -307,7 +324,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens_kernel(const SolveParams pr
                 const double k2i = k1[i] + dk[i];
                 k3[i] = fma(dt, ft[i], p2.f[i] - c32 * (k2i - f1[i]) - 2.0 * (k1[i] - f0[i]));
             }
-            lu_solve_lds<NS, BLOCK>(As, dinv, piv, wp, k3);
+            lu_solve_lds<NS, LUS>(As, dinv, piv, wp, k3);
             // ---- this lane's column through the attempt
             double k1p[NS], k2p[NS], snew[NS], f2p[NS];
             {
@@ -356,7 +373,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens_kernel(const SolveParams pr
 #endif
 #pragma unroll
                 for (int i = 0; i < NS; ++i) k1p[i] = fma(gam, mx[i], f0p[i]);
-                lu_solve_lds<NS, BLOCK>(As, dinv, piv, wp, k1p);
+                lu_solve_lds<NS, LUS>(As, dinv, piv, wp, k1p);
 #pragma unroll
                 for (int i = 0; i < NS; ++i) s1[i] = fma(0.5 * dt, k1p[i], s[i]);
 #if CRNN_HY_SENS_CLOSED
@@ -368,7 +385,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens_kernel(const SolveParams pr
 #endif
 #pragma unroll
                 for (int i = 0; i < NS; ++i) dkp[i] = fma(gam, mx[i], f1p[i] - k1p[i]);
-                lu_solve_lds<NS, BLOCK>(As, dinv, piv, wp, dkp);
+                lu_solve_lds<NS, LUS>(As, dinv, piv, wp, dkp);
 #pragma unroll
                 for (int i = 0; i < NS; ++i) { k2p[i] = k1p[i] + dkp[i]; snew[i] = fma(dt, k2p[i], s[i]); }
 #if CRNN_HY_SENS_CLOSED
@@ -380,7 +397,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens_kernel(const SolveParams pr
 #endif
 #pragma unroll
                 for (int i = 0; i < NS; ++i) k3p[i] = fma(gam, mx[i], f2p[i] - c32 * (k2p[i] - f1p[i]) - 2.0 * (k1p[i] - f0p[i]));
-                lu_solve_lds<NS, BLOCK>(As, dinv, piv, wp, k3p);
+                lu_solve_lds<NS, LUS>(As, dinv, piv, wp, k3p);
                 // the dual-inclusive norm: value and the group's partials per component
                 double es = 0.0;
                 bool fin = okf;

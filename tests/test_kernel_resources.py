@@ -70,3 +70,7 @@ def test_hychem_dual_norm_kernel_scratch_and_its_closed_form_variant(tmp_path):
     closed = _resources(tmp_path, "hychem_sens_kernel.hpp", f"crnn::hychem_sens_kernel<9,10,128>({HY})", flags=("-DCRNN_HY_SENS_CLOSED=1",))
     assert base["scratch"] <= 5400 and base["lds"] <= 163840, base
     assert closed["scratch"] <= 3700 and closed["scratch"] < base["scratch"], (base, closed)
+    # -DCRNN_HY_SENS_SHARED_LU=1: W's factors once per trajectory -> two blocks of 128 per CU (four wavefronts instead of two)
+    both = _resources(tmp_path, "hychem_sens_kernel.hpp", f"crnn::hychem_sens_kernel<9,10,128>({HY})",
+                      flags=("-DCRNN_HY_SENS_CLOSED=1", "-DCRNN_HY_SENS_SHARED_LU=1"))
+    assert 2 * both["lds"] <= 163840 and both["scratch"] <= 3700, both
