@@ -22,6 +22,7 @@
 #include "hychem2_kernel.hpp"
 #include "hychem_auto_kernel.hpp"
 #include "hychem_sens_kernel.hpp"
+#include "hychem_sens2_kernel.hpp"
 #include "tsit5_kernel.hpp"
 #include "auto_adj_kernel.hpp"
 #include "ros23_adj2_kernel.hpp"
@@ -195,6 +196,9 @@ struct Ctx {
     int lanes_per_traj = 0;         // crnn_ctx_set_lanes_per_traj: 0 = AUTO, 1, 2
     int jac_mode = CRNN_JAC_ANALYTIC;   // crnn_ctx_set_jacobian: W of the Rosenbrock23 primal launches
     int hysens_occ = 0;
+    int hysens2_occ = 0;
+    bool hy_dirs_sparse = false;   // the directions of the launch being prepared fit hychem_sens2_kernel's sparse description (set by the entry points)
+    int hy_sens_kernel = 0;        // 0: the sparse-direction kernel where the directions fit; 1: always hychem_sens_kernel (measurement / parity: CRNN_HY_SENS_KERNEL)
     int64_t hy_tape_retries = 0;    // HyChem launches repeated with fewer resident trajectories after a tape overflow
     int last_lanes = 0;             // lanes per trajectory of the most recent adjoint launch (0: another kernel family ran)
     // deferred outcome of adjoint training steps (crnn_train_step): see check_pending
@@ -913,23 +917,37 @@ int32_t launch_sens_chunk(Ctx *c, const KernelEntry *k, const double *d_theta, c
     return 0;
 }
 
+// The rows of d theta / d p that p2vec_kernel writes: for the HyChem map (crnn_pyrolysis_mass.jl:78-90) and the identity every row has at
+// most one entry in w_in's species / log T rows and one in w_out (hychem_sens2_kernel.hpp's description of a direction)
+static bool pmap_dirs_sparse(const Ctx *c) {
+    return c->hychem && (c->cfg.param_map == CRNN_PMAP_HYCHEM || c->cfg.param_map == CRNN_PMAP_IDENTITY);
+}
+
 // HyChem: one ForwardDiff chunk of <= 12 directions, a group of twelve lanes per trajectory (hychem_sens_kernel.hpp); the same
 // per-trajectory gradient rows and fixed-order reduction as launch_sens_chunk.
 int32_t launch_hychem_sens_chunk(Ctx *c, const double *d_theta, const double *d_dtheta, int P, int64_t first, int64_t count,
                                  int n_save_active, bool want_pred, int dual_partials, int n_chunks = 1) {
     if (c->cfg.ns != 9 || c->cfg.nr != 10) return fail(c, "crnn_solve: the HyChem kernel is instantiated for ns = 9, nr = 10");
     if (!c->d_tabs || c->tabs_B != c->B) return fail(c, "crnn_solve: HyChem needs T/P tables (crnn_ctx_set_tables after crnn_ctx_set_data)");
-    constexpr int kC = 12, kBlk = 128, kGroups = (kBlk / 64) * (64 / kC);
+    // two kernels, one result: hychem_sens2_kernel (sparse directions, closed-form tangents, six lanes per trajectory with two columns
+    // each) wherever every direction of the launch fits its description -- the rows of p2vec's Jacobian always do --, hychem_sens_kernel
+    // (dense directions through nested duals, twelve lanes per trajectory) for arbitrary directions
+    const bool sparse = c->hy_dirs_sparse && c->hy_sens_kernel != 1;
+    constexpr int kC = 12;
+    constexpr int kL2 = 6, kBlk2 = 256, kGroups2 = (kBlk2 / 64) * (64 / kL2);
+    constexpr int kBlk1 = 128, kGroups1 = (kBlk1 / 64) * (64 / kC);
+    const int kBlk = sparse ? kBlk2 : kBlk1, kGroups = sparse ? kGroups2 : kGroups1;
     const int ppad = n_chunks > 1 ? P : kC;      // gradient row: the chunk's 12 columns | all chunks in one launch: compact [P]
     const int npart_pad = ppad + crnn::kExtra, npart = P + crnn::kTail;
     using SFn = void (*)(const crnn::SolveParams, const double *, const crnn::HyParams, const crnn::HySensParams);
-    const SFn fn = (SFn)crnn::hychem_sens_kernel<9, 10, kBlk>;
-    if (c->hysens_occ < 1) {
-        HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->hysens_occ, (const void *)fn, kBlk, 0));
-        if (c->hysens_occ < 1) c->hysens_occ = 1;
+    const SFn fn = sparse ? (SFn)crnn::hychem_sens2_kernel<9, 10, kL2, kBlk2> : (SFn)crnn::hychem_sens_kernel<9, 10, kBlk1>;
+    int &occ = sparse ? c->hysens2_occ : c->hysens_occ;
+    if (occ < 1) {
+        HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, kBlk, 0));
+        if (occ < 1) occ = 1;
     }
     const int nch = std::max(1, n_chunks);
-    const int nblk = nch * (int)std::max<int64_t>(1, std::min<int64_t>((count + kGroups - 1) / kGroups, std::max<int64_t>(1, (int64_t)c->num_cu * c->hysens_occ / nch)));
+    const int nblk = nch * (int)std::max<int64_t>(1, std::min<int64_t>((count + kGroups - 1) / kGroups, std::max<int64_t>(1, (int64_t)c->num_cu * occ / nch)));
     const int rblk = (int)((count + 255) / 256);
     if (ensure(c, &c->d_partials, &c->partials_cap, (size_t)rblk * npart_pad)) return -1;
     if (ensure(c, &c->d_gtraj, &c->gtraj_cap, (size_t)count * ppad)) return -1;
@@ -944,6 +962,8 @@ int32_t launch_hychem_sens_chunk(Ctx *c, const double *d_theta, const double *d_
     fill_params(c, prm, P, first, count, n_save_active, want_pred);
     crnn::HyParams hp{};
     hp.tabs = c->d_tabs; hp.n_save_total = c->cfg.n_save; hp.inv_R = c->cfg.inv_R;
+    // batches in the order of the last plain solve's step counts (launch_sens_chunk does the same; only hychem_sens2_kernel reads it)
+    hp.perm = (c->queue_order == CRNN_QUEUE_AUTO && c->perm_ready && c->perm_first == first && c->perm_count == count) ? c->d_perm : nullptr;
     crnn::HySensParams sp{};
     sp.dth = d_dtheta; sp.n_dir = P; sp.mode = c->cfg.errnorm_sens; sp.dual_partials = dual_partials;
     sp.n_chunks = n_chunks; sp.n_total = P;
@@ -1409,6 +1429,7 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
     c->use_scale = false;
     for (int i = 0; i < cfg->ns; ++i) if (cfg->rate_scale[i] != 1.0) c->use_scale = true;
     if (const char *e = getenv("CRNN_SENS_ONE_LAUNCH")) { if (*e) c->sens_one_launch = atoi(e) != 0; }   // measurement override
+    if (const char *e = getenv("CRNN_HY_SENS_KERNEL")) { if (*e) c->hy_sens_kernel = atoi(e); }          // 1: hychem_sens_kernel for every direction set
     // robertson-shaped problems always take the scaled kernel (one instantiation per shape)
     auto has_kernel = [&]() { return c->cfg.solver == CRNN_SOLVER_AUTOTSIT5 ? find_adjoint(c) != nullptr : find_primal(c) != nullptr; };
     if (!c->hychem && !has_kernel()) { c->use_scale = !c->use_scale; if (!has_kernel()) c->use_scale = !c->use_scale; }
@@ -1630,6 +1651,12 @@ int32_t crnn_solve(crnn_ctx *ctx, const double *theta, const double *dtheta, int
     if (n_dir > 0)
         HIP_TRY(c, hipMemcpyAsync(c->d_dtheta, dtheta, sizeof(double) * (size_t)c->n_theta * n_dir, hipMemcpyHostToDevice,
                                   c->stream));
+    c->hy_dirs_sparse = false;
+    if (c->hychem && c->cfg.errnorm_sens && n_dir > 0 && c->cfg.ns == 9 && c->cfg.nr == 10) {   // the caller's rows: do they fit the sparse description?
+        bool fits = true;
+        for (int k = 0; k < n_dir && fits; ++k) fits = crnn::hy_dir_fits<9, 10>(dtheta + (size_t)k * c->n_theta);
+        c->hy_dirs_sparse = fits;
+    }
     if (launch_solve(c, c->d_theta, c->d_dtheta, n_dir, first, count, n_save_active, pred != nullptr, true)) return -1;
     std::vector<double> red(c->last_npart);
     HIP_TRY(c, hipMemcpyAsync(red.data(), c->d_red, sizeof(double) * c->last_npart, hipMemcpyDeviceToHost, c->stream));
@@ -1661,6 +1688,7 @@ int32_t crnn_loss_grad(crnn_ctx *ctx, const double *p, int64_t first, int64_t co
     hipLaunchKernelGGL(p2vec_kernel, dim3(1), dim3(256), 0, c->stream, c->cfg.param_map, c->cfg.ns, c->cfg.nr,
                        c->nfx, c->d_p_eval, c->d_theta, c->d_dtheta, c->n_theta, c->n_params);
     HIP_TRY(c, hipGetLastError());
+    c->hy_dirs_sparse = pmap_dirs_sparse(c);
     if (launch_solve(c, c->d_theta, c->d_dtheta, P, first, count, n_save_active, false, false)) return -1;
     std::vector<double> red(c->last_npart);
     HIP_TRY(c, hipMemcpyAsync(red.data(), c->d_red, sizeof(double) * c->last_npart, hipMemcpyDeviceToHost, c->stream));
@@ -1725,6 +1753,7 @@ static int32_t train_begin_impl(Ctx *c, int64_t first, int64_t count, int32_t n_
     }
     c->theta_current = false;   // consumed: anything else that touches d_theta / d_p must not find a stale flag
     c->defer_next = defer;
+    c->hy_dirs_sparse = pmap_dirs_sparse(c);
     const int32_t rc = launch_solve(c, c->d_theta, c->d_dtheta, c->n_params, first, count, n_save_active, false, false);
     c->defer_next = false;
     return rc;

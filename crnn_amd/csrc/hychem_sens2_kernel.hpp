@@ -1,0 +1,835 @@
+// crnn_amd/csrc/hychem_sens2_kernel.hpp -- gfx950 (MI355X): the HyChem gradient as the reference evaluates it, built for speed.
+//
+// Reference: HyChem/crnn_pyrolysis_mass.jl:201  grad = ForwardDiff.gradient(x -> loss_n_ode(x, sample), p) through :29's stiff solver:
+// eighteen chunks of twelve partials, every chunk its own adaptive Rosenbrock23 solve whose error norm weighs the chunk's partials
+// with the value (hychem_sens_kernel.hpp has the first, nested-dual statement of the same thing: twelve lanes per trajectory, the
+// primal twelve times, 5.2 KB of scratch per lane, 2 000 trajectories+gradients/s).  This kernel computes the same numbers from
+// three observations:
+//
+//  1. THE DIRECTIONS ARE SPARSE.  p2vec (:78-90) maps p_k onto at most one entry of w_in's species / log T rows and one of w_out, both of
+//     ONE reaction -- except the slope p[end] (all of w_b and of the Ea row) and the w_b / Ea parameters themselves (one entry of those).
+//     A column is therefore described by cb[NR] (d w_b), ce[NR] (d Ea row), one (m, j, value) of w_in and one (i, j, value) of w_out.
+//     With that d theta never meets a 210-term contraction: the theta-part of f' is O(nr) per column instead of O(ns nr).  A block builds
+//     its chunk's descriptors from the dense rows it is given; a row that does not fit (arbitrary user directions through crnn_solve) is
+//     the host's to detect -- it launches hychem_sens_kernel for those (crnn_capi.hip: hy_dir_fits).
+//  2. TANGENTS IN CLOSED FORM, ONE SWEEP OVER THETA PER POINT.  hychem_tan.hpp's split by dependence (point / primal direction / column /
+//     both); everything that does not depend on the column (features, rates, the masked column sums B_j, the three primal directions'
+//     z_v and A_v, the time direction) is formed ONCE per trajectory and attempt and parked in the group's LDS record; a column's three
+//     mixed derivatives J'[s, dtheta] k1, J'(k2 - k1), J' k3 and (d_t f)' share one pass over w_in and w_out at the step's first point
+//     (all primal stages are known before the column phase starts), and the lane's columns share the passes at the other two points
+//     and the reads of W's factors in the stage solves.
+//  3. A GROUP OF L LANES PER TRAJECTORY, 12 / L COLUMNS PER LANE.  The primal runs redundantly in the group's lanes (identical
+//     operations, identical bits: the group never diverges), but its by-products are shared: ONE copy of W's factors and of the point
+//     records per trajectory in LDS (written by the group's first lane, read by all as broadcasts), the four direction records
+//     (k1, k2 - k1, k3, time) formed by four different lanes of the group -- same code, other data.  A column's state (s, f0') lives in
+//     registers; the attempt's candidates (s_new, f2') too, so a rejected attempt costs nothing to undo; its gradient increments at the
+//     save points inside the step are formed before the decision (the save points of an attempt follow from t and dt) and added on accept.
+//
+// The norm, the controller, the initial step, the dense output and every formula of the primal are hychem_sens_kernel's (and the oracle's
+// orc_hychem errnorm modes, oracle/crnn_oracle.c): same step sequences, gradient pieces to rounding (tests/test_hychem.py).
+// Work distribution: a wavefront takes GPW = 64 / L consecutive entries of the (step-count sorted) queue at a time and runs them to the end
+// under one wave-uniform loop (no per-lane refills: the persistent-lane experiment of DESIGN appendix A); block b works on chunk
+// b % n_chunks as in hychem_sens_kernel.
+#pragma once
+#include "hychem_sens_kernel.hpp"
+
+namespace crnn {
+
+// group-wide ordering of LDS traffic: the lanes of a group run in lockstep (one wavefront), so this is an s_waitcnt and a compiler
+// fence -- it is what makes "one lane writes, all lanes read" (and the reuse of a cell) well-defined
+#define HYS2_SYNC()                                                  \
+    do {                                                             \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       \
+        __builtin_amdgcn_wave_barrier();                             \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
+    } while (0)
+
+template <int NS, int NR, int L>
+struct HyS2Lay {
+    static constexpr int NF = NS + 2;
+    static constexpr int C = 12, CPL = C / L, GPW = 64 / L;
+    static_assert(CPL * L == C, "lanes per trajectory must divide the chunk");
+    static constexpr int ev(int n) { return n + (n & 1); }
+    // column descriptor (doubles): cb[NR] | ce[NR] | win value, row, reaction | wout value, species, reaction
+    static constexpr int D_CB = 0, D_CE = NR, D_WV = 2 * NR, D_WM = 2 * NR + 1, D_WJ = 2 * NR + 2, D_OV = 2 * NR + 3, D_OI = 2 * NR + 4,
+                         D_OJ = 2 * NR + 5, DSC = 2 * NR + 6;
+    // point record: sg[NS] gx[NS] K[NS] f[NS] r[NR] Bj[NR] x[NF] am (the C-clamp mask as a double)
+    static constexpr int P_SG = 0, P_GX = NS, P_K = 2 * NS, P_F = 3 * NS, P_R = 4 * NS, P_BJ = 4 * NS + NR, P_X = 4 * NS + 2 * NR,
+                         P_AM = 4 * NS + 2 * NR + NF, PT = ev(P_AM + 1);
+    // time record: zt[NR] Bt[NS] ld e1 e2
+    static constexpr int T_ZT = 0, T_BT = NR, T_LD = NR + NS, T_E1 = NR + NS + 1, T_E2 = NR + NS + 2, TM = ev(NR + NS + 3);
+    // direction record: v[NS] zv[NR] A[NS] xv[NS] Lv
+    static constexpr int V_V = 0, V_ZV = NS, V_A = NS + NR, V_XV = 2 * NS + NR, V_LV = 3 * NS + NR, DIR = ev(V_LV + 1);
+    // trajectory record: [W's factors, 1 / diagonal | time record] (dead after the column phase: the lanes' partial sums alias them)
+    //                    | three point slots | three direction records | u_new | sum over the chunk's columns of s_i^2
+    static constexpr int O_LU = 0, LU = ev(NS * NS + NS), O_TM = O_LU + LU, O_RED = 0, RED = L * 2 * NS;
+    static constexpr int HEAD = (LU + TM > RED ? LU + TM : ev(RED));
+    static constexpr int O_PT = HEAD, O_DIR = O_PT + 3 * PT, O_UN = O_DIR + 3 * DIR, O_SSQ = O_UN + ev(NS), REC = O_SSQ + 2 * ev(NS);   // (two buffers of the sums: written for the next step while this one's are read)
+};
+
+// true if a dense direction row fits the sparse description (crnn_capi.hip decides on the host which kernel runs)
+template <int NS, int NR>
+inline bool hy_dir_fits(const double *row) {
+    using L_ = HyTanLay<NS, NR>;      // (the host-callable statement of LayH's offsets)
+    int nin = 0, nout = 0;
+    for (int j = 0; j < NR; ++j) {
+        for (int m = 0; m < NS + 2; ++m)
+            if (m != NS && row[L_::wi(m, j)] != 0.0) ++nin;
+        for (int i = 0; i < NS; ++i)
+            if (row[L_::wo(i, j)] != 0.0) ++nout;
+    }
+    return nin <= 1 && nout <= 1;
+}
+
+// W x = b for NC right-hand sides at once (lu_solve_lds's operations per column; every factor is read once for all of them)
+template <int NS, int NC>
+__device__ __forceinline__ void hys2_solve(const double *As, const int (&piv)[NS], const bool wave_pivots, double (&b)[NC][NS]) {
+    if (wave_pivots) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int p = piv[k];
+#pragma unroll
+            for (int i = k + 1; i < NS; ++i) {
+                const bool sw = (p == i);
+#pragma unroll
+                for (int q = 0; q < NC; ++q) {
+                    const double bk = b[q][k], bi = b[q][i];
+                    b[q][k] = sw ? bi : bk;
+                    b[q][i] = sw ? bk : bi;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+#pragma unroll
+        for (int i = k + 1; i < NS; ++i) {
+            const double l = As[i * NS + k];
+#pragma unroll
+            for (int q = 0; q < NC; ++q) b[q][i] = fma(-l, b[q][k], b[q][i]);
+        }
+    }
+#pragma unroll
+    for (int k = NS - 1; k >= 0; --k) {
+        const double di = As[NS * NS + k];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) b[q][k] *= di;
+#pragma unroll
+        for (int i = 0; i < k; ++i) {
+            const double l = As[i * NS + k];
+#pragma unroll
+            for (int q = 0; q < NC; ++q) b[q][i] = fma(-l, b[q][k], b[q][i]);
+        }
+    }
+}
+
+template <int NS, int NR, int L, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams prm, const double *__restrict__ theta, const HyParams hp,
+                                                             const HySensParams sp) {
+    using L_ = LayH<NS, NR>;
+    using Y_ = HyS2Lay<NS, NR, L>;
+    constexpr int NTH = L_::NTH, NF = NS + 2;
+    constexpr int C = Y_::C, CPL = Y_::CPL, GPW = Y_::GPW, NWAVE = BLOCK / 64, GPB = NWAVE * GPW, REC = Y_::REC;
+    __shared__ double kc_lds[kNConst];
+    __shared__ double ts_lds[kMaxSave];
+    __shared__ double th_lds[NTH];
+    __shared__ double dsc_lds[C * Y_::DSC];
+    __shared__ double rec_lds[GPB * REC];
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < kNConst; idx += BLOCK) kc_lds[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
+    for (int idx = tid; idx < hp.n_save_total; idx += BLOCK) ts_lds[idx] = prm.tsave[idx];
+    for (int idx = tid; idx < NTH; idx += BLOCK) th_lds[idx] = theta[idx];
+    const int nch = sp.n_chunks > 1 ? sp.n_chunks : 1;
+    const int cid = nch > 1 ? (int)(blockIdx.x % nch) : 0;
+    const int ndir = nch > 1 ? min(C, sp.n_total - cid * C) : sp.n_dir;       // real directions of this block's chunk
+    // ---- the chunk's column descriptors from the dense rows (thread c: column c; the padding columns of a short chunk stay zero)
+    if (tid < C) {
+        double *d = dsc_lds + tid * Y_::DSC;
+        for (int k = 0; k < Y_::DSC; ++k) d[k] = 0.0;
+        if (tid < ndir) {
+            const double *row = sp.dth + ((size_t)cid * C + tid) * NTH;
+            for (int j = 0; j < NR; ++j) {
+                d[Y_::D_CB + j] = row[L_::wb(j)];
+                d[Y_::D_CE + j] = row[L_::wi(NS, j)];
+                for (int m = 0; m < NF; ++m) {
+                    const double v = row[L_::wi(m, j)];
+                    if (m != NS && v != 0.0) { d[Y_::D_WV] = v; d[Y_::D_WM] = (double)m; d[Y_::D_WJ] = (double)j; }
+                }
+                for (int i = 0; i < NS; ++i) {
+                    const double v = row[L_::wo(i, j)];
+                    if (v != 0.0) { d[Y_::D_OV] = v; d[Y_::D_OI] = (double)i; d[Y_::D_OJ] = (double)j; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const KConst *kc = reinterpret_cast<const KConst *>(kc_lds);
+    const double *th = th_lds;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int grp = lane / L, sub = lane - grp * L;
+    const bool lane_on = grp < GPW;
+    const bool writer = lane_on && sub == 0;
+    double *const rec = rec_lds + (size_t)(wave * GPW + (lane_on ? grp : 0)) * REC;
+    // this lane's columns: sub, sub + L, ... (the zero columns of a short last chunk spread over the lanes)
+    double wv[CPL], ov[CPL];
+    int wm[CPL], wj[CPL], oi[CPL], oj[CPL];
+    const double *dsc[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        const double *d = dsc_lds + (sub + q * L) * Y_::DSC;
+        dsc[q] = d;
+        wv[q] = d[Y_::D_WV]; wm[q] = (int)d[Y_::D_WM]; wj[q] = (int)d[Y_::D_WJ];
+        ov[q] = d[Y_::D_OV]; oi[q] = (int)d[Y_::D_OI]; oj[q] = (int)d[Y_::D_OJ];
+    }
+
+    const double d_ = 0.29289321881345248, c32 = 7.4142135623730950, inv12d = 2.4142135623730950;
+    const int nsave = prm.n_save, Dfull = hp.n_save_total;
+    const double tend = ts_lds[nsave - 1], ts0 = ts_lds[0], t0 = kc->t0;
+    const double dtmax = tend - t0;
+    const double lqinit = flog(kc->qoldinit);
+    const bool start_saved = (ts0 == t0);
+    const double inv_div = sp.mode == 2 ? 1.0 / ((double)NS * (1.0 + (double)sp.dual_partials)) : 1.0 / (double)NS;
+
+    // ---- the group's shared records
+    // a point: written by the group's first lane; B_j = sum_m [C_m in its window] w_in[m, j] by lane j % L
+    auto put_point = [&](const int slot, const HyPoint<NS, NR> &pp) {
+        double *pt = rec + Y_::O_PT + slot * Y_::PT;
+        if (writer) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const bool iy = (pp.cY >> i) & 1u, ic = (pp.cC >> i) & 1u;
+                pt[Y_::P_SG + i] = iy ? kc->imw[i] * pp.iS : 0.0;
+                pt[Y_::P_GX + i] = (iy && ic) ? frcp(pp.Y[i]) : 0.0;
+                pt[Y_::P_K + i] = kc->gsc[i] * pp.irho;
+                pt[Y_::P_F + i] = pp.f[i];
+            }
+#pragma unroll
+            for (int j = 0; j < NR; ++j) pt[Y_::P_R + j] = pp.r[j];
+#pragma unroll
+            for (int m = 0; m < NF; ++m) pt[Y_::P_X + m] = pp.x[m];
+            pt[Y_::P_AM] = (double)pp.cC;
+        }
+        if (lane_on) {
+            for (int j = sub; j < NR; j += L) {
+                double b = 0.0;
+#pragma unroll
+                for (int m = 0; m < NS; ++m) b += ((pp.cC >> m) & 1u) ? th[L_::wi(m, j)] : 0.0;
+                pt[Y_::P_BJ + j] = b;
+            }
+        }
+    };
+    // f' of the lane's columns at a recorded point, one pass over theta for all of them:
+    //   z'_j = zeta_j + Lp B_j + sum_m w_in[m, j] gx_m s_m,  zeta_j = cb_j + ce_j x_E + [j = wj] wv x[wm]
+    //   f'_i = K_i (sum_j w_out[i, j] r_j z'_j + [i = oi] ov r[oj]) - f_i Lp,  Lp = -sum_i sg_i s_i
+    auto col_fp = [&](const double *pt, const double (&ss)[CPL][NS], double (&fp)[CPL][NS]) {
+        double Lp[CPL], tt[CPL][NS], om[CPL][NS], xw[CPL];
+        const double xE = pt[Y_::P_X + NS];
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            Lp[q] = 0.0;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) { Lp[q] = fma(-pt[Y_::P_SG + i], ss[q][i], Lp[q]); tt[q][i] = pt[Y_::P_GX + i] * ss[q][i]; om[q][i] = 0.0; }
+            xw[q] = wv[q] * pt[Y_::P_X + wm[q]];
+        }
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const double *wi = th + L_::wi(0, j), *wo = th + L_::wo(0, j);
+            const double Bj = pt[Y_::P_BJ + j], rj = pt[Y_::P_R + j];
+            double z[CPL];
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                z[q] = fma(dsc[q][Y_::D_CE + j], xE, dsc[q][Y_::D_CB + j]);
+                z[q] += (j == wj[q]) ? xw[q] : 0.0;
+                z[q] = fma(Lp[q], Bj, z[q]);
+            }
+#pragma unroll
+            for (int m = 0; m < NS; ++m) {
+                const double w = wi[m];
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) z[q] = fma(w, tt[q][m], z[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) z[q] *= rj;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const double w = wo[i];
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) om[q][i] = fma(w, z[q], om[q][i]);
+            }
+            if (j & 1) CRNN_SCHED_FENCE();
+        }
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const double ex = ov[q] * pt[Y_::P_R + oj[q]];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const double o = om[q][i] + ((i == oi[q]) ? ex : 0.0);
+                fp[q][i] = fma(pt[Y_::P_K + i], o, -pt[Y_::P_F + i] * Lp[q]);
+            }
+        }
+    };
+
+    const int64_t nwaves_chunk = (int64_t)(gridDim.x / nch) * NWAVE;            // wavefronts working on this block's chunk
+    const int64_t nbatch = (prm.count + GPW - 1) / GPW;
+    for (int64_t batch = (int64_t)(blockIdx.x / nch) * NWAVE + wave; batch < nbatch; batch += nwaves_chunk) {
+        const int64_t pos = batch * GPW + grp;
+        const bool valid = lane_on && pos < prm.count;
+        const int64_t traj = valid ? (hp.perm ? (int64_t)hp.perm[pos] : pos) : 0;
+        const int64_t b = prm.first + traj;
+        CRNN_CHK(!valid || (b >= 0 && b < prm.B), 28);
+        const double *const tabT = hp.tabs + (size_t)b * 2 * Dfull;
+        const double *const tabP = tabT + Dfull;
+        int seg = 0;                          // table segment of t (t only grows)
+        auto tab = [&](const double tq, int sg, double &T, double &P, double &Td, double &Pd) -> int {
+            while (sg + 1 < Dfull - 1 && ts_lds[sg + 1] <= tq) ++sg;
+            const double idts = frcp(ts_lds[sg + 1] - ts_lds[sg]);
+            Td = (tabT[sg + 1] - tabT[sg]) * idts;
+            Pd = (tabP[sg + 1] - tabP[sg]) * idts;
+            T = fma(tq - ts_lds[sg], Td, tabT[sg]);
+            P = fma(tq - ts_lds[sg], Pd, tabP[sg]);
+            return sg;
+        };
+
+        double u[NS], s[CPL][NS], f0p[CPL][NS], gsum[CPL];
+        double t = t0, dt = 0.0, lqold = lqinit, loss_sum = 0.0;
+        int iter = 0, jsave = 0, nacc = 0, nrej = 0, rc = valid ? -1 : 0;
+        int s0 = 0, s1_ = 1, s2 = 2;          // record slots of the step's three points (s0 and s2 change places on accept)
+        int sq = 0;                           // which buffer holds the current sum of squares of the tangent columns
+#pragma unroll
+        for (int i = 0; i < NS; ++i) u[i] = valid ? prm.u0[(size_t)i * prm.B + b] : 1.0;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            gsum[q] = 0.0;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) s[q][i] = 0.0;
+        }
+        // the partial sums of the group's lanes, summed in lane order by every lane (identical bits in all of them).  Wave-uniform
+        // call sites only: the cells alias W's factors and the time record
+        auto group_reduce = [&](const double (&mine)[2 * NS], double (&tot)[2 * NS]) {
+            HYS2_SYNC();                      // everybody is done with the cells' previous contents
+            if (lane_on) {
+#pragma unroll
+                for (int k = 0; k < 2 * NS; ++k) rec[Y_::O_RED + sub * 2 * NS + k] = mine[k];
+            }
+            HYS2_SYNC();
+#pragma unroll
+            for (int k = 0; k < 2 * NS; ++k) {
+                double a = 0.0;
+#pragma unroll
+                for (int l = 0; l < L; ++l) a += rec[Y_::O_RED + l * 2 * NS + k];
+                tot[k] = a;
+            }
+            HYS2_SYNC();                      // the cells are free again
+        };
+        // ---- first point and the initial step (Hairer's, with the dual-inclusive norms: hychem_sens_kernel.hpp / ros23_sens_kernel.hpp)
+        if (valid) {
+            double T, P, Td, Pd;
+            seg = tab(t0, seg, T, P, Td, Pd);
+            HyPoint<NS, NR> p0;
+            hy_point<NS, NR>(th, kc, hp.inv_R, u, T, P, p0);
+            put_point(s0, p0);
+            if (writer) {
+#pragma unroll
+                for (int i = 0; i < NS; ++i) rec[Y_::O_SSQ + i] = 0.0;       // buffer 0: the tangents start at zero
+            }
+        }
+        HYS2_SYNC();
+        double dt0 = 0.0, d1 = 0.0, sk[NS];
+        {
+            double mine[2 * NS], tot[2 * NS];
+#pragma unroll
+            for (int k = 0; k < 2 * NS; ++k) mine[k] = 0.0;
+            const double *pt0 = rec + Y_::O_PT + s0 * Y_::PT;
+            if (valid) {
+                col_fp(pt0, s, f0p);
+#pragma unroll
+                for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) mine[i] = fma(f0p[q][i], f0p[q][i], mine[i]);
+            }
+            group_reduce(mine, tot);
+            if (valid) {
+                double d0 = 0.0;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    sk[i] = frcp(fma(fabs(u[i]), kc->rtol[i], kc->atol[i]));
+                    const double a = u[i] * sk[i], c = pt0[Y_::P_F + i] * sk[i];
+                    d0 = fma(a, a, d0);
+                    d1 = fma(c, c, d1);
+                }
+                double d1p = 0.0;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) d1p = fma(tot[i], sk[i] * sk[i], d1p);
+                d1 += d1p;
+                d0 = sqrt(d0 * inv_div); d1 = sqrt(d1 * inv_div);
+                dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 / d1);
+                dt0 = fmin(dt0, dtmax);
+                double u1[NS];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) u1[i] = fma(dt0, pt0[Y_::P_F + i], u[i]);
+                double T, P, Td, Pd;
+                tab(t0 + dt0, seg, T, P, Td, Pd);
+                HyPoint<NS, NR> p1;
+                hy_point<NS, NR>(th, kc, hp.inv_R, u1, T, P, p1);
+                put_point(s1_, p1);
+            }
+        }
+        HYS2_SYNC();
+        {
+            double mine[2 * NS], tot[2 * NS];
+#pragma unroll
+            for (int k = 0; k < 2 * NS; ++k) mine[k] = 0.0;
+            const double *pt0 = rec + Y_::O_PT + s0 * Y_::PT, *pt1 = rec + Y_::O_PT + s1_ * Y_::PT;
+            if (valid) {
+                double s1[CPL][NS], f1p[CPL][NS];
+#pragma unroll
+                for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) s1[q][i] = dt0 * f0p[q][i];
+                col_fp(pt1, s1, f1p);
+#pragma unroll
+                for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) { const double e = f1p[q][i] - f0p[q][i]; mine[i] = fma(e, e, mine[i]); }
+            }
+            group_reduce(mine, tot);
+            if (valid) {
+                double d2 = 0.0, d2p = 0.0;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    const double e = (pt1[Y_::P_F + i] - pt0[Y_::P_F + i]) * sk[i];
+                    d2 = fma(e, e, d2);
+                    d2p = fma(tot[i], sk[i] * sk[i], d2p);
+                }
+                d2 += d2p;
+                d2 = sqrt(d2 * inv_div) / dt0;
+                const double dm = fmax(d1, d2);
+                const double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : exp(-0.5 * (4.605170185988091368 + flog(dm)));
+                dt = fmax(kc->dtmin, fmin(fmin(100.0 * dt0, dt1), dtmax));
+            }
+        }
+        // a save point of the primal: seeds d(loss term)/d(v_i); with commit the prediction and the loss term too
+        const double *const prow0 = prm.data + (size_t)b * prm.row_stride;
+        auto save_primal = [&](const double (&v_)[NS], const int j, const bool commit, double (&seed)[NS]) {
+            CRNN_CHK(j >= 0 && (int64_t)(j + 1) * prm.n_obs <= prm.row_stride, 29);
+            const double *prow = prow0 + (size_t)j * prm.n_obs;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                double v = v_[i], pass = 1.0;
+                if (prm.clamp_pred) { const double cl = clampv(v, -kc->ub, kc->ub); pass = (cl == v) ? 1.0 : 0.0; v = cl; }
+                if (commit && prm.pred && sub == 0) prm.pred[((size_t)j * NS + i) * prm.B + b] = v;
+                const int dr = (int)kc->drow[i];
+                seed[i] = 0.0;
+                if (dr >= 0) {
+                    const double rr = (prow[dr] - v) * kc->inv_yscale[i];
+                    if (prm.loss_kind == 0) { if (commit) loss_sum += fabs(rr); seed[i] = pass * ((signbit(rr) ? 1.0 : -1.0) * kc->inv_yscale[i]); }
+                    else { if (commit) loss_sum = fma(rr, rr, loss_sum); seed[i] = pass * (-2.0 * rr * kc->inv_yscale[i]); }
+                }
+            }
+        };
+        if (valid && start_saved) {
+            double seed[NS];
+            save_primal(u, 0, true, seed);       // the tangents are zero at t0: no gradient term
+            jsave = 1;
+        }
+
+        while (__builtin_amdgcn_ballot_w64(rc < 0) != 0) {
+            bool act = rc < 0;
+            bool last = false;
+            if (act) {
+                ++iter;
+                if (jsave >= nsave) { rc = 0; act = false; }
+                else if (iter > prm.maxiters) { rc = 1; act = false; }
+                else {
+                    if (t + dt * (1.0 + 1e-13) >= tend) { dt = tend - t; last = true; }
+                    if (!(dt > kc->dtmin) || t + dt == t) { rc = 2; act = false; }
+                }
+            }
+            const double gam = d_ * dt;
+            const double tnew = last ? tend : t + dt;
+            const double *const pt0 = rec + Y_::O_PT + s0 * Y_::PT, *const pt1 = rec + Y_::O_PT + s1_ * Y_::PT, *const pt2 = rec + Y_::O_PT + s2 * Y_::PT;
+            const double *const As = rec + Y_::O_LU;
+            const double *const tm = rec + Y_::O_TM;
+            int piv[NS];
+            bool anyp = false, okf = true;
+            double k1[NS], ft[NS];
+            double ld = 0.0, e1 = 0.0, e2 = 0.0;
+            // ---- primal, first stage: W = I - gam J and ft from the point record (hy_jac_ft's operations on the recorded sg, gx, K, f, r, B_j)
+            if (act) {
+                double T, P, Td, Pd;
+                seg = tab(t, seg, T, P, Td, Pd);
+                ld = Pd * frcp(P) - Td * frcp(T); e1 = -hp.inv_R * Td * frcp(T * T); e2 = Td * frcp(T);
+                double A[NS][NS], dinv[NS], zd[NR];
+#pragma unroll
+                for (int j = 0; j < NR; ++j) zd[j] = fma(pt0[Y_::P_BJ + j], ld, fma(th[L_::wi(NS, j)], e1, th[L_::wi(NS + 1, j)] * e2));
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    const double Gi = pt0[Y_::P_K + i], fi = pt0[Y_::P_F + i];
+                    double a[NR], tB = 0.0, tz = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        a[j] = Gi * th[L_::wo(i, j)] * pt0[Y_::P_R + j];
+                        tB = fma(a[j], pt0[Y_::P_BJ + j], tB);
+                        tz = fma(a[j], zd[j], tz);
+                    }
+                    ft[i] = fma(-fi, ld, tz);
+#pragma unroll
+                    for (int c = 0; c < NS; ++c) {
+                        double s_ = 0.0;
+#pragma unroll
+                        for (int j = 0; j < NR; ++j) s_ = fma(a[j], th[L_::wi(c, j)], s_);
+                        const double Jic = fma(pt0[Y_::P_GX + c], s_, -pt0[Y_::P_SG + c] * (tB - fi));
+                        A[i][c] = ((i == c) ? 1.0 : 0.0) - gam * Jic;
+                    }
+                    CRNN_SCHED_FENCE();
+                }
+                okf = lu_factor<NS>(A, dinv, piv, anyp);
+                if (writer) {
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+#pragma unroll
+                        for (int c = 0; c < NS; ++c) rec[Y_::O_LU + i * NS + c] = A[i][c];
+                        rec[Y_::O_LU + NS * NS + i] = dinv[i];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NS; ++i) k1[i] = fma(gam, ft[i], pt0[Y_::P_F + i]);
+            }
+            const bool wp = __builtin_amdgcn_ballot_w64(act && anyp) != 0;
+            HYS2_SYNC();                                       // W's factors are in the record
+            double unew[NS];
+            if (act) {
+                // ---- primal, stages two and three; the points go to the record as they are formed
+                double b1[1][NS], dk[NS], k3[NS], f1[NS];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) b1[0][i] = k1[i];
+                hys2_solve<NS, 1>(As, piv, wp, b1);
+#pragma unroll
+                for (int i = 0; i < NS; ++i) k1[i] = b1[0][i];
+                double a_, b_;
+                int sg1;
+                {
+                    double u1[NS], T1, P1;
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) u1[i] = fma(0.5 * dt, k1[i], u[i]);
+                    HyPoint<NS, NR> p1;
+                    sg1 = tab(t + 0.5 * dt, seg, T1, P1, a_, b_);
+                    hy_point<NS, NR>(th, kc, hp.inv_R, u1, T1, P1, p1);
+                    put_point(s1_, p1);
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) { f1[i] = p1.f[i]; b1[0][i] = f1[i] - k1[i]; }
+                }
+                hys2_solve<NS, 1>(As, piv, wp, b1);
+#pragma unroll
+                for (int i = 0; i < NS; ++i) { dk[i] = b1[0][i]; unew[i] = fma(dt, k1[i] + dk[i], u[i]); }
+                {
+                    double T2, P2;
+                    HyPoint<NS, NR> p2;
+                    tab(tnew, sg1, T2, P2, a_, b_);
+                    hy_point<NS, NR>(th, kc, hp.inv_R, unew, T2, P2, p2);
+                    put_point(s2, p2);
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        const double k2i = k1[i] + dk[i];
+                        b1[0][i] = fma(dt, ft[i], p2.f[i] - c32 * (k2i - f1[i]) - 2.0 * (k1[i] - pt0[Y_::P_F + i]));
+                    }
+                }
+                hys2_solve<NS, 1>(As, piv, wp, b1);
+#pragma unroll
+                for (int i = 0; i < NS; ++i) k3[i] = b1[0][i];
+                if (writer) {
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) rec[Y_::O_UN + i] = unew[i];
+                }
+                // ---- direction records: direction k (k1, k2 - k1, k3, time) by lane k % L of the group -- same code, other data
+                //   u-direction v: Lv = -sum sg_i v_i, xv_m = [C_m window] Lv + gx_m v_m;  time: "Lv" = ld, xv = ([C_m window] ld, e1, e2)
+                //   zv_j = sum_m w_in[m, j] xv_m,  A_i = sum_j w_out[i, j] r_j zv_j        (hychem_tan.hpp: hy_tan_v / hy_tan_time)
+                const unsigned am = (unsigned)pt0[Y_::P_AM];
+                for (int k = sub; k < 4; k += L) {
+                    double v[NS], xv[NF], Lv = 0.0;
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        v[i] = (k == 0) ? k1[i] : ((k == 1) ? dk[i] : ((k == 2) ? k3[i] : 0.0));
+                        Lv = fma(-pt0[Y_::P_SG + i], v[i], Lv);
+                    }
+                    if (k == 3) Lv = ld;
+#pragma unroll
+                    for (int m = 0; m < NS; ++m) xv[m] = fma(pt0[Y_::P_GX + m], v[m], ((am >> m) & 1u) ? Lv : 0.0);
+                    xv[NS] = (k == 3) ? e1 : 0.0;
+                    xv[NS + 1] = (k == 3) ? e2 : 0.0;
+                    double zv[NR], Av[NS];
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) Av[i] = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        const double *wi = th + L_::wi(0, j), *wo = th + L_::wo(0, j);
+                        double z = 0.0;
+#pragma unroll
+                        for (int m = 0; m < NF; ++m) z = fma(wi[m], xv[m], z);
+                        zv[j] = z;
+                        const double rz = pt0[Y_::P_R + j] * z;
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) Av[i] = fma(wo[i], rz, Av[i]);
+                        if (j & 1) CRNN_SCHED_FENCE();
+                    }
+                    if (k < 3) {
+                        double *dr = rec + Y_::O_DIR + k * Y_::DIR;
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) { dr[Y_::V_V + i] = v[i]; dr[Y_::V_A + i] = Av[i]; dr[Y_::V_XV + i] = xv[i]; }
+#pragma unroll
+                        for (int j = 0; j < NR; ++j) dr[Y_::V_ZV + j] = zv[j];
+                        dr[Y_::V_LV] = Lv;
+                    } else {
+                        double *tr = rec + Y_::O_TM;
+#pragma unroll
+                        for (int j = 0; j < NR; ++j) tr[Y_::T_ZT + j] = zv[j];
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) tr[Y_::T_BT + i] = Av[i];
+                        tr[Y_::T_LD] = ld; tr[Y_::T_E1] = e1; tr[Y_::T_E2] = e2;
+                    }
+                }
+            }
+            HYS2_SYNC();                                       // points, directions and the time record are in place
+            // ---- the lane's columns through the attempt
+            double snew[CPL][NS], f2p[CPL][NS], gtry[CPL], mine[2 * NS], tot[2 * NS];
+#pragma unroll
+            for (int k = 0; k < 2 * NS; ++k) mine[k] = 0.0;
+            if (act) {
+                double k1p[CPL][NS], k2p[CPL][NS];
+                const double *const dr0 = rec + Y_::O_DIR;
+                const double tld = tm[Y_::T_LD], te1 = tm[Y_::T_E1], te2 = tm[Y_::T_E2];
+                const unsigned am = (unsigned)pt0[Y_::P_AM];
+                // first stage: per column one pass over theta at the step's first point gives (d_t f)' and the three mixed derivatives
+                //   z'_j as in col_fp;  r'_j = r_j z'_j;  eta_j = ce_j e1 + [j = wj] (wm = log T row ? wv e2 : [C_wm window] ld wv)
+                //   zv'_k,j = [j = wj, wm < NS] wv xv_k[wm] + Lv_k Lp B_j - sum_m w_in[m, j] gx_m^2 v_k,m s_m
+                //   (d_t f)'_i = K_i (sum_j w_out[i, j] (r'_j zt_j + r_j eta_j) + [i = oi] ov r zt [oj] - Bt_i Lp) - f0'_i ld
+                //   (J' v_k)_i = K_i (sum_j w_out[i, j] (r'_j zv_k,j + r_j zv'_k,j) + [i = oi] ov r zv_k [oj] - A_k,i Lp) - f0'_i Lv_k - f_i Lv_k Lp
+                double mx[CPL][3][NS];
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) {
+                    double Lp = 0.0, tt[NS], tk[3][NS], Bp[NS], Ap[3][NS], Lv[3];
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        const double gx = pt0[Y_::P_GX + i], si = s[q][i];
+                        Lp = fma(-pt0[Y_::P_SG + i], si, Lp);
+                        tt[i] = gx * si;
+                        const double h = gx * tt[i];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) { tk[k][i] = h * dr0[k * Y_::DIR + Y_::V_V + i]; Ap[k][i] = 0.0; }
+                        Bp[i] = 0.0;
+                    }
+                    const double xE = pt0[Y_::P_X + NS], xw = wv[q] * pt0[Y_::P_X + wm[q]];
+                    const bool w_species = wm[q] < NS;
+                    const double eta_w = (wm[q] == NS + 1) ? wv[q] * te2 : ((w_species && ((am >> wm[q]) & 1u)) ? tld * wv[q] : 0.0);
+                    double xi[3], LvLp[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        Lv[k] = dr0[k * Y_::DIR + Y_::V_LV];
+                        LvLp[k] = Lv[k] * Lp;
+                        xi[k] = w_species ? wv[q] * dr0[k * Y_::DIR + Y_::V_XV + wm[q]] : 0.0;
+                    }
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        const double *wi = th + L_::wi(0, j), *wo = th + L_::wo(0, j);
+                        const double Bj = pt0[Y_::P_BJ + j], rj = pt0[Y_::P_R + j], ce = dsc[q][Y_::D_CE + j];
+                        const bool hit = (j == wj[q]);
+                        double z = fma(ce, xE, dsc[q][Y_::D_CB + j]);
+                        z += hit ? xw : 0.0;
+                        z = fma(Lp, Bj, z);
+                        double y[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int m = 0; m < NS; ++m) {
+                            const double w = wi[m];
+                            z = fma(w, tt[m], z);
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) y[k] = fma(w, tk[k][m], y[k]);
+                        }
+                        const double rp = rj * z;
+                        const double eta = fma(ce, te1, hit ? eta_w : 0.0);
+                        const double cB = fma(rp, tm[Y_::T_ZT + j], rj * eta);
+                        double cA[3];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const double zvp = fma(LvLp[k], Bj, hit ? xi[k] : 0.0) - y[k];
+                            cA[k] = fma(rp, dr0[k * Y_::DIR + Y_::V_ZV + j], rj * zvp);
+                        }
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) {
+                            const double w = wo[i];
+                            Bp[i] = fma(w, cB, Bp[i]);
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) Ap[k][i] = fma(w, cA[k], Ap[k][i]);
+                        }
+                        if (j & 1) CRNN_SCHED_FENCE();
+                    }
+                    const double ro = ov[q] * pt0[Y_::P_R + oj[q]];
+                    const double exB = ro * tm[Y_::T_ZT + oj[q]];
+                    double exA[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) exA[k] = ro * dr0[k * Y_::DIR + Y_::V_ZV + oj[q]];
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        const bool oh = (i == oi[q]);
+                        const double Ki = pt0[Y_::P_K + i], fi = pt0[Y_::P_F + i], fpi = f0p[q][i];
+                        const double ftp = fma(Ki, (Bp[i] + (oh ? exB : 0.0)) - tm[Y_::T_BT + i] * Lp, -fpi * tld);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const double o = fma(Ki, (Ap[k][i] + (oh ? exA[k] : 0.0)) - dr0[k * Y_::DIR + Y_::V_A + i] * Lp, -fpi * Lv[k]) - fi * LvLp[k];
+                            const double tau = (k == 0) ? 1.0 : ((k == 1) ? 0.0 : 1.0 / d_);
+                            mx[q][k][i] = (k == 1) ? o : fma(tau, ftp, o);
+                        }
+                    }
+                    CRNN_SCHED_FENCE();
+                }
+                double rhs[CPL][NS], s1[CPL][NS], f1p[CPL][NS];
+#pragma unroll
+                for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) rhs[q][i] = fma(gam, mx[q][0][i], f0p[q][i]);
+                hys2_solve<NS, CPL>(As, piv, wp, rhs);
+#pragma unroll
+                for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) { k1p[q][i] = rhs[q][i]; s1[q][i] = fma(0.5 * dt, k1p[q][i], s[q][i]); }
+                col_fp(pt1, s1, f1p);
+#pragma unroll
+                for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) rhs[q][i] = fma(gam, mx[q][1][i], f1p[q][i] - k1p[q][i]);
+                hys2_solve<NS, CPL>(As, piv, wp, rhs);
+#pragma unroll
+                for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) { k2p[q][i] = k1p[q][i] + rhs[q][i]; snew[q][i] = fma(dt, k2p[q][i], s[q][i]); }
+                col_fp(pt2, snew, f2p);
+#pragma unroll
+                for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                    for (int i = 0; i < NS; ++i)
+                        rhs[q][i] = fma(gam, mx[q][2][i], f2p[q][i] - c32 * (k2p[q][i] - f1p[q][i]) - 2.0 * (k1p[q][i] - f0p[q][i]));
+                hys2_solve<NS, CPL>(As, piv, wp, rhs);
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) {
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        const double de = dt * (1.0 / 6.0) * (k1p[q][i] - 2.0 * k2p[q][i] + rhs[q][i]);
+                        mine[i] = fma(snew[q][i], snew[q][i], mine[i]);
+                        mine[NS + i] = fma(de, de, mine[NS + i]);
+                    }
+                    gtry[q] = 0.0;
+                }
+                // the columns' gradient terms at the save points inside (t, tnew] -- tentative until the decision
+                for (int j = jsave; j < nsave; ++j) {
+                    const double ts = ts_lds[j];
+                    if (!(ts <= tnew)) break;
+                    const bool at_end = (ts == tnew);
+                    const double Th = at_end ? 1.0 : (ts - t) / dt;
+                    const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
+                    const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d_) * inv12d;
+                    double v[NS], seed[NS];
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        const double k1i = dr0[Y_::V_V + i], k2i = k1i + dr0[Y_::DIR + Y_::V_V + i];
+                        v[i] = at_end ? unew[i] : fma(dt, fma(c1, k1i, c2 * k2i), u[i]);
+                    }
+                    save_primal(v, j, false, seed);
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) {
+                            const double vp = at_end ? snew[q][i] : fma(dt, fma(c1, k1p[q][i], c2 * k2p[q][i]), s[q][i]);
+                            gtry[q] = fma(seed[i], vp, gtry[q]);
+                        }
+                }
+            }
+            group_reduce(mine, tot);                           // (its first fence: all lanes are done with W's factors and the time record)
+            if (act) {
+                // ---- the dual-inclusive norm, the decision, the commit
+                const double *const dr0 = rec + Y_::O_DIR;
+                double es = 0.0;
+                bool fin = okf;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    const double k1i = dr0[Y_::V_V + i], k2i = k1i + dr0[Y_::DIR + Y_::V_V + i], k3i = dr0[2 * Y_::DIR + Y_::V_V + i];
+                    const double ev = dt * (1.0 / 6.0) * (k1i - 2.0 * k2i + k3i);
+                    const double na = fma(u[i], u[i], rec[Y_::O_SSQ + sq * Y_::ev(NS) + i]);
+                    const double nb = fma(unew[i], unew[i], tot[i]);
+                    const double ee = fma(ev, ev, tot[NS + i]);
+                    const double scl = fma(kc->rtol[i], sqrt(fmax(na, nb)), kc->atol[i]);
+                    es += ee / (scl * scl);
+                    fin = fin && isfinite(unew[i]) && isfinite(ev);
+                }
+                es *= inv_div;
+                if (!(fin && isfinite(es))) { rc = 3; }
+                else {
+                    const bool ee_zero = (es == 0.0);
+                    const double lEE = 0.5 * flog(ee_zero ? 1.0 : es);
+                    const double lq11 = kc->beta1 * lEE;
+                    double q_ = ee_zero ? 1.0 / kc->qmax : fmax(1.0 / kc->qmax, fmin(1.0 / kc->qmin, exp(lq11 - kc->beta2 * lqold) / kc->gamma));
+                    if (es <= 1.0) {
+                        ++nacc;
+                        while (jsave < nsave) {
+                            const double ts = ts_lds[jsave];
+                            if (!(ts <= tnew)) break;
+                            const bool at_end = (ts == tnew);
+                            const double Th = at_end ? 1.0 : (ts - t) / dt;
+                            const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
+                            const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d_) * inv12d;
+                            double v[NS], seed[NS];
+#pragma unroll
+                            for (int i = 0; i < NS; ++i) {
+                                const double k1i = dr0[Y_::V_V + i], k2i = k1i + dr0[Y_::DIR + Y_::V_V + i];
+                                v[i] = at_end ? unew[i] : fma(dt, fma(c1, k1i, c2 * k2i), u[i]);
+                            }
+                            save_primal(v, jsave, true, seed);
+                            ++jsave;
+                        }
+#pragma unroll
+                        for (int q = 0; q < CPL; ++q) {
+                            gsum[q] += gtry[q];
+#pragma unroll
+                            for (int i = 0; i < NS; ++i) { s[q][i] = snew[q][i]; f0p[q][i] = f2p[q][i]; }
+                        }
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) u[i] = unew[i];
+                        if (writer) {
+#pragma unroll
+                            for (int i = 0; i < NS; ++i) rec[Y_::O_SSQ + (sq ^ 1) * Y_::ev(NS) + i] = tot[i];
+                        }
+                        sq ^= 1;
+                        { const int tmp_ = s0; s0 = s2; s2 = tmp_; }        // the new point is the next step's first
+                        t = tnew;
+                        if (q_ >= kc->qsteady_min && q_ <= kc->qsteady_max) q_ = 1.0;
+                        lqold = ee_zero ? lqinit : fmax(lEE, lqinit);
+                        dt = fmin(dt / q_, dtmax);
+                        if (jsave >= nsave) rc = 0;
+                    } else {
+                        ++nrej;
+                        dt = dt / fmin(1.0 / kc->qmin, exp(lq11) / kc->gamma);
+                    }
+                }
+            }
+            HYS2_SYNC();                                       // the sum of squares is in the record before the next attempt reads it
+        }
+        if (valid) {
+            const double denom = (double)prm.n_obs * (double)jsave;
+            const double inv = jsave > 0 ? 1.0 / denom : 0.0;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                const int col = sub + q * L;
+                if (nch == 1) prm.gtraj[(size_t)traj * C + col] = gsum[q] * inv;          // d loss_b / d p_k of this chunk's k = column
+                else if (col < ndir) prm.gtraj[(size_t)traj * sp.n_total + cid * C + col] = gsum[q] * inv;
+            }
+            if (sub == 0 && nch == 1) {
+                prm.loss[b] = loss_sum * inv;
+                prm.retcode[b] = rc;
+                prm.n_saved[b] = jsave;
+                prm.n_accept[b] = nacc;
+                prm.n_reject[b] = nrej;
+            }
+        }
+        HYS2_SYNC();                                           // the next batch reuses the records
+    }
+}
+
+}  // namespace crnn
