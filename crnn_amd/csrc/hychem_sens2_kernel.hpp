@@ -64,7 +64,7 @@ struct HyS2Lay {
     //                    | three point slots | three direction records | u_new | sum over the chunk's columns of s_i^2
     static constexpr int O_LU = 0, LU = ev(NS * NS + NS), O_TM = O_LU + LU, O_RED = 0, RED = L * 2 * NS;
     static constexpr int HEAD = (LU + TM > RED ? LU + TM : ev(RED));
-    static constexpr int O_PT = HEAD, O_DIR = O_PT + 3 * PT, O_UN = O_DIR + 3 * DIR, O_SSQ = O_UN + ev(NS), REC = O_SSQ + 2 * ev(NS);   // (two buffers of the sums: written for the next step while this one's are read)
+    static constexpr int O_PT = HEAD, O_DIR = O_PT + 3 * PT, O_UN = O_DIR + 3 * DIR, O_SSQ = O_UN + ev(NS), O_FT = O_SSQ + 2 * ev(NS), REC = O_FT + ev(NS);   // (two buffers of the sums: written for the next step while this one's are read; d_t f)
 };
 
 // true if a dense direction row fits the sparse description (crnn_capi.hip decides on the host which kernel runs)
@@ -79,6 +79,15 @@ inline bool hy_dir_fits(const double *row) {
             if (row[L_::wo(i, j)] != 0.0) ++nout;
     }
     return nin <= 1 && nout <= 1;
+}
+
+// value of a register array at a run-time index (a chain of selects: a dynamically indexed array would live in scratch)
+template <int N>
+__device__ __forceinline__ double hys2_pick(const double (&a)[N], const int idx) {
+    double r = a[0];
+#pragma unroll
+    for (int k = 1; k < N; ++k) r = (idx == k) ? a[k] : r;
+    return r;
 }
 
 // W x = b for NC right-hand sides at once (lu_solve_lds's operations per column; every factor is read once for all of them)
@@ -148,13 +157,16 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
         for (int k = 0; k < Y_::DSC; ++k) d[k] = 0.0;
         if (tid < ndir) {
             const double *row = sp.dth + ((size_t)cid * C + tid) * NTH;
-            for (int j = 0; j < NR; ++j) {
+#pragma unroll 1
+            for (int j = 0; j < NR; ++j) {                    // (rolled: unrolled, 220 loads are issued up front into 440 registers)
                 d[Y_::D_CB + j] = row[L_::wb(j)];
                 d[Y_::D_CE + j] = row[L_::wi(NS, j)];
+#pragma unroll 1
                 for (int m = 0; m < NF; ++m) {
                     const double v = row[L_::wi(m, j)];
                     if (m != NS && v != 0.0) { d[Y_::D_WV] = v; d[Y_::D_WM] = (double)m; d[Y_::D_WJ] = (double)j; }
                 }
+#pragma unroll 1
                 for (int i = 0; i < NS; ++i) {
                     const double v = row[L_::wo(i, j)];
                     if (v != 0.0) { d[Y_::D_OV] = v; d[Y_::D_OI] = (double)i; d[Y_::D_OJ] = (double)j; }
@@ -191,32 +203,85 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
     const double inv_div = sp.mode == 2 ? 1.0 / ((double)NS * (1.0 + (double)sp.dual_partials)) : 1.0 / (double)NS;
 
     // ---- the group's shared records
-    // a point: written by the group's first lane; B_j = sum_m [C_m in its window] w_in[m, j] by lane j % L
-    auto put_point = [&](const int slot, const HyPoint<NS, NR> &pp) {
+    // A point evaluation (hy_point's operations, hychem_kernel.hpp) spread over the group: every lane forms the cheap scalar part (clamps,
+    // S, rho); the ten logarithms, the ten rates and the nine right-hand-side components are taken by lane (index % L) -- two items per
+    // lane -- and meet in the point record.  What the record holds is what the tangents and the Jacobian need: sg, gx, K, f, r, B_j, x.
+    auto eval_point = [&](const int slot, const double (&uu)[NS], const double T, const double P) {
         double *pt = rec + Y_::O_PT + slot * Y_::PT;
-        if (writer) {
+        // (no arrays indexed by the lane's item numbers: a run-time index sends a register array to scratch -- the items are picked up
+        //  by selects inside the unrolled loops)
+        const int m0 = sub, m1 = min(sub + L, NS);            // logarithm arguments of this lane among (C_0 .. C_{NS-1}, T)
+        const int i0_ = sub, i1_ = min(sub + L, NS - 1);       // species of this lane
+        double S = 0.0, yi[2] = {1.0, 1.0};
+        unsigned cY = 0, cC = 0;
 #pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                const bool iy = (pp.cY >> i) & 1u, ic = (pp.cC >> i) & 1u;
-                pt[Y_::P_SG + i] = iy ? kc->imw[i] * pp.iS : 0.0;
-                pt[Y_::P_GX + i] = (iy && ic) ? frcp(pp.Y[i]) : 0.0;
-                pt[Y_::P_K + i] = kc->gsc[i] * pp.irho;
-                pt[Y_::P_F + i] = pp.f[i];
-            }
-#pragma unroll
-            for (int j = 0; j < NR; ++j) pt[Y_::P_R + j] = pp.r[j];
-#pragma unroll
-            for (int m = 0; m < NF; ++m) pt[Y_::P_X + m] = pp.x[m];
-            pt[Y_::P_AM] = (double)pp.cC;
+        for (int i = 0; i < NS; ++i) {
+            const double c = fmin(fmax(uu[i], kc->lb), kc->ub);
+            cY |= (c == uu[i]) ? (1u << i) : 0u;
+            yi[0] = (i == i0_) ? c : yi[0];
+            yi[1] = (i == i1_) ? c : yi[1];
+            S = fma(c, kc->imw[i], S);
         }
-        if (lane_on) {
-            for (int j = sub; j < NR; j += L) {
-                double b = 0.0;
+        const double RTS = kc->Ru * T * S;
+        const double rho = P * frcp(RTS), irho = RTS * frcp(P), iS = frcp(S);
+        double a_[2] = {T, T}, l_[2];
 #pragma unroll
-                for (int m = 0; m < NS; ++m) b += ((pp.cC >> m) & 1u) ? th[L_::wi(m, j)] : 0.0;
-                pt[Y_::P_BJ + j] = b;
+        for (int i = 0; i < NS; ++i) {
+            const double Yi = fmin(fmax(uu[i], kc->lb), kc->ub);
+            const double Cc = rho * (Yi * kc->imw[i]) * 1e3;
+            const double c = fmin(fmax(Cc, kc->lb), kc->ub);
+            cC |= (c == Cc) ? (1u << i) : 0u;
+            a_[0] = (i == m0) ? c : a_[0];
+            a_[1] = (i == m1) ? c : a_[1];
+        }
+        {   // logarithms: a lane without a second argument repeats log T (same value, same cell)
+            flog_vec<2>(a_, l_);
+            if (lane_on) {
+                pt[Y_::P_X + (m0 < NS ? m0 : NS + 1)] = l_[0];
+                pt[Y_::P_X + (m1 < NS ? m1 : NS + 1)] = l_[1];
+                if (sub == 0) { pt[Y_::P_X + NS] = hp.inv_R * frcp(T); pt[Y_::P_AM] = (double)cC; }
             }
         }
+        HYS2_SYNC();
+        {   // rates and masked column sums: reactions sub and sub + L
+            const int j0 = sub, j1 = min(sub + L, NR - 1);
+            double z_[2], e_[2], b_[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j = h ? j1 : j0;
+                const double *wi = th + L_::wi(0, j);
+                double zz = th[L_::wb(j)], bb = 0.0;
+#pragma unroll
+                for (int m = 0; m < NF; ++m) zz = fma(wi[m], pt[Y_::P_X + m], zz);
+#pragma unroll
+                for (int m = 0; m < NS; ++m) bb += ((cC >> m) & 1u) ? wi[m] : 0.0;
+                z_[h] = zz; b_[h] = bb;
+            }
+            fexp_vec<2>(z_, e_);
+            if (lane_on) {
+                pt[Y_::P_R + j0] = e_[0]; pt[Y_::P_BJ + j0] = b_[0];
+                pt[Y_::P_R + j1] = e_[1]; pt[Y_::P_BJ + j1] = b_[1];
+            }
+        }
+        HYS2_SYNC();
+        {   // right-hand side and the per-species factors: species sub and sub + L
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = h ? i1_ : i0_;
+                double a = 0.0;
+#pragma unroll
+                for (int j = 0; j < NR; ++j) a = fma(th[L_::wo(i, j)], pt[Y_::P_R + j], a);
+                const bool iy = (cY >> i) & 1u, ic = (cC >> i) & 1u;
+                const double gsc = kc->gsc[i], imw = kc->imw[i];
+                if (lane_on) {
+                    pt[Y_::P_F + i] = a * gsc * irho;
+                    pt[Y_::P_K + i] = gsc * irho;
+                    pt[Y_::P_SG + i] = iy ? imw * iS : 0.0;
+                    pt[Y_::P_GX + i] = (iy && ic) ? frcp(yi[h]) : 0.0;
+                }
+            }
+        }
+        HYS2_SYNC();
     };
     // f' of the lane's columns at a recorded point, one pass over theta for all of them:
     //   z'_j = zeta_j + Lp B_j + sum_m w_in[m, j] gx_m s_m,  zeta_j = cb_j + ce_j x_E + [j = wj] wv x[wm]
@@ -231,7 +296,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
             for (int i = 0; i < NS; ++i) { Lp[q] = fma(-pt[Y_::P_SG + i], ss[q][i], Lp[q]); tt[q][i] = pt[Y_::P_GX + i] * ss[q][i]; om[q][i] = 0.0; }
             xw[q] = wv[q] * pt[Y_::P_X + wm[q]];
         }
-#pragma unroll
+#pragma unroll 1
         for (int j = 0; j < NR; ++j) {
             const double *wi = th + L_::wi(0, j), *wo = th + L_::wo(0, j);
             const double Bj = pt[Y_::P_BJ + j], rj = pt[Y_::P_R + j];
@@ -313,11 +378,11 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
             }
             HYS2_SYNC();
 #pragma unroll
-            for (int k = 0; k < 2 * NS; ++k) {
-                double a = 0.0;
+            for (int k = 0; k < 2 * NS; ++k) tot[k] = 0.0;
+#pragma unroll 1
+            for (int l = 0; l < L; ++l) {      // (rolled over the lanes: unrolled, all L x 18 reads are issued at once and held in registers)
 #pragma unroll
-                for (int l = 0; l < L; ++l) a += rec[Y_::O_RED + l * 2 * NS + k];
-                tot[k] = a;
+                for (int k = 0; k < 2 * NS; ++k) tot[k] += rec[Y_::O_RED + l * 2 * NS + k];
             }
             HYS2_SYNC();                      // the cells are free again
         };
@@ -325,15 +390,12 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
         if (valid) {
             double T, P, Td, Pd;
             seg = tab(t0, seg, T, P, Td, Pd);
-            HyPoint<NS, NR> p0;
-            hy_point<NS, NR>(th, kc, hp.inv_R, u, T, P, p0);
-            put_point(s0, p0);
             if (writer) {
 #pragma unroll
                 for (int i = 0; i < NS; ++i) rec[Y_::O_SSQ + i] = 0.0;       // buffer 0: the tangents start at zero
             }
+            eval_point(s0, u, T, P);
         }
-        HYS2_SYNC();
         double dt0 = 0.0, d1 = 0.0, sk[NS];
         {
             double mine[2 * NS], tot[2 * NS];
@@ -369,12 +431,9 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                 for (int i = 0; i < NS; ++i) u1[i] = fma(dt0, pt0[Y_::P_F + i], u[i]);
                 double T, P, Td, Pd;
                 tab(t0 + dt0, seg, T, P, Td, Pd);
-                HyPoint<NS, NR> p1;
-                hy_point<NS, NR>(th, kc, hp.inv_R, u1, T, P, p1);
-                put_point(s1_, p1);
+                eval_point(s1_, u1, T, P);
             }
         }
-        HYS2_SYNC();
         {
             double mine[2 * NS], tot[2 * NS];
 #pragma unroll
@@ -452,18 +511,20 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
             const double *const tm = rec + Y_::O_TM;
             int piv[NS];
             bool anyp = false, okf = true;
-            double k1[NS], ft[NS];
             double ld = 0.0, e1 = 0.0, e2 = 0.0;
-            // ---- primal, first stage: W = I - gam J and ft from the point record (hy_jac_ft's operations on the recorded sg, gx, K, f, r, B_j)
+            // ---- primal, first stage.  W = I - gam J and ft = d_t f from the point record (hy_jac_ft's operations on the recorded
+            //      sg, gx, K, f, r, B_j), ROWS sub and sub + L by this lane; they meet in the record's matrix cells
             if (act) {
                 double T, P, Td, Pd;
                 seg = tab(t, seg, T, P, Td, Pd);
                 ld = Pd * frcp(P) - Td * frcp(T); e1 = -hp.inv_R * Td * frcp(T * T); e2 = Td * frcp(T);
-                double A[NS][NS], dinv[NS], zd[NR];
+                double zd[NR];
 #pragma unroll
                 for (int j = 0; j < NR; ++j) zd[j] = fma(pt0[Y_::P_BJ + j], ld, fma(th[L_::wi(NS, j)], e1, th[L_::wi(NS + 1, j)] * e2));
-#pragma unroll
-                for (int i = 0; i < NS; ++i) {
+                const int i0_ = sub, i1_ = min(sub + L, NS - 1);
+#pragma unroll 1
+                for (int h = 0; h < 2; ++h) {                 // (rolled: unrolled, the 90 reads of w_in are shared by the two rows and held in 180 registers)
+                    const int i = h ? i1_ : i0_;
                     const double Gi = pt0[Y_::P_K + i], fi = pt0[Y_::P_F + i];
                     double a[NR], tB = 0.0, tz = 0.0;
 #pragma unroll
@@ -472,18 +533,28 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                         tB = fma(a[j], pt0[Y_::P_BJ + j], tB);
                         tz = fma(a[j], zd[j], tz);
                     }
-                    ft[i] = fma(-fi, ld, tz);
+                    if (lane_on) rec[Y_::O_FT + i] = fma(-fi, ld, tz);
 #pragma unroll
                     for (int c = 0; c < NS; ++c) {
                         double s_ = 0.0;
 #pragma unroll
                         for (int j = 0; j < NR; ++j) s_ = fma(a[j], th[L_::wi(c, j)], s_);
                         const double Jic = fma(pt0[Y_::P_GX + c], s_, -pt0[Y_::P_SG + c] * (tB - fi));
-                        A[i][c] = ((i == c) ? 1.0 : 0.0) - gam * Jic;
+                        if (lane_on) rec[Y_::O_LU + i * NS + c] = ((i == c) ? 1.0 : 0.0) - gam * Jic;
                     }
                     CRNN_SCHED_FENCE();
                 }
+            }
+            HYS2_SYNC();                                       // the rows of W are in the record
+            if (act) {
+                // every lane factors W (the same operations on the same numbers: the pivot order is the group's); the first lane parks the factors
+                double A[NS][NS], dinv[NS];
+#pragma unroll
+                for (int i = 0; i < NS; ++i)
+#pragma unroll
+                    for (int c = 0; c < NS; ++c) A[i][c] = rec[Y_::O_LU + i * NS + c];
                 okf = lu_factor<NS>(A, dinv, piv, anyp);
+                HYS2_SYNC();                                   // (all lanes hold W before its cells become the factors)
                 if (writer) {
 #pragma unroll
                     for (int i = 0; i < NS; ++i) {
@@ -492,17 +563,15 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                         rec[Y_::O_LU + NS * NS + i] = dinv[i];
                     }
                 }
-#pragma unroll
-                for (int i = 0; i < NS; ++i) k1[i] = fma(gam, ft[i], pt0[Y_::P_F + i]);
             }
             const bool wp = __builtin_amdgcn_ballot_w64(act && anyp) != 0;
             HYS2_SYNC();                                       // W's factors are in the record
             double unew[NS];
             if (act) {
-                // ---- primal, stages two and three; the points go to the record as they are formed
-                double b1[1][NS], dk[NS], k3[NS], f1[NS];
+                // ---- primal, the three stage solves; the points are evaluated by the group into the record
+                double b1[1][NS], k1[NS], dk[NS], k3[NS];
 #pragma unroll
-                for (int i = 0; i < NS; ++i) b1[0][i] = k1[i];
+                for (int i = 0; i < NS; ++i) b1[0][i] = fma(gam, rec[Y_::O_FT + i], pt0[Y_::P_F + i]);
                 hys2_solve<NS, 1>(As, piv, wp, b1);
 #pragma unroll
                 for (int i = 0; i < NS; ++i) k1[i] = b1[0][i];
@@ -512,26 +581,22 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                     double u1[NS], T1, P1;
 #pragma unroll
                     for (int i = 0; i < NS; ++i) u1[i] = fma(0.5 * dt, k1[i], u[i]);
-                    HyPoint<NS, NR> p1;
                     sg1 = tab(t + 0.5 * dt, seg, T1, P1, a_, b_);
-                    hy_point<NS, NR>(th, kc, hp.inv_R, u1, T1, P1, p1);
-                    put_point(s1_, p1);
+                    eval_point(s1_, u1, T1, P1);
 #pragma unroll
-                    for (int i = 0; i < NS; ++i) { f1[i] = p1.f[i]; b1[0][i] = f1[i] - k1[i]; }
+                    for (int i = 0; i < NS; ++i) b1[0][i] = pt1[Y_::P_F + i] - k1[i];
                 }
                 hys2_solve<NS, 1>(As, piv, wp, b1);
 #pragma unroll
                 for (int i = 0; i < NS; ++i) { dk[i] = b1[0][i]; unew[i] = fma(dt, k1[i] + dk[i], u[i]); }
                 {
                     double T2, P2;
-                    HyPoint<NS, NR> p2;
                     tab(tnew, sg1, T2, P2, a_, b_);
-                    hy_point<NS, NR>(th, kc, hp.inv_R, unew, T2, P2, p2);
-                    put_point(s2, p2);
+                    eval_point(s2, unew, T2, P2);
 #pragma unroll
                     for (int i = 0; i < NS; ++i) {
                         const double k2i = k1[i] + dk[i];
-                        b1[0][i] = fma(dt, ft[i], p2.f[i] - c32 * (k2i - f1[i]) - 2.0 * (k1[i] - pt0[Y_::P_F + i]));
+                        b1[0][i] = fma(dt, rec[Y_::O_FT + i], pt2[Y_::P_F + i] - c32 * (k2i - pt1[Y_::P_F + i]) - 2.0 * (k1[i] - pt0[Y_::P_F + i]));
                     }
                 }
                 hys2_solve<NS, 1>(As, piv, wp, b1);
@@ -561,7 +626,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
 #pragma unroll
                     for (int i = 0; i < NS; ++i) Av[i] = 0.0;
 #pragma unroll
-                    for (int j = 0; j < NR; ++j) {
+                    for (int j = 0; j < NR; ++j) {            // (unrolled: zv is indexed by j)
                         const double *wi = th + L_::wi(0, j), *wo = th + L_::wo(0, j);
                         double z = 0.0;
 #pragma unroll
@@ -590,133 +655,136 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                 }
             }
             HYS2_SYNC();                                       // points, directions and the time record are in place
-            // ---- the lane's columns through the attempt
+            // ---- the lane's columns through the attempt, stage by stage, all of the lane's columns in every pass over theta
+            //   z'_j as in col_fp at the first point;  r'_j = r_j z'_j (kept: the three mixed derivatives use it)
+            //   eta_j = ce_j e1 + [j = wj] (wm = log T row ? wv e2 : [C_wm window] ld wv)
+            //   (d_t f)'_i = K_i (sum_j w_out[i, j] (r'_j zt_j + r_j eta_j) + [i = oi] ov (r zt)[oj] - Bt_i Lp) - f0'_i ld
+            //   zv'_j = [j = wj, wm < NS] wv xv[wm] + Lv Lp B_j - sum_m w_in[m, j] gx_m^2 v_m s_m
+            //   (J' v)_i = K_i (sum_j w_out[i, j] (r'_j zv_j + r_j zv'_j) + [i = oi] ov (r zv)[oj] - A_i Lp) - f0'_i Lv - f_i Lv Lp
             double snew[CPL][NS], f2p[CPL][NS], gtry[CPL], mine[2 * NS], tot[2 * NS];
 #pragma unroll
             for (int k = 0; k < 2 * NS; ++k) mine[k] = 0.0;
             if (act) {
-                double k1p[CPL][NS], k2p[CPL][NS];
                 const double *const dr0 = rec + Y_::O_DIR;
                 const double tld = tm[Y_::T_LD], te1 = tm[Y_::T_E1], te2 = tm[Y_::T_E2];
                 const unsigned am = (unsigned)pt0[Y_::P_AM];
-                // first stage: per column one pass over theta at the step's first point gives (d_t f)' and the three mixed derivatives
-                //   z'_j as in col_fp;  r'_j = r_j z'_j;  eta_j = ce_j e1 + [j = wj] (wm = log T row ? wv e2 : [C_wm window] ld wv)
-                //   zv'_k,j = [j = wj, wm < NS] wv xv_k[wm] + Lv_k Lp B_j - sum_m w_in[m, j] gx_m^2 v_k,m s_m
-                //   (d_t f)'_i = K_i (sum_j w_out[i, j] (r'_j zt_j + r_j eta_j) + [i = oi] ov r zt [oj] - Bt_i Lp) - f0'_i ld
-                //   (J' v_k)_i = K_i (sum_j w_out[i, j] (r'_j zv_k,j + r_j zv'_k,j) + [i = oi] ov r zv_k [oj] - A_k,i Lp) - f0'_i Lv_k - f_i Lv_k Lp
-                double mx[CPL][3][NS];
+                double Lp[CPL], r3[CPL][NS], rhs[CPL][NS];
+                // the mixed derivative along direction record k for every column of the lane (one pass over theta); WITH_T: the first pass
+                // also forms r' and (d_t f)' (returned in ftp)
+                auto mixed = [&](const int k, const bool with_t, double (&out)[CPL][NS], double (&ftp)[CPL][NS]) {
+                    const double *dr = dr0 + k * Y_::DIR;
+                    const double Lv = dr[Y_::V_LV];
+                    double tt[CPL][NS], tk[CPL][NS], Ap[CPL][NS], Bp[CPL][NS], LvLp[CPL], xi[CPL], xw[CPL], eta_w[CPL];
+                    const double xE = pt0[Y_::P_X + NS];
 #pragma unroll
-                for (int q = 0; q < CPL; ++q) {
-                    double Lp = 0.0, tt[NS], tk[3][NS], Bp[NS], Ap[3][NS], Lv[3];
+                    for (int q = 0; q < CPL; ++q) {
+                        if (with_t) {
+                            Lp[q] = 0.0;
 #pragma unroll
-                    for (int i = 0; i < NS; ++i) {
-                        const double gx = pt0[Y_::P_GX + i], si = s[q][i];
-                        Lp = fma(-pt0[Y_::P_SG + i], si, Lp);
-                        tt[i] = gx * si;
-                        const double h = gx * tt[i];
+                            for (int i = 0; i < NS; ++i) Lp[q] = fma(-pt0[Y_::P_SG + i], s[q][i], Lp[q]);
+                        }
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) { tk[k][i] = h * dr0[k * Y_::DIR + Y_::V_V + i]; Ap[k][i] = 0.0; }
-                        Bp[i] = 0.0;
+                        for (int i = 0; i < NS; ++i) {
+                            const double gx = pt0[Y_::P_GX + i];
+                            tt[q][i] = gx * s[q][i];
+                            tk[q][i] = gx * tt[q][i] * dr[Y_::V_V + i];
+                            Ap[q][i] = 0.0; Bp[q][i] = 0.0;
+                        }
+                        const bool w_species = wm[q] < NS;
+                        LvLp[q] = Lv * Lp[q];
+                        xi[q] = w_species ? wv[q] * dr[Y_::V_XV + (w_species ? wm[q] : 0)] : 0.0;
+                        xw[q] = wv[q] * pt0[Y_::P_X + wm[q]];
+                        eta_w[q] = (wm[q] == NS + 1) ? wv[q] * te2 : ((w_species && ((am >> wm[q]) & 1u)) ? tld * wv[q] : 0.0);
                     }
-                    const double xE = pt0[Y_::P_X + NS], xw = wv[q] * pt0[Y_::P_X + wm[q]];
-                    const bool w_species = wm[q] < NS;
-                    const double eta_w = (wm[q] == NS + 1) ? wv[q] * te2 : ((w_species && ((am >> wm[q]) & 1u)) ? tld * wv[q] : 0.0);
-                    double xi[3], LvLp[3];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        Lv[k] = dr0[k * Y_::DIR + Y_::V_LV];
-                        LvLp[k] = Lv[k] * Lp;
-                        xi[k] = w_species ? wv[q] * dr0[k * Y_::DIR + Y_::V_XV + wm[q]] : 0.0;
-                    }
-#pragma unroll
-                    for (int j = 0; j < NR; ++j) {
+#pragma unroll 1
+                    for (int j = 0; j < NR; ++j) {                 // (rolled; r'_j is re-formed in every pass: indexed by j it would live in scratch)
                         const double *wi = th + L_::wi(0, j), *wo = th + L_::wo(0, j);
-                        const double Bj = pt0[Y_::P_BJ + j], rj = pt0[Y_::P_R + j], ce = dsc[q][Y_::D_CE + j];
-                        const bool hit = (j == wj[q]);
-                        double z = fma(ce, xE, dsc[q][Y_::D_CB + j]);
-                        z += hit ? xw : 0.0;
-                        z = fma(Lp, Bj, z);
-                        double y[3] = {0.0, 0.0, 0.0};
+                        const double Bj = pt0[Y_::P_BJ + j], rj = pt0[Y_::P_R + j], zvj = dr[Y_::V_ZV + j];
+                        double z[CPL], y[CPL], cA[CPL], cB[CPL];
+#pragma unroll
+                        for (int q = 0; q < CPL; ++q) {
+                            const bool hit = (j == wj[q]);
+                            y[q] = 0.0;
+                            z[q] = fma(dsc[q][Y_::D_CE + j], xE, dsc[q][Y_::D_CB + j]);
+                            z[q] += hit ? xw[q] : 0.0;
+                            z[q] = fma(Lp[q], Bj, z[q]);
+                        }
 #pragma unroll
                         for (int m = 0; m < NS; ++m) {
                             const double w = wi[m];
-                            z = fma(w, tt[m], z);
 #pragma unroll
-                            for (int k = 0; k < 3; ++k) y[k] = fma(w, tk[k][m], y[k]);
+                            for (int q = 0; q < CPL; ++q) {
+                                z[q] = fma(w, tt[q][m], z[q]);
+                                y[q] = fma(w, tk[q][m], y[q]);
+                            }
                         }
-                        const double rp = rj * z;
-                        const double eta = fma(ce, te1, hit ? eta_w : 0.0);
-                        const double cB = fma(rp, tm[Y_::T_ZT + j], rj * eta);
-                        double cA[3];
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            const double zvp = fma(LvLp[k], Bj, hit ? xi[k] : 0.0) - y[k];
-                            cA[k] = fma(rp, dr0[k * Y_::DIR + Y_::V_ZV + j], rj * zvp);
+                        for (int q = 0; q < CPL; ++q) {
+                            const bool hit = (j == wj[q]);
+                            const double rp = rj * z[q];
+                            if (with_t) {
+                                const double eta = fma(dsc[q][Y_::D_CE + j], te1, hit ? eta_w[q] : 0.0);
+                                cB[q] = fma(rp, tm[Y_::T_ZT + j], rj * eta);
+                            }
+                            const double zvp = fma(LvLp[q], Bj, hit ? xi[q] : 0.0) - y[q];
+                            cA[q] = fma(rp, zvj, rj * zvp);
                         }
 #pragma unroll
                         for (int i = 0; i < NS; ++i) {
                             const double w = wo[i];
-                            Bp[i] = fma(w, cB, Bp[i]);
 #pragma unroll
-                            for (int k = 0; k < 3; ++k) Ap[k][i] = fma(w, cA[k], Ap[k][i]);
-                        }
-                        if (j & 1) CRNN_SCHED_FENCE();
-                    }
-                    const double ro = ov[q] * pt0[Y_::P_R + oj[q]];
-                    const double exB = ro * tm[Y_::T_ZT + oj[q]];
-                    double exA[3];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) exA[k] = ro * dr0[k * Y_::DIR + Y_::V_ZV + oj[q]];
-#pragma unroll
-                    for (int i = 0; i < NS; ++i) {
-                        const bool oh = (i == oi[q]);
-                        const double Ki = pt0[Y_::P_K + i], fi = pt0[Y_::P_F + i], fpi = f0p[q][i];
-                        const double ftp = fma(Ki, (Bp[i] + (oh ? exB : 0.0)) - tm[Y_::T_BT + i] * Lp, -fpi * tld);
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            const double o = fma(Ki, (Ap[k][i] + (oh ? exA[k] : 0.0)) - dr0[k * Y_::DIR + Y_::V_A + i] * Lp, -fpi * Lv[k]) - fi * LvLp[k];
-                            const double tau = (k == 0) ? 1.0 : ((k == 1) ? 0.0 : 1.0 / d_);
-                            mx[q][k][i] = (k == 1) ? o : fma(tau, ftp, o);
+                            for (int q = 0; q < CPL; ++q) {
+                                Ap[q][i] = fma(w, cA[q], Ap[q][i]);
+                                if (with_t) Bp[q][i] = fma(w, cB[q], Bp[q][i]);
+                            }
                         }
                     }
-                    CRNN_SCHED_FENCE();
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q) {
+                        const double ro = ov[q] * pt0[Y_::P_R + oj[q]];
+                        const double exA = ro * dr[Y_::V_ZV + oj[q]], exB = with_t ? ro * tm[Y_::T_ZT + oj[q]] : 0.0;
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) {
+                            const bool oh = (i == oi[q]);
+                            const double Ki = pt0[Y_::P_K + i], fpi = f0p[q][i];
+                            if (with_t) ftp[q][i] = fma(Ki, (Bp[q][i] + (oh ? exB : 0.0)) - tm[Y_::T_BT + i] * Lp[q], -fpi * tld);
+                            out[q][i] = fma(Ki, (Ap[q][i] + (oh ? exA : 0.0)) - dr[Y_::V_A + i] * Lp[q], -fpi * Lv) - pt0[Y_::P_F + i] * LvLp[q];
+                        }
+                    }
+                };
+                {
+                    double mx[CPL][NS], ftp[CPL][NS];
+                    mixed(0, true, mx, ftp);
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) {
+                            rhs[q][i] = fma(gam, mx[q][i] + ftp[q][i], f0p[q][i]);        // f0' + gam (J' k1 + (d_t f)')
+                            r3[q][i] = (gam / d_) * ftp[q][i];                             // the third stage's gam (dt / gam) ... (d_t f)' share
+                        }
                 }
-                double rhs[CPL][NS], s1[CPL][NS], f1p[CPL][NS];
-#pragma unroll
-                for (int q = 0; q < CPL; ++q)
-#pragma unroll
-                    for (int i = 0; i < NS; ++i) rhs[q][i] = fma(gam, mx[q][0][i], f0p[q][i]);
-                hys2_solve<NS, CPL>(As, piv, wp, rhs);
+                hys2_solve<NS, CPL>(As, piv, wp, rhs);             // rhs = k1'
+                double s1[CPL][NS], f1p[CPL][NS], k1p[CPL][NS];
 #pragma unroll
                 for (int q = 0; q < CPL; ++q)
 #pragma unroll
                     for (int i = 0; i < NS; ++i) { k1p[q][i] = rhs[q][i]; s1[q][i] = fma(0.5 * dt, k1p[q][i], s[q][i]); }
                 col_fp(pt1, s1, f1p);
+                {
+                    double mx[CPL][NS], dummy[CPL][NS];
+                    mixed(1, false, mx, dummy);
 #pragma unroll
-                for (int q = 0; q < CPL; ++q)
+                    for (int q = 0; q < CPL; ++q)
 #pragma unroll
-                    for (int i = 0; i < NS; ++i) rhs[q][i] = fma(gam, mx[q][1][i], f1p[q][i] - k1p[q][i]);
-                hys2_solve<NS, CPL>(As, piv, wp, rhs);
-#pragma unroll
-                for (int q = 0; q < CPL; ++q)
-#pragma unroll
-                    for (int i = 0; i < NS; ++i) { k2p[q][i] = k1p[q][i] + rhs[q][i]; snew[q][i] = fma(dt, k2p[q][i], s[q][i]); }
-                col_fp(pt2, snew, f2p);
-#pragma unroll
-                for (int q = 0; q < CPL; ++q)
-#pragma unroll
-                    for (int i = 0; i < NS; ++i)
-                        rhs[q][i] = fma(gam, mx[q][2][i], f2p[q][i] - c32 * (k2p[q][i] - f1p[q][i]) - 2.0 * (k1p[q][i] - f0p[q][i]));
-                hys2_solve<NS, CPL>(As, piv, wp, rhs);
+                        for (int i = 0; i < NS; ++i) rhs[q][i] = fma(gam, mx[q][i], f1p[q][i] - k1p[q][i]);
+                }
+                hys2_solve<NS, CPL>(As, piv, wp, rhs);             // rhs = k2' - k1'
+                double e12[CPL][NS];
 #pragma unroll
                 for (int q = 0; q < CPL; ++q) {
-#pragma unroll
-                    for (int i = 0; i < NS; ++i) {
-                        const double de = dt * (1.0 / 6.0) * (k1p[q][i] - 2.0 * k2p[q][i] + rhs[q][i]);
-                        mine[i] = fma(snew[q][i], snew[q][i], mine[i]);
-                        mine[NS + i] = fma(de, de, mine[NS + i]);
-                    }
                     gtry[q] = 0.0;
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) { rhs[q][i] += k1p[q][i]; snew[q][i] = fma(dt, rhs[q][i], s[q][i]); }   // rhs = k2'
                 }
                 // the columns' gradient terms at the save points inside (t, tnew] -- tentative until the decision
                 for (int j = jsave; j < nsave; ++j) {
@@ -730,17 +798,42 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
 #pragma unroll
                     for (int i = 0; i < NS; ++i) {
                         const double k1i = dr0[Y_::V_V + i], k2i = k1i + dr0[Y_::DIR + Y_::V_V + i];
-                        v[i] = at_end ? unew[i] : fma(dt, fma(c1, k1i, c2 * k2i), u[i]);
+                        v[i] = at_end ? rec[Y_::O_UN + i] : fma(dt, fma(c1, k1i, c2 * k2i), u[i]);
                     }
                     save_primal(v, j, false, seed);
 #pragma unroll
                     for (int q = 0; q < CPL; ++q)
 #pragma unroll
                         for (int i = 0; i < NS; ++i) {
-                            const double vp = at_end ? snew[q][i] : fma(dt, fma(c1, k1p[q][i], c2 * k2p[q][i]), s[q][i]);
+                            const double vp = at_end ? snew[q][i] : fma(dt, fma(c1, k1p[q][i], c2 * rhs[q][i]), s[q][i]);
                             gtry[q] = fma(seed[i], vp, gtry[q]);
                         }
                 }
+#pragma unroll
+                for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        e12[q][i] = fma(-2.0, rhs[q][i], k1p[q][i]);                                             // k1' - 2 k2'
+                        r3[q][i] += -c32 * (rhs[q][i] - f1p[q][i]) - 2.0 * (k1p[q][i] - f0p[q][i]);               // what the third stage keeps of them
+                    }
+                col_fp(pt2, snew, f2p);
+                {
+                    double mx[CPL][NS], dummy[CPL][NS];
+                    mixed(2, false, mx, dummy);
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) rhs[q][i] = fma(gam, mx[q][i], f2p[q][i] + r3[q][i]);
+                }
+                hys2_solve<NS, CPL>(As, piv, wp, rhs);             // rhs = k3'
+#pragma unroll
+                for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        const double de = dt * (1.0 / 6.0) * (e12[q][i] + rhs[q][i]);
+                        mine[i] = fma(snew[q][i], snew[q][i], mine[i]);
+                        mine[NS + i] = fma(de, de, mine[NS + i]);
+                    }
             }
             group_reduce(mine, tot);                           // (its first fence: all lanes are done with W's factors and the time record)
             if (act) {
