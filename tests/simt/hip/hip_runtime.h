@@ -199,8 +199,8 @@ inline void wave_op_results(BlockCtx &b, int lo, const std::vector<int> &mem, in
         const uint64_t v = b.lanes[mem[0]].op.payload;          // lowest-numbered participating lane
         for (int l : mem) b.lanes[l].op.result = v;
     } else if (kind == OP_MFMA) {
-        // v_mfma_f64_16x16x4_f64: A[i][k] in lane 16 k + i, B[k][j] in lane 16 k + j, D[i][j] = register i % 4 of
-        // lane 16 (i / 4) + j  (tools/ubench/mfma_f64_layout.hip measured this on the device).  The matrix unit ignores EXEC;
+        // v_mfma_f64_16x16x4_f64: A[i][k] in lane 16 k + i, B[k][j] in lane 16 k + j, D[i][j] = register i / 4 of
+        // lane 16 (i % 4) + j  (tools/ubench/mfma_f64_layout.hip measured this on the device).  The matrix unit ignores EXEC;
         // lanes that are not at the instruction contribute zeros here
         double A[16][4] = {}, B[4][16] = {};
         for (int l : mem) {
@@ -212,7 +212,7 @@ inline void wave_op_results(BlockCtx &b, int lo, const std::vector<int> &mem, in
             Lane &L = b.lanes[l];
             const int q = l - lo, jj = q % 16;
             for (int r = 0; r < 4; ++r) {
-                const int ii = 4 * (q / 16) + r;
+                const int ii = 4 * r + q / 16;
                 double acc = L.op.c[r];
                 for (int k = 0; k < 4; ++k) acc = std::fma(A[ii][k], B[k][jj], acc);
                 L.op.d[r] = acc;
