@@ -934,7 +934,7 @@ int32_t launch_hychem_sens_chunk(Ctx *c, const double *d_theta, const double *d_
     // (dense directions through nested duals, twelve lanes per trajectory) for arbitrary directions
     const bool sparse = c->hy_dirs_sparse && c->hy_sens_kernel != 1;
     constexpr int kC = 12;
-    constexpr int kL2 = 6, kBlk2 = 256, kGroups2 = (kBlk2 / 64) * (64 / kL2);
+    constexpr int kL2 = 12, kBlk2 = 256, kGroups2 = (kBlk2 / 64) * (64 / kL2);   // (L = 6: two columns per lane, 1.45x fewer issue slots per trajectory by the static count, but 1.2 KB of scratch per lane -- tools/ubench/hy_sens2_probe.hip)
     constexpr int kBlk1 = 128, kGroups1 = (kBlk1 / 64) * (64 / kC);
     const int kBlk = sparse ? kBlk2 : kBlk1, kGroups = sparse ? kGroups2 : kGroups1;
     const int ppad = n_chunks > 1 ? P : kC;      // gradient row: the chunk's 12 columns | all chunks in one launch: compact [P]

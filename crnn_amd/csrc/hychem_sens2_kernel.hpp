@@ -182,17 +182,22 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
     const bool lane_on = grp < GPW;
     const bool writer = lane_on && sub == 0;
     double *const rec = rec_lds + (size_t)(wave * GPW + (lane_on ? grp : 0)) * REC;
-    // this lane's columns: sub, sub + L, ... (the zero columns of a short last chunk spread over the lanes)
-    double wv[CPL], ov[CPL];
-    int wm[CPL], wj[CPL], oi[CPL], oj[CPL];
-    const double *dsc[CPL];
-#pragma unroll
-    for (int q = 0; q < CPL; ++q) {
-        const double *d = dsc_lds + (sub + q * L) * Y_::DSC;
-        dsc[q] = d;
-        wv[q] = d[Y_::D_WV]; wm[q] = (int)d[Y_::D_WM]; wj[q] = (int)d[Y_::D_WJ];
-        ov[q] = d[Y_::D_OV]; oi[q] = (int)d[Y_::D_OI]; oj[q] = (int)d[Y_::D_OJ];
-    }
+    // this lane's columns: sub, sub + L, ... (the zero columns of a short last chunk spread over the lanes).  A column's sparse entries are
+    // read from its descriptor where they are used, through a pointer the optimiser cannot see through (held in registers for the
+    // kernel's lifetime they are loop invariants the allocator spills)
+    struct ColDsc { const double *d; double wv, ov; int wm, wj, oi, oj; };
+    auto col_dsc = [&](const int q) -> ColDsc {
+        unsigned z_ = 0;
+        asm volatile("" : "+v"(z_));
+        const double *d = dsc_lds + (sub + q * L) * Y_::DSC + z_;
+        return ColDsc{d, d[Y_::D_WV], d[Y_::D_OV], (int)d[Y_::D_WM], (int)d[Y_::D_WJ], (int)d[Y_::D_OI], (int)d[Y_::D_OJ]};
+    };
+    // the group's record through a fresh pointer: what one column read of it is not kept for the next one
+    auto fresh_rec = [&]() -> const double * {
+        unsigned z_ = 0;
+        asm volatile("" : "+v"(z_));
+        return rec + z_;
+    };
 
     const double d_ = 0.29289321881345248, c32 = 7.4142135623730950, inv12d = 2.4142135623730950;
     const int nsave = prm.n_save, Dfull = hp.n_save_total;
@@ -208,47 +213,53 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
     // lane -- and meet in the point record.  What the record holds is what the tangents and the Jacobian need: sg, gx, K, f, r, B_j, x.
     auto eval_point = [&](const int slot, const double (&uu)[NS], const double T, const double P) {
         double *pt = rec + Y_::O_PT + slot * Y_::PT;
+        const double *th; const KConst *kc;            // (fresh pointers: theta and the constants are kernel invariants -- read through the
+        HY_FRESH_THETA(th); HY_FRESH_KC(kc);           //  outer pointers they are hoisted out of every loop, held, and spilled to scratch)
         // (no arrays indexed by the lane's item numbers: a run-time index sends a register array to scratch -- the items are picked up
         //  by selects inside the unrolled loops)
-        const int m0 = sub, m1 = min(sub + L, NS);            // logarithm arguments of this lane among (C_0 .. C_{NS-1}, T)
-        const int i0_ = sub, i1_ = min(sub + L, NS - 1);       // species of this lane
-        double S = 0.0, yi[2] = {1.0, 1.0};
+        // items per lane: ceil(count / L) of each kind; item h of lane `sub` is number sub + h L, clamped to the last one (a lane
+        // beyond the count repeats it: same value into the same cell)
+        constexpr int NLOG = (NS + 1 + L - 1) / L, NRAT = (NR + L - 1) / L, NSPC = (NS + L - 1) / L;
+        double S = 0.0, yi[NSPC];
         unsigned cY = 0, cC = 0;
+#pragma unroll
+        for (int h = 0; h < NSPC; ++h) yi[h] = 1.0;
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             const double c = fmin(fmax(uu[i], kc->lb), kc->ub);
             cY |= (c == uu[i]) ? (1u << i) : 0u;
-            yi[0] = (i == i0_) ? c : yi[0];
-            yi[1] = (i == i1_) ? c : yi[1];
+#pragma unroll
+            for (int h = 0; h < NSPC; ++h) yi[h] = (i == min(sub + h * L, NS - 1)) ? c : yi[h];
             S = fma(c, kc->imw[i], S);
         }
         const double RTS = kc->Ru * T * S;
         const double rho = P * frcp(RTS), irho = RTS * frcp(P), iS = frcp(S);
-        double a_[2] = {T, T}, l_[2];
+        double a_[NLOG], l_[NLOG];
+#pragma unroll
+        for (int h = 0; h < NLOG; ++h) a_[h] = T;              // argument NS (and beyond) is T
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             const double Yi = fmin(fmax(uu[i], kc->lb), kc->ub);
             const double Cc = rho * (Yi * kc->imw[i]) * 1e3;
             const double c = fmin(fmax(Cc, kc->lb), kc->ub);
             cC |= (c == Cc) ? (1u << i) : 0u;
-            a_[0] = (i == m0) ? c : a_[0];
-            a_[1] = (i == m1) ? c : a_[1];
+#pragma unroll
+            for (int h = 0; h < NLOG; ++h) a_[h] = (i == sub + h * L) ? c : a_[h];
         }
-        {   // logarithms: a lane without a second argument repeats log T (same value, same cell)
-            flog_vec<2>(a_, l_);
+        {   // logarithms of (C_0 .. C_{NS-1}, T)
+            flog_vec<NLOG>(a_, l_);
             if (lane_on) {
-                pt[Y_::P_X + (m0 < NS ? m0 : NS + 1)] = l_[0];
-                pt[Y_::P_X + (m1 < NS ? m1 : NS + 1)] = l_[1];
+#pragma unroll
+                for (int h = 0; h < NLOG; ++h) { const int m = sub + h * L; pt[Y_::P_X + (m < NS ? m : NS + 1)] = l_[h]; }
                 if (sub == 0) { pt[Y_::P_X + NS] = hp.inv_R * frcp(T); pt[Y_::P_AM] = (double)cC; }
             }
         }
         HYS2_SYNC();
-        {   // rates and masked column sums: reactions sub and sub + L
-            const int j0 = sub, j1 = min(sub + L, NR - 1);
-            double z_[2], e_[2], b_[2];
+        {   // rates and masked column sums
+            double z_[NRAT], e_[NRAT], b_[NRAT];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int j = h ? j1 : j0;
+            for (int h = 0; h < NRAT; ++h) {
+                const int j = min(sub + h * L, NR - 1);
                 const double *wi = th + L_::wi(0, j);
                 double zz = th[L_::wb(j)], bb = 0.0;
 #pragma unroll
@@ -257,17 +268,17 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                 for (int m = 0; m < NS; ++m) bb += ((cC >> m) & 1u) ? wi[m] : 0.0;
                 z_[h] = zz; b_[h] = bb;
             }
-            fexp_vec<2>(z_, e_);
+            fexp_vec<NRAT>(z_, e_);
             if (lane_on) {
-                pt[Y_::P_R + j0] = e_[0]; pt[Y_::P_BJ + j0] = b_[0];
-                pt[Y_::P_R + j1] = e_[1]; pt[Y_::P_BJ + j1] = b_[1];
+#pragma unroll
+                for (int h = 0; h < NRAT; ++h) { const int j = min(sub + h * L, NR - 1); pt[Y_::P_R + j] = e_[h]; pt[Y_::P_BJ + j] = b_[h]; }
             }
         }
         HYS2_SYNC();
-        {   // right-hand side and the per-species factors: species sub and sub + L
+        {   // right-hand side and the per-species factors
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int i = h ? i1_ : i0_;
+            for (int h = 0; h < NSPC; ++h) {
+                const int i = min(sub + h * L, NS - 1);
                 double a = 0.0;
 #pragma unroll
                 for (int j = 0; j < NR; ++j) a = fma(th[L_::wo(i, j)], pt[Y_::P_R + j], a);
@@ -283,54 +294,37 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
         }
         HYS2_SYNC();
     };
-    // f' of the lane's columns at a recorded point, one pass over theta for all of them:
+    // f' of one column at a recorded point (slot: the point's index among the record's three):
     //   z'_j = zeta_j + Lp B_j + sum_m w_in[m, j] gx_m s_m,  zeta_j = cb_j + ce_j x_E + [j = wj] wv x[wm]
     //   f'_i = K_i (sum_j w_out[i, j] r_j z'_j + [i = oi] ov r[oj]) - f_i Lp,  Lp = -sum_i sg_i s_i
-    auto col_fp = [&](const double *pt, const double (&ss)[CPL][NS], double (&fp)[CPL][NS]) {
-        double Lp[CPL], tt[CPL][NS], om[CPL][NS], xw[CPL];
-        const double xE = pt[Y_::P_X + NS];
+    // One column at a time, here and in the stage passes: two columns side by side halve the reads of theta and of W's factors but
+    // double every temporary of the attempt -- the register report answered with a kilobyte of scratch per lane (stages two and three).
+    auto col_fp = [&](const int slot, const int q, const double (&ss)[NS], double (&fp)[NS]) {
+        const double *th;
+        HY_FRESH_THETA(th);
+        const double *pt = fresh_rec() + Y_::O_PT + slot * Y_::PT;
+        const ColDsc cd = col_dsc(q);
+        double Lp = 0.0, tt[NS], om[NS];
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) {
-            Lp[q] = 0.0;
-#pragma unroll
-            for (int i = 0; i < NS; ++i) { Lp[q] = fma(-pt[Y_::P_SG + i], ss[q][i], Lp[q]); tt[q][i] = pt[Y_::P_GX + i] * ss[q][i]; om[q][i] = 0.0; }
-            xw[q] = wv[q] * pt[Y_::P_X + wm[q]];
-        }
+        for (int i = 0; i < NS; ++i) { Lp = fma(-pt[Y_::P_SG + i], ss[i], Lp); tt[i] = pt[Y_::P_GX + i] * ss[i]; om[i] = 0.0; }
+        const double xE = pt[Y_::P_X + NS], xw = cd.wv * pt[Y_::P_X + cd.wm];
 #pragma unroll 1
         for (int j = 0; j < NR; ++j) {
             const double *wi = th + L_::wi(0, j), *wo = th + L_::wo(0, j);
-            const double Bj = pt[Y_::P_BJ + j], rj = pt[Y_::P_R + j];
-            double z[CPL];
+            double z = fma(cd.d[Y_::D_CE + j], xE, cd.d[Y_::D_CB + j]);
+            z += (j == cd.wj) ? xw : 0.0;
+            z = fma(Lp, pt[Y_::P_BJ + j], z);
 #pragma unroll
-            for (int q = 0; q < CPL; ++q) {
-                z[q] = fma(dsc[q][Y_::D_CE + j], xE, dsc[q][Y_::D_CB + j]);
-                z[q] += (j == wj[q]) ? xw[q] : 0.0;
-                z[q] = fma(Lp[q], Bj, z[q]);
-            }
+            for (int m = 0; m < NS; ++m) z = fma(wi[m], tt[m], z);
+            z *= pt[Y_::P_R + j];
 #pragma unroll
-            for (int m = 0; m < NS; ++m) {
-                const double w = wi[m];
-#pragma unroll
-                for (int q = 0; q < CPL; ++q) z[q] = fma(w, tt[q][m], z[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) z[q] *= rj;
-#pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                const double w = wo[i];
-#pragma unroll
-                for (int q = 0; q < CPL; ++q) om[q][i] = fma(w, z[q], om[q][i]);
-            }
-            if (j & 1) CRNN_SCHED_FENCE();
+            for (int i = 0; i < NS; ++i) om[i] = fma(wo[i], z, om[i]);
         }
+        const double ex = cd.ov * pt[Y_::P_R + cd.oj];
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) {
-            const double ex = ov[q] * pt[Y_::P_R + oj[q]];
-#pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                const double o = om[q][i] + ((i == oi[q]) ? ex : 0.0);
-                fp[q][i] = fma(pt[Y_::P_K + i], o, -pt[Y_::P_F + i] * Lp[q]);
-            }
+        for (int i = 0; i < NS; ++i) {
+            const double o = om[i] + ((i == cd.oi) ? ex : 0.0);
+            fp[i] = fma(pt[Y_::P_K + i], o, -pt[Y_::P_F + i] * Lp);
         }
     };
 
@@ -403,7 +397,8 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
             for (int k = 0; k < 2 * NS; ++k) mine[k] = 0.0;
             const double *pt0 = rec + Y_::O_PT + s0 * Y_::PT;
             if (valid) {
-                col_fp(pt0, s, f0p);
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) col_fp(s0, q, s[q], f0p[q]);
 #pragma unroll
                 for (int q = 0; q < CPL; ++q)
 #pragma unroll
@@ -440,16 +435,15 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
             for (int k = 0; k < 2 * NS; ++k) mine[k] = 0.0;
             const double *pt0 = rec + Y_::O_PT + s0 * Y_::PT, *pt1 = rec + Y_::O_PT + s1_ * Y_::PT;
             if (valid) {
-                double s1[CPL][NS], f1p[CPL][NS];
 #pragma unroll
-                for (int q = 0; q < CPL; ++q)
+                for (int q = 0; q < CPL; ++q) {
+                    double s1[NS], f1p[NS];
 #pragma unroll
-                    for (int i = 0; i < NS; ++i) s1[q][i] = dt0 * f0p[q][i];
-                col_fp(pt1, s1, f1p);
+                    for (int i = 0; i < NS; ++i) s1[i] = dt0 * f0p[q][i];
+                    col_fp(s1_, q, s1, f1p);
 #pragma unroll
-                for (int q = 0; q < CPL; ++q)
-#pragma unroll
-                    for (int i = 0; i < NS; ++i) { const double e = f1p[q][i] - f0p[q][i]; mine[i] = fma(e, e, mine[i]); }
+                    for (int i = 0; i < NS; ++i) { const double e = f1p[i] - f0p[q][i]; mine[i] = fma(e, e, mine[i]); }
+                }
             }
             group_reduce(mine, tot);
             if (valid) {
@@ -515,16 +509,18 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
             // ---- primal, first stage.  W = I - gam J and ft = d_t f from the point record (hy_jac_ft's operations on the recorded
             //      sg, gx, K, f, r, B_j), ROWS sub and sub + L by this lane; they meet in the record's matrix cells
             if (act) {
+                const double *th;
+                HY_FRESH_THETA(th);
                 double T, P, Td, Pd;
                 seg = tab(t, seg, T, P, Td, Pd);
                 ld = Pd * frcp(P) - Td * frcp(T); e1 = -hp.inv_R * Td * frcp(T * T); e2 = Td * frcp(T);
                 double zd[NR];
 #pragma unroll
                 for (int j = 0; j < NR; ++j) zd[j] = fma(pt0[Y_::P_BJ + j], ld, fma(th[L_::wi(NS, j)], e1, th[L_::wi(NS + 1, j)] * e2));
-                const int i0_ = sub, i1_ = min(sub + L, NS - 1);
+                constexpr int NROW = (NS + L - 1) / L;
 #pragma unroll 1
-                for (int h = 0; h < 2; ++h) {                 // (rolled: unrolled, the 90 reads of w_in are shared by the two rows and held in 180 registers)
-                    const int i = h ? i1_ : i0_;
+                for (int h = 0; h < NROW; ++h) {              // (rolled: unrolled, the 90 reads of w_in are shared by the rows and held in 180 registers)
+                    const int i = min(sub + h * L, NS - 1);
                     const double Gi = pt0[Y_::P_K + i], fi = pt0[Y_::P_F + i];
                     double a[NR], tB = 0.0, tz = 0.0;
 #pragma unroll
@@ -566,10 +562,9 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
             }
             const bool wp = __builtin_amdgcn_ballot_w64(act && anyp) != 0;
             HYS2_SYNC();                                       // W's factors are in the record
-            double unew[NS];
             if (act) {
                 // ---- primal, the three stage solves; the points are evaluated by the group into the record
-                double b1[1][NS], k1[NS], dk[NS], k3[NS];
+                double b1[1][NS], k1[NS], dk[NS], k3[NS], unew[NS];
 #pragma unroll
                 for (int i = 0; i < NS; ++i) b1[0][i] = fma(gam, rec[Y_::O_FT + i], pt0[Y_::P_F + i]);
                 hys2_solve<NS, 1>(As, piv, wp, b1);
@@ -610,6 +605,8 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                 //   u-direction v: Lv = -sum sg_i v_i, xv_m = [C_m window] Lv + gx_m v_m;  time: "Lv" = ld, xv = ([C_m window] ld, e1, e2)
                 //   zv_j = sum_m w_in[m, j] xv_m,  A_i = sum_j w_out[i, j] r_j zv_j        (hychem_tan.hpp: hy_tan_v / hy_tan_time)
                 const unsigned am = (unsigned)pt0[Y_::P_AM];
+                const double *th;
+                HY_FRESH_THETA(th);
                 for (int k = sub; k < 4; k += L) {
                     double v[NS], xv[NF], Lv = 0.0;
 #pragma unroll
@@ -655,8 +652,8 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                 }
             }
             HYS2_SYNC();                                       // points, directions and the time record are in place
-            // ---- the lane's columns through the attempt, stage by stage, all of the lane's columns in every pass over theta
-            //   z'_j as in col_fp at the first point;  r'_j = r_j z'_j (kept: the three mixed derivatives use it)
+            // ---- the lane's columns through the attempt, one after the other
+            //   z'_j as in col_fp at the first point;  r'_j = r_j z'_j (re-formed in every pass: indexed by the rolled j it would live in scratch)
             //   eta_j = ce_j e1 + [j = wj] (wm = log T row ? wv e2 : [C_wm window] ld wv)
             //   (d_t f)'_i = K_i (sum_j w_out[i, j] (r'_j zt_j + r_j eta_j) + [i = oi] ov (r zt)[oj] - Bt_i Lp) - f0'_i ld
             //   zv'_j = [j = wj, wm < NS] wv xv[wm] + Lv Lp B_j - sum_m w_in[m, j] gx_m^2 v_m s_m
@@ -665,175 +662,143 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
 #pragma unroll
             for (int k = 0; k < 2 * NS; ++k) mine[k] = 0.0;
             if (act) {
-                const double *const dr0 = rec + Y_::O_DIR;
-                const double tld = tm[Y_::T_LD], te1 = tm[Y_::T_E1], te2 = tm[Y_::T_E2];
-                const unsigned am = (unsigned)pt0[Y_::P_AM];
-                double Lp[CPL], r3[CPL][NS], rhs[CPL][NS];
-                // the mixed derivative along direction record k for every column of the lane (one pass over theta); WITH_T: the first pass
-                // also forms r' and (d_t f)' (returned in ftp)
-                auto mixed = [&](const int k, const bool with_t, double (&out)[CPL][NS], double (&ftp)[CPL][NS]) {
-                    const double *dr = dr0 + k * Y_::DIR;
-                    const double Lv = dr[Y_::V_LV];
-                    double tt[CPL][NS], tk[CPL][NS], Ap[CPL][NS], Bp[CPL][NS], LvLp[CPL], xi[CPL], xw[CPL], eta_w[CPL];
-                    const double xE = pt0[Y_::P_X + NS];
-#pragma unroll
-                    for (int q = 0; q < CPL; ++q) {
-                        if (with_t) {
-                            Lp[q] = 0.0;
-#pragma unroll
-                            for (int i = 0; i < NS; ++i) Lp[q] = fma(-pt0[Y_::P_SG + i], s[q][i], Lp[q]);
-                        }
-#pragma unroll
-                        for (int i = 0; i < NS; ++i) {
-                            const double gx = pt0[Y_::P_GX + i];
-                            tt[q][i] = gx * s[q][i];
-                            tk[q][i] = gx * tt[q][i] * dr[Y_::V_V + i];
-                            Ap[q][i] = 0.0; Bp[q][i] = 0.0;
-                        }
-                        const bool w_species = wm[q] < NS;
-                        LvLp[q] = Lv * Lp[q];
-                        xi[q] = w_species ? wv[q] * dr[Y_::V_XV + (w_species ? wm[q] : 0)] : 0.0;
-                        xw[q] = wv[q] * pt0[Y_::P_X + wm[q]];
-                        eta_w[q] = (wm[q] == NS + 1) ? wv[q] * te2 : ((w_species && ((am >> wm[q]) & 1u)) ? tld * wv[q] : 0.0);
-                    }
-#pragma unroll 1
-                    for (int j = 0; j < NR; ++j) {                 // (rolled; r'_j is re-formed in every pass: indexed by j it would live in scratch)
-                        const double *wi = th + L_::wi(0, j), *wo = th + L_::wo(0, j);
-                        const double Bj = pt0[Y_::P_BJ + j], rj = pt0[Y_::P_R + j], zvj = dr[Y_::V_ZV + j];
-                        double z[CPL], y[CPL], cA[CPL], cB[CPL];
-#pragma unroll
-                        for (int q = 0; q < CPL; ++q) {
-                            const bool hit = (j == wj[q]);
-                            y[q] = 0.0;
-                            z[q] = fma(dsc[q][Y_::D_CE + j], xE, dsc[q][Y_::D_CB + j]);
-                            z[q] += hit ? xw[q] : 0.0;
-                            z[q] = fma(Lp[q], Bj, z[q]);
-                        }
-#pragma unroll
-                        for (int m = 0; m < NS; ++m) {
-                            const double w = wi[m];
-#pragma unroll
-                            for (int q = 0; q < CPL; ++q) {
-                                z[q] = fma(w, tt[q][m], z[q]);
-                                y[q] = fma(w, tk[q][m], y[q]);
-                            }
-                        }
-#pragma unroll
-                        for (int q = 0; q < CPL; ++q) {
-                            const bool hit = (j == wj[q]);
-                            const double rp = rj * z[q];
-                            if (with_t) {
-                                const double eta = fma(dsc[q][Y_::D_CE + j], te1, hit ? eta_w[q] : 0.0);
-                                cB[q] = fma(rp, tm[Y_::T_ZT + j], rj * eta);
-                            }
-                            const double zvp = fma(LvLp[q], Bj, hit ? xi[q] : 0.0) - y[q];
-                            cA[q] = fma(rp, zvj, rj * zvp);
-                        }
-#pragma unroll
-                        for (int i = 0; i < NS; ++i) {
-                            const double w = wo[i];
-#pragma unroll
-                            for (int q = 0; q < CPL; ++q) {
-                                Ap[q][i] = fma(w, cA[q], Ap[q][i]);
-                                if (with_t) Bp[q][i] = fma(w, cB[q], Bp[q][i]);
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < CPL; ++q) {
-                        const double ro = ov[q] * pt0[Y_::P_R + oj[q]];
-                        const double exA = ro * dr[Y_::V_ZV + oj[q]], exB = with_t ? ro * tm[Y_::T_ZT + oj[q]] : 0.0;
-#pragma unroll
-                        for (int i = 0; i < NS; ++i) {
-                            const bool oh = (i == oi[q]);
-                            const double Ki = pt0[Y_::P_K + i], fpi = f0p[q][i];
-                            if (with_t) ftp[q][i] = fma(Ki, (Bp[q][i] + (oh ? exB : 0.0)) - tm[Y_::T_BT + i] * Lp[q], -fpi * tld);
-                            out[q][i] = fma(Ki, (Ap[q][i] + (oh ? exA : 0.0)) - dr[Y_::V_A + i] * Lp[q], -fpi * Lv) - pt0[Y_::P_F + i] * LvLp[q];
-                        }
-                    }
-                };
-                {
-                    double mx[CPL][NS], ftp[CPL][NS];
-                    mixed(0, true, mx, ftp);
-#pragma unroll
-                    for (int q = 0; q < CPL; ++q)
-#pragma unroll
-                        for (int i = 0; i < NS; ++i) {
-                            rhs[q][i] = fma(gam, mx[q][i] + ftp[q][i], f0p[q][i]);        // f0' + gam (J' k1 + (d_t f)')
-                            r3[q][i] = (gam / d_) * ftp[q][i];                             // the third stage's gam (dt / gam) ... (d_t f)' share
-                        }
-                }
-                hys2_solve<NS, CPL>(As, piv, wp, rhs);             // rhs = k1'
-                double s1[CPL][NS], f1p[CPL][NS], k1p[CPL][NS];
-#pragma unroll
-                for (int q = 0; q < CPL; ++q)
-#pragma unroll
-                    for (int i = 0; i < NS; ++i) { k1p[q][i] = rhs[q][i]; s1[q][i] = fma(0.5 * dt, k1p[q][i], s[q][i]); }
-                col_fp(pt1, s1, f1p);
-                {
-                    double mx[CPL][NS], dummy[CPL][NS];
-                    mixed(1, false, mx, dummy);
-#pragma unroll
-                    for (int q = 0; q < CPL; ++q)
-#pragma unroll
-                        for (int i = 0; i < NS; ++i) rhs[q][i] = fma(gam, mx[q][i], f1p[q][i] - k1p[q][i]);
-                }
-                hys2_solve<NS, CPL>(As, piv, wp, rhs);             // rhs = k2' - k1'
-                double e12[CPL][NS];
 #pragma unroll
                 for (int q = 0; q < CPL; ++q) {
-                    gtry[q] = 0.0;
+                    // the mixed derivative along direction record k (one pass over theta); WITH_T: the first pass also forms (d_t f)'
+                    auto mixed = [&](const int k, const bool with_t, double (&out)[NS], double (&ftp)[NS]) {
+                        const double *th;
+                        HY_FRESH_THETA(th);
+                        const double *rc_ = fresh_rec();
+                        const double *p0 = rc_ + Y_::O_PT + s0 * Y_::PT, *dr = rc_ + Y_::O_DIR + k * Y_::DIR, *tmr = rc_ + Y_::O_TM;
+                        const ColDsc cd = col_dsc(q);
+                        const double tld = tmr[Y_::T_LD], te1 = tmr[Y_::T_E1], te2 = tmr[Y_::T_E2];
+                        const unsigned am = (unsigned)p0[Y_::P_AM];
+                        double Lp = 0.0;
 #pragma unroll
-                    for (int i = 0; i < NS; ++i) { rhs[q][i] += k1p[q][i]; snew[q][i] = fma(dt, rhs[q][i], s[q][i]); }   // rhs = k2'
-                }
-                // the columns' gradient terms at the save points inside (t, tnew] -- tentative until the decision
-                for (int j = jsave; j < nsave; ++j) {
-                    const double ts = ts_lds[j];
-                    if (!(ts <= tnew)) break;
-                    const bool at_end = (ts == tnew);
-                    const double Th = at_end ? 1.0 : (ts - t) / dt;
-                    const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
-                    const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d_) * inv12d;
-                    double v[NS], seed[NS];
-#pragma unroll
-                    for (int i = 0; i < NS; ++i) {
-                        const double k1i = dr0[Y_::V_V + i], k2i = k1i + dr0[Y_::DIR + Y_::V_V + i];
-                        v[i] = at_end ? rec[Y_::O_UN + i] : fma(dt, fma(c1, k1i, c2 * k2i), u[i]);
-                    }
-                    save_primal(v, j, false, seed);
-#pragma unroll
-                    for (int q = 0; q < CPL; ++q)
+                        for (int i = 0; i < NS; ++i) Lp = fma(-p0[Y_::P_SG + i], s[q][i], Lp);
+                        const double Lv = dr[Y_::V_LV], LvLp = Lv * Lp;
+                        double tt[NS], tk[NS], Ap[NS], Bp[NS];
 #pragma unroll
                         for (int i = 0; i < NS; ++i) {
-                            const double vp = at_end ? snew[q][i] : fma(dt, fma(c1, k1p[q][i], c2 * rhs[q][i]), s[q][i]);
+                            const double gx = p0[Y_::P_GX + i];
+                            tt[i] = gx * s[q][i];
+                            tk[i] = gx * tt[i] * dr[Y_::V_V + i];
+                            Ap[i] = 0.0; Bp[i] = 0.0;
+                        }
+                        const bool w_species = cd.wm < NS;
+                        const double xE = p0[Y_::P_X + NS], xw = cd.wv * p0[Y_::P_X + cd.wm];
+                        const double xi = w_species ? cd.wv * dr[Y_::V_XV + (w_species ? cd.wm : 0)] : 0.0;
+                        const double eta_w = (cd.wm == NS + 1) ? cd.wv * te2 : ((w_species && ((am >> cd.wm) & 1u)) ? tld * cd.wv : 0.0);
+#pragma unroll 1
+                        for (int j = 0; j < NR; ++j) {
+                            const double *wi = th + L_::wi(0, j), *wo = th + L_::wo(0, j);
+                            const double Bj = p0[Y_::P_BJ + j], rj = p0[Y_::P_R + j];
+                            const bool hit = (j == cd.wj);
+                            double y = 0.0, z = fma(cd.d[Y_::D_CE + j], xE, cd.d[Y_::D_CB + j]);
+                            z += hit ? xw : 0.0;
+                            z = fma(Lp, Bj, z);
+#pragma unroll
+                            for (int m = 0; m < NS; ++m) {
+                                const double w = wi[m];
+                                z = fma(w, tt[m], z);
+                                y = fma(w, tk[m], y);
+                            }
+                            const double rp = rj * z;
+                            double cB = 0.0;
+                            if (with_t) {
+                                const double eta = fma(cd.d[Y_::D_CE + j], te1, hit ? eta_w : 0.0);
+                                cB = fma(rp, tmr[Y_::T_ZT + j], rj * eta);
+                            }
+                            const double zvp = fma(LvLp, Bj, hit ? xi : 0.0) - y;
+                            const double cA = fma(rp, dr[Y_::V_ZV + j], rj * zvp);
+#pragma unroll
+                            for (int i = 0; i < NS; ++i) {
+                                const double w = wo[i];
+                                Ap[i] = fma(w, cA, Ap[i]);
+                                if (with_t) Bp[i] = fma(w, cB, Bp[i]);
+                            }
+                        }
+                        const double ro = cd.ov * p0[Y_::P_R + cd.oj];
+                        const double exA = ro * dr[Y_::V_ZV + cd.oj], exB = with_t ? ro * tmr[Y_::T_ZT + cd.oj] : 0.0;
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) {
+                            const bool oh = (i == cd.oi);
+                            const double Ki = p0[Y_::P_K + i], fpi = f0p[q][i];
+                            if (with_t) ftp[i] = fma(Ki, (Bp[i] + (oh ? exB : 0.0)) - tmr[Y_::T_BT + i] * Lp, -fpi * tld);
+                            out[i] = fma(Ki, (Ap[i] + (oh ? exA : 0.0)) - dr[Y_::V_A + i] * Lp, -fpi * Lv) - p0[Y_::P_F + i] * LvLp;
+                        }
+                    };
+                    double rhs[1][NS], r3[NS], k1p[NS];
+                    {
+                        double mx[NS], ftp[NS];
+                        mixed(0, true, mx, ftp);
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) {
+                            rhs[0][i] = fma(gam, mx[i] + ftp[i], f0p[q][i]);              // f0' + gam (J' k1 + (d_t f)')
+                            r3[i] = (gam / d_) * ftp[i];                                   // the third stage's gam (dt / gam) (d_t f)'
+                        }
+                    }
+                    hys2_solve<NS, 1>(As, piv, wp, rhs);             // k1'
+                    {
+                        double s1[NS], f1p[NS], mx[NS], dummy[NS];
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) { k1p[i] = rhs[0][i]; s1[i] = fma(0.5 * dt, k1p[i], s[q][i]); }
+                        col_fp(s1_, q, s1, f1p);
+                        mixed(1, false, mx, dummy);
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) {
+                            rhs[0][i] = fma(gam, mx[i], f1p[i] - k1p[i]);
+                            r3[i] += c32 * f1p[i] - 2.0 * (k1p[i] - f0p[q][i]);           // (- c32 k2' follows when k2' exists)
+                        }
+                    }
+                    hys2_solve<NS, 1>(As, piv, wp, rhs);             // k2' - k1'
+                    gtry[q] = 0.0;
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) { rhs[0][i] += k1p[i]; snew[q][i] = fma(dt, rhs[0][i], s[q][i]); }   // rhs = k2'
+                    // the column's gradient terms at the save points inside (t, tnew] -- tentative until the decision
+                    for (int j = jsave; j < nsave; ++j) {
+                        const double ts = ts_lds[j];
+                        if (!(ts <= tnew)) break;
+                        const bool at_end = (ts == tnew);
+                        const double Th = at_end ? 1.0 : (ts - t) / dt;
+                        const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
+                        const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d_) * inv12d;
+                        const double *dr0 = rec + Y_::O_DIR;
+                        double v[NS], seed[NS];
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) {
+                            const double k1i = dr0[Y_::V_V + i], k2i = k1i + dr0[Y_::DIR + Y_::V_V + i];
+                            v[i] = at_end ? rec[Y_::O_UN + i] : fma(dt, fma(c1, k1i, c2 * k2i), u[i]);
+                        }
+                        save_primal(v, j, false, seed);
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) {
+                            const double vp = at_end ? snew[q][i] : fma(dt, fma(c1, k1p[i], c2 * rhs[0][i]), s[q][i]);
                             gtry[q] = fma(seed[i], vp, gtry[q]);
                         }
-                }
-#pragma unroll
-                for (int q = 0; q < CPL; ++q)
-#pragma unroll
-                    for (int i = 0; i < NS; ++i) {
-                        e12[q][i] = fma(-2.0, rhs[q][i], k1p[q][i]);                                             // k1' - 2 k2'
-                        r3[q][i] += -c32 * (rhs[q][i] - f1p[q][i]) - 2.0 * (k1p[q][i] - f0p[q][i]);               // what the third stage keeps of them
                     }
-                col_fp(pt2, snew, f2p);
-                {
-                    double mx[CPL][NS], dummy[CPL][NS];
-                    mixed(2, false, mx, dummy);
-#pragma unroll
-                    for (int q = 0; q < CPL; ++q)
-#pragma unroll
-                        for (int i = 0; i < NS; ++i) rhs[q][i] = fma(gam, mx[q][i], f2p[q][i] + r3[q][i]);
-                }
-                hys2_solve<NS, CPL>(As, piv, wp, rhs);             // rhs = k3'
-#pragma unroll
-                for (int q = 0; q < CPL; ++q)
+                    double e12[NS];
 #pragma unroll
                     for (int i = 0; i < NS; ++i) {
-                        const double de = dt * (1.0 / 6.0) * (e12[q][i] + rhs[q][i]);
+                        e12[i] = fma(-2.0, rhs[0][i], k1p[i]);                               // k1' - 2 k2'
+                        r3[i] = fma(-c32, rhs[0][i], r3[i]);
+                    }
+                    {
+                        double mx[NS], dummy[NS];
+                        col_fp(s2, q, snew[q], f2p[q]);
+                        mixed(2, false, mx, dummy);
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) rhs[0][i] = fma(gam, mx[i], f2p[q][i] + r3[i]);
+                    }
+                    hys2_solve<NS, 1>(As, piv, wp, rhs);             // k3'
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        const double de = dt * (1.0 / 6.0) * (e12[i] + rhs[0][i]);
                         mine[i] = fma(snew[q][i], snew[q][i], mine[i]);
                         mine[NS + i] = fma(de, de, mine[NS + i]);
                     }
+                    CRNN_SCHED_FENCE();
+                }
             }
             group_reduce(mine, tot);                           // (its first fence: all lanes are done with W's factors and the time record)
             if (act) {
@@ -846,11 +811,12 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                     const double k1i = dr0[Y_::V_V + i], k2i = k1i + dr0[Y_::DIR + Y_::V_V + i], k3i = dr0[2 * Y_::DIR + Y_::V_V + i];
                     const double ev = dt * (1.0 / 6.0) * (k1i - 2.0 * k2i + k3i);
                     const double na = fma(u[i], u[i], rec[Y_::O_SSQ + sq * Y_::ev(NS) + i]);
-                    const double nb = fma(unew[i], unew[i], tot[i]);
+                    const double uni = rec[Y_::O_UN + i];
+                    const double nb = fma(uni, uni, tot[i]);
                     const double ee = fma(ev, ev, tot[NS + i]);
                     const double scl = fma(kc->rtol[i], sqrt(fmax(na, nb)), kc->atol[i]);
                     es += ee / (scl * scl);
-                    fin = fin && isfinite(unew[i]) && isfinite(ev);
+                    fin = fin && isfinite(uni) && isfinite(ev);
                 }
                 es *= inv_div;
                 if (!(fin && isfinite(es))) { rc = 3; }
@@ -872,7 +838,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
 #pragma unroll
                             for (int i = 0; i < NS; ++i) {
                                 const double k1i = dr0[Y_::V_V + i], k2i = k1i + dr0[Y_::DIR + Y_::V_V + i];
-                                v[i] = at_end ? unew[i] : fma(dt, fma(c1, k1i, c2 * k2i), u[i]);
+                                v[i] = at_end ? rec[Y_::O_UN + i] : fma(dt, fma(c1, k1i, c2 * k2i), u[i]);
                             }
                             save_primal(v, jsave, true, seed);
                             ++jsave;
@@ -884,7 +850,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                             for (int i = 0; i < NS; ++i) { s[q][i] = snew[q][i]; f0p[q][i] = f2p[q][i]; }
                         }
 #pragma unroll
-                        for (int i = 0; i < NS; ++i) u[i] = unew[i];
+                        for (int i = 0; i < NS; ++i) u[i] = rec[Y_::O_UN + i];
                         if (writer) {
 #pragma unroll
                             for (int i = 0; i < NS; ++i) rec[Y_::O_SSQ + (sq ^ 1) * Y_::ev(NS) + i] = tot[i];
