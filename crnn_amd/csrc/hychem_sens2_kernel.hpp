@@ -61,10 +61,10 @@ struct HyS2Lay {
     // direction record: v[NS] zv[NR] A[NS] xv[NS] Lv
     static constexpr int V_V = 0, V_ZV = NS, V_A = NS + NR, V_XV = 2 * NS + NR, V_LV = 3 * NS + NR, DIR = ev(V_LV + 1);
     // trajectory record: [W's factors, 1 / diagonal | time record] (dead after the column phase: the lanes' partial sums alias them)
-    //                    | three point slots | three direction records | u_new | sum over the chunk's columns of s_i^2
+    //                    | three point slots | three direction records | u and u_new (changing places on accept) | sum over the chunk's columns of s_i^2
     static constexpr int O_LU = 0, LU = ev(NS * NS + NS), O_TM = O_LU + LU, O_RED = 0, RED = L * 2 * NS;
     static constexpr int HEAD = (LU + TM > RED ? LU + TM : ev(RED));
-    static constexpr int O_PT = HEAD, O_DIR = O_PT + 3 * PT, O_UN = O_DIR + 3 * DIR, O_SSQ = O_UN + ev(NS), O_FT = O_SSQ + 2 * ev(NS), REC = O_FT + ev(NS);   // (two buffers of the sums: written for the next step while this one's are read; d_t f)
+    static constexpr int O_PT = HEAD, O_DIR = O_PT + 3 * PT, O_U = O_DIR + 3 * DIR, O_SSQ = O_U + 2 * ev(NS), O_FT = O_SSQ + 2 * ev(NS), REC = O_FT + ev(NS);   // (two buffers of the sums: written for the next step while this one's are read; d_t f)
 };
 
 // true if a dense direction row fits the sparse description (crnn_capi.hip decides on the host which kernel runs)
@@ -349,13 +349,16 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
             return sg;
         };
 
-        double u[NS], s[CPL][NS], f0p[CPL][NS], gsum[CPL];
+        double s[CPL][NS], f0p[CPL][NS], gsum[CPL];
         double t = t0, dt = 0.0, lqold = lqinit, loss_sum = 0.0;
         int iter = 0, jsave = 0, nacc = 0, nrej = 0, rc = valid ? -1 : 0;
         int s0 = 0, s1_ = 1, s2 = 2;          // record slots of the step's three points (s0 and s2 change places on accept)
         int sq = 0;                           // which buffer holds the current sum of squares of the tangent columns
+        int uc = 0;                           // which buffer holds u (the other one takes u_new: the state is per trajectory, not per lane)
+#define HYS2_U(i) rec[Y_::O_U + uc * Y_::ev(NS) + (i)]
+#define HYS2_UNEW(i) rec[Y_::O_U + (uc ^ 1) * Y_::ev(NS) + (i)]
 #pragma unroll
-        for (int i = 0; i < NS; ++i) u[i] = valid ? prm.u0[(size_t)i * prm.B + b] : 1.0;
+        for (int i = 0; i < NS; ++i) { const double v0 = valid ? prm.u0[(size_t)i * prm.B + b] : 1.0; if (writer) HYS2_U(i) = v0; }
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
             gsum[q] = 0.0;
@@ -388,7 +391,10 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
 #pragma unroll
                 for (int i = 0; i < NS; ++i) rec[Y_::O_SSQ + i] = 0.0;       // buffer 0: the tangents start at zero
             }
-            eval_point(s0, u, T, P);
+            double u_[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) u_[i] = prm.u0[(size_t)i * prm.B + b];
+            eval_point(s0, u_, T, P);
         }
         double dt0 = 0.0, d1 = 0.0, sk[NS];
         {
@@ -409,8 +415,9 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                 double d0 = 0.0;
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
-                    sk[i] = frcp(fma(fabs(u[i]), kc->rtol[i], kc->atol[i]));
-                    const double a = u[i] * sk[i], c = pt0[Y_::P_F + i] * sk[i];
+                    const double ui = HYS2_U(i);
+                    sk[i] = frcp(fma(fabs(ui), kc->rtol[i], kc->atol[i]));
+                    const double a = ui * sk[i], c = pt0[Y_::P_F + i] * sk[i];
                     d0 = fma(a, a, d0);
                     d1 = fma(c, c, d1);
                 }
@@ -423,7 +430,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                 dt0 = fmin(dt0, dtmax);
                 double u1[NS];
 #pragma unroll
-                for (int i = 0; i < NS; ++i) u1[i] = fma(dt0, pt0[Y_::P_F + i], u[i]);
+                for (int i = 0; i < NS; ++i) u1[i] = fma(dt0, pt0[Y_::P_F + i], HYS2_U(i));
                 double T, P, Td, Pd;
                 tab(t0 + dt0, seg, T, P, Td, Pd);
                 eval_point(s1_, u1, T, P);
@@ -482,7 +489,10 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
         };
         if (valid && start_saved) {
             double seed[NS];
-            save_primal(u, 0, true, seed);       // the tangents are zero at t0: no gradient term
+            double u_[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) u_[i] = HYS2_U(i);
+            save_primal(u_, 0, true, seed);      // the tangents are zero at t0: no gradient term
             jsave = 1;
         }
 
@@ -575,7 +585,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                 {
                     double u1[NS], T1, P1;
 #pragma unroll
-                    for (int i = 0; i < NS; ++i) u1[i] = fma(0.5 * dt, k1[i], u[i]);
+                    for (int i = 0; i < NS; ++i) u1[i] = fma(0.5 * dt, k1[i], HYS2_U(i));
                     sg1 = tab(t + 0.5 * dt, seg, T1, P1, a_, b_);
                     eval_point(s1_, u1, T1, P1);
 #pragma unroll
@@ -583,7 +593,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                 }
                 hys2_solve<NS, 1>(As, piv, wp, b1);
 #pragma unroll
-                for (int i = 0; i < NS; ++i) { dk[i] = b1[0][i]; unew[i] = fma(dt, k1[i] + dk[i], u[i]); }
+                for (int i = 0; i < NS; ++i) { dk[i] = b1[0][i]; unew[i] = fma(dt, k1[i] + dk[i], HYS2_U(i)); }
                 {
                     double T2, P2;
                     tab(tnew, sg1, T2, P2, a_, b_);
@@ -599,7 +609,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                 for (int i = 0; i < NS; ++i) k3[i] = b1[0][i];
                 if (writer) {
 #pragma unroll
-                    for (int i = 0; i < NS; ++i) rec[Y_::O_UN + i] = unew[i];
+                    for (int i = 0; i < NS; ++i) HYS2_UNEW(i) = unew[i];
                 }
                 // ---- direction records: direction k (k1, k2 - k1, k3, time) by lane k % L of the group -- same code, other data
                 //   u-direction v: Lv = -sum sg_i v_i, xv_m = [C_m window] Lv + gx_m v_m;  time: "Lv" = ld, xv = ([C_m window] ld, e1, e2)
@@ -768,7 +778,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
 #pragma unroll
                         for (int i = 0; i < NS; ++i) {
                             const double k1i = dr0[Y_::V_V + i], k2i = k1i + dr0[Y_::DIR + Y_::V_V + i];
-                            v[i] = at_end ? rec[Y_::O_UN + i] : fma(dt, fma(c1, k1i, c2 * k2i), u[i]);
+                            v[i] = at_end ? HYS2_UNEW(i) : fma(dt, fma(c1, k1i, c2 * k2i), HYS2_U(i));
                         }
                         save_primal(v, j, false, seed);
 #pragma unroll
@@ -810,8 +820,9 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                 for (int i = 0; i < NS; ++i) {
                     const double k1i = dr0[Y_::V_V + i], k2i = k1i + dr0[Y_::DIR + Y_::V_V + i], k3i = dr0[2 * Y_::DIR + Y_::V_V + i];
                     const double ev = dt * (1.0 / 6.0) * (k1i - 2.0 * k2i + k3i);
-                    const double na = fma(u[i], u[i], rec[Y_::O_SSQ + sq * Y_::ev(NS) + i]);
-                    const double uni = rec[Y_::O_UN + i];
+                    const double ui = HYS2_U(i);
+                    const double na = fma(ui, ui, rec[Y_::O_SSQ + sq * Y_::ev(NS) + i]);
+                    const double uni = HYS2_UNEW(i);
                     const double nb = fma(uni, uni, tot[i]);
                     const double ee = fma(ev, ev, tot[NS + i]);
                     const double scl = fma(kc->rtol[i], sqrt(fmax(na, nb)), kc->atol[i]);
@@ -838,7 +849,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
 #pragma unroll
                             for (int i = 0; i < NS; ++i) {
                                 const double k1i = dr0[Y_::V_V + i], k2i = k1i + dr0[Y_::DIR + Y_::V_V + i];
-                                v[i] = at_end ? rec[Y_::O_UN + i] : fma(dt, fma(c1, k1i, c2 * k2i), u[i]);
+                                v[i] = at_end ? HYS2_UNEW(i) : fma(dt, fma(c1, k1i, c2 * k2i), HYS2_U(i));
                             }
                             save_primal(v, jsave, true, seed);
                             ++jsave;
@@ -849,13 +860,12 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
 #pragma unroll
                             for (int i = 0; i < NS; ++i) { s[q][i] = snew[q][i]; f0p[q][i] = f2p[q][i]; }
                         }
-#pragma unroll
-                        for (int i = 0; i < NS; ++i) u[i] = rec[Y_::O_UN + i];
                         if (writer) {
 #pragma unroll
                             for (int i = 0; i < NS; ++i) rec[Y_::O_SSQ + (sq ^ 1) * Y_::ev(NS) + i] = tot[i];
                         }
                         sq ^= 1;
+                        uc ^= 1;                                            // u_new is u
                         { const int tmp_ = s0; s0 = s2; s2 = tmp_; }        // the new point is the next step's first
                         t = tnew;
                         if (q_ >= kc->qsteady_min && q_ <= kc->qsteady_max) q_ = 1.0;

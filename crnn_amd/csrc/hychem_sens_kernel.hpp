@@ -8,38 +8,26 @@
 // this kernel for gradient calls; it is also the only forward-tangent path of the HyChem model (the default gradient is the
 // discrete adjoint, hychem2_kernel.hpp: one forward and one reverse sweep instead of 18 x (1 + 12) forward solves).
 //
-// One launch = one chunk.  Mapping: a GROUP OF 12 LANES per trajectory, one tangent column per lane (five groups per wavefront, four
-// lanes idle); every lane of a group carries the primal redundantly -- hychem_kernel.hpp's point evaluation, analytic Jacobian and
-// pivoted LU (factors parked in LDS), the same operations in the same order in all twelve lanes, so the group never diverges -- and
-// ITS column through EVERY ATTEMPT (the decision needs the tangents), including the third stage's
+// This is the GENERAL kernel of that mode: any twelve directions d theta (dense rows).  The rows of p2vec's Jacobian -- every gradient
+// call of the training loop -- touch one reaction each and run through hychem_sens2_kernel.hpp instead (sparse directions; crnn_capi.hip
+// checks the rows and picks); what arrives here are a caller's own directions through crnn_solve.
+//
+// Mapping: a GROUP OF 12 LANES per trajectory, one tangent column per lane (five groups per wavefront, four lanes idle); every lane of a
+// group carries the primal redundantly -- hychem_kernel.hpp's point evaluation, analytic Jacobian and pivoted LU, the same operations in
+// the same order in all twelve lanes, so the group never diverges; ONE copy of W's factors per trajectory in LDS (the lanes store
+// identical values to one address, reads are broadcasts: 31 KB per block of 128, two blocks per CU) -- and ITS column through EVERY
+// ATTEMPT (the decision needs the tangents), including the third stage's
 //     W k3' = f2' - c32 (k2' - f1') - 2 (k1' - f0') + dt ft' + gam J' k3
-// that only the error estimate uses.  The tangent arithmetic is not hand-derived: the right-hand side is written once over a small
-// dual-number type (hy_f<T>) and evaluated
-//     with first-order duals   (u + eps s, theta + eps dtheta)                          ->  f'            (f1', f2')
-//     with second-order duals  (u + eps s + del v, theta + eps dtheta, t + del tau)     ->  J'[s, dtheta] v + tau ft'   (the mixed part)
-// which is ForwardDiff's own arithmetic (nested partials), without its chunk width.  The group sums the lanes' contributions to the
-// norm by ds_bpermute in lane order, takes the decision, and only then commits the attempt: the new tangent column, the column's
-// gradient increments at the save points inside the step.  Cost: about 12 x 30 right-hand sides per attempt -- this mode exists for
-// parity with the reference's step sequences, not for speed (bench.py reports it).
+// that only the error estimate uses.  The column's tangents are hychem_tan.hpp's closed forms on the primal evaluations the attempt
+// already holds (no logarithm or exponential taken twice; one point for the three mixed derivatives of a step), pinned on the host
+// against the complex step (tests/test_hychem.py); only the two evaluations of the initial step size go through the small dual-number
+// type below (hy_f<T> over first-order duals).  The group sums the lanes' contributions to the norm by ds_bpermute in lane order, takes
+// the decision, and only then commits the attempt: the new tangent column, the column's gradient increments at the save points inside
+// the step.  (Round 4 shipped this kernel with nested duals for everything and a copy of W per lane -- 5.2 KB of scratch, 108 KB of LDS;
+// round 5 ran both variants through the SIMT emulator against the oracle, chunk for chunk, and kept this one: 3.5 KB, 31 KB.)
 #pragma once
 #include "hychem_kernel.hpp"
 #include "hychem_tan.hpp"
-
-// 1: the column's tangents by hychem_tan.hpp's closed forms (one point shared by the three mixed derivatives of a step) instead of hy_f
-// over nested duals.  Written at the end of round 4 WITHOUT device access: the arithmetic is pinned on the host (tests/test_hychem.py),
-// the kernel with the switch on has only been compiled (scratch 5 236 -> 3 528 B per lane, static loop instructions 51 219 -> 37 694, FP64
-// 26 579 -> 16 174: tools/kloop.sh) -- off until the errnorm tests and tools/hy_sens_time.py have run on it (tools/gpu_queued_ab.sh).
-#ifndef CRNN_HY_SENS_CLOSED
-#define CRNN_HY_SENS_CLOSED 0
-#endif
-// 1: ONE copy of W's factors per trajectory instead of one per lane.  The twelve lanes of a group factor the same W (same primal
-// state, same instructions, same bits) and park 81 doubles each: 83 KB of the block's 108 KB of LDS, which is why a CU holds one block
-// of 128 -- two wavefronts, two of its four SIMDs.  With the copy shared (the lanes store identical values to one address; reads are
-// broadcasts within a group and consecutive doubles across the five groups of a wavefront) a block needs 31 KB and two blocks fit
-// (registers: one wavefront per SIMD either way).  Same status as the switch above: compiled, not run.
-#ifndef CRNN_HY_SENS_SHARED_LU
-#define CRNN_HY_SENS_SHARED_LU 0
-#endif
 
 namespace crnn {
 
@@ -137,11 +125,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens_kernel(const SolveParams pr
     __shared__ double ts_lds[kMaxSave];
     __shared__ double th_lds[NTH];
     __shared__ double dth_lds[C * NTH];
-#if CRNN_HY_SENS_SHARED_LU
     constexpr int LUS = (BLOCK / 64) * GPW;     // W's factors of every trajectory: element e of group g at lu_lds[e * LUS + g]
-#else
-    constexpr int LUS = BLOCK;                  // W's factors of every lane (hychem_kernel.hpp's layout)
-#endif
     __shared__ double lu_lds[NS * NS * LUS];
     const int tid = threadIdx.x;
     for (int idx = tid; idx < kNConst; idx += BLOCK) kc_lds[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
@@ -160,11 +144,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens_kernel(const SolveParams pr
     const bool lane_on = grp < GPW;
     const int gbase = grp * C;                  // first lane of the group within the wavefront
     const double *const dthc = dth_lds + (lane_on ? col : 0) * NTH;
-#if CRNN_HY_SENS_SHARED_LU
     double *const As = lu_lds + (tid >> 6) * GPW + (lane_on ? grp : 0);
-#else
-    double *const As = lu_lds + tid;
-#endif
     const int64_t groups_total = (int64_t)(gridDim.x / nch) * (BLOCK / 64) * GPW;      // groups working on this block's chunk
     int64_t traj = ((int64_t)(blockIdx.x / nch) * (BLOCK / 64) + (tid >> 6)) * GPW + grp;
     if (!lane_on) traj = prm.count;             // the idle lanes never start a trajectory
@@ -178,9 +158,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens_kernel(const SolveParams pr
     const double inv_div = sp.mode == 2 ? 1.0 / ((double)NS * (1.0 + (double)sp.dual_partials)) : 1.0 / (double)NS;
 
     typedef Du<double> D1;
-    typedef Du<Du<double>> D2;
     auto th1 = [&](const int m) -> D1 { return D1(th[m], dthc[m]); };
-    auto th2 = [&](const int m) -> D2 { return D2(D1(th[m], dthc[m]), D1(0.0, 0.0)); };
     auto group_sum = [&](const double v) -> double {
         double a = 0.0;
 #pragma unroll
@@ -211,17 +189,6 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens_kernel(const SolveParams pr
 #pragma unroll
             for (int i = 0; i < NS; ++i) fp[i] = fd[i].d;
         };
-        // mixed second derivative at (uu, tq): J'[ss, dtheta] v + tau ft'
-        auto mixed = [&](const double (&uu)[NS], const double (&ss)[NS], const double (&v)[NS], const double tau, const double Tq,
-                         const double Pq, const double Td, const double Pd, double (&out)[NS]) {
-            D2 ud[NS], fd[NS];
-#pragma unroll
-            for (int i = 0; i < NS; ++i) ud[i] = D2(D1(uu[i], ss[i]), D1(v[i], 0.0));
-            hy_f<NS, NR, D2>(th2, kc, hp.inv_R, ud, D2(D1(Tq, 0.0), D1(tau * Td, 0.0)), D2(D1(Pq, 0.0), D1(tau * Pd, 0.0)), fd);
-#pragma unroll
-            for (int i = 0; i < NS; ++i) out[i] = fd[i].d.d;
-        };
-
         double u[NS], s[NS], f0[NS], f0p[NS];
         HyPoint<NS, NR> p0;
         double t = t0, dt = 0.0, lqold = lqinit, loss_sum = 0.0, gsum = 0.0;
@@ -329,7 +296,6 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens_kernel(const SolveParams pr
             double k1p[NS], k2p[NS], snew[NS], f2p[NS];
             {
                 double mx[NS], s1[NS], f1p[NS], dkp[NS], k3p[NS];
-#if CRNN_HY_SENS_CLOSED
                 const HyTanConst tk{kc->lb, kc->ub, hp.inv_R, kc->Ru, kc->imw, kc->gsc};
                 HyTanPt<NS, NR> pt;
                 HyTanCol<NS, NR> cl;
@@ -368,33 +334,20 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens_kernel(const SolveParams pr
                     for (int i = 0; i < NS; ++i) out[i] = fma(tau, cl.ftp[i], out[i]);
                 };
                 mixed_c(k1, 1.0, mx);                                           // J' k1 + ft'
-#else
-                mixed(u, s, k1, 1.0, T, P, Td, Pd, mx);                         // J' k1 + ft'
-#endif
 #pragma unroll
                 for (int i = 0; i < NS; ++i) k1p[i] = fma(gam, mx[i], f0p[i]);
                 lu_solve_lds<NS, LUS>(As, dinv, piv, wp, k1p);
 #pragma unroll
                 for (int i = 0; i < NS; ++i) s1[i] = fma(0.5 * dt, k1p[i], s[i]);
-#if CRNN_HY_SENS_CLOSED
                 jvp_c(p1, s1, f1p);
                 mixed_c(dk, 0.0, mx);                                           // J' (k2 - k1)
-#else
-                jvp(u1, s1, T1, P1, f1p);
-                mixed(u, s, dk, 0.0, T, P, Td, Pd, mx);                         // J' (k2 - k1)
-#endif
 #pragma unroll
                 for (int i = 0; i < NS; ++i) dkp[i] = fma(gam, mx[i], f1p[i] - k1p[i]);
                 lu_solve_lds<NS, LUS>(As, dinv, piv, wp, dkp);
 #pragma unroll
                 for (int i = 0; i < NS; ++i) { k2p[i] = k1p[i] + dkp[i]; snew[i] = fma(dt, k2p[i], s[i]); }
-#if CRNN_HY_SENS_CLOSED
                 jvp_c(p2, snew, f2p);
                 mixed_c(k3, 1.0 / d_, mx);                                      // J' k3 + (dt / gam) ft'
-#else
-                jvp(unew, snew, T2, P2, f2p);
-                mixed(u, s, k3, 1.0 / d_, T, P, Td, Pd, mx);                    // J' k3 + (dt / gam) ft'
-#endif
 #pragma unroll
                 for (int i = 0; i < NS; ++i) k3p[i] = fma(gam, mx[i], f2p[i] - c32 * (k2p[i] - f1p[i]) - 2.0 * (k1p[i] - f0p[i]));
                 lu_solve_lds<NS, LUS>(As, dinv, piv, wp, k3p);

@@ -568,6 +568,50 @@ def test_gpu_hychem_errnorm_sens_matches_oracle_chunk_for_chunk(orc, hfx, mode):
 
 
 @pytest.mark.gpu
+def test_gpu_hychem_sparse_direction_kernel_equals_the_dense_one_and_dense_directions_fall_back(orc, hfx, monkeypatch):
+    """hychem_sens2_kernel (sparse directions: what p2vec's rows are) against hychem_sens_kernel (any directions) on the same calls: the
+    same step counts and the same gradient pieces to rounding -- two statements of the same arithmetic, one launch mode each (one chunk
+    per call; all eighteen chunks in one launch).  A caller's DENSE directions (crnn_solve) do not fit the sparse description: the
+    library checks the rows and runs the dense kernel for them, whatever the override says; the result is the oracle's."""
+    from crnn_amd import p2vec_jac
+    # well-conditioned trajectories only (the fixture's cold condition, varied): on the hot ones a rounding difference moves the step
+    # sequence itself (the test above measures that with the oracle), and two kernels that sum in another order would not be comparable
+    rng = np.random.default_rng(5)
+    u0 = np.stack([hfx["u0"][2] * (1 + 0.1 * rng.standard_normal(9)) for _ in range(7)]); u0[0] = hfx["u0"][2]
+    u0 = np.abs(u0); u0[:, 5] += 1.0 - u0.sum(axis=1)                     # N2 takes up the balance
+    data = np.stack([hfx["data"][k % 3] * (1 + 0.05 * rng.standard_normal()) for k in range(7)])
+    Tt = np.repeat(hfx["Ttab"][2:3], 7, axis=0) * (1 + 0.01 * rng.standard_normal((7, 1))); Pt = np.repeat(hfx["Ptab"][2:3], 7, axis=0)
+    p = hfx["p"]
+    res = {}
+    for name, env in (("sparse", "0"), ("dense", "1")):
+        monkeypatch.setenv("CRNN_HY_SENS_KERNEL", env)
+        node = _node(hfx, u0, data, Tt, Pt, errnorm_sens=2)
+        g0 = node.gradient(p, 0)
+        st = list(node.last_chunk_stats)
+        L, G = node.loss_and_grad(p)
+        res[name] = (g0, st, L, G)
+        node.close()
+    gs, ss, Ls, Gs = res["sparse"]; gd, sd, Ld, Gd = res["dense"]
+    assert ss == sd and len(ss) == 18
+    assert np.max(np.abs(gs - gd)) < 1e-7 * np.max(np.abs(gd))
+    assert Ls == Ld and np.max(np.abs(Gs - Gd)) < 1e-7 * np.max(np.abs(Gd))
+    # dense directions: one chunk of twelve random rows
+    monkeypatch.setenv("CRNN_HY_SENS_KERNEL", "0")
+    th, dth = orc.hychem_p2vec(p)
+    rng = np.random.default_rng(4)
+    dirs = 1e-2 * rng.standard_normal((12, th.size))
+    node = _node(hfx, u0[:1], data[:1], Tt[:1], Pt[:1], errnorm_sens=1)
+    th_d, _ = p2vec_jac(node.pmap, 9, 10, p)
+    _, _, g, ret, nsv = node._solve(node._ctx, 1, th_d, dirs.T, 0, 1, None, False)      # (theta x direction, direction-major in memory)
+    c = orc.make_hychem(dydt_scale=hfx["dydt_scale"], yscale=hfx["yscale"], errnorm_sens=1, dual_partials=12)
+    r = orc.hychem_solve_one(c, th, u0[0], hfx["ts"], Tt[0], Pt[0], data[0], dtheta=dirs)
+    assert ret[0] == r["retcode"] == 0
+    assert (node.last_stats["n_accept"], node.last_stats["n_reject"]) == (r["naccept"], r["nreject"])
+    assert np.max(np.abs(g - r["grad"])) < 1e-6 * np.max(np.abs(r["grad"]))
+    node.close()
+
+
+@pytest.mark.gpu
 def test_gpu_hychem_tape_overflow_degrades_instead_of_failing(hfx, monkeypatch):
     """a HyChem trajectory that outran the adjoint tape aborted the call.  With the tape sized automatically the launch is
     now repeated with a quarter of the resident trajectories (four times the records per lane from the same budget) until the records

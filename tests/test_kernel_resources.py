@@ -61,16 +61,21 @@ def test_dual_norm_kernel_has_no_scratch_and_two_blocks_per_cu(tmp_path):
     assert r["scratch"] == 0 and 2 * r["lds"] <= 163840, r
 
 
-def test_hychem_dual_norm_kernel_scratch_and_its_closed_form_variant(tmp_path):
-    """hychem_sens_kernel spills 5.2 KB per lane (the kernel next in line).  The variant behind
-    -DCRNN_HY_SENS_CLOSED=1 (hychem_tan.hpp's closed forms on the primal evaluations the attempt already holds) must keep compiling and
-    keep its smaller footprint until a round with a device measures it."""
-    HY = "const crnn::SolveParams, const double*, const crnn::HyParams, const crnn::HySensParams"
-    base = _resources(tmp_path, "hychem_sens_kernel.hpp", f"crnn::hychem_sens_kernel<9,10,128>({HY})")
-    closed = _resources(tmp_path, "hychem_sens_kernel.hpp", f"crnn::hychem_sens_kernel<9,10,128>({HY})", flags=("-DCRNN_HY_SENS_CLOSED=1",))
-    assert base["scratch"] <= 5400 and base["lds"] <= 163840, base
-    assert closed["scratch"] <= 3700 and closed["scratch"] < base["scratch"], (base, closed)
-    # -DCRNN_HY_SENS_SHARED_LU=1: W's factors once per trajectory -> two blocks of 128 per CU (four wavefronts instead of two)
-    both = _resources(tmp_path, "hychem_sens_kernel.hpp", f"crnn::hychem_sens_kernel<9,10,128>({HY})",
-                      flags=("-DCRNN_HY_SENS_CLOSED=1", "-DCRNN_HY_SENS_SHARED_LU=1"))
-    assert 2 * both["lds"] <= 163840 and both["scratch"] <= 3700, both
+HY = "const crnn::SolveParams, const double*, const crnn::HyParams, const crnn::HySensParams"
+
+
+def test_hychem_dual_norm_kernels(tmp_path):
+    """The HyChem dual-norm gradient.  hychem_sens2_kernel -- sparse directions, closed-form tangents, one column
+    per lane, the primal spread over the group, the trajectory's state in an LDS record -- is the kernel every gradient call of the
+    training loop runs: 60 B of scratch per lane (three spilled pairs around the exponentials of a point evaluation; round 4's kernel:
+    5 236 B) at a full register file, 100 KB of LDS per block of 256 (20 trajectories).  The two-columns-per-lane instantiation costs
+    1.45x fewer issue slots per trajectory by the static count (tools/isa_attempt_cost.py) but keeps over a kilobyte of scratch: it
+    must keep compiling (the A/B is one template argument away once a device is at hand) and is not what ships.
+    hychem_sens_kernel -- dense directions, the fallback for a caller's own directions -- keeps round 4's closed-form / shared-factor
+    footprint: two blocks of 128 per CU."""
+    fast = _resources(tmp_path, "hychem_sens2_kernel.hpp", f"crnn::hychem_sens2_kernel<9,10,12,256>({HY})")
+    assert fast["scratch"] <= 64 and fast["vgpr"] + fast["agpr"] <= 512 and fast["lds"] <= 163840, fast
+    two = _resources(tmp_path, "hychem_sens2_kernel.hpp", f"crnn::hychem_sens2_kernel<9,10,6,256>({HY})")
+    assert two["lds"] <= 163840, two
+    dense = _resources(tmp_path, "hychem_sens_kernel.hpp", f"crnn::hychem_sens_kernel<9,10,128>({HY})")
+    assert dense["scratch"] <= 3700 and 2 * dense["lds"] <= 163840, dense
