@@ -79,7 +79,7 @@ class CathodeUQ:
     """exp_data: list of arrays [D_s, 1 + n_replicas] (col 0 = time in s, dataset.jl:19-23), heating_rates in K/min."""
 
     def __init__(self, exp_data, heating_rates, p_scales, *, atol=None, rtol=None, maxiters=None, lb_clamp=None, device=0,
-                 normalizer=None, grad_mode=None, tape_every=None, solver=None, errnorm_sens=0):
+                 normalizer=None, grad_mode=None, tape_every=None, solver=None, errnorm_sens=2):
         self.cfg = CathodeConfig()
         check(lib.crnn_cathode_config_default(C.byref(self.cfg)))
         self.cfg.device = device
@@ -93,7 +93,11 @@ class CathodeUQ:
         if solver is not None:         # stepper of the primal calls: "autotsit5_trbdf2" = the reference's `alg` (network.jl:195)
             self.set_solver(solver)
         self.p_scales = np.asarray(p_scales, float)[:17].copy()
-        if errnorm_sens:               # gradient calls as ForwardDiff evaluates them (network.jl:232): chunks of 9 + 8, partials in the error norm
+        # errnorm_sens = 2 (default since round 5): gradient calls as the reference evaluates them (network.jl:232) -- ForwardDiff's chunks of
+        # 9 + 8, every chunk its own adaptive solve with the partials in the error norm.  It is also the ROBUST gradient of this model: on a 5 %
+        # particle cloud the primal-norm adjoint (errnorm_sens = 0: 2.2x faster, the most accurate one where it is accurate) is off by 0.2 ... 1 000
+        # times its largest entry on 3 of 78 trajectories, this one on none (profiles/r04m, r05: tools/cathode_gradient_census.py)
+        if errnorm_sens:
             self._check(lib.crnn_cathode_set_errnorm_sens(self.h, int(errnorm_sens), dptr(np.ascontiguousarray(self.p_scales))))
         self.beta = np.ascontiguousarray(heating_rates, np.float64)
         self.exp_data = [np.asarray(e, float) for e in exp_data]

@@ -1228,6 +1228,9 @@ struct CathCtx {
     int errnorm_sens = 0, sens_occ[2] = {0, 0};   // gradient launches as ForwardDiff evaluates them (crnn_cathode_set_errnorm_sens)
     double *d_dirscale = nullptr;                 // [17] d theta / d p of the chunked dual-norm gradient
     int64_t chunk_stats[4] = {0, 0, 0, 0};        // accepted / rejected steps of the two chunk launches of the last gradient call
+    long long *d_chunk_stats = nullptr;           // the same on the device (summed there behind each chunk launch, read on request)
+    bool chunk_stats_stale = false;
+    double h_dirscale[CRNN_CATHODE_NP] = {};      // the p_scales of crnn_cathode_set_errnorm_sens (checked against crnn_cathode_set_particles)
     int tape_every = CRNN_CATH_TAPE_EVERY;   // adjoint tape: 1 = every step in full, 4 / 8 = checkpoint every 4th / 8th step
     // device-resident SVGD loop (crnn_cathode_set_particles / crnn_cathode_svgd_step)
     double *d_pn = nullptr, *d_pn2 = nullptr, *d_lnp = nullptr, *d_pscales = nullptr;   // particles (current / moved), lnpgrad, [p_scales(17) | mean loss, n_failed]
@@ -1237,6 +1240,13 @@ struct CathCtx {
     hipEvent_t ev2 = nullptr, ev3 = nullptr;
     SvgdWs svgd;
 };
+// sum of the accepted / rejected step counts of a chunk launch into out[0], out[1] (wavefront sums, one atomic per wavefront)
+__global__ __launch_bounds__(256) void cath_sum_counts_kernel(const int32_t *nacc, const int32_t *nrej, int64_t n, long long *out) {
+    long long a = 0, r = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { a += nacc[i]; r += nrej[i]; }
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); r += __shfl_down(r, off); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd((unsigned long long *)out, (unsigned long long)a); atomicAdd((unsigned long long *)out + 1, (unsigned long long)r); }
+}
 int32_t cfail(CathCtx *c, const std::string &msg) {
     g_last_error = msg;
     if (c) c->err = msg;
@@ -2122,7 +2132,7 @@ void crnn_cathode_destroy(crnn_cathode_ctx *ctx) {
     if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
     void *ptrs[] = {c->d_ts, c->d_dbar, c->d_d2bar, c->d_beta, c->d_D, c->d_queue, c->d_theta, c->d_loss, c->d_grad,
                     c->d_hrr, c->d_ret, c->d_nsv, c->d_nacc, c->d_nrej, c->d_tape, c->d_overflow, c->d_ag_send, c->d_ag_recv,
-                    c->d_pn, c->d_pn2, c->d_lnp, c->d_pscales, c->d_dirscale};
+                    c->d_pn, c->d_pn2, c->d_lnp, c->d_pscales, c->d_dirscale, c->d_chunk_stats};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     c->svgd.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -2213,7 +2223,8 @@ int32_t cath_run(CathCtx *c, int64_t n_part, int set_first, int set_count, bool 
         sp.dir_scale = c->d_dirscale; sp.mode = c->errnorm_sens; sp.dual_partials = 9;
         crnn::CathodeParams prs = prm;
         prs.hrr = nullptr; prs.want_grad = 1;
-        std::vector<int32_t> h_a((size_t)ntraj), h_r((size_t)ntraj);
+        if (!c->d_chunk_stats) CHIP(c, hipMalloc((void **)&c->d_chunk_stats, sizeof(long long) * 4));
+        CHIP(c, hipMemsetAsync(c->d_chunk_stats, 0, sizeof(long long) * 4, c->stream));
         for (int ch = 0; ch < 2; ++ch) {
             using SensFn = void (*)(const crnn::CathodeParams, const crnn::CathSensParams);
             const SensFn fn = ch == 0 ? (SensFn)crnn::cathode_sens_kernel<kB, 0> : (SensFn)crnn::cathode_sens_kernel<kB, 1>;
@@ -2225,13 +2236,11 @@ int32_t cath_run(CathCtx *c, int64_t n_part, int set_first, int set_count, bool 
             CHIP(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), c->stream));
             hipLaunchKernelGGL(fn, dim3(nblk), dim3(kB), 0, c->stream, prs, sp);
             CHIP(c, hipGetLastError());
-            CHIP(c, hipMemcpyAsync(h_a.data(), c->d_nacc, sizeof(int32_t) * ntraj, hipMemcpyDeviceToHost, c->stream));
-            CHIP(c, hipMemcpyAsync(h_r.data(), c->d_nrej, sizeof(int32_t) * ntraj, hipMemcpyDeviceToHost, c->stream));
-            CHIP(c, hipStreamSynchronize(c->stream));
-            int64_t sa = 0, sr = 0;
-            for (int64_t i = 0; i < ntraj; ++i) { sa += h_a[i]; sr += h_r[i]; }
-            c->chunk_stats[2 * ch] = sa; c->chunk_stats[2 * ch + 1] = sr;
+            // the chunk's step counts, summed where they are (no copy, no wait: crnn_cathode_last_chunk_stats reads four numbers on request)
+            hipLaunchKernelGGL(cath_sum_counts_kernel, dim3(256), dim3(256), 0, c->stream, c->d_nacc, c->d_nrej, ntraj, c->d_chunk_stats + 2 * ch);
+            CHIP(c, hipGetLastError());
         }
+        c->chunk_stats_stale = true;
         CHIP(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), c->stream));
         prm.grad = nullptr; prm.want_grad = 0;      // the gradient rows are complete; what follows is the plain solve
         want_grad = false;
@@ -2410,6 +2419,7 @@ int32_t crnn_cathode_set_errnorm_sens(crnn_cathode_ctx *ctx, int32_t mode, const
         if (!c->d_dirscale) CHIP(c, hipMalloc((void **)&c->d_dirscale, sizeof(double) * CRNN_CATHODE_NP));
         CHIP(c, hipStreamSynchronize(c->stream));
         CHIP(c, hipMemcpy(c->d_dirscale, p_scales, sizeof(double) * CRNN_CATHODE_NP, hipMemcpyHostToDevice));
+        for (int k = 0; k < CRNN_CATHODE_NP; ++k) c->h_dirscale[k] = p_scales[k];
     }
     c->errnorm_sens = mode;
     return 0;
@@ -2418,6 +2428,14 @@ int32_t crnn_cathode_set_errnorm_sens(crnn_cathode_ctx *ctx, int32_t mode, const
 int32_t crnn_cathode_last_chunk_stats(crnn_cathode_ctx *ctx, int64_t *out /* [4] */) {
     CathCtx *c = reinterpret_cast<CathCtx *>(ctx);
     if (!c || !out) return cfail(c, "crnn_cathode_last_chunk_stats: null");
+    if (c->chunk_stats_stale) {
+        long long h[4];
+        CHIP(c, hipSetDevice(c->cfg.device));
+        CHIP(c, hipMemcpyAsync(h, c->d_chunk_stats, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        CHIP(c, hipStreamSynchronize(c->stream));
+        for (int i = 0; i < 4; ++i) c->chunk_stats[i] = h[i];
+        c->chunk_stats_stale = false;
+    }
     for (int i = 0; i < 4; ++i) out[i] = c->chunk_stats[i];
     return 0;
 }
@@ -2426,6 +2444,9 @@ int32_t crnn_cathode_set_particles(crnn_cathode_ctx *ctx, const double *p, const
     CathCtx *c = reinterpret_cast<CathCtx *>(ctx);
     if (!c) return cfail(nullptr, "null ctx");
     if (!p || !p_scales || n_part < 2) return cfail(c, "crnn_cathode_set_particles: bad arguments (n_part >= 2)");
+    if (c->errnorm_sens != 0)      // the dual-norm gradient weighs partials with d theta / d p: one p_scales for both
+        for (int k = 0; k < CRNN_CATHODE_NP; ++k)
+            if (p_scales[k] != c->h_dirscale[k]) return cfail(c, "crnn_cathode_set_particles: p_scales differ from those given to crnn_cathode_set_errnorm_sens");
     CHIP(c, hipSetDevice(c->cfg.device));
     CHIP(c, hipStreamSynchronize(c->stream));
     if ((size_t)n_part > c->cap_part) {

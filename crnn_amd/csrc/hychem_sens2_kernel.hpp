@@ -176,7 +176,6 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
     }
     __syncthreads();
     const KConst *kc = reinterpret_cast<const KConst *>(kc_lds);
-    const double *th = th_lds;
     const int lane = tid & 63, wave = tid >> 6;
     const int grp = lane / L, sub = lane - grp * L;
     const bool lane_on = grp < GPW;
@@ -512,7 +511,6 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
             const double tnew = last ? tend : t + dt;
             const double *const pt0 = rec + Y_::O_PT + s0 * Y_::PT, *const pt1 = rec + Y_::O_PT + s1_ * Y_::PT, *const pt2 = rec + Y_::O_PT + s2 * Y_::PT;
             const double *const As = rec + Y_::O_LU;
-            const double *const tm = rec + Y_::O_TM;
             int piv[NS];
             bool anyp = false, okf = true;
             double ld = 0.0, e1 = 0.0, e2 = 0.0;

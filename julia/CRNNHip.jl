@@ -307,7 +307,7 @@ mutable struct Cathode
 end
 
 """`l_exp_data[i]` = [t, replicas...] per heating rate (dataset.jl:19-23), `heating_rates` in K/min, `p_scales` = the optimum the particles are scaled by."""
-function Cathode(l_exp_data::Vector{Matrix{Float64}}, heating_rates::Vector{Float64}, p_scales::Vector{Float64})
+function Cathode(l_exp_data::Vector{Matrix{Float64}}, heating_rates::Vector{Float64}, p_scales::Vector{Float64}; errnorm_sens::Integer=2)
     cfg = CathodeConfig()
     check(ccall((:crnn_cathode_config_default, LIB), Int32, (Ref{CathodeConfig},), cfg))
     ctx = Ref{Ptr{Cvoid}}(C_NULL)
@@ -325,6 +325,10 @@ function Cathode(l_exp_data::Vector{Matrix{Float64}}, heating_rates::Vector{Floa
     rc == 0 || error(unsafe_string(ccall((:crnn_cathode_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx[])))
     c = Cathode(ctx[], ns, Dmax, p_scales[1:17])
     finalizer(x -> ccall((:crnn_cathode_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.ctx), c)
+    # errnorm_sens = 2 (default): gradient calls as ForwardDiff.gradient evaluates them (network.jl:232) -- chunks of 9 + 8 partials, every
+    # chunk its own adaptive solve with the partials in the error norm; the robust gradient of this model.  0: the primal-norm adjoint
+    # (2.2x faster; off by orders of magnitude on a few per cent of the trajectories of a particle cloud: profiles/r04m)
+    errnorm_sens == 0 || set_errnorm_sens!(c, errnorm_sens)
     return c
 end
 

@@ -136,6 +136,7 @@ def test_cathode_config_abi():
 
 # ------------------------------------------------------------------ GPU: kernel vs oracle / golden
 def _uq(cfx, **kw):
+    kw.setdefault("errnorm_sens", 0)      # these tests pin the primal-norm adjoint / forward tangents unless they say otherwise
     from crnn_amd.cathode import CathodeUQ
     return CathodeUQ([_two_replicas(s) for s in cfx["sets"]], [s["beta"] for s in cfx["sets"]], cfx["theta"], **kw)
 
@@ -259,7 +260,7 @@ def test_gpu_cathode_many_heating_rates(orc, cfx):
     """More heating rates than the LDS stages (8): observation rows are read in place; same results as the oracle."""
     from crnn_amd.cathode import CathodeUQ
     betas, exp_data = _many_rates(cfx, 24)
-    uq = CathodeUQ(exp_data, betas, cfx["theta"], normalizer=np.ones((24, 3)))
+    uq = CathodeUQ(exp_data, betas, cfx["theta"], normalizer=np.ones((24, 3)), errnorm_sens=0)
     rng = np.random.default_rng(4)
     p = 1 + 0.03 * rng.standard_normal((3, 17))
     p[:, 6:9] = 0.0
@@ -285,7 +286,7 @@ def test_gpu_cathode_config5_full_size(orc, cfx):
     checked against the oracle (same stepper, reference tolerances: step for step)."""
     from crnn_amd.cathode import CathodeUQ
     betas, exp_data = _many_rates(cfx, 256)
-    uq = CathodeUQ(exp_data, betas, cfx["theta"], normalizer=np.ones((256, 3)))
+    uq = CathodeUQ(exp_data, betas, cfx["theta"], normalizer=np.ones((256, 3)), errnorm_sens=0)
     rng = np.random.default_rng(55)
     base = 1 + 1e-3 * rng.standard_normal((16, 17))           # SURVEY 8(d): particles = 1 + 1e-3 N(0,1)
     base[:, 6:9] = 0.0
@@ -469,7 +470,7 @@ def test_gpu_cathode_composite_primal_matches_oracle_composite(orc, cfx, solver,
     the accepted step counts agree to 4 % (rtol 1e-9: 12 %)."""
     from crnn_amd.cathode import CathodeUQ
     th = np.array(cfx["theta"])
-    mk = lambda **kw: CathodeUQ([_two_replicas(s) for s in cfx["sets"]], [s["beta"] for s in cfx["sets"]], cfx["theta"], **kw)
+    mk = lambda **kw: CathodeUQ([_two_replicas(s) for s in cfx["sets"]], [s["beta"] for s in cfx["sets"]], cfx["theta"], errnorm_sens=0, **kw)
     for spread, N in ((1e-3, 16), (0.05, 24)):
         p = _perturbed(spread, N)
         for (atol, rtol), bar_l, bar_h in (((1e-12, 1e-3), 1e-3, 4e-3), ((1e-13, 1e-6), 2e-6, 1e-5), ((1e-14, 1e-9), 1e-8, 1e-7)):
@@ -506,7 +507,7 @@ def test_gpu_cathode_composite_primal_matches_golden_at_tight_tolerance(cfx):
     vectors of the reference's own data (measured 1e-9)."""
     from crnn_amd.cathode import CathodeUQ
     for solver in ("autotsit5_trbdf2", "autotsit5_rosenbrock23"):
-        uq = CathodeUQ([_two_replicas(s) for s in cfx["sets"]], [s["beta"] for s in cfx["sets"]], cfx["theta"], atol=1e-14, rtol=1e-9, solver=solver)
+        uq = CathodeUQ([_two_replicas(s) for s in cfx["sets"]], [s["beta"] for s in cfx["sets"]], cfx["theta"], errnorm_sens=0, atol=1e-14, rtol=1e-9, solver=solver)
         loss, _, hrr = uq.solve(np.ones((1, 17)), want_grad=False, want_hrr=True)
         for i, s in enumerate(cfx["sets"]):
             D = len(s["ts"])
@@ -524,7 +525,7 @@ def test_gpu_cathode_composite_config5_full_size(orc, cfx):
     accepted steps, tiles bit-identical wherever they sat in the queue, 48 random rows within solver tolerance of the oracle."""
     from crnn_amd.cathode import CathodeUQ
     betas, exp_data = _many_rates(cfx, 256)
-    uq = CathodeUQ(exp_data, betas, cfx["theta"], normalizer=np.ones((256, 3)), solver="autotsit5_trbdf2")
+    uq = CathodeUQ(exp_data, betas, cfx["theta"], normalizer=np.ones((256, 3)), solver="autotsit5_trbdf2", errnorm_sens=0)
     rng = np.random.default_rng(55)
     base = 1 + 1e-3 * rng.standard_normal((16, 17))
     base[:, 6:9] = 0.0
@@ -584,7 +585,7 @@ def test_gpu_cathode_errnorm_sens_matches_oracle_chunk_for_chunk(orc, cfx, mode)
     N = 6
     p = _perturbed(0.03, N, seed=17)
     uq = CathodeUQ([_two_replicas(s) for s in cfx["sets"]], [s["beta"] for s in cfx["sets"]], cfx["theta"], errnorm_sens=mode)
-    ref = CathodeUQ([_two_replicas(s) for s in cfx["sets"]], [s["beta"] for s in cfx["sets"]], cfx["theta"])
+    ref = CathodeUQ([_two_replicas(s) for s in cfx["sets"]], [s["beta"] for s in cfx["sets"]], cfx["theta"], errnorm_sens=0)
     loss, grad, hrr = uq.solve(p, want_hrr=True)
     l0, g0, h0 = ref.solve(p, want_hrr=True)
     n_acc_plain = ref.last_stats["n_accept"]

@@ -171,7 +171,7 @@ def cathode(n_part=4096, n_rates=256, reps=3, device=0):
         dbar, d2bar = np.array(s["dbar"]), np.array(s["d2bar"])
         sd = np.sqrt(np.maximum(d2bar - dbar ** 2, 0.0))
         exp_data.append(np.stack([np.array(s["ts"]) * s["beta"] / b, dbar + sd, dbar - sd], axis=1))
-    uq = CathodeUQ(exp_data, betas, fx["theta"], normalizer=np.ones((n_rates, 3)), device=device)
+    uq = CathodeUQ(exp_data, betas, fx["theta"], normalizer=np.ones((n_rates, 3)), device=device, errnorm_sens=0)      # the primal-norm adjoint (opt-in since round 5)
     rng = np.random.default_rng(0)
     p = 1 + 1e-3 * rng.standard_normal((n_part, 17))
     p[:, 6:9] = 0.0

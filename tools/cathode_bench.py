@@ -28,7 +28,7 @@ for b in betas:
     dbar, d2bar = np.array(s["dbar"]), np.array(s["d2bar"])
     sd = np.sqrt(np.maximum(d2bar - dbar ** 2, 0.0))
     exp_data.append(np.stack([np.array(s["ts"]) * s["beta"] / b, dbar + sd, dbar - sd], axis=1))
-uq = CathodeUQ(exp_data, betas, fx["theta"], normalizer=np.ones((args.rates, 3)))
+uq = CathodeUQ(exp_data, betas, fx["theta"], normalizer=np.ones((args.rates, 3)), errnorm_sens=0)
 rng = np.random.default_rng(0)
 p = 1 + 1e-3 * rng.standard_normal((args.particles, 17))          # particles = 1 + 1e-3 N(0,1)
 p[:, 6:9] = 0.0

@@ -42,9 +42,9 @@ for it in range(args.n):
     N = int(rng.integers(1, 9))
     p = 1 + rng.uniform(0.005, 0.1) * rng.standard_normal((N, 17))
     p[:, 6:9] = 0.0
-    uq = CathodeUQ(exp_data, betas, fx["theta"], atol=atol, rtol=rtol, maxiters=maxiters)
+    uq = CathodeUQ(exp_data, betas, fx["theta"], atol=atol, rtol=rtol, maxiters=maxiters, errnorm_sens=0)
     loss, grad, hrr = uq.solve(p, want_hrr=True)
-    fwd = CathodeUQ(exp_data, betas, fx["theta"], atol=atol, rtol=rtol, maxiters=maxiters, grad_mode=1)   # 14 tangent columns
+    fwd = CathodeUQ(exp_data, betas, fx["theta"], atol=atol, rtol=rtol, maxiters=maxiters, grad_mode=1, errnorm_sens=0)   # 14 tangent columns
     _, gfwd, _ = fwd.solve(p)
     for n in range(N):
         for i, (tsb, dbar, d2bar) in enumerate(sets):

@@ -18,10 +18,18 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/benc
 # 3. kernel trace of the same command
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $O/trace -o trace -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_trace.json 2> $O/trace.err )
 python tools/rocpd_summary.py $O > $O/trace_summary.txt 2>&1; head -30 $O/trace_summary.txt | cut -c1-200
-# 4. queued A/B (libraries prebuilt here under crnn_amd/csrc/dbg/, which travels for this call)
-if ls $R/crnn_amd/csrc/dbg/libcrnn_kv_*.so > /dev/null 2>&1; then
-  timeout 900 bash tools/gpu_queued_ab.sh run > $O/queued_ab.txt 2>&1; cat $O/queued_ab.txt | cut -c1-200
+# 4. A/B on the same box: (a) the lane-pair headline kernel with branch-free save-point seeds (-DCRNN_ADJ2_SEEDS_FLAT=1; parity-green under
+#    the SIMT emulator, never timed), libraries prebuilt under crnn_amd/csrc/dbg/ (tools/kvariants.sh build base=... flat=...);
+#    (b) the HyChem dual-norm gradient: hychem_sens2_kernel (sparse directions, default) against hychem_sens_kernel (CRNN_HY_SENS_KERNEL=1)
+if ls $R/crnn_amd/csrc/dbg/libcrnn_kv_flat.so > /dev/null 2>&1; then
+  for rep in 1 2 3; do for v in base flat; do
+    CRNN_HIP_LIB=$R/crnn_amd/csrc/dbg/libcrnn_kv_$v.so timeout 300 python tools/kbench.py --lanes 2 --reps 30 | tail -1 | cut -c1-170
+  done; done > $O/ab_seeds_flat.txt 2>&1; cat $O/ab_seeds_flat.txt
 fi
+for n in 1024 4096 32768; do
+  echo "sparse $n"; timeout 600 python tools/hy_sens_time.py $n
+  if [ $n -le 4096 ]; then echo "dense $n"; CRNN_HY_SENS_KERNEL=1 timeout 900 python tools/hy_sens_time.py $n; fi
+done > $O/ab_hychem_sens.txt 2>&1; cat $O/ab_hychem_sens.txt | cut -c1-200
 # 5. fuzz sweeps on the tree that ships
 for f in fuzz_parity fuzz_hychem fuzz_cathode; do
   timeout 600 python tools/$f.py > $O/$f.txt 2>&1; tail -3 $O/$f.txt | cut -c1-200
