@@ -196,7 +196,7 @@ struct Ctx {
     int lanes_per_traj = 0;         // crnn_ctx_set_lanes_per_traj: 0 = AUTO, 1, 2
     int jac_mode = CRNN_JAC_ANALYTIC;   // crnn_ctx_set_jacobian: W of the Rosenbrock23 primal launches
     int hysens_occ = 0;
-    int hysens2_occ = 0;
+    int hysens2_occ = 0, hysens2c_occ = 0;
     bool hy_dirs_sparse = false;   // the directions of the launch being prepared fit hychem_sens2_kernel's sparse description (set by the entry points)
     int hy_sens_kernel = 0;        // 0: the sparse-direction kernel where the directions fit; 1: always hychem_sens_kernel (measurement / parity: CRNN_HY_SENS_KERNEL)
     int64_t hy_tape_retries = 0;    // HyChem launches repeated with fewer resident trajectories after a tape overflow
@@ -932,7 +932,10 @@ int32_t launch_hychem_sens_chunk(Ctx *c, const double *d_theta, const double *d_
     // two kernels, one result: hychem_sens2_kernel (sparse directions, closed-form tangents, six lanes per trajectory with two columns
     // each) wherever every direction of the launch fits its description -- the rows of p2vec's Jacobian always do --, hychem_sens_kernel
     // (dense directions through nested duals, twelve lanes per trajectory) for arbitrary directions
-    const bool sparse = c->hy_dirs_sparse && c->hy_sens_kernel != 1;
+    const bool comp = c->cfg.solver == CRNN_SOLVER_AUTOTSIT5;      // the reference's composite inside the gradient: the sparse kernel only
+    if (comp && !c->hy_dirs_sparse)
+        return fail(c, "crnn_solve: the dual-norm gradient through AutoTsit5 takes the rows of p2vec's Jacobian (one entry of w_in's species / log T rows and one of w_out per direction); arbitrary directions run with solver = ROSENBROCK23");
+    const bool sparse = comp || (c->hy_dirs_sparse && c->hy_sens_kernel != 1);
     constexpr int kC = 12;
     constexpr int kL2 = 12, kBlk2 = 256, kGroups2 = (kBlk2 / 64) * (64 / kL2);   // (L = 6: two columns per lane, 1.45x fewer issue slots per trajectory by the static count, but 1.2 KB of scratch per lane -- tools/ubench/hy_sens2_probe.hip)
     constexpr int kBlk1 = 128, kGroups1 = (kBlk1 / 64) * (64 / kC);
@@ -940,8 +943,9 @@ int32_t launch_hychem_sens_chunk(Ctx *c, const double *d_theta, const double *d_
     const int ppad = n_chunks > 1 ? P : kC;      // gradient row: the chunk's 12 columns | all chunks in one launch: compact [P]
     const int npart_pad = ppad + crnn::kExtra, npart = P + crnn::kTail;
     using SFn = void (*)(const crnn::SolveParams, const double *, const crnn::HyParams, const crnn::HySensParams);
-    const SFn fn = sparse ? (SFn)crnn::hychem_sens2_kernel<9, 10, kL2, kBlk2> : (SFn)crnn::hychem_sens_kernel<9, 10, kBlk1>;
-    int &occ = sparse ? c->hysens2_occ : c->hysens_occ;
+    const SFn fn = comp ? (SFn)crnn::hychem_sens2_kernel<9, 10, kL2, kBlk2, true>
+                        : sparse ? (SFn)crnn::hychem_sens2_kernel<9, 10, kL2, kBlk2, false> : (SFn)crnn::hychem_sens_kernel<9, 10, kBlk1>;
+    int &occ = comp ? c->hysens2c_occ : sparse ? c->hysens2_occ : c->hysens_occ;
     if (occ < 1) {
         HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, kBlk, 0));
         if (occ < 1) occ = 1;
@@ -1415,9 +1419,10 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
     if (cfg->ns < 1 || cfg->nr < 1 || cfg->ns + cfg->has_temp > CRNN_MAX_N || cfg->nr > CRNN_MAX_NR)
         return fail(nullptr, "crnn_ctx_create: ns/nr out of range");
     if (cfg->errnorm_sens < 0 || cfg->errnorm_sens > 2) return fail(nullptr, "crnn_ctx_create: errnorm_sens must be 0, 1 or 2");
-    if (cfg->errnorm_sens != 0 && (cfg->solver == CRNN_SOLVER_AUTOTSIT5 || cfg->grad_mode == CRNN_GRAD_ADJOINT ||
-                                   (cfg->rhs_kind == CRNN_RHS_HYCHEM && cfg->solver != CRNN_SOLVER_ROSENBROCK23)))
-        return fail(nullptr, "crnn_ctx_create: errnorm_sens = 1 / 2 exists for Rosenbrock23 and Tsit5 (HyChem: Rosenbrock23) with forward tangents (grad_mode AUTO or FORWARD)");
+    // (HyChem: also through the reference's composite, AutoTsit5(Rosenbrock23) -- hychem_sens2_kernel<..., COMPOSITE>)
+    if (cfg->errnorm_sens != 0 && ((cfg->solver == CRNN_SOLVER_AUTOTSIT5 && cfg->rhs_kind != CRNN_RHS_HYCHEM) || cfg->grad_mode == CRNN_GRAD_ADJOINT ||
+                                   (cfg->rhs_kind == CRNN_RHS_HYCHEM && cfg->solver == CRNN_SOLVER_TSIT5)))
+        return fail(nullptr, "crnn_ctx_create: errnorm_sens = 1 / 2 exists for Rosenbrock23 and Tsit5 (HyChem: Rosenbrock23 and AutoTsit5) with forward tangents (grad_mode AUTO or FORWARD)");
     if (cfg->solver != CRNN_SOLVER_ROSENBROCK23 && cfg->solver != CRNN_SOLVER_TSIT5 && cfg->solver != CRNN_SOLVER_AUTOTSIT5)
         return fail(nullptr, "crnn_ctx_create: unknown solver");
     if (cfg->rhs_kind != CRNN_RHS_CRNN && cfg->rhs_kind != CRNN_RHS_HYCHEM) return fail(nullptr, "crnn_ctx_create: unknown rhs_kind");

@@ -32,6 +32,7 @@
 // b % n_chunks as in hychem_sens_kernel.
 #pragma once
 #include "hychem_sens_kernel.hpp"
+#include "auto_adj_kernel.hpp"      // AutoSw, Ts5 (the composite)
 
 namespace crnn {
 
@@ -44,7 +45,7 @@ namespace crnn {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
     } while (0)
 
-template <int NS, int NR, int L>
+template <int NS, int NR, int L, bool COMPOSITE = false>
 struct HyS2Lay {
     static constexpr int NF = NS + 2;
     static constexpr int C = 12, CPL = C / L, GPW = 64 / L;
@@ -64,7 +65,9 @@ struct HyS2Lay {
     //                    | three point slots | three direction records | u and u_new (changing places on accept) | sum over the chunk's columns of s_i^2
     static constexpr int O_LU = 0, LU = ev(NS * NS + NS), O_TM = O_LU + LU, O_RED = 0, RED = L * 2 * NS;
     static constexpr int HEAD = (LU + TM > RED ? LU + TM : ev(RED));
-    static constexpr int O_PT = HEAD, O_DIR = O_PT + 3 * PT, O_U = O_DIR + 3 * DIR, O_SSQ = O_U + 2 * ev(NS), O_FT = O_SSQ + 2 * ev(NS), REC = O_FT + ev(NS);   // (two buffers of the sums: written for the next step while this one's are read; d_t f)
+    static constexpr int O_PT = HEAD, O_DIR = O_PT + 3 * PT, O_U = O_DIR + 3 * DIR, O_SSQ = O_U + 2 * ev(NS), O_FT = O_SSQ + 2 * ev(NS),
+                         // the composite: the seven Tsit5 stage slopes of the primal, the lanes' row sums of |J| (opnorm(J, Inf))
+                         O_KT = O_FT + ev(NS), KT = COMPOSITE ? 7 * ev(NS) : 0, O_EIG = O_KT + KT, REC = O_EIG + (COMPOSITE ? ev(L) : 0);   // (two buffers of the sums: written for the next step while this one's are read; d_t f)
 };
 
 // true if a dense direction row fits the sparse description (crnn_capi.hip decides on the host which kernel runs)
@@ -132,11 +135,16 @@ __device__ __forceinline__ void hys2_solve(const double *As, const int (&piv)[NS
     }
 }
 
-template <int NS, int NR, int L, int BLOCK>
+// COMPOSITE: the reference's own stepper inside the gradient -- AutoTsit5(Rosenbrock23) (crnn_pyrolysis_mass.jl:29) with the chunk's partials
+// in the error norm of BOTH algorithms: a Tsit5 attempt carries the columns through its seven stages (k_s' = f'(g_s; g_s'), the embedded
+// estimate's partials dt sum_j bt_j k_j'), OrdinaryDiffEq's AutoSwitch rule as hychem_auto_kernel.hpp states it decides on the primal's
+// stiffness estimates (Hairer's |k7 - k6| / |g7 - g6| after a Tsit5 attempt, opnorm(J, Inf) after a Rosenbrock23 attempt), the PI exponents
+// are the running algorithm's.  Checked against the oracle's solver = 2 with errnorm_sens (tests/test_hychem.py).
+template <int NS, int NR, int L, int BLOCK, bool COMPOSITE = false>
 __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams prm, const double *__restrict__ theta, const HyParams hp,
                                                              const HySensParams sp) {
     using L_ = LayH<NS, NR>;
-    using Y_ = HyS2Lay<NS, NR, L>;
+    using Y_ = HyS2Lay<NS, NR, L, COMPOSITE>;
     constexpr int NTH = L_::NTH, NF = NS + 2;
     constexpr int C = Y_::C, CPL = Y_::CPL, GPW = Y_::GPW, NWAVE = BLOCK / 64, GPB = NWAVE * GPW, REC = Y_::REC;
     __shared__ double kc_lds[kNConst];
@@ -210,7 +218,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
     // A point evaluation (hy_point's operations, hychem_kernel.hpp) spread over the group: every lane forms the cheap scalar part (clamps,
     // S, rho); the ten logarithms, the ten rates and the nine right-hand-side components are taken by lane (index % L) -- two items per
     // lane -- and meet in the point record.  What the record holds is what the tangents and the Jacobian need: sg, gx, K, f, r, B_j, x.
-    auto eval_point = [&](const int slot, const double (&uu)[NS], const double T, const double P) {
+    auto eval_point = [&](const int slot, const double (&uu)[NS], const double T, const double P, double *kout = nullptr) {
         double *pt = rec + Y_::O_PT + slot * Y_::PT;
         const double *th; const KConst *kc;            // (fresh pointers: theta and the constants are kernel invariants -- read through the
         HY_FRESH_THETA(th); HY_FRESH_KC(kc);           //  outer pointers they are hoisted out of every loop, held, and spilled to scratch)
@@ -285,6 +293,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                 const double gsc = kc->gsc[i], imw = kc->imw[i];
                 if (lane_on) {
                     pt[Y_::P_F + i] = a * gsc * irho;
+                    if (kout) kout[i] = a * gsc * irho;        // (a Tsit5 stage slope of the primal)
                     pt[Y_::P_K + i] = gsc * irho;
                     pt[Y_::P_SG + i] = iy ? imw * iS : 0.0;
                     pt[Y_::P_GX + i] = (iy && ic) ? frcp(yi[h]) : 0.0;
@@ -463,7 +472,8 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                 d2 += d2p;
                 d2 = sqrt(d2 * inv_div) / dt0;
                 const double dm = fmax(d1, d2);
-                const double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : exp(-0.5 * (4.605170185988091368 + flog(dm)));
+                // 10^(-(2 + log10 dm) / (order + 1)) with the order of the STARTING algorithm: Rosenbrock23 2, the composite's Tsit5 4
+                const double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : exp((COMPOSITE ? -0.2 : -0.5) * (4.605170185988091368 + flog(dm)));
                 dt = fmax(kc->dtmin, fmin(fmin(100.0 * dt0, dt1), dtmax));
             }
         }
@@ -495,6 +505,9 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
             jsave = 1;
         }
 
+        int alg = COMPOSITE ? 0 : 1, cnt = 0;   // 0 Tsit5, 1 Rosenbrock23; signed run length of the stiffness verdicts
+        double eig = 0.0;
+        bool have_eig = false;
         while (__builtin_amdgcn_ballot_w64(rc < 0) != 0) {
             bool act = rc < 0;
             bool last = false;
@@ -503,10 +516,17 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                 if (jsave >= nsave) { rc = 0; act = false; }
                 else if (iter > prm.maxiters) { rc = 1; act = false; }
                 else {
+                    if (COMPOSITE && have_eig) {   // choose_algorithm! at the loop header (hychem_auto_kernel.hpp)
+                        const bool stiff = fabs(eig * dt * (1.0 / AutoSw::stability_size)) > AutoSw::tol;      // (false for NaN)
+                        cnt = stiff ? (cnt < 0 ? 1 : cnt + 1) : (cnt > 0 ? -1 : cnt - 1);
+                        if (alg == 0 && cnt > AutoSw::maxstiffstep) { dt *= AutoSw::dtfac; alg = 1; }
+                        else if (alg == 1 && cnt < -AutoSw::maxnonstiffstep) { dt *= 1.0 / AutoSw::dtfac; alg = 0; }
+                    }
                     if (t + dt * (1.0 + 1e-13) >= tend) { dt = tend - t; last = true; }
                     if (!(dt > kc->dtmin) || t + dt == t) { rc = 2; act = false; }
                 }
             }
+            const bool act_r = act && (!COMPOSITE || alg == 1), act_t = act && COMPOSITE && alg == 0;     // this attempt's algorithm
             const double gam = d_ * dt;
             const double tnew = last ? tend : t + dt;
             const double *const pt0 = rec + Y_::O_PT + s0 * Y_::PT, *const pt1 = rec + Y_::O_PT + s1_ * Y_::PT, *const pt2 = rec + Y_::O_PT + s2 * Y_::PT;
@@ -516,7 +536,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
             double ld = 0.0, e1 = 0.0, e2 = 0.0;
             // ---- primal, first stage.  W = I - gam J and ft = d_t f from the point record (hy_jac_ft's operations on the recorded
             //      sg, gx, K, f, r, B_j), ROWS sub and sub + L by this lane; they meet in the record's matrix cells
-            if (act) {
+            if (act_r) {
                 const double *th;
                 HY_FRESH_THETA(th);
                 double T, P, Td, Pd;
@@ -526,6 +546,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
 #pragma unroll
                 for (int j = 0; j < NR; ++j) zd[j] = fma(pt0[Y_::P_BJ + j], ld, fma(th[L_::wi(NS, j)], e1, th[L_::wi(NS + 1, j)] * e2));
                 constexpr int NROW = (NS + L - 1) / L;
+                double rowmax = 0.0;
 #pragma unroll 1
                 for (int h = 0; h < NROW; ++h) {              // (rolled: unrolled, the 90 reads of w_in are shared by the rows and held in 180 registers)
                     const int i = min(sub + h * L, NS - 1);
@@ -538,20 +559,29 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                         tz = fma(a[j], zd[j], tz);
                     }
                     if (lane_on) rec[Y_::O_FT + i] = fma(-fi, ld, tz);
+                    double rsum = 0.0;
 #pragma unroll
                     for (int c = 0; c < NS; ++c) {
                         double s_ = 0.0;
 #pragma unroll
                         for (int j = 0; j < NR; ++j) s_ = fma(a[j], th[L_::wi(c, j)], s_);
                         const double Jic = fma(pt0[Y_::P_GX + c], s_, -pt0[Y_::P_SG + c] * (tB - fi));
+                        rsum += fabs(Jic);
                         if (lane_on) rec[Y_::O_LU + i * NS + c] = ((i == c) ? 1.0 : 0.0) - gam * Jic;
                     }
+                    if (COMPOSITE) { rowmax = fmax(rowmax, rsum); }
                     CRNN_SCHED_FENCE();
                 }
+                if (COMPOSITE && lane_on) rec[Y_::O_EIG + sub] = rowmax;          // this lane's share of opnorm(J, Inf)
             }
             HYS2_SYNC();                                       // the rows of W are in the record
-            if (act) {
+            if (act_r) {
                 // every lane factors W (the same operations on the same numbers: the pivot order is the group's); the first lane parks the factors
+                if (COMPOSITE) {               // eigen_est of a stiff attempt: opnorm(J, Inf), the group's lanes hold the row sums
+                    double e_ = 0.0;
+                    for (int l = 0; l < L; ++l) e_ = fmax(e_, rec[Y_::O_EIG + l]);
+                    eig = e_; have_eig = true;
+                }
                 double A[NS][NS], dinv[NS];
 #pragma unroll
                 for (int i = 0; i < NS; ++i)
@@ -568,9 +598,9 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                     }
                 }
             }
-            const bool wp = __builtin_amdgcn_ballot_w64(act && anyp) != 0;
+            const bool wp = __builtin_amdgcn_ballot_w64(act_r && anyp) != 0;
             HYS2_SYNC();                                       // W's factors are in the record
-            if (act) {
+            if (act_r) {
                 // ---- primal, the three stage solves; the points are evaluated by the group into the record
                 double b1[1][NS], k1[NS], dk[NS], k3[NS], unew[NS];
 #pragma unroll
@@ -669,7 +699,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
             double snew[CPL][NS], f2p[CPL][NS], gtry[CPL], mine[2 * NS], tot[2 * NS];
 #pragma unroll
             for (int k = 0; k < 2 * NS; ++k) mine[k] = 0.0;
-            if (act) {
+            if (act_r) {
 #pragma unroll
                 for (int q = 0; q < CPL; ++q) {
                     // the mixed derivative along direction record k (one pass over theta); WITH_T: the first pass also forms (d_t f)'
@@ -808,16 +838,128 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                     CRNN_SCHED_FENCE();
                 }
             }
+            if (COMPOSITE && act_t) {
+                // ---- a Tsit5 attempt with the columns: stage s at t + c_s dt on the tables (the seventh at the step's end time).  The primal's
+                //      slopes meet in the record (KT), the stage point is evaluated by the group into a slot and read by the columns.
+                double *const KTr = rec + Y_::O_KT;
+                double kp[CPL][7][NS];
+                if (writer) {
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) KTr[i] = pt0[Y_::P_F + i];                  // k_1 = f0 (FSAL)
+                }
+#pragma unroll
+                for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) kp[q][0][i] = f0p[q][i];
+                int sgq = seg;
+#pragma unroll
+                for (int st = 1; st < 7; ++st) {
+                    HYS2_SYNC();                       // the slopes so far are in the record; the slot's previous contents have been read
+                    double g[NS];
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        double a = 0.0;
+#pragma unroll
+                        for (int j = 0; j < 6; ++j)
+                            if (j < st) a = fma(Ts5::a(st - 1, j), KTr[j * Y_::ev(NS) + i], a);
+                        g[i] = fma(dt, a, HYS2_U(i));
+                    }
+                    const double tq = st == 6 ? tnew : st == 5 ? t + dt : fma(st == 1 ? Ts5::c2 : st == 2 ? Ts5::c3 : st == 3 ? Ts5::c4 : Ts5::c5, dt, t);
+                    double Tq, Pq, a_, b_;
+                    sgq = tab(tq, st == 1 ? seg : sgq, Tq, Pq, a_, b_);
+                    const int slot = st == 6 ? s2 : s1_;
+                    eval_point(slot, g, Tq, Pq, KTr + st * Y_::ev(NS));
+                    if (st == 6 && writer) {
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) HYS2_UNEW(i) = g[i];
+                    }
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q) {
+                        double gs[NS];
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) {
+                            double a = 0.0;
+#pragma unroll
+                            for (int j = 0; j < 6; ++j)
+                                if (j < st) a = fma(Ts5::a(st - 1, j), kp[q][j][i], a);
+                            gs[i] = fma(dt, a, s[q][i]);
+                        }
+                        col_fp(slot, q, gs, kp[q][st]);
+                        if (st == 6) {
+#pragma unroll
+                            for (int i = 0; i < NS; ++i) { snew[q][i] = gs[i]; f2p[q][i] = kp[q][6][i]; }
+                        }
+                    }
+                    CRNN_SCHED_FENCE();
+                }
+                HYS2_SYNC();                           // (the seventh slope and u_new are in the record)
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) {
+                    gtry[q] = 0.0;
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        double a = 0.0;
+#pragma unroll
+                        for (int j = 0; j < 7; ++j) a = fma(Ts5::bt(j), kp[q][j][i], a);
+                        const double de = dt * a;                                            // the embedded estimate's partial
+                        mine[i] = fma(snew[q][i], snew[q][i], mine[i]);
+                        mine[NS + i] = fma(de, de, mine[NS + i]);
+                    }
+                }
+                // the columns' gradient terms at the save points inside (t, tnew] -- tentative until the decision (Tsit5's free interpolant)
+                for (int j = jsave; j < nsave; ++j) {
+                    const double ts = ts_lds[j];
+                    if (!(ts <= tnew)) break;
+                    const bool at_end = (ts == tnew);
+                    double bth[7], v[NS], seed[NS];
+                    Ts5::dense(at_end ? 1.0 : (ts - t) / dt, bth);
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        double a = 0.0;
+#pragma unroll
+                        for (int jj = 0; jj < 7; ++jj) a = fma(bth[jj], KTr[jj * Y_::ev(NS) + i], a);
+                        v[i] = at_end ? HYS2_UNEW(i) : fma(dt, a, HYS2_U(i));
+                    }
+                    save_primal(v, j, false, seed);
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) {
+                            double a = 0.0;
+#pragma unroll
+                            for (int jj = 0; jj < 7; ++jj) a = fma(bth[jj], kp[q][jj][i], a);
+                            const double vp = at_end ? snew[q][i] : fma(dt, a, s[q][i]);
+                            gtry[q] = fma(seed[i], vp, gtry[q]);
+                        }
+                }
+            }
             group_reduce(mine, tot);                           // (its first fence: all lanes are done with W's factors and the time record)
             if (act) {
                 // ---- the dual-inclusive norm, the decision, the commit
                 const double *const dr0 = rec + Y_::O_DIR;
                 double es = 0.0;
                 bool fin = okf;
+                const double *const KTr = rec + Y_::O_KT;
+                double est = 0.0;
+                bool est_nan = false;
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
-                    const double k1i = dr0[Y_::V_V + i], k2i = k1i + dr0[Y_::DIR + Y_::V_V + i], k3i = dr0[2 * Y_::DIR + Y_::V_V + i];
-                    const double ev = dt * (1.0 / 6.0) * (k1i - 2.0 * k2i + k3i);
+                    double ev;
+                    if (COMPOSITE && alg == 0) {           // Tsit5: the embedded estimate; Hairer's stiffness estimate |k7 - k6| / |g7 - g6| (Inf norm, primal)
+                        double a = 0.0, a6 = 0.0;
+#pragma unroll
+                        for (int j = 0; j < 7; ++j) a = fma(Ts5::bt(j), KTr[j * Y_::ev(NS) + i], a);
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) a6 = fma(Ts5::a(4, j), KTr[j * Y_::ev(NS) + i], a6);
+                        ev = dt * a;
+                        const double g6 = fma(dt, a6, HYS2_U(i));
+                        const double qq = fabs((KTr[6 * Y_::ev(NS) + i] - KTr[5 * Y_::ev(NS) + i]) / (HYS2_UNEW(i) - g6));
+                        est_nan = est_nan || (qq != qq);
+                        est = (qq > est) ? qq : est;
+                    } else {
+                        const double k1i = dr0[Y_::V_V + i], k2i = k1i + dr0[Y_::DIR + Y_::V_V + i], k3i = dr0[2 * Y_::DIR + Y_::V_V + i];
+                        ev = dt * (1.0 / 6.0) * (k1i - 2.0 * k2i + k3i);
+                    }
                     const double ui = HYS2_U(i);
                     const double na = fma(ui, ui, rec[Y_::O_SSQ + sq * Y_::ev(NS) + i]);
                     const double uni = HYS2_UNEW(i);
@@ -828,12 +970,16 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                     fin = fin && isfinite(uni) && isfinite(ev);
                 }
                 es *= inv_div;
+                if (COMPOSITE && alg == 0) { eig = est_nan ? __longlong_as_double(0x7ff8000000000000LL) : est; have_eig = true; }
                 if (!(fin && isfinite(es))) { rc = 3; }
                 else {
+                    // PI exponents: the running algorithm's in the composite (Tsit5 7/50, 2/25; Rosenbrock23 7/20, 2/10), the context's otherwise
+                    const double b1_ = COMPOSITE ? (alg == 0 ? 7.0 / 50.0 : 7.0 / 20.0) : kc->beta1;
+                    const double b2_ = COMPOSITE ? (alg == 0 ? 2.0 / 25.0 : 2.0 / 10.0) : kc->beta2;
                     const bool ee_zero = (es == 0.0);
                     const double lEE = 0.5 * flog(ee_zero ? 1.0 : es);
-                    const double lq11 = kc->beta1 * lEE;
-                    double q_ = ee_zero ? 1.0 / kc->qmax : fmax(1.0 / kc->qmax, fmin(1.0 / kc->qmin, exp(lq11 - kc->beta2 * lqold) / kc->gamma));
+                    const double lq11 = b1_ * lEE;
+                    double q_ = ee_zero ? 1.0 / kc->qmax : fmax(1.0 / kc->qmax, fmin(1.0 / kc->qmin, exp(lq11 - b2_ * lqold) / kc->gamma));
                     if (es <= 1.0) {
                         ++nacc;
                         while (jsave < nsave) {
@@ -844,10 +990,22 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                             const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
                             const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d_) * inv12d;
                             double v[NS], seed[NS];
+                            if (COMPOSITE && alg == 0) {
+                                double bth[7];
+                                Ts5::dense(Th, bth);
 #pragma unroll
-                            for (int i = 0; i < NS; ++i) {
-                                const double k1i = dr0[Y_::V_V + i], k2i = k1i + dr0[Y_::DIR + Y_::V_V + i];
-                                v[i] = at_end ? HYS2_UNEW(i) : fma(dt, fma(c1, k1i, c2 * k2i), HYS2_U(i));
+                                for (int i = 0; i < NS; ++i) {
+                                    double a = 0.0;
+#pragma unroll
+                                    for (int jj = 0; jj < 7; ++jj) a = fma(bth[jj], KTr[jj * Y_::ev(NS) + i], a);
+                                    v[i] = at_end ? HYS2_UNEW(i) : fma(dt, a, HYS2_U(i));
+                                }
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < NS; ++i) {
+                                    const double k1i = dr0[Y_::V_V + i], k2i = k1i + dr0[Y_::DIR + Y_::V_V + i];
+                                    v[i] = at_end ? HYS2_UNEW(i) : fma(dt, fma(c1, k1i, c2 * k2i), HYS2_U(i));
+                                }
                             }
                             save_primal(v, jsave, true, seed);
                             ++jsave;

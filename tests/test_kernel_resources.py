@@ -73,8 +73,10 @@ def test_hychem_dual_norm_kernels(tmp_path):
     must keep compiling (the A/B is one template argument away once a device is at hand) and is not what ships.
     hychem_sens_kernel -- dense directions, the fallback for a caller's own directions -- keeps round 4's closed-form / shared-factor
     footprint: two blocks of 128 per CU."""
-    fast = _resources(tmp_path, "hychem_sens2_kernel.hpp", f"crnn::hychem_sens2_kernel<9,10,12,256>({HY})")
+    fast = _resources(tmp_path, "hychem_sens2_kernel.hpp", f"crnn::hychem_sens2_kernel<9,10,12,256,false>({HY})")
     assert fast["scratch"] <= 64 and fast["vgpr"] + fast["agpr"] <= 512 and fast["lds"] <= 163840, fast
+    comp = _resources(tmp_path, "hychem_sens2_kernel.hpp", f"crnn::hychem_sens2_kernel<9,10,12,256,true>({HY})")       # through AutoTsit5(Rosenbrock23)
+    assert comp["scratch"] <= 128 and comp["lds"] <= 163840, comp
     two = _resources(tmp_path, "hychem_sens2_kernel.hpp", f"crnn::hychem_sens2_kernel<9,10,6,256>({HY})")
     assert two["lds"] <= 163840, two
     dense = _resources(tmp_path, "hychem_sens_kernel.hpp", f"crnn::hychem_sens_kernel<9,10,128>({HY})")
