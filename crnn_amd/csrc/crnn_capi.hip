@@ -200,6 +200,8 @@ struct Ctx {
     bool hy_dirs_sparse = false;   // the directions of the launch being prepared fit hychem_sens2_kernel's sparse description (set by the entry points)
     int hy_sens_kernel = 0;        // 0: the sparse-direction kernel where the directions fit; 1: always hychem_sens_kernel (measurement / parity: CRNN_HY_SENS_KERNEL)
     int64_t hy_tape_retries = 0;    // HyChem launches repeated with fewer resident trajectories after a tape overflow
+    int hy_block_cap = 0;           // the block count such a repetition found to fit: later launches over the same range start from it
+    int64_t hy_cap_first = -1, hy_cap_count = -1;   // (without it every later step overflowed, drained and relaunched again)
     int last_lanes = 0;             // lanes per trajectory of the most recent adjoint launch (0: another kernel family ran)
     // deferred outcome of adjoint training steps (crnn_train_step): see check_pending
     bool defer_next = false, last_deferred = false, force_forward = false;
@@ -749,6 +751,7 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
     if (occ < 1) occ = 1;
     const int64_t need_blocks = (count + 127) / 128;
     int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(need_blocks, (int64_t)c->num_cu * occ));
+    if (max_blocks == 0 && P > 0 && c->hy_block_cap > 0 && c->hy_cap_first == first && c->hy_cap_count == count) max_blocks = c->hy_block_cap;
     if (max_blocks > 0) nblk = std::min(nblk, max_blocks);
     const size_t lanes = (size_t)nblk * 128;      // resident trajectories = tape slots
     const size_t recw = (size_t)c->cfg.ns + 2;
@@ -846,6 +849,7 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
         c->hy_tape_retries++;
         return launch_hychem(c, d_theta, d_dtheta, P, first, count, n_save_active, want_pred, std::max(1, nblk / 4));
     }
+    if (max_blocks > 0 && P > 0) { c->hy_block_cap = nblk; c->hy_cap_first = first; c->hy_cap_count = count; }     // what fitted
     return 0;
 }
 
@@ -1555,6 +1559,7 @@ static int32_t set_data_common(Ctx *c, const double *tsteps, const double *yscal
     c->n_obs = n_obs;
     c->kc_dirty = true;
     c->steps_first = 0; c->steps_count = 0;     // a new ensemble: no step counts known yet
+    c->hy_block_cap = 0; c->hy_cap_first = c->hy_cap_count = -1;
     c->perm_ready = false;
     for (int j = 1; j < c->cfg.n_save; ++j)
         if (!(tsteps[j] > tsteps[j - 1])) return fail(c, "crnn_ctx_set_data: tsteps must be strictly increasing");

@@ -103,7 +103,10 @@ typedef struct crnn_config {
                                      dual-inclusive norm, chunked like ForwardDiff.pickchunksize -- what the reference's
                                      ForwardDiff.gradient through the adaptive solver does (case2/case2.jl:195); Rosenbrock23 and
                                      Tsit5, forward tangents (grad_mode AUTO or FORWARD); round 4: also the HyChem right-hand side
-                                     (Rosenbrock23; crnn_pyrolysis_mass.jl:201: 211 parameters in 18 chunks of 12).  crnn_solve then
+                                     (crnn_pyrolysis_mass.jl:201: 211 parameters in 18 chunks of 12) -- round 5: at speed
+                                     (hychem_sens2_kernel: the rows of p2vec's Jacobian are sparse, one reaction each; a caller's
+                                     dense directions run the general hychem_sens_kernel), and with solver = AUTOTSIT5 through the
+                                     reference's own composite, the partials in both algorithms' norms (:29).  crnn_solve then
                                      treats its n_dir directions as ONE chunk (n_dir <= 9 case2, 12 case1 / robertson / HyChem);
                                      crnn_loss_grad / crnn_train_step run ForwardDiff's chunks, loss and statistics from a
                                      final plain solve.  The squared norm is divided by length(u) -- DiffEqBase of the Julia-1.6
@@ -228,12 +231,13 @@ int32_t crnn_ctx_set_lanes_per_traj(crnn_ctx *ctx, int32_t lanes);
 int32_t crnn_last_lanes_per_traj(const crnn_ctx *ctx);
 /* Jacobian behind W = I - gam J of the Rosenbrock23 stepper in PRIMAL launches (crnn_solve with n_dir = 0: predict_neuralode,
  * loss_neuralode, the epoch-end loop).  ANALYTIC (default): the exact J -- what Rosenbrock23(autodiff = true) forms
- * (robertson/rober_crnn.jl:33).  FINITE_DIFF: what Rosenbrock23(autodiff = false) forms (case2/case2.jl:26,
- * robertson/rober_crnn_lm.jl:34): forward differences of the right-hand side, column c = (f(u + eps_c e_c) - f(u)) / eps_c with
+ * (robertson/rober_crnn.jl:33).  FINITE_DIFF: what Rosenbrock23(autodiff = false) forms (the stiff algorithm inside case2's
+ * AutoTsit5(Rosenbrock23(autodiff=false)), case2/case2.jl:26 -- a context with solver = AUTOTSIT5 has NO finite-difference
+ * variant, the mode is refused there; robertson/rober_crnn_lm.jl:34): forward differences of the right-hand side, column c = (f(u + eps_c e_c) - f(u)) / eps_c with
  * eps_c = max(sqrt(eps) |u_c|, sqrt(eps)) (FiniteDiff.jl's default step for forward differences, restated -- FiniteDiff is
  * not vendored with the reference), ns more right-hand sides per attempt and a dense ns x ns factorisation.  Rosenbrock23 is a
- * W-method, so both are Rosenbrock23 solves of the same problem: results differ by ~1e-8 relative in J, ~1e-9 in a loss at
- * the reference's tolerances.  Gradient launches are not affected: they differentiate the analytic-W step (the reference
+ * W-method, so both are Rosenbrock23 solves of the same problem: results differ by ~1e-8 relative in J; in a loss at the
+ * reference's tolerances by ~2e-9 on case2 and 3e-4 ... 1.3e-3 on robertson (stiffness 1e11: tests/test_gpu_primal.py).  Gradient launches are not affected: they differentiate the analytic-W step (the reference
  * pushes Duals through FiniteDiff's increments).  CRNN right-hand side with Rosenbrock23 only (not HyChem,
  * whose reference Jacobian also carries a finite-difference time derivative). */
 enum { CRNN_JAC_ANALYTIC = 0, CRNN_JAC_FINITE_DIFF = 1 };
@@ -402,6 +406,9 @@ int32_t crnn_cathode_set_tape_every(crnn_cathode_ctx *ctx, int32_t every);
  *   CRNN_CATH_SOLVER_AUTOTSIT5_TRBDF2  the reference's composite: Tsit5 + OrdinaryDiffEq's AutoSwitch + TRBDF2 (Newton iteration,
  *                                      Jacobian / W reuse, smoothed error estimate) -- 114 accepted steps per trajectory
  *   CRNN_CATH_SOLVER_AUTOTSIT5_ROS23   the same composite with Rosenbrock23 as its stiff algorithm
+ * PARITY MODES, SLOWER than the default: 17.8 ms (TRBDF2) / 17.2 ms (ROS23) per 4 096 x 256 launch against Rosenbrock23's 15.6 -- a
+ * Tsit5 attempt is six right-hand sides with their logarithms and exponentials, a Rosenbrock23 attempt two; a third of the steps does
+ * not buy a third of the time (profiles/r04i).  They exist so that a primal launch can be the reference's own algorithm.
  * All restated from the published algorithms ([UNVERIFIED-DEP]: the packages are not in the reference tree; oracle/crnn_oracle.c
  * states every branch).  GRADIENT launches are not affected: they run the L-stable Rosenbrock23 discrete adjoint whatever this
  * setting (the adjoint through Tsit5's steps is unstable for this model: cathode_auto_kernel.hpp).  Results of the three agree to
