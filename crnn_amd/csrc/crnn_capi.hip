@@ -2675,7 +2675,7 @@ hipError_t svgd_enqueue(SvgdWs &w, hipStream_t stream, const double *d_p, const 
         hipLaunchKernelGGL(crnn::svgd_rows_dev_kernel, grid, dim3(256), 0, stream, d_p, d_g, N, dim, (const crnn::SvgdSel *)w.d_sel,
                            w.nchunk, w.d_part);
     hipLaunchKernelGGL(crnn::svgd_update_dev_kernel, dim3((unsigned)(((size_t)N * dim + 255) / 256)), dim3(256), 0, stream, d_p,
-                       (const double *)w.d_part, N, dim, w.nchunk, (const crnn::SvgdSel *)w.d_sel, stepsize / (double)N, d_new, d_dt, d_rep);
+                       (const double *)w.d_part, N, dim, w.nchunk, (crnn::SvgdSel *)w.d_sel, stepsize / (double)N, d_new, d_dt, d_rep);
     return hipGetLastError();
 }
 

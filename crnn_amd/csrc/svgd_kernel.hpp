@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void svgd_rows_dev_kernel(const double *__rest
 // the move with the bandwidth from the device state; p_new may alias nothing (p is read by every thread's row sums only
 // through `partial`, so p_new == p would also be safe: each thread reads and writes its own element)
 __global__ __launch_bounds__(256) void svgd_update_dev_kernel(const double *__restrict__ p, const double *__restrict__ partial,
-                                                              int64_t N, int dim, int nchunk, const SvgdSel *__restrict__ st,
+                                                              int64_t N, int dim, int nchunk, SvgdSel *st,          // (not const: the sticky `bad` flag is written here)
                                                               double step_over_n, double *p_new, double *__restrict__ data_term,
                                                               double *__restrict__ repulsion) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void svgd_update_dev_kernel(const double *__re
     // the particles stay where they are and the state says so (the host checks `bad` where it looks at the loop)
     const double hh = st->h;
     const bool ok = hh > 0.0 && hh < INFINITY;
-    if (!ok && idx == 0) const_cast<SvgdSel *>(st)->bad = 1;
+    if (!ok && idx == 0) st->bad = 1;
     p_new[idx] = ok ? pv + step_over_n * (sg + rep) : pv;
 }
 
