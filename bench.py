@@ -98,6 +98,9 @@ def main():
     import torch.distributed as dist
 
     import crnn_amd
+    from crnn_amd import _lib as _L
+    if "SIMT-EMULATION" in _L.lib.crnn_build_info().decode():      # (tests/simt: the kernels' sources on host fibres -- a checker, never a measurement)
+        raise SystemExit("bench.py: CRNN_HIP_LIB points at the SIMT emulation library; a bench line needs the gfx950 library on an MI355X")
     from crnn_amd import NeuralODE, ODEProblem, Optimiser, PRESET_CASE2, SOLVER_AUTOTSIT5, SOLVER_ROSENBROCK23, SOLVER_TSIT5, cases
     from crnn_amd._lib import check, dptr, lib
     from crnn_amd.dist import DataParallel
@@ -244,7 +247,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "case2: 6 species + T, 3 reactions, P=25, D=50 save points on [0,50], "
                                    f"{ {'tsit5': 'Tsit5', 'autotsit5': 'AutoTsit5(Rosenbrock23)', 'rosenbrock23': 'Rosenbrock23'}[args.solver]} atol 1e-6 rtol 1e-3, MAE loss, "
-                                   f"{'discrete-adjoint' if adjoint else 'forward-tangent'} gradient of the accepted steps (= ForwardDiff's derivative), "
+                                   f"{'discrete-adjoint' if adjoint else 'forward-tangent'} gradient of the accepted Rosenbrock23 steps, dt held fixed (= ForwardDiff's derivative of THOSE steps: 6e-4 from the converged sensitivity at the reference's tolerances, where the reference's own Tsit5 sits at 3e-6 -- profiles/r04o), "
                                    "ExpDecay+ADAM+WeightDecay update",
                        "batch_per_gpu": B_rank, "global_batch": B_rank * world, "theta0": args.theta0,
                        "comm": comm if world > 1 else "none", "parallelism": f"dp{world} (ICs sharded, 1 all-reduce/step)"},
