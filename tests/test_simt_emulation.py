@@ -1,0 +1,74 @@
+"""The kernels' OWN SOURCES executed on the CPU (no `gpu` marker: this runs in the driver's `-m "not gpu"` session).
+
+tests/simt/ compiles crnn_amd/csrc/crnn_capi.hip and every kernel header UNCHANGED as host C++ against a SIMT emulation of
+<hip/hip_runtime.h> (a fibre per lane; DPP moves, shuffles, ballots, readfirstlane, the FP64 MFMA and the barriers resolved between the
+fibres of a wavefront) into tests/simt/libcrnn_simt.so -- the same C ABI.  A sample of the `-m gpu` parity tests is then run against it in
+a child process (CRNN_HIP_LIB selects the library at import; one library per process): every stepper family, both gradient algorithms,
+the lane-pair kernel, the dual-norm kernels of all three right-hand sides -- round 5's hychem_sens2_kernel (sparse directions), its
+COMPOSITE instantiation (the reference's gradient through the reference's own AutoTsit5(Rosenbrock23)) and the cathode's chunked gradient.
+It proves what the sources compute (control flow, tapes, queues, reductions included), under an interleaving of lanes more adversarial than
+the device's lockstep; it says nothing about time or about the ISA.  The whole emulated suite: `bash tools/simt_suite.sh`
+(profiles/r05a_simt_suite.txt).  The emulation library is never loaded by the product (crnn_amd/_lib.py loads libcrnn_hip.so unless a test
+sets CRNN_HIP_LIB; bench.py and smoke() refuse a library whose build info says SIMT-EMULATION)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIMT = os.path.join(ROOT, "tests", "simt")
+CLANG = os.environ.get("SIMT_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(CLANG) or os.uname().machine != "x86_64",
+                                reason="the SIMT emulation build needs the ROCm clang++ on an x86-64 host")
+
+
+@pytest.fixture(scope="module")
+def simt_lib():
+    subprocess.run(["bash", os.path.join(SIMT, "build.sh")], check=True, timeout=1500)
+    lib = os.path.join(SIMT, "libcrnn_simt.so")
+    assert os.path.exists(lib)
+    return lib
+
+
+def _run(lib, args, timeout=1500):
+    env = dict(os.environ, CRNN_HIP_LIB=lib, SIMT_THREADS=os.environ.get("SIMT_THREADS", "4"))
+    out = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-p", "no:cacheprovider", *args], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=timeout)
+    tail = out.stdout[-3000:] + out.stderr[-2000:]
+    assert out.returncode == 0, tail
+    m = re.search(r"(\d+) passed", out.stdout)
+    assert m, tail
+    return int(m.group(1))
+
+
+def test_emulated_library_says_what_it_is_and_is_refused_by_the_bench(simt_lib):
+    code = ("import os, sys; sys.path.insert(0, %r); from crnn_amd import _lib as L; i = L.lib.crnn_build_info().decode(); "
+            "assert 'SIMT-EMULATION' in i, i; print(i)") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CRNN_HIP_LIB=simt_lib), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], env=dict(os.environ, CRNN_HIP_LIB=simt_lib),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "SIMT emulation" in (out.stderr + out.stdout)
+
+
+def test_case2_and_robertson_kernels_against_the_oracle_under_emulation(simt_lib):
+    """ros23_adj_kernel / ros23_adj2_kernel (lane pair) / ros23_kernel (forward tangents) / tsit5 / auto_adj: loss 1e-9, gradient 1e-7, step counts."""
+    n = _run(simt_lib, ["tests/test_gpu_parity.py", "-k", "gradient_matches_oracle or adjoint_equals_forward_tangents or tsit5_adjoint_equals"])
+    assert n >= 8
+    n = _run(simt_lib, ["tests/test_gpu_lanes2.py", "-k", "not auto_beyond_one_generation"])
+    assert n >= 4
+
+
+def test_hychem_dual_norm_kernels_against_the_oracle_under_emulation(simt_lib):
+    """hychem_sens2_kernel chunk for chunk against the oracle (mode 2), the same through the reference's composite, and equal to the dense kernel."""
+    n = _run(simt_lib, ["tests/test_hychem.py", "-k",
+                        "(errnorm_sens_matches_oracle_chunk_for_chunk and 2) or through_the_reference_composite_matches or sparse_direction_kernel"])
+    assert n == 3
+
+
+def test_cathode_chunked_gradient_against_the_oracle_under_emulation(simt_lib):
+    n = _run(simt_lib, ["tests/test_cathode.py", "-k", "errnorm_sens_matches_oracle_chunk_for_chunk and 2"])
+    assert n == 1
