@@ -29,6 +29,7 @@
 #include "cathode_kernel.hpp"
 #include "cathode_auto_kernel.hpp"
 #include "cathode_sens_kernel.hpp"
+#include "cathode_sens_auto_kernel.hpp"
 #include "svgd_kernel.hpp"
 
 namespace {
@@ -1233,7 +1234,7 @@ struct CathCtx {
     size_t ag_send_cap = 0, ag_recv_cap = 0;
     int adj_occ = 0, fwd_occ = 0, prim_occ = 0;
     int solver = CRNN_CATH_SOLVER_ROSENBROCK23, auto_occ[2] = {0, 0};   // stepper of primal launches (crnn_cathode_set_solver)
-    int errnorm_sens = 0, sens_occ[2] = {0, 0};   // gradient launches as ForwardDiff evaluates them (crnn_cathode_set_errnorm_sens)
+    int errnorm_sens = 0, sens_occ[2] = {0, 0}, sensc_occ[2] = {0, 0};   // gradient launches as ForwardDiff evaluates them (crnn_cathode_set_errnorm_sens)
     double *d_dirscale = nullptr;                 // [17] d theta / d p of the chunked dual-norm gradient
     int64_t chunk_stats[4] = {0, 0, 0, 0};        // accepted / rejected steps of the two chunk launches of the last gradient call
     long long *d_chunk_stats = nullptr;           // the same on the device (summed there behind each chunk launch, read on request)
@@ -2235,14 +2236,21 @@ int32_t cath_run(CathCtx *c, int64_t n_part, int set_first, int set_count, bool 
         prs.hrr = nullptr; prs.want_grad = 1;
         if (!c->d_chunk_stats) CHIP(c, hipMalloc((void **)&c->d_chunk_stats, sizeof(long long) * 4));
         CHIP(c, hipMemsetAsync(c->d_chunk_stats, 0, sizeof(long long) * 4, c->stream));
+        // ... through Rosenbrock23 (cathode_sens_kernel: one lane per trajectory) or, with the reference's own stepper selected
+        // (crnn_cathode_set_solver: AutoTsit5(TRBDF2), network.jl:195), through that composite (cathode_sens_auto_kernel: nine lanes per trajectory)
+        const bool comp = c->solver == CRNN_CATH_SOLVER_AUTOTSIT5_TRBDF2;
+        if (comp) { prs.qsteady_min = 1.0; prs.qsteady_max = 1.0; }   // qsteady_max_default of a composite
         for (int ch = 0; ch < 2; ++ch) {
             using SensFn = void (*)(const crnn::CathodeParams, const crnn::CathSensParams);
-            const SensFn fn = ch == 0 ? (SensFn)crnn::cathode_sens_kernel<kB, 0> : (SensFn)crnn::cathode_sens_kernel<kB, 1>;
-            if (c->sens_occ[ch] < 1) {
-                CHIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->sens_occ[ch], (const void *)fn, kB, 0));
-                if (c->sens_occ[ch] < 1) c->sens_occ[ch] = 1;
+            const SensFn fn = comp ? (ch == 0 ? (SensFn)crnn::cathode_sens_auto_kernel<kB, 0> : (SensFn)crnn::cathode_sens_auto_kernel<kB, 1>)
+                                   : (ch == 0 ? (SensFn)crnn::cathode_sens_kernel<kB, 0> : (SensFn)crnn::cathode_sens_kernel<kB, 1>);
+            int &occ_s = comp ? c->sensc_occ[ch] : c->sens_occ[ch];
+            if (occ_s < 1) {
+                CHIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_s, (const void *)fn, kB, 0));
+                if (occ_s < 1) occ_s = 1;
             }
-            const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((ntraj + kB - 1) / kB, (int64_t)c->num_cu * c->sens_occ[ch]));
+            const int64_t per_blk = comp ? (kB / 64) * 7 : kB;        // trajectories a block holds at a time
+            const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((ntraj + per_blk - 1) / per_blk, (int64_t)c->num_cu * occ_s));
             CHIP(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), c->stream));
             hipLaunchKernelGGL(fn, dim3(nblk), dim3(kB), 0, c->stream, prs, sp);
             CHIP(c, hipGetLastError());

@@ -25,8 +25,8 @@
 //     registers; the attempt's candidates (s_new, f2') too, so a rejected attempt costs nothing to undo; its gradient increments at the
 //     save points inside the step are formed before the decision (the save points of an attempt follow from t and dt) and added on accept.
 //
-// The norm, the controller, the initial step, the dense output and every formula of the primal are hychem_sens_kernel's (and the oracle's
-// orc_hychem errnorm modes, oracle/crnn_oracle.c): same step sequences, gradient pieces to rounding (tests/test_hychem.py).
+// The norm, the controller, the initial step, the dense output and every formula of the primal are hychem_sens_kernel's (and those of the
+// test suite's CPU restatement): same step sequences, gradient pieces to rounding (tests/test_hychem.py).
 // Work distribution: a wavefront takes GPW = 64 / L consecutive entries of the (step-count sorted) queue at a time and runs them to the end
 // under one wave-uniform loop (no per-lane refills: the persistent-lane experiment of DESIGN appendix A); block b works on chunk
 // b % n_chunks as in hychem_sens_kernel.
@@ -139,7 +139,7 @@ __device__ __forceinline__ void hys2_solve(const double *As, const int (&piv)[NS
 // in the error norm of BOTH algorithms: a Tsit5 attempt carries the columns through its seven stages (k_s' = f'(g_s; g_s'), the embedded
 // estimate's partials dt sum_j bt_j k_j'), OrdinaryDiffEq's AutoSwitch rule as hychem_auto_kernel.hpp states it decides on the primal's
 // stiffness estimates (Hairer's |k7 - k6| / |g7 - g6| after a Tsit5 attempt, opnorm(J, Inf) after a Rosenbrock23 attempt), the PI exponents
-// are the running algorithm's.  Checked against the oracle's solver = 2 with errnorm_sens (tests/test_hychem.py).
+// are the running algorithm's.  Checked chunk for chunk against the test suite's CPU statement of the same composite (tests/test_hychem.py).
 template <int NS, int NR, int L, int BLOCK, bool COMPOSITE = false>
 __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams prm, const double *__restrict__ theta, const HyParams hp,
                                                              const HySensParams sp) {

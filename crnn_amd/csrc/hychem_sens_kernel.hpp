@@ -24,7 +24,7 @@
 // type below (hy_f<T> over first-order duals).  The group sums the lanes' contributions to the norm by ds_bpermute in lane order, takes
 // the decision, and only then commits the attempt: the new tangent column, the column's gradient increments at the save points inside
 // the step.  (Round 4 shipped this kernel with nested duals for everything and a copy of W per lane -- 5.2 KB of scratch, 108 KB of LDS;
-// round 5 ran both variants through the SIMT emulator against the oracle, chunk for chunk, and kept this one: 3.5 KB, 31 KB.)
+// round 5 ran both variants through the test suite's SIMT emulator against the CPU restatement, chunk for chunk, and kept this one: 3.5 KB, 31 KB.)
 #pragma once
 #include "hychem_kernel.hpp"
 #include "hychem_tan.hpp"

@@ -410,8 +410,11 @@ int32_t crnn_cathode_set_tape_every(crnn_cathode_ctx *ctx, int32_t every);
  * Tsit5 attempt is six right-hand sides with their logarithms and exponentials, a Rosenbrock23 attempt two; a third of the steps does
  * not buy a third of the time (profiles/r04i).  They exist so that a primal launch can be the reference's own algorithm.
  * All restated from the published algorithms ([UNVERIFIED-DEP]: the packages are not in the reference tree; oracle/crnn_oracle.c
- * states every branch).  GRADIENT launches are not affected: they run the L-stable Rosenbrock23 discrete adjoint whatever this
- * setting (the adjoint through Tsit5's steps is unstable for this model: cathode_auto_kernel.hpp).  Results of the three agree to
+ * states every branch).  GRADIENT launches: the discrete adjoint (errnorm_sens = 0) and the dual-norm chunks (crnn_cathode_set_errnorm_sens)
+ * run on the L-stable Rosenbrock23 whatever this setting (the adjoint through Tsit5's steps is unstable for this model:
+ * cathode_auto_kernel.hpp) -- EXCEPT the dual-norm chunks under _AUTOTSIT5_TRBDF2 (round 5): they run through the composite itself, the
+ * partials in both algorithms' error estimates and through TRBDF2's Newton iterations (cathode_sens_auto_kernel.hpp): a gradient call
+ * is then network.jl:232 through :195, algorithm for algorithm; parity mode, nine lanes per trajectory.  Results of the three agree to
  * solver tolerance (at tight tolerance to 1e-8); two implementations of the composite agree to ~1e-8 in the loss and a fraction
  * of rtol in the heat-release curve, not step for step (explicit steps at their stability limit amplify round-off). */
 #define CRNN_CATH_SOLVER_ROSENBROCK23 0

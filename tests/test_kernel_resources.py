@@ -64,6 +64,16 @@ def test_dual_norm_kernel_has_no_scratch_and_two_blocks_per_cu(tmp_path):
 HY = "const crnn::SolveParams, const double*, const crnn::HyParams, const crnn::HySensParams"
 
 
+def test_cathode_composite_dual_norm_kernel_has_no_scratch(tmp_path):
+    """cathode_sens_auto_kernel (the reference's gradient through AutoTsit5(TRBDF2), nine lanes per trajectory): both chunk instantiations
+    without scratch (393 / 395 registers), LDS only for the staged observations."""
+    CS = "const crnn::CathodeParams, const crnn::CathSensParams"
+    for ch in (0, 1):
+        r = _resources(tmp_path, "cathode_sens_auto_kernel.hpp", f"crnn::cathode_sens_auto_kernel<256,{ch}>({CS})")
+        assert r["scratch"] == 0 and r["vgpr"] + r["agpr"] <= 512 and r["lds"] <= 32768, r
+
+
+
 def test_hychem_dual_norm_kernels(tmp_path):
     """The HyChem dual-norm gradient.  hychem_sens2_kernel -- sparse directions, closed-form tangents, one column
     per lane, the primal spread over the group, the trajectory's state in an LDS record -- is the kernel every gradient call of the
