@@ -31,6 +31,6 @@ for n in 1024 4096 32768; do
   if [ $n -le 4096 ]; then echo "dense $n"; CRNN_HY_SENS_KERNEL=1 timeout 900 python tools/hy_sens_time.py $n; fi
 done > $O/ab_hychem_sens.txt 2>&1; cat $O/ab_hychem_sens.txt | cut -c1-200
 # 5. fuzz sweeps on the tree that ships
-for f in fuzz_parity fuzz_hychem fuzz_cathode; do
+for f in fuzz_parity fuzz_hychem fuzz_cathode fuzz_hychem_sens; do
   timeout 600 python tools/$f.py > $O/$f.txt 2>&1; tail -3 $O/$f.txt | cut -c1-200
 done
