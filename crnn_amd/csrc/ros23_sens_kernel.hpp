@@ -145,8 +145,9 @@ __device__ __forceinline__ double fsqrt_pos(const double m) {
 // inclusive one -- d1 and d2 grow by the partials, d0 only shares the divisor ([UNVERIFIED-DEP] like the norm itself).
 // Every lane of the group calls this with the same primal point (x0, r0, f0) and its own C columns; the partial sums are
 // combined over the group's L lanes in lane order.  Stmp: the lane's LDS slot (C * NS doubles, stride 64) parks f0'.
-// The lane's columns qc < nvalid are the rows dcols + qc * pitch of d theta / d p, the others read the all-zero row zcol.
-template <int NS, int NR, bool HAS_T, bool USE_SCALE, int C, int L, int ORDER>
+// The lane's columns qc < nvalid are the rows dcols + qc * pitch of d theta / d p, the others read the all-zero row zcol -- or, MASKED
+// (rows read from global memory, where there is no zero row to point at: tsit5_sens_kernel), row 0 with the result replaced by zero.
+template <int NS, int NR, bool HAS_T, bool USE_SCALE, int C, int L, int ORDER, bool MASKED = false>
 __device__ __forceinline__ double sens_init_dt(const double *__restrict__ th, const KConst *kc, const double *dcols, const int pitch,
                                                double *Stmp, const double (&u)[NS], const double (&f0)[NS], const double (&x0)[NS],
                                                const double (&r0)[NR], const double (&bT)[NR], const double xT, const double Tconst,
@@ -173,7 +174,8 @@ __device__ __forceinline__ double sens_init_dt(const double *__restrict__ th, co
     double d1p = 0.0;
 #pragma unroll 1
     for (int qc = 0; qc < C; ++qc) {
-        const double *dcol = qc < nvalid ? dcols + qc * pitch : zcol;
+        const bool cvalid = qc < nvalid;
+        const double *dcol = MASKED ? dcols + (cvalid ? qc : 0) * pitch : (cvalid ? dcols + qc * pitch : zcol);
         double f0p[NS];
 #pragma unroll
         for (int i = 0; i < NS; ++i) f0p[i] = 0.0;
@@ -189,6 +191,7 @@ __device__ __forceinline__ double sens_init_dt(const double *__restrict__ th, co
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             if (USE_SCALE) f0p[i] *= kc->scale[i];
+            if (MASKED && !cvalid) f0p[i] = 0.0;
             Stmp[(qc * NS + i) * 64] = f0p[i];
             const double c = f0p[i] * sk[i];
             d1p = fma(c, c, d1p);
@@ -210,7 +213,8 @@ __device__ __forceinline__ double sens_init_dt(const double *__restrict__ th, co
     for (int i = 0; i < NS; ++i) { const double e = (f1[i] - f0[i]) * sk[i]; d2 = fma(e, e, d2); }
 #pragma unroll 1
     for (int qc = 0; qc < C; ++qc) {
-        const double *dcol = qc < nvalid ? dcols + qc * pitch : zcol;
+        const bool cvalid = qc < nvalid;
+        const double *dcol = MASKED ? dcols + (cvalid ? qc : 0) * pitch : (cvalid ? dcols + qc * pitch : zcol);
         double gs1[NS], f1p[NS];
 #pragma unroll
         for (int c = 0; c < NS; ++c) { gs1[c] = g1[c] * (dt0 * Stmp[(qc * NS + c) * 64]); f1p[c] = 0.0; }
@@ -226,6 +230,7 @@ __device__ __forceinline__ double sens_init_dt(const double *__restrict__ th, co
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             if (USE_SCALE) f1p[i] *= kc->scale[i];
+            if (MASKED && !cvalid) f1p[i] = 0.0;
             const double e = (f1p[i] - Stmp[(qc * NS + i) * 64]) * sk[i];
             d2p = fma(e, e, d2p);
         }

@@ -10,9 +10,15 @@
 //     EEst^2 = 1/n sum_i (e_i^2 + sum_k e'_ik^2) / (atol_i + rtol_i sqrt(max(u_i^2 + sum_k s_ik^2, u+_i^2 + sum_k s+_ik^2)))^2
 //
 // ([UNVERIFIED-DEP] DiffEqBase.ODE_DEFAULT_NORM on Dual arrays; the initial step size uses the same norm.)
-// Lane groups (L lanes per trajectory, C columns each), a per-group LDS record with the seven stage areas (x, g, r) that
-// lane 0 of the group publishes, provisional save-point seeds / tangent columns / gradient increments until the group has
-// summed its lanes' norm contributions; trajectories by a plain grid-stride loop.
+// Lane groups (L lanes per trajectory, C columns each), a per-group LDS record with the stage areas (x, g, r) of stages 2..6 that
+// lane 0 of the group publishes (the first and the last stage's are registers of every lane: the primal runs redundantly),
+// provisional save-point seeds / tangent columns / gradient increments until the group has summed its lanes' norm contributions;
+// trajectories in wave-synchronous batches from a queue.
+// LDS: 79 KB per block of two wavefronts (case2: 2 x (25.7 KB of tangent columns, two slots per lane + 20.7 KB of records) + constants),
+// so that TWO blocks -- one wavefront on each of the CU's four SIMDs, 507 registers each -- are resident (round 4: 100 KB, two SIMDs
+// idle).  What left the LDS for that: the rows of d theta / d p (read from global memory into registers at the head of every column,
+// 42 loads that the L2 serves; a surplus column of a short chunk reads row 0 and replaces it by zero), the save times (one load per
+// save point passed: ts_next), and two of the seven stage areas.
 #pragma once
 #include "tsit5_kernel.hpp"
 #include "ros23_sens_kernel.hpp"
@@ -23,7 +29,8 @@ template <int NS, int NR>
 struct RecTS {
     static constexpr int SA = 2 * NS + NR;          // one stage area: X, G, R
     static constexpr int XO = 0, GO = NS, RO = 2 * NS;
-    static constexpr int AA = 7 * SA;
+    static constexpr int NSTG = 5;                  // stages 2..6 (area s - 1 for stage index s = 1..5); stages 1 and 7 stay in registers
+    static constexpr int AA = NSTG * SA;
     static constexpr int BB = AA + NS;              // B_j at BB + j*NS
     static constexpr int NREC = BB + 7 * NS;
 };
@@ -44,8 +51,6 @@ __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm
     static_assert(C > 0 && L >= 1 && L <= 64 && DROWS > PPAD, "lane-group shape");
 
     __shared__ double kc_lds[kNConst];
-    __shared__ double ts_lds[kMaxSave];
-    __shared__ double dth_lds[DROWS * NTHP];
     __shared__ double S_lds[2 * WAVES * C * NS * 64];   // two slots per lane: committed columns / columns of the attempt
     __shared__ double rec_lds[WAVES * NREC * GPW];
 
@@ -58,12 +63,6 @@ __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm
     double *const rec = rec_lds + wave * NREC * GPW + (lane_active ? grp : 0);
 
     for (int idx = tid; idx < kNConst; idx += BLOCK) kc_lds[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
-    for (int idx = tid; idx < prm.n_save; idx += BLOCK) ts_lds[idx] = prm.tsave[idx];
-    for (int idx = tid; idx < DROWS * NTHP; idx += BLOCK) {
-        const int k = idx / NTHP, m = idx - k * NTHP;
-        dth_lds[idx] = (k < prm.P && k < DROWS - 1 && m < NTH) ? dtheta[(size_t)k * NTH + m] : 0.0;
-    }
-    const double *const zcol = dth_lds + (DROWS - 1) * NTHP;
     const int nch = prm.n_chunks > 1 ? prm.n_chunks : 1;     // chunks in this launch
     const int cs_eff = nch > 1 ? prm.chunk_size : PPAD;      // partials of a (full) chunk
     const int ncols = nch > 1 ? prm.P : PPAD;                // columns in a gradient row
@@ -72,7 +71,8 @@ __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm
     const double *__restrict__ th = theta;
 
     const int nsave = prm.n_save;
-    const double tend = ts_lds[nsave - 1], ts0 = ts_lds[0], t0 = kc->t0;
+    const double *__restrict__ const tsv = prm.tsave;       // save times from L2: one load per save point passed (ts_next below), none per attempt
+    const double tend = tsv[nsave - 1], ts0 = tsv[0], t0 = kc->t0;
     const double dtmax = tend - t0;
     const double lqinit = flog(kc->qoldinit);
     const unsigned nwaves = gridDim.x * WAVES;
@@ -92,8 +92,9 @@ __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm
         const int cid = nch > 1 ? (int)(bi % nch) : 0;
         const int64_t pos = (nch > 1 ? bi / nch : bi) * GPW + grp;
         const int col0 = cid * cs_eff + chunk * C;        // this lane's first column; the valid ones are a prefix
-        const int nvalid = max(0, min(C, min(cs_eff - chunk * C, ncols - col0)));
-        const double *const dcols = dth_lds + (nvalid > 0 ? col0 : 0) * NTHP;
+        const int nwr = max(0, min(C, min(cs_eff - chunk * C, ncols - col0)));     // columns of the gradient row this lane writes
+        const int nvalid = max(0, min(nwr, prm.P - col0));                           // ... of which these have a row of d theta / d p (a short chunk's surplus columns are zero)
+        const double *const dcols = dtheta + (size_t)(nvalid > 0 ? col0 : 0) * NTH;      // rows of d theta / d p straight from HBM / L2 (see the header)
         if (lane_active && pos < prm.count) {
         CRNN_CHK(!prm.perm || ((int64_t)prm.perm[pos] >= 0 && (int64_t)prm.perm[pos] < prm.count), 0x5201);
         const int64_t traj = prm.perm ? (int64_t)prm.perm[pos] : pos;
@@ -113,9 +114,9 @@ __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm
         rates<NS, NR, HAS_T>(th, x1, bT, r1);
         rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r1, kc->scale, k1);
         // Hairer initial step (order 5) with the dual-inclusive norms: ros23_sens_kernel.hpp sens_init_dt
-        double dt = sens_init_dt<NS, NR, HAS_T, USE_SCALE, C, L, 5>(th, kc, dcols, NTHP,
-                                                                      S_base + (size_t)C * NS * 64, u, k1, x1, r1, bT, xT, Tconst,
-                                                                      dtmax, prm.norm_cols, gbase, nvalid, zcol);
+        double dt = sens_init_dt<NS, NR, HAS_T, USE_SCALE, C, L, 5, true>(th, kc, dcols, NTH,
+                                                                            S_base + (size_t)C * NS * 64, u, k1, x1, r1, bT, xT, Tconst,
+                                                                            dtmax, prm.norm_cols, gbase, nvalid);
         double t = t0, lqold = lqinit, loss_sum = 0.0;
         int iter = 0, jsave = 0, nacc = 0, nrej = 0, cur = 0, rc = -1;
 #pragma unroll
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm
             }
             jsave = 1;
         }
+        double ts_next = jsave < nsave ? tsv[jsave] : tend;     // the save time the next accepted step has to reach first
 
         while (rc < 0) {
             ++iter;
@@ -154,12 +156,6 @@ __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm
             double k[7][NS], unew[NS], x7[NS], g7[NS], r7[NR], ev[NS];
 #pragma unroll
             for (int i = 0; i < NS; ++i) k[0][i] = k1[i];
-            if (lead) {
-#pragma unroll
-                for (int i = 0; i < NS; ++i) { rec[(R_::XO + i) * GPW] = x1[i]; rec[(R_::GO + i) * GPW] = g1[i]; }
-#pragma unroll
-                for (int j = 0; j < NR; ++j) rec[(R_::RO + j) * GPW] = r1[j];
-            }
 #pragma unroll
             for (int s = 1; s < 7; ++s) {
                 double g[NS], x[NS], gg[NS], r[NR];
@@ -173,8 +169,8 @@ __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm
                 features<NS>(g, kc->lb, kc->ub, x, gg);
                 rates<NS, NR, HAS_T>(th, x, bT, r);
                 rhs_from_rates<NS, NR, HAS_T, USE_SCALE>(th, r, kc->scale, k[s]);
-                if (lead) {
-                    const int o = s * R_::SA;
+                if (lead && s < 6) {       // the first and the last stage's (x, g, r) are registers of every lane of the group: x1 / g1 / r1, x7 / g7 / r7
+                    const int o = (s - 1) * R_::SA;
 #pragma unroll
                     for (int i = 0; i < NS; ++i) { rec[(o + R_::XO + i) * GPW] = x[i]; rec[(o + R_::GO + i) * GPW] = gg[i]; }
 #pragma unroll
@@ -210,7 +206,7 @@ __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm
             double loss_new = loss_sum;
             int jnew = jsave;
             while (jnew < nsave) {
-                const double ts = ts_lds[jnew];
+                const double ts = jnew == jsave ? ts_next : tsv[jnew];
                 if (!(ts <= tnew)) break;
                 const bool at_end = (ts == tnew);
                 double bth[7];
@@ -268,12 +264,13 @@ __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm
             for (int i = 0; i < NS; ++i) { ee[i] = 0.0; na[i] = 0.0; nb[i] = 0.0; }
 #pragma unroll 1
             for (int qc = 0; qc < C; ++qc) {
-                const double *dcol = qc < nvalid ? dcols + qc * NTHP : zcol;
+                const bool cvalid = qc < nvalid;          // surplus columns of a short chunk: zero direction (their tangents stay zero)
+                const double *dcol = dcols + (cvalid ? qc : 0) * NTH;
                 const double *Sq = Sc + qc * NS * 64;
                 double *Sqn = Sn + qc * NS * 64;
                 double dth_r[NTH];
 #pragma unroll
-                for (int m = 0; m < NTH; ++m) dth_r[m] = dcol[m];
+                for (int m = 0; m < NTH; ++m) dth_r[m] = cvalid ? dcol[m] : 0.0;
                 double s[NS], kp[6][NS], de[NS];
 #pragma unroll
                 for (int i = 0; i < NS; ++i) { s[i] = Sq[i * 64]; na[i] = fma(s[i], s[i], na[i]); de[i] = 0.0; }
@@ -283,14 +280,17 @@ __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm
 #pragma unroll
                 for (int st = 0; st < 7; ++st) {
                     __builtin_amdgcn_sched_barrier(0);
-                    const int o = st * R_::SA;
+                    const int o = (st - 1) * R_::SA;
+                    auto Xs = [&](int c) -> double { return st == 0 ? x1[c] : st == 6 ? x7[c] : rec[(o + R_::XO + c) * GPW]; };
+                    auto Gs = [&](int c) -> double { return st == 0 ? g1[c] : st == 6 ? g7[c] : rec[(o + R_::GO + c) * GPW]; };
+                    auto Rs = [&](int j) -> double { return st == 0 ? r1[j] : st == 6 ? r7[j] : rec[(o + R_::RO + j) * GPW]; };
                     double gs[NS];
 #pragma unroll
                     for (int c = 0; c < NS; ++c) {
                         double a = 0.0;
 #pragma unroll
                         for (int j = 0; j < st; ++j) a = fma(Ts5::a(st - 1, j), kp[j][c], a);
-                        gs[c] = rec[(o + R_::GO + c) * GPW] * (st == 0 ? s[c] : fma(dt, a, s[c]));
+                        gs[c] = Gs(c) * (st == 0 ? s[c] : fma(dt, a, s[c]));
                     }
                     double kps[NS];
 #pragma unroll
@@ -301,10 +301,10 @@ __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm
                         if (HAS_T) e = fma(dth_r[L_::wi(NS, j)], xT, e);
 #pragma unroll
                         for (int c = 0; c < NS; ++c) {
-                            e = fma(dth_r[L_::wi(c, j)], rec[(o + R_::XO + c) * GPW], e);
+                            e = fma(dth_r[L_::wi(c, j)], Xs(c), e);
                             e = fma(th[L_::wi(c, j)], gs[c], e);
                         }
-                        const double rj = rec[(o + R_::RO + j) * GPW];
+                        const double rj = Rs(j);
                         const double er = e * rj;
 #pragma unroll
                         for (int i = 0; i < NS; ++i) {
@@ -361,6 +361,7 @@ __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm
                 for (int qc = 0; qc < C; ++qc) gtr[qc] += gnew[qc];
                 cur ^= 1;
                 loss_sum = loss_new;
+                if (jnew != jsave && jnew < nsave) ts_next = tsv[jnew];
                 jsave = jnew;
                 t = tnew;
                 if (q >= kc->qsteady_min && q <= kc->qsteady_max) q = 1.0;
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm
         double *grow = prm.gtraj + (size_t)traj * ncols + col0;
 #pragma unroll
         for (int q_ = 0; q_ < C; ++q_)
-            if (q_ < nvalid) grow[q_] = gtr[q_] * inv_den;
+            if (q_ < nwr) grow[q_] = gtr[q_] * inv_den;
         }
         bi = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)nx) + nwaves;
     }

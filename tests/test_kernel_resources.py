@@ -61,6 +61,15 @@ def test_dual_norm_kernel_has_no_scratch_and_two_blocks_per_cu(tmp_path):
     assert r["scratch"] == 0 and 2 * r["lds"] <= 163840, r
 
 
+def test_tsit5_dual_norm_kernel_has_no_scratch_and_two_blocks_per_cu(tmp_path):
+    """case1's and case2's reference algorithm inside the reference's gradient (tsit5_sens_kernel): 100 144 B of LDS in round 4 (one block of
+    two wavefronts per CU, two SIMDs idle), 79 072 / 78 800 B since the rows of d theta / d p, the save times and two of the seven stage
+    areas left the LDS: two blocks per CU, a wavefront on every SIMD."""
+    for inst in ("6,3,true,false,3,3,128,26", "5,4,false,false,4,3,128,13"):
+        r = _resources(tmp_path, "tsit5_sens_kernel.hpp", f"crnn::tsit5_sens_kernel<{inst}>({SENS})")
+        assert r["scratch"] == 0 and r["vgpr"] + r["agpr"] <= 512 and r["lds"] <= 80000, r
+
+
 HY = "const crnn::SolveParams, const double*, const crnn::HyParams, const crnn::HySensParams"
 
 
