@@ -73,58 +73,7 @@ __device__ __forceinline__ void pair_own(const double (&full)[NS], const bool m1
     for (int i = 0; i < H; ++i) own[i] = m1 ? (2 * i + 1 < NS ? full[2 * i + 1 < NS ? 2 * i + 1 : 0] : 0.0) : full[2 * i];
 }
 
-// ros23_kernel.hpp's flog, bit for bit, for the step-size controller.  The five constants that START a multiply-add chain are
-// addends of v_fmac, i.e. live in VGPRs; the compiler materialises them once per kernel, cannot keep ten registers for a function
-// that runs once per step, and reloads them from SCRATCH at each call (five memory latencies per step).  Passed through an
-// SGPR-constrained asm they are formed where they are used (two s_mov each).
-__device__ __forceinline__ double hy_sconst(double c) {
-    asm volatile("" : "+s"(c));
-    return c;
-}
-__device__ __forceinline__ double flog_ctl(double x) {
-    double m = __builtin_amdgcn_frexp_mant(x);      // [0.5, 1)
-    int k = __builtin_amdgcn_frexp_exp(x);
-    const bool lo = m < 0.70710678118654752440;
-    m = lo ? m + m : m;                             // [sqrt(1/2), sqrt 2)
-    k = lo ? k - 1 : k;
-    const double f = m - 1.0;
-    const double r = frcp1(2.0 + f);
-    double s = f * r;
-    s = fma(fma(-(2.0 + f), s, f), r, s);
-    const double z = s * s;
-    const double w = z * z;
-    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, hy_sconst(2.222219843214978396e-01)), hy_sconst(3.999999999940941908e-01));
-    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, hy_sconst(1.818357216161805012e-01)),
-                                     hy_sconst(2.857142874366239149e-01)), hy_sconst(6.666666666666735130e-01));
-    const double R = t2 + t1;
-    const double hfsq = 0.5 * f * f;
-    const double dk = (double)k;
-    return fma(dk, 6.93147180369123816490e-01, -((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f));
-}
-
-// exp for the step-size controller: __ocml_exp_f64's arithmetic, operation for operation (the same bits as the exp() call it
-// replaces -- the constants are the device library's, read off the ISA), with the same cure as flog_ctl: the ten coefficients that
-// are ADDENDS of the multiply-add chain were materialised once per kernel in fourteen AGPRs and two scratch slots (two memory
-// latencies per step, in the controller's dependent chain); formed in SGPRs where they are used they cost two s_mov each.
-__device__ __forceinline__ double fexp_ctl(double x) {
-    const double dn = __builtin_rint(x * 0x1.71547652b82fep+0);
-    double t = fma(-dn, 0x1.62e42fefa39efp-1, x);
-    t = fma(-dn, 0x1.abc9e3b39803fp-56, t);
-    double p = fma(t, 0x1.ade156a5dcb37p-26, hy_sconst(0x1.28af3fca7ab0cp-22));
-    p = fma(t, p, hy_sconst(0x1.71dee623fde64p-19));
-    p = fma(t, p, hy_sconst(0x1.a01997c89e6b0p-16));
-    p = fma(t, p, hy_sconst(0x1.a01a014761f6ep-13));
-    p = fma(t, p, hy_sconst(0x1.6c16c1852b7b0p-10));
-    p = fma(t, p, hy_sconst(0x1.1111111122322p-7));
-    p = fma(t, p, hy_sconst(0x1.55555555502a1p-5));
-    p = fma(t, p, hy_sconst(0x1.5555555555511p-3));
-    p = fma(t, p, hy_sconst(0x1.000000000000bp-1));
-    p = fma(t, p, 1.0);
-    p = fma(t, p, 1.0);
-    double z = __builtin_amdgcn_ldexp(p, (int)dn);
-    z = x > 1024.0 ? __builtin_inf() : z;
-    return x < -1075.0 ? 0.0 : z;
-}
+// (flog_ctl / fexp_ctl / sconst -- log and exp with their constants formed in SGPRs where they are used -- live in ros23_kernel.hpp)
 
 template <int NS, int NR>
 struct HyPoint2 {

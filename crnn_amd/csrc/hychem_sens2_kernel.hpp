@@ -32,6 +32,7 @@
 // b % n_chunks as in hychem_sens_kernel.
 #pragma once
 #include "hychem_sens_kernel.hpp"
+#include "hychem2_kernel.hpp"       // fexp_ctl: the controller's exp with its constants formed in SGPRs where they are used
 #include "auto_adj_kernel.hpp"      // AutoSw, Ts5 (the composite)
 
 namespace crnn {
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                 for (int m = 0; m < NS; ++m) bb += ((cC >> m) & 1u) ? wi[m] : 0.0;
                 z_[h] = zz; b_[h] = bb;
             }
-            fexp_vec<NRAT>(z_, e_);
+            fexp_vec_s<NRAT>(z_, e_);      // (constants in SGPRs at the point of use: fexp_vec kept eleven of them in registers and scratch)
             if (lane_on) {
 #pragma unroll
                 for (int h = 0; h < NRAT; ++h) { const int j = min(sub + h * L, NR - 1); pt[Y_::P_R + j] = e_[h]; pt[Y_::P_BJ + j] = b_[h]; }
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                 d2 = sqrt(d2 * inv_div) / dt0;
                 const double dm = fmax(d1, d2);
                 // 10^(-(2 + log10 dm) / (order + 1)) with the order of the STARTING algorithm: Rosenbrock23 2, the composite's Tsit5 4
-                const double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : exp((COMPOSITE ? -0.2 : -0.5) * (4.605170185988091368 + flog(dm)));
+                const double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : fexp_ctl((COMPOSITE ? -0.2 : -0.5) * (4.605170185988091368 + flog(dm)));
                 dt = fmax(kc->dtmin, fmin(fmin(100.0 * dt0, dt1), dtmax));
             }
         }
@@ -979,7 +980,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                     const bool ee_zero = (es == 0.0);
                     const double lEE = 0.5 * flog(ee_zero ? 1.0 : es);
                     const double lq11 = b1_ * lEE;
-                    double q_ = ee_zero ? 1.0 / kc->qmax : fmax(1.0 / kc->qmax, fmin(1.0 / kc->qmin, exp(lq11 - b2_ * lqold) / kc->gamma));
+                    double q_ = ee_zero ? 1.0 / kc->qmax : fmax(1.0 / kc->qmax, fmin(1.0 / kc->qmin, fexp_ctl(lq11 - b2_ * lqold) / kc->gamma));
                     if (es <= 1.0) {
                         ++nacc;
                         while (jsave < nsave) {
@@ -1030,7 +1031,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_sens2_kernel(const SolveParams p
                         if (jsave >= nsave) rc = 0;
                     } else {
                         ++nrej;
-                        dt = dt / fmin(1.0 / kc->qmin, exp(lq11) / kc->gamma);
+                        dt = dt / fmin(1.0 / kc->qmin, fexp_ctl(lq11) / kc->gamma);
                     }
                 }
             }

@@ -151,6 +151,69 @@ __device__ __forceinline__ double flog(double x) {
     return fma(dk, 6.93147180369123816490e-01, -((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f));
 }
 
+// A double constant formed in an SGPR pair WHERE IT IS USED (two s_mov_b32 with literals) instead of once per kernel: the addend of a
+// v_fmac chain has to be a register, the compiler materialises such constants ahead of the loops, cannot keep them in a full
+// register file and reloads them from SCRATCH at every use (a memory latency per constant in a kernel that runs one wavefront per
+// SIMD).  The moves are the asm itself: a constant merely passed THROUGH an SGPR-constrained asm is still hoisted and spilled
+// (cathode kernels, round 5).  (Under the test suite's SIMT emulation the asm is dropped and the initialisers stay.)
+template <unsigned LO, unsigned HI>
+__device__ __forceinline__ double sconst_bits() {
+    unsigned lo = LO, hi = HI;
+    asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "n"(LO), "n"(HI));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+#define CRNN_SCONST(x) (::crnn::sconst_bits<(unsigned)__builtin_bit_cast(unsigned long long, (double)(x)), \
+                                            (unsigned)(__builtin_bit_cast(unsigned long long, (double)(x)) >> 32)>())
+// flog, bit for bit, for kernels whose register file is full (first: the step-size controller of hychem2_kernel).  The five constants that START a multiply-add chain are
+// addends of v_fmac, i.e. live in VGPRs; the compiler materialises them once per kernel, cannot keep ten registers for a function
+// that runs once per step, and reloads them from SCRATCH at each call (five memory latencies per step).  Passed through an
+// SGPR-constrained asm they are formed where they are used (two s_mov each).
+__device__ __forceinline__ double flog_ctl(double x) {
+    double m = __builtin_amdgcn_frexp_mant(x);      // [0.5, 1)
+    int k = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;                             // [sqrt(1/2), sqrt 2)
+    k = lo ? k - 1 : k;
+    const double f = m - 1.0;
+    const double r = frcp1(2.0 + f);
+    double s = f * r;
+    s = fma(fma(-(2.0 + f), s, f), r, s);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, CRNN_SCONST(2.222219843214978396e-01)), CRNN_SCONST(3.999999999940941908e-01));
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, CRNN_SCONST(1.818357216161805012e-01)),
+                                     CRNN_SCONST(2.857142874366239149e-01)), CRNN_SCONST(6.666666666666735130e-01));
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    return fma(dk, 6.93147180369123816490e-01, -((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f));
+}
+
+// exp for the step-size controller: __ocml_exp_f64's arithmetic, operation for operation (the same bits as the exp() call it
+// replaces -- the constants are the device library's, read off the ISA), with the same cure as flog_ctl: the ten coefficients that
+// are ADDENDS of the multiply-add chain were materialised once per kernel in fourteen AGPRs and two scratch slots (two memory
+// latencies per step, in the controller's dependent chain); formed in SGPRs where they are used they cost two s_mov each.
+__device__ __forceinline__ double fexp_ctl(double x) {
+    const double dn = __builtin_rint(x * 0x1.71547652b82fep+0);
+    double t = fma(-dn, 0x1.62e42fefa39efp-1, x);
+    t = fma(-dn, 0x1.abc9e3b39803fp-56, t);
+    double p = fma(t, 0x1.ade156a5dcb37p-26, CRNN_SCONST(0x1.28af3fca7ab0cp-22));
+    p = fma(t, p, CRNN_SCONST(0x1.71dee623fde64p-19));
+    p = fma(t, p, CRNN_SCONST(0x1.a01997c89e6b0p-16));
+    p = fma(t, p, CRNN_SCONST(0x1.a01a014761f6ep-13));
+    p = fma(t, p, CRNN_SCONST(0x1.6c16c1852b7b0p-10));
+    p = fma(t, p, CRNN_SCONST(0x1.1111111122322p-7));
+    p = fma(t, p, CRNN_SCONST(0x1.55555555502a1p-5));
+    p = fma(t, p, CRNN_SCONST(0x1.5555555555511p-3));
+    p = fma(t, p, CRNN_SCONST(0x1.000000000000bp-1));
+    p = fma(t, p, 1.0);
+    p = fma(t, p, 1.0);
+    double z = __builtin_amdgcn_ldexp(p, (int)dn);
+    z = x > 1024.0 ? __builtin_inf() : z;
+    return x < -1075.0 ? 0.0 : z;
+}
+
+
 template <int NS>
 __device__ __forceinline__ bool lu_factor(double (&A)[NS][NS], double (&dinv)[NS], int (&piv)[NS], bool &anyp) {
     bool ok = true;
@@ -351,6 +414,49 @@ __device__ __forceinline__ void fexp_vec(const double (&z)[NR], double (&e)[NR])
     for (int j = 0; j < NR; ++j) p[j] = fma(r[j], p[j], 1.6666666666666666e-01);                   // 1/3!
 #pragma unroll
     for (int j = 0; j < NR; ++j) p[j] = fma(r[j], p[j], 0.5);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) { const double r2 = r[j] * r[j]; p[j] = fma(r2, p[j], r[j]) + 1.0; }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        // |z| beyond +-1100 would overflow the int conversion's meaning, not its saturation: clamp k, ldexp saturates
+        const int k = (int)fmin(fmax(kd[j], -2200.0), 2200.0);
+        e[j] = __builtin_amdgcn_ldexp(p[j], k);
+    }
+}
+
+// fexp_vec with its eleven addend constants through CRNN_SCONST(): the same operations on the same values (the same bits), for kernels
+// whose registers are full and whose vectors are short (hychem_sens2_kernel: one exponential per lane and point).
+template <int NR>
+__device__ __forceinline__ void fexp_vec_s(const double (&z)[NR], double (&e)[NR]) {
+    double kd[NR], r[NR], p[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) kd[j] = __builtin_rint(z[j] * 1.44269504088896338700e+00);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) r[j] = fma(kd[j], -6.93147180369123816490e-01, z[j]);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) r[j] = fma(kd[j], -1.90821492927058770002e-10, r[j]);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) p[j] = fma(r[j], 1.6059043836821613e-10, CRNN_SCONST(2.08767569878681e-09));   // 1/13!, 1/12!
+#pragma unroll
+    for (int j = 0; j < NR; ++j) p[j] = fma(r[j], p[j], CRNN_SCONST(2.505210838544172e-08));                    // 1/11!
+#pragma unroll
+    for (int j = 0; j < NR; ++j) p[j] = fma(r[j], p[j], CRNN_SCONST(2.755731922398589e-07));                    // 1/10!
+#pragma unroll
+    for (int j = 0; j < NR; ++j) p[j] = fma(r[j], p[j], CRNN_SCONST(2.7557319223985893e-06));                   // 1/9!
+#pragma unroll
+    for (int j = 0; j < NR; ++j) p[j] = fma(r[j], p[j], CRNN_SCONST(2.48015873015873e-05));                     // 1/8!
+#pragma unroll
+    for (int j = 0; j < NR; ++j) p[j] = fma(r[j], p[j], CRNN_SCONST(1.984126984126984e-04));                    // 1/7!
+#pragma unroll
+    for (int j = 0; j < NR; ++j) p[j] = fma(r[j], p[j], CRNN_SCONST(1.388888888888889e-03));                    // 1/6!
+#pragma unroll
+    for (int j = 0; j < NR; ++j) p[j] = fma(r[j], p[j], CRNN_SCONST(8.333333333333333e-03));                    // 1/5!
+#pragma unroll
+    for (int j = 0; j < NR; ++j) p[j] = fma(r[j], p[j], CRNN_SCONST(4.1666666666666664e-02));                   // 1/4!
+#pragma unroll
+    for (int j = 0; j < NR; ++j) p[j] = fma(r[j], p[j], CRNN_SCONST(1.6666666666666666e-01));                   // 1/3!
+#pragma unroll
+    for (int j = 0; j < NR; ++j) p[j] = fma(r[j], p[j], CRNN_SCONST(0.5));
 #pragma unroll
     for (int j = 0; j < NR; ++j) { const double r2 = r[j] * r[j]; p[j] = fma(r2, p[j], r[j]) + 1.0; }
 #pragma unroll

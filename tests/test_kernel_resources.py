@@ -86,16 +86,17 @@ def test_cathode_composite_dual_norm_kernel_has_no_scratch(tmp_path):
 def test_hychem_dual_norm_kernels(tmp_path):
     """The HyChem dual-norm gradient.  hychem_sens2_kernel -- sparse directions, closed-form tangents, one column
     per lane, the primal spread over the group, the trajectory's state in an LDS record -- is the kernel every gradient call of the
-    training loop runs: 60 B of scratch per lane (three spilled pairs around the exponentials of a point evaluation; round 4's kernel:
-    5 236 B) at a full register file, 100 KB of LDS per block of 256 (20 trajectories).  The two-columns-per-lane instantiation costs
+    training loop runs: NO scratch (round 4's kernel: 5 236 B; 60 B until the addend constants of its exponentials -- which the compiler
+    materialised ahead of the loops and reloaded from scratch at every use -- were formed in SGPRs where they are used: ros23_kernel.hpp
+    CRNN_SCONST, fexp_vec_s, fexp_ctl) at 488 of 512 registers, 100 KB of LDS per block of 256 (20 trajectories).  The two-columns-per-lane instantiation costs
     1.45x fewer issue slots per trajectory by the static count (tools/isa_attempt_cost.py) but keeps over a kilobyte of scratch: it
     must keep compiling (the A/B is one template argument away once a device is at hand) and is not what ships.
     hychem_sens_kernel -- dense directions, the fallback for a caller's own directions -- keeps round 4's closed-form / shared-factor
     footprint: two blocks of 128 per CU."""
     fast = _resources(tmp_path, "hychem_sens2_kernel.hpp", f"crnn::hychem_sens2_kernel<9,10,12,256,false>({HY})")
-    assert fast["scratch"] <= 64 and fast["vgpr"] + fast["agpr"] <= 512 and fast["lds"] <= 163840, fast
+    assert fast["scratch"] == 0 and fast["vgpr"] + fast["agpr"] <= 512 and fast["lds"] <= 163840, fast
     comp = _resources(tmp_path, "hychem_sens2_kernel.hpp", f"crnn::hychem_sens2_kernel<9,10,12,256,true>({HY})")       # through AutoTsit5(Rosenbrock23)
-    assert comp["scratch"] <= 128 and comp["lds"] <= 163840, comp
+    assert comp["scratch"] == 0 and comp["vgpr"] + comp["agpr"] <= 512 and comp["lds"] <= 163840, comp
     two = _resources(tmp_path, "hychem_sens2_kernel.hpp", f"crnn::hychem_sens2_kernel<9,10,6,256>({HY})")
     assert two["lds"] <= 163840, two
     dense = _resources(tmp_path, "hychem_sens_kernel.hpp", f"crnn::hychem_sens_kernel<9,10,128>({HY})")

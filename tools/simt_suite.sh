@@ -4,9 +4,19 @@
 # builds of the device library (crossbuild) or more than one rank.  Output: gpurun-free evidence of what the kernel sources compute;
 # the log is committed under profiles/ when it backs a claim.
 #   bash tools/simt_suite.sh [pytest args...]        e.g.  bash tools/simt_suite.sh tests/test_hychem.py -k errnorm
+#   SIMT_ASAN=1 bash tools/simt_suite.sh [...]       the same with the emulated kernels compiled under AddressSanitizer: "device" buffers are
+#       host allocations, LDS arrays and per-lane arrays are host objects, so an out-of-bounds read or write of a kernel is reported with its
+#       source line -- the compute-sanitizer this toolchain does not have (profiles/r05g_simt_asan_suite.txt)
 R=$(cd $(dirname $0)/.. && pwd)
+if [ -n "$SIMT_ASAN" ]; then
+  RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
+  SIMT_OUT=$R/tests/simt/libcrnn_simt_asan.so SIMT_FLAGS="-fsanitize=address -fno-omit-frame-pointer -shared-libasan" bash $R/tests/simt/build.sh || exit 1
+  export CRNN_HIP_LIB=$R/tests/simt/libcrnn_simt_asan.so LD_PRELOAD=$RT
+  export ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1:abort_on_error=1
+else
 bash $R/tests/simt/build.sh || exit 1
 export CRNN_HIP_LIB=$R/tests/simt/libcrnn_simt.so
+fi
 export SIMT_THREADS=${SIMT_THREADS:-6}
 cd $R
 if [ $# -gt 0 ]; then exec python -m pytest -m gpu -p no:cacheprovider "$@"; fi
