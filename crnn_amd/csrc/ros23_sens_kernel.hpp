@@ -238,7 +238,7 @@ __device__ __forceinline__ double sens_init_dt(const double *__restrict__ th, co
     d2 = sqrt((d2 + group_sum(d2p)) * idiv) / dt0;
     const double dm = fmax(d1, d2);
     // 10^(-(2 + log10 dm)/order) = exp(-(ln 100 + ln dm)/order)
-    const double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : exp((-1.0 / ORDER) * (4.605170185988091368 + flog(dm)));
+    const double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : fexp_ctl((-1.0 / ORDER) * (4.605170185988091368 + flog(dm)));
     return fmax(kc->dtmin, fmin(fmin(100.0 * dt0, dt1), dtmax));
 }
 
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
             es = es / ((double)N * (1.0 + (double)prm.norm_cols));
             if (!isfinite(es)) { rc = 3; break; }
             const bool ee_zero = (es == 0.0);
-            const double lEE = 0.5 * flog(ee_zero ? 1.0 : es);
+            const double lEE = 0.5 * flog_ctl(ee_zero ? 1.0 : es);
             const double lq11 = kc->beta1 * lEE;
             // one exponential and one division for both outcomes (with 21 trajectories in a wavefront some lane rejects in most
             // iterations, so both branches used to run): accepted: q = clamp(exp(lq11 - beta2 lqold) / gamma), rejected: exp(lq11) / gamma
@@ -796,7 +796,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_sens_kernel(const SolveParams prm
 #pragma unroll
                 for (int j = 0; j < NR; ++j) r0[j] = rec[(R_::R0 + po + j) * GPW];
             }
-            const double qe = exp(accept ? lq11 - kc->beta2 * lqold : lq11) / kc->gamma;
+            const double qe = fexp_ctl(accept ? lq11 - kc->beta2 * lqold : lq11) / kc->gamma;
             double q = ee_zero ? 1.0 / kc->qmax : fmax(1.0 / kc->qmax, fmin(1.0 / kc->qmin, qe));
             if (q >= kc->qsteady_min && q <= kc->qsteady_max) q = 1.0;
             const double dtq = dt / (accept ? q : fmin(1.0 / kc->qmin, qe));

@@ -347,10 +347,10 @@ __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm
             es = es / ((double)N * (1.0 + (double)prm.norm_cols));
             if (!isfinite(es)) { rc = 3; break; }
             const bool ee_zero = (es == 0.0);
-            const double lEE = 0.5 * flog(ee_zero ? 1.0 : es);
+            const double lEE = 0.5 * flog_ctl(ee_zero ? 1.0 : es);
             const double lq11 = kc->beta1 * lEE;
             double q = ee_zero ? 1.0 / kc->qmax
-                               : fmax(1.0 / kc->qmax, fmin(1.0 / kc->qmin, exp(lq11 - kc->beta2 * lqold) / kc->gamma));
+                               : fmax(1.0 / kc->qmax, fmin(1.0 / kc->qmin, fexp_ctl(lq11 - kc->beta2 * lqold) / kc->gamma));
             if (es <= 1.0) {
                 ++nacc;
 #pragma unroll
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm
                 if (jsave >= nsave) rc = 0;
             } else {
                 ++nrej;
-                dt = dt / fmin(1.0 / kc->qmin, exp(lq11) / kc->gamma);
+                dt = dt / fmin(1.0 / kc->qmin, fexp_ctl(lq11) / kc->gamma);
             }
             __builtin_amdgcn_wave_barrier();
         }

@@ -59,6 +59,10 @@ def test_dual_norm_kernel_has_no_scratch_and_two_blocks_per_cu(tmp_path):
     r = _resources(tmp_path, "ros23_sens_kernel.hpp", f"crnn::ros23_sens_kernel<6,3,true,false,3,3,128,26>({SENS})")
     # all of d theta / d p staged (26 rows) and still two blocks of 128 per CU: 2 x 79 984 B <= 160 KB; no scratch at 256 + 230 registers
     assert r["scratch"] == 0 and 2 * r["lds"] <= 163840, r
+    # robertson's instantiation (all four chunks in one launch: 44 rows): 60 B of scratch until the controller's exponential formed its
+    # constants in SGPRs (fexp_ctl) -- six serialised scratch reloads per attempt
+    r = _resources(tmp_path, "ros23_sens_kernel.hpp", f"crnn::ros23_sens_kernel<3,6,false,true,4,3,128,44>({SENS})")
+    assert r["scratch"] == 0 and 2 * r["lds"] <= 163840, r
 
 
 def test_tsit5_dual_norm_kernel_has_no_scratch_and_two_blocks_per_cu(tmp_path):

@@ -5,7 +5,7 @@
 # the log is committed under profiles/ when it backs a claim.
 #   bash tools/simt_suite.sh [pytest args...]        e.g.  bash tools/simt_suite.sh tests/test_hychem.py -k errnorm
 #   SIMT_ASAN=1 bash tools/simt_suite.sh [...]       the same with the emulated kernels compiled under AddressSanitizer: "device" buffers are
-#       host allocations, LDS arrays and per-lane arrays are host objects, so an out-of-bounds read or write of a kernel is reported with its
+#       host allocations, LDS arrays and per-lane arrays are host objects, so a read or write of a kernel outside the object it indexes (beyond an allocation, an LDS array, a per-lane array) is reported with its
 #       source line -- the compute-sanitizer this toolchain does not have (profiles/r05g_simt_asan_suite.txt)
 R=$(cd $(dirname $0)/.. && pwd)
 if [ -n "$SIMT_ASAN" ]; then
