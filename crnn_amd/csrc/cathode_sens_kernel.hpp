@@ -35,7 +35,13 @@ __global__ __launch_bounds__(BLOCK) void cathode_sens_kernel(const CathodeParams
     __shared__ double ts_s[kCathMaxSets * kCathMaxD];
     __shared__ double db_s[kCathMaxSets * kCathMaxD];
     __shared__ double d2_s[kCathMaxSets * kCathMaxD];
+    // the attempt's stage tangents k1', k2' of every column wait for the decision (commit: gradient increments, new columns).  Nine
+    // columns of them are 108 registers of a file that is full (292 B of scratch per lane, ~100 scratch instructions per attempt):
+    // the first chunk parks them in LDS (lane-contiguous, conflict-free; 108 KB per block of 256, one block per CU either way)
+    constexpr bool KP_LDS = (CH == 0);
+    __shared__ double kp_s[KP_LDS ? 2 * NCOL * 3 * BLOCK : 1];
     const int tid = threadIdx.x;
+    double *const kpl = kp_s + (KP_LDS ? tid : 0);
     // up to kCathMaxSets observation sets (the reference's five heating rates) are staged in LDS; larger ensembles of
     // heating rates (BASELINE config 5: 256) are read in place from HBM/L2 (rows of <= 1 KB, shared by all particles)
     const bool staged = prm.n_sets <= kCathMaxSets;
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(BLOCK) void cathode_sens_kernel(const CathodeParams
                 }
                 d2 = sqrt(d2 * inv_div) / dt0;
                 const double dm = fmax(d1, d2);
-                const double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : exp(-0.5 * (4.605170185988091368 + flog(dm)));
+                const double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : fexp_ctl(-0.5 * (4.605170185988091368 + flog_ctl(dm)));
                 dt = fmin(fmin(100.0 * dt0, dt1), dtmax);
             }
             {   // saveat contains tspan[1]
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(BLOCK) void cathode_sens_kernel(const CathodeParams
                 finite = finite && isfinite(unew[i]) && isfinite(ev);
             }
             // ---- the chunk's tangents through THIS ATTEMPT (the decision needs them), third stage included ----
-            double K1P[NCOL][3], K2P[NCOL][3];
+            double K1P[KP_LDS ? 1 : NCOL][3], K2P[KP_LDS ? 1 : NCOL][3];
 #pragma unroll
             for (int kk = 0; kk < NCOL; ++kk) {
                 const int k = K0 + kk;
@@ -295,7 +301,8 @@ __global__ __launch_bounds__(BLOCK) void cathode_sens_kernel(const CathodeParams
                     na[i] = fma(sc2[kk] * s[i], s[i], na[i]);
                     nb[i] = fma(sc2[kk] * sn[i], sn[i], nb[i]);
                     ee[i] = fma(sc2[kk] * de, de, ee[i]);
-                    K1P[kk][i] = k1p[i]; K2P[kk][i] = k2p;
+                    if constexpr (KP_LDS) { kpl[((0 * NCOL + kk) * 3 + i) * BLOCK] = k1p[i]; kpl[((1 * NCOL + kk) * 3 + i) * BLOCK] = k2p; }
+                    else { K1P[kk][i] = k1p[i]; K2P[kk][i] = k2p; }
                 }
             }
 #pragma unroll
@@ -308,10 +315,10 @@ __global__ __launch_bounds__(BLOCK) void cathode_sens_kernel(const CathodeParams
             if (!finite) rc = 3;
             else {
                 const bool ee_zero = (es == 0.0);
-                const double lEE = 0.5 * flog(ee_zero ? 1.0 : es);
+                const double lEE = 0.5 * flog_ctl(ee_zero ? 1.0 : es);
                 const double lq11 = prm.beta1 * lEE;
                 double q = ee_zero ? 1.0 / prm.qmax
-                                   : fmax(1.0 / prm.qmax, fmin(1.0 / prm.qmin, exp(lq11 - prm.beta2 * lqold) / prm.gamma));
+                                   : fmax(1.0 / prm.qmax, fmin(1.0 / prm.qmin, fexp_ctl(lq11 - prm.beta2 * lqold) / prm.gamma));
                 if (es <= 1.0) {
                     ++nacc;
                     // ---- save points: HRR observable, loss, seeds A, B1, B2 for the state tangents ----
@@ -341,10 +348,12 @@ __global__ __launch_bounds__(BLOCK) void cathode_sens_kernel(const CathodeParams
                         double acc = 0.0;
 #pragma unroll
                         for (int i = 0; i < 3; ++i) {
+                            const double k1p_ = KP_LDS ? kpl[((0 * NCOL + kk) * 3 + i) * BLOCK] : K1P[KP_LDS ? 0 : kk][i];
+                            const double k2p_ = KP_LDS ? kpl[((1 * NCOL + kk) * 3 + i) * BLOCK] : K2P[KP_LDS ? 0 : kk][i];
                             acc = fma(A_[i], S[kk][i], acc);
-                            acc = fma(B1[i], K1P[kk][i], acc);
-                            acc = fma(B2[i], K2P[kk][i], acc);
-                            S[kk][i] = fma(dt, K2P[kk][i], S[kk][i]);
+                            acc = fma(B1[i], k1p_, acc);
+                            acc = fma(B2[i], k2p_, acc);
+                            S[kk][i] = fma(dt, k2p_, S[kk][i]);
                         }
                         gS[kk] += acc;
                     }
@@ -359,7 +368,7 @@ __global__ __launch_bounds__(BLOCK) void cathode_sens_kernel(const CathodeParams
                     if (jsave >= D) rc = 0;
                 } else {
                     ++nrej;
-                    dt = dt / fmin(1.0 / prm.qmin, exp(lq11) / prm.gamma);
+                    dt = dt / fmin(1.0 / prm.qmin, fexp_ctl(lq11) / prm.gamma);
                 }
             }
         }

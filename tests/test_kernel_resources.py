@@ -77,6 +77,17 @@ def test_tsit5_dual_norm_kernel_has_no_scratch_and_two_blocks_per_cu(tmp_path):
 HY = "const crnn::SolveParams, const double*, const crnn::HyParams, const crnn::HySensParams"
 
 
+def test_cathode_dual_norm_kernel_has_no_scratch(tmp_path):
+    """cathode_sens_kernel, the default gradient of config 5 (ForwardDiff's chunks 9 + 8, one lane per trajectory): the first chunk's
+    instantiation carried 292 B of scratch per lane at 512 registers in round 4 (~100 scratch instructions per attempt); with the attempt's
+    stage tangents parked in LDS until the decision and the controller's constants formed in SGPRs: none, 484 registers, 132 KB of LDS
+    per block of 256 (one block per CU, as the registers dictate anyway)."""
+    CS = "const crnn::CathodeParams, const crnn::CathSensParams"
+    for ch in (0, 1):
+        r = _resources(tmp_path, "cathode_sens_kernel.hpp", f"crnn::cathode_sens_kernel<256,{ch}>({CS})")
+        assert r["scratch"] == 0 and r["vgpr"] + r["agpr"] <= 512 and r["lds"] <= 163840, r
+
+
 def test_cathode_composite_dual_norm_kernel_has_no_scratch(tmp_path):
     """cathode_sens_auto_kernel (the reference's gradient through AutoTsit5(TRBDF2), nine lanes per trajectory): both chunk instantiations
     without scratch (393 / 395 registers), LDS only for the staged observations."""
