@@ -112,6 +112,7 @@ SYMBOLS = {
     "crnn_ctx_set_queue_order": (C.c_int32, [_CTX, C.c_int32]),
     "crnn_ctx_set_lanes_per_traj": (C.c_int32, [_CTX, C.c_int32]),
     "crnn_last_lanes_per_traj": (C.c_int32, [_CTX]),
+    "crnn_tape_retries": (C.c_int64, [_CTX]),
     "crnn_ctx_set_jacobian": (C.c_int32, [_CTX, C.c_int32]),
     "crnn_last_step_counts": (C.c_int32, [_CTX, C.c_int64, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "crnn_kernel_times": (C.c_int32, [_CTX, _DP, C.c_int32]),

@@ -451,6 +451,10 @@ class NeuralODE:
         """Lanes per trajectory of the most recent adjoint gradient launch (1 or 2; 0: none yet)."""
         return int(lib.crnn_last_lanes_per_traj(self._ctx.h))
 
+    def tape_retries(self):
+        """HyChem: gradient launches repeated with fewer resident trajectories after a tape overflow (0: never)."""
+        return int(lib.crnn_tape_retries(self._ctx.h))
+
     def step_counts(self, first=0, count=None):
         """(naccept, nreject) of every trajectory in [first, first+count) of the most recent solve -- `sol.destats` of
         each `solve` of the ensemble (case2/case2.jl:126)."""

@@ -1972,6 +1972,11 @@ int32_t crnn_last_lanes_per_traj(const crnn_ctx *ctx) {
     return c ? c->last_lanes : -1;
 }
 
+int64_t crnn_tape_retries(const crnn_ctx *ctx) {
+    const Ctx *c = reinterpret_cast<const Ctx *>(ctx);
+    return c ? c->hy_tape_retries : -1;
+}
+
 int32_t crnn_ctx_set_lanes_per_traj(crnn_ctx *ctx, int32_t lanes) {
     Ctx *c = reinterpret_cast<Ctx *>(ctx);
     if (!c) return fail(c, "crnn_ctx_set_lanes_per_traj: null");

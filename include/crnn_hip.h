@@ -229,6 +229,11 @@ int32_t crnn_ctx_set_queue_order(crnn_ctx *ctx, int32_t order);
 int32_t crnn_ctx_set_lanes_per_traj(crnn_ctx *ctx, int32_t lanes);
 /* Lanes per trajectory the most recent adjoint gradient launch used (1 or 2; 0 if no adjoint launch has run, -1 for a null ctx). */
 int32_t crnn_last_lanes_per_traj(const crnn_ctx *ctx);
+/* HyChem: gradient launches this context had to repeat with fewer resident trajectories because a trajectory accepted more steps than
+ * its share of the adjoint tape holds (tape sized automatically, crnn_config.tape_steps = 0).  The width that fitted is remembered for
+ * calls of the same shape, so a count that keeps growing from call to call says the tape budget is too small for this ensemble: set
+ * crnn_config.tape_steps.  0 if it never happened; -1 for a null ctx. */
+int64_t crnn_tape_retries(const crnn_ctx *ctx);
 /* Jacobian behind W = I - gam J of the Rosenbrock23 stepper in PRIMAL launches (crnn_solve with n_dir = 0: predict_neuralode,
  * loss_neuralode, the epoch-end loop).  ANALYTIC (default): the exact J -- what Rosenbrock23(autodiff = true) forms
  * (robertson/rober_crnn.jl:33).  FINITE_DIFF: what Rosenbrock23(autodiff = false) forms (the stiff algorithm inside case2's

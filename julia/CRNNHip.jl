@@ -110,6 +110,7 @@ set_queue_order!(prob::Problem, order::Integer) =
 """Lanes per trajectory in the Rosenbrock23 adjoint kernel: 0 = auto (default), 1, 2 (a lane pair per trajectory: shards
 smaller than the chip, e.g. one GPU's share of a strongly-scaled batch)."""
 last_lanes_per_traj(prob::Problem) = ccall((:crnn_last_lanes_per_traj, LIB), Int32, (Ptr{Cvoid},), prob.ctx)
+tape_retries(prob::Problem) = ccall((:crnn_tape_retries, LIB), Int64, (Ptr{Cvoid},), prob.ctx)
 set_lanes_per_traj!(prob::Problem, lanes::Integer) =
     check(ccall((:crnn_ctx_set_lanes_per_traj, LIB), Int32, (Ptr{Cvoid}, Int32), prob.ctx, Int32(lanes)), prob.ctx)
 
