@@ -347,6 +347,12 @@ def main():
                                    "attempt) + the plain solve for the loss: the reference-faithful gradient mode; kernel_ms is the LAST launch only, "
                                    "call_ms the whole loss+gradient call"}, reps=3, errnorm_sens=1)
             sec["case2_errnorm_sens1"]["value"] = B / (sec["case2_errnorm_sens1"]["call_ms"] * 1e-3)
+            # the same through Tsit5 -- the branch of case2's AutoTsit5(Rosenbrock23) the reference stays in (tsit5_sens_kernel; round 5: 79 KB of
+            # LDS per block instead of 100, two blocks per CU)
+            sec["case2_errnorm_sens1_tsit5"] = bs.case2_fixed(u0, data, yscale, ck, {
+                "workload": note.replace("Rosenbrock23", "Tsit5") + "errnorm_sens = 1 as above, explicit Tsit5 (case2's reference algorithm while it stays "
+                                                                    "non-stiff; case1's Tsit5()): tsit5_sens_kernel"}, reps=3, errnorm_sens=1, solver=SOLVER_TSIT5)
+            sec["case2_errnorm_sens1_tsit5"]["value"] = B / (sec["case2_errnorm_sens1_tsit5"]["call_ms"] * 1e-3)
             progress("case2 strong-scaling shares (8 192 / 16 384 / 32 768 of the 65 536)")
             for nb in (8192, 16384, 32768):
                 sec[f"case2_B{nb}_share"] = bs.case2_fixed(u0[:nb], data[:nb], yscale, ck, {
