@@ -732,12 +732,16 @@ int32_t launch_hychem(Ctx *c, const double *d_theta, const double *d_dtheta, int
     // AutoTsit5(Rosenbrock23) (crnn_pyrolysis_mass.jl:29): primal launches run the composite (hychem_auto_kernel, a lane pair per
     // trajectory); gradient launches run the Rosenbrock23 adjoint with Rosenbrock23's controller constants (hychem_auto_kernel.hpp)
     const bool composite = c->cfg.solver == CRNN_SOLVER_AUTOTSIT5;
-    const bool auto_primal = composite && P == 0;
+    // Rosenbrock23(autodiff = false) (crnn_ctx_set_jacobian): primal launches of either solver run hychem_auto_kernel's finite-difference
+    // instantiations (the composite's, or its stiff branch alone for CRNN_SOLVER_ROSENBROCK23); gradient launches keep the analytic W
+    const bool fd_primal = c->jac_mode == CRNN_JAC_FINITE_DIFF && P == 0;
+    const bool auto_primal = (composite || fd_primal) && P == 0;
     const int G = (c->lanes_per_traj == 1 && !auto_primal) ? 1 : 2;
     const size_t gacc_need = G == 1 ? (size_t)((count + 63) / 64) * nth * 64 : 0;
     c->last_lanes = G;
     const int kHyBlock = 128 * G;
-    KFn fn = auto_primal ? (KFn)crnn::hychem_auto_kernel<9, 10, 256>
+    KFn fn = auto_primal ? (fd_primal ? (composite ? (KFn)crnn::hychem_auto_kernel<9, 10, 256, true, false> : (KFn)crnn::hychem_auto_kernel<9, 10, 256, true, true>)
+                                      : (KFn)crnn::hychem_auto_kernel<9, 10, 256>)
              : G == 2 ? (P > 0 ? (KFn)crnn::hychem2_kernel<9, 10, true, 256> : (KFn)crnn::hychem2_kernel<9, 10, false, 256>)
                       : (P > 0 ? (KFn)crnn::hychem_kernel<9, 10, true, 128> : (KFn)crnn::hychem_kernel<9, 10, false, 128>);
     struct CtlGuard {   // a gradient launch of a composite context: Rosenbrock23's PI exponents and steady band for this launch
@@ -1991,10 +1995,15 @@ int32_t crnn_ctx_set_jacobian(crnn_ctx *ctx, int32_t mode) {
     Ctx *c = reinterpret_cast<Ctx *>(ctx);
     if (!c) return fail(c, "crnn_ctx_set_jacobian: null");
     if (mode != CRNN_JAC_ANALYTIC && mode != CRNN_JAC_FINITE_DIFF) return fail(c, "crnn_ctx_set_jacobian: mode must be CRNN_JAC_ANALYTIC or CRNN_JAC_FINITE_DIFF");
-    if (mode == CRNN_JAC_FINITE_DIFF) {
-        const AdjEntry *ka = (c->hychem || c->cfg.solver != CRNN_SOLVER_ROSENBROCK23) ? nullptr : find_adjoint(c);
+    if (mode == CRNN_JAC_FINITE_DIFF && c->hychem) {
+        // HyChem (crnn_pyrolysis_mass.jl:29): J and dT by forward differences in the primal launches of Rosenbrock23 and of the
+        // AutoTsit5(Rosenbrock23) composite (hychem_auto_kernel<..., JFD>)
+        if (c->cfg.solver != CRNN_SOLVER_ROSENBROCK23 && c->cfg.solver != CRNN_SOLVER_AUTOTSIT5)
+            return fail(c, "crnn_ctx_set_jacobian: HyChem's finite-difference J exists for Rosenbrock23 and AutoTsit5(Rosenbrock23)");
+    } else if (mode == CRNN_JAC_FINITE_DIFF) {
+        const AdjEntry *ka = (c->cfg.solver != CRNN_SOLVER_ROSENBROCK23) ? nullptr : find_adjoint(c);
         if (!ka || !ka->fn_primal_fd)
-            return fail(c, "crnn_ctx_set_jacobian: the finite-difference W exists for the Rosenbrock23 primal launches of the CRNN right-hand side (case1, case2, robertson shapes)");
+            return fail(c, "crnn_ctx_set_jacobian: the finite-difference W exists for the Rosenbrock23 primal launches of the CRNN right-hand side (case1, case2, robertson shapes) and of HyChem");
     }
     c->jac_mode = mode;
     return 0;

@@ -23,7 +23,50 @@
 
 namespace crnn {
 
-template <int NS, int NR, int BLOCK>
+// Rosenbrock23(autodiff = false) -- what the reference configures (crnn_pyrolysis_mass.jl:29): this lane's rows of W = I - gam J with J from
+// FiniteDiff's forward differences of the right-hand side, column c = (f(u + eps_c e_c, t) - f(u, t)) / eps_c, eps_c = max(sqrt(eps) |u_c|,
+// sqrt(eps)), against the FSAL value f(u, t), and the time derivative dT = (f(u, t + e_t) - f(u, t)) / e_t, e_t = max(sqrt(eps) |t|, sqrt(eps)),
+// on the T(t), P(t) tables (Te, Pe = the tables at t + e_t).  NS + 1 point evaluations per attempt instead of one analytic pass: a parity
+// mode (primal launches; crnn_ctx_set_jacobian), checked against the oracle's orc_hychem.jac_fd = 1.  [UNVERIFIED-DEP] as the oracle's.
+template <int NS, int NR>
+__device__ __forceinline__ void hy_jac_ft2_fd(const double *th, const KConst *kc, const double inv_R, const double (&uo)[(NS + 1) / 2],
+                                              const double (&f0)[(NS + 1) / 2], const double T, const double P, const double Te, const double Pe,
+                                              const double et, const double gam, const bool m1, const HyLane<(NS + 1) / 2> &ln,
+                                              double (&A)[(NS + 1) / 2][NS], double (&fto)[(NS + 1) / 2]) {
+    constexpr int H = (NS + 1) / 2;
+    constexpr double rel = 1.4901161193847656e-08;   // sqrt(eps(Float64)): FiniteDiff's default relative step of forward differences
+#pragma unroll
+    for (int c = 0; c < NS; ++c) {
+        const bool codd = (c & 1) != 0;
+        const double uc = pair_pick(uo[c >> 1], codd, m1);
+        const double eps = fmax(rel * fabs(uc), rel);
+        double up[H];
+#pragma unroll
+        for (int i = 0; i < H; ++i) up[i] = uo[i];
+        if (m1 == codd) up[c >> 1] = uc + eps;
+        HyPoint2<NS, NR> pp;
+        hy_point2<NS, NR, 1>(th, kc, inv_R, up, T, P, m1, ln, pp, nullptr);
+        const double ie = 1.0 / eps;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            const bool diag = (c == 2 * i) ? !m1 : ((c == 2 * i + 1) ? m1 : false);
+            A[i][c] = (diag ? 1.0 : 0.0) - gam * ((pp.fo[i] - f0[i]) * ie);
+        }
+#pragma unroll
+        for (int i = 0; i < H; ++i) opaque(A[i][c]);   // column by column: the NS evaluations are not interleaved (registers)
+        CRNN_SCHED_FENCE();
+    }
+    HyPoint2<NS, NR> pe;
+    hy_point2<NS, NR, 1>(th, kc, inv_R, uo, Te, Pe, m1, ln, pe, nullptr);
+    const double iet = 1.0 / et;
+#pragma unroll
+    for (int i = 0; i < H; ++i) fto[i] = ln.ow[i] ? (pe.fo[i] - f0[i]) * iet : 0.0;
+}
+
+// JFD: the stiff algorithm's J and dT by forward differences (above).  STIFF_ONLY: no Tsit5 branch and no switching -- plain Rosenbrock23 with the
+// context's PI exponents (hychem2_kernel's primal launch operation for operation; instantiated with JFD for CRNN_SOLVER_ROSENBROCK23 contexts
+// in finite-difference mode).
+template <int NS, int NR, int BLOCK, bool JFD = false, bool STIFF_ONLY = false>
 __global__ __launch_bounds__(BLOCK) void hychem_auto_kernel(const SolveParams prm, const double *__restrict__ theta, const HyParams hp) {
     using L_ = LayH<NS, NR>;
     constexpr int NTH = L_::NTH;
@@ -114,7 +157,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_auto_kernel(const SolveParams pr
         double t = t0, dt = 0.0, lqold = lqinit;
         int iter = 0, jsave = 0, nacc = 0, nrej = 0;
         int rc = valid ? -1 : 0;
-        int alg = 0, cnt = 0;          // 0 Tsit5, 1 Rosenbrock23; signed run length of the stiffness test
+        int alg = STIFF_ONLY ? 1 : 0, cnt = 0;          // 0 Tsit5, 1 Rosenbrock23; signed run length of the stiffness test
         double eig = 0.0;
         bool have_eig = false;
 #pragma unroll
@@ -151,7 +194,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_auto_kernel(const SolveParams pr
             d2 = sqrt(pair_sum(d2) * (1.0 / NS)) / dt0;
             const double dm = fmax(d1, d2);
             // the order of the STARTING algorithm (5): 10^(-(2 + log10 dm) / 5)
-            const double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : exp(-0.2 * (4.605170185988091368 + flog(dm)));
+            const double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : exp((STIFF_ONLY ? -0.5 : -0.2) * (4.605170185988091368 + flog(dm)));
             dt = fmax(kc->dtmin, fmin(fmin(100.0 * dt0, dt1), dtmax));
 #pragma unroll
             for (int i = 0; i < H; ++i) f0[i] = p0.fo[i];
@@ -186,7 +229,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_auto_kernel(const SolveParams pr
                 bool last = false;
                 if (jsave >= nsave) rc = 0;
                 else if (iter > prm.maxiters) rc = 1;
-                if (rc < 0 && have_eig) {   // choose_algorithm! at the loop header
+                if (!STIFF_ONLY && rc < 0 && have_eig) {   // choose_algorithm! at the loop header
                     const bool stiff = fabs(eig * dt * (1.0 / AutoSw::stability_size)) > AutoSw::tol;
                     cnt = stiff ? (cnt < 0 ? 1 : cnt + 1) : (cnt > 0 ? -1 : cnt - 1);
                     if (alg == 0 && cnt > AutoSw::maxstiffstep) { dt *= AutoSw::dtfac; alg = 1; }
@@ -209,7 +252,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_auto_kernel(const SolveParams pr
                         q = ee_zero ? inv_qmax : fmax(inv_qmax, fmin(inv_qmin, fexp_ctl(lq11 - b2 * lqold) / kc->gamma));
                         return es <= 1.0;
                     };
-                    if (alg == 0) {
+                    if (!STIFF_ONLY && alg == 0) {
                         // ---------------------------------------------------------------- Tsit5 attempt
                         double k[7][H], g6[H];
 #pragma unroll
@@ -309,6 +352,13 @@ __global__ __launch_bounds__(BLOCK) void hychem_auto_kernel(const SolveParams pr
                             p0.irho = fq[63]; p0.iS = fq[64];
                             p0.cY = f0cY; p0.cC = f0cC;
                         }
+                        if constexpr (JFD) {
+                            const double et = fmax(1.4901161193847656e-08 * fabs(t), 1.4901161193847656e-08);
+                            double Te, Pe, a_, b_;
+                            tab(t + et, Te, Pe, a_, b_);
+                            hy_jac_ft2_fd<NS, NR>(th, kc, hp.inv_R, u, f0, T, P, Te, Pe, et, gam, m1, ln, A, ft);
+                            HYA_FRESH_THETA(th); HYA_FRESH_KC(kc);
+                        } else
                         hy_jac_ft2<NS, NR, 1>(th, kc, p0, fr, gam, Pd * frcp(P) - Td * frcp(T), -hp.inv_R * Td * frcp(T * T), Td * frcp(T), m1, ln, A, ft);
                         CRNN_SCHED_FENCE();
                         {   // eigen_est = opnorm(J, Inf): J = (I - A) / gam, this lane's rows, then the pair's maximum
@@ -379,7 +429,7 @@ __global__ __launch_bounds__(BLOCK) void hychem_auto_kernel(const SolveParams pr
                         }
                         es = pair_sum(es) * (1.0 / NS);
                         if (pair_and(fin) == 0) rc = 3;
-                        else if (controller(b1_rb, b2_rb)) {
+                        else if (STIFF_ONLY ? controller(kc->beta1, kc->beta2) : controller(b1_rb, b2_rb)) {
                             accepted = true;
                             ++nacc;
                             while (jsave < nsave) {

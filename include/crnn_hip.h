@@ -243,8 +243,12 @@ int64_t crnn_tape_retries(const crnn_ctx *ctx);
  * not vendored with the reference), ns more right-hand sides per attempt and a dense ns x ns factorisation.  Rosenbrock23 is a
  * W-method, so both are Rosenbrock23 solves of the same problem: results differ by ~1e-8 relative in J; in a loss at the
  * reference's tolerances by ~2e-9 on case2 and 3e-4 ... 1.3e-3 on robertson (stiffness 1e11: tests/test_gpu_primal.py).  Gradient launches are not affected: they differentiate the analytic-W step (the reference
- * pushes Duals through FiniteDiff's increments).  CRNN right-hand side with Rosenbrock23 only (not HyChem,
- * whose reference Jacobian also carries a finite-difference time derivative). */
+ * pushes Duals through FiniteDiff's increments).  CRNN right-hand side: Rosenbrock23 contexts only.
+ * HyChem contexts (round 5; HyChem/crnn_pyrolysis_mass.jl:29, AutoTsit5(Rosenbrock23(autodiff=false))): the primal launches of a
+ * Rosenbrock23 or an AUTOTSIT5 context form J column by column from ns more right-hand sides AND the time derivative
+ * dT = (f(u, t + e_t) - f(u, t)) / e_t, e_t = max(sqrt(eps) |t|, sqrt(eps)), on the T(t), P(t) tables (hychem_auto_kernel<..., JFD>):
+ * a parity mode, ~3x the right-hand sides of an attempt; it moves a loss at the reference's tolerances by ~3e-4 on hot trajectories
+ * (1e-5 inside the composite, 5e-9 at rtol 1e-8; tests/test_hychem.py). */
 enum { CRNN_JAC_ANALYTIC = 0, CRNN_JAC_FINITE_DIFF = 1 };
 int32_t crnn_ctx_set_jacobian(crnn_ctx *ctx, int32_t mode);
 

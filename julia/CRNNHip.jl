@@ -115,7 +115,9 @@ set_lanes_per_traj!(prob::Problem, lanes::Integer) =
     check(ccall((:crnn_ctx_set_lanes_per_traj, LIB), Int32, (Ptr{Cvoid}, Int32), prob.ctx, Int32(lanes)), prob.ctx)
 
 """`set_jacobian!(prob, JAC_FINITE_DIFF)`: the primal launches build `W` from forward differences of the right-hand side, as
-`Rosenbrock23(autodiff=false)` does (`case2/case2.jl:26`); `JAC_ANALYTIC` (default): the exact Jacobian (`autodiff=true`)."""
+`Rosenbrock23(autodiff=false)` does (`case2/case2.jl:26`); on a HyChem problem (`HyChem/crnn_pyrolysis_mass.jl:29`) also the
+finite-difference time derivative on the `T(t)`, `P(t)` tables, for Rosenbrock23 and inside `AutoTsit5(Rosenbrock23)`;
+`JAC_ANALYTIC` (default): the exact Jacobian (`autodiff=true`)."""
 set_jacobian!(prob::Problem, mode::Integer) =
     check(ccall((:crnn_ctx_set_jacobian, LIB), Int32, (Ptr{Cvoid}, Int32), prob.ctx, Int32(mode)), prob.ctx)
 const JAC_ANALYTIC = Int32(0)

@@ -326,6 +326,56 @@ def test_gpu_hychem_autotsit5_composite_primal(orc, hfx):
     assert n_switch >= 3
 
 
+@pytest.mark.gpu
+def test_gpu_hychem_finite_difference_jacobian_primal(orc, hfx):
+    """Rosenbrock23(autodiff=false) as config 4 configures its stiff algorithm (crnn_pyrolysis_mass.jl:29) on the DEVICE: after
+    crnn_ctx_set_jacobian(FINITE_DIFF) the primal launches (predict_n_ode, loss_n_ode: :135-147) of a HyChem context form J by FiniteDiff's
+    forward differences and dT = (f(u, t + e_t) - f(u, t)) / e_t on the T(t), P(t) tables (hychem_auto_kernel<..., JFD>), for plain
+    Rosenbrock23 and inside AutoTsit5(Rosenbrock23) -- against the oracle's jac_fd = 1.  A difference quotient over 1.5e-8 |u| amplifies
+    last-bit differences of the right-hand side by ~1e8, so W agrees to ~1e-8 relative rather than 1e-16; a Rosenbrock-W step forgives
+    that: measured on the kernel's source under SIMT emulation (no device in round 5) predictions 6e-11, losses 2e-10, accepted steps
+    357 = 357 / 35 330 vs 35 335 / 238 = 238 (composite).  Bars 1e-8 / 1e-7 leave room for the device's rcp / exp rounding.  The mode moves
+    the analytic-J loss by what the oracle says it should (2.8e-4 on the hot trajectories at rtol 1e-3, 1.3e-5 inside the composite,
+    5e-9 at rtol 1e-8).  Gradient launches keep the analytic W."""
+    from crnn_amd import SOLVER_AUTOTSIT5, SOLVER_ROSENBROCK23, JAC_FINITE_DIFF, JAC_ANALYTIC
+    u0s, datas, Tts, Pts = _synthetic(hfx, 5, 3)
+    u0 = np.concatenate([hfx["u0"], u0s]); data = np.concatenate([hfx["data"], datas])
+    Tt = np.concatenate([hfx["Ttab"], Tts]); Pt = np.concatenate([hfx["Ptab"], Pts])
+    B = u0.shape[0]
+    p = hfx["p"]
+    th, _ = orc.hychem_p2vec(p)
+    moved = 0.0
+    for solver, osolver in ((SOLVER_ROSENBROCK23, 0), (SOLVER_AUTOTSIT5, 2)):
+        for atol, rtol, bar_l, bar_p in ((1e-8, 1e-3, 1e-7, 1e-8), (1e-12, 1e-8, 1e-7, 1e-8)):
+            if osolver == 2 and rtol == 1e-8:
+                continue       # (the composite at tight tolerance never leaves Tsit5 on these conditions: nothing of J to test)
+            node = _node(hfx, u0, data, Tt, Pt, solver=solver, atol=atol, rtol=rtol, maxiters=10**6)
+            la = node.loss_n_ode(p)
+            ga = node.loss_and_grad(p)
+            node.set_jacobian(JAC_FINITE_DIFF)
+            pred = node.predict_n_ode(p)
+            assert np.all(node.last_retcode == 0)
+            lf = node.loss_n_ode(p)
+            st = dict(node.last_stats)
+            gf = node.loss_and_grad(p)
+            assert ga[0] == gf[0] and np.array_equal(ga[1], gf[1])          # gradient launches: the analytic W either way
+            c = orc.make_hychem(dydt_scale=hfx["dydt_scale"], yscale=hfx["yscale"], atol=atol, rtol=rtol, maxiters=10**6, solver=osolver, jac_fd=1)
+            nacc = nrej = 0
+            for b in range(B):
+                r = orc.hychem_solve_one(c, th, u0[b], hfx["ts"], Tt[b], Pt[b], data[b], want_pred=True)
+                assert r["retcode"] == 0 and r["n_saved"] == 40
+                assert np.max(np.abs(pred[b] - r["pred"])) < bar_p, (solver, rtol, b, np.max(np.abs(pred[b] - r["pred"])))
+                assert abs(lf[b] - r["loss"]) < bar_l * r["loss"], (solver, rtol, b, abs(lf[b] - r["loss"]) / r["loss"])
+                nacc += r["naccept"]; nrej += r["nreject"]
+            assert abs(st["n_accept"] - nacc) <= max(2, 0.01 * nacc) and abs(st["n_reject"] - nrej) <= max(2, 0.05 * nrej), (st, nacc, nrej)
+            if rtol == 1e-3 and osolver == 0:
+                moved = np.max(np.abs(lf - la) / la)
+            node.set_jacobian(JAC_ANALYTIC)
+            assert np.array_equal(node.loss_n_ode(p), la)
+            node.close()
+    assert 1e-5 < moved < 5e-3      # the mode is not a no-op, and not a different problem
+
+
 def test_hychem_oracle_errnorm_sens_chunks(orc, hfx):
     """errnorm_sens in the oracle's HyChem solve (crnn_pyrolysis_mass.jl:201 as ForwardDiff evaluates it: 211 parameters in chunks of
     12, each its own adaptive solve with the chunk's partials in the error norm): the chunks take their own step counts, the gradient
@@ -352,7 +402,7 @@ def test_hychem_oracle_errnorm_sens_chunks(orc, hfx):
 def test_hychem_oracle_finite_difference_jacobian_and_time_derivative(orc, hfx):
     """The stiff algorithm as the reference configures it for config 4, Rosenbrock23(autodiff=false) (crnn_pyrolysis_mass.jl:29): J by
     FiniteDiff's forward differences and dT = (f(u, t + e_t) - f(u, t)) / e_t on the T(t), P(t) tables (oracle jac_fd = 1, primal
-    solves; [UNVERIFIED-DEP] increments).  Oracle only -- the device forms the analytic J and the analytic table slope.  It is a
+    solves; [UNVERIFIED-DEP] increments).  The oracle's side of test_gpu_hychem_finite_difference_jacobian_primal.  It is a
     W-method either way: at tight tolerance both converge to the same solution; at the reference's tolerances the hot trajectories move
     by ~3e-4 in the loss (and a few accept / reject decisions), the cold one by 4e-7; inside the composite, which spends few steps in
     the stiff branch, by 1e-5.  Tangents through the quotients are refused, not silently analytic."""

@@ -116,3 +116,12 @@ def test_hychem_dual_norm_kernels(tmp_path):
     assert two["lds"] <= 163840, two
     dense = _resources(tmp_path, "hychem_sens_kernel.hpp", f"crnn::hychem_sens_kernel<9,10,128>({HY})")
     assert dense["scratch"] <= 3700 and 2 * dense["lds"] <= 163840, dense
+
+
+def test_hychem_finite_difference_primal_kernels(tmp_path):
+    """hychem_auto_kernel<..., JFD> (crnn_ctx_set_jacobian on a HyChem context, round 5): ten more inlined point evaluations per stiff
+    attempt must not push the lane-pair layout into scratch -- column by column, each evaluation's registers released before the next."""
+    for inst in ("true,false", "true,true"):
+        r = _resources(tmp_path, "hychem_auto_kernel.hpp", f"crnn::hychem_auto_kernel<9,10,256,{inst}>(const crnn::SolveParams, const double*, const crnn::HyParams)")
+        assert r["scratch"] == 0 and r["vgpr"] + r["agpr"] <= 512 and r["lds"] <= 160 * 1024, r
+

@@ -70,6 +70,11 @@ def test_hychem_dual_norm_kernels_against_the_oracle_under_emulation(simt_lib):
     assert n == 3
 
 
+def test_hychem_finite_difference_jacobian_against_the_oracle_under_emulation(simt_lib):
+    """hychem_auto_kernel<..., JFD>: Rosenbrock23(autodiff=false)'s J and dT (crnn_pyrolysis_mass.jl:29), alone and inside the composite."""
+    assert _run(simt_lib, ["tests/test_hychem.py", "-k", "finite_difference_jacobian_primal"]) == 1
+
+
 def test_cathode_chunked_gradient_against_the_oracle_under_emulation(simt_lib):
     n = _run(simt_lib, ["tests/test_cathode.py", "-k", "(errnorm_sens_matches_oracle_chunk_for_chunk and 2) or gradient_through_the_reference_composite"])
     assert n == 2
