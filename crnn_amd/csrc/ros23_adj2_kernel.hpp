@@ -23,6 +23,7 @@
 // pairs still fit the resident lanes (crnn_capi.hip launch_adjoint; crnn_ctx_set_lanes_per_traj).
 // Shapes: nr < ns (Woodbury form of W: case1, case2), no rate scaling.  Robertson (ns = 3 < nr = 6, dense W) keeps one lane.
 #pragma once
+#include <type_traits>
 #include "ros23_adj_kernel.hpp"
 
 // phase timing (tools/kvariants.sh build prof2="-DCRNN_ADJ2_PROF=1"; the library prints the shares of wave 0 of block 0 to stderr after
@@ -57,9 +58,6 @@ __device__ __forceinline__ int pair_and(int a) { return a & __builtin_amdgcn_upd
 #ifndef CRNN_ADJ2_LEAN
 #define CRNN_ADJ2_LEAN 0
 #endif
-#ifndef CRNN_ADJ2_SEEDS_FLAT
-#define CRNN_ADJ2_SEEDS_FLAT 0   // experiment: branch-free save-point seeds in the reverse sweep (see seed_point)
-#endif
 template <int NS, int NR, bool HAS_T, int BLOCK, int OCC>
 __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParams prm, const double *__restrict__ theta,
                                                                 const AdjParams adj) {
@@ -73,7 +71,8 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
     static_assert(NTH + kExtra <= 64, "the per-batch sums use one lane per column");
 
     __shared__ double kc_lds[kNConst];
-    __shared__ double ts_lds[kMaxSave];
+    __shared__ double tsp_lds[kMaxSave + 2];               // two -inf slots in front: the reverse sweep reads two save times back unconditionally
+    double *const ts_lds = tsp_lds + 2;
     __shared__ double stage_lds[(NTH + kExtra) * GPB];    // batch sums: [column][pair of this block]
     constexpr bool LEAN = (CRNN_ADJ2_LEAN != 0) && (NS % 2 == 0);
     __shared__ double th2_lds[LEAN ? NTH : 1];
@@ -81,6 +80,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
     if (LEAN) for (int idx = tid; idx < NTH; idx += BLOCK) th2_lds[idx] = theta[idx];
     for (int idx = tid; idx < kNConst; idx += BLOCK) kc_lds[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
     for (int idx = tid; idx < prm.n_save; idx += BLOCK) ts_lds[idx] = prm.tsave[idx];
+    if (tid < 2) tsp_lds[tid] = -INFINITY;
     __syncthreads();
     const KConst *kc = reinterpret_cast<const KConst *>(kc_lds);
 
@@ -129,6 +129,9 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
 #define RTL(i) (LEAN ? reinterpret_cast<const KConst *>(kcl0 + opaque_zero())->rtol[m * H + (i)] : rtl_[LEAN ? 0 : (i)])
 #define IYS(i) (LEAN ? reinterpret_cast<const KConst *>(kcl0 + opaque_zero())->inv_yscale[m * H + (i)] : iys_[LEAN ? 0 : (i)])
 
+    double iyz[H];                          // 1/yscale of this lane's observed species, 0 for unobserved / padding ones (reverse sweep)
+#pragma unroll
+    for (int i = 0; i < H; ++i) iyz[i] = dro[i] >= 0 ? kc->inv_yscale[m * H + i < NS ? m * H + i : 0] : 0.0;
     const double d_ = 0.29289321881345248;    // 1/(2+sqrt 2)
     const double c32 = 7.4142135623730950;    // 6+sqrt 2
     const double inv12d = 2.4142135623730950; // 1/(1-2d)
@@ -139,10 +142,8 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
     const double dtmax = tend - t0;
     const double lqinit = flog(kc->qoldinit);
     const bool start_saved = (ts0 == t0);
-#if CRNN_ADJ2_SEEDS_FLAT
-    const double ubc = prm.clamp_pred ? kc->ub : __builtin_inf();
+    const double ubc = prm.clamp_pred ? kc->ub : __builtin_inf();   // no clamp = an infinite clamp
     const bool lk0 = prm.loss_kind == 0;
-#endif
 
     double *const tape = adj.tape + (size_t)((size_t)blockIdx.x * GPB + gib) * adj.tape_cap * RECW;
 #ifdef CRNN_ADJ2_PROF
@@ -480,8 +481,10 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
 #pragma unroll
             for (int i = 0; i < H; ++i) d[i] = row[doff[i]];
         };
-        double ts_cur = (jsave - 1 >= jlo) ? ts_lds[jsave - 1] : -INFINITY;
-        double ts_nxt = (jsave - 2 >= jlo) ? ts_lds[jsave - 2] : -INFINITY;
+        // the save times the reverse sweep is about to pass.  No guard on the index: below zero sit the -inf slots, and with save_start
+        // (jlo = 1) slot 0 holds t0 itself, which no step begins before -- "ts > tn" is false for it as it would be for -inf
+        double ts_cur = ts_lds[jsave - 1];
+        double ts_nxt = ts_lds[jsave - 2];
         double rt = 0.0, rdt = 0.0, ru[H];   // tape record s, prefetched
         auto load_rec = [&](int idx) {
             CRNN_CHK(idx < adj.tape_cap, 23);
@@ -528,78 +531,58 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
                 ADJ2_T(9);   // reverse: re-formation of the step
 
                 // ---- loss and its seeds at the save points inside (tn, tnew]
-                double A_[H], B1[H], B2[H];
+                // Straight-line per point (round 5; a fifth of the kernel's time in round 4's phase profile, profiles/r04l, mostly selects and
+                // per-species branches): the loss kind is ONE wave-uniform branch around the whole phase; an unobserved (or padding) species is
+                // a zero weight, no clamp an infinite clamp; the end-of-step point needs no select (c1 = 0, c2 = 1 give h k2 + u_n bit for bit);
+                // the mask is "the clamp changed nothing".  Same values as the branchy form it replaces (parity + cross-kernel tests).
+                double A_[H], B1[H], B2[H], k2[H];
 #pragma unroll
-                for (int i = 0; i < H; ++i) { A_[i] = 0.0; B1[i] = 0.0; B2[i] = 0.0; }
+                for (int i = 0; i < H; ++i) { A_[i] = 0.0; B1[i] = 0.0; B2[i] = 0.0; k2[i] = k1[i] + dk[i]; }
                 const double inv_h = frcp(h);
                 auto in_step = [&]() -> bool { return ts_cur > tn; };
-                auto seed_point = [&](const double (&dobs)[H]) {
+                auto seed_point = [&](const double (&dobs)[H], auto lk_) {
+                    constexpr bool LK0 = decltype(lk_)::value;
                     const double ts = ts_cur;
                     CRNN_CHK(jsave - 1 >= jlo && jsave - 1 < nsave, 28);
                     ts_cur = ts_nxt;
-                    ts_nxt = (jsave - 3 >= jlo) ? ts_lds[jsave - 3] : -INFINITY;
+                    ts_nxt = ts_lds[jsave - 3];
                     const bool at_end = (ts == tnew);
                     const double Th = at_end ? 1.0 : (ts - tn) * inv_h;
-                    const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
+                    const double c1 = Th * (1.0 - Th) * inv12d;        // at the end of the step: 1 * 0 * inv12d = 0 exactly, no select
                     const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d_) * inv12d;
-#if CRNN_ADJ2_SEEDS_FLAT
-                    // straight-line: an unobserved (or padding) species is a zero weight, no clamp an infinite clamp, the loss kind a
-                    // select -- this phase is a fifth of the kernel by -DCRNN_ADJ2_PROF=2 (20.3 %, as much as re-forming the step).
-                    // UNMEASURED: written when GPU access closed; same values by construction; default off until timed (kvariants flat="-DCRNN_ADJ2_SEEDS_FLAT=1")
+                    const double hc1 = h * c1, hc2 = h * c2;
 #pragma unroll
                     for (int i = 0; i < H; ++i) {
-                        const double k2i = k1[i] + dk[i];
-                        double v = at_end ? fma(h, k2i, un[i]) : fma(h, fma(c1, k1[i], c2 * k2i), un[i]);
-                        const double mask = (v > ubc || v < -ubc) ? 0.0 : 1.0;
-                        v = clampv(v, -ubc, ubc);
-                        const double iy = dro[i] >= 0 ? IYS(i) : 0.0;
-                        const double rr = (dobs[i] - v) * iy;
-                        loss_sum = lk0 ? loss_sum + fabs(rr) : fma(rr, rr, loss_sum);
-                        double w = lk0 ? (signbit(rr) ? 1.0 : -1.0) : -2.0 * rr;
-                        w *= mask * iy;
+                        const double v = fma(h, fma(c1, k1[i], c2 * k2[i]), un[i]);
+                        const double vc = fmin(fmax(v, -ubc), ubc);      // v is finite here (accepted steps only): = clampv
+                        const double rr = (dobs[i] - vc) * iyz[i];
+                        double w;
+                        if constexpr (LK0) { loss_sum += fabs(rr); w = signbit(rr) ? iyz[i] : -iyz[i]; }
+                        else { loss_sum = fma(rr, rr, loss_sum); w = (-2.0 * rr) * iyz[i]; }
+                        w = (vc == v) ? w : 0.0;
                         A_[i] += w;
-                        B1[i] = fma(w, h * c1, B1[i]);
-                        B2[i] = fma(w, h * c2, B2[i]);
+                        B1[i] = fma(w, hc1, B1[i]);
+                        B2[i] = fma(w, hc2, B2[i]);
                     }
-#else
-#pragma unroll
-                    for (int i = 0; i < H; ++i) {
-                        if (dro[i] >= 0) {
-                            const double k2i = k1[i] + dk[i];
-                            double v = at_end ? fma(h, k2i, un[i]) : fma(h, fma(c1, k1[i], c2 * k2i), un[i]);
-                            double mask = 1.0;
-                            if (prm.clamp_pred) {
-                                mask = (v > kc->ub || v < -kc->ub) ? 0.0 : 1.0;
-                                v = clampv(v, -kc->ub, kc->ub);
-                            }
-                            const double iy = IYS(i);
-                            const double rr = (dobs[i] - v) * iy;
-                            double w;
-                            if (prm.loss_kind == 0) { loss_sum += fabs(rr); w = signbit(rr) ? 1.0 : -1.0; }
-                            else { loss_sum = fma(rr, rr, loss_sum); w = -2.0 * rr; }
-                            w *= mask * iy;
-                            A_[i] += w;
-                            B1[i] = fma(w, h * c1, B1[i]);
-                            B2[i] = fma(w, h * c2, B2[i]);
-                        }
-                    }
-#endif
                     --jsave;
                 };
-                if (in_step()) {
-                    seed_point(dA);
+                auto seeds = [&](auto lk_) {
                     if (in_step()) {
-                        seed_point(dB);
+                        seed_point(dA, lk_);
                         if (in_step()) {
-                            seed_point(dC);
-                            while (in_step()) {
-                                double dD[H];
-                                load_row(jsave - 1, dD);
-                                seed_point(dD);
+                            seed_point(dB, lk_);
+                            if (in_step()) {
+                                seed_point(dC, lk_);
+                                while (in_step()) {
+                                    double dD[H];
+                                    load_row(jsave - 1, dD);
+                                    seed_point(dD, lk_);
+                                }
                             }
                         }
                     }
-                }
+                };
+                if (lk0) seeds(std::true_type{}); else seeds(std::false_type{});
 
                 ADJ2_T(10);   // reverse: loss + seeds
                 // ---- adjoint of the step (ros23_adj_kernel.hpp, same formulas; sums over species cross the pair once)

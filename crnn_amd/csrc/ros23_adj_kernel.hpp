@@ -29,6 +29,7 @@
 // read once, by the reverse sweep, where loss and seeds are formed together.  theta sits in LDS (see below), the 42 (case2)
 // gradient accumulators of a lane in LDS ([m][lane], ds_add_f64), the per-batch sums are formed in the kernel.
 #pragma once
+#include <type_traits>
 #include "ros23_kernel.hpp"
 
 // kernel-timing ablations (tools/kvariants.sh): 1 = no reverse sweep, 2 = no observed-data loads, 4 = no tape stores,
@@ -646,6 +647,9 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
 
                 ADJ_T(9);    // reverse: prefetches + re-formation of the step
                 // ---- loss and its seeds at the save points inside (tn, tnew]
+                // Straight-line per point (round 5, as ros23_adj2_kernel.hpp): the loss kind is one wave-uniform branch around the phase, no
+                // clamp is an infinite clamp, the end-of-step point needs no select on v (c1 = 0, c2 = 1 give h k2 + u_n bit for bit), the
+                // mask is "the clamp changed nothing" -- the values of the branchy form it replaces.
                 double A_[NS], B1[NS], B2[NS];
 #pragma unroll
                 for (int i = 0; i < NS; ++i) { A_[i] = 0.0; B1[i] = 0.0; B2[i] = 0.0; }
@@ -653,8 +657,10 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                 // inside this step" and the seed itself do not wait for LDS (the same in the forward sweep's save-point loop gains
                 // nothing: two more registers live across that loop)
                 const double inv_h = frcp(h);      // one reciprocal per step instead of an IEEE division per save point (1e-16)
+                const double ubc = prm.clamp_pred ? kc->ub : __builtin_inf();
                 auto in_step = [&]() -> bool { return ts_cur > tn; };
-                auto seed_point = [&](const double (&dobs)[NS]) {
+                auto seed_point = [&](const double (&dobs)[NS], auto lk_) {
+                    constexpr bool LK0 = decltype(lk_)::value;
                     const double ts = ts_cur;
                     CRNN_CHK(jsave - 1 >= jlo && jsave - 1 < nsave, 8);
                     if (TS_PF) {
@@ -665,45 +671,46 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                     }
                     const bool at_end = (ts == tnew);
                     const double Th = at_end ? 1.0 : (ts - tn) * inv_h;
-                    const double c1 = at_end ? 0.0 : Th * (1.0 - Th) * inv12d;
+                    const double c1 = Th * (1.0 - Th) * inv12d;        // at the end of the step: 1 * 0 * inv12d = 0 exactly
                     const double c2 = at_end ? 1.0 : Th * (Th - 2.0 * d_) * inv12d;
+                    const double hc1 = h * c1, hc2 = h * c2;
 #pragma unroll
                     for (int i = 0; i < NS; ++i) {
                         const int dr = (int)kc->drow[i];
                         if (dr >= 0) {
-                            const double k2i = k1[i] + dk[i];
-                            double v = at_end ? fma(h, k2i, un[i]) : fma(h, fma(c1, k1[i], c2 * k2i), un[i]);
-                            double mask = 1.0;
-                            if (prm.clamp_pred) {
-                                mask = (v > kc->ub || v < -kc->ub) ? 0.0 : 1.0;
-                                v = clampv(v, -kc->ub, kc->ub);
-                            }
+                            const double v = fma(h, fma(c1, k1[i], c2 * (k1[i] + dk[i])), un[i]);
+                            const double vc = fmin(fmax(v, -ubc), ubc);      // v is finite here (accepted steps only): = clampv
                             const double iy = kc->inv_yscale[i];
-                            const double rr = (dobs[i] - v) * iy;
+                            const double rr = (dobs[i] - vc) * iy;
                             double w;
-                            if (prm.loss_kind == 0) { loss_sum += fabs(rr); w = signbit(rr) ? 1.0 : -1.0; }
-                            else { loss_sum = fma(rr, rr, loss_sum); w = -2.0 * rr; }
-                            w *= mask * iy;
+                            if constexpr (LK0) { loss_sum += fabs(rr); w = signbit(rr) ? iy : -iy; }
+                            else { loss_sum = fma(rr, rr, loss_sum); w = (-2.0 * rr) * iy; }
+                            w = (vc == v) ? w : 0.0;
                             A_[i] += w;
-                            B1[i] = fma(w, h * c1, B1[i]);
-                            B2[i] = fma(w, h * c2, B2[i]);
+                            B1[i] = fma(w, hc1, B1[i]);
+                            B2[i] = fma(w, hc2, B2[i]);
                         }
                     }
                     --jsave;
                 };
-                if (!(CRNN_ADJ_DBG & 8) && in_step()) {   // ablation 8: no loss / seeds at all (timing only)
-                    seed_point(dA);
+                auto seeds = [&](auto lk_) {
                     if (in_step()) {
-                        seed_point(dB);
+                        seed_point(dA, lk_);
                         if (in_step()) {
-                            seed_point(dC);
-                            while (in_step()) {  // more than three save points inside one step: fetch on demand
-                                double dD[NS];
-                                load_row(jsave - 1, dD);
-                                seed_point(dD);
+                            seed_point(dB, lk_);
+                            if (in_step()) {
+                                seed_point(dC, lk_);
+                                while (in_step()) {  // more than three save points inside one step: fetch on demand
+                                    double dD[NS];
+                                    load_row(jsave - 1, dD);
+                                    seed_point(dD, lk_);
+                                }
                             }
                         }
                     }
+                };
+                if (!(CRNN_ADJ_DBG & 8)) {   // ablation 8: no loss / seeds at all (timing only)
+                    if (prm.loss_kind == 0) seeds(std::true_type{}); else seeds(std::false_type{});
                 }
 
                 ADJ_T(10);   // reverse: loss + seeds
