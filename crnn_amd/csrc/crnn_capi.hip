@@ -112,10 +112,7 @@ struct AdjEntry {
     { SOLVER, NS, NR, HT, SC, (AdjKernelFn)crnn::auto_adj_kernel<NS, NR, (HT) != 0, (SC) != 0, kBlock, COMPOSITE>, 1, \
       (AdjKernelFn)crnn::auto_adj_kernel<NS, NR, (HT) != 0, (SC) != 0, kBlock, COMPOSITE, true> }
 // Rosenbrock23 discrete adjoint with TWO lanes per trajectory (ros23_adj2_kernel.hpp): shapes with nr < ns, no rate scaling.
-// Two instantiations per shape: at most 512 registers per lane (one wavefront per SIMD) and at most 256 (two per SIMD).
-#ifndef CRNN_ADJ2_OCC
-#define CRNN_ADJ2_OCC 1
-#endif
+// One wavefront per SIMD (at most 512 registers per lane); a 256-register build at two per SIMD measured break-even in round 4 and was deleted.
 // max_gen (measured, tools/kbench.py --lanes 1|2, MI355X): while the pairs fit the resident lanes the two-lane kernel always
 // wins (case2 4 096-32 768 trajectories: 0.28-0.32 ms against 0.48; case1's shape with Rosenbrock23, 16 384: 0.139 against
 // 0.176).  With TWO generations of pairs (32 769-65 536 trajectories) it depends on how widely the step counts spread -- the
@@ -124,7 +121,7 @@ struct AdjEntry {
 // nearly uniform) 65 536: 0.373 against 0.33; case1 (6 steps each) 65 536: 0.304 against 0.215.  AUTO therefore stops at
 // one generation; a host that knows its step counts spread asks for two lanes itself (crnn_ctx_set_lanes_per_traj).
 #define KADJ2(NS, NR, HT, MAXGEN) \
-    { CRNN_SOLVER_ROSENBROCK23, NS, NR, HT, 0, (AdjKernelFn)crnn::ros23_adj2_kernel<NS, NR, (HT) != 0, kBlock, CRNN_ADJ2_OCC>, MAXGEN }
+    { CRNN_SOLVER_ROSENBROCK23, NS, NR, HT, 0, (AdjKernelFn)crnn::ros23_adj2_kernel<NS, NR, (HT) != 0, kBlock, 1>, MAXGEN }
 const AdjEntry kAdj2Kernels[] = { KADJ2(6, 3, 1, 1), KADJ2(5, 4, 0, 1) };
 // discrete-adjoint gradient kernels, one lane per trajectory: Rosenbrock23; Tsit5; the AutoTsit5(Rosenbrock23()) composite
 // (with a constant temperature state it never leaves Tsit5 -- auto_adj_kernel.hpp -- and shares that instantiation)

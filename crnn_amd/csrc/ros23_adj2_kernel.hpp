@@ -51,13 +51,8 @@ __device__ __forceinline__ double pair_sum(double a) {
 }
 __device__ __forceinline__ int pair_and(int a) { return a & __builtin_amdgcn_update_dpp(0, a, 0xB1, 0xF, 0xF, true); }
 
-// CRNN_ADJ2_LEAN (round 4 experiment): the lane's weight rows and tolerances are re-read from LDS where they are used (the
-// two lanes of a pair need different rows, but there are only two variants per wavefront: a broadcast read) and its gradient accumulators
-// live in the staging area's cells (lane-private: ds_add_f64, fire and forget) -- 51 doubles less in registers, for a build at two
-// wavefronts per SIMD (CRNN_ADJ2_OCC = 2).  NS even only (no padding slot whose weights would have to read as zero).
-#ifndef CRNN_ADJ2_LEAN
-#define CRNN_ADJ2_LEAN 0
-#endif
+// (Round 4 measured a register-lean build of this kernel -- weight rows re-read from LDS, accumulators in LDS cells, two wavefronts per
+// SIMD -- at break-even with this one; its switches CRNN_ADJ2_LEAN / CRNN_ADJ2_OCC were deleted in round 5.)
 template <int NS, int NR, bool HAS_T, int BLOCK, int OCC>
 __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParams prm, const double *__restrict__ theta,
                                                                 const AdjParams adj) {
@@ -74,10 +69,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
     __shared__ double tsp_lds[kMaxSave + 2];               // two -inf slots in front: the reverse sweep reads two save times back unconditionally
     double *const ts_lds = tsp_lds + 2;
     __shared__ double stage_lds[(NTH + kExtra) * GPB];    // batch sums: [column][pair of this block]
-    constexpr bool LEAN = (CRNN_ADJ2_LEAN != 0) && (NS % 2 == 0);
-    __shared__ double th2_lds[LEAN ? NTH : 1];
     const int tid = threadIdx.x;
-    if (LEAN) for (int idx = tid; idx < NTH; idx += BLOCK) th2_lds[idx] = theta[idx];
     for (int idx = tid; idx < kNConst; idx += BLOCK) kc_lds[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
     for (int idx = tid; idx < prm.n_save; idx += BLOCK) ts_lds[idx] = prm.tsave[idx];
     if (tid < 2) tsp_lds[tid] = -INFINITY;
@@ -90,8 +82,8 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
     const int giw = lane >> 1;              // pair index within the wavefront (0..31)
 
     // ---- this lane's weights and per-species constants, in registers for the whole kernel
-    double wi_[LEAN ? 1 : H][NR], wo_[LEAN ? 1 : H][NR], wT[LEAN ? 1 : NR], wb_[LEAN ? 1 : NR];
-    double atl_[LEAN ? 1 : H], rtl_[LEAN ? 1 : H], iys_[LEAN ? 1 : H];
+    double wi_[H][NR], wo_[H][NR], wT[NR], wb_[NR];
+    double atl_[H], rtl_[H], iys_[H];
     int dro[H];                             // data column of the species, -1 if unobserved (or padding)
     bool own[H];
 #pragma unroll
@@ -99,35 +91,26 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
         const int c = m * H + i;
         own[i] = c < NS;
         const int cc = own[i] ? c : 0;
-        if constexpr (!LEAN) {
-#pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                wi_[i][j] = own[i] ? theta[L_::wi(cc, j)] : 0.0;
-                wo_[i][j] = own[i] ? theta[L_::wo(cc, j)] : 0.0;
-            }
-            atl_[i] = own[i] ? kc->atol[cc] : 1.0;
-            rtl_[i] = own[i] ? kc->rtol[cc] : 0.0;
-            iys_[i] = own[i] ? kc->inv_yscale[cc] : 0.0;
-        }
-        dro[i] = own[i] ? (int)kc->drow[cc] : -1;
-    }
-    if constexpr (!LEAN) {
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
-            wT[j] = HAS_T ? theta[L_::wi(NS, j)] : 0.0;
-            wb_[j] = theta[L_::wb(j)];
+            wi_[i][j] = own[i] ? theta[L_::wi(cc, j)] : 0.0;
+            wo_[i][j] = own[i] ? theta[L_::wo(cc, j)] : 0.0;
         }
+        atl_[i] = own[i] ? kc->atol[cc] : 1.0;
+        rtl_[i] = own[i] ? kc->rtol[cc] : 0.0;
+        iys_[i] = own[i] ? kc->inv_yscale[cc] : 0.0;
+        dro[i] = own[i] ? (int)kc->drow[cc] : -1;
     }
-    // LEAN: this lane's rows through a pointer that is re-derived (opaque zero) in every phase, so that the reads are neither hoisted
-    // out of the step loops nor kept alive across phases
-    const double *const thl0 = th2_lds + (LEAN ? m * H : 0);
-    const double *const kcl0 = kc_lds;
-#define ADJ2_THP() (thl0 + opaque_zero())
-#define WI(i, j) (LEAN ? thp[L_::wi((i), (j))] : wi_[LEAN ? 0 : (i)][(j)])
-#define WO(i, j) (LEAN ? thp[L_::wo((i), (j))] : wo_[LEAN ? 0 : (i)][(j)])
-#define ATL(i) (LEAN ? reinterpret_cast<const KConst *>(kcl0 + opaque_zero())->atol[m * H + (i)] : atl_[LEAN ? 0 : (i)])
-#define RTL(i) (LEAN ? reinterpret_cast<const KConst *>(kcl0 + opaque_zero())->rtol[m * H + (i)] : rtl_[LEAN ? 0 : (i)])
-#define IYS(i) (LEAN ? reinterpret_cast<const KConst *>(kcl0 + opaque_zero())->inv_yscale[m * H + (i)] : iys_[LEAN ? 0 : (i)])
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        wT[j] = HAS_T ? theta[L_::wi(NS, j)] : 0.0;
+        wb_[j] = theta[L_::wb(j)];
+    }
+#define WI(i, j) wi_[(i)][(j)]
+#define WO(i, j) wo_[(i)][(j)]
+#define ATL(i) atl_[(i)]
+#define RTL(i) rtl_[(i)]
+#define IYS(i) iys_[(i)]
 
     double iyz[H];                          // 1/yscale of this lane's observed species, 0 for unobserved / padding ones (reverse sweep)
 #pragma unroll
@@ -168,8 +151,6 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
         double xT = 0.0, Tconst = 0.0;
         // point evaluation: x = log clamp(u), g = dx/du (this lane's species); r (replicated); f (this lane's species)
         auto eval_point = [&](const double (&uu)[H], double (&x)[H], double (&g)[H], double (&r)[NR], double (&f)[H]) {
-            const double *const thp = ADJ2_THP();
-            (void)thp;
             features<H>(uu, kc->lb, kc->ub, x, g);
             double z[NR];
 #pragma unroll
@@ -193,8 +174,6 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
         int piv[NR];
         bool wave_pivots = false;
         auto factor = [&](const double (&g)[H], const double (&r)[NR], const double gam) -> bool {
-            const double *const thp = ADJ2_THP();
-            (void)thp;
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
                 double tj[H];
@@ -215,8 +194,6 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
         };
         // b <- W^-1 b = b + w_out (gr .* M^-1 (w_in^T (g .* b)))
         auto solve = [&](const double (&g)[H], const double (&gr)[NR], double (&bb)[H]) {
-            const double *const thp = ADJ2_THP();
-            (void)thp;
             double y[NR];
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
@@ -238,8 +215,6 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
         };
         // b <- W^-T b = b + g .* (w_in (M^-T (gr .* (w_out^T b))))
         auto solve_Tr = [&](const double (&g)[H], const double (&gr)[NR], double (&bb)[H]) {
-            const double *const thp = ADJ2_THP();
-            (void)thp;
             double y[NR];
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
@@ -271,8 +246,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
         }
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
-            const double wTj = LEAN ? (HAS_T ? th2_lds[L_::wi(NS, j)] : 0.0) : wT[LEAN ? 0 : j], wbj = LEAN ? th2_lds[L_::wb(j)] : wb_[LEAN ? 0 : j];
-            bT[j] = HAS_T ? fma(wTj, xT, wbj) : wbj;
+            bT[j] = HAS_T ? fma(wT[j], xT, wb_[j]) : wb_[j];
         }
         {
             double x0[H];
@@ -450,17 +424,13 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
         // ================================================================== reverse sweep
         const int n_saved = jsave;
         const int jlo = start_saved ? 1 : 0;
-        double awi[LEAN ? 1 : H][NR], awo[LEAN ? 1 : H][NR];     // d loss / d (this lane's rows of w_in, w_out): registers, no atomics
-        double *const stc = stage_lds + gib;               // LEAN: the accumulators live in the pair's staging cells (this lane's rows)
+        double awi[H][NR], awo[H][NR];     // d loss / d (this lane's rows of w_in, w_out): registers, no atomics
 #pragma unroll
         for (int i = 0; i < H; ++i)
 #pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                if constexpr (LEAN) { stc[L_::wi(m * H + i, j) * GPB] = 0.0; stc[L_::wo(m * H + i, j) * GPB] = 0.0; }
-                else { awi[LEAN ? 0 : i][j] = 0.0; awo[LEAN ? 0 : i][j] = 0.0; }
-            }
-#define AWI_ADD(i, j, val) do { if constexpr (LEAN) unsafeAtomicAdd(&stc[L_::wi(m * H + (i), (j)) * GPB], (val)); else awi[LEAN ? 0 : (i)][(j)] += (val); } while (0)
-#define AWO_ADD(i, j, val) do { if constexpr (LEAN) unsafeAtomicAdd(&stc[L_::wo(m * H + (i), (j)) * GPB], (val)); else awo[LEAN ? 0 : (i)][(j)] += (val); } while (0)
+            for (int j = 0; j < NR; ++j) { awi[i][j] = 0.0; awo[i][j] = 0.0; }
+#define AWI_ADD(i, j, val) awi[(i)][(j)] += (val)
+#define AWO_ADD(i, j, val) awo[(i)][(j)] += (val)
         double lam[H];
 #pragma unroll
         for (int i = 0; i < H; ++i) lam[i] = 0.0;
@@ -594,8 +564,6 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
                 solve_Tr(gg0, gr0, v);                 // v = W^-T kb2
 #pragma unroll
                 for (int i = 0; i < H; ++i) kb1[i] -= v[i];
-                const double *const thp = ADJ2_THP();
-                (void)thp;
                 double av[NR];
 #pragma unroll
                 for (int j = 0; j < NR; ++j) {
@@ -703,11 +671,8 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
                 if (own[i]) {
 #pragma unroll
                     for (int j = 0; j < NR; ++j) {
-                        if constexpr (LEAN) { st[L_::wi(m * H + i, j) * GPB] *= scale_; st[L_::wo(m * H + i, j) * GPB] *= scale_; }
-                        else {
-                            st[L_::wi(m * H + i, j) * GPB] = awi[LEAN ? 0 : i][j] * scale_;
-                            st[L_::wo(m * H + i, j) * GPB] = awo[LEAN ? 0 : i][j] * scale_;
-                        }
+                        st[L_::wi(m * H + i, j) * GPB] = awi[i][j] * scale_;
+                        st[L_::wo(m * H + i, j) * GPB] = awo[i][j] * scale_;
                     }
                 }
             }
@@ -745,7 +710,6 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
 #endif
 }
 
-#undef ADJ2_THP
 #undef WI
 #undef WO
 #undef ATL

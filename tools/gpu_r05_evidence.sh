@@ -18,13 +18,15 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/benc
 # 3. kernel trace of the same command
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $O/trace -o trace -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_trace.json 2> $O/trace.err )
 python tools/rocpd_summary.py $O > $O/trace_summary.txt 2>&1; head -30 $O/trace_summary.txt | cut -c1-200
-# 4. A/B on the same box: (a) the lane-pair headline kernel with branch-free save-point seeds (-DCRNN_ADJ2_SEEDS_FLAT=1; parity-green under
-#    the SIMT emulator, never timed), libraries prebuilt under crnn_amd/csrc/dbg/ (tools/kvariants.sh build base=... flat=...);
+# 4. A/B on the same box: (a) the adjoint kernels' reverse-sweep loss + seeds phase rewritten straight-line in round 5 (static count of the
+#    executed path -12 %; parity-green under the SIMT emulator, never timed): the round-start library (commit 258bf9d, built from `git archive`
+#    into crnn_amd/csrc/dbg/libcrnn_kv_r5start.so, travels with the snapshot) against the tree's libcrnn_hip.so, lane pair and one lane;
 #    (b) the HyChem dual-norm gradient: hychem_sens2_kernel (sparse directions, default) against hychem_sens_kernel (CRNN_HY_SENS_KERNEL=1)
-if ls $R/crnn_amd/csrc/dbg/libcrnn_kv_flat.so > /dev/null 2>&1; then
-  for rep in 1 2 3; do for v in base flat; do
-    CRNN_HIP_LIB=$R/crnn_amd/csrc/dbg/libcrnn_kv_$v.so timeout 300 python tools/kbench.py --lanes 2 --reps 30 | tail -1 | cut -c1-170
-  done; done > $O/ab_seeds_flat.txt 2>&1; cat $O/ab_seeds_flat.txt
+if ls $R/crnn_amd/csrc/dbg/libcrnn_kv_r5start.so > /dev/null 2>&1; then
+  for rep in 1 2 3; do for v in r5start head; do for ln in 2 1; do
+    L=$R/crnn_amd/csrc/dbg/libcrnn_kv_$v.so; [ $v = head ] && L=$R/crnn_amd/csrc/libcrnn_hip.so
+    echo -n "$v lanes=$ln: "; CRNN_HIP_LIB=$L timeout 300 python tools/kbench.py --lanes $ln --reps 30 | tail -1 | cut -c1-170
+  done; done; done > $O/ab_seeds.txt 2>&1; cat $O/ab_seeds.txt
 fi
 for n in 1024 4096 32768; do
   echo "sparse $n"; timeout 600 python tools/hy_sens_time.py $n
