@@ -87,9 +87,49 @@ def parse():
                          "chosen, the other mode is timed too (same K, W) and reported under 'other_scaling' when N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (other configs / regimes, N = 1 only)")
+    ap.add_argument("--secondary-seconds", type=float, default=900.0, help="wall-clock limit of the child process that measures the secondary figures")
     ap.add_argument("--cpu-sample", type=int, default=65536)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall time to spend on the CPU baseline")
     return ap.parse_args()
+
+
+def secondary_in_child(cmd, seconds):
+    """Runs `cmd --out <file>` with a wall-clock limit and returns the dictionary it left in <file>: complete, or -- child crashed, was killed by
+    a signal, outlived the limit -- the entries it had finished plus "_incomplete": why.  Never raises: the headline line does not depend on it."""
+    import subprocess
+    import tempfile
+    status = "ok"
+    sec_path = None
+    try:
+        with tempfile.NamedTemporaryFile(prefix="crnn_bench_secondary_", suffix=".json", delete=False) as tf:
+            sec_path = tf.name
+        try:
+            rc_ = subprocess.run(cmd + ["--out", sec_path], timeout=seconds, stdout=sys.stderr, stderr=sys.stderr).returncode
+            if rc_ != 0:
+                status = f"child exited with code {rc_}"
+        except subprocess.TimeoutExpired:
+            status = f"child stopped after --secondary-seconds = {seconds:.0f} s"
+        except Exception as e:  # noqa: BLE001
+            status = f"child could not be run: {e}"
+        try:
+            sec = json.load(open(sec_path))
+            if not isinstance(sec, dict):
+                sec = {}
+        except Exception:  # noqa: BLE001
+            sec = {}
+    except Exception as e:  # noqa: BLE001
+        sec, status = {}, f"no temporary file: {e}"
+    finally:
+        for pth in (sec_path, (sec_path or "") + ".tmp"):
+            try:
+                if pth:
+                    os.unlink(pth)
+            except OSError:
+                pass
+    if status != "ok":
+        print(f"[bench] secondary: {status}; {len(sec)} entries kept", file=sys.stderr, flush=True)
+        sec["_incomplete"] = status
+    return sec
 
 
 def main():
@@ -311,76 +351,12 @@ def main():
                                              f"executes ({t_fwd:.1f} s wall) -> forward_tangents_value; a C restatement, not DifferentialEquations.jl "
                                              f"(Julia absent)"}
         # ---- secondary figures (N = 1): the same hot path at FIXED parameters on the other regimes / BASELINE configs ----
+        # In a CHILD process with a wall-clock limit (tools/bench_secondary.py --all; it redraws rank 0's ensemble from the same seed): the
+        # headline line above is printed whatever happens there -- an entry that throws is recorded as {"error": ...} by the child, a child
+        # that crashes or outlives the limit leaves the entries it had finished (it rewrites its output file after each one).
         if world == 1 and not args.no_secondary:
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            import bench_secondary as bs
-            sec = {}
-
-            def progress(msg):
-                print(f"[bench] secondary: {msg}", file=sys.stderr, flush=True)
-            ck = np.array(fx["case2_ckpt"]["p"])
-            p_init = cases.case2_init_p(np.random.Generator(np.random.PCG64(7)))
-            p_hard = np.array(json.load(open(os.path.join(ROOT, "tests", "golden", "case2_hard_p.json")))["p"])
-            note = "case2, 65 536 ICs of the headline ensemble, Rosenbrock23 atol 1e-6 rtol 1e-3, adjoint gradient, fixed p: "
-            progress("case2 at fixed p (init / early training / diverged / errnorm_sens)")
-            sec["case2_reference_init_p"] = bs.case2_fixed(u0, data, yscale, p_init, {"workload": note + "the reference's random initialiser (case2.jl:85-89)"})
-            sec["case2_early_training_p"] = bs.case2_fixed(u0, data, yscale, p_hard, {
-                "workload": note + "p after epoch 2 of a reference-schedule training run from that initialiser -- the hardest state a healthy run "
-                                   "visits (tests/golden/case2_hard_p.json, tools/train_case2_converge.py)"})
-            # 30 FULL-BATCH ADAM steps from the initialiser (what --theta0 init times): after four such updates the
-            # network sits in a sliding mode on the kink of log(clamp(u, lb, ub)) -- about 10 % of the trajectories alternate
-            # accepted and rejected steps thousands of times and their tangents overflow (1e175), ADAM's second moment swallows
-            # the update and training stalls at loss 0.237.  The CPU restatement reproduces all of it step for step; it is a
-            # diverged training state of this schedule (the reference updates per experiment), timed here for the record.
-            nd = NeuralODE(ODEProblem(PRESET_CASE2, ts, device=local_rank))
-            nd.set_ensemble(u0, data, yscale)
-            nd.train_init(Optimiser(25, PRESET_CASE2), p_init)
-            for _ in range(30):
-                nd.train_step(want_loss=False)
-            p_deg = nd.params()
-            nd.close()
-            sec["case2_after_30_full_batch_adam_steps_from_init"] = bs.case2_fixed(u0, data, yscale, p_deg, {
-                "workload": note + "p after 30 full-batch ADAM steps from the initialiser: a diverged (sliding-mode) state, launch time = the longest "
-                                   "trajectory's thousands of attempts; see DESIGN.md"}, reps=3)
-            sec["case2_errnorm_sens1"] = bs.case2_fixed(u0, data, yscale, ck, {
-                "workload": note + "errnorm_sens = 1 (ForwardDiff's dual-inclusive error norm, chunks 9 + 9 + 7, forward tangents through every "
-                                   "attempt) + the plain solve for the loss: the reference-faithful gradient mode; kernel_ms is the LAST launch only, "
-                                   "call_ms the whole loss+gradient call"}, reps=3, errnorm_sens=1)
-            sec["case2_errnorm_sens1"]["value"] = B / (sec["case2_errnorm_sens1"]["call_ms"] * 1e-3)
-            # the same through Tsit5 -- the branch of case2's AutoTsit5(Rosenbrock23) the reference stays in (tsit5_sens_kernel; round 5: 79 KB of
-            # LDS per block instead of 100, two blocks per CU)
-            sec["case2_errnorm_sens1_tsit5"] = bs.case2_fixed(u0, data, yscale, ck, {
-                "workload": note.replace("Rosenbrock23", "Tsit5") + "errnorm_sens = 1 as above, explicit Tsit5 (case2's reference algorithm while it stays "
-                                                                    "non-stiff; case1's Tsit5()): tsit5_sens_kernel"}, reps=3, errnorm_sens=1, solver=SOLVER_TSIT5)
-            sec["case2_errnorm_sens1_tsit5"]["value"] = B / (sec["case2_errnorm_sens1_tsit5"]["call_ms"] * 1e-3)
-            progress("case2 strong-scaling shares (8 192 / 16 384 / 32 768 of the 65 536)")
-            for nb in (8192, 16384, 32768):
-                sec[f"case2_B{nb}_share"] = bs.case2_fixed(u0[:nb], data[:nb], yscale, ck, {
-                    "workload": f"case2, {nb} ICs = one GPU's share of the 65 536 batch on {65536 // nb} GPUs (strong scaling), checkpoint p, adjoint gradient; "
-                                "AUTO takes the lane-pair kernel (ros23_adj2_kernel) below 32 769 trajectories"})
-                sec[f"case2_B{nb}_share_one_lane"] = bs.case2_fixed(u0[:nb], data[:nb], yscale, ck, {
-                    "workload": f"the same with one lane per trajectory (crnn_ctx_set_lanes_per_traj(1): round 2's kernel)"}, lanes=1)
-            sec["case2_B65536_two_lanes"] = bs.case2_fixed(u0, data, yscale, ck, {
-                "workload": note + "checkpoint p, TWO lanes per trajectory forced (two generations of pairs, longest first)"}, lanes=2)
-            progress("case2 B = 131072 / 262144")
-            ub_, db_, yb_ = bs.case2_ensemble(262144, [1234, 99], device=local_rank)
-            for nb in (131072, 262144):
-                sec[f"case2_B{nb}"] = bs.case2_fixed(ub_[:nb], db_[:nb], yb_, ck, {
-                    "workload": f"case2, {nb} ICs on one GPU (more than the 65 536 resident lanes: queued by the previous launch's step counts), "
-                                "checkpoint p, adjoint gradient"})
-            del ub_, db_
-            progress("robertson")
-            sec["robertson_B65536"] = bs.robertson(device=local_rank)
-            progress("hychem 32768")
-            sec["hychem_B32768"] = bs.hychem(device=local_rank)
-            progress("hychem 262144")
-            sec["hychem_B262144_one_gpu"] = bs.hychem(B=262144, reps=3, device=local_rank)
-            sec["hychem_B262144_one_gpu"]["workload"] = ("HyChem pyrolysis CRNN, ALL 262 144 ICs of BASELINE config 4 on ONE GPU (eight generations of "
-                                                         "wavefronts, queued by the previous launch's step counts), adjoint gradient (P = 211)")
-            progress("cathode 4096 x 256")
-            sec["cathode_4096x256"] = bs.cathode(device=local_rank)
-            progress("done")
-            out["secondary"] = sec
+            out["secondary"] = secondary_in_child([sys.executable, os.path.join(ROOT, "tools", "bench_secondary.py"), "--all", "--device", str(local_rank),
+                                                   "--batch", str(B)], args.secondary_seconds)
         # RCCL prints a version banner through C stdio (block-buffered on a pipe): flush it first so
         # that the JSON line is the LAST line of stdout.
         C.CDLL(None).fflush(None)

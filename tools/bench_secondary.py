@@ -43,6 +43,11 @@ def _entry(kind, B, kms, st, extra=None, wall_ms=None, traffic_key=None):
     return e
 
 
+def _med(x):
+    """median, or None for an empty list (an entry whose extras failed must still serialise as strict JSON)"""
+    return float(np.median(x)) if len(x) else None
+
+
 def _time_calls(node, p, reps):
     kms, walls = [], []
     for _ in range(reps):
@@ -135,27 +140,30 @@ def hychem(B=32768, reps=4, device=0):
     node.close()
     extra4 = {}
     if B == 32768:      # round 4: the reference's composite for primal launches; the gradient as ForwardDiff evaluates it (1 024 of the ICs)
-        from crnn_amd import SOLVER_AUTOTSIT5
-        comp = NeuralODE(ODEProblem(PRESET_HYCHEM, ts, rate_scale=hy.DYDT_SCALE, device=device, solver=SOLVER_AUTOTSIT5))
-        comp.set_ensemble(u0, data, ys); comp.set_tables(Tt, Pt)
-        extra4["primal_autotsit5_kernel_ms"] = _primal_ms(comp, p, 3)
-        extra4["primal_autotsit5_steps_per_traj"] = comp.last_stats["n_accept"] / B
-        comp.close()
-        # the reference-faithful gradient (errnorm_sens = 2): round 5's hychem_sens2_kernel (sparse directions) at 1 024 ICs -- the size round 4's
-        # nested-dual kernel was quoted on (522.8 ms, 1 959 /s: profiles/r04i) -- and at the whole share
-        for n in (1024, B):
-            sens = NeuralODE(ODEProblem(PRESET_HYCHEM, ts, rate_scale=hy.DYDT_SCALE, device=device, errnorm_sens=2))
-            sens.set_ensemble(u0[:n], data[:n], ys); sens.set_tables(Tt[:n], Pt[:n])
-            sens.loss_and_grad(p)
-            t0 = time.perf_counter(); sens.loss_and_grad(p); w = (time.perf_counter() - t0) * 1e3
-            sens.close()
-            tag = "B1024" if n == 1024 else f"B{n}"
-            extra4[f"errnorm_sens2_{tag}_call_ms"] = w
-            extra4[f"errnorm_sens2_{tag}_value"] = n / (w * 1e-3)
-        extra4["errnorm_sens2_value"] = extra4[f"errnorm_sens2_B{B}_value"]
-        extra4["errnorm_sens_note"] = ("crnn_config.errnorm_sens = 2 on the HyChem preset: ForwardDiff's 18 chunks of 12 partials, each its own "
-                                       "adaptive solve with the partials in the error norm (hychem_sens2_kernel: sparse directions, closed-form "
-                                       "tangents, one column per lane) + the plain solve; wall time of one loss+gradient call")
+      try:
+            from crnn_amd import SOLVER_AUTOTSIT5
+            comp = NeuralODE(ODEProblem(PRESET_HYCHEM, ts, rate_scale=hy.DYDT_SCALE, device=device, solver=SOLVER_AUTOTSIT5))
+            comp.set_ensemble(u0, data, ys); comp.set_tables(Tt, Pt)
+            extra4["primal_autotsit5_kernel_ms"] = _primal_ms(comp, p, 3)
+            extra4["primal_autotsit5_steps_per_traj"] = comp.last_stats["n_accept"] / B
+            comp.close()
+            # the reference-faithful gradient (errnorm_sens = 2): round 5's hychem_sens2_kernel (sparse directions) at 1 024 ICs -- the size round 4's
+            # nested-dual kernel was quoted on (522.8 ms, 1 959 /s: profiles/r04i) -- and at the whole share
+            for n in (1024, B):
+                sens = NeuralODE(ODEProblem(PRESET_HYCHEM, ts, rate_scale=hy.DYDT_SCALE, device=device, errnorm_sens=2))
+                sens.set_ensemble(u0[:n], data[:n], ys); sens.set_tables(Tt[:n], Pt[:n])
+                sens.loss_and_grad(p)
+                t0 = time.perf_counter(); sens.loss_and_grad(p); w = (time.perf_counter() - t0) * 1e3
+                sens.close()
+                tag = "B1024" if n == 1024 else f"B{n}"
+                extra4[f"errnorm_sens2_{tag}_call_ms"] = w
+                extra4[f"errnorm_sens2_{tag}_value"] = n / (w * 1e-3)
+            extra4["errnorm_sens2_value"] = extra4[f"errnorm_sens2_B{B}_value"]
+            extra4["errnorm_sens_note"] = ("crnn_config.errnorm_sens = 2 on the HyChem preset: ForwardDiff's 18 chunks of 12 partials, each its own "
+                                           "adaptive solve with the partials in the error norm (hychem_sens2_kernel: sparse directions, closed-form "
+                                           "tangents, one column per lane) + the plain solve; wall time of one loss+gradient call")
+      except Exception as e:  # noqa: BLE001  (these kernels are round 4 / 5 additions: their failure must not take the adjoint figures of the entry along)
+        extra4["extras_error"] = f"{type(e).__name__}: {e}"[:500]
     return _entry("hychem", B, kms, st, {**extra4, "primal_kernel_ms": prim, "workload": "HyChem pyrolysis CRNN, 32 768 ICs (one GPU's share of 262 144), T(t)/P(t) tables, "
                                                      "Rosenbrock23 atol 1e-8 rtol 1e-3, adjoint gradient (P = 211)",
                                          "kernel": "hychem2_kernel<9,10,GRAD,256> (a lane pair per trajectory, W's rows in registers, LDS frame, "
@@ -189,29 +197,40 @@ def cathode(n_part=4096, n_rates=256, reps=3, device=0):
         uq.solve(p, want_grad=False)
         pk.append(uq.last_stats["kernel_ms"])
     # round 4: primal launches through the reference's composite (network.jl:195); the gradient as ForwardDiff evaluates it
-    comp_ms = {}
-    for name in ("autotsit5_trbdf2", "autotsit5_rosenbrock23"):
-        uq.set_solver(name)
-        ck = []
-        for _ in range(3):
-            uq.solve(p, want_grad=False)
-            ck.append(uq.last_stats["kernel_ms"])
-        comp_ms[name] = (float(np.median(ck[1:])), uq.last_stats["n_accept"] / uq.last_stats["n_traj"])
-    uq.set_solver("rosenbrock23")
-    sens = CathodeUQ(exp_data, betas, fx["theta"], normalizer=np.ones((n_rates, 3)), device=device, errnorm_sens=2)
-    sens.solve(p)
-    t0 = time.perf_counter(); sens.solve(p); sens_wall = (time.perf_counter() - t0) * 1e3
-    t0 = time.perf_counter(); uq.solve(p); adj_wall = (time.perf_counter() - t0) * 1e3
-    sens_chunks = sens.last_chunk_stats()
-    sens.close()
-    # the reference's own iteration (crnn_cathode.jl:36-50): ONE heating rate per SVGD move, particles resident on the device --
-    # solve of n_part trajectories + chain rule + exact-median select + kernel sums + update, enqueued back to back
-    uq.set_particles(p)
+    comp_ms = {"autotsit5_trbdf2": (None, None), "autotsit5_rosenbrock23": (None, None)}
+    sens_wall = adj_wall = None
+    sens_chunks = ((0, 0), (0, 0))
     sv, so = [], []
-    for it in range(8):
-        _, _, ms = uq.svgd_step((37 * it) % n_rates, 1e-3)
-        sv.append(ms["svgd_ms"]); so.append(ms["solve_ms"])
-    uq.close()
+    extras_error = None
+    try:
+        for name in ("autotsit5_trbdf2", "autotsit5_rosenbrock23"):
+            uq.set_solver(name)
+            ck = []
+            for _ in range(3):
+                uq.solve(p, want_grad=False)
+                ck.append(uq.last_stats["kernel_ms"])
+            comp_ms[name] = (float(np.median(ck[1:])), uq.last_stats["n_accept"] / uq.last_stats["n_traj"])
+        uq.set_solver("rosenbrock23")
+        sens = CathodeUQ(exp_data, betas, fx["theta"], normalizer=np.ones((n_rates, 3)), device=device, errnorm_sens=2)
+        sens.solve(p)
+        t0 = time.perf_counter(); sens.solve(p); sens_wall = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter(); uq.solve(p); adj_wall = (time.perf_counter() - t0) * 1e3
+        sens_chunks = sens.last_chunk_stats()
+        sens.close()
+        # the reference's own iteration (crnn_cathode.jl:36-50): ONE heating rate per SVGD move, particles resident on the device --
+        # solve of n_part trajectories + chain rule + exact-median select + kernel sums + update, enqueued back to back
+        uq.set_particles(p)
+        sv, so = [], []
+        for it in range(8):
+            _, _, ms = uq.svgd_step((37 * it) % n_rates, 1e-3)
+            sv.append(ms["svgd_ms"]); so.append(ms["solve_ms"])
+        uq.close()
+    except Exception as e:  # noqa: BLE001  (composites, dual-norm chunks, device-resident SVGD: must not take the adjoint figures of the entry along)
+        extras_error = f"{type(e).__name__}: {e}"[:500]
+        try:
+            uq.close()
+        except Exception:  # noqa: BLE001
+            pass
     return _entry("cathode", n_part * n_rates, kms[1:], st,
                   {"workload": "Cathode-UQ: 4 096 particles x 256 heating rates, non-autonomous Rosenbrock23 atol 1e-12 rtol 1e-3, "
                                "per-particle adjoint gradients (17 parameters each)", "kernel": "cathode_adj_kernel<256,1> (full tape, two wavefronts per SIMD, accumulators in LDS)",
@@ -225,7 +244,140 @@ def cathode(n_part=4096, n_rates=256, reps=3, device=0):
                    "errnorm_sens_note": "crnn_cathode_set_errnorm_sens(2): ForwardDiff's chunks 9 + 8, each its own adaptive solve with the partials in "
                                         "the error norm (cathode_sens_kernel) + the plain solve; wall time of one gradient call incl. the read-back, next "
                                         "to the adjoint call's",
-                   "svgd_move_ms": float(np.median(sv[2:])), "svgd_iteration_solve_ms": float(np.median(so[2:])),
+                   "extras_error": extras_error,
+                   "svgd_move_ms": _med(sv[2:]), "svgd_iteration_solve_ms": _med(so[2:]),
                    "svgd_note": "device-resident SVGD iteration (crnn_cathode_svgd_step): svgd_iteration_solve_ms = the solve kernel "
                                 "over the 4 096 particles of ONE heating rate, svgd_move_ms = median select + kernel sums + move "
                                 "(HIP events on the ctx stream)"}, traffic_key="cathode_4096x256_full_tape" if (n_part, n_rates) == (4096, 256) else None)
+
+def run_all(u0, data, yscale, device=0, out_path=None):
+    """Every secondary entry of bench.py's line, each on its own: an entry that throws becomes {"error": ...} and the next one runs; the
+    dictionary is rewritten to out_path after each entry, so a caller that has to stop this process keeps what was finished."""
+    import sys
+    import traceback
+    from crnn_amd import NeuralODE, ODEProblem, Optimiser, PRESET_CASE2, SOLVER_TSIT5, cases
+    sec = {}
+    B = u0.shape[0]
+    local_rank = device
+    ts = cases.case2_tsteps()
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fixtures.json")))
+
+    def progress(msg):
+        print(f"[bench] secondary: {msg}", file=sys.stderr, flush=True)
+
+    def flush():
+        if out_path:
+            with open(out_path + ".tmp", "w") as f:
+                json.dump(sec, f)
+            os.replace(out_path + ".tmp", out_path)
+
+    def put(key, fn):
+        try:
+            sec[key] = fn()
+        except Exception as e:  # noqa: BLE001
+            sec[key] = {"error": f"{type(e).__name__}: {e}"[:500]}
+            print(f"[bench] secondary: {key} FAILED: {e}", file=sys.stderr, flush=True)
+            traceback.print_exc(file=sys.stderr)
+        flush()
+
+    ck = np.array(fx["case2_ckpt"]["p"])
+    p_init = cases.case2_init_p(np.random.Generator(np.random.PCG64(7)))
+    p_hard = np.array(json.load(open(os.path.join(ROOT, "tests", "golden", "case2_hard_p.json")))["p"])
+    note = "case2, 65 536 ICs of the headline ensemble, Rosenbrock23 atol 1e-6 rtol 1e-3, adjoint gradient, fixed p: "
+    progress("case2 at fixed p (init / early training / diverged / errnorm_sens)")
+    put("case2_reference_init_p", lambda: case2_fixed(u0, data, yscale, p_init, {"workload": note + "the reference's random initialiser (case2.jl:85-89)"}))
+    put("case2_early_training_p", lambda: case2_fixed(u0, data, yscale, p_hard, {
+        "workload": note + "p after epoch 2 of a reference-schedule training run from that initialiser -- the hardest state a healthy run "
+                           "visits (tests/golden/case2_hard_p.json, tools/train_case2_converge.py)"}))
+    # 30 FULL-BATCH ADAM steps from the initialiser (what --theta0 init times): after four such updates the
+    # network sits in a sliding mode on the kink of log(clamp(u, lb, ub)) -- about 10 % of the trajectories alternate
+    # accepted and rejected steps thousands of times and their tangents overflow (1e175), ADAM's second moment swallows
+    # the update and training stalls at loss 0.237.  The CPU restatement reproduces all of it step for step; it is a
+    # diverged training state of this schedule (the reference updates per experiment), timed here for the record.
+    def diverged_p():
+        nd = NeuralODE(ODEProblem(PRESET_CASE2, ts, device=local_rank))
+        nd.set_ensemble(u0, data, yscale)
+        nd.train_init(Optimiser(25, PRESET_CASE2), p_init)
+        for _ in range(30):
+            nd.train_step(want_loss=False)
+        p_ = nd.params()
+        nd.close()
+        return p_
+    try:
+        p_deg = diverged_p()
+    except Exception as e:  # noqa: BLE001
+        p_deg = None
+        sec["case2_after_30_full_batch_adam_steps_from_init"] = {"error": f"{type(e).__name__}: {e}"[:500]}
+        flush()
+    if p_deg is not None:
+      put("case2_after_30_full_batch_adam_steps_from_init", lambda: case2_fixed(u0, data, yscale, p_deg, {
+        "workload": note + "p after 30 full-batch ADAM steps from the initialiser: a diverged (sliding-mode) state, launch time = the longest "
+                           "trajectory's thousands of attempts; see DESIGN.md"}, reps=3))
+    put("case2_errnorm_sens1", lambda: case2_fixed(u0, data, yscale, ck, {
+        "workload": note + "errnorm_sens = 1 (ForwardDiff's dual-inclusive error norm, chunks 9 + 9 + 7, forward tangents through every "
+                           "attempt) + the plain solve for the loss: the reference-faithful gradient mode; kernel_ms is the LAST launch only, "
+                           "call_ms the whole loss+gradient call"}, reps=3, errnorm_sens=1))
+    if "error" not in sec.get("case2_errnorm_sens1", {"error": 1}):
+        sec["case2_errnorm_sens1"]["value"] = B / (sec["case2_errnorm_sens1"]["call_ms"] * 1e-3)
+    # the same through Tsit5 -- the branch of case2's AutoTsit5(Rosenbrock23) the reference stays in (tsit5_sens_kernel; round 5: 79 KB of
+    # LDS per block instead of 100, two blocks per CU)
+    put("case2_errnorm_sens1_tsit5", lambda: case2_fixed(u0, data, yscale, ck, {
+        "workload": note.replace("Rosenbrock23", "Tsit5") + "errnorm_sens = 1 as above, explicit Tsit5 (case2's reference algorithm while it stays "
+                                                            "non-stiff; case1's Tsit5()): tsit5_sens_kernel"}, reps=3, errnorm_sens=1, solver=SOLVER_TSIT5))
+    if "error" not in sec.get("case2_errnorm_sens1_tsit5", {"error": 1}):
+        sec["case2_errnorm_sens1_tsit5"]["value"] = B / (sec["case2_errnorm_sens1_tsit5"]["call_ms"] * 1e-3)
+    progress("case2 strong-scaling shares (8 192 / 16 384 / 32 768 of the 65 536)")
+    for nb in (8192, 16384, 32768):
+        put(f"case2_B{nb}_share", lambda: case2_fixed(u0[:nb], data[:nb], yscale, ck, {
+            "workload": f"case2, {nb} ICs = one GPU's share of the 65 536 batch on {65536 // nb} GPUs (strong scaling), checkpoint p, adjoint gradient; "
+                        "AUTO takes the lane-pair kernel (ros23_adj2_kernel) below 32 769 trajectories"}))
+        put(f"case2_B{nb}_share_one_lane", lambda: case2_fixed(u0[:nb], data[:nb], yscale, ck, {
+            "workload": f"the same with one lane per trajectory (crnn_ctx_set_lanes_per_traj(1): round 2's kernel)"}, lanes=1))
+    put("case2_B65536_two_lanes", lambda: case2_fixed(u0, data, yscale, ck, {
+        "workload": note + "checkpoint p, TWO lanes per trajectory forced (two generations of pairs, longest first)"}, lanes=2))
+    progress("case2 B = 131072 / 262144")
+    try:
+        ub_, db_, yb_ = case2_ensemble(262144, [1234, 99], device=local_rank)
+    except Exception as e:  # noqa: BLE001
+        ub_ = None
+        sec["case2_B262144"] = {"error": f"{type(e).__name__}: {e}"[:500]}
+        flush()
+    if ub_ is not None:
+        for nb in (131072, 262144):
+            put(f"case2_B{nb}", lambda: case2_fixed(ub_[:nb], db_[:nb], yb_, ck, {
+                "workload": f"case2, {nb} ICs on one GPU (more than the 65 536 resident lanes: queued by the previous launch's step counts), "
+                            "checkpoint p, adjoint gradient"}))
+        del ub_, db_
+    progress("robertson")
+    put("robertson_B65536", lambda: robertson(device=local_rank))
+    progress("hychem 32768")
+    put("hychem_B32768", lambda: hychem(device=local_rank))
+    progress("hychem 262144")
+    put("hychem_B262144_one_gpu", lambda: hychem(B=262144, reps=3, device=local_rank))
+    if "error" not in sec["hychem_B262144_one_gpu"]:
+      sec["hychem_B262144_one_gpu"]["workload"] = ("HyChem pyrolysis CRNN, ALL 262 144 ICs of BASELINE config 4 on ONE GPU (eight generations of "
+                                                 "wavefronts, queued by the previous launch's step counts), adjoint gradient (P = 211)")
+    progress("cathode 4096 x 256")
+    put("cathode_4096x256", lambda: cathode(device=local_rank))
+    progress("done")
+    flush()
+    return sec
+
+
+if __name__ == "__main__":
+    import argparse
+    import sys
+    sys.path.insert(0, ROOT)
+    ap = argparse.ArgumentParser(description="the secondary figures of bench.py's line, as its child process (or by hand)")
+    ap.add_argument("--all", action="store_true")
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=65536)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    from crnn_amd import _lib as _L
+    if "SIMT-EMULATION" in _L.lib.crnn_build_info().decode():
+        raise SystemExit("bench_secondary.py: CRNN_HIP_LIB points at the SIMT emulation library; timings need the gfx950 library on an MI355X")
+    u0_, data_, ys_ = case2_ensemble(a.batch, [1234, 0], device=a.device)      # rank 0's ensemble of bench.py, from the same seed
+    res = run_all(u0_, data_, ys_, device=a.device, out_path=a.out)
+    if not a.out:
+        print(json.dumps(res))
