@@ -2,6 +2,8 @@
 (no compute on a GPU): exported symbols, p2vec / optimiser host code against
 the oracle and the golden vectors, presets, argument validation."""
 import ctypes as C
+import json
+import sys
 import os
 import re
 
@@ -269,3 +271,25 @@ def test_julia_shim_binds_every_entry_point():
     assert not missing, missing
     abi = int(re.search(r"#define CRNN_ABI_VERSION (\d+)", hdr).group(1))
     assert f"v == {abi} ||" in jl
+
+
+def test_device_session_runs_the_driver_proven_tests_first():
+    """tests/conftest.py on a box with a device: every test joins the -m gpu session (except the emulation sample), ordered so that the
+    functions a driver has already seen green on an MI355X (round 3, tests/golden/device_history.json) come before rounds 4 / 5's -- `pytest -x`
+    then records everything proven before it can stop at a first-contact failure.  Nothing is dropped: the collection is the same set."""
+    import subprocess
+    env = dict(os.environ, CRNN_TEST_ASSUME_GPU="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", "tests", "--collect-only", "-q", "-m", "gpu", "-p", "no:cacheprovider"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=300)
+    names = [l.strip() for l in out.stdout.splitlines() if "::" in l]
+    seen = set(json.load(open(os.path.join(ROOT, "tests", "golden", "device_history.json")))["functions"])
+    flags = [n.split("[")[0] in seen for n in names]
+    first_new = flags.index(False)
+    assert first_new >= 180 and not any(flags[first_new:]), names[first_new]
+    assert not any("test_simt_emulation" in n for n in names)
+    plain = subprocess.run([sys.executable, "-m", "pytest", "tests", "--collect-only", "-q", "-p", "no:cacheprovider"], cwd=ROOT, capture_output=True,
+                           text=True, timeout=300)
+    every = {l.strip() for l in plain.stdout.splitlines() if "::" in l}
+    missing = {n for n in every if n not in set(names) and "test_simt_emulation" not in n and "needs_reference" not in n}
+    # what stays out: the emulation sample (cpu_only) and the tests that read /root/reference
+    assert all("ckpt_opt_pin" in n or "reference" in n for n in missing), sorted(missing)[:5]

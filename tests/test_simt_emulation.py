@@ -22,8 +22,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIMT = os.path.join(ROOT, "tests", "simt")
 CLANG = os.environ.get("SIMT_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 
-pytestmark = pytest.mark.skipif(not os.path.exists(CLANG) or os.uname().machine != "x86_64",
-                                reason="the SIMT emulation build needs the ROCm clang++ on an x86-64 host")
+# cpu_only: on a box WITH a device the same parity tests run on the device itself; tests/conftest.py keeps these out of the -m gpu session
+pytestmark = [pytest.mark.cpu_only,
+              pytest.mark.skipif(not os.path.exists(CLANG) or os.uname().machine != "x86_64",
+                                 reason="the SIMT emulation build needs the ROCm clang++ on an x86-64 host")]
 
 
 @pytest.fixture(scope="module")
