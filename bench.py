@@ -293,6 +293,10 @@ def main():
                        "comm": comm if world > 1 else "none", "parallelism": f"dp{world} (ICs sharded, 1 all-reduce/step)"},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_measured_on": (None if traffic is None else
+                                                 "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an EARLIER library (round 3 / round 4, "
+                                                 "sources named there); the tape records this kernel writes and reads are unchanged since, the figure is not "
+                                                 "re-measured in this run"),
                          # traffic: PMC figure of the committed rocprofv3 passes (profiles/traffic.json; counters cannot be read
                          # inside this process).  traffic_model: the same quantity from THIS run's step counts -- algorithmic bytes +
                          # the adjoint's step tape, 64 B per accepted step written at 1.27x its payload (lane-strided partial
