@@ -66,13 +66,16 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
     static_assert(NTH + kExtra <= 64, "the per-batch sums use one lane per column");
 
     __shared__ double kc_lds[kNConst];
-    __shared__ double tsp_lds[kMaxSave + 2];               // two -inf slots in front: the reverse sweep reads two save times back unconditionally
+    // two -inf slots in front (the reverse sweep reads two save times back unconditionally), four +inf slots behind the last save time (the
+    // forward sweep counts the save points a step passes four at a time)
+    __shared__ double tsp_lds[kMaxSave + 2 + 4];
     double *const ts_lds = tsp_lds + 2;
     __shared__ double stage_lds[(NTH + kExtra) * GPB];    // batch sums: [column][pair of this block]
     const int tid = threadIdx.x;
     for (int idx = tid; idx < kNConst; idx += BLOCK) kc_lds[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
     for (int idx = tid; idx < prm.n_save; idx += BLOCK) ts_lds[idx] = prm.tsave[idx];
     if (tid < 2) tsp_lds[tid] = -INFINITY;
+    if (tid >= 2 && tid < 6) ts_lds[prm.n_save + tid - 2] = INFINITY;
     __syncthreads();
     const KConst *kc = reinterpret_cast<const KConst *>(kc_lds);
 
@@ -381,6 +384,18 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
                                     if (own[i]) rec[2 + m * H + i] = u[i];
                                 ++nacc;
                                 const double tnew = last ? tend : t + dt;
+                                if (!prm.pred) {
+                                    // a gradient launch only COUNTS the save points inside the step (the reverse sweep evaluates them): four save
+                                    // times per LDS round trip instead of a dependent read, a compare and a branch per point (the times ascend;
+                                    // +inf behind the last one stops the count at nsave)
+                                    while (true) {
+                                        CRNN_CHK(jsave >= 0 && jsave <= nsave, 26);
+                                        const double a0 = ts_lds[jsave], a1 = ts_lds[jsave + 1], a2 = ts_lds[jsave + 2], a3 = ts_lds[jsave + 3];
+                                        const int c = (a0 <= tnew ? 1 : 0) + (a1 <= tnew ? 1 : 0) + (a2 <= tnew ? 1 : 0) + (a3 <= tnew ? 1 : 0);
+                                        jsave += c;
+                                        if (c < 4) break;
+                                    }
+                                } else
                                 while (jsave < nsave) {
                                     CRNN_CHK(jsave >= 0 && jsave < nsave, 26);
                                     const double ts = ts_lds[jsave];
