@@ -187,12 +187,13 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
     using Solver = typename SolverSel<(NR < NS) && !JFD, NS, NR, HAS_T, USE_SCALE>::type;
 
     __shared__ double kc_lds[kNConst];
-    __shared__ double ts_lds[kMaxSave];
+    __shared__ double ts_lds[kMaxSave + 4];                       // four +inf slots behind the last save time: gradient launches count save points four at a time
     __shared__ double thb_lds[NTH * BLOCK];     // gradient accumulators [m][lane] (also the staging area of the batch sums)
     __shared__ double ex_lds[kExtra * BLOCK];
     const int tid = threadIdx.x;
     for (int idx = tid; idx < kNConst; idx += BLOCK) kc_lds[idx] = reinterpret_cast<const double *>(prm.kc)[idx];
     for (int idx = tid; idx < prm.n_save; idx += BLOCK) ts_lds[idx] = prm.tsave[idx];
+    if (tid < 4) ts_lds[prm.n_save + tid] = INFINITY;
     const KConst *kc = reinterpret_cast<const KConst *>(kc_lds);
     // theta is read from LDS (broadcast ds_read), not through scalar loads: with 42-43 parameters live across the forward
     // AND the reverse sweep the SGPR file overflows (247 SGPR spills -> v_readlane/v_writelane churn, s_load + s_waitcnt
@@ -428,6 +429,18 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                                 }
                                 ++nacc;
                                 const double tnew = last ? tend : t + dt;
+                                if (!PRIMAL && !prm.pred) {
+                                    // a gradient launch only COUNTS the save points inside the step (the reverse sweep evaluates them): four save
+                                    // times per LDS round trip instead of a dependent read, a compare and a branch per point (ascending times,
+                                    // +inf behind the last one)
+                                    while (true) {
+                                        CRNN_CHK(jsave >= 0 && jsave <= nsave, 6);
+                                        const double a0 = ts_lds[jsave], a1 = ts_lds[jsave + 1], a2 = ts_lds[jsave + 2], a3 = ts_lds[jsave + 3];
+                                        const int c = (a0 <= tnew ? 1 : 0) + (a1 <= tnew ? 1 : 0) + (a2 <= tnew ? 1 : 0) + (a3 <= tnew ? 1 : 0);
+                                        jsave += c;
+                                        if (c < 4) break;
+                                    }
+                                } else
                                 while (jsave < nsave) {
                                     CRNN_CHK(jsave >= 0 && jsave < nsave, 6);
                                     const double ts = ts_lds[jsave];
