@@ -485,18 +485,17 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
             for (int i = 0; i < NS; ++i) d[i] = row[doff[i]];
         };
         // residual of one save point: adds its loss term, returns the seed weight w_i = d loss_term / d v_i
-        auto residual = [&](int i, double v, double dobs) -> double {
-            double mask = 1.0;
-            if (prm.clamp_pred) {
-                mask = (v > kc->ub || v < -kc->ub) ? 0.0 : 1.0;
-                v = clampv(v, -kc->ub, kc->ub);
-            }
+        // (round 5, as the Rosenbrock23 adjoint kernels: no clamp is an infinite clamp -- v_max / v_min, v is finite on accepted steps --, the
+        // mask is "the clamp changed nothing"; the same values as the compare-and-select form it replaces)
+        const double ubc = prm.clamp_pred ? kc->ub : __builtin_inf();
+        auto residual = [&](int i, const double v, double dobs) -> double {
+            const double vc = fmin(fmax(v, -ubc), ubc);
             const double iy = kc->inv_yscale[i];
-            const double rr = (dobs - v) * iy;
+            const double rr = (dobs - vc) * iy;
             double w;
-            if (prm.loss_kind == 0) { loss_sum += fabs(rr); w = signbit(rr) ? 1.0 : -1.0; }
-            else { loss_sum = fma(rr, rr, loss_sum); w = -2.0 * rr; }
-            return w * mask * iy;
+            if (prm.loss_kind == 0) { loss_sum += fabs(rr); w = signbit(rr) ? iy : -iy; }
+            else { loss_sum = fma(rr, rr, loss_sum); w = (-2.0 * rr) * iy; }
+            return (vc == v) ? w : 0.0;
         };
         // reverse accumulation through one right-hand-side evaluation k = f(point) with features (x, g, r):
         //   gb = f_u^T kb,   thb += f_theta^T kb
