@@ -40,7 +40,7 @@ SENS = "const crnn::SolveParams, const double*, const double*"
 
 def test_headline_lane_pair_kernel_has_no_scratch_and_fits_two_blocks_of_lds(tmp_path):
     r = _resources(tmp_path, "ros23_adj2_kernel.hpp", f"crnn::ros23_adj2_kernel<6,3,true,256,1>({ADJ})")
-    assert r["scratch"] == 0 and r["vgpr"] + r["agpr"] <= 512 and r["lds"] <= 81920, r      # 404 registers, 51 KB (profiles/r04g)
+    assert r["scratch"] == 0 and r["vgpr"] + r["agpr"] <= 512 and r["lds"] <= 81920, r      # 440 registers, 51 KB (round 5; 404 in profiles/r04g)
 
 
 def test_one_lane_primal_kernels_have_no_scratch(tmp_path):
