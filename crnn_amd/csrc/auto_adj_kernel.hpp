@@ -91,11 +91,7 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
 #define CRNN_TH_FRESH() th
 #endif
     double *const thb_s = thb_lds + tid;
-#if CRNN_ADJ_THB_ATOMIC
 #define THB_ADD(m, val) unsafeAtomicAdd(&thb_s[(m) * BLOCK], (val))
-#else
-#define THB_ADD(m, val) thb_s[(m) * BLOCK] += (val)
-#endif
 
     const double d_ = 0.29289321881345248;    // 1/(2+sqrt 2)
     const double c32 = 7.4142135623730950;    // 6+sqrt 2

@@ -576,7 +576,7 @@ int32_t launch_adjoint(Ctx *c, const AdjEntry *k, const double *d_theta, const d
     const int64_t need_blocks = (count + tpb - 1) / tpb;
     const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(need_blocks, (int64_t)c->num_cu * occ));
     const size_t lanes = (size_t)nblk * tpb;                     // tape slots (one per resident trajectory)
-    const size_t recw = CRNN_ADJ_TAPE_K ? (size_t)3 * c->cfg.ns + 2 : (size_t)c->cfg.ns + 2;
+    const size_t recw = (size_t)c->cfg.ns + 2;
     int64_t cap = c->cfg.tape_steps;
     if (cap <= 0) {  // auto: what fits in min(free/4, 16 GiB), at most maxiters (no trajectory accepts more steps)
         if (c->tape_budget == 0) {

@@ -38,26 +38,11 @@
 #ifndef CRNN_ADJ_DBG
 #define CRNN_ADJ_DBG 0
 #endif
-// 1: the n_theta gradient accumulators of a lane live in LDS ([m][lane], conflict-free) and are updated with
-//    ds_add_f64; 0: they live in registers (84 VGPRs for case2, which the allocator parks in AGPRs)
-#ifndef CRNN_ADJ_THB_LDS
-#define CRNN_ADJ_THB_LDS 1
-#endif
-// 1: the tape record also holds the stages k1 and k2 - k1 of the accepted step (NS + 2 -> 3 NS + 2 doubles).  The reverse
-//    sweep then skips two right-hand sides and two solves, and -- more important at one wavefront per SIMD -- the point
-//    u_mid is known at once, so the two feature / rate evaluations of a reverse step are independent of each other.
-//    Measured (tools/kvariants.sh): no gain (case2 0.612 vs 0.618 ms, robertson 0.706 vs 0.704 ms) -- the 2.3x tape
-//    traffic eats the saved arithmetic -- so the default stays 0.
-// 1: lane-private LDS accumulators are updated with ds_add_f64 (fire and forget); 0: ds_read + add + ds_write.  In isolation
-//    (tools/ubench/lds_acc.hip) the atomic costs a wavefront 22-30 cycles and the plain sequence 6-8; inside the kernels the
-//    read's latency is exposed and the plain sequence is 2-8 % SLOWER (case2 0.558 vs 0.548 ms, AutoTsit5 robertson 1.35 vs
-//    1.24 ms) -- so: atomics, and as few of them as possible (see the folded addends below).
-#ifndef CRNN_ADJ_THB_ATOMIC
-#define CRNN_ADJ_THB_ATOMIC 1
-#endif
-#ifndef CRNN_ADJ_TAPE_K
-#define CRNN_ADJ_TAPE_K 0
-#endif
+// Settled experiments (their switches were deleted in round 5; measurements in DESIGN.md 3.1 / docs/HISTORY.md): the n_theta gradient accumulators
+// of a lane live in LDS ([m][lane], conflict-free) and are updated with ds_add_f64 -- fire and forget; read + add + write was 2-8 % slower inside the
+// kernels although cheaper in isolation (tools/ubench/lds_acc.hip), registers (84 VGPRs for case2) parked them in AGPRs --; the tape record holds
+// (t, dt, u) only -- with the stages k1, k2 - k1 on it as well the reverse sweep skips two right-hand sides and two solves but the 2.3x tape traffic
+// eats the saved arithmetic (case2 0.612 vs 0.618 ms, robertson 0.706 vs 0.704).
 
 // phase timing (tools/kvariants.sh build prof="-DCRNN_ADJ_PROF=1"; the library then prints the shares of wave 0 of block 0 to
 // stderr after every launch): s_memtime deltas per phase, with scheduling fences at the phase boundaries (the fenced
@@ -181,7 +166,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
     using L_ = Lay<NS, NR, HAS_T>;
     constexpr int N = L_::N;
     constexpr int NTH = L_::NTH;
-    constexpr int RECW = CRNN_ADJ_TAPE_K ? 3 * NS + 2 : NS + 2;
+    constexpr int RECW = NS + 2;
     static_assert(NTH + kExtra <= 64, "the per-batch sums use one lane per column");
     static_assert(!JFD || PRIMAL, "the finite-difference W exists for primal launches");
     using Solver = typename SolverSel<(NR < NS) && !JFD, NS, NR, HAS_T, USE_SCALE>::type;
@@ -422,10 +407,6 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                                     rec[1] = dt;
 #pragma unroll
                                     for (int i = 0; i < NS; ++i) rec[2 + i] = u[i];
-#if CRNN_ADJ_TAPE_K
-#pragma unroll
-                                    for (int i = 0; i < NS; ++i) { rec[2 + NS + i] = k1[i]; rec[2 + 2 * NS + i] = dk[i]; }
-#endif
                                 }
                                 ++nacc;
                                 const double tnew = last ? tend : t + dt;
@@ -501,22 +482,10 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
         // ================================================================== reverse sweep
         const int n_saved = jsave;
         const int jlo = start_saved ? 1 : 0;
-#if CRNN_ADJ_THB_LDS
 #pragma unroll
         for (int m = 0; m < NTH; ++m) thb_s[m * BLOCK] = 0.0;
-#if CRNN_ADJ_THB_ATOMIC
 #define THB_ADD(m, val) unsafeAtomicAdd(&thb_s[(m) * BLOCK], (val))
-#else
-#define THB_ADD(m, val) thb_s[(m) * BLOCK] += (val)
-#endif
 #define THB_REG(m) 0.0
-#else
-        double thb[NTH];
-#pragma unroll
-        for (int m = 0; m < NTH; ++m) thb[m] = 0.0;
-#define THB_ADD(m, val) thb[m] += (val)
-#define THB_REG(m) thb[m]
-#endif
         double lam[NS];
 #pragma unroll
         for (int i = 0; i < NS; ++i) lam[i] = 0.0;
@@ -548,26 +517,15 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
         constexpr bool TS_PF = NS < 5;
         double ts_nxt = (TS_PF && jsave - 2 >= jlo) ? ts_lds[jsave - 2] : -INFINITY;
         double rt = 0.0, rdt = 0.0, ru[NS];   // tape record s, prefetched
-#if CRNN_ADJ_TAPE_K
-        double rk1[NS], rdk[NS];
-#endif
         if constexpr (!PRIMAL) {   // a context that has only made primal calls has no tape at all: nothing may touch it
             CRNN_CHK(s < adj.tape_cap, 3);
             const double *rec = tape + (size_t)(s > 0 ? s : 0) * RECW;
             rt = rec[0]; rdt = rec[1];
 #pragma unroll
             for (int i = 0; i < NS; ++i) ru[i] = rec[2 + i];
-#if CRNN_ADJ_TAPE_K
-#pragma unroll
-            for (int i = 0; i < NS; ++i) { rk1[i] = rec[2 + NS + i]; rdk[i] = rec[2 + 2 * NS + i]; }
-#endif
         } else {
 #pragma unroll
             for (int i = 0; i < NS; ++i) ru[i] = 0.0;
-#if CRNN_ADJ_TAPE_K
-#pragma unroll
-            for (int i = 0; i < NS; ++i) { rk1[i] = 0.0; rdk[i] = 0.0; }
-#endif
         }
 
         // Which lanes reverse together.  All lanes start with their LAST step (lag 0: the lanes of an iteration are at about
@@ -594,11 +552,6 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                 double un[NS];
 #pragma unroll
                 for (int i = 0; i < NS; ++i) un[i] = ru[i];
-#if CRNN_ADJ_TAPE_K
-                double k1[NS], dk[NS];
-#pragma unroll
-                for (int i = 0; i < NS; ++i) { k1[i] = rk1[i]; dk[i] = rdk[i]; }
-#endif
                 double dA[NS], dB[NS], dC[NS];
                 load_row(jsave - 1, dA);
                 load_row(jsave - 2, dB);
@@ -609,10 +562,6 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                     rt = rec[0]; rdt = rec[1];
 #pragma unroll
                     for (int i = 0; i < NS; ++i) ru[i] = rec[2 + i];
-#if CRNN_ADJ_TAPE_K
-#pragma unroll
-                    for (int i = 0; i < NS; ++i) { rk1[i] = rec[2 + NS + i]; rdk[i] = rec[2 + 2 * NS + i]; }
-#endif
                 }
                 // ---- re-form the step
                 const double *th = CRNN_ADJ_TH_FRESH();
@@ -620,20 +569,6 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                 Solver W;
                 const double gam = d_ * h;
                 double gr0[NR], x1[NS], g1[NS], r1[NR];
-#if CRNN_ADJ_TAPE_K
-                {   // both points are known from the tape: two independent evaluations
-                    double u1[NS];
-#pragma unroll
-                    for (int i = 0; i < NS; ++i) u1[i] = fma(0.5 * h, k1[i], un[i]);
-                    features<NS>(un, kc->lb, kc->ub, x0, gg0);
-                    features<NS>(u1, kc->lb, kc->ub, x1, g1);
-                    rates<NS, NR, HAS_T>(th, x0, bT, rr0);
-                    rates<NS, NR, HAS_T>(th, x1, bT, r1);
-                }
-#pragma unroll
-                for (int j = 0; j < NR; ++j) gr0[j] = gam * rr0[j];
-                (void)W.factor(th, gg0, rr0, gam, kc->scale);
-#else
                 double ff0[NS];
                 features<NS>(un, kc->lb, kc->ub, x0, gg0);
                 rates<NS, NR, HAS_T>(th, x0, bT, rr0);
@@ -656,7 +591,6 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                     for (int i = 0; i < NS; ++i) dk[i] = f1[i] - k1[i];
                 }
                 W.solve(th, gg0, gr0, kc->scale, dk);
-#endif
 
                 ADJ_T(9);    // reverse: prefetches + re-formation of the step
                 // ---- loss and its seeds at the save points inside (tn, tnew]
@@ -855,7 +789,7 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
                 if (HAS_T) THB_ADD(L_::wi(NS, j), wbb[j] * xT);
             }
 #pragma unroll
-            for (int m = 0; m < NTH; ++m) thb_s[m * BLOCK] = (CRNN_ADJ_THB_LDS ? thb_s[m * BLOCK] : THB_REG(m)) * scale_;
+            for (int m = 0; m < NTH; ++m) thb_s[m * BLOCK] = thb_s[m * BLOCK] * scale_;
             ex_lds[0 * BLOCK + tid] = valid ? loss_sum * scale_ : 0.0;
             ex_lds[1 * BLOCK + tid] = (valid && rc == 0) ? 1.0 : 0.0;
             ex_lds[2 * BLOCK + tid] = valid ? (double)nacc : 0.0;
