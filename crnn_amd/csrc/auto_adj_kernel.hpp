@@ -25,17 +25,7 @@
 // on Tsit5 for ever, so HAS_T shapes are instantiated with COMPOSITE = false.  The PI exponents follow the running
 // algorithm (beta1 = 7/(10 order), beta2 = 2/(5 order)); gamma, qmin, qmax, the steady band and qold are shared.
 #pragma once
-#ifndef CRNN_AUTO_THETA_LDS
-#define CRNN_AUTO_THETA_LDS 3   // where theta lives: see the kernel preamble (3 measured fastest AND leanest, round 3)
-#endif
-#ifndef CRNN_AUTO_FENCES
-#define CRNN_AUTO_FENCES 0
-#endif
-#if CRNN_AUTO_FENCES
-#define CRNN_AUTO_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define CRNN_AUTO_FENCE() ((void)0)
-#endif
+#define CRNN_AUTO_FENCE() ((void)0)   // (a scheduling-fence experiment of round 3, measured slower: the call sites mark where it stood)
 #include "ros23_adj_kernel.hpp"
 #include "tsit5_kernel.hpp"
 
@@ -70,26 +60,12 @@ __global__ __launch_bounds__(BLOCK) void auto_adj_kernel(const SolveParams prm, 
     for (int idx = tid; idx < prm.n_save; idx += BLOCK) ts_lds[idx] = prm.tsave[idx];
     __syncthreads();
     const KConst *kc = reinterpret_cast<const KConst *>(kc_lds);
-    // Where theta lives (CRNN_AUTO_THETA_LDS):
-    //   0  wave-uniform scalar loads, hoisted by the compiler: theta sits in ~88 SGPRs for the whole kernel
-    //   1  LDS, broadcast ds_read, hoisted: theta sits in VGPRs / AGPRs for the whole kernel
-    //   2  LDS, read afresh by every right-hand-side evaluation / adjoint contraction / Rosenbrock23 body (pointer with
-    //      an opaque zero offset: the loads cannot be hoisted out of the step loops)
-    //   3  scalar loads re-issued per phase the same way (a handful of s_load_dwordx16 per evaluation, issued ahead of the
-    //      logarithms that precede theta's first use)
-#if CRNN_AUTO_THETA_LDS == 1 || CRNN_AUTO_THETA_LDS == 2
-    __shared__ double th_lds[NTH];
-    for (int idx = tid; idx < NTH; idx += BLOCK) th_lds[idx] = theta[idx];
-    __syncthreads();
-    const double *th = th_lds;
-#define CRNN_TH_FRESH() (CRNN_AUTO_THETA_LDS == 2 ? th_lds + opaque_zero() : th)
-#elif CRNN_AUTO_THETA_LDS == 3
+    // Where theta lives: wave-uniform scalar loads RE-ISSUED per phase (a handful of s_load_dwordx16 per evaluation through a pointer with an opaque
+    // SGPR zero offset, issued ahead of the logarithms that precede theta's first use), theta as SGPR operands of the FMAs.  Round 3 measured this
+    // fastest and leanest of four placements (hoisted scalar loads: ~88 SGPRs for the whole kernel; LDS hoisted into VGPRs / AGPRs; LDS re-read per
+    // phase); the switch that selected among them was deleted in round 5.
     const double *th = theta;
 #define CRNN_TH_FRESH() (theta + opaque_zero_s())
-#else
-    const double *__restrict__ th = theta;
-#define CRNN_TH_FRESH() th
-#endif
     double *const thb_s = thb_lds + tid;
 #define THB_ADD(m, val) unsafeAtomicAdd(&thb_s[(m) * BLOCK], (val))
 

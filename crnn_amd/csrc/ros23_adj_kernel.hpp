@@ -59,9 +59,6 @@ namespace crnn {
 // -- tape records, save times in LDS, observed rows, u0 / pred / per-trajectory outputs, the queue permutation, the batch
 // partial rows -- is checked against its extent on the lanes that perform it; violations are counted in g_bounds[0], the site
 // code of the first one is kept in g_bounds[1] (crnn_debug_bounds reads the pair).  Release builds compile the checks away.
-#ifndef CRNN_ADJ_THETA
-#define CRNN_ADJ_THETA 0     // 0: theta staged in LDS (broadcast reads, parked in AGPRs); 3: scalar loads re-issued per step
-#endif
 // (g_bounds / CRNN_CHK live in ros23_kernel.hpp since round 4: the HyChem, cathode and forward-tangent kernels carry checks too --
 //  site codes 1-19 adjoint kernels, 20-39 HyChem, 40-59 cathode, 60-69 forward tangents)
 
@@ -187,19 +184,13 @@ __global__ __launch_bounds__(BLOCK) void ros23_adj_kernel(const SolveParams prm,
     // The compiler loads theta once and parks it in AGPRs (two v_accvgpr_read per use); forcing a fresh LDS read per
     // phase instead (pointer laundered through an empty asm) removes 10 % of the VALU instructions and is SLOWER (case2
     // +4 %, robertson +15 %): at one wavefront per SIMD the exposed lgkmcnt waits cost more than the issue slots saved.
-#if CRNN_ADJ_THETA == 3
-    // experiment (round 3): wave-uniform scalar loads RE-ISSUED at the top of every forward attempt / reverse step (pointer
-    // with an opaque SGPR zero offset), theta as SGPR operands of the FMAs -- what auto_adj_kernel.hpp ships
-    __syncthreads();
-    const double *th = theta;
-#define CRNN_ADJ_TH_FRESH() (theta + opaque_zero_s())
-#else
+    // (Round 3 also measured wave-uniform scalar loads re-issued at the top of every attempt / reverse step -- what auto_adj_kernel.hpp ships -- here:
+    // slower for this kernel; its switch was deleted in round 5.)
     __shared__ double th_lds[NTH];
     for (int idx = tid; idx < NTH; idx += BLOCK) th_lds[idx] = theta[idx];
     __syncthreads();
     const double *th = th_lds;
 #define CRNN_ADJ_TH_FRESH() th_outer
-#endif
     const double *const th_outer = th;
     double *const thb_s = thb_lds + tid;   // accumulator m of this lane: thb_s[m * BLOCK]
 
