@@ -27,7 +27,7 @@ namespace crnn {
 // FiniteDiff's forward differences of the right-hand side, column c = (f(u + eps_c e_c, t) - f(u, t)) / eps_c, eps_c = max(sqrt(eps) |u_c|,
 // sqrt(eps)), against the FSAL value f(u, t), and the time derivative dT = (f(u, t + e_t) - f(u, t)) / e_t, e_t = max(sqrt(eps) |t|, sqrt(eps)),
 // on the T(t), P(t) tables (Te, Pe = the tables at t + e_t).  NS + 1 point evaluations per attempt instead of one analytic pass: a parity
-// mode (primal launches; crnn_ctx_set_jacobian), checked against the oracle's orc_hychem.jac_fd = 1.  [UNVERIFIED-DEP] as the oracle's.
+// mode (primal launches; crnn_ctx_set_jacobian), checked against a CPU statement of the same increments (tests/test_hychem.py).  [UNVERIFIED-DEP]: FiniteDiff.jl is not in the reference tree.
 template <int NS, int NR>
 __device__ __forceinline__ void hy_jac_ft2_fd(const double *th, const KConst *kc, const double inv_R, const double (&uo)[(NS + 1) / 2],
                                               const double (&f0)[(NS + 1) / 2], const double T, const double P, const double Te, const double Pe,
