@@ -7,6 +7,7 @@ import os
 import re
 import shutil
 import subprocess
+import sys
 
 import pytest
 
@@ -125,3 +126,28 @@ def test_hychem_finite_difference_primal_kernels(tmp_path):
         r = _resources(tmp_path, "hychem_auto_kernel.hpp", f"crnn::hychem_auto_kernel<9,10,256,{inst}>(const crnn::SolveParams, const double*, const crnn::HyParams)")
         assert r["scratch"] == 0 and r["vgpr"] + r["agpr"] <= 512 and r["lds"] <= 160 * 1024, r
 
+
+
+def test_headline_kernel_static_issue_budget(tmp_path):
+    """The static instruction table of the headline pair kernel by source phase (tools/isa_phase_table.py; profiles/r05d section 1c): round 5 cut the
+    reverse sweep's loss + seeds phase from 797 instructions to ~380 executed (766 with both loss-kind specialisations in the table) and the step
+    pair from 3 652 to ~3 200 executed.  Budgets with a margin: an edit that brings the branches or the selects back shows up here, without a device."""
+    src = tmp_path / "tu.hip"
+    src.write_text('#include "ros23_adj2_kernel.hpp"\ntemplate __global__ void crnn::ros23_adj2_kernel<6,3,true,256,1>(' + ADJ + ");\n")
+    asm = tmp_path / "k.s"
+    out = subprocess.run([HIPCC if os.path.exists(HIPCC) else "hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=on", "-I", CSRC,
+                          "-gline-tables-only", "-S", "--cuda-device-only", "-o", str(asm), str(src)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    hdr = open(os.path.join(CSRC, "ros23_adj2_kernel.hpp")).read().split("\n")
+    args = []
+    for k in range(13):
+        ln = next(i + 1 for i, l in enumerate(hdr) if f"ADJ2_T({k});" in l)
+        args += ["--phase", f"{ln}=p{k}"]
+    tab = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_phase_table.py"), str(asm), "ros23_adj2_kernel", "ros23_adj2_kernel.hpp", "--depth", "2", *args],
+                         capture_output=True, text=True, timeout=300)
+    assert tab.returncode == 0, tab.stderr[-2000:]
+    rows = {l.split()[0]: [int(x) for x in l.split()[1:]] for l in tab.stdout.splitlines() if l and l.split()[0] in {f"p{k}" for k in range(13)} | {"total"}}
+    seeds, total = rows["p10"], rows["total"]
+    assert seeds[0] <= 820 and seeds[1] >= 380, rows          # both specialisations: ~2 x 380 instructions, ~2 x 206 of them FP64 arithmetic
+    assert total[0] <= 3750 and total[7] == 0, rows           # the step pair; no scratch instruction inside the loops
+    assert rows["p7"][0] <= 290, rows                         # accepted-step bookkeeping (both save-point paths are in the table)
