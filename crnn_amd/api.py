@@ -440,8 +440,9 @@ class NeuralODE:
 
     def set_jacobian(self, mode):
         """JAC_ANALYTIC (default) / JAC_FINITE_DIFF: the Jacobian behind W in the Rosenbrock23 primal launches (predict, loss) --
-        `Rosenbrock23(autodiff=true)` (robertson/rober_crnn.jl:33) / `Rosenbrock23(autodiff=false)` (case2/case2.jl:26):
-        include/crnn_hip.h: crnn_ctx_set_jacobian."""
+        `Rosenbrock23(autodiff=true)` (robertson/rober_crnn.jl:33) / `Rosenbrock23(autodiff=false)` (case2/case2.jl:26); on a HyChem
+        problem (HyChem/crnn_pyrolysis_mass.jl:29) FINITE_DIFF also takes the time derivative on the T(t), P(t) tables by a forward
+        difference, for Rosenbrock23 and inside AutoTsit5(Rosenbrock23): include/crnn_hip.h: crnn_ctx_set_jacobian."""
         check(lib.crnn_ctx_set_jacobian(self._ctx.h, int(mode)), self._ctx.h)
         self._jac_mode = int(mode)
         if self._adhoc is not None:     # predict_theta / predict_neuralode integrate on their own context
