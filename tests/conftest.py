@@ -60,6 +60,13 @@ def pytest_collection_modifyitems(config, items):
         items.sort(key=lambda it: 0 if known(it) else 1)       # stable: file / definition order is kept within each group
 
 
+def emulated():
+    """True when CRNN_HIP_LIB points at the SIMT emulation library (tools/simt_suite.sh).  The BASELINE-size tests then run the same logic and the
+    same assertions (minus the clock) at sizes scaled to the emulated device's two CUs instead of being left out."""
+    from crnn_amd import _lib as L
+    return "SIMT-EMULATION" in L.lib.crnn_build_info().decode()
+
+
 @pytest.fixture(scope="session")
 def fx():
     with open(os.path.join(ROOT, "tests", "golden", "fixtures.json")) as f:

@@ -284,23 +284,25 @@ def test_gpu_cathode_config5_full_size(orc, cfx):
     per-particle 17-parameter gradients in ONE launch.  All retcodes 0; the 4 096 particles are 256 tiles of 16 distinct
     ones, so every tile must be bit-identical wherever it sat in the work queue; 64 random (particle, rate) rows are
     checked against the oracle (same stepper, reference tolerances: step for step)."""
+    from conftest import emulated
     from crnn_amd.cathode import CathodeUQ
-    betas, exp_data = _many_rates(cfx, 256)
-    uq = CathodeUQ(exp_data, betas, cfx["theta"], normalizer=np.ones((256, 3)), errnorm_sens=0)
+    NT, NRt, NS_ = (6, 12, 12) if emulated() else (256, 256, 64)     # tiles of 16 particles, heating rates, oracle rows (SIMT emulation: scaled down)
+    betas, exp_data = _many_rates(cfx, NRt)
+    uq = CathodeUQ(exp_data, betas, cfx["theta"], normalizer=np.ones((NRt, 3)), errnorm_sens=0)
     rng = np.random.default_rng(55)
     base = 1 + 1e-3 * rng.standard_normal((16, 17))           # SURVEY 8(d): particles = 1 + 1e-3 N(0,1)
     base[:, 6:9] = 0.0
-    p = np.tile(base, (256, 1))
+    p = np.tile(base, (NT, 1))
     loss, grad, _ = uq.solve(p)
     st = uq.last_stats
-    assert st["n_traj"] == 4096 * 256 == st["n_ok"] and np.all(uq.last_retcode == 0)
+    assert st["n_traj"] == 16 * NT * NRt == st["n_ok"] and np.all(uq.last_retcode == 0)
     assert np.all(uq.last_n_saved == np.array([e.shape[0] for e in exp_data])[None, :])
-    L4, G4 = loss.reshape(256, 16, 256), grad.reshape(256, 16, 256, 17)
+    L4, G4 = loss.reshape(NT, 16, NRt), grad.reshape(NT, 16, NRt, 17)
     assert np.array_equal(L4, np.broadcast_to(L4[0], L4.shape))
     assert np.array_equal(G4, np.broadcast_to(G4[0], G4.shape))
     ps = np.array(cfx["theta"])
-    for _ in range(64):
-        n, i = int(rng.integers(0, 4096)), int(rng.integers(0, 256))
+    for _ in range(NS_):
+        n, i = int(rng.integers(0, 16 * NT)), int(rng.integers(0, NRt))
         e = exp_data[i]
         r = orc.cathode_solve_one(orc.make_cathode(betas[i]), p[n] * ps, e[:, 0], e[:, 1:].mean(axis=1), (e[:, 1:] ** 2).mean(axis=1))
         assert r["retcode"] == 0
@@ -523,21 +525,23 @@ def test_gpu_cathode_composite_primal_matches_golden_at_tight_tolerance(cfx):
 def test_gpu_cathode_composite_config5_full_size(orc, cfx):
     """BASELINE config 5 at full size through the reference's composite, primal: every solve succeeds, a third of Rosenbrock23's
     accepted steps, tiles bit-identical wherever they sat in the queue, 48 random rows within solver tolerance of the oracle."""
+    from conftest import emulated
     from crnn_amd.cathode import CathodeUQ
-    betas, exp_data = _many_rates(cfx, 256)
-    uq = CathodeUQ(exp_data, betas, cfx["theta"], normalizer=np.ones((256, 3)), solver="autotsit5_trbdf2", errnorm_sens=0)
+    NT, NRt, NS_ = (6, 12, 12) if emulated() else (256, 256, 48)     # tiles of 16 particles, heating rates, oracle rows (SIMT emulation: scaled down)
+    betas, exp_data = _many_rates(cfx, NRt)
+    uq = CathodeUQ(exp_data, betas, cfx["theta"], normalizer=np.ones((NRt, 3)), solver="autotsit5_trbdf2", errnorm_sens=0)
     rng = np.random.default_rng(55)
     base = 1 + 1e-3 * rng.standard_normal((16, 17))
     base[:, 6:9] = 0.0
-    p = np.tile(base, (256, 1))
+    p = np.tile(base, (NT, 1))
     loss, _, _ = uq.solve(p, want_grad=False)
     st = uq.last_stats
-    assert st["n_traj"] == 4096 * 256 == st["n_ok"] and 100 < st["n_accept"] / st["n_traj"] < 130
-    L4 = loss.reshape(256, 16, 256)
+    assert st["n_traj"] == 16 * NT * NRt == st["n_ok"] and 100 < st["n_accept"] / st["n_traj"] < 130
+    L4 = loss.reshape(NT, 16, NRt)
     assert np.array_equal(L4, np.broadcast_to(L4[0], L4.shape))
     ps = np.array(cfx["theta"])
-    for _ in range(48):
-        n, i = int(rng.integers(0, 4096)), int(rng.integers(0, 256))
+    for _ in range(NS_):
+        n, i = int(rng.integers(0, 16 * NT)), int(rng.integers(0, NRt))
         e = exp_data[i]
         r = orc.cathode_solve_one(orc.make_cathode(betas[i], solver=3), p[n] * ps, e[:, 0], e[:, 1:].mean(axis=1), (e[:, 1:] ** 2).mean(axis=1),
                                   want_grad=False)
