@@ -6,6 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
 O=$R/gpurun_out/r05a
 mkdir -p $O
 cd $R
+if [ -z "$SKIP_BASE" ]; then   # SKIP_BASE=1: steps 1-3 were taken by tools/gpu_r05_call1.sh in an earlier call
 ( time python -c "import __graft_entry__ as g; g.build(); g.smoke()" ) > $O/build_smoke.log 2>&1
 tail -4 $O/build_smoke.log | cut -c1-300
 # 1. the whole -m gpu suite (no -x: every failure is wanted), full tail kept
@@ -18,6 +19,7 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/benc
 # 3. kernel trace of the same command
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $O/trace -o trace -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_trace.json 2> $O/trace.err )
 python tools/rocpd_summary.py $O > $O/trace_summary.txt 2>&1; head -30 $O/trace_summary.txt | cut -c1-200
+fi
 # 4. A/B on the same box: (a) the adjoint kernels' reverse-sweep loss + seeds phase rewritten straight-line in round 5 (static count of the
 #    executed path -12 %; parity-green under the SIMT emulator, never timed): the round-start library (commit 258bf9d, built from `git archive`
 #    into crnn_amd/csrc/dbg/libcrnn_kv_r5start.so, travels with the snapshot) against the tree's libcrnn_hip.so, lane pair and one lane;

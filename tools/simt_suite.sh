@@ -4,6 +4,7 @@
 # builds of the device library (crossbuild) or more than one rank.  Output: gpurun-free evidence of what the kernel sources compute;
 # the log is committed under profiles/ when it backs a claim.
 #   bash tools/simt_suite.sh [pytest args...]        e.g.  bash tools/simt_suite.sh tests/test_hychem.py -k errnorm
+#   SIMT_NOISE=1 bash tools/simt_suite.sh [...]      the same with one-ulp noise on what the device rounds differently (profiles/r05j_simt_ulp_noise.txt)
 #   SIMT_ASAN=1 bash tools/simt_suite.sh [...]       the same with the emulated kernels compiled under AddressSanitizer: "device" buffers are
 #       host allocations, LDS arrays and per-lane arrays are host objects, so a read or write of a kernel outside the object it indexes (beyond an allocation, an LDS array, a per-lane array) is reported with its
 #       source line -- the compute-sanitizer this toolchain does not have (profiles/r05g_simt_asan_suite.txt)
@@ -13,6 +14,11 @@ if [ -n "$SIMT_ASAN" ]; then
   SIMT_OUT=$R/tests/simt/libcrnn_simt_asan.so SIMT_FLAGS="-fsanitize=address -fno-omit-frame-pointer -shared-libasan" bash $R/tests/simt/build.sh || exit 1
   export CRNN_HIP_LIB=$R/tests/simt/libcrnn_simt_asan.so LD_PRELOAD=$RT
   export ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1:abort_on_error=1
+elif [ -n "$SIMT_NOISE" ]; then
+  # one-ulp noise on rcp / rsq / exp / log / pow (tests/simt/hip/hip_runtime.h, SIMT_ULP_NOISE): which parity bars survive last-place differences
+  # between the device's arithmetic and the host's -- the bars that would otherwise be met only because emulation and oracle share a libm
+  SIMT_OUT=$R/tests/simt/libcrnn_simt_noise.so SIMT_FLAGS="-DSIMT_ULP_NOISE=1 -Wl,--wrap=exp -Wl,--wrap=log -Wl,--wrap=pow" bash $R/tests/simt/build.sh || exit 1
+  export CRNN_HIP_LIB=$R/tests/simt/libcrnn_simt_noise.so
 else
 bash $R/tests/simt/build.sh || exit 1
 export CRNN_HIP_LIB=$R/tests/simt/libcrnn_simt.so
