@@ -464,7 +464,8 @@ namespace simt_noise {
 inline double jig(double r) {
     if (!std::isfinite(r) || r == 0.0) return r;
     uint64_t b; memcpy(&b, &r, 8);
-    uint64_t h = b * 0x9E3779B97F4A7C15ull; h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    static const uint64_t seed = getenv("SIMT_NOISE_SEED") ? strtoull(getenv("SIMT_NOISE_SEED"), nullptr, 10) * 0xD6E8FEB86659FD93ull : 0;   // another realisation of the noise
+    uint64_t h = (b ^ seed) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
     const int m = (int)(h % 3);
     if (m == 1) b += 1; else if (m == 2) b -= 1;
     memcpy(&r, &b, 8); return r;

@@ -135,6 +135,9 @@ def test_cathode_config_abi():
 
 
 # ------------------------------------------------------------------ GPU: kernel vs oracle / golden
+CLOUD_SEED_PRIMAL_NORM = 13      # a 2 % cloud on which the primal-norm gradient is well-conditioned under every noise realisation tried (11 is not: see the SVGD loop test)
+
+
 def _uq(cfx, **kw):
     kw.setdefault("errnorm_sens", 0)      # these tests pin the primal-norm adjoint / forward tangents unless they say otherwise
     from crnn_amd.cathode import CathodeUQ
@@ -663,14 +666,21 @@ def test_gpu_cathode_gradient_through_the_reference_composite_matches_oracle(orc
 
 
 @pytest.mark.gpu
-def test_gpu_device_resident_svgd_loop_matches_host_driven_loop(orc, cfx):
+@pytest.mark.parametrize("errnorm_sens,cloud_seed", [(2, 11), (0, CLOUD_SEED_PRIMAL_NORM)])
+def test_gpu_device_resident_svgd_loop_matches_host_driven_loop(orc, cfx, errnorm_sens, cloud_seed):
     """crnn_cathode_set_particles / crnn_cathode_svgd_step (particles, per-particle gradients, median select and move all on the
     device, one heating rate per iteration as crnn_cathode.jl:36-50 draws them) against the same iterations driven from the
     host through the entry points the other tests pin to the oracle: dlnprob (crnn_cathode_solve) + crnn_svgd_update, and the
     first move against the oracle's SVGD (orc_svgd_update).  Same kernels, same order: particles agree to 1e-12 after
-    six iterations; the bandwidth is the exact median every time (1e-14)."""
-    uq_dev, uq_host = _uq(cfx), _uq(cfx)
-    rng = np.random.default_rng(11)
+    six iterations; the bandwidth is the exact median every time (1e-14).
+
+    Both gradient modes: the default (errnorm_sens = 2, ForwardDiff's dual-inclusive norm, network.jl:232) on the cloud this test has always used,
+    and the opt-in primal-norm adjoint on a cloud where it is well-conditioned.  On cloud 11 it is not: particle 20's gradient at the third heating
+    rate is 9.06e1 in the plain build and 1e6 ... 5e9 under five of six realisations of one-ulp noise (profiles/r05j_simt_ulp_noise.txt: the
+    derivative of the discrete step map itself, adjoint = forward tangents), after which the SVGD move throws the cloud out of the solvable region --
+    round 3's device happened to realise the benign case; a device whose last places differ need not."""
+    uq_dev, uq_host = _uq(cfx, errnorm_sens=errnorm_sens), _uq(cfx, errnorm_sens=errnorm_sens)
+    rng = np.random.default_rng(cloud_seed)
     N = 96
     p0 = 1 + 2e-2 * rng.standard_normal((N, 17))
     p0[:, 6:9] = 0.0
@@ -685,19 +695,26 @@ def test_gpu_device_resident_svgd_loop_matches_host_driven_loop(orc, cfx):
             pn_o, _, _, h_o = orc.svgd_update(p, lnp, step)
         from crnn_amd.cathode import svgd_update
         p, _, _, h_h = svgd_update(p, lnp, step)
+        if not np.isfinite(loss_h):
+            # primal-norm half only: an ill-conditioned gradient (docstring) has thrown the cloud out of the solvable region on an earlier move.
+            # Both loops made that move with the same bits (asserted below, iteration by iteration) and both have to report the failed solves.
+            assert errnorm_sens == 0 and it > 0 and not np.isfinite(loss_d), (errnorm_sens, it, loss_d, loss_h)
+            break
         assert abs(loss_d - loss_h) <= 1e-12 * abs(loss_h) and abs(h_d - h_h) <= 1e-14 * h_h
         assert ms["solve_ms"] > 0 and ms["svgd_ms"] > 0
         pd = uq_dev.particles()
-        assert np.max(np.abs(pd - p)) < 1e-12, it
+        scale = max(1.0, float(np.abs(p).max()))            # 1 unless a gradient has exploded (then the move is large and so is its last place)
+        assert np.max(np.abs(pd - p)) < 1e-12 * scale, it
         if it == 0:
-            assert abs(h_d - h_o) <= 1e-14 * h_o and np.max(np.abs(pd - pn_o)) < 1e-12
+            tol_o = 1e-12 * scale + 4e-15 * step * np.abs(lnp).mean(axis=0).max()     # the oracle's exp is the host's: last-place differences times |lnp|
+            assert abs(h_d - h_o) <= 1e-14 * h_o and np.max(np.abs(pd - pn_o)) < tol_o, (np.max(np.abs(pd - pn_o)), tol_o)
     # without looking: steps stay enqueued, the particles are the same
-    uq_a, uq_b = _uq(cfx), _uq(cfx)
+    uq_a, uq_b = _uq(cfx, errnorm_sens=errnorm_sens), _uq(cfx, errnorm_sens=errnorm_sens)
     uq_a.set_particles(p0); uq_b.set_particles(p0)
     for i_exp in order[:3]:
         uq_a.svgd_step(i_exp, step, look=False)
         uq_b.svgd_step(i_exp, step)
-    assert np.array_equal(uq_a.particles(), uq_b.particles())
+    assert np.array_equal(uq_a.particles(), uq_b.particles(), equal_nan=True)
     for u in (uq_dev, uq_host, uq_a, uq_b):
         u.close()
 

@@ -40,8 +40,8 @@ if [ $# -gt 0 ]; then exec python -m pytest -m gpu -p no:cacheprovider "$@"; fi
 #       2 % particle cloud; one-ulp noise moves particle 20's gradient from 9e1 to 5e9 (the discrete map's own derivative: adjoint = forward
 #       tangents to 1e-14 of it; the depleted-species clamp inside a step -- profiles/r04m's census from another side), the SVGD move then throws the
 #       cloud out of the solvable region.  The default dual-norm gradient (errnorm_sens = 2) stays at 90.7 under the same noise (profiles/r05j).
-NOISE_DESELECT=""
-[ -n "$SIMT_NOISE" ] && NOISE_DESELECT="--deselect tests/test_cathode.py::test_gpu_device_resident_svgd_loop_matches_host_driven_loop"
+NOISE_DESELECT=""   # (since the last session of round 5 the test runs its primal-norm half on a well-conditioned cloud and nothing is deselected)
+true
 python -m pytest tests -m gpu -p no:cacheprovider -v --timeout=${SIMT_TIMEOUT:-2400} --durations=20 $NOISE_DESELECT \
   --ignore=tests/test_gpu_crossbuild.py --ignore=tests/test_dist_gpu2proc.py \
   --ignore=tests/test_kernel_resources.py --ignore=tests/test_oracle_sanitizers.py \
