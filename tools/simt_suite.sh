@@ -38,7 +38,7 @@ if [ $# -gt 0 ]; then exec python -m pytest -m gpu -p no:cacheprovider "$@"; fi
 #   test_kernel_resources.py, test_oracle_sanitizers.py   CPU tests of the ordinary suite
 #   under SIMT_NOISE=1 only: test_gpu_device_resident_svgd_loop_matches_host_driven_loop -- it drives the OPT-IN primal-norm adjoint of the cathode over a
 #       2 % particle cloud; one-ulp noise moves particle 20's gradient from 9e1 to 5e9 (the discrete map's own derivative: adjoint = forward
-#       tangents to 1e-14 of it; the depleted-species clamp inside a step -- profiles/r04m's census from another side), the SVGD move then throws the
+#       tangents to 1e-14 of it; presumably the kink of the depleted-species clamp -- profiles/r04m's census from another side), the SVGD move then throws the
 #       cloud out of the solvable region.  The default dual-norm gradient (errnorm_sens = 2) stays at 90.7 under the same noise (profiles/r05j).
 NOISE_DESELECT=""   # (since the last session of round 5 the test runs its primal-norm half on a well-conditioned cloud and nothing is deselected)
 true
