@@ -11,7 +11,7 @@ import os
 
 MAX_N = 12
 MAX_NR = 16
-ABI_VERSION = 4
+ABI_VERSION = 5
 UNIQUE_ID_BYTES = 128
 
 PMAP_IDENTITY, PMAP_CASE1, PMAP_CASE2, PMAP_ROBER, PMAP_HYCHEM = 0, 1, 2, 3, 4
@@ -113,6 +113,7 @@ SYMBOLS = {
     "crnn_ctx_set_lanes_per_traj": (C.c_int32, [_CTX, C.c_int32]),
     "crnn_last_lanes_per_traj": (C.c_int32, [_CTX]),
     "crnn_tape_retries": (C.c_int64, [_CTX]),
+    "crnn_hychem_block_cap": (C.c_int32, [_CTX]),
     "crnn_ctx_set_jacobian": (C.c_int32, [_CTX, C.c_int32]),
     "crnn_last_step_counts": (C.c_int32, [_CTX, C.c_int64, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "crnn_kernel_times": (C.c_int32, [_CTX, _DP, C.c_int32]),

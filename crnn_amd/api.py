@@ -156,7 +156,7 @@ class ODEProblem:
     grad_mode: int = 0            # GRAD_AUTO (adjoint where available) / GRAD_FORWARD (tangents) / GRAD_ADJOINT
     tape_steps: int = 0           # adjoint tape capacity per trajectory, 0 = auto
     errnorm_sens: int = 0         # 1 / 2: ForwardDiff's dual-inclusive error norm drives the step sizes of gradient calls
-                                  # (1: squared norm / length(u), Julia-1.6-era DiffEqBase; 2: / totallength(u), later versions)
+                                  # (1: squared norm / length(u); 2: / totallength(u) -- the reference's: tests/test_case2_stream_pin.py)
 
     def config(self) -> Config:
         cfg = Config()
@@ -455,6 +455,10 @@ class NeuralODE:
     def tape_retries(self):
         """HyChem: gradient launches repeated with fewer resident trajectories after a tape overflow (0: never)."""
         return int(lib.crnn_tape_retries(self._ctx.h))
+
+    def hychem_block_cap(self):
+        """HyChem: the resident-block limit the next gradient launch over the last overflowing range starts from (0: full width)."""
+        return int(lib.crnn_hychem_block_cap(self._ctx.h))
 
     def step_counts(self, first=0, count=None):
         """(naccept, nreject) of every trajectory in [first, first+count) of the most recent solve -- `sol.destats` of

@@ -80,6 +80,11 @@ class CathodeUQ:
 
     def __init__(self, exp_data, heating_rates, p_scales, *, atol=None, rtol=None, maxiters=None, lb_clamp=None, device=0,
                  normalizer=None, grad_mode=None, tape_every=None, solver=None, errnorm_sens=2):
+        if errnorm_sens and (grad_mode is not None or tape_every is not None):
+            # the dual-norm gradient is two forward-tangent chunk launches: it reads neither switch, and a caller who sets one expects the
+            # primal-norm gradient they configure (this used to be ignored silently)
+            raise ValueError("CathodeUQ: grad_mode / tape_every configure the primal-norm gradient (adjoint tape, forward tangents); they have no "
+                             "effect on the dual-norm gradient that is the default here -- pass errnorm_sens=0 with them")
         self.cfg = CathodeConfig()
         check(lib.crnn_cathode_config_default(C.byref(self.cfg)))
         self.cfg.device = device

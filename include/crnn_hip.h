@@ -44,7 +44,8 @@ extern "C" {
 /* v4 (round 4): + crnn_cathode_set_solver, crnn_cathode_set_errnorm_sens, crnn_cathode_last_chunk_stats; crnn_cathode_set_tape_every
  * takes 2; CRNN_SOLVER_AUTOTSIT5 is accepted on the HyChem preset; the lb of the case1 / case2 presets is the Float32 value.  No
  * struct layout changed. */
-#define CRNN_ABI_VERSION 4
+/* v5 (round 6): + crnn_tape_retries (added in round 5 without a bump), crnn_hychem_block_cap.  No struct layout changed. */
+#define CRNN_ABI_VERSION 5
 #define CRNN_MAX_N 12   /* max ODE states  */
 #define CRNN_MAX_NR 16  /* max reactions   */
 
@@ -109,10 +110,13 @@ typedef struct crnn_config {
                                      reference's own composite, the partials in both algorithms' norms (:29).  crnn_solve then
                                      treats its n_dir directions as ONE chunk (n_dir <= 9 case2, 12 case1 / robertson / HyChem);
                                      crnn_loss_grad / crnn_train_step run ForwardDiff's chunks, loss and statistics from a
-                                     final plain solve.  The squared norm is divided by length(u) -- DiffEqBase of the Julia-1.6
-                                     era the reference's README names for case1 / case2 / robertson.  2: the same with
-                                     totallength(u) = n (1 + partials per Dual) as divisor, the form later DiffEqBase versions
-                                     use (the reference pins no version for these scripts: pick the one your Manifest has). */
+                                     final plain solve.  The squared norm is divided by length(u) (early DiffEqBase 6).  2: the
+                                     same with totallength(u) = n (1 + partials per Dual) as divisor.  The reference pins no
+                                     DiffEqBase version for case1 / case2 / robertson / HyChem, but its case2 checkpoint says
+                                     which form ran: replaying the recorded training history from the script's seeded RNG stream
+                                     lands within 5e-4 per epoch with mode 2 and 1e-2 off with mode 1
+                                     (tests/test_case2_stream_pin.py); the cathode Manifest pins a version with form 2 as well.
+                                     Use 2 to reproduce the reference. */
     int32_t device;               /* HIP device ordinal */
     int32_t cols_per_lane;        /* kernel tuning: tangent columns per lane, 0 = auto */
     int32_t solver;               /* CRNN_SOLVER_*; set it with crnn_config_set_solver (also sets the controller) */
@@ -231,9 +235,13 @@ int32_t crnn_ctx_set_lanes_per_traj(crnn_ctx *ctx, int32_t lanes);
 int32_t crnn_last_lanes_per_traj(const crnn_ctx *ctx);
 /* HyChem: gradient launches this context had to repeat with fewer resident trajectories because a trajectory accepted more steps than
  * its share of the adjoint tape holds (tape sized automatically, crnn_config.tape_steps = 0).  The width that fitted is remembered for
- * calls of the same shape, so a count that keeps growing from call to call says the tape budget is too small for this ensemble: set
- * crnn_config.tape_steps.  0 if it never happened; -1 for a null ctx. */
+ * calls of the same shape (and re-probed: crnn_hychem_block_cap), so a count that grows by more than one in 16 calls says the tape budget is
+ * too small for this ensemble: set crnn_config.tape_steps.  0 if it never happened; -1 for a null ctx. */
 int64_t crnn_tape_retries(const crnn_ctx *ctx);
+/* HyChem: the resident-block limit gradient launches over the last overflowing range currently start from (0: none, full width; -1 for a
+ * null ctx).  It is only a starting point: every 16th launch served from it tries four times the width again, so a limit set by one hard
+ * parameter vector does not outlive it; crnn_ctx_set_data clears it. */
+int32_t crnn_hychem_block_cap(const crnn_ctx *ctx);
 /* Jacobian behind W = I - gam J of the Rosenbrock23 stepper in PRIMAL launches (crnn_solve with n_dir = 0: predict_neuralode,
  * loss_neuralode, the epoch-end loop).  ANALYTIC (default): the exact J -- what Rosenbrock23(autodiff = true) forms
  * (robertson/rober_crnn.jl:33).  FINITE_DIFF: what Rosenbrock23(autodiff = false) forms (the stiff algorithm inside case2's
@@ -436,8 +444,12 @@ int32_t crnn_cathode_set_solver(crnn_cathode_ctx *ctx, int32_t solver);
  * / length(u); mode 2: / totallength(u), the form of the DiffEqBase 6.189 this project's Manifest pins).  p_scales[17] = d theta / d p
  * (network.jl:152-157): the partials in the norm are those with respect to p.  mode != 0: a gradient call = two chunk launches
  * (forward tangents through every attempt, Rosenbrock23: cathode_sens_kernel.hpp) + the plain solve whose loss / curves / return
- * codes it reports; the gradient is still returned with respect to theta.  mode 0 (default): primal-only norm, discrete adjoint
- * (about three times faster; the two gradients differ by up to a few 1e-3 of their largest entry at reltol 1e-3).
+ * codes it reports; the gradient is still returned with respect to theta.  mode 0 (the default OF THIS C ABI: a context that was never
+ * told otherwise): primal-only norm, discrete adjoint (about 2.2 times faster; the two gradients differ by a few 1e-3 of their largest entry
+ * at reltol 1e-3 on most trajectories, and by orders of magnitude on a few per cent of a particle cloud: profiles/r04m, r05c).  The host
+ * mirrors of the reference surface (crnn_amd.CathodeUQ, CRNNHip.jl's Cathode) call this with mode 2 in their constructors -- `dlnprob`
+ * there is the reference's gradient unless the caller passes errnorm_sens = 0; crnn_cathode_config.grad_mode and
+ * crnn_cathode_set_tape_every configure the mode-0 gradient only, and the mirrors refuse them together with mode != 0.
  * crnn_cathode_last_chunk_stats: {accepted, rejected} steps summed over the trajectories, for chunk 1 and chunk 2 of the last call. */
 int32_t crnn_cathode_set_errnorm_sens(crnn_cathode_ctx *ctx, int32_t mode, const double *p_scales /* [17] */);
 int32_t crnn_cathode_last_chunk_stats(crnn_cathode_ctx *ctx, int64_t *out /* [4] */);

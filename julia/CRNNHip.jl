@@ -67,8 +67,9 @@ function ODEProblem(preset::Integer, tsteps::AbstractVector; atol=nothing, rtol=
         cfg = deepcopy(cfg)            # a second context with the same problem constants (predict_neuralode's one-IC context)
     end
     # errnorm_sens = 1: the step-size controller sees ForwardDiff's dual-inclusive error norm, i.e. a gradient call
-    # takes the step sequence `ForwardDiff.gradient` through the adaptive solver takes (the reference-faithful mode;
-    # squared norm / length(u), DiffEqBase of the Julia-1.6 era).  errnorm_sens = 2: / totallength(u), later DiffEqBase.
+    # takes the step sequence `ForwardDiff.gradient` through the adaptive solver takes; squared norm / length(u) (early DiffEqBase 6).
+    # errnorm_sens = 2: / totallength(u) -- the form the reference's case2 checkpoint history was recorded with (tests/test_case2_stream_pin.py)
+    # and the cathode Manifest pins: the reference-faithful mode.
     errnorm_sens === nothing || (cfg.errnorm_sens = errnorm_sens)
     alg === nothing || check(ccall((:crnn_config_set_solver, LIB), Int32, (Ref{Config}, Int32), cfg, alg))   # also sets the PI exponents
     cfg.n_save = length(tsteps); cfg.device = device
@@ -111,6 +112,7 @@ set_queue_order!(prob::Problem, order::Integer) =
 smaller than the chip, e.g. one GPU's share of a strongly-scaled batch)."""
 last_lanes_per_traj(prob::Problem) = ccall((:crnn_last_lanes_per_traj, LIB), Int32, (Ptr{Cvoid},), prob.ctx)
 tape_retries(prob::Problem) = ccall((:crnn_tape_retries, LIB), Int64, (Ptr{Cvoid},), prob.ctx)
+hychem_block_cap(prob::Problem) = ccall((:crnn_hychem_block_cap, LIB), Int32, (Ptr{Cvoid},), prob.ctx)
 set_lanes_per_traj!(prob::Problem, lanes::Integer) =
     check(ccall((:crnn_ctx_set_lanes_per_traj, LIB), Int32, (Ptr{Cvoid}, Int32), prob.ctx, Int32(lanes)), prob.ctx)
 
@@ -405,7 +407,7 @@ for `crnn_config` / `crnn_stats` / `crnn_opt_config` / `crnn_cathode_config`).  
 the binary was compiled from (`"src=<16 hex digits> arch=gfx950"`)."""
 function check_abi()
     v = ccall((:crnn_abi_version, LIB), Int32, ())
-    v == 4 || error("libcrnn_hip.so has ABI version $v, CRNNHip.jl is written against 4")
+    v == 5 || error("libcrnn_hip.so has ABI version $v, CRNNHip.jl is written against 5")
     for (which, T) in ((0, Config), (1, Stats), (2, OptConfig), (3, CathodeConfig))
         n = ccall((:crnn_sizeof, LIB), Int32, (Int32,), Int32(which))
         n == sizeof(T) || error("sizeof mismatch for $T: library $n, Julia mirror $(sizeof(T))")

@@ -669,10 +669,10 @@ static int solve_one_ws(const orc_problem *pb, const double *th, const double *d
                     double sc = pb->atol[i] + pb->rtol[i] * sqrt(fmax(na, nb));
                     ssum += ee / (sc * sc);
                 }
-                /* errnorm_sens 1: sqrt(sum(sse, u) / length(u)) -- DiffEqBase of the Julia-1.6 era (case1, case2, robertson name no
-                   versions: README.md:15-21); 2: / totallength(u) = n (1 + partials per Dual), the form later DiffEqBase
-                   versions use (the cathode Manifest pins 6.189).  P counts every partial of the Dual: a caller passes the
-                   zero-padded directions of ForwardDiff's last chunk too. */
+                /* errnorm_sens 1: sqrt(sum(sse, u) / length(u)) (early DiffEqBase 6); 2: / totallength(u) = n (1 + partials per Dual)
+                   (the cathode Manifest pins 6.189, which has it; case1, case2, robertson name no versions, README.md:15-21, but the case2
+                   checkpoint's recorded history is reproduced with 2 and not with 1: tests/test_case2_stream_pin.py).  P counts every
+                   partial of the Dual: a caller passes the zero-padded directions of ForwardDiff's last chunk too. */
                 EEst = sqrt(ssum / (pb->errnorm_sens == 2 ? (double)n * (1.0 + (double)P) : (double)n));
                 if (!isfinite(EEst)) { retcode = 3; break; }
                 accept = (EEst <= 1.0);
@@ -875,10 +875,7 @@ static int solve_one_tsit5(const orc_problem *pb, const double *th, const double
                     double sc = pb->atol[i] + pb->rtol[i] * sqrt(fmax(na, nb));
                     ssum += ee / (sc * sc);
                 }
-                /* errnorm_sens 1: sqrt(sum(sse, u) / length(u)) -- DiffEqBase of the Julia-1.6 era (case1, case2, robertson name no
-                   versions: README.md:15-21); 2: / totallength(u) = n (1 + partials per Dual), the form later DiffEqBase
-                   versions use (the cathode Manifest pins 6.189).  P counts every partial of the Dual: a caller passes the
-                   zero-padded directions of ForwardDiff's last chunk too. */
+                /* errnorm_sens 1 / 2: as in the Rosenbrock23 stepper above (the recorded case2 history selects 2) */
                 EEst = sqrt(ssum / (pb->errnorm_sens == 2 ? (double)n * (1.0 + (double)P) : (double)n));
                 if (!isfinite(EEst)) { retcode = 3; break; }
                 accept = (EEst <= 1.0);

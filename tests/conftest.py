@@ -18,8 +18,10 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "cpu_only: a stand-in for the device (the SIMT emulation sample) -- pointless where the device itself runs the same tests")
 
 
-def _gpu_present():
-    if os.environ.get("CRNN_TEST_ASSUME_GPU") == "1":     # collection checks only (tests/test_host.py: the order of a device session)
+def _gpu_present(config=None):
+    # CRNN_TEST_ASSUME_GPU=1: collection checks only (tests/test_host.py: the order of a device session) -- honoured with --collect-only and
+    # nowhere else, so a stray variable cannot mark every test `gpu` on a CPU box
+    if os.environ.get("CRNN_TEST_ASSUME_GPU") == "1" and config is not None and getattr(config.option, "collectonly", False):
         return True
     try:
         import torch
@@ -39,7 +41,7 @@ def pytest_collection_modifyitems(config, items):
         for it in items:
             if it.get_closest_marker("timeout") is None:
                 it.add_marker(pytest.mark.timeout(900))
-    if not _gpu_present():
+    if not _gpu_present(config):
         return
     for it in items:
         if it.get_closest_marker("gpu") is None and it.get_closest_marker("needs_reference") is None and it.get_closest_marker("cpu_only") is None:

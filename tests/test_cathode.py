@@ -120,6 +120,16 @@ def test_gpu_svgd_update_matches_oracle(orc, N, dim):
     assert h2 == 0.37 and np.max(np.abs(p2 - orc.svgd_update(p, g, 0.01, h=0.37)[0])) < 1e-13
 
 
+def test_cathode_host_refuses_switches_the_default_gradient_would_ignore(cfx):
+    """CathodeUQ's default gradient is the dual-norm one (errnorm_sens = 2), which reads neither grad_mode nor tape_every; a caller
+    who sets them gets an error (before any device call), not a silently different gradient."""
+    from crnn_amd.cathode import CathodeUQ
+    args = ([np.zeros((4, 2))], [2.0], np.ones(17))
+    for kw in (dict(grad_mode=1), dict(tape_every=4), dict(grad_mode=2, tape_every=1)):
+        with pytest.raises(ValueError, match="errnorm_sens=0"):
+            CathodeUQ(*args, **kw)
+
+
 def test_cathode_config_abi():
     import ctypes as C
     from crnn_amd import _lib as L

@@ -50,7 +50,7 @@ def test_chunked_dual_norm_gradient_matches_oracle(orc, fx, case2_setup, rober_s
     from crnn_amd.api import fd_chunk_size
     s, mk, (kind, ns, nr), mkpb = _setup(case, case2_setup, rober_setup, fx)
     p = s[pkey]
-    # mode 1: squared norm / length(u) (DiffEqBase of the Julia-1.6 era); mode 2: / totallength(u) = n (1 + partials per Dual)
+    # mode 1: squared norm / length(u); mode 2: / totallength(u) = n (1 + partials per Dual) -- the one the reference's recorded history selects
     node = mk(errnorm_sens=mode)
     node.set_ensemble(s["u0"], s["data"], s["yscale"])
     th, dth = orc.p2vec(kind, ns, nr, p)

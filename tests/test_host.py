@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, n), f"{n} declared in crnn_hip.h but not exported"
         assert n in L.SYMBOLS, f"{n} not bound in crnn_amd/_lib.py"
     assert set(L.SYMBOLS) == names
-    assert raw.crnn_abi_version() == 4
+    assert raw.crnn_abi_version() == 5
 
 
 def test_header_is_plain_c99(tmp_path):

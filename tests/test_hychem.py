@@ -550,10 +550,10 @@ def test_hychem_oracle_gradient_through_the_reference_composite(orc, hfx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [1, 2])
-def test_gpu_hychem_errnorm_sens_matches_oracle_chunk_for_chunk(orc, hfx, mode):
-    """crnn_config.errnorm_sens on the HyChem preset (hychem_sens_kernel: a group of twelve lanes per trajectory, the tangents through
-    every attempt by nested dual numbers) against the oracle's chunked complex-step solves: the same step sequence (accepted / rejected
+@pytest.mark.parametrize("mode,kernel", [(1, "1"), (2, "2")])
+def test_gpu_hychem_errnorm_sens_matches_oracle_chunk_for_chunk(orc, hfx, mode, kernel, monkeypatch):
+    """crnn_config.errnorm_sens on the HyChem preset (mode 1 on hychem_sens_kernel, the default: a group of twelve lanes per trajectory, the
+    tangents through every attempt by nested dual numbers; mode 2 on hychem_sens2_kernel, CRNN_HY_SENS_KERNEL=2: sparse directions) against the oracle's chunked complex-step solves: the same step sequence (accepted / rejected
     counts) and gradient pieces to 1e-6 of the largest entry in every chunk that is well-conditioned by the oracle's own measure; the batched call (crnn_loss_grad) assembles
     the same pieces; loss and step statistics of a gradient call are the plain solve's."""
     from crnn_amd import p2vec_jac
@@ -562,6 +562,7 @@ def test_gpu_hychem_errnorm_sens_matches_oracle_chunk_for_chunk(orc, hfx, mode):
     u0 = np.concatenate([hfx["u0"], hfx["u0"][2:3], u0c[None]]); data = np.concatenate([hfx["data"], 0.9 * hfx["data"][0:1], 1.1 * hfx["data"][1:2]])
     Tt = np.concatenate([hfx["Ttab"], hfx["Ttab"][2:3], hfx["Ttab"][2:3]]); Pt = np.concatenate([hfx["Ptab"], hfx["Ptab"][2:3], hfx["Ptab"][2:3]])
     B = u0.shape[0]
+    monkeypatch.setenv("CRNN_HY_SENS_KERNEL", kernel)          # read at crnn_ctx_create
     node = _node(hfx, u0, data, Tt, Pt, errnorm_sens=mode)
     plain = _node(hfx, u0, data, Tt, Pt)
     p = hfx["p"]
@@ -633,7 +634,7 @@ def test_gpu_hychem_sparse_direction_kernel_equals_the_dense_one_and_dense_direc
     Tt = np.repeat(hfx["Ttab"][2:3], 7, axis=0) * (1 + 0.01 * rng.standard_normal((7, 1))); Pt = np.repeat(hfx["Ptab"][2:3], 7, axis=0)
     p = hfx["p"]
     res = {}
-    for name, env in (("sparse", "0"), ("dense", "1")):
+    for name, env in (("sparse", "2"), ("dense", "1")):
         monkeypatch.setenv("CRNN_HY_SENS_KERNEL", env)
         node = _node(hfx, u0, data, Tt, Pt, errnorm_sens=2)
         g0 = node.gradient(p, 0)
@@ -645,8 +646,8 @@ def test_gpu_hychem_sparse_direction_kernel_equals_the_dense_one_and_dense_direc
     assert ss == sd and len(ss) == 18
     assert np.max(np.abs(gs - gd)) < 1e-7 * np.max(np.abs(gd))
     assert Ls == Ld and np.max(np.abs(Gs - Gd)) < 1e-7 * np.max(np.abs(Gd))
-    # dense directions: one chunk of twelve random rows
-    monkeypatch.setenv("CRNN_HY_SENS_KERNEL", "0")
+    # dense directions: one chunk of twelve random rows, with the sparse kernel asked for
+    monkeypatch.setenv("CRNN_HY_SENS_KERNEL", "2")
     th, dth = orc.hychem_p2vec(p)
     rng = np.random.default_rng(4)
     dirs = 1e-2 * rng.standard_normal((12, th.size))
@@ -735,8 +736,17 @@ def test_gpu_hychem_tape_overflow_degrades_instead_of_failing(hfx, monkeypatch):
     from crnn_amd import _lib as L_
     emulated = b"SIMT-EMULATION" in L_.lib.crnn_build_info()                       # (the emulated device has two CUs: 256 resident trajectories, no overflow)
     assert (r1 >= 1 or emulated) and ref.tape_retries() == 0                       # crnn_tape_retries: the degradation is visible to the caller
-    l2, g2 = small.loss_and_grad(p)                                                # ... and the width that fitted is remembered:
+    cap1 = small.hychem_block_cap()
+    assert (cap1 >= 1 or emulated) and ref.hychem_block_cap() == 0                 # ... and so is the width that fitted, which is remembered:
+    l2, g2 = small.loss_and_grad(p)
     assert small.tape_retries() == r1 and l2 == l1                                 #     the same call again repeats nothing
+    # ... but not for ever: the 16th launch served from the remembered width tries four times the width again.  Here the
+    # parameters have not moved, so the probe overflows once more and falls back; results stay the same throughout
+    if not emulated:
+        for _ in range(16):
+            lk, gk = small.loss_and_grad(p)
+            assert lk == l1
+        assert r1 < small.tape_retries() <= r1 + 2 and small.hychem_block_cap() >= 1
     small.close()
     hard = _node(hfx, u0, data, Tt, Pt, tape_steps=64)
     with pytest.raises(CrnnError, match="tape"):

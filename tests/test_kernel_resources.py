@@ -1,8 +1,9 @@
-"""Register / scratch / LDS budget of the kernels whose speed depends on them, checked at compile time (no GPU: hipcc cross-compiles gfx950
-and reports every kernel's resources with -Rpass-analysis=kernel-resource-usage).  These kernels run one wavefront per SIMD with a full
+"""Register / scratch / LDS budget of the kernels whose speed depends on them, read from the shipping library's gfx950 code object (no GPU
+needed: the metadata of every kernel the C ABI can launch; an instantiation the library does not hold is compiled on the spot with
+-Rpass-analysis=kernel-resource-usage).  These kernels run one wavefront per SIMD with a full
 register file; a few more live values turn into scratch memory traffic that nothing hides (+40 ... +90 % kernel time), and
 a few more KB of LDS halve the blocks per CU.  Each budget below is what the shipped source compiles to, with the measurement it protects.
-One small translation unit per kernel header (seconds each), the library's flags."""
+"""
 import os
 import re
 import shutil
@@ -18,7 +19,42 @@ HIPCC = "/opt/rocm/bin/hipcc"
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="hipcc not available")
 
 
-def _resources(tmp_path, header, instantiation, flags=()):
+LLVM = "/opt/rocm/lib/llvm/bin"
+_LIB_META = None
+
+
+def _library_kernels():
+    """{demangled name without spaces, up to '(' : resources} of every kernel in the SHIPPING library, read from the gfx950 code object's metadata
+    (.hip_fatbin -> clang-offload-bundler -> llvm-readelf --notes): no compile, and it is the binary that runs.  Built on demand like everywhere
+    else (crnn_amd/_lib.py: rebuilt when the sources' hash differs)."""
+    global _LIB_META
+    if _LIB_META is not None:
+        return _LIB_META
+    import tempfile
+    sys.path.insert(0, ROOT)
+    from crnn_amd import _lib as L
+    so = os.path.join(CSRC, "libcrnn_hip.so")
+    assert f"src={L.source_hash()} " in L.lib.crnn_build_info().decode()       # the library next to the sources is theirs
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "k.co")
+        subprocess.check_call([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", so, os.devnull])
+        subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
+        notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+    ks = []
+    for blk in notes.split("  - .agpr_count:")[1:]:
+        g = lambda key: re.search(r"\." + key + r":\s+(\S+)", blk).group(1)
+        ks.append(dict(mangled=g("name"), agpr=int(blk.split()[0]), total=int(g("vgpr_count")), scratch=int(g("private_segment_fixed_size")),
+                       lds=int(g("group_segment_fixed_size"))))
+    dem = subprocess.run(["c++filt"], input="\n".join(k["mangled"] for k in ks), capture_output=True, text=True, check=True).stdout.splitlines()
+    _LIB_META = {}
+    for k, name in zip(ks, dem):
+        key = name.replace("void ", "", 1).split("(")[0].replace(" ", "")
+        k["vgpr"] = k["total"] - k["agpr"]           # the metadata's .vgpr_count is the unified file's total (architectural + accumulation registers)
+        _LIB_META[key] = k
+    return _LIB_META
+
+
+def _compile_resources(tmp_path, header, instantiation, flags=()):
     src = tmp_path / "tu.hip"
     src.write_text(f'#include "{header}"\ntemplate __global__ void {instantiation};\n')
     cmd = [HIPCC if os.path.exists(HIPCC) else "hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=on", "-I", CSRC,
@@ -33,6 +69,16 @@ def _resources(tmp_path, header, instantiation, flags=()):
             return dict(vgpr=g(r"VGPRs"), agpr=g(r"AGPRs"), scratch=g(r"ScratchSize \[bytes/lane\]"), lds=g(r"LDS Size \[bytes/block\]"),
                         occ=g(r"Occupancy \[waves/SIMD\]"))
     raise AssertionError("kernel not found in the resource report: " + name)
+
+
+def _resources(tmp_path, header, instantiation, flags=()):
+    """Resources of one kernel instantiation: from the shipping library's code object where the library holds it (every instantiation the C ABI
+    can launch: milliseconds), by compiling a one-kernel translation unit with the library's flags otherwise (an experiment's variant; seconds)."""
+    key = instantiation.split("(")[0].replace(" ", "")
+    lib = _library_kernels()
+    if not flags and key in lib:
+        return dict(lib[key], source="library")
+    return dict(_compile_resources(tmp_path, header, instantiation, flags), source="compiled")
 
 
 ADJ = "const crnn::SolveParams, const double*, const crnn::AdjParams"

@@ -36,13 +36,39 @@ def simt_lib():
     return lib
 
 
-def _run(lib, args, timeout=1500):
-    env = dict(os.environ, CRNN_HIP_LIB=lib, SIMT_THREADS=os.environ.get("SIMT_THREADS", "4"))
-    out = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-p", "no:cacheprovider", *args], cwd=ROOT, env=env,
-                         capture_output=True, text=True, timeout=timeout)
-    tail = out.stdout[-3000:] + out.stderr[-2000:]
-    assert out.returncode == 0, tail
-    m = re.search(r"(\d+) passed", out.stdout)
+SAMPLES = {      # child sessions of `-m gpu` parity tests against the emulation library; started together (they are independent processes)
+    "case2_rober": ["tests/test_gpu_parity.py", "-k", "gradient_matches_oracle or adjoint_equals_forward_tangents or tsit5_adjoint_equals"],
+    "lanes2": ["tests/test_gpu_lanes2.py", "-k", "not auto_beyond_one_generation"],
+    "hychem_dual": ["tests/test_hychem.py", "-k",
+                    "(errnorm_sens_matches_oracle_chunk_for_chunk and 2-2) or through_the_reference_composite_matches or sparse_direction_kernel"],
+    "cathode": ["tests/test_cathode.py", "-k", "(errnorm_sens_matches_oracle_chunk_for_chunk and 2) or gradient_through_the_reference_composite"],
+    "case2_stream": ["tests/test_case2_stream_pin.py", "-k", "loss_at_the_checkpoint"],
+}
+
+
+@pytest.fixture(scope="module")
+def samples(simt_lib):
+    """All child sessions at once, two emulation threads each: the wall time of the slowest instead of the sum (the CPU suite's budget)."""
+    env = dict(os.environ, CRNN_HIP_LIB=simt_lib, SIMT_THREADS=os.environ.get("SIMT_THREADS", "2"))
+    procs = {k: subprocess.Popen([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-p", "no:cacheprovider", *a], cwd=ROOT, env=env,
+                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k, a in SAMPLES.items()}
+    res = {}
+    for k, p in procs.items():
+        try:
+            out, err = p.communicate(timeout=1500)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, err = p.communicate()
+            err += "\n[timeout]"
+        res[k] = (p.returncode, out, err)
+    return res
+
+
+def _passed(samples, key):
+    rc, out, err = samples[key]
+    tail = out[-3000:] + err[-2000:]
+    assert rc == 0, tail
+    m = re.search(r"(\d+) passed", out)
     assert m, tail
     return int(m.group(1))
 
@@ -57,26 +83,25 @@ def test_emulated_library_says_what_it_is_and_is_refused_by_the_bench(simt_lib):
     assert out.returncode != 0 and "SIMT emulation" in (out.stderr + out.stdout)
 
 
-def test_case2_and_robertson_kernels_against_the_oracle_under_emulation(simt_lib):
+def test_case2_and_robertson_kernels_against_the_oracle_under_emulation(samples):
     """ros23_adj_kernel / ros23_adj2_kernel (lane pair) / ros23_kernel (forward tangents) / tsit5 / auto_adj: loss 1e-9, gradient 1e-7, step counts."""
-    n = _run(simt_lib, ["tests/test_gpu_parity.py", "-k", "gradient_matches_oracle or adjoint_equals_forward_tangents or tsit5_adjoint_equals"])
-    assert n >= 8
-    n = _run(simt_lib, ["tests/test_gpu_lanes2.py", "-k", "not auto_beyond_one_generation"])
-    assert n >= 4
+    assert _passed(samples, "case2_rober") >= 8
+    assert _passed(samples, "lanes2") >= 4
 
 
-def test_hychem_dual_norm_kernels_against_the_oracle_under_emulation(simt_lib):
+def test_hychem_dual_norm_kernels_against_the_oracle_under_emulation(samples):
     """hychem_sens2_kernel chunk for chunk against the oracle (mode 2), the same through the reference's composite, and equal to the dense kernel."""
-    n = _run(simt_lib, ["tests/test_hychem.py", "-k",
-                        "(errnorm_sens_matches_oracle_chunk_for_chunk and 2) or through_the_reference_composite_matches or sparse_direction_kernel"])
-    assert n == 3
+    assert _passed(samples, "hychem_dual") == 3
 
 
-def test_hychem_finite_difference_jacobian_against_the_oracle_under_emulation(simt_lib):
-    """hychem_auto_kernel<..., JFD>: Rosenbrock23(autodiff=false)'s J and dT (crnn_pyrolysis_mass.jl:29), alone and inside the composite."""
-    assert _run(simt_lib, ["tests/test_hychem.py", "-k", "finite_difference_jacobian_primal"]) == 1
+# (the finite-difference-Jacobian kernels, 70 s under emulation, are part of the whole emulated suite only: tools/simt_suite.sh, profiles/r06b)
 
 
-def test_cathode_chunked_gradient_against_the_oracle_under_emulation(simt_lib):
-    n = _run(simt_lib, ["tests/test_cathode.py", "-k", "(errnorm_sens_matches_oracle_chunk_for_chunk and 2) or gradient_through_the_reference_composite"])
-    assert n == 2
+def test_cathode_chunked_gradient_against_the_oracle_under_emulation(samples):
+    assert _passed(samples, "cathode") == 2
+
+
+def test_case2_recorded_checkpoint_loss_under_emulation(samples):
+    """The product's loss at the reference's checkpoint on the experiments re-drawn from the reference's RNG stream equals the number the
+    reference recorded (tests/test_case2_stream_pin.py), Tsit5 / AutoTsit5 / Rosenbrock23 kernels."""
+    assert _passed(samples, "case2_stream") == 1

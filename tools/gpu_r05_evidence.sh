@@ -31,7 +31,7 @@ if ls $R/crnn_amd/csrc/dbg/libcrnn_kv_r5start.so > /dev/null 2>&1; then
   done; done; done > $O/ab_seeds.txt 2>&1; cat $O/ab_seeds.txt
 fi
 for n in 1024 4096 32768; do
-  echo "sparse $n"; timeout 600 python tools/hy_sens_time.py $n
+  echo "sparse $n"; CRNN_HY_SENS_KERNEL=2 timeout 600 python tools/hy_sens_time.py $n
   if [ $n -le 4096 ]; then echo "dense $n"; CRNN_HY_SENS_KERNEL=1 timeout 900 python tools/hy_sens_time.py $n; fi
 done > $O/ab_hychem_sens.txt 2>&1; cat $O/ab_hychem_sens.txt | cut -c1-200
 # 5. fuzz sweeps on the tree that ships
