@@ -147,21 +147,33 @@ def hychem(B=32768, reps=4, device=0):
             extra4["primal_autotsit5_kernel_ms"] = _primal_ms(comp, p, 3)
             extra4["primal_autotsit5_steps_per_traj"] = comp.last_stats["n_accept"] / B
             comp.close()
-            # the reference-faithful gradient (errnorm_sens = 2): round 5's hychem_sens2_kernel (sparse directions) at 1 024 ICs -- the size round 4's
-            # nested-dual kernel was quoted on (522.8 ms, 1 959 /s: profiles/r04i) -- and at the whole share
-            for n in (1024, B):
-                sens = NeuralODE(ODEProblem(PRESET_HYCHEM, ts, rate_scale=hy.DYDT_SCALE, device=device, errnorm_sens=2))
-                sens.set_ensemble(u0[:n], data[:n], ys); sens.set_tables(Tt[:n], Pt[:n])
-                sens.loss_and_grad(p)
-                t0 = time.perf_counter(); sens.loss_and_grad(p); w = (time.perf_counter() - t0) * 1e3
-                sens.close()
-                tag = "B1024" if n == 1024 else f"B{n}"
-                extra4[f"errnorm_sens2_{tag}_call_ms"] = w
-                extra4[f"errnorm_sens2_{tag}_value"] = n / (w * 1e-3)
-            extra4["errnorm_sens2_value"] = extra4[f"errnorm_sens2_B{B}_value"]
+            # the reference-faithful gradient (errnorm_sens = 2).  Two kernels (crnn_capi.hip launch_hychem_sens_chunk): the dense-direction
+            # hychem_sens_kernel is the library's default until a device session has passed the sparse kernel's parity tests; round 5's
+            # hychem_sens2_kernel (sparse directions) is asked for with CRNN_HY_SENS_KERNEL=2 (read at crnn_ctx_create).  1 024 ICs -- the size
+            # round 4's nested-dual kernel was quoted on (522.8 ms, 1 959 /s: profiles/r04i) -- for both, the whole share for the sparse one
+            import os
+            for kern, sizes in (("dense", (1024,)), ("sparse", (1024, B))):
+                for n in sizes:
+                    old_env = os.environ.get("CRNN_HY_SENS_KERNEL")
+                    os.environ["CRNN_HY_SENS_KERNEL"] = "2" if kern == "sparse" else "1"
+                    try:
+                        sens = NeuralODE(ODEProblem(PRESET_HYCHEM, ts, rate_scale=hy.DYDT_SCALE, device=device, errnorm_sens=2))
+                    finally:
+                        if old_env is None:
+                            os.environ.pop("CRNN_HY_SENS_KERNEL", None)
+                        else:
+                            os.environ["CRNN_HY_SENS_KERNEL"] = old_env
+                    sens.set_ensemble(u0[:n], data[:n], ys); sens.set_tables(Tt[:n], Pt[:n])
+                    sens.loss_and_grad(p)
+                    t0 = time.perf_counter(); sens.loss_and_grad(p); w = (time.perf_counter() - t0) * 1e3
+                    sens.close()
+                    extra4[f"errnorm_sens2_{kern}_B{n}_call_ms"] = w
+                    extra4[f"errnorm_sens2_{kern}_B{n}_value"] = n / (w * 1e-3)
+            extra4["errnorm_sens2_value"] = extra4[f"errnorm_sens2_sparse_B{B}_value"]
             extra4["errnorm_sens_note"] = ("crnn_config.errnorm_sens = 2 on the HyChem preset: ForwardDiff's 18 chunks of 12 partials, each its own "
-                                           "adaptive solve with the partials in the error norm (hychem_sens2_kernel: sparse directions, closed-form "
-                                           "tangents, one column per lane) + the plain solve; wall time of one loss+gradient call")
+                                           "adaptive solve with the partials in the error norm + the plain solve; wall time of one loss+gradient call. "
+                                           "dense = hychem_sens_kernel (library default), sparse = hychem_sens2_kernel (CRNN_HY_SENS_KERNEL=2: sparse "
+                                           "directions, closed-form tangents, one column per lane)")
       except Exception as e:  # noqa: BLE001  (these kernels are round 4 / 5 additions: their failure must not take the adjoint figures of the entry along)
         extra4["extras_error"] = f"{type(e).__name__}: {e}"[:500]
     return _entry("hychem", B, kms, st, {**extra4, "primal_kernel_ms": prim, "workload": "HyChem pyrolysis CRNN, 32 768 ICs (one GPU's share of 262 144), T(t)/P(t) tables, "
