@@ -1352,6 +1352,7 @@ static int solve_dispatch(const orc_problem *pb, const double *th, const double 
                           double *loss_out, double *grad, int32_t *n_saved_out, orc_stats *st, double *ws) {
     if (pb->jac_fd && pb->solver != 0) return -7;   /* the finite-difference W is restated for plain Rosenbrock23 (primal solves and forward tangents) */
     if (pb->jac_fd) return solve_one_ws(pb, th, dth, P, u0, tsave, nsave, data, pred, dpred, loss_out, grad, n_saved_out, st, ws);   /* never the analytic-J adjoint */
+    if (pb->solver == 2 && pb->errnorm_sens && P > 0) return -8;   /* the CRNN composite below carries tangents on accepted steps only: no dual norm (it used to be ignored silently; case2's composite IS Tsit5 -- solver 1 -- see solve_one_auto's header) */
     if (pb->solver == 2) return solve_one_auto(pb, th, dth, P, u0, tsave, nsave, data, pred, dpred, loss_out, grad, n_saved_out, st, ws, NULL);
     if (pb->solver == 1) return solve_one_tsit5(pb, th, dth, P, u0, tsave, nsave, data, pred, dpred, loss_out, grad, n_saved_out, st, ws);
     if (pb->grad_adjoint && P > 0 && !pb->errnorm_sens && !dpred)
@@ -1368,6 +1369,7 @@ int orc_solve_one_auto(const orc_problem *pb, const double *th, const double *dt
     double *ws = P > 0 ? (double *)malloc(sizeof(double) * ((size_t)n * P * 9 + P)) : NULL;
     if (st_alg) st_alg[0] = st_alg[1] = st_alg[2] = 0;
     if (pb->jac_fd) { free(ws); return -7; }   /* the composite's stiff branch is restated with the analytic J only */
+    if (pb->errnorm_sens && P > 0) { free(ws); return -8; }   /* as in solve_dispatch */
     int rc = solve_one_auto(pb, th, dth, P, u0, tsave, nsave, data, pred, dpred, loss_out, grad, n_saved_out, st, ws, st_alg);
     free(ws);
     return rc;

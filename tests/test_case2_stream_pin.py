@@ -176,6 +176,18 @@ def test_replay_discriminates_the_error_norm(orc, sfx):
     assert _rel(h0[1, 0], rec["l_loss_train_head"][1]) > 3e-2, h0
 
 
+def test_oracle_composite_refuses_the_dual_norm_instead_of_ignoring_it(orc, sfx):
+    """oracle solver 2 (the CRNN composite) propagates tangents on accepted steps only; until round 6 it returned the primal-norm gradient when
+    asked for errnorm_sens (which is how the replay first went wrong).  It now says so: return code -8, like the product's crnn_ctx_create."""
+    des = sfx["des"]
+    pb = _oracle_problem(orc, des, solver=2, errnorm_sens=2)
+    th, dth = orc.p2vec(2, 6, 3, des["p0"])
+    o = orc.solve_one(pb, th, des["u0"][0], des["ts"], des["data"][0], dtheta=dth[:, :9], want_pred=False)
+    assert o["retcode"] == -8
+    o = orc.solve_one(_oracle_problem(orc, des, solver=2), th, des["u0"][0], des["ts"], des["data"][0], dtheta=dth[:, :9], want_pred=False)
+    assert o["retcode"] == 0 and o["n_rosenbrock"] == 0          # ... and the composite never leaves Tsit5 on case2 (constant temperature component)
+
+
 # ------------------------------------------------------------------ product (-m gpu)
 def _node(des, **kw):
     from crnn_amd import NeuralODE, ODEProblem, PRESET_CASE2

@@ -54,6 +54,34 @@ def _library_kernels():
     return _LIB_META
 
 
+def test_sgpr_literal_constants_are_formed_low_word_first_in_the_shipping_isa(tmp_path):
+    """CRNN_SCONST (ros23_kernel.hpp:158-166): a double formed where it is used by two `s_mov_b32` with literals inside an asm statement -- the one
+    piece of the kernels the SIMT emulation drops, and (round 5 form) not yet executed by a device.  What can be checked without one: in the
+    shipping code object every such constant of fexp_ctl / flog_ctl appears as `s_mov_b32 sN, <low word>` directly followed by
+    `s_mov_b32 sM, <high word>` (low word into the first output, high word into the second -- the order `sconst_bits` reassembles them in),
+    and never in another order."""
+    import struct
+    so = os.path.join(CSRC, "libcrnn_hip.so")
+    _library_kernels()                                         # (asserts that the library is the sources')
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "k.co")
+    subprocess.check_call([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", so, os.devnull])
+    subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
+    isa = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--mcpu=gfx950", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
+    src = open(os.path.join(CSRC, "ros23_kernel.hpp")).read()
+    body = src[src.index("double fexp_ctl(double x)"):src.index("double z = __builtin_amdgcn_ldexp(p, (int)dn);")] + src[src.index("double flog_ctl(double x)"):src.index("double fexp_ctl(double x)")]
+    consts = [float.fromhex(c) if c.startswith("0x") else float(c) for c in re.findall(r"CRNN_SCONST\(([^)]+)\)", body)]
+    assert len(consts) >= 14, consts
+    for c in consts:
+        b = struct.unpack("<Q", struct.pack("<d", c))[0]
+        lo, hi = b & 0xffffffff, b >> 32
+        lit = lambda w: (f"0x{w:x}" if w > 64 else str(w))     # (the assembler prints small values as inline constants)
+        pairs = re.findall(r"s_mov_b32 s(\d+), %s\b[^\n]*\n\s*s_mov_b32 s(\d+), %s\b" % (lit(lo), lit(hi)), isa)
+        assert pairs, (c, hex(lo), hex(hi))
+        # (the two outputs are independent 32-bit SGPRs: the compiler usually allocates an aligned pair and otherwise moves them into one.  The
+        #  same coefficients also occur in exponentials that do not use CRNN_SCONST, where the compiler forms them itself in any order; so the
+        #  statement is existence of the asm's own two-move form, low word first)
+
+
 def _compile_resources(tmp_path, header, instantiation, flags=()):
     src = tmp_path / "tu.hip"
     src.write_text(f'#include "{header}"\ntemplate __global__ void {instantiation};\n')
