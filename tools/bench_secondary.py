@@ -338,6 +338,15 @@ def run_all(u0, data, yscale, device=0, out_path=None):
                                                             "non-stiff; case1's Tsit5()): tsit5_sens_kernel"}, reps=3, errnorm_sens=1, solver=SOLVER_TSIT5))
     if "error" not in sec.get("case2_errnorm_sens1_tsit5", {"error": 1}):
         sec["case2_errnorm_sens1_tsit5"]["value"] = B / (sec["case2_errnorm_sens1_tsit5"]["call_ms"] * 1e-3)
+    # what the reference's recorded case2 history was computed with (tests/test_case2_stream_pin.py): Tsit5 -- its AutoTsit5(Rosenbrock23) never
+    # switches -- and the dual norm divided by totallength(u)
+    put("case2_reference_gradient_tsit5_errnorm_sens2", lambda: case2_fixed(u0, data, yscale, ck, {
+        "workload": note.replace("Rosenbrock23", "Tsit5") + "the gradient exactly as the reference's training run evaluated it: ForwardDiff's chunks 9 + 9 + 7, "
+                    "every chunk its own adaptive Tsit5 solve with the partials in the error norm / totallength(u) (errnorm_sens = 2; the mode that "
+                    "reproduces the recorded training history), + the plain solve for the loss: tsit5_sens_kernel; call_ms is the whole call"},
+        reps=3, errnorm_sens=2, solver=SOLVER_TSIT5))
+    if "error" not in sec.get("case2_reference_gradient_tsit5_errnorm_sens2", {"error": 1}):
+        sec["case2_reference_gradient_tsit5_errnorm_sens2"]["value"] = B / (sec["case2_reference_gradient_tsit5_errnorm_sens2"]["call_ms"] * 1e-3)
     progress("case2 strong-scaling shares (8 192 / 16 384 / 32 768 of the 65 536)")
     for nb in (8192, 16384, 32768):
         put(f"case2_B{nb}_share", lambda: case2_fixed(u0[:nb], data[:nb], yscale, ck, {
