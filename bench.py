@@ -87,7 +87,7 @@ def parse():
                          "chosen, the other mode is timed too (same K, W) and reported under 'other_scaling' when N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (other configs / regimes, N = 1 only)")
-    ap.add_argument("--secondary-seconds", type=float, default=900.0, help="wall-clock limit of the child process that measures the secondary figures")
+    ap.add_argument("--secondary-seconds", type=float, default=420.0, help="wall-clock limit of the child process that measures the secondary figures")
     ap.add_argument("--cpu-sample", type=int, default=65536)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall time to spend on the CPU baseline")
     return ap.parse_args()

@@ -120,7 +120,7 @@ def robertson(B=65536, reps=6, device=0):
                                             "kernel": "ros23_adj_kernel<3,6,scaled>"}, wall, traffic_key="robertson_B65536" if B == 65536 else None)
 
 
-def hychem(B=32768, reps=4, device=0):
+def hychem(B=32768, reps=4, device=0, unproven=False):
     """BASELINE config 4, one GPU's share (262 144 / 8): HyChem pyrolysis CRNN, 9 species, 10 reactions, P = 211."""
     from crnn_amd import NeuralODE, ODEProblem, PRESET_HYCHEM, hychem as hy
     rng = np.random.Generator(np.random.PCG64([1234, 4]))
@@ -141,39 +141,41 @@ def hychem(B=32768, reps=4, device=0):
     extra4 = {}
     if B == 32768:      # round 4: the reference's composite for primal launches; the gradient as ForwardDiff evaluates it (1 024 of the ICs)
       try:
+        if not unproven:
             from crnn_amd import SOLVER_AUTOTSIT5
             comp = NeuralODE(ODEProblem(PRESET_HYCHEM, ts, rate_scale=hy.DYDT_SCALE, device=device, solver=SOLVER_AUTOTSIT5))
             comp.set_ensemble(u0, data, ys); comp.set_tables(Tt, Pt)
             extra4["primal_autotsit5_kernel_ms"] = _primal_ms(comp, p, 3)
             extra4["primal_autotsit5_steps_per_traj"] = comp.last_stats["n_accept"] / B
             comp.close()
-            # the reference-faithful gradient (errnorm_sens = 2).  Two kernels (crnn_capi.hip launch_hychem_sens_chunk): the dense-direction
-            # hychem_sens_kernel is the library's default until a device session has passed the sparse kernel's parity tests; round 5's
-            # hychem_sens2_kernel (sparse directions) is asked for with CRNN_HY_SENS_KERNEL=2 (read at crnn_ctx_create).  1 024 ICs -- the size
-            # round 4's nested-dual kernel was quoted on (522.8 ms, 1 959 /s: profiles/r04i) -- for both, the whole share for the sparse one
-            import os
-            for kern, sizes in (("dense", (1024,)), ("sparse", (1024, B))):
-                for n in sizes:
-                    old_env = os.environ.get("CRNN_HY_SENS_KERNEL")
-                    os.environ["CRNN_HY_SENS_KERNEL"] = "2" if kern == "sparse" else "1"
-                    try:
-                        sens = NeuralODE(ODEProblem(PRESET_HYCHEM, ts, rate_scale=hy.DYDT_SCALE, device=device, errnorm_sens=2))
-                    finally:
-                        if old_env is None:
-                            os.environ.pop("CRNN_HY_SENS_KERNEL", None)
-                        else:
-                            os.environ["CRNN_HY_SENS_KERNEL"] = old_env
-                    sens.set_ensemble(u0[:n], data[:n], ys); sens.set_tables(Tt[:n], Pt[:n])
-                    sens.loss_and_grad(p)
-                    t0 = time.perf_counter(); sens.loss_and_grad(p); w = (time.perf_counter() - t0) * 1e3
-                    sens.close()
-                    extra4[f"errnorm_sens2_{kern}_B{n}_call_ms"] = w
-                    extra4[f"errnorm_sens2_{kern}_B{n}_value"] = n / (w * 1e-3)
-            extra4["errnorm_sens2_value"] = extra4[f"errnorm_sens2_sparse_B{B}_value"]
-            extra4["errnorm_sens_note"] = ("crnn_config.errnorm_sens = 2 on the HyChem preset: ForwardDiff's 18 chunks of 12 partials, each its own "
-                                           "adaptive solve with the partials in the error norm + the plain solve; wall time of one loss+gradient call. "
-                                           "dense = hychem_sens_kernel (library default), sparse = hychem_sens2_kernel (CRNN_HY_SENS_KERNEL=2: sparse "
-                                           "directions, closed-form tangents, one column per lane)")
+        if unproven:
+                # the reference-faithful gradient (errnorm_sens = 2).  Two kernels (crnn_capi.hip launch_hychem_sens_chunk): the dense-direction
+                # hychem_sens_kernel is the library's default until a device session has passed the sparse kernel's parity tests; round 5's
+                # hychem_sens2_kernel (sparse directions) is asked for with CRNN_HY_SENS_KERNEL=2 (read at crnn_ctx_create).  1 024 ICs -- the size
+                # round 4's nested-dual kernel was quoted on (522.8 ms, 1 959 /s: profiles/r04i) -- for both, the whole share for the sparse one
+                import os
+                for kern, sizes in (("dense", (1024,)), ("sparse", (1024, B))):
+                    for n in sizes:
+                        old_env = os.environ.get("CRNN_HY_SENS_KERNEL")
+                        os.environ["CRNN_HY_SENS_KERNEL"] = "2" if kern == "sparse" else "1"
+                        try:
+                            sens = NeuralODE(ODEProblem(PRESET_HYCHEM, ts, rate_scale=hy.DYDT_SCALE, device=device, errnorm_sens=2))
+                        finally:
+                            if old_env is None:
+                                os.environ.pop("CRNN_HY_SENS_KERNEL", None)
+                            else:
+                                os.environ["CRNN_HY_SENS_KERNEL"] = old_env
+                        sens.set_ensemble(u0[:n], data[:n], ys); sens.set_tables(Tt[:n], Pt[:n])
+                        sens.loss_and_grad(p)
+                        t0 = time.perf_counter(); sens.loss_and_grad(p); w = (time.perf_counter() - t0) * 1e3
+                        sens.close()
+                        extra4[f"errnorm_sens2_{kern}_B{n}_call_ms"] = w
+                        extra4[f"errnorm_sens2_{kern}_B{n}_value"] = n / (w * 1e-3)
+                extra4["errnorm_sens2_value"] = extra4[f"errnorm_sens2_sparse_B{B}_value"]
+                extra4["errnorm_sens_note"] = ("crnn_config.errnorm_sens = 2 on the HyChem preset: ForwardDiff's 18 chunks of 12 partials, each its own "
+                                               "adaptive solve with the partials in the error norm + the plain solve; wall time of one loss+gradient call. "
+                                               "dense = hychem_sens_kernel (library default), sparse = hychem_sens2_kernel (CRNN_HY_SENS_KERNEL=2: sparse "
+                                               "directions, closed-form tangents, one column per lane)")
       except Exception as e:  # noqa: BLE001  (these kernels are round 4 / 5 additions: their failure must not take the adjoint figures of the entry along)
         extra4["extras_error"] = f"{type(e).__name__}: {e}"[:500]
     return _entry("hychem", B, kms, st, {**extra4, "primal_kernel_ms": prim, "workload": "HyChem pyrolysis CRNN, 32 768 ICs (one GPU's share of 262 144), T(t)/P(t) tables, "
@@ -183,7 +185,7 @@ def hychem(B=32768, reps=4, device=0):
                   traffic_key="hychem_B32768_lane_pair" if B == 32768 else None)
 
 
-def cathode(n_part=4096, n_rates=256, reps=3, device=0):
+def cathode(n_part=4096, n_rates=256, reps=3, device=0, unproven=False):
     """BASELINE config 5 on one GPU: 4 096 particles x 256 heating rates, per-particle 17-parameter gradients."""
     from crnn_amd.cathode import CathodeUQ
     fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fixtures_cathode.json")))
@@ -215,7 +217,7 @@ def cathode(n_part=4096, n_rates=256, reps=3, device=0):
     sv, so = [], []
     extras_error = None
     try:
-        for name in ("autotsit5_trbdf2", "autotsit5_rosenbrock23"):
+        for name in (() if unproven else ("autotsit5_trbdf2", "autotsit5_rosenbrock23")):
             uq.set_solver(name)
             ck = []
             for _ in range(3):
@@ -223,12 +225,14 @@ def cathode(n_part=4096, n_rates=256, reps=3, device=0):
                 ck.append(uq.last_stats["kernel_ms"])
             comp_ms[name] = (float(np.median(ck[1:])), uq.last_stats["n_accept"] / uq.last_stats["n_traj"])
         uq.set_solver("rosenbrock23")
-        sens = CathodeUQ(exp_data, betas, fx["theta"], normalizer=np.ones((n_rates, 3)), device=device, errnorm_sens=2)
-        sens.solve(p)
-        t0 = time.perf_counter(); sens.solve(p); sens_wall = (time.perf_counter() - t0) * 1e3
         t0 = time.perf_counter(); uq.solve(p); adj_wall = (time.perf_counter() - t0) * 1e3
-        sens_chunks = sens.last_chunk_stats()
-        sens.close()
+        if unproven:      # cathode_sens_kernel in its round-5 form (stage tangents parked in 135 KB of LDS): no device has launched it
+            sens = CathodeUQ(exp_data, betas, fx["theta"], normalizer=np.ones((n_rates, 3)), device=device, errnorm_sens=2)
+            sens.solve(p)
+            t0 = time.perf_counter(); sens.solve(p); sens_wall = (time.perf_counter() - t0) * 1e3
+            sens_chunks = sens.last_chunk_stats()
+            sens.close()
+            raise StopIteration        # (the device-resident SVGD figures belong to the proven pass)
         # the reference's own iteration (crnn_cathode.jl:36-50): ONE heating rate per SVGD move, particles resident on the device --
         # solve of n_part trajectories + chain rule + exact-median select + kernel sums + update, enqueued back to back
         uq.set_particles(p)
@@ -236,6 +240,8 @@ def cathode(n_part=4096, n_rates=256, reps=3, device=0):
         for it in range(8):
             _, _, ms = uq.svgd_step((37 * it) % n_rates, 1e-3)
             sv.append(ms["svgd_ms"]); so.append(ms["solve_ms"])
+        uq.close()
+    except StopIteration:
         uq.close()
     except Exception as e:  # noqa: BLE001  (composites, dual-norm chunks, device-resident SVGD: must not take the adjoint figures of the entry along)
         extras_error = f"{type(e).__name__}: {e}"[:500]
@@ -331,22 +337,6 @@ def run_all(u0, data, yscale, device=0, out_path=None):
                            "call_ms the whole loss+gradient call"}, reps=3, errnorm_sens=1))
     if "error" not in sec.get("case2_errnorm_sens1", {"error": 1}):
         sec["case2_errnorm_sens1"]["value"] = B / (sec["case2_errnorm_sens1"]["call_ms"] * 1e-3)
-    # the same through Tsit5 -- the branch of case2's AutoTsit5(Rosenbrock23) the reference stays in (tsit5_sens_kernel; round 5: 79 KB of
-    # LDS per block instead of 100, two blocks per CU)
-    put("case2_errnorm_sens1_tsit5", lambda: case2_fixed(u0, data, yscale, ck, {
-        "workload": note.replace("Rosenbrock23", "Tsit5") + "errnorm_sens = 1 as above, explicit Tsit5 (case2's reference algorithm while it stays "
-                                                            "non-stiff; case1's Tsit5()): tsit5_sens_kernel"}, reps=3, errnorm_sens=1, solver=SOLVER_TSIT5))
-    if "error" not in sec.get("case2_errnorm_sens1_tsit5", {"error": 1}):
-        sec["case2_errnorm_sens1_tsit5"]["value"] = B / (sec["case2_errnorm_sens1_tsit5"]["call_ms"] * 1e-3)
-    # what the reference's recorded case2 history was computed with (tests/test_case2_stream_pin.py): Tsit5 -- its AutoTsit5(Rosenbrock23) never
-    # switches -- and the dual norm divided by totallength(u)
-    put("case2_reference_gradient_tsit5_errnorm_sens2", lambda: case2_fixed(u0, data, yscale, ck, {
-        "workload": note.replace("Rosenbrock23", "Tsit5") + "the gradient exactly as the reference's training run evaluated it: ForwardDiff's chunks 9 + 9 + 7, "
-                    "every chunk its own adaptive Tsit5 solve with the partials in the error norm / totallength(u) (errnorm_sens = 2; the mode that "
-                    "reproduces the recorded training history), + the plain solve for the loss: tsit5_sens_kernel; call_ms is the whole call"},
-        reps=3, errnorm_sens=2, solver=SOLVER_TSIT5))
-    if "error" not in sec.get("case2_reference_gradient_tsit5_errnorm_sens2", {"error": 1}):
-        sec["case2_reference_gradient_tsit5_errnorm_sens2"]["value"] = B / (sec["case2_reference_gradient_tsit5_errnorm_sens2"]["call_ms"] * 1e-3)
     progress("case2 strong-scaling shares (8 192 / 16 384 / 32 768 of the 65 536)")
     for nb in (8192, 16384, 32768):
         put(f"case2_B{nb}_share", lambda: case2_fixed(u0[:nb], data[:nb], yscale, ck, {
@@ -380,6 +370,29 @@ def run_all(u0, data, yscale, device=0, out_path=None):
                                                  "wavefronts, queued by the previous launch's step counts), adjoint gradient (P = 211)")
     progress("cathode 4096 x 256")
     put("cathode_4096x256", lambda: cathode(device=local_rank))
+    # LAST: kernels no device has executed in their shipping form (rounds 5 / 6 had none).  Each in an entry of its own, after everything a driver has
+    # seen before: if one of them hangs, the parent's wall-clock limit ends this process and every figure above is already on file
+    progress("unproven kernels, last: tsit5_sens_kernel (79 KB build)")
+    # the same through Tsit5 -- the branch of case2's AutoTsit5(Rosenbrock23) the reference stays in (tsit5_sens_kernel; round 5: 79 KB of
+    # LDS per block instead of 100, two blocks per CU)
+    put("case2_errnorm_sens1_tsit5", lambda: case2_fixed(u0, data, yscale, ck, {
+        "workload": note.replace("Rosenbrock23", "Tsit5") + "errnorm_sens = 1 as above, explicit Tsit5 (case2's reference algorithm while it stays "
+                                                            "non-stiff; case1's Tsit5()): tsit5_sens_kernel"}, reps=3, errnorm_sens=1, solver=SOLVER_TSIT5))
+    if "error" not in sec.get("case2_errnorm_sens1_tsit5", {"error": 1}):
+        sec["case2_errnorm_sens1_tsit5"]["value"] = B / (sec["case2_errnorm_sens1_tsit5"]["call_ms"] * 1e-3)
+    # what the reference's recorded case2 history was computed with (tests/test_case2_stream_pin.py): Tsit5 -- its AutoTsit5(Rosenbrock23) never
+    # switches -- and the dual norm divided by totallength(u)
+    put("case2_reference_gradient_tsit5_errnorm_sens2", lambda: case2_fixed(u0, data, yscale, ck, {
+        "workload": note.replace("Rosenbrock23", "Tsit5") + "the gradient exactly as the reference's training run evaluated it: ForwardDiff's chunks 9 + 9 + 7, "
+                    "every chunk its own adaptive Tsit5 solve with the partials in the error norm / totallength(u) (errnorm_sens = 2; the mode that "
+                    "reproduces the recorded training history), + the plain solve for the loss: tsit5_sens_kernel; call_ms is the whole call"},
+        reps=3, errnorm_sens=2, solver=SOLVER_TSIT5))
+    if "error" not in sec.get("case2_reference_gradient_tsit5_errnorm_sens2", {"error": 1}):
+        sec["case2_reference_gradient_tsit5_errnorm_sens2"]["value"] = B / (sec["case2_reference_gradient_tsit5_errnorm_sens2"]["call_ms"] * 1e-3)
+    progress("unproven kernels: HyChem dual-norm gradient (dense default / sparse opt-in)")
+    put("hychem_B32768_dual_norm", lambda: hychem(reps=2, device=local_rank, unproven=True))
+    progress("unproven kernels: cathode dual-norm gradient (135 KB-LDS build)")
+    put("cathode_4096x256_dual_norm", lambda: cathode(reps=2, device=local_rank, unproven=True))
     progress("done")
     flush()
     return sec
