@@ -36,11 +36,15 @@ def pytest_collection_modifyitems(config, items):
     in one go: golden vectors -> oracle (test_oracle_golden, the CPU halves of test_cathode / test_hychem, test_host) ->
     HIP kernels.  Without a GPU nothing changes: `-m "not gpu"` runs the CPU tests, the GPU tests stay deselected.
     (tryfirst: this runs before the mark plugin evaluates -m.)"""
-    # no test may hang a session: a default per-test limit wherever pytest-timeout is installed (explicit marks win)
+    # no test may hang a session: a default per-test limit wherever pytest-timeout is installed (explicit marks win).  On a box with a device the
+    # limit is shorter and enforced from a watchdog THREAD (os._exit): a kernel that never returns blocks inside hipStreamSynchronize, where the
+    # default SIGALRM handler never gets to run -- the session would sit there until the driver's own limit, and a wedged GPU is a strike.  Ending
+    # the process ends the kernel.  (Kernels no device has executed yet are what this is for; every device test of rounds 1-4 ran in seconds.)
+    on_device = _gpu_present(config) and os.environ.get("CRNN_TEST_ASSUME_GPU") != "1"
     if config.pluginmanager.hasplugin("timeout"):
         for it in items:
             if it.get_closest_marker("timeout") is None:
-                it.add_marker(pytest.mark.timeout(900))
+                it.add_marker(pytest.mark.timeout(420, method="thread") if on_device else pytest.mark.timeout(900))
     if not _gpu_present(config):
         return
     for it in items:
