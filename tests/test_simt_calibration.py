@@ -141,6 +141,8 @@ def test_emulator_primitives_match_their_numpy_statement(seed, tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
 def test_gpu_primitives_equal_the_emulators_bit_for_bit(seed, tmp_path):
+    if "simt" in os.path.basename(os.environ.get("CRNN_HIP_LIB", "")):
+        pytest.skip("the emulated suite (tools/simt_suite.sh) has no device to calibrate against")
     x, idx = _inputs(seed)
     emu = _run(_build_emulated(), x, idx, tmp_path, "emu")
     dev = _run(_build_device(), x, idx, tmp_path, "dev")
