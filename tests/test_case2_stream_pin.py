@@ -176,6 +176,47 @@ def test_replay_discriminates_the_error_norm(orc, sfx):
     assert _rel(h0[1, 0], rec["l_loss_train_head"][1]) > 3e-2, h0
 
 
+def test_recorded_history_confirms_the_restated_step_size_controller(orc, fx, sfx):
+    """OrdinaryDiffEq's PI controller is restated in the oracle from its published form ([UNVERIFIED-DEP]: the package is not in the reference tree).
+    The reference's own numbers confirm the constants: with the restated ones the final-loss pin stands at 5e-6 and the first six replayed epochs at
+    <= 1.4e-3 (median 4e-4); changing any ONE of them makes both worse (profiles/r06c_case2_stream_controller_ablation.txt, 11 variants; four here)."""
+    rec, des = sfx["rec"], sfx["des"]
+    ck = np.array(fx["case2_ckpt"]["p"])
+    u0T, dataT = np.ascontiguousarray(des["u0"].T), np.ascontiguousarray(des["data"].transpose(2, 1, 0))
+
+    def run(**ctl):
+        def mk(mode):
+            pb = _oracle_problem(orc, des, solver=1, errnorm_sens=mode)
+            for k, v in ctl.items():
+                setattr(pb, k, v)
+            return pb
+        pbg, pbl = mk(2), mk(0)
+        def loss(p):
+            return _split(orc.solve_batch(pbl, orc.p2vec(2, 6, 3, p)[0], u0T, des["ts"], dataT)["loss"])
+        tr, va = loss(ck)
+        fin = max(_rel(tr, rec["l_loss_train_last"]), _rel(va, rec["l_loss_val_last"]))
+        opt = orc.Optimiser(25, eta=0.005, wd=WD, expdecay=EXPDECAY)
+        p = des["p0"].copy()
+        dev = []
+        for ep in range(6):
+            for i in des["perms"][ep]:
+                p = opt.update(p, _oracle_gradient(orc, pbg, des, p, i - 1))
+            tr, va = loss(p)
+            dev += [_rel(tr, rec["l_loss_train_head"][ep]), _rel(va, rec["l_loss_val_head"][ep])]
+        return fin, max(dev), float(np.median(dev))
+
+    f0, mx0, md0 = run()
+    assert f0 < 3e-5 and mx0 < 2.5e-3 and md0 < 8e-4, (f0, mx0, md0)
+    for ctl in (dict(beta1=7 / 20, beta2=2 / 10),      # the exponents of a second / third-order pair instead of Tsit5's
+                dict(beta1=1 / 5, beta2=0.0),          # a plain I controller
+                dict(gamma=0.8),
+                dict(qoldinit=1.0)):
+        f, mx, md = run(**ctl)
+        assert mx > 3 * mx0 and md > 3 * md0, (ctl, f, mx, md)
+    # (the final-loss pin alone already tells the exponents: 3e-4 / 1e-3 against 5e-6)
+    assert run(beta1=7 / 20, beta2=2 / 10)[0] > 1e-4
+
+
 def test_oracle_composite_refuses_the_dual_norm_instead_of_ignoring_it(orc, sfx):
     """oracle solver 2 (the CRNN composite) propagates tangents on accepted steps only; until round 6 it returned the primal-norm gradient when
     asked for errnorm_sens (which is how the replay first went wrong).  It now says so: return code -8, like the product's crnn_ctx_create."""
