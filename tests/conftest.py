@@ -66,6 +66,27 @@ def pytest_collection_modifyitems(config, items):
         items.sort(key=lambda it: 0 if known(it) else 1)       # stable: file / definition order is kept within each group
 
 
+# A device session has a wall-clock budget.  The driver gives `pytest -m gpu` a fixed time (1 200 s in rounds 1-5); a session it has to kill leaves no
+# record at all.  Nobody could measure this suite's wall time on a device since round 3 (159 s for 184 tests then; 270 tests now), so the session
+# watches its own clock: once CRNN_SESSION_BUDGET_S (default 900) have passed, the remaining tests are SKIPPED with that reason -- visibly, not
+# silently -- instead of running into the driver's limit.  The driver-proven tests run first (above), so what can fall off the end is the newest.
+_SESSION_T0 = None
+
+
+def pytest_sessionstart(session):
+    global _SESSION_T0
+    import time
+    _SESSION_T0 = time.monotonic()
+
+
+def pytest_runtest_setup(item):
+    import time
+    budget = float(os.environ.get("CRNN_SESSION_BUDGET_S", "900"))
+    if _SESSION_T0 is not None and budget > 0 and item.get_closest_marker("gpu") is not None and _gpu_present(item.config) \
+            and os.environ.get("CRNN_TEST_ASSUME_GPU") != "1" and time.monotonic() - _SESSION_T0 > budget:
+        pytest.skip(f"device session budget of {budget:.0f} s spent (tests/conftest.py): not run, NOT passed")
+
+
 def emulated():
     """True when CRNN_HIP_LIB points at the SIMT emulation library (tools/simt_suite.sh).  The BASELINE-size tests then run the same logic and the
     same assertions (minus the clock) at sizes scaled to the emulated device's two CUs instead of being left out."""
