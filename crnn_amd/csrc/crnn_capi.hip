@@ -262,9 +262,18 @@ bool shape_match(const Ctx *c, const KernelEntry &k) {
            k.use_scale == (c->use_scale ? 1 : 0);
 }
 
+// AutoTsit5(Rosenbrock23) on a state vector with a constant component (case2's temperature) never leaves Tsit5: OrdinaryDiffEq's stiffness
+// estimate max_i |k7_i - k6_i| / |g7_i - g6_i| is 0/0 = NaN there and NaN > 9/10 is false (auto_adj_kernel.hpp; the reference's recorded case2
+// history confirms it to 5e-6: tests/test_case2_stream_pin.py).  So `alg = AutoTsit5(Rosenbrock23())` (case2/case2.jl:26) with errnorm_sens IS
+// the Tsit5 dual-norm gradient, and a host that keeps the reference's `alg` gets it instead of an error
+static bool composite_is_tsit5(const crnn_config &cfg) {
+    return cfg.solver == CRNN_SOLVER_AUTOTSIT5 && cfg.rhs_kind == CRNN_RHS_CRNN && cfg.has_temp != 0;
+}
+
 const KernelEntry *find_sens(const Ctx *c) {
+    const int solver = composite_is_tsit5(c->cfg) ? CRNN_SOLVER_TSIT5 : c->cfg.solver;
     for (const auto &k : kSensKernels)
-        if (shape_match(c, k)) return &k;
+        if (k.solver == solver && k.ns == c->cfg.ns && k.nr == c->cfg.nr && k.has_t == c->cfg.has_temp && k.use_scale == (c->use_scale ? 1 : 0)) return &k;
     return nullptr;
 }
 
@@ -1442,9 +1451,9 @@ int32_t crnn_ctx_create(const crnn_config *cfg, crnn_ctx **out) {
         return fail(nullptr, "crnn_ctx_create: ns/nr out of range");
     if (cfg->errnorm_sens < 0 || cfg->errnorm_sens > 2) return fail(nullptr, "crnn_ctx_create: errnorm_sens must be 0, 1 or 2");
     // (HyChem: also through the reference's composite, AutoTsit5(Rosenbrock23) -- hychem_sens2_kernel<..., COMPOSITE>)
-    if (cfg->errnorm_sens != 0 && ((cfg->solver == CRNN_SOLVER_AUTOTSIT5 && cfg->rhs_kind != CRNN_RHS_HYCHEM) || cfg->grad_mode == CRNN_GRAD_ADJOINT ||
+    if (cfg->errnorm_sens != 0 && ((cfg->solver == CRNN_SOLVER_AUTOTSIT5 && cfg->rhs_kind != CRNN_RHS_HYCHEM && !composite_is_tsit5(*cfg)) || cfg->grad_mode == CRNN_GRAD_ADJOINT ||
                                    (cfg->rhs_kind == CRNN_RHS_HYCHEM && cfg->solver == CRNN_SOLVER_TSIT5)))
-        return fail(nullptr, "crnn_ctx_create: errnorm_sens = 1 / 2 exists for Rosenbrock23 and Tsit5 (HyChem: Rosenbrock23 and AutoTsit5) with forward tangents (grad_mode AUTO or FORWARD)");
+        return fail(nullptr, "crnn_ctx_create: errnorm_sens = 1 / 2 exists for Rosenbrock23 and Tsit5 (HyChem: Rosenbrock23 and AutoTsit5; AutoTsit5 on a shape with a temperature state, which never leaves Tsit5) with forward tangents (grad_mode AUTO or FORWARD)");
     if (cfg->solver != CRNN_SOLVER_ROSENBROCK23 && cfg->solver != CRNN_SOLVER_TSIT5 && cfg->solver != CRNN_SOLVER_AUTOTSIT5)
         return fail(nullptr, "crnn_ctx_create: unknown solver");
     if (cfg->rhs_kind != CRNN_RHS_CRNN && cfg->rhs_kind != CRNN_RHS_HYCHEM) return fail(nullptr, "crnn_ctx_create: unknown rhs_kind");

@@ -45,16 +45,16 @@ def main():
     ref = None
     if args.reference_run:
         import json
-        from crnn_amd import SOLVER_TSIT5
+        from crnn_amd import SOLVER_AUTOTSIT5
         with open(os.path.join(ROOT, "tests", "golden", "fixtures_case2_stream.json")) as f:
             ref = json.load(f)
         d = ref["design"]
         n_train, n_exp = 20, 30
         ts, u0, data, yscale, p = (np.array(d[k]) for k in ("tsteps", "u0", "data", "yscale", "p0"))
         args.epochs = min(args.epochs, len(d["perms"]))
-        # case2.jl:26 `alg = AutoTsit5(Rosenbrock23(autodiff=false))` stays on Tsit5 for this model; :195 ForwardDiff.gradient through it puts the
-        # partials into the error norm (/ totallength(u)): errnorm_sens = 2 -- the combination that reproduces the recorded history
-        node = NeuralODE(ODEProblem(PRESET_CASE2, ts, solver=SOLVER_TSIT5, errnorm_sens=2))
+        # case2.jl:26 `alg = AutoTsit5(Rosenbrock23(autodiff=false))` (stays on Tsit5 for this model: the library runs its Tsit5 kernels); :195
+        # ForwardDiff.gradient through it puts the partials into the error norm (/ totallength(u)): errnorm_sens = 2 -- what reproduces the recorded history
+        node = NeuralODE(ODEProblem(PRESET_CASE2, ts, solver=SOLVER_AUTOTSIT5, errnorm_sens=2))
     else:
         ts = cases.case2_tsteps()
         u0 = cases.case2_u0(n_exp, rng)

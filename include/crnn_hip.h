@@ -103,7 +103,8 @@ typedef struct crnn_config {
                                      call takes the step sequence of a plain solve; every gradient algorithm).  1: ForwardDiff's
                                      dual-inclusive norm, chunked like ForwardDiff.pickchunksize -- what the reference's
                                      ForwardDiff.gradient through the adaptive solver does (case2/case2.jl:195); Rosenbrock23 and
-                                     Tsit5, forward tangents (grad_mode AUTO or FORWARD); round 4: also the HyChem right-hand side
+                                     Tsit5 -- and AUTOTSIT5 on a shape with a temperature state (case2's own `alg`, :26), where the
+                                     composite never leaves Tsit5 and the Tsit5 kernel runs --, forward tangents (grad_mode AUTO or FORWARD); round 4: also the HyChem right-hand side
                                      (crnn_pyrolysis_mass.jl:201: 211 parameters in 18 chunks of 12) -- round 5: at speed
                                      (hychem_sens2_kernel: the rows of p2vec's Jacobian are sparse, one reaction each; a caller's
                                      dense directions run the general hychem_sens_kernel), and with solver = AUTOTSIT5 through the

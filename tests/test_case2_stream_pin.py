@@ -252,9 +252,9 @@ def test_gpu_loss_at_the_checkpoint_equals_the_recorded_numbers(fx, sfx):
 def test_gpu_replays_the_recorded_first_epochs(orc, sfx):
     """The reference's training loop on the device: crnn_train_step per experiment (dual-norm chunks of ForwardDiff.gradient, reduction, Flux
     optimiser, all on the device), the epoch-end loss loop, against the recorded history and against the oracle's replay."""
-    from crnn_amd import PRESET_CASE2, SOLVER_TSIT5, Optimiser
+    from crnn_amd import PRESET_CASE2, SOLVER_AUTOTSIT5, Optimiser
     rec, des = sfx["rec"], sfx["des"]
-    node = _node(des, solver=SOLVER_TSIT5, errnorm_sens=2)
+    node = _node(des, solver=SOLVER_AUTOTSIT5, errnorm_sens=2)      # the script's own `alg` (case2.jl:26) and ForwardDiff's norm: Tsit5 dual-norm chunks
     node.train_init(Optimiser(25, preset=PRESET_CASE2), des["p0"])      # crnn_opt_preset: the chain above
     hist = []
     for ep in range(EPOCHS):

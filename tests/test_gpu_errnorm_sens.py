@@ -148,3 +148,33 @@ def test_errnorm_sens_rejects_unsupported_combinations():
         NeuralODE(ODEProblem(PRESET_CASE2, cases.case2_tsteps(), errnorm_sens=1, solver=SOLVER_AUTOTSIT5))   # composite: tape kernel only
     with pytest.raises(CrnnError, match="errnorm_sens"):
         NeuralODE(ODEProblem(PRESET_CASE2, cases.case2_tsteps(), errnorm_sens=1, grad_mode=2))
+
+
+def test_the_references_alg_with_the_dual_norm_is_the_tsit5_gradient(case2_setup):
+    """case2.jl:26 `alg = AutoTsit5(Rosenbrock23(autodiff=false))` + :195 `ForwardDiff.gradient`: a host that keeps the reference's `alg` and asks for
+    the reference's error norm gets the gradient the reference's run evaluated -- the composite never leaves Tsit5 on a state with a constant
+    temperature component (tests/test_case2_stream_pin.py: the recorded history says so to 5e-6), so the dual-norm chunks run on tsit5_sens_kernel:
+    bit for bit the SOLVER_TSIT5 context's numbers (gradient(), loss_and_grad(), the device-resident training step).  Until round 6 this
+    combination was refused at crnn_ctx_create.  robertson's shape (no temperature state: the composite does switch) still is."""
+    from crnn_amd import CrnnError, NeuralODE, ODEProblem, Optimiser, PRESET_CASE2, PRESET_ROBER, SOLVER_AUTOTSIT5, SOLVER_TSIT5
+    s = case2_setup
+    nodes = {}
+    for name, solver in (("auto", SOLVER_AUTOTSIT5), ("tsit5", SOLVER_TSIT5)):
+        n = NeuralODE(ODEProblem(PRESET_CASE2, s["tsteps"], solver=solver, errnorm_sens=2))
+        n.set_ensemble(s["u0"], s["data"], s["yscale"])
+        nodes[name] = n
+    for pkey in ("p_ckpt", "p_init"):
+        p = s[pkey]
+        ga, gt = nodes["auto"].gradient(p, 3), nodes["tsit5"].gradient(p, 3)
+        assert np.array_equal(ga, gt) and nodes["auto"].last_chunk_stats == nodes["tsit5"].last_chunk_stats
+        (la, Ga), (lt, Gt) = nodes["auto"].loss_and_grad(p), nodes["tsit5"].loss_and_grad(p)
+        assert la == lt and np.array_equal(Ga, Gt)
+    for n in nodes.values():
+        n.train_init(Optimiser(25, preset=PRESET_CASE2), s["p_init"])
+        for i in (2, 0, 5):
+            n.train_step(first=i, count=1, want_loss=False)
+    assert np.array_equal(nodes["auto"].params(), nodes["tsit5"].params())
+    for n in nodes.values():
+        n.close()
+    with pytest.raises(CrnnError, match="errnorm_sens"):
+        NeuralODE(ODEProblem(PRESET_ROBER, np.logspace(0, 5, 40), solver=SOLVER_AUTOTSIT5, errnorm_sens=2))
