@@ -1,12 +1,12 @@
 #!/bin/bash
-# Round-5 evidence run: everything the final tree needs re-measured, in one gpurun call.
-#   gpurun --timeout 2400 -- 'bash tools/gpu_r05_evidence.sh'
-# Writes under gpurun_out/r05a/ ; the summaries judged are copied into profiles/ afterwards (by hand, from the merged gpurun_out).
+# Round-6 evidence run: everything the final tree needs re-measured, in one gpurun call.
+#   gpurun --timeout 2400 -- 'bash tools/gpu_r06_evidence.sh'
+# Writes under gpurun_out/r06a/ ; the summaries judged are copied into profiles/ afterwards (by hand, from the merged gpurun_out).
 R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
-O=$R/gpurun_out/r05a
+O=$R/gpurun_out/r06a
 mkdir -p $O
 cd $R
-if [ -z "$SKIP_BASE" ]; then   # SKIP_BASE=1: steps 1-3 were taken by tools/gpu_r05_call1.sh in an earlier call
+if [ -z "$SKIP_BASE" ]; then   # SKIP_BASE=1: steps 1-3 were taken by tools/gpu_r06_call1.sh in an earlier call
 ( time python -c "import __graft_entry__ as g; g.build(); g.smoke()" ) > $O/build_smoke.log 2>&1
 tail -4 $O/build_smoke.log | cut -c1-300
 # 1. the whole -m gpu suite (no -x: every failure is wanted), full tail kept
@@ -34,6 +34,10 @@ for n in 1024 4096 32768; do
   echo "sparse $n"; CRNN_HY_SENS_KERNEL=2 timeout 600 python tools/hy_sens_time.py $n
   if [ $n -le 4096 ]; then echo "dense $n"; CRNN_HY_SENS_KERNEL=1 timeout 900 python tools/hy_sens_time.py $n; fi
 done > $O/ab_hychem_sens.txt 2>&1; cat $O/ab_hychem_sens.txt | cut -c1-200
+# 4b. the reference's own recorded run on the device loop (tests/test_case2_stream_pin.py's replay, 100 epochs, next to the oracle's), and the
+#     kernel behind it on the clock (tsit5_sens_kernel, errnorm_sens = 2: VERDICT r5 item 8)
+timeout 900 python tools/case2_stream_replay.py --device --epochs 100 > $O/case2_stream_replay_device.txt 2>&1; tail -8 $O/case2_stream_replay_device.txt | cut -c1-200
+timeout 300 python tools/kbench.py --reps 6 --errnorm-sens 2 --solver tsit5 --wall > $O/tsit5_sens_time.txt 2>&1; tail -2 $O/tsit5_sens_time.txt | cut -c1-200
 # 5. fuzz sweeps on the tree that ships
 for f in fuzz_parity fuzz_hychem fuzz_cathode fuzz_hychem_sens; do
   timeout 600 python tools/$f.py > $O/$f.txt 2>&1; tail -3 $O/$f.txt | cut -c1-200
@@ -48,4 +52,4 @@ for spec in "hychem --case hychem --batch 32768" "rober --case rober" "case2_sen
 done
 cp -r $R/gpurun_out/pmc_r05_* $R/gpurun_out/pmck_r05_* $O/ 2> /dev/null
 find $O -name "*.db" -size +8M -delete      # keep the merged gpurun_out under its size limit: the summaries are what is judged
-echo "evidence run complete: $(ls $O | wc -l) files under gpurun_out/r05a"
+echo "evidence run complete: $(ls $O | wc -l) files under gpurun_out/r06a"
