@@ -438,7 +438,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void ros23_adj2_kernel(const SolveParam
 
         // ================================================================== reverse sweep
         const int n_saved = jsave;
-        const int jlo = start_saved ? 1 : 0;
+        [[maybe_unused]] const int jlo = start_saved ? 1 : 0;      // (read by the bounds checks only: -DCRNN_BOUNDS_CHECK)
         double awi[H][NR], awo[H][NR];     // d loss / d (this lane's rows of w_in, w_out): registers, no atomics
 #pragma unroll
         for (int i = 0; i < H; ++i)

@@ -43,7 +43,6 @@ __global__ __launch_bounds__(BLOCK) void tsit5_sens_kernel(const SolveParams prm
     using R_ = RecTS<NS, NR>;
     constexpr int N = L_::N;
     constexpr int NTH = L_::NTH;
-    constexpr int NTHP = L_::NTHP;
     constexpr int NREC = R_::NREC;
     constexpr int WAVES = BLOCK / 64;
     constexpr int GPW = 64 / L;
