@@ -143,9 +143,9 @@ def test_all_chunks_in_one_launch_equal_one_launch_per_chunk(monkeypatch, fx, ca
 
 
 def test_errnorm_sens_rejects_unsupported_combinations():
-    from crnn_amd import CrnnError, NeuralODE, ODEProblem, PRESET_CASE2, SOLVER_AUTOTSIT5, cases
-    with pytest.raises(CrnnError, match="errnorm_sens"):
-        NeuralODE(ODEProblem(PRESET_CASE2, cases.case2_tsteps(), errnorm_sens=1, solver=SOLVER_AUTOTSIT5))   # composite: tape kernel only
+    from crnn_amd import CrnnError, NeuralODE, ODEProblem, PRESET_CASE2, PRESET_ROBER, SOLVER_AUTOTSIT5, cases
+    with pytest.raises(CrnnError, match="errnorm_sens"):      # a composite that does switch (no temperature state): tape kernel only
+        NeuralODE(ODEProblem(PRESET_ROBER, cases.rober_tsteps(), errnorm_sens=1, solver=SOLVER_AUTOTSIT5))
     with pytest.raises(CrnnError, match="errnorm_sens"):
         NeuralODE(ODEProblem(PRESET_CASE2, cases.case2_tsteps(), errnorm_sens=1, grad_mode=2))
 
