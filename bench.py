@@ -68,6 +68,34 @@ def usable_cores():
     return max(1, n)
 
 
+def cpu_reference_algorithm_rate(orc, pb_kwargs, p, u0_s, ts, data_s, cores, seconds):
+    """trajectories+gradients/s of the C oracle running what the reference's CPU path executes per `ForwardDiff.gradient` call on case2
+    (case2/case2.jl:26,195; which algorithm and which norm: tests/test_case2_stream_pin.py): Tsit5 -- the AutoTsit5 composite never leaves it
+    on this model --, ForwardDiff's chunks of 9 + 9 + 7 partials, every chunk its own adaptive solve with the chunk's partials in the error norm
+    / totallength(u).  OpenMP over trajectories (the stand-in for EnsembleThreads()); bounded to `seconds` of wall time."""
+    from crnn_amd.api import fd_chunk_size
+    pb = orc.make_problem(**dict(pb_kwargs, solver=1, errnorm_sens=2))
+    th, dth = orc.p2vec(2, 6, 3, p)
+    P = dth.shape[1]
+    chunk = fd_chunk_size(P)
+    cols = []
+    for k0 in range(0, P, chunk):
+        c = np.zeros((dth.shape[0], chunk), order="F")          # the Dual carries `chunk` partials; the last chunk's surplus ones are zero
+        c[:, :min(P, k0 + chunk) - k0] = dth[:, k0:k0 + chunk]
+        cols.append(c)
+    ns_ = u0_s.shape[1]
+    for c in cols:                                              # warm-up
+        orc.solve_batch(pb, th, u0_s[:, :256].copy(), ts, data_s[:, :, :256].copy(), dtheta=c, nthreads=cores)
+    tc, passes = 0.0, 0
+    while tc < seconds and passes < 64:
+        t1 = time.perf_counter()
+        for c in cols:
+            orc.solve_batch(pb, th, u0_s, ts, data_s, dtheta=c, nthreads=cores)
+        tc += time.perf_counter() - t1
+        passes += 1
+    return ns_ * passes / tc, passes, tc
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -323,8 +351,8 @@ def main():
             from oracle import oracle as orc
             ns_ = min(args.cpu_sample, B)
             th, dth = orc.p2vec(2, 6, 3, p0)
-            pb = orc.make_problem(ns=6, nr=3, has_temp=1, lb=LB_CASE2, ub=10.0, inv_R=cases.INV_R, atol=1e-6, rtol=1e-3,
-                                  yscale=yscale, clamp_pred=1, solver={"rosenbrock23": 0, "tsit5": 1, "autotsit5": 2}[args.solver])
+            pb_kwargs = dict(ns=6, nr=3, has_temp=1, lb=LB_CASE2, ub=10.0, inv_R=cases.INV_R, atol=1e-6, rtol=1e-3, yscale=yscale, clamp_pred=1)
+            pb = orc.make_problem(**pb_kwargs, solver={"rosenbrock23": 0, "tsit5": 1, "autotsit5": 2}[args.solver])
             u0_s = np.ascontiguousarray(u0[:ns_].T)
             data_s = np.ascontiguousarray(data[:ns_].transpose(2, 1, 0))
             cores = usable_cores()
@@ -343,12 +371,23 @@ def main():
             # the SAME algorithm as the GPU (discrete adjoint of the accepted steps; Rosenbrock23 only) and ForwardDiff's
             # arithmetic (forward tangents, 1 + 25 columns: what the reference's CPU path executes), half of the time each
             have_adj = args.solver == "rosenbrock23"
-            v_fwd, n_fwd, t_fwd = cpu_rate(0, args.cpu_seconds / (2 if have_adj else 1))
-            v_adj, n_adj, t_adj = cpu_rate(1, args.cpu_seconds / 2) if have_adj else (None, 0, 0.0)
+            share = args.cpu_seconds / (3 if have_adj else 2)
+            v_fwd, n_fwd, t_fwd = cpu_rate(0, share)
+            v_adj, n_adj, t_adj = cpu_rate(1, share) if have_adj else (None, 0, 0.0)
+            try:      # a third share: the algorithm the reference's own run evaluated (a sample of 8 192 ICs: three chunk solves each)
+                nr_ = min(ns_, 8192)
+                v_ref, n_ref, t_ref = cpu_reference_algorithm_rate(orc, pb_kwargs, p0, u0_s[:, :nr_].copy(), ts, data_s[:, :, :nr_].copy(), cores, share)
+            except Exception as e:  # noqa: BLE001  (an extra figure must not take the baseline along)
+                v_ref, n_ref, t_ref = None, 0, 0.0
+                print(f"[bench] cpu_baseline: reference-algorithm figure failed: {e}", file=sys.stderr, flush=True)
             out["cpu_baseline"] = {"value": v_adj if have_adj else v_fwd, "unit": "trajectories+grads/s", "cores": cores, "kind": "port",
                                    "algorithm": ("discrete adjoint of the accepted steps -- the algorithm the GPU kernel runs" if have_adj else
                                                  "forward tangents, 1 + 25 columns per trajectory"),
                                    "forward_tangents_value": v_fwd,
+                                   "reference_algorithm_value": v_ref,
+                                   "reference_algorithm": "Tsit5 (case2's AutoTsit5(Rosenbrock23) never leaves it), ForwardDiff's chunks 9 + 9 + 7, every chunk its own "
+                                                          "adaptive solve with the partials in the error norm / totallength(u): what the reference's recorded training "
+                                                          f"history reproduces with (tests/test_case2_stream_pin.py); {n_ref} passes over 8 192 ICs, {t_ref:.1f} s wall",
                                    "sample": f"the first {ns_} ICs of the same ensemble at the same p, solve+loss+gradient, C oracle with OpenMP over "
                                              f"trajectories on {cores} cores: {n_adj} passes with the discrete adjoint ({t_adj:.1f} s wall) -> value; {n_fwd} "
                                              f"passes with forward tangents, 1 + 25 columns = ForwardDiff's arithmetic, what the reference's CPU path "
