@@ -12,7 +12,7 @@ using .CRNNHip
 
 n_exp = length(ARGS) >= 1 ? parse(Int, ARGS[1]) : 4096
 Random.seed!(1234)
-tsteps = collect(0.0:1.0:49.0)                                   # case2/case2.jl:18-19,67-68
+tsteps = collect(range(0.0, 50.0, length = 50))                  # case2/case2.jl:18-19,64-65: 50 points on [0, 50], spacing 50 / 49
 prob_dev = CRNNHip.ODEProblem(CRNNHip.PRESET_CASE2, tsteps)      # problem constants (lb, ub, inv_R, tolerances) from the preset
 p = randn(25) .* 0.1; p[1:3] .+= 0.8; p[22:24] .+= 0.8; p[25] = 0.1   # case2/case2.jl:85-89
 u0_list = zeros(n_exp, 7)
@@ -31,7 +31,9 @@ end
 rhs!(du, u, p, t) = CRNNHip.crnn!(du, u, p, t, prob_dev)
 prob_ref = OrdinaryDiffEq.ODEProblem(rhs!, u0_list[1, :], (tsteps[1], tsteps[end]), p)
 ens = EnsembleProblem(prob_ref; prob_func = (pr, i, _) -> remake(pr, u0 = u0_list[i, :]))
-alg = Rosenbrock23(autodiff = false)                             # the stiff branch of case2/case2.jl:26
+alg = AutoTsit5(Rosenbrock23(autodiff = false))                  # case2/case2.jl:26, the script's own (on this model it never leaves Tsit5: a constant
+                                                                 # temperature state makes the stiffness estimate NaN; tests/test_case2_stream_pin.py)
+alg_stiff = Rosenbrock23(autodiff = false)                       # its stiff branch alone = the stepper the GPU's headline number is quoted on
 solve(ens, alg, EnsembleThreads(); trajectories = min(n_exp, 64), saveat = tsteps, abstol = 1e-6, reltol = 1e-3)   # compile
 t_solve = @elapsed solve(ens, alg, EnsembleThreads(); trajectories = n_exp, saveat = tsteps, abstol = 1e-6, reltol = 1e-3)
 
@@ -44,5 +46,15 @@ ForwardDiff.gradient(x -> loss_of(x, 1), p)                      # compile
 t_grad = @elapsed Threads.@threads for i in 1:n_exp
     ForwardDiff.gradient(x -> loss_of(x, i), p)
 end
-println("EnsembleThreads() on $(Threads.nthreads()) threads: $(n_exp / t_solve) trajectories/s, ",
+println("EnsembleThreads() on $(Threads.nthreads()) threads, alg = AutoTsit5(Rosenbrock23): $(n_exp / t_solve) trajectories/s, ",
         "$(n_exp / t_grad) trajectories+gradients/s")
+# the same with the stiff branch alone (what bench.py's headline and its `cpu_baseline.forward_tangents_value` correspond to)
+function loss_of_stiff(x, i)
+    sol = solve(remake(prob_ref, u0 = u0_list[i, :], p = x), alg_stiff; saveat = tsteps, abstol = 1e-6, reltol = 1e-3)
+    return mean(abs, clamp.(Array(sol), -10.0, 10.0))
+end
+ForwardDiff.gradient(x -> loss_of_stiff(x, 1), p)
+t_grad_stiff = @elapsed Threads.@threads for i in 1:n_exp
+    ForwardDiff.gradient(x -> loss_of_stiff(x, i), p)
+end
+println("  Rosenbrock23(autodiff = false) alone: $(n_exp / t_grad_stiff) trajectories+gradients/s")
